@@ -1,0 +1,774 @@
+"""Schema loader: CityLearn ``schema.json`` + CSV files -> district specification -> packed device tables.
+
+Host-side mirror of the reference loader for the hot path (behaviour, not code):
+
+* ``CityLearnEnv._load`` / ``_load_building``          /root/reference/citylearn/citylearn.py:1973-2409
+* ``process_metadata`` (active observations / actions) /root/reference/citylearn/citylearn.py:2411-2555
+* ``EnergySimulation`` / ``Weather`` / ``Pricing`` / ``CarbonIntensity`` dtype + clipping rules
+                                                       /root/reference/citylearn/data.py:341-661
+* seeded default device parameters                     /root/reference/citylearn/energy_model.py:67-83, 977-1003
+                                                       and citylearn.py:2364-2379 (md5-derived per-device seed)
+* device autosizing (heat pump / heater / tank)        /root/reference/citylearn/energy_model.py:309-352, 425-450, 770-795
+* ``Building.estimate_action_space``                    /root/reference/citylearn/building.py:2160-2282
+* ``EpisodeTracker``                                    /root/reference/citylearn/base.py:6-134
+* ``ReliabilityMetricsPowerOutage.get_signals``         /root/reference/citylearn/power_outage.py:131-169
+
+The output of :func:`load_district` is a :class:`DistrictSpec` holding exact (float64 / Python float) device
+parameters and the full simulation-period series; :meth:`DistrictSpec.episode_tables` packs one episode
+window into the float32 ``params`` / ``ts`` tables described in ``include/citylearn_amd.h``.
+
+Out of scope (raises ``NotImplementedError``): EV chargers, washing machines, occupant models, PV / battery
+autosizing (needs PySAM / external sizing tables) -- SURVEY.md section 2 rows 13-15.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import math
+import os
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Any, Dict, List, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import abi
+
+ZERO_DIVISION_PLACEHOLDER = 1e-6   # data.py:19
+TOLERANCE = 1e-4                   # data.py:18
+DEFAULT_COMFORT_BAND = 2.0         # data.py:399
+
+_STORAGE_ACTIONS = ('cooling_storage', 'heating_storage', 'dhw_storage', 'electrical_storage')
+_DEVICE_ACTIONS = ('cooling_device', 'heating_device', 'cooling_or_heating_device')
+_ACTION_SLOT = {
+    'cooling_storage': abi.CLP_ACT_COOL_STO, 'heating_storage': abi.CLP_ACT_HEAT_STO,
+    'dhw_storage': abi.CLP_ACT_DHW_STO, 'electrical_storage': abi.CLP_ACT_ELEC_STO,
+    'cooling_device': abi.CLP_ACT_COOL_DEV, 'heating_device': abi.CLP_ACT_HEAT_DEV,
+    'cooling_or_heating_device': abi.CLP_ACT_COH_DEV,
+}
+
+_ES_REQUIRED = ('month', 'hour', 'day_type', 'indoor_dry_bulb_temperature', 'non_shiftable_load', 'dhw_demand',
+                'cooling_demand', 'heating_demand', 'solar_generation')
+_WEATHER_COLUMNS = tuple(
+    [f'{k}' for k in ('outdoor_dry_bulb_temperature', 'outdoor_relative_humidity', 'diffuse_solar_irradiance',
+                      'direct_solar_irradiance')]
+    + [f'{k}_predicted_{i}' for k in ('outdoor_dry_bulb_temperature', 'outdoor_relative_humidity',
+                                      'diffuse_solar_irradiance', 'direct_solar_irradiance') for i in (1, 2, 3)])
+_PRICING_COLUMNS = ('electricity_pricing', 'electricity_pricing_predicted_1', 'electricity_pricing_predicted_2',
+                    'electricity_pricing_predicted_3')
+
+
+# --------------------------------------------------------------------------------------------------------------
+# device specifications
+# --------------------------------------------------------------------------------------------------------------
+
+class _Sampler:
+    """Reference semantics for unspecified device parameters.
+
+    ``Environment.numpy_random_state`` builds a *fresh* ``RandomState(seed)`` on every access
+    (base.py:203-206), so every ``uniform(lo, hi)`` draw of one device uses the generator's first sample.
+    """
+
+    def __init__(self, seed: int):
+        self.seed = int(seed)
+
+    def uniform(self, lo: float, hi: float) -> float:
+        return float(np.random.RandomState(self.seed).uniform(lo, hi))
+
+    def value(self, value, default):
+        """`Device._get_property_value` (energy_model.py:67-83)."""
+        if value is None or (isinstance(value, float) and math.isnan(value)):
+            return self.uniform(*default) if isinstance(default, tuple) else default
+        if isinstance(value, (tuple, list)) and len(value) == 2 and not isinstance(default, list):
+            return self.uniform(*value)
+        return value
+
+
+def device_seed(building_name: str, building_type: str, device_name: str, device_type: str, schema_seed: int) -> int:
+    """Per-device seed: cumulative md5 over the four strings (citylearn.py:2364-2373)."""
+    md5 = hashlib.md5()
+    total = 0
+    for s in (building_name, building_type, device_name, device_type):
+        md5.update(s.encode())
+        total += int(md5.hexdigest(), 16)
+    return int(str(total * (schema_seed + 1))[:9])
+
+
+@dataclass
+class HeatPumpSpec:
+    nominal_power: float = 0.0
+    efficiency: float = 0.25
+    target_cooling_temperature: float = 8.0
+    target_heating_temperature: float = 45.0
+    is_heat_pump: bool = True
+    present: bool = False
+
+    def cop(self, t_out: np.ndarray, heating: bool) -> np.ndarray:
+        """`HeatPump.get_cop` (energy_model.py:216-250); same float32/python-float promotion as the reference."""
+        t_out = np.array(t_out)
+        if heating:
+            cop = self.efficiency * (self.target_heating_temperature + 273.15) / (self.target_heating_temperature - t_out)
+        else:
+            cop = self.efficiency * (self.target_cooling_temperature + 273.15) / (t_out - self.target_cooling_temperature)
+        cop = np.array(cop)
+        cop[cop < 0] = 20
+        cop[cop > 20] = 20
+        return cop
+
+
+@dataclass
+class HeaterSpec:
+    nominal_power: float = 0.0
+    efficiency: float = 0.95
+    is_heat_pump: bool = False
+    present: bool = False
+
+
+@dataclass
+class TankSpec:
+    capacity: float = 0.0
+    efficiency: float = 0.95
+    loss_coefficient: float = 0.0
+    initial_soc: float = 0.0
+    max_input_power: Optional[float] = None
+    max_output_power: Optional[float] = None
+    present: bool = False
+
+
+@dataclass
+class BatterySpec:
+    capacity: float = 0.0
+    nominal_power: float = 0.0
+    efficiency: float = 0.95
+    loss_coefficient: float = 0.0
+    capacity_loss_coefficient: float = 1e-5
+    depth_of_discharge: float = 1.0
+    initial_soc: float = 0.0
+    power_efficiency_curve: np.ndarray = field(default_factory=lambda: np.array([[0, 0.3, 0.7, 0.8, 1.0], [0.83, 0.83, 0.9, 0.9, 0.85]]))
+    capacity_power_curve: np.ndarray = field(default_factory=lambda: np.array([[0.0, 0.8, 1.0], [1.0, 1.0, 0.2]]))
+    present: bool = False
+
+
+def _make_heat_pump(attrs: Mapping[str, Any], sampler: _Sampler) -> HeatPumpSpec:
+    # setter order: Device.__init__ -> efficiency; HeatPump.__init__ -> targets (energy_model.py:157-214)
+    return HeatPumpSpec(
+        nominal_power=0.0 if attrs.get('nominal_power') is None else attrs['nominal_power'],
+        efficiency=sampler.value(attrs.get('efficiency'), (0.2, 0.3)),
+        target_cooling_temperature=sampler.value(attrs.get('target_cooling_temperature'), (7.0, 10.0)),
+        target_heating_temperature=sampler.value(attrs.get('target_heating_temperature'), (45.0, 50.0)),
+        present=True)
+
+
+def _make_heater(attrs: Mapping[str, Any], sampler: _Sampler) -> HeaterSpec:
+    return HeaterSpec(
+        nominal_power=0.0 if attrs.get('nominal_power') is None else attrs['nominal_power'],
+        efficiency=sampler.value(attrs.get('efficiency'), (0.9, 0.99)),
+        present=True)
+
+
+def _make_tank(attrs: Mapping[str, Any], sampler: _Sampler) -> TankSpec:
+    # StorageDevice.__init__ (energy_model.py:623-629)
+    return TankSpec(
+        capacity=0.0 if attrs.get('capacity') is None else attrs['capacity'],
+        efficiency=sampler.value(attrs.get('efficiency'), (0.9, 0.98)),
+        loss_coefficient=sampler.value(attrs.get('loss_coefficient'), (0.001, 0.009)),
+        initial_soc=sampler.value(attrs.get('initial_soc'), 0.0),
+        max_input_power=attrs.get('max_input_power'),
+        max_output_power=attrs.get('max_output_power'),
+        present=True)
+
+
+def _make_battery(attrs: Mapping[str, Any], sampler: _Sampler) -> BatterySpec:
+    # Battery.__init__ (energy_model.py:896-906) and curve defaults (977-1003)
+    dod = sampler.value(attrs.get('depth_of_discharge'), 1.0)
+    eff = sampler.value(attrs.get('efficiency'), (0.9, 0.98))
+    initial_soc = attrs.get('initial_soc')
+    initial_soc = 1.0 - dod if initial_soc is None else sampler.value(initial_soc, 0.0)
+    pec = attrs.get('power_efficiency_curve')
+    if pec is None:
+        u = sampler.uniform
+        pec = [[0, u(eff * 0.85, eff * 0.90)],
+               [u(0.25, 0.35), u(eff * 0.90, eff * 0.95)],
+               [u(0.65, 0.75), u(eff * 0.98, eff * 1.0)],
+               [u(0.75, 0.85), eff],
+               [1, u(eff * 0.95, eff * 0.98)]]
+    cpc = attrs.get('capacity_power_curve')
+    if cpc is None:
+        u = sampler.uniform
+        cpc = [[0.0, u(0.95, 1.0)], [u(0.75, 0.85), u(0.90, 0.95)], [1.0, u(0.20, 0.30)]]
+    pec = np.array(pec, dtype=float).T
+    cpc = np.array(cpc, dtype=float).T
+    if pec.shape != (2, 5) or cpc.shape != (2, 3):
+        raise NotImplementedError('battery curves must have 5 (power_efficiency) and 3 (capacity_power) points; '
+                                  f'got {pec.shape[1]} and {cpc.shape[1]}')
+    return BatterySpec(
+        capacity=0.0 if attrs.get('capacity') is None else attrs['capacity'],
+        nominal_power=0.0 if attrs.get('nominal_power') is None else attrs['nominal_power'],
+        efficiency=eff,
+        loss_coefficient=sampler.value(attrs.get('loss_coefficient'), (0.001, 0.009)),
+        capacity_loss_coefficient=sampler.value(attrs.get('capacity_loss_coefficient'), (1e-5, 1e-4)),
+        depth_of_discharge=dod, initial_soc=initial_soc,
+        power_efficiency_curve=pec, capacity_power_curve=cpc, present=True)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# building / district specification
+# --------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class OutageSpec:
+    simulate: bool = False
+    stochastic: bool = False
+    model: Optional[str] = None            # 'PowerOutage' | 'ReliabilityMetricsPowerOutage'
+    random_seed: Optional[int] = None
+    saifi: float = 1.436
+    caidi: float = 331.2
+    start_time_steps: Optional[List[int]] = None
+
+
+@dataclass
+class DynamicsSpec:
+    """LSTMDynamics attributes (dynamics.py:50-101); weights are only needed by the adjacent temperature stage."""
+    filepath: str
+    input_size: int
+    hidden_size: int
+    num_layers: int
+    lookback: int
+    input_observation_names: List[str]
+    input_normalization_minimum: List[float]
+    input_normalization_maximum: List[float]
+
+
+@dataclass
+class BuildingSpec:
+    name: str
+    kind: str                                  # 'Building' | 'LSTMDynamicsBuilding'
+    series: Dict[str, np.ndarray]              # full data-file length, reference dtypes
+    observation_metadata: Dict[str, bool]
+    action_metadata: Dict[str, bool]
+    cooling_device: HeatPumpSpec
+    heating_device: Union[HeatPumpSpec, HeaterSpec]
+    dhw_device: Union[HeatPumpSpec, HeaterSpec]
+    cooling_storage: TankSpec
+    heating_storage: TankSpec
+    dhw_storage: TankSpec
+    electrical_storage: BatterySpec
+    pv_nominal_power: float
+    outage: OutageSpec
+    dynamics: Optional[DynamicsSpec]
+    seconds_per_time_step: float
+    time_step_ratio: float
+
+    @property
+    def active_actions(self) -> List[str]:
+        return [k for k, v in self.action_metadata.items() if v]
+
+    @property
+    def active_observations(self) -> List[str]:
+        return [k for k, v in self.observation_metadata.items() if v]
+
+    @property
+    def is_dynamics(self) -> bool:
+        return self.kind == 'LSTMDynamicsBuilding'
+
+    def action_space_limits(self, sim_start: int, sim_end: int) -> Tuple[np.ndarray, np.ndarray]:
+        """`Building.estimate_action_space` (building.py:2160-2282)."""
+        low, high = [], []
+        for key in self.active_actions:
+            if key == 'cooling_or_heating_device':
+                low.append(-1.0 if self.cooling_device.nominal_power > ZERO_DIVISION_PLACEHOLDER else 0.0)
+                high.append(1.0 if self.heating_device.nominal_power > ZERO_DIVISION_PLACEHOLDER else 0.0)
+            elif key in ('cooling_device', 'heating_device'):
+                low.append(0.0)
+                high.append(1.0)
+            elif key == 'electrical_storage':
+                low.append(-1.0)
+                high.append(1.0)
+            elif key in ('cooling_storage', 'heating_storage', 'dhw_storage'):
+                end_use = key.split('_')[0]
+                capacity = getattr(self, key).capacity
+                power = getattr(self, f'{end_use}_device').nominal_power
+                limit = min(power / max(capacity, ZERO_DIVISION_PLACEHOLDER), 1.0)
+                low.append(-limit)
+                high.append(limit)
+            else:
+                raise NotImplementedError(f'action {key!r} is outside the hot-path scope')
+        return np.array(low, dtype='float32'), np.array(high, dtype='float32')
+
+
+@dataclass
+class EpisodeTables:
+    """One episode window packed for the device (layouts: include/citylearn_amd.h)."""
+    params: np.ndarray          # uint32 view [B, CL_NP]
+    ts: np.ndarray              # float32 [T, B, CL_NF]
+    start: int
+    end: int
+    outage: np.ndarray          # float32 [T, B] raw signals (before AND with simulate flag)
+
+    @property
+    def n_steps(self) -> int:
+        return self.ts.shape[0]
+
+    def params_f32(self) -> np.ndarray:
+        return self.params.view(np.float32)
+
+
+@dataclass
+class DistrictSpec:
+    buildings: List[BuildingSpec]
+    central_agent: bool
+    shared_observations: List[str]
+    random_seed: int
+    seconds_per_time_step: float
+    simulation_start_time_step: int
+    simulation_end_time_step: int
+    episode_time_steps: Union[None, int, List[Tuple[int, int]]]
+    rolling_episode_split: bool
+    random_episode_split: bool
+    reward_function: Dict[str, Any]
+    root_directory: str
+    schema: Dict[str, Any]
+
+    # ---- action layout -----------------------------------------------------------------------------------
+    @property
+    def action_columns(self) -> List[Tuple[int, str]]:
+        """(building index, action name) per action column, building-major (citylearn.py:1069-1079)."""
+        return [(i, k) for i, b in enumerate(self.buildings) for k in b.active_actions]
+
+    @property
+    def n_action_columns(self) -> int:
+        return len(self.action_columns)
+
+    def action_limits(self) -> Tuple[np.ndarray, np.ndarray]:
+        lows, highs = zip(*[b.action_space_limits(self.simulation_start_time_step, self.simulation_end_time_step)
+                            for b in self.buildings])
+        return np.concatenate(lows).astype('float32'), np.concatenate(highs).astype('float32')
+
+    # ---- episodes (base.py:76-129) -------------------------------------------------------------------------
+    def episode_splits(self) -> List[Tuple[int, int]]:
+        ets = self.episode_time_steps
+        if isinstance(ets, (list, tuple)):
+            return [tuple(s) for s in ets]
+        if ets is None:
+            ets = self.simulation_end_time_step - self.simulation_start_time_step + 1
+        earliest = self.simulation_start_time_step
+        latest = (self.simulation_end_time_step + 1) - ets
+        starts = range(earliest, latest + 1) if self.rolling_episode_split else range(earliest, latest + 1, ets)
+        return [(s, s + ets - 1) for s in starts]
+
+    def episode_window(self, episode: int, random_seed: Optional[int] = None) -> Tuple[int, int]:
+        splits = self.episode_splits()
+        if self.random_episode_split:
+            seed = int((self.random_seed if random_seed is None else random_seed) * (episode + 1))
+            ix = np.random.RandomState(seed).choice(len(splits) - 1)   # sic: last split never chosen (base.py:124)
+        else:
+            ix = episode % len(splits)
+        return splits[ix]
+
+    # ---- outage signals (building.py:2566-2594) ------------------------------------------------------------
+    def outage_signal(self, b: BuildingSpec, start: int, end: int) -> np.ndarray:
+        n = end - start + 1
+        o = b.outage
+        if not o.simulate:
+            return np.zeros(n, dtype='float32')
+        if not o.stochastic:
+            return b.series['power_outage'][start:end + 1].astype('float32')
+        seed = o.random_seed
+        if seed is None:
+            seed = np.random.randint(0, 100_000_000)
+        nprs = np.random.RandomState(seed)
+        if o.model == 'PowerOutage':
+            return nprs.choice([0, 1], size=n).astype('float32')
+        # ReliabilityMetricsPowerOutage.get_signals (power_outage.py:131-169): binomial outage days, uniform
+        # start step, exponential duration -- the draw order on the MT19937 stream is what fixes the signal.
+        steps_per_day = 86400.0 / b.seconds_per_time_step
+        steps_per_minute = 60.0 / b.seconds_per_time_step
+        day_count = n / steps_per_day
+        days = nprs.binomial(n=1, p=o.saifi / 365.0, size=int(day_count))
+        day_ixs = days * np.arange(day_count)
+        day_ixs = day_ixs[day_ixs != 0]
+        count = days[days == 1].shape[0]
+        candidates = list(range(int(steps_per_day))) if o.start_time_steps is None else o.start_time_steps
+        starts = nprs.choice(candidates, size=count)
+        durations = nprs.exponential(scale=o.caidi, size=count) * steps_per_minute
+        signal = np.zeros(n, dtype=int)
+        for i, j, k in zip(day_ixs, starts, durations):
+            s = i * steps_per_day + j
+            signal[int(s):int(s + k)] = 1
+        return signal.astype('float32')
+
+    # ---- packing -------------------------------------------------------------------------------------------
+    def episode_tables(self, episode: int = 0, random_seed: Optional[int] = None,
+                       reward_exponent: float = 1.0) -> EpisodeTables:
+        start, end = self.episode_window(episode, random_seed)
+        T, B = end - start + 1, len(self.buildings)
+        params = np.zeros((B, abi.CL_NP), dtype=np.uint32)
+        pf = params.view(np.float32)
+        pi = params.view(np.int32)
+        ts = np.zeros((T, B, abi.CL_NF), dtype=np.float32)
+        outage = np.zeros((T, B), dtype=np.float32)
+        col = 0
+        for i, b in enumerate(self.buildings):
+            r = float(b.time_step_ratio)
+            flags = 0
+            pf[i, abi.CLP_DT_HOURS] = b.seconds_per_time_step / 3600.0
+            pf[i, abi.CLP_TSR] = r
+            # battery
+            e = b.electrical_storage
+            if e.present:
+                flags |= abi.CLF_BATTERY
+            pf[i, abi.CLP_B_CAP] = e.capacity
+            pf[i, abi.CLP_B_POW] = e.nominal_power
+            pf[i, abi.CLP_B_LOSS] = e.loss_coefficient * r
+            pf[i, abi.CLP_B_CLC] = e.capacity_loss_coefficient
+            pf[i, abi.CLP_B_DOD] = e.depth_of_discharge
+            pf[i, abi.CLP_B_EFF0] = e.efficiency
+            pf[i, abi.CLP_B_SOC0] = e.initial_soc
+            pf[i, abi.CLP_B_CPC_X0:abi.CLP_B_CPC_X0 + 3] = e.capacity_power_curve[0]
+            pf[i, abi.CLP_B_CPC_Y0:abi.CLP_B_CPC_Y0 + 3] = e.capacity_power_curve[1]
+            pf[i, abi.CLP_B_PEC_X0:abi.CLP_B_PEC_X0 + 5] = e.power_efficiency_curve[0]
+            pf[i, abi.CLP_B_PEC_Y0:abi.CLP_B_PEC_Y0 + 5] = e.power_efficiency_curve[1]
+            # tanks
+            for tank, base, flag in ((b.cooling_storage, abi.CLP_CS_CAP, abi.CLF_COOL_STO),
+                                     (b.heating_storage, abi.CLP_HS_CAP, abi.CLF_HEAT_STO),
+                                     (b.dhw_storage, abi.CLP_DS_CAP, abi.CLF_DHW_STO)):
+                if tank.present:
+                    flags |= flag
+                pf[i, base + 0] = tank.capacity
+                pf[i, base + 1] = tank.loss_coefficient * r
+                pf[i, base + 2] = math.sqrt(tank.efficiency)
+                pf[i, base + 3] = tank.initial_soc
+                pf[i, base + 4] = np.inf if tank.max_input_power is None else tank.max_input_power
+                pf[i, base + 5] = np.inf if tank.max_output_power is None else tank.max_output_power
+            # devices
+            cd, hd, dd = b.cooling_device, b.heating_device, b.dhw_device
+            flags |= abi.CLF_COOL_DEV if cd.present else 0
+            flags |= abi.CLF_HEAT_DEV if hd.present else 0
+            flags |= abi.CLF_DHW_DEV if dd.present else 0
+            flags |= abi.CLF_HEAT_IS_HP if hd.is_heat_pump else 0
+            flags |= abi.CLF_DHW_IS_HP if dd.is_heat_pump else 0
+            pf[i, abi.CLP_CD_POW], pf[i, abi.CLP_HD_POW], pf[i, abi.CLP_DD_POW] = cd.nominal_power, hd.nominal_power, dd.nominal_power
+            pf[i, abi.CLP_CD_EFF], pf[i, abi.CLP_CD_TC] = cd.efficiency, cd.target_cooling_temperature
+            pf[i, abi.CLP_HD_EFF] = hd.efficiency
+            pf[i, abi.CLP_HD_TH] = hd.target_heating_temperature if hd.is_heat_pump else 0.0
+            pf[i, abi.CLP_DD_EFF] = dd.efficiency
+            pf[i, abi.CLP_DD_TH] = dd.target_heating_temperature if dd.is_heat_pump else 0.0
+            # outage / dynamics
+            flags |= abi.CLF_OUTAGE if b.outage.simulate else 0
+            flags |= abi.CLF_DYNAMICS if b.is_dynamics else 0
+            pf[i, abi.CLP_DYN_WARMUP] = float(b.dynamics.lookback + 1) if b.dynamics is not None else 0.0
+            # action columns
+            for slot in _ACTION_SLOT.values():
+                pi[i, slot] = -1
+            for k in b.active_actions:
+                pi[i, _ACTION_SLOT[k]] = col
+                col += 1
+            pf[i, abi.CLP_RW_EXPONENT] = reward_exponent
+            params[i, abi.CLP_FLAGS] = flags
+            # time series rows
+            s = b.series
+            w = slice(start, end + 1)
+            t_out = s['outdoor_dry_bulb_temperature'][w]
+            ts[:, i, abi.CLT_NSL] = s['non_shiftable_load'][w]
+            ts[:, i, abi.CLT_SOLAR] = -(b.pv_nominal_power * np.array(s['solar_generation'][w]) / 1000.0)
+            ts[:, i, abi.CLT_COOL_DEM] = s['cooling_demand'][w]
+            ts[:, i, abi.CLT_HEAT_DEM] = s['heating_demand'][w]
+            ts[:, i, abi.CLT_DHW_DEM] = s['dhw_demand'][w]
+            ts[:, i, abi.CLT_COP_COOL] = cd.cop(t_out, heating=False)
+            ts[:, i, abi.CLT_COP_HEAT] = hd.cop(t_out, heating=True) if hd.is_heat_pump else hd.efficiency
+            ts[:, i, abi.CLT_COP_DHW] = dd.cop(t_out, heating=True) if dd.is_heat_pump else dd.efficiency
+            ts[:, i, abi.CLT_PRICE] = s['electricity_pricing'][w]
+            ts[:, i, abi.CLT_CARBON] = s['carbon_intensity'][w]
+            outage[:, i] = self.outage_signal(b, start, end)
+            ts[:, i, abi.CLT_OUTAGE] = outage[:, i] if b.outage.simulate else 0.0
+            ts[:, i, abi.CLT_HVAC_MODE] = s['hvac_mode'][w]
+            ts[:, i, abi.CLT_T_OUT] = t_out
+            # divisor of the reference's t=0 heating re-add (building.py:2626-2634; SURVEY App.B6)
+            pf[i, abi.CLP_T0_HEAT_DIV] = ts[0, i, abi.CLT_COP_HEAT] if hd.is_heat_pump else dd.efficiency
+        return EpisodeTables(params=params, ts=ts, start=start, end=end, outage=outage)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# loading
+# --------------------------------------------------------------------------------------------------------------
+
+def _read_csv(path: str) -> Dict[str, np.ndarray]:
+    import pandas as pd
+    frame = pd.read_csv(path)
+    return {c: frame[c].to_numpy() for c in frame.columns}
+
+
+def _energy_simulation_series(cols: Mapping[str, np.ndarray], seconds_per_time_step: float) -> Tuple[Dict[str, np.ndarray], float]:
+    """`EnergySimulation.__init__` casts / defaults (data.py:395-493) without the noise terms (noise_std = 0)."""
+    for k in _ES_REQUIRED:
+        if k not in cols:
+            raise KeyError(f'energy_simulation file lacks column {k!r}')
+    n = len(cols['solar_generation'])
+    f32 = lambda k, default=0.0: (np.zeros(n, dtype='float32') + default) if k not in cols else np.array(cols[k], dtype='float32')
+    out: Dict[str, np.ndarray] = {}
+    for k in ('month', 'hour', 'day_type'):
+        out[k] = np.array(cols[k], dtype='int32')
+    # `float32 + np.zeros(...)` in the reference promotes these two to float64 holding float32 values
+    out['indoor_dry_bulb_temperature'] = np.clip(np.array(cols['indoor_dry_bulb_temperature'], dtype='float32').astype('float64'), -90, 57)
+    out['solar_generation'] = np.array(cols['solar_generation'], dtype='float32').astype('float64')
+    for k in ('non_shiftable_load', 'dhw_demand', 'cooling_demand', 'heating_demand'):
+        out[k] = np.array(cols[k], dtype='float32')
+    if float((out['cooling_demand'] * out['heating_demand']).sum()) != 0:
+        raise AssertionError('Cooling and heating in the same time step is not allowed.')
+    out['minutes'] = np.array(cols['minutes'], dtype='int32') if 'minutes' in cols else None
+    out['daylight_savings_status'] = np.zeros(n, dtype='int32') if 'daylight_savings_status' not in cols else np.array(cols['daylight_savings_status'], dtype='int32')
+    out['average_unmet_cooling_setpoint_difference'] = f32('average_unmet_cooling_setpoint_difference')
+    out['indoor_relative_humidity'] = np.zeros(n, dtype='float32') if 'indoor_relative_humidity' not in cols else \
+        np.clip(np.array(cols['indoor_relative_humidity'], dtype='float32').astype('float64'), 0, 100)
+    out['occupant_count'] = f32('occupant_count')
+    out['indoor_dry_bulb_temperature_cooling_set_point'] = f32('indoor_dry_bulb_temperature_cooling_set_point')
+    out['indoor_dry_bulb_temperature_heating_set_point'] = f32('indoor_dry_bulb_temperature_heating_set_point')
+    out['power_outage'] = f32('power_outage')
+    out['comfort_band'] = f32('comfort_band', DEFAULT_COMFORT_BAND)
+    if 'hvac_mode' in cols:
+        hv = np.array(cols['hvac_mode'])
+        bad = sorted(set(hv.tolist()) - {0, 1, 2, 3})
+        assert not bad, f'Invalid hvac_mode values were found: {bad}. Valid values are 0, 1, 2, 3.'
+        out['hvac_mode'] = hv.astype('int32')
+    else:
+        out['hvac_mode'] = np.ones(n, dtype='int32')
+    # time_step_ratio (data.py:427-455)
+    hour = out['hour']
+    delta = int(hour[1]) * 60 - int(hour[0]) * 60
+    if out['minutes'] is not None and len(out['minutes']) > 1:
+        delta = (int(hour[1]) * 60 + int(out['minutes'][1])) - (int(hour[0]) * 60 + int(out['minutes'][0]))
+    if delta < 0:
+        delta += 1440
+    base = max(1, delta * 60)
+    ratio = seconds_per_time_step / base if seconds_per_time_step and base else None
+    return out, ratio
+
+
+def _weather_series(cols: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    out = {}
+    for k in _WEATHER_COLUMNS:
+        a = np.array(cols[k], dtype='float32')
+        out[k] = a if '_predicted_' not in k else a.astype('float64')   # data.py:567-596 promotion
+    return out
+
+
+def _pick(kwargs: Mapping[str, Any], schema: Mapping[str, Any], key: str, default=None):
+    return kwargs[key] if kwargs.get(key) is not None else schema.get(key, default)
+
+
+def _class_name(dotted: Optional[str], default: str) -> str:
+    return default if dotted is None else dotted.split('.')[-1]
+
+
+def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) -> DistrictSpec:
+    """Parse a CityLearn schema (file path or dict) and its data files into a :class:`DistrictSpec`.
+
+    Keyword arguments override schema entries exactly like ``CityLearnEnv.__init__`` (citylearn.py:133-205,
+    2006-2051): ``root_directory, buildings, simulation_start_time_step, simulation_end_time_step,
+    episode_time_steps, rolling_episode_split, random_episode_split, seconds_per_time_step, reward_function,
+    reward_function_kwargs, central_agent, shared_observations, active_observations, inactive_observations,
+    active_actions, inactive_actions, simulate_power_outage, solar_generation, random_seed``.
+    """
+    if isinstance(schema, (str, Path)):
+        path = Path(schema)
+        if not path.is_file():
+            raise FileNotFoundError(
+                f'schema {str(schema)!r} is not a file; dataset names are resolved by the reference through a GitHub '
+                'download (data.py:168-169) which is out of scope here -- pass the path of a schema.json')
+        with open(path) as f:
+            sc = json.load(f)
+        if sc.get('root_directory') is None:
+            sc['root_directory'] = str(path.parent.resolve())
+    elif isinstance(schema, Mapping):
+        sc = json.loads(json.dumps(schema))
+    else:
+        raise TypeError('schema must be a path or a dict')
+    root = kwargs['root_directory'] if kwargs.get('root_directory') is not None else sc['root_directory']
+    if root is None:
+        raise ValueError('root_directory is required when the schema is passed as a dict')
+    for unsupported in ('electric_vehicles_def',):
+        if any(v.get('include') for v in (sc.get(unsupported) or {}).values()):
+            raise NotImplementedError('electric vehicles are outside the hot-path scope (SURVEY.md section 2 row 13)')
+
+    seed = sc.get('random_seed') if kwargs.get('random_seed') is None else kwargs['random_seed']
+    seed = 0 if seed is None else int(seed)
+    central_agent = bool(_pick(kwargs, sc, 'central_agent', False))
+    seconds = float(_pick(kwargs, sc, 'seconds_per_time_step', 3600.0))
+    sim_start = int(_pick(kwargs, sc, 'simulation_start_time_step'))
+    sim_end = int(_pick(kwargs, sc, 'simulation_end_time_step'))
+    observations = {k: v for k, v in sc['observations'].items() if 'electric_vehicle_' not in k and 'washing_machine' not in k}
+    actions = {k: v for k, v in sc['actions'].items() if 'electric_vehicle_' not in k and 'washing_machine' not in k}
+    for k, v in sc['actions'].items():
+        if k not in actions and v.get('active'):
+            raise NotImplementedError(f'action {k!r} is outside the hot-path scope')
+    shared = kwargs['shared_observations'] if kwargs.get('shared_observations') is not None else \
+        [k for k, v in observations.items() if v.get('shared_in_central_agent', False)]
+
+    names = list(sc['buildings'].keys())
+    sel = kwargs.get('buildings')
+    if sel is not None and len(sel) > 0:
+        if isinstance(sel[0], str):
+            names = [n for n in names if n in sel]
+        elif isinstance(sel[0], (int, np.integer)):
+            names = [names[i] for i in sel]
+        else:
+            raise TypeError('buildings must be a list of names or indices')
+    else:
+        names = [n for n in names if sc['buildings'][n]['include']]
+
+    buildings: List[BuildingSpec] = []
+    for index, name in enumerate(names):
+        bs = sc['buildings'][name]
+        for k in ('chargers', 'washing_machines', 'occupant'):
+            if bs.get(k):
+                raise NotImplementedError(f'building {name}: {k!r} is outside the hot-path scope')
+        if bs.get('noise_std', 0.0):
+            raise NotImplementedError('noise_std > 0 (stochastic data files) is not supported yet')
+        kind = _class_name(bs.get('type'), 'Building')
+        if kind not in ('Building', 'LSTMDynamicsBuilding'):
+            raise NotImplementedError(f'building type {bs.get("type")!r} is outside the hot-path scope')
+        building_type = 'citylearn.citylearn.Building' if bs.get('type') is None else bs['type']
+        es, ratio = _energy_simulation_series(_read_csv(os.path.join(root, bs['energy_simulation'])), seconds)
+        series = dict(es)
+        series.update(_weather_series(_read_csv(os.path.join(root, bs['weather']))))
+        n = len(series['hour'])
+        if bs.get('carbon_intensity') is not None:
+            ci = _read_csv(os.path.join(root, bs['carbon_intensity']))['carbon_intensity']
+            series['carbon_intensity'] = np.clip(np.array(ci, dtype='float32').astype('float64'), 0, 1)
+        else:
+            series['carbon_intensity'] = np.clip(np.zeros(n, dtype='float32').astype('float64'), 0, 1)
+        if bs.get('pricing') is not None:
+            pr = _read_csv(os.path.join(root, bs['pricing']))
+            for k in _PRICING_COLUMNS:
+                series[k] = np.clip(np.array(pr[k], dtype='float32').astype('float64'), 0, 1)
+        else:
+            for k in _PRICING_COLUMNS:
+                series[k] = np.zeros(n, dtype='float64')
+
+        # observation / action metadata (citylearn.py:2411-2497)
+        obs_meta = {k: v['active'] for k, v in observations.items()}
+        if 'minutes' in obs_meta and series['minutes'] is None:
+            obs_meta.pop('minutes')
+        per_b = lambda v: v[index] if isinstance(v[0], list) else v
+        if kwargs.get('active_observations') is not None:
+            act = per_b(kwargs['active_observations'])
+            obs_meta = {k: k in act for k in obs_meta}
+        inactive = per_b(kwargs['inactive_observations']) if kwargs.get('inactive_observations') is not None else (bs.get('inactive_observations') or [])
+        obs_meta = {k: False if k in inactive else v for k, v in obs_meta.items()}
+        act_meta = {k: v['active'] for k, v in actions.items()}
+        if kwargs.get('active_actions') is not None:
+            act = per_b(kwargs['active_actions'])
+            act_meta = {k: k in act for k in act_meta}
+        inactive = per_b(kwargs['inactive_actions']) if kwargs.get('inactive_actions') is not None else (bs.get('inactive_actions') or [])
+        act_meta = {k: False if k in inactive else v for k, v in act_meta.items()}
+
+        # devices
+        solar_on = kwargs.get('solar_generation')
+        solar_on = True if solar_on is None else (solar_on[index] if isinstance(solar_on, list) else solar_on)
+        dev: Dict[str, Any] = {}
+        w = slice(sim_start, sim_end + 1)
+        for device_name in ('cooling_device', 'heating_device', 'dhw_device', 'dhw_storage', 'cooling_storage',
+                            'heating_storage', 'electrical_storage', 'pv'):
+            ds = bs.get(device_name)
+            if ds is None or (device_name == 'pv' and not solar_on):
+                continue
+            attrs = dict(ds.get('attributes') or {})
+            dseed = attrs.pop('random_seed', None)
+            dseed = device_seed(name, building_type, device_name, ds['type'], seed) if dseed is None else dseed
+            sampler = _Sampler(dseed)
+            cls = _class_name(ds['type'], '')
+            autosize = bool(ds.get('autosize'))
+            akw = dict(ds.get('autosize_attributes') or {})
+            t_out = series['outdoor_dry_bulb_temperature'][w]
+            if cls == 'HeatPump':
+                d = _make_heat_pump(attrs, sampler)
+                if autosize:   # HeatPump.autosize (energy_model.py:309-352); device time_step_ratio is 1 at this point
+                    sf = sampler.value(akw.get('safety_factor'), 1.0)
+                    if device_name == 'cooling_device':
+                        load = np.array(series['cooling_demand'][w] * 1) / d.cop(t_out, False)
+                    else:
+                        key = 'heating_demand' if device_name == 'heating_device' else 'dhw_demand'
+                        load = np.array(series[key][w] * 1) / d.cop(t_out, True)
+                    d.nominal_power = np.nanmax(load) * sf
+            elif cls == 'ElectricHeater':
+                d = _make_heater(attrs, sampler)
+                if autosize:   # ElectricHeater.autosize (energy_model.py:425-450)
+                    sf = sampler.value(akw.get('safety_factor'), 1.0)
+                    key = {'heating_device': 'heating_demand', 'dhw_device': 'dhw_demand'}[device_name]
+                    d.nominal_power = np.nanmax(np.array(series[key][w] * 1) / d.efficiency) * sf
+            elif cls == 'StorageTank':
+                d = _make_tank(attrs, sampler)
+                if autosize:   # StorageDevice.autosize (energy_model.py:770-795)
+                    sf = sampler.value(akw.get('safety_factor'), (1.0, 2.0))
+                    key = device_name.split('_')[0] + '_demand'
+                    d.capacity = np.nanmax(series[key][w] * 1) * sf
+            elif cls == 'Battery':
+                if autosize:
+                    raise NotImplementedError('Battery.autosize needs the battery sizing table (out of scope)')
+                d = _make_battery(attrs, sampler)
+            elif cls == 'PV':
+                if autosize:
+                    raise NotImplementedError('PV.autosize needs PySAM (out of scope)')
+                d = 0.0 if attrs.get('nominal_power') is None else attrs['nominal_power']
+            else:
+                raise NotImplementedError(f'device class {ds["type"]!r} is outside the hot-path scope')
+            dev[device_name] = d
+        if 'cooling_device' in dev and not isinstance(dev['cooling_device'], HeatPumpSpec):
+            raise NotImplementedError('cooling_device must be a HeatPump')
+
+        po = bs.get('power_outage') or {}
+        sim_out = kwargs.get('simulate_power_outage')
+        sim_out = po.get('simulate_power_outage') if sim_out is None else sim_out
+        sim_out = sim_out[index] if isinstance(sim_out, list) else sim_out
+        model = po.get('stochastic_power_outage_model')
+        mattrs = (model or {}).get('attributes') or {}
+        outage = OutageSpec(
+            simulate=bool(sim_out), stochastic=bool(po.get('stochastic_power_outage')),
+            model=_class_name(model['type'], 'PowerOutage') if model else None,
+            random_seed=mattrs.get('random_seed'),
+            saifi=1.436 if mattrs.get('saifi') is None else mattrs['saifi'],
+            caidi=331.2 if mattrs.get('caidi') is None else mattrs['caidi'],
+            start_time_steps=mattrs.get('start_time_steps'))
+        if outage.simulate and outage.stochastic and outage.model is None:
+            outage.model = 'PowerOutage'
+
+        dynamics = None
+        if kind == 'LSTMDynamicsBuilding':
+            da = dict(bs['dynamics']['attributes'])
+            dynamics = DynamicsSpec(
+                filepath=os.path.join(root, da['filename']), input_size=da['input_size'], hidden_size=da['hidden_size'],
+                num_layers=da['num_layers'], lookback=da['lookback'],
+                input_observation_names=list(da['input_observation_names']),
+                input_normalization_minimum=list(da['input_normalization_minimum']),
+                input_normalization_maximum=list(da['input_normalization_maximum']))
+
+        buildings.append(BuildingSpec(
+            name=name, kind=kind, series=series, observation_metadata=obs_meta, action_metadata=act_meta,
+            cooling_device=dev.get('cooling_device', HeatPumpSpec()),
+            heating_device=dev.get('heating_device', HeatPumpSpec()),
+            dhw_device=dev.get('dhw_device', HeaterSpec()),
+            cooling_storage=dev.get('cooling_storage', TankSpec()),
+            heating_storage=dev.get('heating_storage', TankSpec()),
+            dhw_storage=dev.get('dhw_storage', TankSpec()),
+            electrical_storage=dev.get('electrical_storage', BatterySpec()),
+            pv_nominal_power=dev.get('pv', 0.0), outage=outage, dynamics=dynamics,
+            seconds_per_time_step=seconds, time_step_ratio=1.0 if ratio is None else ratio))
+
+    # the env propagates building 0's ratio to every building and device (citylearn.py:209-210, building.py:1076-1087)
+    if buildings:
+        r0 = buildings[0].time_step_ratio
+        for b in buildings:
+            b.time_step_ratio = r0
+
+    rf = dict(sc.get('reward_function') or {'type': 'citylearn.reward_function.RewardFunction'})
+    if kwargs.get('reward_function') is not None:
+        rf['type'] = kwargs['reward_function']
+    rf['attributes'] = kwargs.get('reward_function_kwargs') or rf.get('attributes') or {}
+
+    return DistrictSpec(
+        buildings=buildings, central_agent=central_agent, shared_observations=list(shared), random_seed=seed,
+        seconds_per_time_step=seconds, simulation_start_time_step=sim_start, simulation_end_time_step=sim_end,
+        episode_time_steps=_pick(kwargs, sc, 'episode_time_steps'),
+        rolling_episode_split=bool(_pick(kwargs, sc, 'rolling_episode_split', False)),
+        random_episode_split=bool(_pick(kwargs, sc, 'random_episode_split', False)),
+        reward_function=rf, root_directory=str(root), schema=sc)

@@ -1,0 +1,204 @@
+/*
+ * citylearn_amd.h -- C-ABI of the MI355X-native CityLearn step engine.
+ *
+ * The reference (intelligent-environments-lab/CityLearn v2.4.2) is pure Python and has no FFI; its
+ * boundary for this path is `CityLearnEnv.step` (citylearn/citylearn.py:978-1056) which loops
+ * `Building.apply_actions` (citylearn/building.py:1500-1634), `Building.update_variables`
+ * (building.py:2615-2703), `RewardFunction.calculate` (citylearn/reward_function.py:65-88 and subclasses)
+ * and `Building.next_time_step` (building.py:2502-2524) over the buildings of ONE district.  The entry
+ * points below are what a ctypes binding inside the reference would call instead of those loops, for a
+ * whole batch of independent districts ("envs") at once.  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE buffer (HBM); the library never allocates, frees or retains it;
+ *   - all entry points are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value 0 = success, negative CL_E* otherwise; `cl_last_error()` gives a thread-local message;
+ *   - no C++ types, no torch types, no exceptions cross the boundary;
+ *   - base pointers must be 16-byte aligned; `n_env` must be a multiple of 4 (pad the batch).
+ *
+ * Memory layout (structure of arrays, env index fastest => coalesced 64-lane wavefront access)
+ *   params  [n_bldg][CL_NP]            32-bit words, per-building static device parameters (cl_param slots)
+ *   ts      [n_steps][n_bldg][CL_NF]   f32, per-(time step, building) time-series row (cl_feat slots);
+ *                                      identical for every env (all envs replay the same episode window)
+ *   state   [CL_NS][n_bldg][n_env]     f32, carried device state (cl_state planes)
+ *   actions element (col, env) at actions[col*act_stride_col + env*act_stride_env]; one column per active
+ *                                      (building, action) pair in the reference's central-agent order
+ *                                      (citylearn.py:1069-1079); [n_act_cols][n_env] is the coalesced layout
+ *   out_bldg [CL_NO][n_bldg][n_env]    f32, per-building outputs of the step (cl_out planes)
+ *   out_env  [CL_NQ][n_env]            f32, district sums over buildings (cl_envout planes)
+ *   kpi_bldg [CL_NKB][n_bldg][n_env], kpi_env [CL_NKE][n_env]   optional streaming KPI accumulators
+ */
+#ifndef CITYLEARN_AMD_H
+#define CITYLEARN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CL_ABI_VERSION 1
+
+/* ---- error codes ---- */
+#define CL_OK            0
+#define CL_EINVAL       -1   /* bad dims / flag combination */
+#define CL_ENULL        -2   /* required pointer is NULL */
+#define CL_EALIGN       -3   /* pointer or n_env alignment */
+#define CL_EHIP         -4   /* HIP runtime error (message in cl_last_error) */
+#define CL_ERANGE       -5   /* t / k_steps outside [0, n_steps) */
+
+/* ---- table widths ---- */
+#define CL_NP   96   /* words per building in `params` */
+#define CL_NF   16   /* floats per (t, building) row in `ts` */
+#define CL_NS    6   /* state planes */
+#define CL_NO    8   /* per-building output planes */
+#define CL_NQ    4   /* per-env (district) output planes */
+#define CL_NKB   8   /* per-building KPI accumulator planes */
+#define CL_NKE  24   /* per-env KPI accumulator planes */
+
+/* ---- per-building parameter slots (`params[b][slot]`, f32 unless noted) ---- */
+enum cl_param {
+    CLP_FLAGS = 0,        /* u32 bit pattern, CLF_* below */
+    CLP_DT_HOURS,         /* seconds_per_time_step/3600 (building.py:113) */
+    CLP_TSR,              /* time_step_ratio r (data.py:427-455); 1.0 for hourly data + hourly control */
+    /* electrical storage (energy_model.py:872-1141) */
+    CLP_B_CAP, CLP_B_POW, CLP_B_LOSS /* loss_coefficient*r */, CLP_B_CLC, CLP_B_DOD, CLP_B_EFF0, CLP_B_SOC0,
+    CLP_B_CPC_X0, CLP_B_CPC_X1, CLP_B_CPC_X2,          /* capacity_power_curve soc breakpoints */
+    CLP_B_CPC_Y0, CLP_B_CPC_Y1, CLP_B_CPC_Y2,          /* ... power fractions */
+    CLP_B_PEC_X0, CLP_B_PEC_X1, CLP_B_PEC_X2, CLP_B_PEC_X3, CLP_B_PEC_X4,   /* power_efficiency_curve */
+    CLP_B_PEC_Y0, CLP_B_PEC_Y1, CLP_B_PEC_Y2, CLP_B_PEC_Y3, CLP_B_PEC_Y4,
+    /* thermal storages (energy_model.py:603-870): capacity, loss*r, sqrt(efficiency), initial soc, max in / out */
+    CLP_CS_CAP, CLP_CS_LOSS, CLP_CS_RTE, CLP_CS_SOC0, CLP_CS_MAXIN, CLP_CS_MAXOUT,
+    CLP_HS_CAP, CLP_HS_LOSS, CLP_HS_RTE, CLP_HS_SOC0, CLP_HS_MAXIN, CLP_HS_MAXOUT,
+    CLP_DS_CAP, CLP_DS_LOSS, CLP_DS_RTE, CLP_DS_SOC0, CLP_DS_MAXIN, CLP_DS_MAXOUT,
+    /* electric devices: nominal power [kW] (energy_model.py:85-155) */
+    CLP_CD_POW, CLP_HD_POW, CLP_DD_POW,
+    /* divisor used by the reference for the t=0 heating re-add when heating_device is an ElectricHeater
+       (building.py:2632 uses dhw_device.get_input_power, SURVEY App.B6) */
+    CLP_T0_HEAT_DIV,
+    /* heat-pump / heater nameplate (only read by the oracle; the kernel reads precomputed COP columns in `ts`) */
+    CLP_CD_EFF, CLP_CD_TC, CLP_HD_EFF, CLP_HD_TH, CLP_DD_EFF, CLP_DD_TH,
+    /* LSTMDynamicsBuilding: first step index at which the device action overrides the ideal load
+       (lookback + 1; building.py:2998-2999, 3108) */
+    CLP_DYN_WARMUP,
+    /* action columns (i32 bit pattern; -1 = action inactive for this building; building.py:1557-1564) */
+    CLP_ACT_COOL_STO, CLP_ACT_HEAT_STO, CLP_ACT_DHW_STO, CLP_ACT_ELEC_STO,
+    CLP_ACT_COOL_DEV, CLP_ACT_HEAT_DEV, CLP_ACT_COH_DEV,
+    /* reward parameters (reward_function.py) */
+    CLP_RW_EXPONENT,      /* RewardFunction.exponent */
+    CLP_USED
+};
+
+/* ---- building flag bits (CLP_FLAGS) ---- */
+#define CLF_BATTERY      (1u << 0)   /* electrical_storage present */
+#define CLF_COOL_DEV     (1u << 1)
+#define CLF_HEAT_DEV     (1u << 2)
+#define CLF_DHW_DEV      (1u << 3)
+#define CLF_COOL_STO     (1u << 4)
+#define CLF_HEAT_STO     (1u << 5)
+#define CLF_DHW_STO      (1u << 6)
+#define CLF_HEAT_IS_HP   (1u << 7)   /* heating_device is a HeatPump (else ElectricHeater) */
+#define CLF_DHW_IS_HP    (1u << 8)
+#define CLF_OUTAGE       (1u << 9)   /* simulate_power_outage (building.py:671-674) */
+#define CLF_DYNAMICS     (1u << 10)  /* LSTMDynamicsBuilding: partial-load cooling/heating demand (building.py:3080-3158) */
+#define CLF_THERMAL      (CLF_COOL_DEV | CLF_HEAT_DEV | CLF_DHW_DEV | CLF_COOL_STO | CLF_HEAT_STO | CLF_DHW_STO)
+
+/* ---- time-series row (`ts[t][b][feat]`) ---- */
+enum cl_feat {
+    CLT_NSL = 0,      /* non_shiftable_load [kWh] */
+    CLT_SOLAR,        /* -pv.nominal_power * W_per_kW / 1000  (<= 0; building.py:2554) */
+    CLT_COOL_DEM, CLT_HEAT_DEM, CLT_DHW_DEM,           /* ideal demands [kWh] */
+    CLT_COP_COOL, CLT_COP_HEAT, CLT_COP_DHW,           /* HeatPump.get_cop (energy_model.py:216-250) or heater efficiency */
+    CLT_PRICE, CLT_CARBON,                             /* electricity_pricing, carbon_intensity */
+    CLT_OUTAGE,       /* power-outage signal 0/1 (power_outage.py:131-169), already AND-ed with simulate_power_outage */
+    CLT_HVAC_MODE,    /* 0 off, 1 cooling, 2 heating, 3 auto (data.py:341) */
+    CLT_T_OUT,        /* outdoor_dry_bulb_temperature [C] (oracle recomputes COP from it) */
+    CLT_RESERVED0, CLT_RESERVED1, CLT_RESERVED2
+};
+
+/* ---- state planes (`state[plane][b][env]`) ---- */
+enum cl_state {
+    CLS_B_SOC = 0,    /* electrical_storage.soc[t] */
+    CLS_B_EFF,        /* Battery.efficiency left by the previous charge() call (energy_model.py:1039-1052) */
+    CLS_B_DEGCAP,     /* Battery.degraded_capacity [kWh] */
+    CLS_CS_SOC, CLS_HS_SOC, CLS_DS_SOC                 /* cooling / heating / dhw tank soc[t] */
+};
+
+/* ---- per-building outputs (`out_bldg[plane][b][env]`) ---- */
+enum cl_out {
+    CLO_NET = 0,      /* net_electricity_consumption[t] (building.py:2681-2694) */
+    CLO_REWARD,       /* per-building reward (reward_function.py) */
+    CLO_B_EB,         /* electrical_storage.energy_balance[t] */
+    CLO_COOL_DEM,     /* delivered cooling: energy_from_cooling_device + |min(eb_cs,0)| (building.py:1435-1437) */
+    CLO_C_COOL, CLO_C_HEAT, CLO_C_DHW, CLO_C_NSL       /* device electricity_consumption[t] */
+};
+
+/* ---- district outputs (`out_env[plane][env]`) ---- */
+enum cl_envout {
+    CLQ_NET = 0, CLQ_COST, CLQ_EMISSION,               /* citylearn.py:1909-1918 */
+    CLQ_REWARD                                         /* sum over buildings (central_agent reward) */
+};
+
+/* ---- step flags (`cl_dims.flags`) ---- */
+#define CLD_REF_T0_QUIRK   (1u << 0)  /* replicate the reference's repeated t=0 update_variables (SURVEY App.B1) */
+#define CLD_WRITE_DETAIL   (1u << 1)  /* also write CLO_B_EB .. CLO_C_NSL planes (parity / KPI baselines) */
+#define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators */
+#define CLD_REWARD_SHIFT   8          /* reward kind in bits 8..11 */
+#define CLD_REWARD_MASK    (0xFu << CLD_REWARD_SHIFT)
+enum cl_reward_kind {
+    CLR_DEFAULT = 0,          /* RewardFunction: -max(net,0)**exponent          (reward_function.py:65-88)  */
+    CLR_MARL = 1,             /* MARL                                            (reward_function.py:132-143) */
+    CLR_INDEPENDENT_SAC = 2,  /* IndependentSACReward: min(-net, 0)             (reward_function.py:159-168) */
+    CLR_SOLAR_PENALTY = 3     /* SolarPenaltyReward                              (reward_function.py:189-214) */
+};
+
+typedef struct cl_dims {
+    int32_t n_env;        /* envs in this shard (multiple of 4) */
+    int32_t n_bldg;       /* buildings per district */
+    int32_t n_steps;      /* rows in `ts` (episode_time_steps) */
+    int32_t n_act_cols;   /* action columns */
+    uint32_t flags;       /* CLD_* */
+    int32_t reserved[3];
+} cl_dims;
+
+/* ABI version of the loaded library (== CL_ABI_VERSION of the header it was built from). */
+int cl_abi_version(void);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* cl_last_error(void);
+
+/* Episode start: writes soc[0] / nominal efficiency / nominal capacity into `state`
+ * (StorageDevice.reset energy_model.py:797-803, Battery.reset 1237-1242) and zeroes the KPI accumulators
+ * (either may be NULL).  Replaces the per-device reset() loop of Building.reset (building.py:2526-2564). */
+int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, float* kpi_bldg, float* kpi_env,
+                 void* stream);
+
+/* One environment step `t` for every (env, building): apply_actions + update_variables + reward + district
+ * sums.  Replaces citylearn.py:1010-1027 for a whole env batch.  `out_bldg`, `out_env` must be non-NULL;
+ * `kpi_*` only with CLD_KPI. */
+int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
+                const float* actions, int64_t act_stride_col, int64_t act_stride_env,
+                float* out_bldg, float* out_env, float* kpi_bldg, float* kpi_env, int32_t t, void* stream);
+
+/* Fused rollout: steps t0 .. t0+k_steps-1 in one launch with the per-unit state held in registers.
+ * actions == NULL: on-device uniform random policy, a = low + u*(high-low) with u from Philox4x32-10 keyed by
+ * (seed, env, action column, t) -- the device analogue of Agent.predict's action_space.sample()
+ * (agents/base.py:188-209); `act_low/act_high` are [n_act_cols].
+ * actions != NULL: open-loop action tensor, element (k, col, env) at
+ * actions[k*act_stride_step + col*act_stride_col + env*act_stride_env].
+ * `ret_env` [n_env] (optional) accumulates the district reward sum over the k steps (episode return);
+ * out_bldg / out_env receive the values of the LAST step. */
+int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
+                   const float* actions, int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env,
+                   const float* act_low, const float* act_high, uint64_t seed,
+                   float* out_bldg, float* out_env, float* ret_env, float* kpi_bldg, float* kpi_env,
+                   int32_t t0, int32_t k_steps, void* stream);
+
+/* Philox4x32-10 reference draw used by cl_rollout_f32 (host-callable so tests can reproduce the policy):
+ * returns u in [0,1) for (seed, env, col, t). */
+float cl_philox_uniform(uint64_t seed, uint32_t env, uint32_t col, uint32_t t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CITYLEARN_AMD_H */

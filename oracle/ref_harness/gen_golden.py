@@ -1,0 +1,226 @@
+"""Generate the committed golden fixtures under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+TEST INFRASTRUCTURE ONLY.  Run once in the build container (where /root/reference exists):
+
+    python oracle/ref_harness/gen_golden.py            # all fixtures
+    python oracle/ref_harness/gen_golden.py g2022_all  # one fixture
+
+Each fixture is a directory tests/golden/<name>/ holding
+
+* ``dataset/``  a *mini dataset*: the schema.json of a reference dataset with ``simulation_end_time_step``
+  shortened and every data file cut to the first N rows (gzip for the full-year one).  The reference is run
+  on exactly these files, so the loader under test and the reference read the same bytes;
+* ``reference.npz``  what the reference computed on that mini dataset for a seeded action sequence:
+  per-step per-building trajectories (SoC, energy balance, efficiency / degraded-capacity history, tank SoCs,
+  device electricity consumption, net electricity, delivered cooling, baseline net), district sums, the
+  rewards of four reward functions evaluated on the reference's own reward observations, `evaluate()` KPIs,
+  and loader facts (action bounds, observation / action names, derived device parameters, outage signals).
+
+Actions are drawn with ``np.random.RandomState(seed).uniform(low, high)`` per step over the central-agent
+action vector, rounded to float32 and handed to the reference as Python floats of those float32 values, so the
+reference, the oracle and the GPU kernel all see bit-identical actions.
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import shutil
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(HERE))
+import ref_env  # noqa: E402
+
+GOLDEN = REPO / 'tests' / 'golden'
+
+FIXTURES = {
+    # name: (reference dataset, rows kept, steps simulated, action seed, gzip, env kwargs)
+    'g2022_all': ('citylearn_challenge_2022_phase_all', 720, 719, 1234, False, {}),
+    'g2022_p1_year': ('citylearn_challenge_2022_phase_1', 8760, 8759, 0, True, {}),
+    'g2020_cz1': ('citylearn_challenge_2020_climate_zone_1', 744, 743, 2020, False, {}),
+    'g2023_p2': ('citylearn_challenge_2023_phase_2_local_evaluation', 720, 719, 2023, False, {}),
+}
+
+
+def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool):
+    import pandas as pd
+    dst.mkdir(parents=True, exist_ok=True)
+    schema = json.loads((src / 'schema.json').read_text())
+    schema['simulation_start_time_step'] = 0
+    schema['simulation_end_time_step'] = rows - 1
+    schema['root_directory'] = None
+    schema.pop('agent', None)
+    files = set()
+    for b in schema['buildings'].values():
+        for k in ('energy_simulation', 'weather', 'carbon_intensity', 'pricing'):
+            if b.get(k):
+                files.add(b[k])
+                if gz:
+                    b[k] = b[k] + '.gz'
+        if b.get('dynamics'):
+            fn = b['dynamics']['attributes']['filename']
+            shutil.copyfile(src / fn, dst / fn)
+    for fn in sorted(files):
+        frame = pd.read_csv(src / fn).iloc[:rows]
+        text = frame.to_csv(index=False)
+        # the mini dataset must hold the SAME float32 values the full files give: to_csv round-trips doubles exactly
+        if gz:
+            with gzip.GzipFile(dst / (fn + '.gz'), 'wb', mtime=0) as f:
+                f.write(text.encode())
+        else:
+            (dst / fn).write_text(text)
+    (dst / 'schema.json').write_text(json.dumps(schema, indent=1))
+    return schema
+
+
+def run_reference(name: str):
+    dataset, rows, steps, seed, gz, env_kwargs = FIXTURES[name]
+    out_dir = GOLDEN / name
+    if out_dir.exists():
+        shutil.rmtree(out_dir)
+    make_mini_dataset(ref_env.REFERENCE_ROOT / 'data' / 'datasets' / dataset, out_dir / 'dataset', rows, gz)
+
+    ref_env.setup_reference()
+    from citylearn.citylearn import CityLearnEnv
+    from citylearn import reward_function as rf
+    from citylearn.building import DynamicsBuilding
+    from citylearn.energy_model import HeatPump
+
+    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'), **env_kwargs)
+    B = len(env.buildings)
+    low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
+    high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
+    sizes = [b.action_space.shape[0] for b in env.buildings]
+    rng = np.random.RandomState(seed)
+
+    md = env.get_metadata()
+    extra_rewards = {
+        'RewardFunction': rf.RewardFunction(md), 'MARL': rf.MARL(md),
+        'IndependentSACReward': rf.IndependentSACReward(md), 'SolarPenaltyReward': rf.SolarPenaltyReward(md),
+    }
+    captured = {}
+    original_calculate = env.reward_function.calculate
+
+    def capture(observations):
+        captured['obs'] = observations
+        return original_calculate(observations)
+
+    env.reward_function.calculate = capture
+
+    env.reset()
+    reset_net = np.array([b.net_electricity_consumption[0] for b in env.buildings], dtype='float32')
+    K = steps
+    per_b = ['net', 'soc', 'eb', 'eff', 'degcap', 'cs_soc', 'hs_soc', 'ds_soc', 'c_cool', 'c_heat', 'c_dhw', 'c_ns',
+             'c_b', 'cool_dem', 'cost', 'emission', 'e_cool_dev', 'e_dhw_dev', 'e_ns']
+    traj = {k: np.zeros((K, B), dtype='float32') for k in per_b}
+    traj['actions'] = np.zeros((K, len(low)), dtype='float32')
+    traj['reward_default'] = None
+    rewards_all = {k: np.zeros((K, B), dtype='float64') for k in extra_rewards}
+    env_rewards = []
+    for t in range(K):
+        a = rng.uniform(low, high).astype('float32')
+        traj['actions'][t] = a
+        al = [float(x) for x in a]
+        if env.central_agent:
+            acts = [al]
+        else:
+            acts, p = [], 0
+            for s in sizes:
+                acts.append(al[p:p + s])
+                p += s
+        _, r, terminated, _, _ = env.step(acts)
+        env_rewards.append([float(x) for x in r])
+        for k, f in extra_rewards.items():
+            central = f.env_metadata['central_agent']
+            f.env_metadata = {**f.env_metadata, 'central_agent': False}
+            rewards_all[k][t] = np.array(f.calculate(captured['obs']), dtype='float64')
+            f.env_metadata = {**f.env_metadata, 'central_agent': central}
+        for i, b in enumerate(env.buildings):
+            es = b.electrical_storage
+            traj['net'][t, i] = b._Building__net_electricity_consumption[t]
+            traj['cost'][t, i] = b._Building__net_electricity_consumption_cost[t]
+            traj['emission'][t, i] = b._Building__net_electricity_consumption_emission[t]
+            traj['soc'][t, i] = es.soc[t]
+            traj['eb'][t, i] = es.energy_balance[t]
+            traj['eff'][t, i] = es.efficiency_history[-1]
+            traj['degcap'][t, i] = es.capacity_history[-1]
+            traj['cs_soc'][t, i] = b.cooling_storage.soc[t]
+            traj['hs_soc'][t, i] = b.heating_storage.soc[t]
+            traj['ds_soc'][t, i] = b.dhw_storage.soc[t]
+            traj['c_cool'][t, i] = b.cooling_device.electricity_consumption[t]
+            traj['c_heat'][t, i] = b.heating_device.electricity_consumption[t]
+            traj['c_dhw'][t, i] = b.dhw_device.electricity_consumption[t]
+            traj['c_ns'][t, i] = b.non_shiftable_load_device.electricity_consumption[t]
+            traj['c_b'][t, i] = es.electricity_consumption[t]
+            traj['cool_dem'][t, i] = captured['obs'][i]['cooling_demand']
+            traj['e_cool_dev'][t, i] = b._Building__energy_from_cooling_device[t]
+            traj['e_dhw_dev'][t, i] = b._Building__energy_from_dhw_device[t]
+            traj['e_ns'][t, i] = b._Building__energy_to_non_shiftable_load[t]
+        if terminated:
+            assert t == K - 1, (t, K)
+    assert env.terminated == (K == rows - 1)
+
+    # baseline series used by evaluate() (building.py:345-366, 2877-2905)
+    base = np.zeros((K, B), dtype='float64')
+    for i, b in enumerate(env.buildings):
+        s = b.net_electricity_consumption_without_storage_and_partial_load if isinstance(b, DynamicsBuilding) \
+            else b.net_electricity_consumption_without_storage
+        base[:, i] = np.array(s, dtype='float64')[:K]
+    kpis = env.evaluate()
+    kpis = kpis[kpis['value'].notnull()]
+    d_net = np.array(env.net_electricity_consumption, dtype='float32')
+    d_cost = np.array(env.net_electricity_consumption_cost, dtype='float32')
+    d_emission = np.array(env.net_electricity_consumption_emission, dtype='float32')
+
+    facts = {
+        'dataset': dataset, 'rows': rows, 'steps': K, 'seed': seed, 'central_agent': bool(env.central_agent),
+        'reward_type': type(env.reward_function).__name__,
+        'building_names': [b.name for b in env.buildings],
+        'action_names': env.action_names, 'observation_names': env.observation_names,
+        'shared_observations': env.shared_observations,
+        'time_steps': int(env.time_steps), 'time_step_ratio': float(env.time_step_ratio),
+        'devices': [{
+            'cooling_device': {'nominal_power': float(b.cooling_device.nominal_power), 'efficiency': float(b.cooling_device.efficiency),
+                               'target_cooling_temperature': float(b.cooling_device.target_cooling_temperature)},
+            'heating_device': {'nominal_power': float(b.heating_device.nominal_power), 'is_heat_pump': isinstance(b.heating_device, HeatPump)},
+            'dhw_device': {'nominal_power': float(b.dhw_device.nominal_power), 'efficiency': float(b.dhw_device.efficiency),
+                           'is_heat_pump': isinstance(b.dhw_device, HeatPump)},
+            'cooling_storage': {'capacity': float(b.cooling_storage.capacity), 'efficiency': float(b.cooling_storage.efficiency),
+                                'loss_coefficient': float(b.cooling_storage.loss_coefficient)},
+            'heating_storage': {'capacity': float(b.heating_storage.capacity)},
+            'dhw_storage': {'capacity': float(b.dhw_storage.capacity), 'efficiency': float(b.dhw_storage.efficiency),
+                            'loss_coefficient': float(b.dhw_storage.loss_coefficient)},
+            'electrical_storage': {
+                'capacity': float(b.electrical_storage.capacity), 'nominal_power': float(b.electrical_storage.nominal_power),
+                'efficiency': float(b.electrical_storage.efficiency_history[0]),
+                'loss_coefficient': float(b.electrical_storage.loss_coefficient),
+                'capacity_loss_coefficient': float(b.electrical_storage.capacity_loss_coefficient),
+                'depth_of_discharge': float(b.electrical_storage.depth_of_discharge),
+                'initial_soc': float(b.electrical_storage.initial_soc),
+                'power_efficiency_curve': np.asarray(b.electrical_storage.power_efficiency_curve, dtype=float).tolist(),
+                'capacity_power_curve': np.asarray(b.electrical_storage.capacity_power_curve, dtype=float).tolist()},
+            'pv_nominal_power': float(b.pv.nominal_power),
+        } for b in env.buildings],
+    }
+    np.savez_compressed(
+        out_dir / 'reference.npz',
+        facts=json.dumps(facts), action_low=low, action_high=high, reset_net=reset_net,
+        env_rewards=np.array(env_rewards, dtype='float64'), base_net=base,
+        d_net=d_net, d_cost=d_cost, d_emission=d_emission,
+        outage=np.array([b._Building__power_outage_signal for b in env.buildings], dtype='float32').T,
+        kpi_names=np.array([f'{r.level}|{r.name}|{r.cost_function}' for r in kpis.itertuples()]),
+        kpi_values=kpis['value'].to_numpy(dtype='float64'),
+        **{f'reward_{k}': v for k, v in rewards_all.items()},
+        **{k: v for k, v in traj.items() if v is not None})
+    size = sum(p.stat().st_size for p in out_dir.rglob('*') if p.is_file())
+    print(f'{name}: {B} buildings x {K} steps, reward {facts["reward_type"]}, fixture {size / 1e6:.2f} MB')
+
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(FIXTURES)
+    for n in names:
+        run_reference(n)
