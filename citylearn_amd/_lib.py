@@ -1,0 +1,88 @@
+"""ctypes binding of ``libcitylearn_amd.so`` (the C-ABI in ``include/citylearn_amd.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails the error propagates
+(``EngineUnavailable`` / ``EngineError``).  Build with ``python -c 'import __graft_entry__ as g; g.build()'``
+(or ``make -C citylearn_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+from . import abi
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / 'libcitylearn_amd.so'
+CSRC = PKG / 'csrc'
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC']
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f'citylearn_amd C-ABI error {code}: {message}')
+        self.code = code
+
+
+class Dims(ctypes.Structure):
+    """``cl_dims`` (include/citylearn_amd.h)."""
+    _fields_ = [('n_env', ctypes.c_int32), ('n_bldg', ctypes.c_int32), ('n_steps', ctypes.c_int32),
+                ('n_act_cols', ctypes.c_int32), ('flags', ctypes.c_uint32), ('reserved', ctypes.c_int32 * 3)]
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 into the in-tree shared library (cross-compiles without a GPU)."""
+    sources = [CSRC / 'cl_kernels.hip']
+    deps = sources + [CSRC / 'cl_unit.h', abi.HEADER]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, *HIPCC_FLAGS, *map(str, sources), '-o', str(LIB_PATH)]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library (after torch, so that both share one libamdhip64 / one HIP context)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  -- must come first: the HIP runtime torch ships is the one the kernels run on
+    if not LIB_PATH.exists():
+        raise EngineUnavailable(f'{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build())')
+    lib = ctypes.CDLL(str(LIB_PATH))
+    vp, i32, i64, u64, f32p = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p
+    lib.cl_abi_version.restype = ctypes.c_int
+    lib.cl_last_error.restype = ctypes.c_char_p
+    lib.cl_reset_f32.restype = ctypes.c_int
+    lib.cl_reset_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, vp]
+    lib.cl_step_f32.restype = ctypes.c_int
+    lib.cl_step_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, f32p, f32p, f32p, f32p, i32, vp]
+    lib.cl_rollout_f32.restype = ctypes.c_int
+    lib.cl_rollout_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, i64, f32p, f32p, u64,
+                                   f32p, f32p, f32p, f32p, f32p, i32, i32, vp]
+    lib.cl_philox_uniform.restype = ctypes.c_float
+    lib.cl_philox_uniform.argtypes = [u64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    if hasattr(lib, 'cl_debug_set_vec'):
+        lib.cl_debug_set_vec.argtypes = [ctypes.c_int]
+        lib.cl_debug_set_vec.restype = None
+    got = lib.cl_abi_version()
+    if got != abi.CL_ABI_VERSION:
+        raise EngineUnavailable(f'ABI mismatch: library {got}, header {abi.CL_ABI_VERSION}; rebuild the extension')
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise EngineError(rc, load().cl_last_error().decode(errors='replace'))

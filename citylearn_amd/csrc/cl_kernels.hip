@@ -1,0 +1,362 @@
+// cl_kernels.hip -- HIP kernels (gfx950 / CDNA4) + the extern "C" boundary declared in include/citylearn_amd.h.
+//
+// Work decomposition ("2-D tile"): a workgroup owns ENV_TILE = 64*VEC consecutive envs and ALL buildings of
+// the district.  Wave w of the workgroup advances buildings w, w+NW, w+2NW, ... so that the building index is
+// wave-uniform: its parameter block and its time-series row are fetched with scalar loads into SGPRs, and the
+// 64 lanes of the wave touch 64*VEC consecutive floats of every state / action / output plane (one fully
+// coalesced request per plane).  District sums over buildings (net, cost, emission, reward) are reduced
+// through LDS in a fixed order (wave-partials -> serial sum over waves), so results are bit-reproducible
+// run to run -- no atomics on the step path.
+#include "cl_unit.h"
+
+#include <stdarg.h>
+#include <string.h>
+#include <stdio.h>
+
+namespace {
+
+thread_local char g_err[512] = {0};
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(CL_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+struct StepArgs {
+    const uint32_t* __restrict__ params;
+    const float* __restrict__ ts;
+    float* __restrict__ state;
+    const float* __restrict__ actions;
+    float* __restrict__ out_bldg;
+    float* __restrict__ out_env;
+    float* __restrict__ kpi_bldg;
+    float* __restrict__ kpi_env;
+    long long act_stride_col, act_stride_env;
+    int n_env, n_bldg, n_steps, n_act_cols;
+    uint32_t flags;
+    int t;
+    int nw;        // waves per workgroup == building lanes
+};
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> { using type = float; };
+template <> struct Vec<2> { using type = float __attribute__((ext_vector_type(2))); };
+template <> struct Vec<4> { using type = float __attribute__((ext_vector_type(4))); };
+
+template <int VEC>
+CL_DEV void vload(float (&dst)[VEC], const float* __restrict__ p) {
+    using V = typename Vec<VEC>::type;
+    const V v = *reinterpret_cast<const V*>(p);
+    if constexpr (VEC == 1) dst[0] = v;
+    else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dst[i] = v[i];
+    }
+}
+
+template <int VEC>
+CL_DEV void vstore(float* __restrict__ p, const float (&src)[VEC]) {
+    using V = typename Vec<VEC>::type;
+    V v;
+    if constexpr (VEC == 1) v = src[0];
+    else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = src[i];
+    }
+    *reinterpret_cast<V*>(p) = v;
+}
+
+// action element (col, env): coalesced when act_stride_env == 1
+template <int VEC>
+CL_DEV void load_action(float (&dst)[VEC], const StepArgs& a, int col, int env0) {
+    if (col < 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dst[i] = 0.0f;
+        return;
+    }
+    const float* p = a.actions + (long long)col * a.act_stride_col;
+    if (a.act_stride_env == 1) vload<VEC>(dst, p + env0);
+    else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dst[i] = p[(long long)(env0 + i) * a.act_stride_env];
+    }
+}
+
+constexpr int NQ = CL_NQ;
+
+template <int VEC>
+__global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
+    constexpr int TILE = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env0 = blockIdx.x * TILE + lane * VEC;
+    const bool live = env0 < a.n_env;                     // n_env % VEC == 0 is enforced on the host
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    const bool quirk = a.flags & CLD_REF_T0_QUIRK;
+    const bool detail = a.flags & CLD_WRITE_DETAIL;
+
+    float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
+
+    for (int b = w; b < a.n_bldg; b += a.nw) {
+        cl::Bp B;
+        cl::load_bp(B, a.params + (long long)b * CL_NP);
+        cl::Row R;
+        cl::load_row(R, a.ts + ((long long)a.t * a.n_bldg + b) * CL_NF, B.flags);
+        if (live) {
+            const long long off = (long long)b * a.n_env + env0;
+            float s_soc[VEC], s_eff[VEC], s_deg[VEC], s_cs[VEC], s_hs[VEC], s_ds[VEC];
+            float a_cs[VEC], a_hs[VEC], a_ds[VEC], a_es[VEC], a_cd[VEC], a_hd[VEC];
+            const bool batt = B.flags & CLF_BATTERY;
+            if (batt) {
+                vload<VEC>(s_soc, a.state + CLS_B_SOC * plane + off);
+                vload<VEC>(s_eff, a.state + CLS_B_EFF * plane + off);
+                vload<VEC>(s_deg, a.state + CLS_B_DEGCAP * plane + off);
+            }
+            if (B.flags & CLF_COOL_STO) vload<VEC>(s_cs, a.state + CLS_CS_SOC * plane + off);
+            if (B.flags & CLF_HEAT_STO) vload<VEC>(s_hs, a.state + CLS_HS_SOC * plane + off);
+            if (B.flags & CLF_DHW_STO) vload<VEC>(s_ds, a.state + CLS_DS_SOC * plane + off);
+            load_action<VEC>(a_es, a, B.a_es, env0);
+            load_action<VEC>(a_cs, a, B.a_cs, env0);
+            load_action<VEC>(a_hs, a, B.a_hs, env0);
+            load_action<VEC>(a_ds, a, B.a_ds, env0);
+            if (B.a_coh >= 0) {
+                float c[VEC];
+                load_action<VEC>(c, a, B.a_coh, env0);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { a_cd[i] = fabsf(fminf(c[i], 0.0f)); a_hd[i] = fabsf(fmaxf(c[i], 0.0f)); }
+            } else {
+                load_action<VEC>(a_cd, a, B.a_cd, env0);
+                load_action<VEC>(a_hd, a, B.a_hd, env0);
+            }
+            float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                cl::State S;
+                S.soc = batt ? s_soc[i] : 0.0f; S.eff = batt ? s_eff[i] : 1.0f; S.degcap = batt ? s_deg[i] : 0.0f;
+                S.cs = (B.flags & CLF_COOL_STO) ? s_cs[i] : 0.0f;
+                S.hs = (B.flags & CLF_HEAT_STO) ? s_hs[i] : 0.0f;
+                S.ds = (B.flags & CLF_DHW_STO) ? s_ds[i] : 0.0f;
+                const cl::Act act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
+                cl::Out O;
+                cl::unit_step(B, R, a.t, quirk, act, S, O);
+                const float rw = cl::unit_reward(rkind, B, S, O.net);
+                s_soc[i] = S.soc; s_eff[i] = S.eff; s_deg[i] = S.degcap; s_cs[i] = S.cs; s_hs[i] = S.hs; s_ds[i] = S.ds;
+                o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem;
+                o_cc[i] = O.c_cool; o_ch[i] = O.c_heat; o_cw[i] = O.c_dhw; o_cn[i] = O.c_ns;
+                q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission; q_rw[i] += rw;
+            }
+            if (batt) {
+                vstore<VEC>(a.state + CLS_B_SOC * plane + off, s_soc);
+                vstore<VEC>(a.state + CLS_B_EFF * plane + off, s_eff);
+                vstore<VEC>(a.state + CLS_B_DEGCAP * plane + off, s_deg);
+            }
+            if (B.flags & CLF_COOL_STO) vstore<VEC>(a.state + CLS_CS_SOC * plane + off, s_cs);
+            if (B.flags & CLF_HEAT_STO) vstore<VEC>(a.state + CLS_HS_SOC * plane + off, s_hs);
+            if (B.flags & CLF_DHW_STO) vstore<VEC>(a.state + CLS_DS_SOC * plane + off, s_ds);
+            vstore<VEC>(a.out_bldg + CLO_NET * plane + off, o_net);
+            if (rkind != CLR_MARL) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+            if (detail) {
+                vstore<VEC>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
+                vstore<VEC>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
+                vstore<VEC>(a.out_bldg + CLO_C_COOL * plane + off, o_cc);
+                vstore<VEC>(a.out_bldg + CLO_C_HEAT * plane + off, o_ch);
+                vstore<VEC>(a.out_bldg + CLO_C_DHW * plane + off, o_cw);
+                vstore<VEC>(a.out_bldg + CLO_C_NSL * plane + off, o_cn);
+            }
+        }
+    }
+
+    // ---- district sums over buildings: wave partials -> LDS -> fixed-order sum over waves ----
+    float* mine = lds + (size_t)w * NQ * TILE + lane * VEC;
+    vstore<VEC>(mine + 0 * TILE, q_net);
+    vstore<VEC>(mine + 1 * TILE, q_cost);
+    vstore<VEC>(mine + 2 * TILE, q_em);
+    vstore<VEC>(mine + 3 * TILE, q_rw);
+    __syncthreads();
+    const int tile_env0 = blockIdx.x * TILE;
+    for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
+        const int q = i / TILE, e = i - q * TILE;
+        float s = 0.0f;
+        for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
+        if (rkind == CLR_MARL && q == CLQ_REWARD) continue;    // finished below
+        if (tile_env0 + e < a.n_env) a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
+        if (rkind == CLR_MARL && q == CLQ_NET) lds[i] = s;     // wave-0 slot now holds the district net
+    }
+    if (rkind == CLR_MARL) {
+        // MARL couples every building to the district net (reward_function.py:132-143): second sweep over the
+        // nets this same thread wrote a moment ago (L1/L2 hits), then a second LDS reduction for the reward sum.
+        __syncthreads();
+        float dnet[VEC];
+        vload<VEC>(dnet, lds + CLQ_NET * TILE + lane * VEC);
+        __syncthreads();
+        float r_sum[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r_sum[i] = 0.0f;
+        if (live) {
+            for (int b = w; b < a.n_bldg; b += a.nw) {
+                const long long off = (long long)b * a.n_env + env0;
+                float n[VEC], rw[VEC];
+                vload<VEC>(n, a.out_bldg + CLO_NET * plane + off);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { rw[i] = cl::marl_reward(n[i], dnet[i]); r_sum[i] += rw[i]; }
+                vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, rw);
+            }
+        }
+        vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, r_sum);
+        __syncthreads();
+        for (int e = threadIdx.x; e < TILE; e += blockDim.x) {
+            float s = 0.0f;
+            for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * TILE + e];
+            if (tile_env0 + e < a.n_env) a.out_env[(long long)CLQ_REWARD * a.n_env + tile_env0 + e] = s;
+        }
+    }
+}
+
+__global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __restrict__ state,
+                                float* __restrict__ kpi_bldg, float* __restrict__ kpi_env, int n_env, int n_bldg) {
+    const long long plane = (long long)n_bldg * n_env;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < plane) {
+        const int b = (int)(i / n_env);
+        const uint32_t* p = params + (long long)b * CL_NP;
+        if (state) {
+            state[CLS_B_SOC * plane + i] = __uint_as_float(p[CLP_B_SOC0]);
+            state[CLS_B_EFF * plane + i] = __uint_as_float(p[CLP_B_EFF0]);
+            state[CLS_B_DEGCAP * plane + i] = __uint_as_float(p[CLP_B_CAP]);
+            state[CLS_CS_SOC * plane + i] = __uint_as_float(p[CLP_CS_SOC0]);
+            state[CLS_HS_SOC * plane + i] = __uint_as_float(p[CLP_HS_SOC0]);
+            state[CLS_DS_SOC * plane + i] = __uint_as_float(p[CLP_DS_SOC0]);
+        }
+        if (kpi_bldg)
+            for (int k = 0; k < CL_NKB; ++k) kpi_bldg[k * plane + i] = 0.0f;
+    }
+    if (kpi_env && i < n_env)
+        for (int k = 0; k < CL_NKE; ++k) kpi_env[(long long)k * n_env + i] = 0.0f;
+}
+
+int check_dims(const cl_dims* d) {
+    if (!d) return fail(CL_ENULL, "dims is NULL");
+    if (d->n_env <= 0 || d->n_bldg <= 0 || d->n_steps <= 0 || d->n_act_cols < 0)
+        return fail(CL_EINVAL, "bad dims: n_env=%d n_bldg=%d n_steps=%d n_act_cols=%d", d->n_env, d->n_bldg,
+                    d->n_steps, d->n_act_cols);
+    if (d->n_env % 4 != 0) return fail(CL_EALIGN, "n_env=%d must be a multiple of 4 (pad the env batch)", d->n_env);
+    const uint32_t rk = (d->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    if (rk > CLR_SOLAR_PENALTY) return fail(CL_EINVAL, "unknown reward kind %u", rk);
+    return CL_OK;
+}
+
+int check_ptr(const void* p, const char* name, bool required = true) {
+    if (!p) return required ? fail(CL_ENULL, "%s is NULL", name) : CL_OK;
+    if (reinterpret_cast<uintptr_t>(p) & 15) return fail(CL_EALIGN, "%s is not 16-byte aligned", name);
+    return CL_OK;
+}
+
+// waves per workgroup: spread the buildings over at most 16 waves with equal trip counts
+int pick_nw(int n_bldg) {
+    const int rounds = (n_bldg + 15) / 16;
+    return (n_bldg + rounds - 1) / rounds;
+}
+
+// envs per lane: wide (16 B) accesses once the batch is large enough to still fill 256 CUs
+int pick_vec(int n_env, int n_bldg, bool unit_stride) {
+    if (!unit_stride) return 1;
+    const long long units = (long long)n_env * n_bldg;
+    if (units >= (1ll << 22)) return 4;
+    if (units >= (1ll << 20)) return 2;
+    return 1;
+}
+
+int g_force_vec = 0;   // test / tuning hook (cl_debug_set_vec)
+
+}  // namespace
+
+extern "C" {
+
+int cl_abi_version(void) { return CL_ABI_VERSION; }
+
+const char* cl_last_error(void) { return g_err; }
+
+void cl_debug_set_vec(int vec) { g_force_vec = vec; }
+
+int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, float* kpi_bldg, float* kpi_env,
+                 void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(params, "params")) return rc;
+    if (int rc = check_ptr(state, "state", false)) return rc;
+    if (int rc = check_ptr(kpi_bldg, "kpi_bldg", false)) return rc;
+    if (int rc = check_ptr(kpi_env, "kpi_env", false)) return rc;
+    const long long n = (long long)dims->n_env * dims->n_bldg;
+    const int block = 256;
+    const unsigned grid = (unsigned)((n + block - 1) / block);
+    hipLaunchKernelGGL(cl_reset_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, params, state, kpi_bldg,
+                       kpi_env, dims->n_env, dims->n_bldg);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_reset_kernel launch");
+    return CL_OK;
+}
+
+int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+                int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg,
+                float* kpi_env, int32_t t, void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(params, "params")) return rc;
+    if (int rc = check_ptr(ts, "ts")) return rc;
+    if (int rc = check_ptr(state, "state")) return rc;
+    if (int rc = check_ptr(actions, "actions", dims->n_act_cols > 0)) return rc;
+    if (int rc = check_ptr(out_bldg, "out_bldg")) return rc;
+    if (int rc = check_ptr(out_env, "out_env")) return rc;
+    if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "CLD_KPI is not implemented in this build");
+    if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
+    if (act_stride_env == 1 && (act_stride_col % 4) != 0)
+        return fail(CL_EALIGN, "act_stride_col=%lld must be a multiple of 4 floats for the coalesced layout",
+                    (long long)act_stride_col);
+
+    StepArgs a;
+    a.params = params; a.ts = ts; a.state = state; a.actions = actions; a.out_bldg = out_bldg; a.out_env = out_env;
+    a.kpi_bldg = kpi_bldg; a.kpi_env = kpi_env;
+    a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
+    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
+    a.flags = dims->flags; a.t = t;
+    a.nw = pick_nw(dims->n_bldg);
+    const int vec = g_force_vec ? g_force_vec : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1);
+    const int tile = 64 * vec;
+    const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
+    const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
+    const dim3 block(64 * a.nw);
+    hipStream_t s = (hipStream_t)stream;
+    switch (vec) {
+    case 1: hipLaunchKernelGGL(cl_step_kernel<1>, dim3(grid), block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL(cl_step_kernel<2>, dim3(grid), block, lds, s, a); break;
+    case 4: hipLaunchKernelGGL(cl_step_kernel<4>, dim3(grid), block, lds, s, a); break;
+    default: return fail(CL_EINVAL, "bad vec %d", vec);
+    }
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");
+    return CL_OK;
+}
+
+int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+                   int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env, const float* act_low,
+                   const float* act_high, uint64_t seed, float* out_bldg, float* out_env, float* ret_env,
+                   float* kpi_bldg, float* kpi_env, int32_t t0, int32_t k_steps, void* stream) {
+    (void)dims; (void)params; (void)ts; (void)state; (void)actions; (void)act_stride_step; (void)act_stride_col;
+    (void)act_stride_env; (void)act_low; (void)act_high; (void)seed; (void)out_bldg; (void)out_env; (void)ret_env;
+    (void)kpi_bldg; (void)kpi_env; (void)t0; (void)k_steps; (void)stream;
+    return fail(CL_EINVAL, "cl_rollout_f32 is not implemented in this build");
+}
+
+float cl_philox_uniform(uint64_t seed, uint32_t env, uint32_t col, uint32_t t) {
+    (void)seed; (void)env; (void)col; (void)t;
+    return 0.0f;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+"""Device-side step engine: HBM-resident tables + state, advanced by the HIP kernels through the C-ABI.
+
+This is the replacement for the per-building Python loops of ``CityLearnEnv.step`` (reference
+citylearn/citylearn.py:1010-1027) for a whole batch of independent environments.  Tensors are PyTorch-ROCm
+tensors (plumbing for device memory and streams only); all arithmetic happens in
+``citylearn_amd/csrc/cl_kernels.hip``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, abi
+from .schema import EpisodeTables
+
+REWARD_KINDS = {
+    'RewardFunction': abi.CLR_DEFAULT,
+    'MARL': abi.CLR_MARL,
+    'IndependentSACReward': abi.CLR_INDEPENDENT_SAC,
+    'SolarPenaltyReward': abi.CLR_SOLAR_PENALTY,
+}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class StepEngine:
+    """One env shard on one GPU.
+
+    Layouts follow include/citylearn_amd.h: ``state [CL_NS, B, E]``, ``out_bldg [CL_NO, B, E]``,
+    ``out_env [CL_NQ, E]``; ``actions`` is ``[n_act_cols, E]`` (coalesced) or any strided 2-D view.
+    """
+
+    def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
+                 t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None):
+        self.lib = _lib.load()                      # raises if the HIP extension is not built
+        if not torch.cuda.is_available():
+            raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
+        if n_env % 4:
+            raise ValueError('n_env must be a multiple of 4 (pad the batch)')
+        self.device = torch.device(device)
+        self.n_env = int(n_env)
+        self.n_bldg = int(tables.params.shape[0])
+        self.n_steps = int(tables.ts.shape[0])
+        if n_act_cols is None:
+            cols = tables.params.view(np.int32)[:, abi.CLP_ACT_COOL_STO:abi.CLP_ACT_COH_DEV + 1]
+            n_act_cols = int(cols.max()) + 1
+        self.n_act_cols = n_act_cols
+        self.reward = reward
+        flags = (REWARD_KINDS[reward] << abi.CLD_REWARD_SHIFT)
+        flags |= abi.CLD_REF_T0_QUIRK if t0_quirk else 0
+        flags |= abi.CLD_WRITE_DETAIL if detail else 0
+        self.dims = _lib.Dims(self.n_env, self.n_bldg, self.n_steps, self.n_act_cols, flags)
+        with torch.cuda.device(self.device):
+            self.params = torch.from_numpy(tables.params.view(np.int32).copy()).to(self.device)
+            self.ts = torch.from_numpy(np.ascontiguousarray(tables.ts)).to(self.device)
+            self.state = torch.zeros((abi.CL_NS, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device)
+            self.out_bldg = torch.zeros((abi.CL_NO, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device)
+            self.out_env = torch.zeros((abi.CL_NQ, self.n_env), dtype=torch.float32, device=self.device)
+        self.t = 0
+        self.reset()
+
+    # ---------------------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def reset(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cl_reset_f32(ctypes.byref(self.dims), _ptr(self.params), _ptr(self.state), None, None,
+                                             self._stream()))
+        self.t = 0
+
+    def step(self, actions: torch.Tensor, t: Optional[int] = None):
+        """Advance every (env, building) by one step.  ``actions``: float32 ``[n_act_cols, n_env]`` on the
+        engine's device (any 2-D strides; ``[n_env, n_act_cols].T`` works too)."""
+        t = self.t if t is None else t
+        if actions.dtype != torch.float32 or actions.device != self.device:
+            raise TypeError('actions must be a float32 tensor on the engine device')
+        if tuple(actions.shape) != (self.n_act_cols, self.n_env):
+            raise ValueError(f'actions shape {tuple(actions.shape)} != {(self.n_act_cols, self.n_env)}')
+        sc, se = actions.stride()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cl_step_f32(
+                ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), sc, se,
+                _ptr(self.out_bldg), _ptr(self.out_env), None, None, int(t), self._stream()))
+        self.t = t + 1
+
+    # convenient views ------------------------------------------------------------------------------------
+    @property
+    def soc(self) -> torch.Tensor:
+        return self.state[abi.CLS_B_SOC]
+
+    @property
+    def net(self) -> torch.Tensor:
+        return self.out_bldg[abi.CLO_NET]
+
+    @property
+    def reward_bldg(self) -> torch.Tensor:
+        return self.out_bldg[abi.CLO_REWARD]
+
+    @property
+    def district_net(self) -> torch.Tensor:
+        return self.out_env[abi.CLQ_NET]
+
+    @property
+    def district_reward(self) -> torch.Tensor:
+        return self.out_env[abi.CLQ_REWARD]
+
+    def algorithmic_bytes_per_unit(self) -> float:
+        """HBM bytes one (env, building) unit must move in one `cl_step_f32` launch (mode A-min):
+        state planes read+written, action columns read, net + reward written, district sums written."""
+        flags = self.params[:, abi.CLP_FLAGS].cpu().numpy().view(np.uint32)
+        planes = 0.0
+        for f in flags:
+            planes += 3 * bool(f & abi.CLF_BATTERY) + bool(f & abi.CLF_COOL_STO) + bool(f & abi.CLF_HEAT_STO) + bool(f & abi.CLF_DHW_STO)
+        planes /= self.n_bldg
+        return 8.0 * planes + 4.0 * self.n_act_cols / self.n_bldg + 8.0 + 4.0 * abi.CL_NQ / self.n_bldg

@@ -1,0 +1,32 @@
+"""Helpers to read the committed golden fixtures (tests/golden/<name>/{dataset/,reference.npz})."""
+import json
+from functools import lru_cache
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN = Path(__file__).resolve().parent / 'golden'
+FIXTURES = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2022_p1_year')
+
+
+class Golden:
+    def __init__(self, name: str):
+        self.name = name
+        self.dir = GOLDEN / name
+        self.schema_path = str(self.dir / 'dataset' / 'schema.json')
+        self.ref = np.load(self.dir / 'reference.npz', allow_pickle=False)
+        self.facts = json.loads(str(self.ref['facts']))
+
+    @property
+    def reward_kind(self) -> str:
+        k = self.facts['reward_type']
+        return k if k in ('RewardFunction', 'MARL', 'IndependentSACReward', 'SolarPenaltyReward') else 'RewardFunction'
+
+    def spec(self, **kwargs):
+        from citylearn_amd.schema import load_district
+        return load_district(self.schema_path, **kwargs)
+
+
+@lru_cache(maxsize=None)
+def golden(name: str) -> Golden:
+    return Golden(name)
