@@ -91,7 +91,7 @@ CL_DEV void load_action(float (&dst)[VEC], const StepArgs& a, int col, int env0)
 
 constexpr int NQ = CL_NQ;
 
-template <int VEC>
+template <int VEC, bool FULL>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
@@ -110,9 +110,9 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 
     for (int b = w; b < a.n_bldg; b += a.nw) {
         cl::Bp B;
-        cl::load_bp(B, a.params + (long long)b * CL_NP);
+        cl::load_bp<FULL>(B, a.params + (long long)b * CL_NP);
         cl::Row R;
-        cl::load_row(R, a.ts + ((long long)a.t * a.n_bldg + b) * CL_NF, B.flags);
+        cl::load_row<FULL>(R, a.ts + ((long long)a.t * a.n_bldg + b) * CL_NF, B.flags);
         if (live) {
             const long long off = (long long)b * a.n_env + env0;
             float s_soc[VEC], s_eff[VEC], s_deg[VEC], s_cs[VEC], s_hs[VEC], s_ds[VEC];
@@ -123,34 +123,40 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 vload<VEC>(s_eff, a.state + CLS_B_EFF * plane + off);
                 vload<VEC>(s_deg, a.state + CLS_B_DEGCAP * plane + off);
             }
-            if (B.flags & CLF_COOL_STO) vload<VEC>(s_cs, a.state + CLS_CS_SOC * plane + off);
-            if (B.flags & CLF_HEAT_STO) vload<VEC>(s_hs, a.state + CLS_HS_SOC * plane + off);
-            if (B.flags & CLF_DHW_STO) vload<VEC>(s_ds, a.state + CLS_DS_SOC * plane + off);
             load_action<VEC>(a_es, a, B.a_es, env0);
-            load_action<VEC>(a_cs, a, B.a_cs, env0);
-            load_action<VEC>(a_hs, a, B.a_hs, env0);
-            load_action<VEC>(a_ds, a, B.a_ds, env0);
-            if (B.a_coh >= 0) {
-                float c[VEC];
-                load_action<VEC>(c, a, B.a_coh, env0);
+            if constexpr (FULL) {
+                if (B.flags & CLF_COOL_STO) vload<VEC>(s_cs, a.state + CLS_CS_SOC * plane + off);
+                if (B.flags & CLF_HEAT_STO) vload<VEC>(s_hs, a.state + CLS_HS_SOC * plane + off);
+                if (B.flags & CLF_DHW_STO) vload<VEC>(s_ds, a.state + CLS_DS_SOC * plane + off);
+                load_action<VEC>(a_cs, a, B.a_cs, env0);
+                load_action<VEC>(a_hs, a, B.a_hs, env0);
+                load_action<VEC>(a_ds, a, B.a_ds, env0);
+                if (B.a_coh >= 0) {
+                    float c[VEC];
+                    load_action<VEC>(c, a, B.a_coh, env0);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) { a_cd[i] = fabsf(fminf(c[i], 0.0f)); a_hd[i] = fabsf(fmaxf(c[i], 0.0f)); }
-            } else {
-                load_action<VEC>(a_cd, a, B.a_cd, env0);
-                load_action<VEC>(a_hd, a, B.a_hd, env0);
+                    for (int i = 0; i < VEC; ++i) { a_cd[i] = fabsf(fminf(c[i], 0.0f)); a_hd[i] = fabsf(fmaxf(c[i], 0.0f)); }
+                } else {
+                    load_action<VEC>(a_cd, a, B.a_cd, env0);
+                    load_action<VEC>(a_hd, a, B.a_hd, env0);
+                }
             }
             float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 cl::State S;
                 S.soc = batt ? s_soc[i] : 0.0f; S.eff = batt ? s_eff[i] : 1.0f; S.degcap = batt ? s_deg[i] : 0.0f;
-                S.cs = (B.flags & CLF_COOL_STO) ? s_cs[i] : 0.0f;
-                S.hs = (B.flags & CLF_HEAT_STO) ? s_hs[i] : 0.0f;
-                S.ds = (B.flags & CLF_DHW_STO) ? s_ds[i] : 0.0f;
-                const cl::Act act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
+                S.cs = S.hs = S.ds = 0.0f;
+                cl::Act act = {0.0f, 0.0f, 0.0f, a_es[i], 0.0f, 0.0f};
+                if constexpr (FULL) {
+                    S.cs = (B.flags & CLF_COOL_STO) ? s_cs[i] : 0.0f;
+                    S.hs = (B.flags & CLF_HEAT_STO) ? s_hs[i] : 0.0f;
+                    S.ds = (B.flags & CLF_DHW_STO) ? s_ds[i] : 0.0f;
+                    act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
+                }
                 cl::Out O;
-                cl::unit_step(B, R, a.t, quirk, act, S, O);
-                const float rw = cl::unit_reward(rkind, B, S, O.net);
+                cl::unit_step<FULL>(B, R, a.t, quirk, act, S, O);
+                const float rw = cl::unit_reward<FULL>(rkind, B, S, O.net);
                 s_soc[i] = S.soc; s_eff[i] = S.eff; s_deg[i] = S.degcap; s_cs[i] = S.cs; s_hs[i] = S.hs; s_ds[i] = S.ds;
                 o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem;
                 o_cc[i] = O.c_cool; o_ch[i] = O.c_heat; o_cw[i] = O.c_dhw; o_cn[i] = O.c_ns;
@@ -161,12 +167,14 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 vstore<VEC>(a.state + CLS_B_EFF * plane + off, s_eff);
                 vstore<VEC>(a.state + CLS_B_DEGCAP * plane + off, s_deg);
             }
-            if (B.flags & CLF_COOL_STO) vstore<VEC>(a.state + CLS_CS_SOC * plane + off, s_cs);
-            if (B.flags & CLF_HEAT_STO) vstore<VEC>(a.state + CLS_HS_SOC * plane + off, s_hs);
-            if (B.flags & CLF_DHW_STO) vstore<VEC>(a.state + CLS_DS_SOC * plane + off, s_ds);
+            if constexpr (FULL) {
+                if (B.flags & CLF_COOL_STO) vstore<VEC>(a.state + CLS_CS_SOC * plane + off, s_cs);
+                if (B.flags & CLF_HEAT_STO) vstore<VEC>(a.state + CLS_HS_SOC * plane + off, s_hs);
+                if (B.flags & CLF_DHW_STO) vstore<VEC>(a.state + CLS_DS_SOC * plane + off, s_ds);
+            }
             vstore<VEC>(a.out_bldg + CLO_NET * plane + off, o_net);
             if (rkind != CLR_MARL) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
-            if (detail) {
+            if (FULL && detail) {
                 vstore<VEC>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
                 vstore<VEC>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
                 vstore<VEC>(a.out_bldg + CLO_C_COOL * plane + off, o_cc);
@@ -231,9 +239,9 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
         const int b = (int)(i / n_env);
         const uint32_t* p = params + (long long)b * CL_NP;
         if (state) {
-            state[CLS_B_SOC * plane + i] = __uint_as_float(p[CLP_B_SOC0]);
-            state[CLS_B_EFF * plane + i] = __uint_as_float(p[CLP_B_EFF0]);
-            state[CLS_B_DEGCAP * plane + i] = __uint_as_float(p[CLP_B_CAP]);
+            state[CLS_B_SOC * plane + i] = __uint_as_float(p[CLP_L_SOC0]);
+            state[CLS_B_EFF * plane + i] = __uint_as_float(p[CLP_L_EFF0]);
+            state[CLS_B_DEGCAP * plane + i] = __uint_as_float(p[CLP_L_CAP]);
             state[CLS_CS_SOC * plane + i] = __uint_as_float(p[CLP_CS_SOC0]);
             state[CLS_HS_SOC * plane + i] = __uint_as_float(p[CLP_HS_SOC0]);
             state[CLS_DS_SOC * plane + i] = __uint_as_float(p[CLP_DS_SOC0]);
@@ -328,16 +336,20 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t;
     a.nw = pick_nw(dims->n_bldg);
-    const int vec = g_force_vec ? g_force_vec : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1);
+    const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
+    const int vec = g_force_vec ? g_force_vec : (full ? 1 : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1));
     const int tile = 64 * vec;
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
-    switch (vec) {
-    case 1: hipLaunchKernelGGL(cl_step_kernel<1>, dim3(grid), block, lds, s, a); break;
-    case 2: hipLaunchKernelGGL(cl_step_kernel<2>, dim3(grid), block, lds, s, a); break;
-    case 4: hipLaunchKernelGGL(cl_step_kernel<4>, dim3(grid), block, lds, s, a); break;
+    switch (vec * 2 + (full ? 1 : 0)) {
+    case 2: hipLaunchKernelGGL((cl_step_kernel<1, false>), dim3(grid), block, lds, s, a); break;
+    case 3: hipLaunchKernelGGL((cl_step_kernel<1, true>), dim3(grid), block, lds, s, a); break;
+    case 4: hipLaunchKernelGGL((cl_step_kernel<2, false>), dim3(grid), block, lds, s, a); break;
+    case 5: hipLaunchKernelGGL((cl_step_kernel<2, true>), dim3(grid), block, lds, s, a); break;
+    case 8: hipLaunchKernelGGL((cl_step_kernel<4, false>), dim3(grid), block, lds, s, a); break;
+    case 9: hipLaunchKernelGGL((cl_step_kernel<4, true>), dim3(grid), block, lds, s, a); break;
     default: return fail(CL_EINVAL, "bad vec %d", vec);
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");

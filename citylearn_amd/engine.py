@@ -54,6 +54,10 @@ class StepEngine:
         flags = (REWARD_KINDS[reward] << abi.CLD_REWARD_SHIFT)
         flags |= abi.CLD_REF_T0_QUIRK if t0_quirk else 0
         flags |= abi.CLD_WRITE_DETAIL if detail else 0
+        bflags = tables.params[:, abi.CLP_FLAGS]
+        heavy = abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS
+        self.lean = not bool(np.any(bflags & heavy)) and not bool(np.any(tables.ts[:, :, [abi.CLT_COOL_DEM, abi.CLT_HEAT_DEM, abi.CLT_DHW_DEM]]))
+        flags |= abi.CLD_LEAN if self.lean else 0
         self.dims = _lib.Dims(self.n_env, self.n_bldg, self.n_steps, self.n_act_cols, flags)
         with torch.cuda.device(self.device):
             self.params = torch.from_numpy(tables.params.view(np.int32).copy()).to(self.device)

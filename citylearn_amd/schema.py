@@ -106,6 +106,10 @@ class HeatPumpSpec:
     def cop(self, t_out: np.ndarray, heating: bool) -> np.ndarray:
         """`HeatPump.get_cop` (energy_model.py:216-250); same float32/python-float promotion as the reference."""
         t_out = np.array(t_out)
+        with np.errstate(divide='ignore', invalid='ignore'):      # energy_model.py:14 sets the same globally
+            return self._cop(t_out, heating)
+
+    def _cop(self, t_out: np.ndarray, heating: bool) -> np.ndarray:
         if heating:
             cop = self.efficiency * (self.target_heating_temperature + 273.15) / (self.target_heating_temperature - t_out)
         else:
@@ -465,6 +469,40 @@ class DistrictSpec:
                 col += 1
             pf[i, abi.CLP_RW_EXPONENT] = reward_exponent
             params[i, abi.CLP_FLAGS] = flags
+            # ---- derived block (float64 here, rounded once into the f32 table) ----
+            dt = b.seconds_per_time_step / 3600.0
+            cap, powr = float(e.capacity), float(e.nominal_power)
+            params[i, abi.CLP_L_FLAGS] = flags
+            pi[i, abi.CLP_L_ACT_ES] = pi[i, abi.CLP_ACT_ELEC_STO]
+            pf[i, abi.CLP_L_TSR] = r
+            pf[i, abi.CLP_L_PDT] = powr * dt
+            pf[i, abi.CLP_L_POW] = powr
+            pf[i, abi.CLP_L_CAP] = cap
+            pf[i, abi.CLP_L_CAPL] = cap * (1.0 - e.loss_coefficient * r)
+            pf[i, abi.CLP_L_INV_CAP] = 1.0 / max(cap, ZERO_DIVISION_PLACEHOLDER)
+            pf[i, abi.CLP_L_INV_POW] = 1.0 / max(powr, ZERO_DIVISION_PLACEHOLDER)
+            pf[i, abi.CLP_L_OMD] = 1.0 - e.depth_of_discharge
+            pf[i, abi.CLP_L_DEGK] = e.capacity_loss_coefficient * cap * r / 2.0
+            cx, cy = np.asarray(e.capacity_power_curve, dtype=float)
+            pf[i, abi.CLP_L_CPC_X1] = cx[1]
+            for k, (sa, sb) in enumerate(((abi.CLP_L_CPC_A0, abi.CLP_L_CPC_B0), (abi.CLP_L_CPC_A1, abi.CLP_L_CPC_B1))):
+                slope = (cy[k + 1] - cy[k]) / (cx[k + 1] - cx[k])
+                pf[i, sa] = powr * (cy[k] - slope * cx[k])
+                pf[i, sb] = powr * slope
+            ex, ey = np.asarray(e.power_efficiency_curve, dtype=float)
+            pf[i, abi.CLP_L_PEC_X1:abi.CLP_L_PEC_X1 + 3] = ex[1:4]
+            for k in range(4):
+                slope = (ey[k + 1] - ey[k]) / (ex[k + 1] - ex[k])
+                pf[i, abi.CLP_L_PEC_A0 + 2 * k] = ey[k] - slope * ex[k]
+                pf[i, abi.CLP_L_PEC_B0 + 2 * k] = slope
+            pf[i, abi.CLP_L_RW_EXPONENT] = reward_exponent
+            pf[i, abi.CLP_L_SOC0] = e.initial_soc
+            pf[i, abi.CLP_L_EFF0] = e.efficiency
+            for tank, base in ((b.cooling_storage, abi.CLP_CS_IRTE), (b.heating_storage, abi.CLP_HS_IRTE),
+                               (b.dhw_storage, abi.CLP_DS_IRTE)):
+                pf[i, base + 0] = 1.0 / math.sqrt(tank.efficiency)
+                pf[i, base + 1] = 1.0 / max(float(tank.capacity), ZERO_DIVISION_PLACEHOLDER)
+                pf[i, base + 2] = float(tank.capacity) * (1.0 - tank.loss_coefficient * r)
             # time series rows
             s = b.series
             w = slice(start, end + 1)
@@ -485,6 +523,11 @@ class DistrictSpec:
             ts[:, i, abi.CLT_T_OUT] = t_out
             # divisor of the reference's t=0 heating re-add (building.py:2626-2634; SURVEY App.B6)
             pf[i, abi.CLP_T0_HEAT_DIV] = ts[0, i, abi.CLT_COP_HEAT] if hd.is_heat_pump else dd.efficiency
+            pf[i, abi.CLP_T0_IHEAT_DIV] = 1.0 / float(pf[i, abi.CLP_T0_HEAT_DIV])
+            with np.errstate(divide='ignore'):
+                for c_col, i_col in ((abi.CLT_COP_COOL, abi.CLT_ICOP_COOL), (abi.CLT_COP_HEAT, abi.CLT_ICOP_HEAT),
+                                     (abi.CLT_COP_DHW, abi.CLT_ICOP_DHW)):
+                    ts[:, i, i_col] = 1.0 / ts[:, i, c_col].astype(np.float64)
         return EpisodeTables(params=params, ts=ts, start=start, end=end, outage=outage)
 
 

@@ -48,7 +48,7 @@ extern "C" {
 #define CL_ERANGE       -5   /* t / k_steps outside [0, n_steps) */
 
 /* ---- table widths ---- */
-#define CL_NP   96   /* words per building in `params` */
+#define CL_NP  128   /* words per building in `params` */
 #define CL_NF   16   /* floats per (t, building) row in `ts` */
 #define CL_NS    6   /* state planes */
 #define CL_NO    8   /* per-building output planes */
@@ -86,6 +86,33 @@ enum cl_param {
     CLP_ACT_COOL_DEV, CLP_ACT_HEAT_DEV, CLP_ACT_COH_DEV,
     /* reward parameters (reward_function.py) */
     CLP_RW_EXPONENT,      /* RewardFunction.exponent */
+    /* ---- derived values, computed by the host packer in float64 and rounded once (the kernels read these
+     *      instead of dividing by wave-uniform quantities).  The "lean" battery+PV kernel reads only the
+     *      contiguous block CLP_L_FIRST .. CLP_L_LAST (two 16-dword scalar loads). ---- */
+    CLP_L_FIRST = 64,
+    CLP_L_FLAGS = CLP_L_FIRST, /* copy of CLP_FLAGS */
+    CLP_L_ACT_ES,         /* copy of CLP_ACT_ELEC_STO */
+    CLP_L_TSR,            /* r */
+    CLP_L_PDT,            /* nominal_power * dt  [kWh per unit action] */
+    CLP_L_POW,            /* nominal_power */
+    CLP_L_CAP,            /* capacity */
+    CLP_L_CAPL,           /* capacity * (1 - loss*r) */
+    CLP_L_INV_CAP,        /* 1 / max(capacity, ZDP) */
+    CLP_L_INV_POW,        /* 1 / max(nominal_power, ZDP) */
+    CLP_L_OMD,            /* 1 - depth_of_discharge */
+    CLP_L_DEGK,           /* capacity_loss_coefficient * capacity * r / 2 */
+    CLP_L_CPC_X1,         /* capacity_power_curve breakpoint; pmax = A + B*soc on either side (already times P) */
+    CLP_L_CPC_A0, CLP_L_CPC_B0, CLP_L_CPC_A1, CLP_L_CPC_B1,
+    CLP_L_PEC_X1, CLP_L_PEC_X2, CLP_L_PEC_X3,          /* power_efficiency_curve: eff = A + B*x per segment */
+    CLP_L_PEC_A0, CLP_L_PEC_B0, CLP_L_PEC_A1, CLP_L_PEC_B1, CLP_L_PEC_A2, CLP_L_PEC_B2, CLP_L_PEC_A3, CLP_L_PEC_B3,
+    CLP_L_RW_EXPONENT,    /* copy of CLP_RW_EXPONENT */
+    CLP_L_SOC0, CLP_L_EFF0,   /* copies of CLP_B_SOC0 / CLP_B_EFF0 */
+    CLP_L_LAST = CLP_L_EFF0,
+    /* tanks: 1/sqrt(eff), 1/max(cap, ZDP), cap*(1-loss*r) */
+    CLP_CS_IRTE, CLP_CS_ICAP, CLP_CS_CAPL,
+    CLP_HS_IRTE, CLP_HS_ICAP, CLP_HS_CAPL,
+    CLP_DS_IRTE, CLP_DS_ICAP, CLP_DS_CAPL,
+    CLP_T0_IHEAT_DIV,     /* 1 / CLP_T0_HEAT_DIV */
     CLP_USED
 };
 
@@ -113,7 +140,7 @@ enum cl_feat {
     CLT_OUTAGE,       /* power-outage signal 0/1 (power_outage.py:131-169), already AND-ed with simulate_power_outage */
     CLT_HVAC_MODE,    /* 0 off, 1 cooling, 2 heating, 3 auto (data.py:341) */
     CLT_T_OUT,        /* outdoor_dry_bulb_temperature [C] (oracle recomputes COP from it) */
-    CLT_RESERVED0, CLT_RESERVED1, CLT_RESERVED2
+    CLT_ICOP_COOL, CLT_ICOP_HEAT, CLT_ICOP_DHW          /* reciprocals of the three COP columns */
 };
 
 /* ---- state planes (`state[plane][b][env]`) ---- */
@@ -143,6 +170,9 @@ enum cl_envout {
 #define CLD_REF_T0_QUIRK   (1u << 0)  /* replicate the reference's repeated t=0 update_variables (SURVEY App.B1) */
 #define CLD_WRITE_DETAIL   (1u << 1)  /* also write CLO_B_EB .. CLO_C_NSL planes (parity / KPI baselines) */
 #define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators */
+#define CLD_LEAN           (1u << 3)  /* caller asserts: no building has a thermal device / tank, outage or dynamics
+                                         flag (battery + PV + non-shiftable load only, e.g. the 2022 schemas) ->
+                                         the specialised lean kernel may be used */
 #define CLD_REWARD_SHIFT   8          /* reward kind in bits 8..11 */
 #define CLD_REWARD_MASK    (0xFu << CLD_REWARD_SHIFT)
 enum cl_reward_kind {
