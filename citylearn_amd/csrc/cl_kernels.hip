@@ -91,6 +91,58 @@ CL_DEV void load_action(float (&dst)[VEC], const StepArgs& a, int col, int env0)
 
 constexpr int NQ = CL_NQ;
 
+// District sums over buildings: wave partials -> LDS -> fixed-order serial sum over waves (deterministic).
+// `stride` is the building stride used by the caller's loop (needed by the MARL second sweep).
+template <int VEC>
+CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int env0, bool live, long long plane, int rkind,
+                            const float (&q_net)[VEC], const float (&q_cost)[VEC], const float (&q_em)[VEC],
+                            const float (&q_rw)[VEC], int stride) {
+    constexpr int TILE = 64 * VEC;
+    float* mine = lds + (size_t)w * NQ * TILE + lane * VEC;
+    vstore<VEC>(mine + 0 * TILE, q_net);
+    vstore<VEC>(mine + 1 * TILE, q_cost);
+    vstore<VEC>(mine + 2 * TILE, q_em);
+    vstore<VEC>(mine + 3 * TILE, q_rw);
+    __syncthreads();
+    const int tile_env0 = blockIdx.x * TILE;
+    for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
+        const int q = i / TILE, e = i - q * TILE;
+        float s = 0.0f;
+        for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
+        if (rkind == CLR_MARL && q == CLQ_REWARD) continue;    // finished below
+        if (tile_env0 + e < a.n_env) a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
+        if (rkind == CLR_MARL && q == CLQ_NET) lds[i] = s;     // wave-0 slot now holds the district net
+    }
+    if (rkind == CLR_MARL) {
+        // MARL couples every building to the district net (reward_function.py:132-143): second sweep over the
+        // nets this same thread wrote a moment ago (L1/L2 hits), then a second LDS reduction for the reward sum.
+        __syncthreads();
+        float dnet[VEC];
+        vload<VEC>(dnet, lds + CLQ_NET * TILE + lane * VEC);
+        __syncthreads();
+        float r_sum[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) r_sum[i] = 0.0f;
+        if (live) {
+            for (int b = w; b < a.n_bldg; b += stride) {
+                const long long off = (long long)b * a.n_env + env0;
+                float n[VEC], rw[VEC];
+                vload<VEC>(n, a.out_bldg + CLO_NET * plane + off);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { rw[i] = cl::marl_reward(n[i], dnet[i]); r_sum[i] += rw[i]; }
+                vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, rw);
+            }
+        }
+        vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, r_sum);
+        __syncthreads();
+        for (int e = threadIdx.x; e < TILE; e += blockDim.x) {
+            float s = 0.0f;
+            for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * TILE + e];
+            if (tile_env0 + e < a.n_env) a.out_env[(long long)CLQ_REWARD * a.n_env + tile_env0 + e] = s;
+        }
+    }
+}
+
 template <int VEC, bool FULL>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
@@ -185,50 +237,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
         }
     }
 
-    // ---- district sums over buildings: wave partials -> LDS -> fixed-order sum over waves ----
-    float* mine = lds + (size_t)w * NQ * TILE + lane * VEC;
-    vstore<VEC>(mine + 0 * TILE, q_net);
-    vstore<VEC>(mine + 1 * TILE, q_cost);
-    vstore<VEC>(mine + 2 * TILE, q_em);
-    vstore<VEC>(mine + 3 * TILE, q_rw);
-    __syncthreads();
-    const int tile_env0 = blockIdx.x * TILE;
-    for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
-        const int q = i / TILE, e = i - q * TILE;
-        float s = 0.0f;
-        for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
-        if (rkind == CLR_MARL && q == CLQ_REWARD) continue;    // finished below
-        if (tile_env0 + e < a.n_env) a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
-        if (rkind == CLR_MARL && q == CLQ_NET) lds[i] = s;     // wave-0 slot now holds the district net
-    }
-    if (rkind == CLR_MARL) {
-        // MARL couples every building to the district net (reward_function.py:132-143): second sweep over the
-        // nets this same thread wrote a moment ago (L1/L2 hits), then a second LDS reduction for the reward sum.
-        __syncthreads();
-        float dnet[VEC];
-        vload<VEC>(dnet, lds + CLQ_NET * TILE + lane * VEC);
-        __syncthreads();
-        float r_sum[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) r_sum[i] = 0.0f;
-        if (live) {
-            for (int b = w; b < a.n_bldg; b += a.nw) {
-                const long long off = (long long)b * a.n_env + env0;
-                float n[VEC], rw[VEC];
-                vload<VEC>(n, a.out_bldg + CLO_NET * plane + off);
-#pragma unroll
-                for (int i = 0; i < VEC; ++i) { rw[i] = cl::marl_reward(n[i], dnet[i]); r_sum[i] += rw[i]; }
-                vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, rw);
-            }
-        }
-        vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, r_sum);
-        __syncthreads();
-        for (int e = threadIdx.x; e < TILE; e += blockDim.x) {
-            float s = 0.0f;
-            for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * TILE + e];
-            if (tile_env0 + e < a.n_env) a.out_env[(long long)CLQ_REWARD * a.n_env + tile_env0 + e] = s;
-        }
-    }
+    district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
 }
 
 __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __restrict__ state,
@@ -270,22 +279,27 @@ int check_ptr(const void* p, const char* name, bool required = true) {
     return CL_OK;
 }
 
-// waves per workgroup: spread the buildings over at most 16 waves with equal trip counts
-int pick_nw(int n_bldg) {
+// Launch geometry.  Measured on MI355X (scripts/tune.py, profiles/): at ~1M units per launch the 16-wave
+// workgroup with 16-byte accesses (1 workgroup per CU, every wave one memory round trip) is fastest; the
+// full (thermal) kernel needs too many registers for VEC > 1.
+int pick_nw(int n_bldg, int /*vec*/) {
     const int rounds = (n_bldg + 15) / 16;
-    return (n_bldg + rounds - 1) / rounds;
+    int nw = (n_bldg + rounds - 1) / rounds;
+    if (n_bldg > 16 && n_bldg <= 32) nw = 16;            // e.g. 17 buildings: 16 waves, wave 0 takes two
+    return nw;
 }
 
-// envs per lane: wide (16 B) accesses once the batch is large enough to still fill 256 CUs
+// envs per lane: wide (16 B) accesses once the batch is large enough to still give every CU a workgroup
 int pick_vec(int n_env, int n_bldg, bool unit_stride) {
     if (!unit_stride) return 1;
-    const long long units = (long long)n_env * n_bldg;
-    if (units >= (1ll << 22)) return 4;
-    if (units >= (1ll << 20)) return 2;
+    if (n_env >= 256 * 256) return 4;
+    if (n_env >= 256 * 128) return 2;
+    (void)n_bldg;
     return 1;
 }
 
-int g_force_vec = 0;   // test / tuning hook (cl_debug_set_vec)
+int g_force_vec = 0;   // test / tuning hooks (cl_debug_set_vec / cl_debug_set_lean)
+int g_force_nw = 0;
 
 }  // namespace
 
@@ -296,6 +310,7 @@ int cl_abi_version(void) { return CL_ABI_VERSION; }
 const char* cl_last_error(void) { return g_err; }
 
 void cl_debug_set_vec(int vec) { g_force_vec = vec; }
+void cl_debug_set_lean(int u, int nw) { (void)u; g_force_nw = nw; }
 
 int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, float* kpi_bldg, float* kpi_env,
                  void* stream) {
@@ -335,22 +350,28 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t;
-    a.nw = pick_nw(dims->n_bldg);
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
+    a.nw = g_force_nw ? g_force_nw : pick_nw(dims->n_bldg, 1);
     const int vec = g_force_vec ? g_force_vec : (full ? 1 : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1));
     const int tile = 64 * vec;
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
-    switch (vec * 2 + (full ? 1 : 0)) {
-    case 2: hipLaunchKernelGGL((cl_step_kernel<1, false>), dim3(grid), block, lds, s, a); break;
-    case 3: hipLaunchKernelGGL((cl_step_kernel<1, true>), dim3(grid), block, lds, s, a); break;
-    case 4: hipLaunchKernelGGL((cl_step_kernel<2, false>), dim3(grid), block, lds, s, a); break;
-    case 5: hipLaunchKernelGGL((cl_step_kernel<2, true>), dim3(grid), block, lds, s, a); break;
-    case 8: hipLaunchKernelGGL((cl_step_kernel<4, false>), dim3(grid), block, lds, s, a); break;
-    case 9: hipLaunchKernelGGL((cl_step_kernel<4, true>), dim3(grid), block, lds, s, a); break;
-    default: return fail(CL_EINVAL, "bad vec %d", vec);
+    if (full) {
+        switch (vec) {
+        case 1: hipLaunchKernelGGL((cl_step_kernel<1, true>), dim3(grid), block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((cl_step_kernel<2, true>), dim3(grid), block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((cl_step_kernel<4, true>), dim3(grid), block, lds, s, a); break;
+        default: return fail(CL_EINVAL, "bad vec %d", vec);
+        }
+    } else {
+        switch (vec) {
+        case 1: hipLaunchKernelGGL((cl_step_kernel<1, false>), dim3(grid), block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((cl_step_kernel<2, false>), dim3(grid), block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((cl_step_kernel<4, false>), dim3(grid), block, lds, s, a); break;
+        default: return fail(CL_EINVAL, "bad vec %d", vec);
+        }
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");
     return CL_OK;
