@@ -150,10 +150,9 @@ def main():
         wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
 
-    wall_t = torch.tensor([wall, ev_ms / 1e3], device=device, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall_max, ev_max = float(wall_t[0]), float(wall_t[1])
+    from citylearn_amd.parallel import reduce_max_seconds
+    wall_max = reduce_max_seconds(wall, dist, device)          # MAX over ranks
+    ev_max = reduce_max_seconds(ev_ms / 1e3, dist, device)
     units_per_step = eng.n_bldg * E
     bytes_per_unit = eng.algorithmic_bytes_per_unit()
     launch_s = ev_max / args.steps

@@ -22,7 +22,7 @@ def _parse(text: str) -> dict:
     out: dict = {}
     for m in re.finditer(r'#define\s+(CL\w+)\s+(.+)', text):
         name, expr = m.group(1), m.group(2).strip()
-        expr = re.sub(r'(\d+)[uU]\b', r'\1', expr)
+        expr = re.sub(r'(0x[0-9a-fA-F]+|\d+)[uU]\b', r'\1', expr)
         try:
             out[name] = int(eval(expr, {'__builtins__': {}}, out))  # noqa: S307 - header constants only
         except Exception:

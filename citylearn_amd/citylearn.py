@@ -1,0 +1,465 @@
+"""`CityLearnEnv`: the reference's Gymnasium-style surface on top of the MI355X step engine.
+
+Drop-in boundary: ``CityLearnEnv(schema, **overrides)``, ``reset(seed, options) -> (observations,
+info)``, ``step(actions) -> (observations, reward, terminated, truncated, info)``, ``evaluate()``,
+``observation_names / action_names / action_space / observation_space``, ``rewards / episode_rewards`` and the
+``RewardFunction`` plugin -- same names, argument meaning and error behaviour as
+/root/reference/citylearn/citylearn.py:133-271 (ctor), 978-1056 (step), 1063-1134 (_parse_actions),
+1136-1323 (evaluate), 1829-1886 (reset).
+
+Everything between parsing the action lists and reading the results runs on the GPU through the C-ABI
+(``engine.StepEngine`` -> ``cl_step_f32``); there is no CPU implementation of the step in this package.
+
+`CityLearnEnv` holds one district (the reference's semantics, incl. its quirks of SURVEY App. B behind flags);
+`VectorCityLearnEnv` (vector_env.py) is the batched tensor-in / tensor-out form the engine is built for.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Any, Dict, List, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import abi
+from .cost_function import CostFunction
+from .reward_function import RewardFunction, resolve as resolve_reward
+from .schema import DistrictSpec, load_district
+from .spaces import Box
+
+# observation names whose value depends on the environment's own trajectory (everything else is a pure
+# function of the data files and the time step)
+_ENV_DEPENDENT = {
+    'cooling_storage_soc', 'heating_storage_soc', 'dhw_storage_soc', 'electrical_storage_soc',
+    'net_electricity_consumption', 'cooling_electricity_consumption', 'heating_electricity_consumption',
+    'dhw_electricity_consumption', 'cooling_storage_electricity_consumption', 'heating_storage_electricity_consumption',
+    'dhw_storage_electricity_consumption', 'electrical_storage_electricity_consumption',
+    'washing_machine_electricity_consumption',
+}
+
+
+class _BuildingView:
+    """Read-only per-building accessor (`env.buildings[i]`), the subset of `citylearn.building.Building` that
+    callers of the hot path use: names, metadata, spaces and the simulated series up to the current step."""
+
+    def __init__(self, env: 'CityLearnEnv', index: int):
+        self._env, self._i = env, index
+        self.spec = env.spec.buildings[index]
+        self.name = self.spec.name
+
+    @property
+    def active_observations(self) -> List[str]:
+        return list(self._env._obs_names[self._i])
+
+    @property
+    def active_actions(self) -> List[str]:
+        return self.spec.active_actions
+
+    @property
+    def action_metadata(self) -> Dict[str, bool]:
+        return dict(self.spec.action_metadata)
+
+    @property
+    def observation_metadata(self) -> Dict[str, bool]:
+        return dict(self.spec.observation_metadata)
+
+    @property
+    def action_space(self) -> Box:
+        lo, hi = self.spec.action_space_limits(self._env.spec.simulation_start_time_step, self._env.spec.simulation_end_time_step)
+        return Box(low=lo, high=hi, dtype=np.float32)
+
+    def _series(self, key: str) -> np.ndarray:
+        return self._env._history_array(key)[:, self._i]
+
+    @property
+    def net_electricity_consumption(self) -> np.ndarray:
+        return self._series('net')
+
+    @property
+    def net_electricity_consumption_without_storage(self) -> np.ndarray:
+        return self._series('base_net')
+
+    @property
+    def electrical_storage_soc(self) -> np.ndarray:
+        return self._series('soc')
+
+
+class CityLearnEnv:
+    """One CityLearn district stepped on the GPU.  See the module docstring for the mirrored interface."""
+
+    def __init__(self, schema: Union[str, Path, Mapping[str, Any]], device: str = 'cuda:0',
+                 observation_mode: str = 'reference', reference_quirks: bool = True, **kwargs: Any):
+        """`schema` and `**kwargs` exactly as the reference constructor (citylearn.py:133-205).  Extra arguments:
+        `device`; `observation_mode`: ``'reference'`` returns the reference's observation semantics (values of step
+        t+1 read before they are computed -- SoC / net read 0), ``'current'`` returns the SoC / net
+        just computed; `reference_quirks`: replicate the repeated t = 0 bookkeeping."""
+        if observation_mode not in ('reference', 'current'):
+            raise ValueError("observation_mode must be 'reference' or 'current'")
+        self.spec: DistrictSpec = load_district(schema, **kwargs)
+        self.device = device
+        self.observation_mode = observation_mode
+        self.reference_quirks = reference_quirks
+        self.central_agent = self.spec.central_agent
+        self.shared_observations = list(self.spec.shared_observations)
+        self.random_seed = self.spec.random_seed
+        self.seconds_per_time_step = self.spec.seconds_per_time_step
+        rf_cls = resolve_reward(self.spec.reward_function.get('type'))
+        self.reward_function: RewardFunction = rf_cls(None, **(self.spec.reward_function.get('attributes') or {}))
+        self.buildings = [_BuildingView(self, i) for i in range(len(self.spec.buildings))]
+        self._episode = -1
+        self._engine = None
+        self.__rewards: List[List[float]] = [[]]
+        self.__episode_rewards: List[Mapping[str, Any]] = []
+        self._obs_names = [self._building_observation_names(b) for b in self.spec.buildings]
+        self.reward_function.env_metadata = self.get_metadata()
+        self.reset()
+
+    # ---- static structure ------------------------------------------------------------------------------------
+    @staticmethod
+    def _available_observations(b) -> set:
+        keys = {k for k, v in b.series.items() if isinstance(v, np.ndarray)}
+        keys |= {'solar_generation', 'cooling_storage_soc', 'heating_storage_soc', 'dhw_storage_soc', 'electrical_storage_soc',
+                 'cooling_demand', 'heating_demand', 'dhw_demand', 'net_electricity_consumption', 'cooling_electricity_consumption',
+                 'heating_electricity_consumption', 'dhw_electricity_consumption', 'cooling_storage_electricity_consumption',
+                 'heating_storage_electricity_consumption', 'dhw_storage_electricity_consumption',
+                 'electrical_storage_electricity_consumption', 'washing_machine_electricity_consumption',
+                 'cooling_device_efficiency', 'heating_device_efficiency', 'dhw_device_efficiency',
+                 'indoor_dry_bulb_temperature_cooling_set_point', 'indoor_dry_bulb_temperature_heating_set_point',
+                 'indoor_dry_bulb_temperature_cooling_delta', 'indoor_dry_bulb_temperature_heating_delta', 'comfort_band',
+                 'occupant_count', 'power_outage'}
+        return keys
+
+    def _building_observation_names(self, b) -> List[str]:
+        """Active observations in schema order, restricted to what a building can report (building.py:1146-1153)."""
+        available = self._available_observations(b)
+        return [k for k in b.active_observations if k in available]
+
+    @property
+    def observation_names(self) -> List[List[str]]:
+        if not self.central_agent:
+            return [list(n) for n in self._obs_names]
+        names: List[str] = []
+        for i, bn in enumerate(self._obs_names):
+            for k in bn:
+                if i == 0 or k not in self.shared_observations or k not in names:
+                    names.append(k)
+        return [names]
+
+    @property
+    def action_names(self) -> List[List[str]]:
+        if self.central_agent:
+            return [[k for b in self.spec.buildings for k in b.active_actions]]
+        return [list(b.active_actions) for b in self.spec.buildings]
+
+    @property
+    def action_space(self) -> List[Box]:
+        spaces_ = [b.action_space for b in self.buildings]
+        if self.central_agent:
+            return [Box(low=np.concatenate([s.low for s in spaces_]), high=np.concatenate([s.high for s in spaces_]), dtype=np.float32)]
+        return spaces_
+
+    @property
+    def observation_space(self) -> List[Box]:
+        """Observation limits.  Exogenous observations: min / max of the data series over the simulation period;
+        SoC observations [0, 1]; electricity observations: loose bounds from device sizes.  (The reference's exact
+        estimates, building.py:1836-2158, are an agent-side normalisation aid and are not part of the hot path.)"""
+        per_b = []
+        for i, b in enumerate(self.spec.buildings):
+            lo, hi = [], []
+            w = slice(self.spec.simulation_start_time_step, self.spec.simulation_end_time_step + 1)
+            peak = float(np.max(b.series['non_shiftable_load'][w]) + b.cooling_device.nominal_power + b.heating_device.nominal_power
+                         + b.dhw_device.nominal_power + b.electrical_storage.nominal_power)
+            for k in self._obs_names[i]:
+                if k.endswith('_soc'):
+                    lo.append(0.0); hi.append(1.0)
+                elif k == 'solar_generation':
+                    lo.append(0.0); hi.append(float(np.max(b.pv_nominal_power * b.series['solar_generation'][w] / 1000.0)))
+                elif k in _ENV_DEPENDENT or k.endswith('_electricity_consumption'):
+                    lo.append(-peak - b.pv_nominal_power); hi.append(peak)
+                elif k in b.series and isinstance(b.series[k], np.ndarray):
+                    s = np.asarray(b.series[k][w], dtype=float)
+                    lo.append(float(np.nanmin(s)) if np.any(~np.isnan(s)) else 0.0)
+                    hi.append(float(np.nanmax(s)) if np.any(~np.isnan(s)) else 0.0)
+                else:
+                    lo.append(-np.inf); hi.append(np.inf)
+            per_b.append((np.array(lo, dtype='float32'), np.array(hi, dtype='float32')))
+        if not self.central_agent:
+            return [Box(low=lo, high=hi, dtype=np.float32) for lo, hi in per_b]
+        lo_all, hi_all, seen = [], [], []
+        for i, (lo, hi) in enumerate(per_b):
+            for l, h, k in zip(lo, hi, self._obs_names[i]):
+                if i == 0 or k not in self.shared_observations or k not in seen:
+                    lo_all.append(l); hi_all.append(h)
+                if k in self.shared_observations and k not in seen:
+                    seen.append(k)
+        return [Box(low=np.array(lo_all, dtype='float32'), high=np.array(hi_all, dtype='float32'), dtype=np.float32)]
+
+    def get_metadata(self) -> Mapping[str, Any]:
+        """Static information handed to the reward function (`env_metadata`, citylearn.py:243, 897-937)."""
+        return {
+            'central_agent': self.central_agent, 'shared_observations': self.shared_observations,
+            'seconds_per_time_step': self.seconds_per_time_step, 'random_seed': self.random_seed,
+            'buildings': [{
+                'name': b.name,
+                'cooling_storage': {'capacity': b.cooling_storage.capacity}, 'heating_storage': {'capacity': b.heating_storage.capacity},
+                'dhw_storage': {'capacity': b.dhw_storage.capacity},
+                'electrical_storage': {'capacity': b.electrical_storage.capacity, 'nominal_power': b.electrical_storage.nominal_power},
+                'cooling_device': {'nominal_power': b.cooling_device.nominal_power},
+                'heating_device': {'nominal_power': b.heating_device.nominal_power},
+                'dhw_device': {'nominal_power': b.dhw_device.nominal_power}, 'pv': {'nominal_power': b.pv_nominal_power},
+                'action_metadata': dict(b.action_metadata), 'observation_metadata': dict(b.observation_metadata),
+            } for b in self.spec.buildings],
+        }
+
+    # ---- episode state ---------------------------------------------------------------------------------------
+    @property
+    def time_step(self) -> int:
+        return self._t
+
+    @property
+    def time_steps(self) -> int:
+        return self._tables.n_steps
+
+    @property
+    def episode(self) -> int:
+        return self._episode
+
+    @property
+    def terminated(self) -> bool:
+        return self._t == self.time_steps - 1          # citylearn.py:373-376
+
+    @property
+    def truncated(self) -> bool:
+        return False
+
+    @property
+    def rewards(self) -> List[List[float]]:
+        return self.__rewards
+
+    @property
+    def episode_rewards(self) -> List[Mapping[str, Any]]:
+        return self.__episode_rewards
+
+    @property
+    def net_electricity_consumption(self) -> List[float]:
+        """District net electricity consumption, one entry per completed step (citylearn.py:696, 1909-1918)."""
+        return list(self._hist['d_net'])
+
+    @property
+    def net_electricity_consumption_cost(self) -> List[float]:
+        return list(self._hist['d_cost'])
+
+    @property
+    def net_electricity_consumption_emission(self) -> List[float]:
+        return list(self._hist['d_emission'])
+
+    def get_info(self) -> Mapping[Any, Any]:
+        return {}
+
+    def _history_array(self, key: str) -> np.ndarray:
+        rows = self._hist[key]
+        B = len(self.spec.buildings)
+        return np.array(rows, dtype='float32').reshape(len(rows), B)
+
+    # ---- reset / step ----------------------------------------------------------------------------------------
+    def reset(self, seed: int = None, options: Mapping[str, Any] = None) -> Tuple[List[List[float]], dict]:
+        import torch
+        from .engine import StepEngine, REWARD_KINDS
+        if seed is not None:
+            self.random_seed = seed
+        self._episode += 1
+        exponent = getattr(self.reward_function, 'exponent', 1.0)
+        self._tables = self.spec.episode_tables(self._episode, self.random_seed, reward_exponent=float(exponent))
+        kind = getattr(type(self.reward_function), 'device_kind', None)
+        fused = kind is not None and type(self.reward_function).calculate is _stock_calculate(type(self.reward_function))
+        self._fused_reward = fused
+        names = {v: k for k, v in REWARD_KINDS.items()}
+        self._engine = StepEngine(self._tables, 4, device=self.device, reward=names[kind] if fused else 'RewardFunction',
+                                  t0_quirk=self.reference_quirks, detail=True)
+        self._torch = torch
+        self._t = 0
+        self.reward_function.reset()
+        self.__rewards = [[]]
+        self._hist: Dict[str, list] = {k: [] for k in ('net', 'base_net', 'soc', 'cost', 'emission', 'expected', 'served',
+                                                       'd_net', 'd_cost', 'd_emission')}
+        self._obs_table = [self._observation_table(i) for i in range(len(self.spec.buildings))]
+        return self.observations, self.get_info()
+
+    def _parse_actions(self, actions: Sequence[Sequence[float]]) -> np.ndarray:
+        """List-of-lists -> flat action-column vector, with the reference's count checks (citylearn.py:1063-1134)."""
+        actions = list(actions)
+        sizes = [len(b.active_actions) for b in self.spec.buildings]
+        if self.central_agent:
+            flat = list(actions[0])
+            expected = sum(sizes)
+            assert len(flat) == expected, f'Expected {expected} actions but {len(flat)} were parsed to env.step.'
+        else:
+            per_b = [list(a) for a in actions]
+            for b, a, n in zip(self.spec.buildings, per_b, sizes):
+                assert len(a) == n, f'Expected {n} for {b.name} but {len(a)} actions were provided.'
+            assert len(per_b) == len(sizes), f'Expected {len(sizes)} action lists but {len(per_b)} were provided.'
+            flat = [x for a in per_b for x in a]
+        return np.asarray(flat, dtype=np.float32)
+
+    def step(self, actions: Sequence[Sequence[float]]):
+        torch = self._torch
+        eng = self._engine
+        flat = self._parse_actions(actions)
+        if self.terminated:
+            raise RuntimeError('episode has terminated: call reset()')
+        a = torch.from_numpy(flat).to(eng.device)[:, None].expand(-1, eng.n_env).contiguous()
+        t = self._t
+        eng.step(a, t)
+        ob = eng.out_bldg[:, :, 0].cpu().numpy()
+        oe = eng.out_env[:, 0].cpu().numpy()
+        st = eng.state[:, :, 0].cpu().numpy()
+        self._last_state, self._last_out = st, ob
+        h = self._hist
+        h['net'].append(ob[abi.CLO_NET]); h['base_net'].append(ob[abi.CLO_BASE_NET]); h['soc'].append(st[abi.CLS_B_SOC])
+        h['expected'].append(ob[abi.CLO_EXPECTED]); h['served'].append(ob[abi.CLO_SERVED])
+        ts = self._tables.ts[t]
+        net64 = ob[abi.CLO_NET].astype(np.float64)
+        h['cost'].append((net64 * ts[:, abi.CLT_PRICE]).astype('float32'))
+        h['emission'].append(np.maximum(0.0, net64 * ts[:, abi.CLT_CARBON]).astype('float32'))
+        h['d_net'].append(float(oe[abi.CLQ_NET])); h['d_cost'].append(float(oe[abi.CLQ_COST])); h['d_emission'].append(float(oe[abi.CLQ_EMISSION]))
+        if self._fused_reward:
+            reward = [float(oe[abi.CLQ_REWARD])] if self.central_agent else [float(x) for x in ob[abi.CLO_REWARD]]
+        else:
+            reward = self.reward_function.calculate(observations=self._reward_observations(t, st, ob))
+        self.__rewards.append(reward)
+        self._t += 1
+        if self.terminated:
+            r = np.array(self.__rewards[1:], dtype='float32')
+            self.__episode_rewards.append({'min': r.min(axis=0).tolist(), 'max': r.max(axis=0).tolist(),
+                                           'sum': r.sum(axis=0).tolist(), 'mean': r.mean(axis=0).tolist()})
+        return self.observations, reward, self.terminated, self.truncated, self.get_info()
+
+    # ---- observations ----------------------------------------------------------------------------------------
+    def _observation_table(self, i: int) -> np.ndarray:
+        """[T, n_obs] table of the env-independent observation values of building `i` for the current episode.
+        Env-dependent columns hold what the reference reports when it reads step t+1 before computing it
+        (zero-initialised series), with the t = 0 row holding the reset-time values."""
+        b = self.spec.buildings[i]
+        tab = self._tables
+        T = tab.n_steps
+        w = slice(tab.start, tab.end + 1)
+        names = self._obs_names[i]
+        out = np.zeros((T, len(names)), dtype=np.float64)
+        ts = tab.ts[:, i]
+        outage0 = bool(ts[0, abi.CLT_OUTAGE])
+        for j, k in enumerate(names):
+            if k == 'solar_generation':
+                out[:, j] = np.abs(ts[:, abi.CLT_SOLAR])
+            elif k == 'power_outage':
+                out[:, j] = tab.outage[:, i]
+            elif k in ('cooling_demand', 'heating_demand', 'dhw_demand', 'occupant_count', 'comfort_band',
+                       'indoor_dry_bulb_temperature_cooling_set_point', 'indoor_dry_bulb_temperature_heating_set_point'):
+                out[:, j] = b.series[k][w]
+            elif k == 'indoor_dry_bulb_temperature_cooling_delta':
+                out[:, j] = b.series['indoor_dry_bulb_temperature'][w] - b.series['indoor_dry_bulb_temperature_cooling_set_point'][w]
+            elif k == 'indoor_dry_bulb_temperature_heating_delta':
+                out[:, j] = b.series['indoor_dry_bulb_temperature'][w] - b.series['indoor_dry_bulb_temperature_heating_set_point'][w]
+            elif k == 'cooling_device_efficiency':
+                out[:, j] = ts[:, abi.CLT_COP_COOL]
+            elif k == 'heating_device_efficiency':
+                out[:, j] = ts[:, abi.CLT_COP_HEAT]
+            elif k == 'dhw_device_efficiency':
+                out[:, j] = ts[:, abi.CLT_COP_DHW]
+            elif k in _ENV_DEPENDENT:
+                pf = tab.params_f32()[i]
+                first = {'electrical_storage_soc': pf[abi.CLP_B_SOC0], 'cooling_storage_soc': pf[abi.CLP_CS_SOC0],
+                         'heating_storage_soc': pf[abi.CLP_HS_SOC0], 'dhw_storage_soc': pf[abi.CLP_DS_SOC0]}
+                if self.reference_quirks:
+                    c_cool = ts[0, abi.CLT_COOL_DEM] * ts[0, abi.CLT_ICOP_COOL]
+                    c_heat = ts[0, abi.CLT_HEAT_DEM] * pf[abi.CLP_T0_IHEAT_DIV]
+                    c_dhw = ts[0, abi.CLT_DHW_DEM] * ts[0, abi.CLT_ICOP_DHW]
+                    first.update({
+                        'cooling_electricity_consumption': c_cool, 'heating_electricity_consumption': c_heat,
+                        'dhw_electricity_consumption': c_dhw,
+                        'net_electricity_consumption': 0.0 if outage0 else c_cool + c_heat + c_dhw + ts[0, abi.CLT_NSL] + ts[0, abi.CLT_SOLAR]})
+                out[0, j] = first.get(k, 0.0)
+            elif k in b.series and isinstance(b.series[k], np.ndarray):
+                out[:, j] = b.series[k][w]
+            else:
+                raise KeyError(f'observation {k!r} cannot be produced for building {b.name}')
+        return out
+
+    def _building_observations(self, i: int) -> List[float]:
+        row = self._obs_table[i][self._t].tolist()
+        if self.observation_mode == 'current' and self._t > 0:
+            st, ob = self._last_state, self._last_out
+            cur = {'electrical_storage_soc': st[abi.CLS_B_SOC, i], 'cooling_storage_soc': st[abi.CLS_CS_SOC, i],
+                   'heating_storage_soc': st[abi.CLS_HS_SOC, i], 'dhw_storage_soc': st[abi.CLS_DS_SOC, i],
+                   'net_electricity_consumption': ob[abi.CLO_NET, i], 'cooling_electricity_consumption': ob[abi.CLO_C_COOL, i],
+                   'heating_electricity_consumption': ob[abi.CLO_C_HEAT, i], 'dhw_electricity_consumption': ob[abi.CLO_C_DHW, i]}
+            for j, k in enumerate(self._obs_names[i]):
+                if k in cur:
+                    row[j] = float(cur[k])
+        return row
+
+    @property
+    def observations(self) -> List[List[float]]:
+        per_b = [self._building_observations(i) for i in range(len(self.spec.buildings))]
+        if not self.central_agent:
+            return per_b
+        flat, seen = [], []
+        for i, (vals, names) in enumerate(zip(per_b, self._obs_names)):       # citylearn.py:462-480
+            for v, k in zip(vals, names):
+                if i == 0 or k not in self.shared_observations or k not in seen:
+                    flat.append(v)
+                if k in self.shared_observations and k not in seen:
+                    seen.append(k)
+        return [flat]
+
+    def _reward_observations(self, t: int, st: np.ndarray, ob: np.ndarray) -> List[Dict[str, float]]:
+        """`Building.observations(include_all=True)` at step t for host-side reward plugins (citylearn.py:1022)."""
+        out = []
+        tab = self._tables
+        for i, b in enumerate(self.spec.buildings):
+            d: Dict[str, float] = {}
+            for k, v in b.series.items():
+                if isinstance(v, np.ndarray):
+                    d[k] = v[tab.start + t]
+            ts = tab.ts[t, i]
+            d.update({
+                'solar_generation': abs(float(ts[abi.CLT_SOLAR])), 'power_outage': float(tab.outage[t, i]),
+                'cooling_storage_soc': float(st[abi.CLS_CS_SOC, i]), 'heating_storage_soc': float(st[abi.CLS_HS_SOC, i]),
+                'dhw_storage_soc': float(st[abi.CLS_DS_SOC, i]), 'electrical_storage_soc': float(st[abi.CLS_B_SOC, i]),
+                'cooling_demand': float(ob[abi.CLO_COOL_DEM, i]), 'net_electricity_consumption': float(ob[abi.CLO_NET, i]),
+                'cooling_electricity_consumption': float(ob[abi.CLO_C_COOL, i]),
+                'heating_electricity_consumption': float(ob[abi.CLO_C_HEAT, i]),
+                'dhw_electricity_consumption': float(ob[abi.CLO_C_DHW, i]),
+                'electrical_storage_electricity_consumption': float(ob[abi.CLO_B_EB, i]),
+                'cooling_device_efficiency': float(ts[abi.CLT_COP_COOL]), 'heating_device_efficiency': float(ts[abi.CLT_COP_HEAT]),
+                'dhw_device_efficiency': float(ts[abi.CLT_COP_DHW]),
+            })
+            out.append(d)
+        return out
+
+    # ---- evaluate --------------------------------------------------------------------------------------------
+    def evaluate(self, control_condition=None, baseline_condition=None, comfort_band: float = None):
+        """Cost functions normalised by the no-control baseline (citylearn.py:1136-1323).  Only the default
+        evaluation conditions are supported: control = with storage (and partial load) and PV, baseline = without
+        storage (and partial load) but with PV.  Returns a ``pandas.DataFrame[cost_function, value, name, level]``."""
+        if control_condition is not None or baseline_condition is not None:
+            raise NotImplementedError('only the default evaluation conditions are implemented')
+        from .kpi import evaluate_district
+        h = self._history_array
+        return evaluate_district(self.spec, self._tables, self._t, h('net'), h('base_net'), h('cost'), h('emission'),
+                                 h('expected'), h('served'), np.array(self._hist['d_net'], dtype=np.float64), comfort_band)
+
+    def close(self):
+        self._engine = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+def _stock_calculate(cls):
+    """`calculate` of the stock class a reward class was derived from (None for foreign classes): a subclass that
+    overrides `calculate` must take the host path."""
+    from . import reward_function as rf
+    for base in cls.__mro__:
+        if base.__module__ == rf.__name__:
+            return base.calculate if base is cls else None
+    return None

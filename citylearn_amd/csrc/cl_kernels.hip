@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                     load_action<VEC>(a_hd, a, B.a_hd, env0);
                 }
             }
-            float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC];
+            float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 cl::State S;
@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 s_soc[i] = S.soc; s_eff[i] = S.eff; s_deg[i] = S.degcap; s_cs[i] = S.cs; s_hs[i] = S.hs; s_ds[i] = S.ds;
                 o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem;
                 o_cc[i] = O.c_cool; o_ch[i] = O.c_heat; o_cw[i] = O.c_dhw; o_cn[i] = O.c_ns;
+                o_bn[i] = O.base_net; o_ex[i] = O.expected; o_sv[i] = O.served;
                 q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission; q_rw[i] += rw;
             }
             if (batt) {
@@ -233,6 +234,9 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 vstore<VEC>(a.out_bldg + CLO_C_HEAT * plane + off, o_ch);
                 vstore<VEC>(a.out_bldg + CLO_C_DHW * plane + off, o_cw);
                 vstore<VEC>(a.out_bldg + CLO_C_NSL * plane + off, o_cn);
+                vstore<VEC>(a.out_bldg + CLO_BASE_NET * plane + off, o_bn);
+                vstore<VEC>(a.out_bldg + CLO_EXPECTED * plane + off, o_ex);
+                vstore<VEC>(a.out_bldg + CLO_SERVED * plane + off, o_sv);
             }
         }
     }

@@ -692,7 +692,7 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
         obs_meta = {k: v['active'] for k, v in observations.items()}
         if 'minutes' in obs_meta and series['minutes'] is None:
             obs_meta.pop('minutes')
-        per_b = lambda v: v[index] if isinstance(v[0], list) else v
+        per_b = lambda v: v[index] if len(v) > 0 and isinstance(v[0], list) else v
         if kwargs.get('active_observations') is not None:
             act = per_b(kwargs['active_observations'])
             obs_meta = {k: k in act for k in obs_meta}

@@ -1,0 +1,101 @@
+"""`VectorCityLearnEnv`: E independent CityLearn districts stepped together on one GPU, tensors in / tensors out.
+
+This is the form the engine is designed for (one `cl_step_f32` launch advances every (env, building) unit); the
+list-based `CityLearnEnv` is the single-district compatibility surface.  All envs replay the same episode window
+of the schema; they differ by their actions (and therefore storage trajectories).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Mapping, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import abi
+from .engine import REWARD_KINDS, StepEngine
+from .reward_function import resolve as resolve_reward
+from .schema import DistrictSpec, load_district
+
+
+class VectorCityLearnEnv:
+    """Batched environment.
+
+    * ``actions``: float32 tensor ``[n_act_cols, n_envs]`` (coalesced layout) or ``[n_envs, n_act_cols]`` (policy
+      layout, read through strides); columns follow the reference's central-agent order (building-major).
+    * ``step`` returns ``(obs, reward, terminated, truncated, info)`` where ``reward`` is ``[n_envs]`` (central agent:
+      sum over buildings) or ``[n_bldg, n_envs]``; ``obs`` is a dict of device tensors: ``'exogenous'`` ``[n_exo]`` -- the
+      env-independent observation values of the next time step shared by all envs -- and the env-dependent planes
+      ``'electrical_storage_soc'`` ``[n_bldg, n_envs]``, ``'net_electricity_consumption'`` ``[n_bldg, n_envs]``, tank SoCs.
+    """
+
+    def __init__(self, schema: Union[str, Mapping[str, Any], DistrictSpec], n_envs: int, device: str = 'cuda:0',
+                 reference_quirks: bool = True, **kwargs: Any):
+        self.spec = schema if isinstance(schema, DistrictSpec) else load_district(schema, **kwargs)
+        self.n_envs = int(n_envs)
+        self.device = torch.device(device)
+        self.reference_quirks = reference_quirks
+        self.central_agent = self.spec.central_agent
+        rf_cls = resolve_reward(self.spec.reward_function.get('type'))
+        kind = getattr(rf_cls, 'device_kind', None)
+        if kind is None:
+            raise NotImplementedError(f'{rf_cls.__name__} has no fused device epilogue; use reward_function='
+                                      "'citylearn.reward_function.RewardFunction' | MARL | IndependentSACReward | SolarPenaltyReward")
+        self.reward_name = {v: k for k, v in REWARD_KINDS.items()}[kind]
+        self.reward_exponent = float((self.spec.reward_function.get('attributes') or {}).get('exponent') or 1.0)
+        self._episode = -1
+        low, high = self.spec.action_limits()
+        self.action_low = torch.from_numpy(low).to(self.device)
+        self.action_high = torch.from_numpy(high).to(self.device)
+        self.reset()
+
+    @property
+    def n_act_cols(self) -> int:
+        return self.engine.n_act_cols
+
+    @property
+    def n_bldg(self) -> int:
+        return self.engine.n_bldg
+
+    @property
+    def time_step(self) -> int:
+        return self._t
+
+    @property
+    def time_steps(self) -> int:
+        return self.engine.n_steps
+
+    @property
+    def terminated(self) -> bool:
+        return self._t == self.time_steps - 1
+
+    def reset(self, seed: Optional[int] = None) -> Tuple[Dict[str, torch.Tensor], dict]:
+        self._episode += 1
+        self.tables = self.spec.episode_tables(self._episode, seed, reward_exponent=self.reward_exponent)
+        self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
+                                 t0_quirk=self.reference_quirks)
+        self._t = 0
+        self._exo = self.engine.ts            # [T, B, CL_NF] on device: exogenous values per (t, building)
+        return self._obs(), {}
+
+    def _obs(self) -> Dict[str, torch.Tensor]:
+        e = self.engine
+        return {'exogenous': self._exo[min(self._t, e.n_steps - 1)],
+                'electrical_storage_soc': e.state[abi.CLS_B_SOC], 'cooling_storage_soc': e.state[abi.CLS_CS_SOC],
+                'heating_storage_soc': e.state[abi.CLS_HS_SOC], 'dhw_storage_soc': e.state[abi.CLS_DS_SOC],
+                'net_electricity_consumption': e.out_bldg[abi.CLO_NET]}
+
+    def step(self, actions: torch.Tensor):
+        if self.terminated:
+            raise RuntimeError('episode has terminated: call reset()')
+        e = self.engine
+        if actions.shape == (e.n_env, e.n_act_cols) and e.n_env != e.n_act_cols:
+            actions = actions.t()                       # strided view, no copy
+        e.step(actions, self._t)
+        self._t += 1
+        reward = e.district_reward if self.central_agent else e.reward_bldg
+        return self._obs(), reward, self.terminated, False, {}
+
+    def sample_actions(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """Uniform random actions inside the action space (the device analogue of `Agent.predict`, agents/base.py:188-209)."""
+        u = torch.rand((self.n_act_cols, self.n_envs), device=self.device, generator=generator)
+        return self.action_low[:, None] + u * (self.action_high - self.action_low)[:, None]

@@ -51,7 +51,7 @@ extern "C" {
 #define CL_NP  128   /* words per building in `params` */
 #define CL_NF   16   /* floats per (t, building) row in `ts` */
 #define CL_NS    6   /* state planes */
-#define CL_NO    8   /* per-building output planes */
+#define CL_NO   12   /* per-building output planes */
 #define CL_NQ    4   /* per-env (district) output planes */
 #define CL_NKB   8   /* per-building KPI accumulator planes */
 #define CL_NKE  24   /* per-env KPI accumulator planes */
@@ -157,7 +157,12 @@ enum cl_out {
     CLO_REWARD,       /* per-building reward (reward_function.py) */
     CLO_B_EB,         /* electrical_storage.energy_balance[t] */
     CLO_COOL_DEM,     /* delivered cooling: energy_from_cooling_device + |min(eb_cs,0)| (building.py:1435-1437) */
-    CLO_C_COOL, CLO_C_HEAT, CLO_C_DHW, CLO_C_NSL       /* device electricity_consumption[t] */
+    CLO_C_COOL, CLO_C_HEAT, CLO_C_DHW, CLO_C_NSL,      /* device electricity_consumption[t] */
+    CLO_BASE_NET,     /* baseline net of evaluate(): net_electricity_consumption_without_storage (building.py:345-366)
+                         or ..._and_partial_load for dynamics buildings (building.py:2877-2905) */
+    CLO_EXPECTED,     /* cooling + heating + dhw demand + non_shiftable_load (citylearn.py:1216) */
+    CLO_SERVED,       /* energy from devices + storages + energy_to_non_shiftable_load (citylearn.py:1217-1220) */
+    CLO_RESERVED
 };
 
 /* ---- district outputs (`out_env[plane][env]`) ---- */

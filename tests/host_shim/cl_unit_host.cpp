@@ -16,7 +16,7 @@ static void run(const uint32_t* params, const float* ts_row, int t, int quirk, i
     *reward = cl::unit_reward<FULL>(rkind, B, S, O.net);
     state6[0] = S.soc; state6[1] = S.eff; state6[2] = S.degcap; state6[3] = S.cs; state6[4] = S.hs; state6[5] = S.ds;
     out10[0] = O.net; out10[1] = O.cost; out10[2] = O.emission; out10[3] = O.eb; out10[4] = O.cool_dem;
-    out10[5] = O.c_cool; out10[6] = O.c_heat; out10[7] = O.c_dhw; out10[8] = O.c_ns; out10[9] = 0;
+    out10[5] = O.c_cool; out10[6] = O.c_heat; out10[7] = O.c_dhw; out10[8] = O.c_ns; out10[9] = O.base_net;
 }
 
 extern "C" void host_unit_step(const uint32_t* params, const float* ts_row, int t, int quirk, int rkind, int full,

@@ -1,0 +1,62 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol `include/citylearn_amd.h` declares;
+argument validation happens before any HIP call, so error codes are testable on CPU."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from citylearn_amd import _lib, abi
+
+
+@pytest.fixture(scope='module')
+def lib():
+    _lib.build()
+    return ctypes.CDLL(str(_lib.LIB_PATH))
+
+
+def test_exports_every_declared_symbol(lib):
+    assert abi.EXPORTED_SYMBOLS == ['cl_abi_version', 'cl_last_error', 'cl_philox_uniform', 'cl_reset_f32', 'cl_rollout_f32',
+                                    'cl_step_f32']
+    for s in abi.EXPORTED_SYMBOLS:
+        assert hasattr(lib, s), s
+    assert lib.cl_abi_version() == abi.CL_ABI_VERSION
+
+
+def test_header_constants_are_consistent():
+    assert abi.CLP_USED <= abi.CL_NP and abi.CLP_L_FIRST % 16 == 0 and abi.CLP_L_LAST - abi.CLP_L_FIRST < 32
+    assert abi.CLT_ICOP_DHW < abi.CL_NF and abi.CLO_RESERVED < abi.CL_NO and abi.CLQ_REWARD < abi.CL_NQ
+    assert ctypes.sizeof(_lib.Dims) == 32
+    assert abi.CLD_REWARD_MASK >> abi.CLD_REWARD_SHIFT >= abi.CLR_SOLAR_PENALTY
+
+
+def test_argument_validation_without_gpu(lib):
+    lib.cl_last_error.restype = ctypes.c_char_p
+    vp = ctypes.c_void_p
+    lib.cl_step_f32.argtypes = [ctypes.POINTER(_lib.Dims), vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp, vp, vp, vp,
+                                ctypes.c_int32, vp]
+    lib.cl_reset_f32.argtypes = [ctypes.POINTER(_lib.Dims), vp, vp, vp, vp, vp]
+    buf = np.zeros(64, dtype=np.float32)
+    p = buf.ctypes.data_as(vp)
+    assert lib.cl_step_f32(None, p, p, p, p, 4, 1, p, p, None, None, 0, None) == abi.CL_ENULL
+    d = _lib.Dims(6, 1, 10, 1, 0)
+    assert lib.cl_step_f32(ctypes.byref(d), p, p, p, p, 8, 1, p, p, None, None, 0, None) == abi.CL_EALIGN   # n_env % 4
+    assert b'multiple of 4' in lib.cl_last_error()
+    d = _lib.Dims(8, 1, 10, 1, 0)
+    assert lib.cl_step_f32(ctypes.byref(d), None, p, p, p, 8, 1, p, p, None, None, 0, None) == abi.CL_ENULL
+    assert lib.cl_step_f32(ctypes.byref(d), p, p, p, p, 8, 1, p, p, None, None, 10, None) == abi.CL_ERANGE   # t >= n_steps
+    assert lib.cl_step_f32(ctypes.byref(d), p, p, ctypes.c_void_p(buf.ctypes.data + 4), p, 8, 1, p, p, None, None, 0, None) == abi.CL_EALIGN
+    d = _lib.Dims(8, 1, 10, 1, 9 << abi.CLD_REWARD_SHIFT)
+    assert lib.cl_step_f32(ctypes.byref(d), p, p, p, p, 8, 1, p, p, None, None, 0, None) == abi.CL_EINVAL    # unknown reward kind
+    d = _lib.Dims(0, 1, 10, 1, 0)
+    assert lib.cl_reset_f32(ctypes.byref(d), p, p, None, None, None) == abi.CL_EINVAL
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from golden_util import golden
+    from citylearn_amd.engine import StepEngine
+    tab = golden('g2022_all').spec().episode_tables(0)
+    with pytest.raises(_lib.EngineUnavailable):
+        StepEngine(tab, 64)

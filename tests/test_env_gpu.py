@@ -1,0 +1,114 @@
+"""`CityLearnEnv` / `VectorCityLearnEnv` (the reference's reset/step/evaluate surface) on the GPU, against what the
+reference returned for the same schema and action sequence.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _actions(g, env, t):
+    a = [float(x) for x in g.ref['actions'][t]]
+    if env.central_agent:
+        return [a]
+    out, p = [], 0
+    for names in env.action_names:
+        out.append(a[p:p + len(names)]); p += len(names)
+    return out
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+def test_env_matches_reference_api_and_rewards(name):
+    from citylearn_amd.citylearn import CityLearnEnv
+    g = golden(name)
+    kw = {}
+    if g.facts['reward_type'] == 'ComfortReward':
+        kw['reward_function'] = 'citylearn.reward_function.SolarPenaltyReward'   # comfort needs the LSTM stage (next)
+    env = CityLearnEnv(g.schema_path, **kw)
+    assert env.observation_names == g.facts['observation_names']
+    assert env.action_names == g.facts['action_names']
+    assert env.time_steps == g.facts['time_steps']
+    lo = np.concatenate([s.low for s in env.action_space]); hi = np.concatenate([s.high for s in env.action_space])
+    assert np.array_equal(lo, g.ref['action_low']) and np.array_equal(hi, g.ref['action_high'])
+    obs, info = env.reset()
+    assert info == {} and [len(o) for o in obs] == [len(n) for n in env.observation_names]
+    K = 120
+    kind = 'SolarPenaltyReward' if kw else g.facts['reward_type']
+    for t in range(K):
+        obs, reward, terminated, truncated, info = env.step(_actions(g, env, t))
+        ref = g.ref['reward_' + kind][t]
+        ref = [ref.sum()] if env.central_agent else ref
+        np.testing.assert_allclose(reward, ref, rtol=1e-3, atol=1e-3)
+        assert not truncated and info == {} and terminated == (t == env.time_steps - 2)
+    np.testing.assert_allclose(env.net_electricity_consumption, g.ref['d_net'][:K], rtol=1e-3, atol=2e-3)
+    # reference semantics: the returned SoC / net observations are the untouched slots of step t+1
+    names = env.observation_names[0]
+    if 'electrical_storage_soc' in names:
+        assert obs[0][names.index('electrical_storage_soc')] == 0.0
+    frame = env.evaluate()
+    assert set(frame.columns) == {'cost_function', 'value', 'name', 'level'} and 'District' in set(frame['name'])
+    with pytest.raises(AssertionError):
+        env.step([[0.0]])                                          # wrong action count (citylearn.py:1073, 1088)
+
+
+def test_env_full_episode_kpis_and_termination():
+    from citylearn_amd.citylearn import CityLearnEnv
+    g = golden('g2023_p2')
+    env = CityLearnEnv(g.schema_path, reward_function='citylearn.reward_function.RewardFunction', observation_mode='current')
+    t = 0
+    while not env.terminated:
+        obs, r, term, trunc, _ = env.step(_actions(g, env, t)); t += 1
+    assert t == g.facts['steps'] == env.time_steps - 1 and len(env.episode_rewards) == 1
+    with pytest.raises(RuntimeError):
+        env.step(_actions(g, env, 0))
+    frame = env.evaluate()
+    got = {f'{r.level}|{r.name}|{r.cost_function}': r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
+    ref = dict(zip([str(x) for x in g.ref['kpi_names']], g.ref['kpi_values']))
+    n = 0
+    for k, v in ref.items():
+        fn = k.split('|')[-1]
+        if fn.startswith(('discomfort', 'one_minus_thermal')):
+            continue                                               # need the LSTM indoor temperature (next stage)
+        np.testing.assert_allclose(got[k], v, rtol=2e-3, atol=1e-4, err_msg=k)   # free-running fp32 episode
+        n += 1
+    assert n >= 20                                                 # incl. the two unserved-energy (outage) KPIs
+    obs2, _ = env.reset()
+    assert env.time_step == 0 and env.episode == 1
+
+
+def test_custom_reward_plugin_runs_on_host():
+    """A user subclass (the reference's examples/custom_reward_function.py pattern) overrides `calculate` and is
+    driven with per-building observation dicts built from the device outputs."""
+    from citylearn_amd.citylearn import CityLearnEnv
+    from citylearn_amd.reward_function import RewardFunction
+
+    class Mine(RewardFunction):
+        def calculate(self, observations):
+            return [-(o['net_electricity_consumption'] ** 2) * (1 + o['electrical_storage_soc']) for o in observations]
+
+    g = golden('g2022_all')
+    env = CityLearnEnv(g.schema_path, reward_function=Mine)
+    assert not env._fused_reward
+    _, r, *_ = env.step(_actions(g, env, 0))
+    net = g.ref['net'][0].astype(np.float64); soc = g.ref['soc'][0].astype(np.float64)
+    np.testing.assert_allclose(r, -(net ** 2) * (1 + soc), rtol=1e-3, atol=1e-3)
+
+
+def test_vector_env():
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden('g2022_all')
+    env = VectorCityLearnEnv(g.schema_path, n_envs=512)
+    obs, _ = env.reset()
+    assert obs['electrical_storage_soc'].shape == (17, 512)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    total = torch.zeros(512, device='cuda')
+    for t in range(50):
+        a = env.sample_actions(gen)
+        obs, reward, term, trunc, _ = env.step(a if t % 2 else a.t().contiguous())      # both layouts
+        assert reward.shape == (17, 512)
+        total += reward.sum(dim=0)
+    assert torch.isfinite(total).all() and (total < 0).all()
+    assert (obs['electrical_storage_soc'] >= 0).all() and (obs['electrical_storage_soc'] <= 1).all()
+    torch.testing.assert_close(env.engine.district_reward, reward.sum(dim=0), rtol=1e-5, atol=1e-4)

@@ -1,0 +1,193 @@
+"""Parity of the HIP step path (through the C-ABI) with the reference trajectories and the oracle.  GPU only.
+
+Tolerances (fp32 kernel vs the reference's float32-series / float64-scalar arithmetic):
+* teacher-forced (every step starts from the reference's own state of step t-1, which isolates the step function):
+  |got - ref| <= 1e-4 + 1e-4 |ref| on every quantity -- BASELINE.json's "1e-4 relative" bar;
+* free-running (the engine feeds back its own state for the whole fixture): 1e-3 + 1e-3 |ref|.  The battery map
+  soc_t = f(soc_t-1, a_t) is locally expansive when discharging from the steep part of the capacity-power curve
+  (DESIGN.md "Numerics"), so one-ulp differences grow for a few steps before a clamp resets them; the
+  double-precision C port of the oracle drifts the same way against the reference (tests/test_oracle_golden.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden
+from citylearn_amd import _lib, abi
+from citylearn_amd.engine import StepEngine
+
+pytestmark = pytest.mark.gpu
+
+STATE_KEYS = (('soc', abi.CLS_B_SOC), ('eff', abi.CLS_B_EFF), ('degcap', abi.CLS_B_DEGCAP), ('cs_soc', abi.CLS_CS_SOC),
+              ('hs_soc', abi.CLS_HS_SOC), ('ds_soc', abi.CLS_DS_SOC))
+DETAIL_KEYS = (('eb', abi.CLO_B_EB), ('cool_dem', abi.CLO_COOL_DEM), ('c_cool', abi.CLO_C_COOL), ('c_heat', abi.CLO_C_HEAT),
+               ('c_dhw', abi.CLO_C_DHW), ('c_ns', abi.CLO_C_NSL), ('base_net', abi.CLO_BASE_NET))
+REWARDS = ('RewardFunction', 'MARL', 'IndependentSACReward', 'SolarPenaltyReward')
+
+
+def _err(got, ref, atol, rtol):
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(np.asarray(got, dtype=np.float64) - ref) / (atol + rtol * np.abs(ref))))
+
+
+def _run(name, kind, vec, detail, teach, steps=None, E=64, atol=1e-4, rtol=1e-4):
+    g = golden(name)
+    tab = g.spec().episode_tables(0)
+    lib = _lib.load()
+    lib.cl_debug_set_vec(vec)
+    try:
+        eng = StepEngine(tab, E, reward=kind, detail=detail)
+        K = g.facts['steps'] if steps is None else min(steps, g.facts['steps'])
+        acts = torch.from_numpy(g.ref['actions']).cuda()
+        ref_state = {k: torch.from_numpy(g.ref[k]).cuda() for k, _ in STATE_KEYS}
+        worst = {}
+        for t in range(K):
+            if teach and t > 0:
+                for k, pl in STATE_KEYS:
+                    eng.state[pl] = ref_state[k][t - 1][:, None]
+            eng.step(acts[t][:, None].expand(-1, E).contiguous())
+            st, ob, oe = eng.state.cpu().numpy(), eng.out_bldg.cpu().numpy(), eng.out_env.cpu().numpy()
+            assert (st[:, :, :1] == st).all() and (ob[:2, :, :1] == ob[:2]).all(), 'envs with equal actions diverged'
+            pairs = {k: st[pl, :, 0] for k, pl in STATE_KEYS}
+            pairs['net'] = ob[abi.CLO_NET, :, 0]
+            if detail:
+                pairs.update({k: ob[pl, :, 0] for k, pl in DETAIL_KEYS})
+            for k, v in pairs.items():
+                worst[k] = max(worst.get(k, 0.0), _err(v, g.ref[k][t], atol, rtol))
+            rw = g.ref['reward_' + kind][t]
+            worst['reward'] = max(worst.get('reward', 0.0), _err(ob[abi.CLO_REWARD, :, 0], rw, atol, rtol))
+            worst['district_reward'] = max(worst.get('district_reward', 0.0), _err(oe[abi.CLQ_REWARD, 0], rw.sum(), atol, rtol * 2))
+            for k, q in (('d_net', abi.CLQ_NET), ('d_cost', abi.CLQ_COST), ('d_emission', abi.CLQ_EMISSION)):
+                worst[k] = max(worst.get(k, 0.0), _err(oe[q, 0], g.ref[k][t], atol * 4, rtol))
+        return worst, eng
+    finally:
+        lib.cl_debug_set_vec(0)
+
+
+@pytest.mark.parametrize('kind', REWARDS)
+@pytest.mark.parametrize('vec', [1, 2, 4])
+def test_lean_kernel_teacher_forced(kind, vec):
+    """2022 schema (17 buildings, battery + PV): the specialised lean kernel, every vector width, every fused reward."""
+    worst, eng = _run('g2022_all', kind, vec, detail=False, teach=True, steps=240 if vec > 1 or kind != 'RewardFunction' else None)
+    assert eng.lean
+    assert max(worst.values()) < 1.0, worst
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+@pytest.mark.parametrize('kind', REWARDS)
+def test_full_kernel_teacher_forced(name, kind):
+    """Heat pump / heater / tanks (2020), outage + partial-load cooling (2023), and the 2022 schema through the
+    general kernel, with the detail planes (energy balance, device consumption, baseline net)."""
+    steps = None if kind == 'RewardFunction' else 200
+    worst, _ = _run(name, kind, 1, detail=True, teach=True, steps=steps)
+    assert max(worst.values()) < 1.0, worst
+
+
+@pytest.mark.parametrize('name', ['g2020_cz1', 'g2023_p2'])
+def test_full_kernel_vec2(name):
+    worst, _ = _run(name, 'RewardFunction', 2, detail=False, teach=True, steps=150)
+    assert max(worst.values()) < 1.0, worst
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+def test_free_running_whole_fixture(name):
+    worst, _ = _run(name, 'RewardFunction', 1, detail=False, teach=False, atol=1e-3, rtol=1e-3)
+    assert max(worst.values()) < 1.0, worst
+
+
+def test_full_year_free_running_kpis():
+    """C1: 2022_phase_1, 5 buildings, the full 8759-step episode, free-running on the GPU; the cost KPIs of
+    `evaluate()` (sums over the year) match the reference within 1e-4 relative."""
+    from citylearn_amd.kpi import evaluate_district
+    g = golden('g2022_p1_year')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E, K = 4, g.facts['steps']
+    eng = StepEngine(tab, E, detail=True)
+    acts = torch.from_numpy(g.ref['actions']).cuda()
+    hist = {k: torch.zeros((K, eng.n_bldg), device='cuda') for k in ('net', 'base', 'exp', 'srv')}
+    d_net = torch.zeros(K, device='cuda')
+    for t in range(K):
+        eng.step(acts[t][:, None].expand(-1, E).contiguous())
+        hist['net'][t] = eng.out_bldg[abi.CLO_NET, :, 0]; hist['base'][t] = eng.out_bldg[abi.CLO_BASE_NET, :, 0]
+        hist['exp'][t] = eng.out_bldg[abi.CLO_EXPECTED, :, 0]; hist['srv'][t] = eng.out_bldg[abi.CLO_SERVED, :, 0]
+        d_net[t] = eng.out_env[abi.CLQ_NET, 0]
+    net = hist['net'].cpu().numpy()
+    assert _err(net, g.ref['net'][:K], 1e-3, 1e-3) < 1.0
+    cost = (net.astype(np.float64) * tab.ts[:K, :, abi.CLT_PRICE]).astype('float32')
+    em = np.maximum(0, net.astype(np.float64) * tab.ts[:K, :, abi.CLT_CARBON]).astype('float32')
+    frame = evaluate_district(spec, tab, K, net, hist['base'].cpu().numpy(), cost, em, hist['exp'].cpu().numpy(),
+                              hist['srv'].cpu().numpy(), d_net.cpu().numpy())
+    got = {f'{r.level}|{r.name}|{r.cost_function}': r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
+    ref = dict(zip([str(x) for x in g.ref['kpi_names']], g.ref['kpi_values']))
+    n = 0
+    for k, v in ref.items():
+        if k.split('|')[-1].startswith(('discomfort', 'one_minus_thermal')):
+            continue
+        np.testing.assert_allclose(got[k], v, rtol=1e-4, atol=1e-6, err_msg=k)
+        n += 1
+    assert n >= 29
+
+
+def test_batch_against_c_oracle_distinct_actions():
+    """Every env gets its own actions (incl. zeros and bounds); teacher-forced from the oracle's state each step;
+    also exercises the strided [n_env, n_act_cols] action layout and a batch that is not a multiple of the tile."""
+    from oracle.c_oracle import COracle, OS, OO
+    for name, kind, E in (('g2022_all', 'MARL', 260), ('g2023_p2', 'SolarPenaltyReward', 132), ('g2020_cz1', 'IndependentSACReward', 68)):
+        g = golden(name)
+        spec = g.spec()
+        tab = spec.episode_tables(0)
+        eng, ora = StepEngine(tab, E, reward=kind), COracle(spec, tab, E, reward=kind)
+        low, high = spec.action_limits()
+        rng = np.random.RandomState(5)
+        worst = 0.0
+        for t in range(40):
+            a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
+            a[:, 0] = 0.0
+            a[:, 1], a[:, 2] = low, high
+            for pl, key in ((abi.CLS_B_SOC, 'SOC'), (abi.CLS_B_EFF, 'EFF'), (abi.CLS_B_DEGCAP, 'DEGCAP'), (abi.CLS_CS_SOC, 'CS'),
+                            (abi.CLS_HS_SOC, 'HS'), (abi.CLS_DS_SOC, 'DS')):
+                eng.state[pl] = torch.from_numpy(ora.state[:, :, OS[key]].T.astype(np.float32)).cuda()
+            a_dev = torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t() if t % 2 else torch.from_numpy(a).cuda()
+            eng.step(a_dev, t)
+            out, oe = ora.step(a, t)
+            worst = max(worst, _err(eng.soc.cpu().numpy(), ora.state[:, :, OS['SOC']].T, 1e-4, 1e-4),
+                        _err(eng.net.cpu().numpy(), out[:, :, OO['NET']].T, 1e-4, 1e-4),
+                        _err(eng.reward_bldg.cpu().numpy(), out[:, :, OO['REWARD']].T, 1e-4, 2e-4),
+                        _err(eng.district_net.cpu().numpy(), oe[:, 0], 4e-4, 1e-4),
+                        _err(eng.district_reward.cpu().numpy(), oe[:, 3], 4e-4, 2e-4))
+        assert worst < 1.0, (name, worst)
+
+
+def test_results_are_reproducible_and_layout_independent():
+    """Same inputs -> bit-identical outputs run to run (fixed-order LDS reduction, no atomics), and the strided
+    action layout gives bit-identical results to the coalesced one."""
+    g = golden('g2022_all')
+    tab = g.spec().episode_tables(0)
+    E = 1024
+    gen = torch.Generator(device='cuda').manual_seed(0)
+    acts = [torch.rand((17, E), device='cuda', generator=gen) * 2 - 1 for _ in range(30)]
+    outs = []
+    for variant in range(3):
+        eng = StepEngine(tab, E)
+        for t, a in enumerate(acts):
+            eng.step(a.t().contiguous().t() if variant == 2 else a, t)
+        outs.append((eng.state.clone(), eng.out_bldg[:2].clone(), eng.out_env.clone()))
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert torch.equal(x, y)
+
+
+def test_errors_surface_as_exceptions():
+    g = golden('g2022_all')
+    tab = g.spec().episode_tables(0)
+    eng = StepEngine(tab, 64)
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros((3, 64), device='cuda'))
+    with pytest.raises(TypeError):
+        eng.step(torch.zeros((17, 64), device='cuda', dtype=torch.float64))
+    with pytest.raises(_lib.EngineError) as e:
+        eng.step(torch.zeros((17, 64), device='cuda'), t=10 ** 6)
+    assert e.value.code == abi.CL_ERANGE
+    with pytest.raises(ValueError):
+        StepEngine(tab, 62)

@@ -1,0 +1,130 @@
+"""Schema loader (citylearn_amd/schema.py) against facts recorded from the reference on the same mini datasets
+(tests/golden/*/reference.npz `facts`), plus error behaviour and a synthetic schema.  CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+from golden_util import golden
+from citylearn_amd import abi
+from citylearn_amd.schema import load_district
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+def test_loader_matches_reference_facts(name):
+    g = golden(name)
+    spec = g.spec()
+    f = g.facts
+    assert [b.name for b in spec.buildings] == f['building_names']
+    assert spec.central_agent == f['central_agent']
+    low, high = spec.action_limits()
+    assert np.array_equal(low, g.ref['action_low']) and np.array_equal(high, g.ref['action_high'])
+    names = [[k for b in spec.buildings for k in b.active_actions]] if spec.central_agent else [b.active_actions for b in spec.buildings]
+    assert names == f['action_names']
+    tab = spec.episode_tables(0)
+    assert tab.n_steps == f['time_steps'] and float(spec.buildings[0].time_step_ratio) == f['time_step_ratio']
+    assert np.array_equal(tab.outage, g.ref['outage'])          # same MT19937 draws as power_outage.py:131-169
+    for b, d in zip(spec.buildings, f['devices']):
+        es = d['electrical_storage']
+        # seeded defaults (md5 device seed + RandomState first draw) and explicit values alike
+        assert np.array_equal(b.electrical_storage.power_efficiency_curve, np.array(es['power_efficiency_curve']))
+        assert np.array_equal(b.electrical_storage.capacity_power_curve, np.array(es['capacity_power_curve']))
+        for k in ('capacity', 'nominal_power', 'efficiency', 'capacity_loss_coefficient', 'depth_of_discharge', 'initial_soc'):
+            assert float(getattr(b.electrical_storage, k)) == pytest.approx(es[k], rel=1e-12, abs=0), k
+        assert float(b.cooling_device.nominal_power) == pytest.approx(d['cooling_device']['nominal_power'], rel=1e-12)   # autosized in 2020
+        assert float(b.dhw_device.nominal_power) == pytest.approx(d['dhw_device']['nominal_power'], rel=1e-12)
+        assert float(b.cooling_storage.capacity) == pytest.approx(d['cooling_storage']['capacity'], rel=1e-12)
+        assert float(b.dhw_storage.capacity) == pytest.approx(d['dhw_storage']['capacity'], rel=1e-12)
+        assert float(b.pv_nominal_power) == pytest.approx(d['pv_nominal_power'], rel=1e-12)
+        assert b.heating_device.is_heat_pump == d['heating_device']['is_heat_pump']
+        assert b.dhw_device.is_heat_pump == d['dhw_device']['is_heat_pump']
+
+
+def test_packed_tables_layout():
+    g = golden('g2023_p2')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    B = len(spec.buildings)
+    assert tab.params.shape == (B, abi.CL_NP) and tab.params.dtype == np.uint32
+    assert tab.ts.shape == (tab.n_steps, B, abi.CL_NF) and tab.ts.dtype == np.float32
+    pi = tab.params.view(np.int32)
+    cols = sorted(int(c) for c in pi[:, abi.CLP_ACT_COOL_STO:abi.CLP_ACT_COH_DEV + 1].ravel() if c >= 0)
+    assert cols == list(range(spec.n_action_columns))               # one column per active (building, action)
+    flags = tab.params[:, abi.CLP_FLAGS]
+    assert all(f & abi.CLF_OUTAGE and f & abi.CLF_DYNAMICS and f & abi.CLF_BATTERY for f in flags)
+    assert np.array_equal(tab.params[:, abi.CLP_L_FLAGS], flags)
+    pf = tab.params_f32()
+    np.testing.assert_allclose(pf[:, abi.CLP_L_INV_CAP] * pf[:, abi.CLP_L_CAP], 1.0, rtol=1e-6)
+    np.testing.assert_allclose(tab.ts[:, :, abi.CLT_ICOP_COOL] * tab.ts[:, :, abi.CLT_COP_COOL], 1.0, rtol=1e-6)
+    assert (tab.ts[:, :, abi.CLT_SOLAR] <= 0).all() and (tab.ts[:, :, abi.CLT_COP_COOL] <= 20).all()
+    # 15 outage steps per building in this fixture
+    assert (tab.ts[:, :, abi.CLT_OUTAGE].sum(axis=0) == 15).all()
+
+
+def test_episode_splits_and_overrides():
+    g = golden('g2022_all')
+    spec = g.spec(episode_time_steps=240, buildings=['Building_1', 'Building_5'], central_agent=True,
+                  inactive_actions=[], simulation_end_time_step=719)
+    assert [b.name for b in spec.buildings] == ['Building_1', 'Building_5'] and spec.central_agent
+    assert spec.episode_splits() == [(0, 239), (240, 479), (480, 719)]
+    assert spec.episode_window(4) == (240, 479)
+    t = spec.episode_tables(1)
+    assert (t.start, t.end, t.n_steps) == (240, 479, 240)
+    rolling = g.spec(episode_time_steps=700, rolling_episode_split=True)
+    assert len(rolling.episode_splits()) == 21
+
+
+def test_error_behaviour(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        load_district('citylearn_challenge_2022_phase_1')            # dataset names need the network in the reference
+    g = golden('g2022_all')
+    schema = json.loads(open(g.schema_path).read())
+    schema['root_directory'] = str(g.dir / 'dataset')
+    schema['actions']['electric_vehicle_storage'] = {'active': True}
+    with pytest.raises(NotImplementedError):
+        load_district(schema)
+    schema['actions'].pop('electric_vehicle_storage')
+    schema['buildings']['Building_1']['electrical_storage']['autosize'] = True
+    with pytest.raises(NotImplementedError):
+        load_district(schema)
+
+
+def test_synthetic_schema(tmp_path):
+    """A hand-made 2-building district (no reference data involved): heater for space heating, sub-hourly control."""
+    import pandas as pd
+    n = 96
+    hours = (np.arange(n) // 4) % 24 + 1
+    minutes = (np.arange(n) % 4) * 15
+    rng = np.random.RandomState(3)
+    for k in (1, 2):
+        pd.DataFrame({'month': 1, 'hour': hours, 'minutes': minutes, 'day_type': 1, 'indoor_dry_bulb_temperature': 21.0,
+                      'non_shiftable_load': rng.rand(n), 'dhw_demand': rng.rand(n) * 0.2, 'cooling_demand': 0.0,
+                      'heating_demand': rng.rand(n), 'solar_generation': rng.rand(n) * 500}).to_csv(tmp_path / f'b{k}.csv', index=False)
+    w = {k: rng.rand(n) * 10 for k in ['outdoor_dry_bulb_temperature', 'outdoor_relative_humidity', 'diffuse_solar_irradiance', 'direct_solar_irradiance']
+         + [f'{v}_predicted_{i}' for v in ('outdoor_dry_bulb_temperature', 'outdoor_relative_humidity', 'diffuse_solar_irradiance', 'direct_solar_irradiance') for i in (1, 2, 3)]}
+    pd.DataFrame(w).to_csv(tmp_path / 'weather.csv', index=False)
+    bld = lambda f: {'include': True, 'energy_simulation': f, 'weather': 'weather.csv', 'carbon_intensity': None, 'pricing': None,
+                     'heating_device': {'type': 'citylearn.energy_model.ElectricHeater', 'autosize': True, 'attributes': {'efficiency': 0.9}},
+                     'dhw_device': {'type': 'citylearn.energy_model.ElectricHeater', 'autosize': True, 'attributes': {'efficiency': 0.95}},
+                     'heating_storage': {'type': 'citylearn.energy_model.StorageTank', 'autosize': True, 'autosize_attributes': {'safety_factor': 3.0},
+                                         'attributes': {'loss_coefficient': 0.01, 'efficiency': 0.9}},
+                     'electrical_storage': {'type': 'citylearn.energy_model.Battery', 'attributes': {'capacity': 5.0, 'nominal_power': 2.5}},
+                     'pv': {'type': 'citylearn.energy_model.PV', 'attributes': {'nominal_power': 3.0}}}
+    schema = {'random_seed': 1, 'root_directory': str(tmp_path), 'central_agent': False, 'simulation_start_time_step': 0,
+              'simulation_end_time_step': n - 1, 'seconds_per_time_step': 900,
+              'observations': {'hour': {'active': True, 'shared_in_central_agent': True}, 'electrical_storage_soc': {'active': True}},
+              'actions': {'heating_storage': {'active': True}, 'electrical_storage': {'active': True}},
+              'reward_function': {'type': 'citylearn.reward_function.MARL'},
+              'buildings': {'A': bld('b1.csv'), 'B': bld('b2.csv')}}
+    spec = load_district(schema)
+    a, b = spec.buildings
+    assert a.time_step_ratio == 1.0 and a.seconds_per_time_step == 900        # 15-minute data, 15-minute control
+    assert not a.heating_device.is_heat_pump and a.heating_device.nominal_power > 0
+    assert a.heating_storage.capacity == pytest.approx(3.0 * float(a.series['heating_demand'].max()))
+    # seeded battery defaults differ per building (md5 of the names) but are reproducible
+    again = load_district(schema)
+    assert np.array_equal(a.electrical_storage.capacity_power_curve, again.buildings[0].electrical_storage.capacity_power_curve)
+    assert not np.array_equal(a.electrical_storage.capacity_power_curve, b.electrical_storage.capacity_power_curve)
+    tab = spec.episode_tables(0)
+    assert tab.params_f32()[0, abi.CLP_DT_HOURS] == 0.25 and spec.n_action_columns == 4
+    assert tab.params[0, abi.CLP_FLAGS] & abi.CLF_HEAT_STO and not (tab.params[0, abi.CLP_FLAGS] & abi.CLF_HEAT_IS_HP)
