@@ -25,7 +25,9 @@ def test_env_matches_reference_api_and_rewards(name):
     g = golden(name)
     kw = {}
     if g.facts['reward_type'] == 'ComfortReward':
-        kw['reward_function'] = 'citylearn.reward_function.SolarPenaltyReward'   # comfort needs the LSTM stage (next)
+        # comfort needs the LSTM stage (next); the schema's reward attributes (band, exponents) are still handed to the
+        # override, exactly like the reference does (citylearn.py:2152) -- RewardFunction accepts **kwargs
+        kw['reward_function'] = 'citylearn.reward_function.RewardFunction'
     env = CityLearnEnv(g.schema_path, **kw)
     assert env.observation_names == g.facts['observation_names']
     assert env.action_names == g.facts['action_names']
@@ -35,7 +37,7 @@ def test_env_matches_reference_api_and_rewards(name):
     obs, info = env.reset()
     assert info == {} and [len(o) for o in obs] == [len(n) for n in env.observation_names]
     K = 120
-    kind = 'SolarPenaltyReward' if kw else g.facts['reward_type']
+    kind = 'RewardFunction' if kw else g.facts['reward_type']
     for t in range(K):
         obs, reward, terminated, truncated, info = env.step(_actions(g, env, t))
         ref = g.ref['reward_' + kind][t]
