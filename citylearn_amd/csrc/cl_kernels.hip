@@ -314,7 +314,7 @@ int cl_abi_version(void) { return CL_ABI_VERSION; }
 const char* cl_last_error(void) { return g_err; }
 
 void cl_debug_set_vec(int vec) { g_force_vec = vec; }
-void cl_debug_set_lean(int u, int nw) { (void)u; g_force_nw = nw; }
+void cl_debug_set_lean(int unused, int nw) { (void)unused; g_force_nw = nw; }
 
 int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, float* kpi_bldg, float* kpi_env,
                  void* stream) {

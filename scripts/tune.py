@@ -34,10 +34,11 @@ if __name__ == '__main__':
         acts = [(torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1) for _ in range(4)]
         bpu = eng.algorithmic_bytes_per_unit(); units = E * eng.n_bldg
         res = []
-        for vec in (1, 2, 4):
-            for nw in (16, 9, 6, 4, 3):
-                lib.cl_debug_set_vec(vec); lib.cl_debug_set_lean(1, nw)
-                us = measure(eng, acts)
-                res.append((us, vec, nw))
-                print(f'E={E} vec={vec} nw={nw}: {us:.2f} us/step  {units*bpu/us/1e3:.0f} GB/s', flush=True)
+        for pipe in (0, 1):
+            for vec in (1, 2, 4):
+                for nw in (16, 9, 6):
+                    lib.cl_debug_set_vec(vec); lib.cl_debug_set_lean(pipe, nw)
+                    us = measure(eng, acts)
+                    res.append((us, pipe, vec, nw))
+                    print(f'E={E} pipe={pipe} vec={vec} nw={nw}: {us:.2f} us/step  {units*bpu/us/1e3:.0f} GB/s', flush=True)
         print('best', min(res))
