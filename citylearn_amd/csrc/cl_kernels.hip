@@ -266,6 +266,12 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
         for (int k = 0; k < CL_NKE; ++k) kpi_env[(long long)k * n_env + i] = 0.0f;
 }
 
+}  // namespace
+
+#include "cl_rollout.h"
+
+namespace {
+
 int check_dims(const cl_dims* d) {
     if (!d) return fail(CL_ENULL, "dims is NULL");
     if (d->n_env <= 0 || d->n_bldg <= 0 || d->n_steps <= 0 || d->n_act_cols < 0)
@@ -385,15 +391,60 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
                    int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env, const float* act_low,
                    const float* act_high, uint64_t seed, float* out_bldg, float* out_env, float* ret_env,
                    float* kpi_bldg, float* kpi_env, int32_t t0, int32_t k_steps, void* stream) {
-    (void)dims; (void)params; (void)ts; (void)state; (void)actions; (void)act_stride_step; (void)act_stride_col;
-    (void)act_stride_env; (void)act_low; (void)act_high; (void)seed; (void)out_bldg; (void)out_env; (void)ret_env;
-    (void)kpi_bldg; (void)kpi_env; (void)t0; (void)k_steps; (void)stream;
-    return fail(CL_EINVAL, "cl_rollout_f32 is not implemented in this build");
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(params, "params")) return rc;
+    if (int rc = check_ptr(ts, "ts")) return rc;
+    if (int rc = check_ptr(state, "state")) return rc;
+    if (int rc = check_ptr(out_bldg, "out_bldg")) return rc;
+    if (int rc = check_ptr(out_env, "out_env")) return rc;
+    if (int rc = check_ptr(actions, "actions", false)) return rc;
+    if (int rc = check_ptr(ret_env, "ret_env", false)) return rc;
+    if (!actions && dims->n_act_cols > 0) {
+        if (!act_low || !act_high) return fail(CL_ENULL, "act_low / act_high are required for the on-device policy");
+    }
+    if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "CLD_KPI is not implemented in this build");
+    (void)kpi_bldg; (void)kpi_env;
+    if (k_steps < 0 || t0 < 0 || t0 + k_steps > dims->n_steps)
+        return fail(CL_ERANGE, "steps [%d, %d) outside [0, %d)", t0, t0 + k_steps, dims->n_steps);
+    if (dims->n_bldg > 32) return fail(CL_EINVAL, "cl_rollout_f32 supports n_bldg <= 32 (got %d)", dims->n_bldg);
+    if (actions && act_stride_env == 1 && ((act_stride_col % 4) != 0 || (act_stride_step % 4) != 0))
+        return fail(CL_EALIGN, "action strides must be multiples of 4 floats for the coalesced layout");
+
+    RolloutArgs r;
+    StepArgs& a = r.s;
+    a.params = params; a.ts = ts; a.state = state; a.actions = actions; a.out_bldg = out_bldg; a.out_env = out_env;
+    a.kpi_bldg = nullptr; a.kpi_env = nullptr;
+    a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
+    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
+    a.flags = dims->flags; a.t = t0;
+    r.act_stride_step = act_stride_step; r.act_low = act_low; r.act_high = act_high; r.ret_env = ret_env; r.seed = seed;
+    r.t0 = t0; r.k_steps = k_steps;
+    const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
+    const int mb = full ? 1 : (dims->n_bldg > 16 ? 2 : 1);
+    if (full && dims->n_bldg > 16) return fail(CL_EINVAL, "cl_rollout_f32 (thermal districts) supports n_bldg <= 16 (got %d)", dims->n_bldg);
+    a.nw = g_force_nw ? g_force_nw : (dims->n_bldg + mb - 1) / mb;
+    if (a.nw * mb < dims->n_bldg || a.nw > 16) return fail(CL_EINVAL, "bad nw %d", a.nw);
+    const int vec = g_force_vec ? g_force_vec : ((!full && (actions == nullptr || act_stride_env == 1) && dims->n_env >= 131072) ? 2 : 1);
+    const int tile = 64 * vec;
+    const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
+    const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
+    const dim3 block(64 * a.nw);
+    hipStream_t s = (hipStream_t)stream;
+    const int key = (full ? 100 : 0) + vec * 10 + mb;
+    switch (key) {
+    case 11: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 1>), dim3(grid), block, lds, s, r); break;
+    case 12: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2>), dim3(grid), block, lds, s, r); break;
+    case 21: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 1>), dim3(grid), block, lds, s, r); break;
+    case 22: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2>), dim3(grid), block, lds, s, r); break;
+    case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), dim3(grid), block, lds, s, r); break;
+    default: return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
+    }
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_kernel launch");
+    return CL_OK;
 }
 
 float cl_philox_uniform(uint64_t seed, uint32_t env, uint32_t col, uint32_t t) {
-    (void)seed; (void)env; (void)col; (void)t;
-    return 0.0f;
+    return cl::philox_u01(seed, env, col, t);
 }
 
 }  // extern "C"

@@ -1,0 +1,276 @@
+// cl_rollout.h -- mode B: K consecutive environment steps in ONE launch with the per-unit state held in VGPRs.
+// Included by cl_kernels.hip after the shared helpers (StepArgs, vload/vstore, district_reduce).
+//
+// What it replaces in the reference: K iterations of `Agent.learn`'s inner loop (agents/base.py:127-186) =
+// `Agent.predict` (uniform `action_space.sample()`, agents/base.py:188-209) + `CityLearnEnv.step`
+// (citylearn.py:978-1056), for every env of the batch.  Actions come either from an open-loop tensor
+// (k, column, env) or from an on-device policy: a = low + u * (high - low), u = Philox4x32-10(seed; env, column, t).
+//
+// HBM traffic per unit is (state read + write) / K plus the last step's outputs -- the kernel is VALU-bound, not
+// HBM-bound (mode B); the time-series rows of steps t0 .. t0+K-1 are scalar loads that hit in L2.
+#pragma once
+
+namespace cl {
+
+// Philox4x32-10 (Salmon et al., SC'11).  One block yields four 32-bit words; the policy stream is defined as
+//   u(seed; env, column, t) = word[t & 3] of Philox(counter = (env, column, t >> 2, 0), key = (seed lo, seed hi))
+// so a unit needs one block per four time steps.
+struct U4 { uint32_t w[4]; };
+
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline U4 philox_block(unsigned long long seed, uint32_t env, uint32_t col, uint32_t tq) {
+    uint32_t c0 = env, c1 = col, c2 = tq, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{{c0, c1, c2, c3}};
+}
+
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline float u01(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0f); }   // 24 random bits -> [0, 1)
+
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline float philox_u01(unsigned long long seed, uint32_t env, uint32_t col, uint32_t t) {
+    return u01(philox_block(seed, env, col, t >> 2).w[t & 3]);
+}
+
+}  // namespace cl
+
+#ifdef __HIPCC__
+namespace {
+
+struct RolloutArgs {
+    StepArgs s;                        // tables, state, (open-loop) actions, outputs, dims; s.t is unused
+    long long act_stride_step;
+    const float* __restrict__ act_low;
+    const float* __restrict__ act_high;
+    float* __restrict__ ret_env;       // [n_env] += sum over the K steps of the district reward (may be NULL)
+    unsigned long long seed;
+    int t0, k_steps;
+};
+
+// Electrical-storage action with the Philox block cached across four steps (wave-uniform refresh).
+template <int VEC>
+CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k);
+
+template <int VEC>
+CL_DEV void rollout_action(float (&dst)[VEC], const RolloutArgs& r, int col, int env0, int t, int k) {
+    if (col < 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dst[i] = 0.0f;
+        return;
+    }
+    if (r.s.actions) {
+        const float* p = r.s.actions + (long long)k * r.act_stride_step + (long long)col * r.s.act_stride_col;
+        if (r.s.act_stride_env == 1) vload<VEC>(dst, p + env0);
+        else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dst[i] = p[(long long)(env0 + i) * r.s.act_stride_env];
+        }
+    } else {
+        const float lo = r.act_low[col], span = r.act_high[col] - lo;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            dst[i] = fmaf(cl::philox_u01(r.seed, (uint32_t)(env0 + i), (uint32_t)col, (uint32_t)t), span, lo);
+    }
+}
+
+template <int VEC>
+CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k) {
+    if (col < 0 || r.s.actions) { rollout_action<VEC>(dst, r, col, env0, t, k); return; }
+    if (k == 0 || (t & 3) == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) cache[i] = cl::philox_block(r.seed, (uint32_t)(env0 + i), (uint32_t)col, (uint32_t)t >> 2);
+    }
+    const float lo = r.act_low[col], span = r.act_high[col] - lo;
+    const int sel = t & 3;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const uint32_t word = sel == 0 ? cache[i].w[0] : sel == 1 ? cache[i].w[1] : sel == 2 ? cache[i].w[2] : cache[i].w[3];
+        dst[i] = fmaf(cl::u01(word), span, lo);
+    }
+}
+
+// MB = buildings owned by one wave (wave w owns w, w + nw, ...): their State stays in registers for all K steps.
+template <int VEC, bool FULL, int MB>
+__global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
+    const StepArgs& a = r.s;
+    constexpr int TILE = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env0 = blockIdx.x * TILE + lane * VEC;
+    const bool live = env0 < a.n_env;
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    const bool quirk = a.flags & CLD_REF_T0_QUIRK;
+    const bool detail = a.flags & CLD_WRITE_DETAIL;
+
+    cl::Bp B[MB];
+    cl::State S[MB][VEC];
+    bool own[MB];
+    long long off[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const int b = w + m * a.nw;
+        own[m] = b < a.n_bldg;
+        const int bc = own[m] ? b : w;
+        off[m] = (long long)bc * a.n_env + env0;
+        cl::load_bp<FULL>(B[m], a.params + (long long)bc * CL_NP);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            S[m][i] = {0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            if (live && own[m]) {
+                const long long o = off[m] + i;
+                S[m][i].soc = a.state[CLS_B_SOC * plane + o];
+                S[m][i].eff = a.state[CLS_B_EFF * plane + o];
+                S[m][i].degcap = a.state[CLS_B_DEGCAP * plane + o];
+                if constexpr (FULL) {
+                    S[m][i].cs = a.state[CLS_CS_SOC * plane + o];
+                    S[m][i].hs = a.state[CLS_HS_SOC * plane + o];
+                    S[m][i].ds = a.state[CLS_DS_SOC * plane + o];
+                }
+            }
+        }
+    }
+    float ret[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ret[i] = 0.0f;
+    float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
+    cl::Out last[MB][VEC];
+    float last_rw[MB][VEC];
+    cl::U4 rnd[MB][VEC];
+
+    for (int k = 0; k < r.k_steps; ++k) {
+        const int t = r.t0 + k;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (!own[m]) continue;                                       // wave-uniform
+            const int b = w + m * a.nw;
+            cl::Row R;
+            cl::load_row<FULL>(R, a.ts + ((long long)t * a.n_bldg + b) * CL_NF, B[m].flags);
+            float a_es[VEC], a_cs[VEC], a_hs[VEC], a_ds[VEC], a_cd[VEC], a_hd[VEC];
+            rollout_action_cached<VEC>(a_es, rnd[m], r, B[m].a_es, env0, t, k);
+            if constexpr (FULL) {
+                rollout_action<VEC>(a_cs, r, B[m].a_cs, env0, t, k);
+                rollout_action<VEC>(a_hs, r, B[m].a_hs, env0, t, k);
+                rollout_action<VEC>(a_ds, r, B[m].a_ds, env0, t, k);
+                if (B[m].a_coh >= 0) {
+                    float c[VEC];
+                    rollout_action<VEC>(c, r, B[m].a_coh, env0, t, k);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) { a_cd[i] = fabsf(fminf(c[i], 0.0f)); a_hd[i] = fabsf(fmaxf(c[i], 0.0f)); }
+                } else {
+                    rollout_action<VEC>(a_cd, r, B[m].a_cd, env0, t, k);
+                    rollout_action<VEC>(a_hd, r, B[m].a_hd, env0, t, k);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                cl::Act act = {0.0f, 0.0f, 0.0f, a_es[i], 0.0f, 0.0f};
+                if constexpr (FULL) act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
+                cl::unit_step<FULL>(B[m], R, t, quirk, act, S[m][i], last[m][i]);
+                const float rw = cl::unit_reward<FULL>(rkind, B[m], S[m][i], last[m][i].net);
+                last_rw[m][i] = rw;
+                q_net[i] += last[m][i].net; q_cost[i] += last[m][i].cost; q_em[i] += last[m][i].emission; q_rw[i] += rw;
+            }
+        }
+        if (rkind == CLR_MARL) {
+            // the MARL reward couples the buildings through the district net of THIS step: one LDS exchange per step
+            vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, q_net);
+            __syncthreads();
+            float dnet[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dnet[i] = 0.0f;
+            for (int kk = 0; kk < a.nw; ++kk) {
+                float part[VEC];
+                vload<VEC>(part, lds + (size_t)kk * TILE + lane * VEC);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) dnet[i] += part[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (!own[m]) continue;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { last_rw[m][i] = cl::marl_reward(last[m][i].net, dnet[i]); ret[i] += last_rw[m][i]; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) ret[i] += q_rw[i];
+        }
+    }
+
+    // ---- write back: carried state, the last step's per-building outputs, district sums, episode-return partials ----
+    if (live) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (!own[m]) continue;
+            float v[VEC];
+#define CL_PUT(base, plane_id, expr)                                   \
+    _Pragma("unroll") for (int i = 0; i < VEC; ++i) v[i] = (expr);      \
+    vstore<VEC>(base + (plane_id) * plane + off[m], v);
+            if (B[m].flags & CLF_BATTERY) {
+                CL_PUT(a.state, CLS_B_SOC, S[m][i].soc) CL_PUT(a.state, CLS_B_EFF, S[m][i].eff) CL_PUT(a.state, CLS_B_DEGCAP, S[m][i].degcap)
+            }
+            if constexpr (FULL) {
+                if (B[m].flags & CLF_COOL_STO) { CL_PUT(a.state, CLS_CS_SOC, S[m][i].cs) }
+                if (B[m].flags & CLF_HEAT_STO) { CL_PUT(a.state, CLS_HS_SOC, S[m][i].hs) }
+                if (B[m].flags & CLF_DHW_STO) { CL_PUT(a.state, CLS_DS_SOC, S[m][i].ds) }
+            }
+            if (r.k_steps > 0) {
+                CL_PUT(a.out_bldg, CLO_NET, last[m][i].net)
+                CL_PUT(a.out_bldg, CLO_REWARD, last_rw[m][i])
+                if (FULL && detail) {
+                    CL_PUT(a.out_bldg, CLO_B_EB, last[m][i].eb) CL_PUT(a.out_bldg, CLO_COOL_DEM, last[m][i].cool_dem)
+                    CL_PUT(a.out_bldg, CLO_C_COOL, last[m][i].c_cool) CL_PUT(a.out_bldg, CLO_C_HEAT, last[m][i].c_heat)
+                    CL_PUT(a.out_bldg, CLO_C_DHW, last[m][i].c_dhw) CL_PUT(a.out_bldg, CLO_C_NSL, last[m][i].c_ns)
+                    CL_PUT(a.out_bldg, CLO_BASE_NET, last[m][i].base_net) CL_PUT(a.out_bldg, CLO_EXPECTED, last[m][i].expected)
+                    CL_PUT(a.out_bldg, CLO_SERVED, last[m][i].served)
+                }
+            }
+#undef CL_PUT
+        }
+    }
+    if (r.k_steps > 0) {
+        if (rkind == CLR_MARL) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                q_rw[i] = 0.0f;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) q_rw[i] += own[m] ? last_rw[m][i] : 0.0f;
+            }
+        }
+        // district sums of the last step (for MARL the reward plane / sum were finished above: pass kind DEFAULT)
+        district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind == CLR_MARL ? (int)CLR_DEFAULT : rkind, q_net, q_cost, q_em,
+                             q_rw, a.nw);
+    }
+    if (r.ret_env) {
+        __syncthreads();
+        vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, ret);
+        __syncthreads();
+        const int tile_env0 = blockIdx.x * TILE;
+        for (int e = threadIdx.x; e < TILE; e += blockDim.x) {
+            float s = 0.0f;
+            for (int kk = 0; kk < a.nw; ++kk) s += lds[(size_t)kk * TILE + e];
+            if (tile_env0 + e < a.n_env) r.ret_env[tile_env0 + e] += s;
+        }
+    }
+}
+
+}  // namespace
+#endif  // __HIPCC__

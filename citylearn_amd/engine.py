@@ -93,6 +93,36 @@ class StepEngine:
                 _ptr(self.out_bldg), _ptr(self.out_env), None, None, int(t), self._stream()))
         self.t = t + 1
 
+    def set_action_limits(self, low, high):
+        """Bounds of the on-device uniform random policy of :meth:`rollout` (``[n_act_cols]`` each)."""
+        self.act_low = torch.as_tensor(np.asarray(low, dtype=np.float32)).to(self.device).contiguous()
+        self.act_high = torch.as_tensor(np.asarray(high, dtype=np.float32)).to(self.device).contiguous()
+        assert self.act_low.numel() == self.n_act_cols == self.act_high.numel()
+
+    def rollout(self, k_steps: int, actions: Optional[torch.Tensor] = None, seed: int = 0,
+                ret_env: Optional[torch.Tensor] = None, t0: Optional[int] = None):
+        """Fused K-step rollout in one launch (`cl_rollout_f32`): state stays in registers between steps.
+
+        ``actions``: open-loop float32 tensor ``[k_steps, n_act_cols, n_env]`` (any strides), or ``None`` for the
+        on-device policy ``a = low + u (high - low)``, ``u = Philox4x32-10(seed; env, column, t)``.
+        ``ret_env`` (``[n_env]``, optional) accumulates the district reward summed over the K steps."""
+        t0 = self.t if t0 is None else t0
+        st = (0, 0, 0)
+        if actions is not None:
+            if actions.dtype != torch.float32 or actions.device != self.device:
+                raise TypeError('actions must be a float32 tensor on the engine device')
+            if tuple(actions.shape) != (k_steps, self.n_act_cols, self.n_env):
+                raise ValueError(f'actions shape {tuple(actions.shape)} != {(k_steps, self.n_act_cols, self.n_env)}')
+            st = actions.stride()
+        elif getattr(self, 'act_low', None) is None:
+            raise ValueError('call set_action_limits(low, high) before using the on-device policy')
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cl_rollout_f32(
+                ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
+                _ptr(getattr(self, 'act_low', None)), _ptr(getattr(self, 'act_high', None)), int(seed) & (2 ** 64 - 1),
+                _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env), None, None, int(t0), int(k_steps), self._stream()))
+        self.t = t0 + k_steps
+
     # convenient views ------------------------------------------------------------------------------------
     @property
     def soc(self) -> torch.Tensor:

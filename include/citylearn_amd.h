@@ -216,8 +216,9 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
                 float* out_bldg, float* out_env, float* kpi_bldg, float* kpi_env, int32_t t, void* stream);
 
 /* Fused rollout: steps t0 .. t0+k_steps-1 in one launch with the per-unit state held in registers.
- * actions == NULL: on-device uniform random policy, a = low + u*(high-low) with u from Philox4x32-10 keyed by
- * (seed, env, action column, t) -- the device analogue of Agent.predict's action_space.sample()
+ * actions == NULL: on-device uniform random policy, a = low + u*(high-low) with
+ *   u(seed; env, column, t) = word[t & 3] of Philox4x32-10(counter = (env, column, t >> 2, 0), key = seed)  (24 bits)
+ * -- the device analogue of Agent.predict's action_space.sample()
  * (agents/base.py:188-209); `act_low/act_high` are [n_act_cols].
  * actions != NULL: open-loop action tensor, element (k, col, env) at
  * actions[k*act_stride_step + col*act_stride_col + env*act_stride_env].

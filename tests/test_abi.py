@@ -60,3 +60,12 @@ def test_engine_refuses_to_run_without_gpu():
     tab = golden('g2022_all').spec().episode_tables(0)
     with pytest.raises(_lib.EngineUnavailable):
         StepEngine(tab, 64)
+
+
+def test_philox_known_answer(lib):
+    """Philox4x32-10 known-answer vector of Random123 (counter 0, key 0 -> first word 0x6627e8d5)."""
+    lib.cl_philox_uniform.restype = ctypes.c_float
+    lib.cl_philox_uniform.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    assert lib.cl_philox_uniform(0, 0, 0, 0) == np.float32((0x6627e8d5 >> 8) / 16777216.0)
+    u = np.array([lib.cl_philox_uniform(7, e, 3, 11) for e in range(4096)])
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02

@@ -1,0 +1,82 @@
+"""Fused K-step rollout (`cl_rollout_f32`, mode B) against K single steps (`cl_step_f32`) and the Philox policy
+against its host-callable definition.  GPU only (the Philox host function is also checked on CPU in test_abi)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden
+from citylearn_amd import _lib, abi
+from citylearn_amd.engine import StepEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=2e-6):
+    torch.testing.assert_close(a, b, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('name,kind,E', [('g2022_all', 'RewardFunction', 512), ('g2022_all', 'MARL', 256),
+                                         ('g2023_p2', 'SolarPenaltyReward', 192), ('g2020_cz1', 'IndependentSACReward', 128)])
+def test_open_loop_rollout_equals_single_steps(name, kind, E):
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    K = 24
+    low, high = spec.action_limits()
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+    acts = lo[None, :, None] + torch.rand((K, len(low), E), device='cuda', generator=gen) * (hi - lo)[None, :, None]
+    a, b = StepEngine(tab, E, reward=kind), StepEngine(tab, E, reward=kind)
+    ret_ref = torch.zeros(E, device='cuda')
+    for k in range(K):
+        a.step(acts[k])
+        ret_ref += a.district_reward
+    ret = torch.zeros(E, device='cuda')
+    b.rollout(K, actions=acts, ret_env=ret)
+    _close(b.state, a.state)
+    _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
+    _close(b.out_env, a.out_env, 1e-4)
+    torch.testing.assert_close(ret, ret_ref, rtol=1e-5, atol=1e-3)
+    assert b.t == a.t == K
+    # continue from the rolled-out state: a second rollout of 12 steps from t = 24
+    more = acts[:12].contiguous()
+    for k in range(12):
+        a.step(more[k])
+    b.rollout(12, actions=more)
+    _close(b.state, a.state)
+
+
+def test_on_device_philox_policy_matches_host_definition():
+    g = golden('g2022_all')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E, K, seed = 128, 6, 5
+    lib = _lib.load()
+    low, high = spec.action_limits()
+    u = np.array([[[lib.cl_philox_uniform(seed, e, c, t) for e in range(E)] for c in range(len(low))] for t in range(K)], dtype=np.float32)
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02 and len(np.unique(u)) > 0.99 * u.size
+    host_actions = torch.from_numpy((low[None, :, None] + u * (high - low)[None, :, None]).astype(np.float32)).cuda()
+    a, b = StepEngine(tab, E), StepEngine(tab, E)
+    b.set_action_limits(low, high)
+    ret_a, ret_b = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
+    a.rollout(K, actions=host_actions, ret_env=ret_a)
+    b.rollout(K, seed=seed, ret_env=ret_b)
+    _close(b.state, a.state)
+    torch.testing.assert_close(ret_b, ret_a, rtol=1e-5, atol=1e-4)
+    c = StepEngine(tab, E)
+    c.set_action_limits(low, high)
+    c.rollout(K, seed=seed + 1)
+    assert not torch.equal(c.state, b.state)                      # a different seed is a different policy draw
+
+
+def test_rollout_errors():
+    g = golden('g2022_all')
+    tab = g.spec().episode_tables(0)
+    eng = StepEngine(tab, 64)
+    with pytest.raises(ValueError):
+        eng.rollout(4)                                            # on-device policy without action limits
+    with pytest.raises(_lib.EngineError) as e:
+        eng.rollout(10 ** 6, actions=None, seed=1) if eng.set_action_limits(*g.spec().action_limits()) is None else None
+    assert e.value.code == abi.CL_ERANGE
