@@ -43,6 +43,8 @@ struct StepArgs {
     uint32_t flags;
     int t;
     int nw;        // waves per workgroup == building lanes
+    int b_chunk;   // buildings per workgroup row (gridDim.y = n_chunks rows); == n_bldg when the grid is 1-D
+    int n_chunks;
 };
 
 template <int VEC> struct Vec;
@@ -105,6 +107,18 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
     vstore<VEC>(mine + 3 * TILE, q_rw);
     __syncthreads();
     const int tile_env0 = blockIdx.x * TILE;
+    if (a.n_chunks > 1) {
+        // large districts: this workgroup only saw buildings [y*b_chunk, (y+1)*b_chunk).  Its partial sums go to the
+        // scratch rows of out_bldg's reserved plane; cl_finish_kernel adds the chunks in order (deterministic).
+        float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
+        for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
+            const int q = i / TILE, e = i - q * TILE;
+            float s = 0.0f;
+            for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
+            if (tile_env0 + e < a.n_env) scratch[((long long)blockIdx.y * NQ + q) * a.n_env + tile_env0 + e] = s;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
         const int q = i / TILE, e = i - q * TILE;
         float s = 0.0f;
@@ -160,7 +174,10 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
 
-    for (int b = w; b < a.n_bldg; b += a.nw) {
+    const int b_lo = blockIdx.y * a.b_chunk;
+    const int b_hi = min(a.n_bldg, b_lo + a.b_chunk);
+    const bool marl_partial = rkind == CLR_MARL && a.n_chunks > 1;
+    for (int b = b_lo + w; b < b_hi; b += a.nw) {
         cl::Bp B;
         cl::load_bp<FULL>(B, a.params + (long long)b * CL_NP);
         cl::Row R;
@@ -213,7 +230,9 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem;
                 o_cc[i] = O.c_cool; o_ch[i] = O.c_heat; o_cw[i] = O.c_dhw; o_cn[i] = O.c_ns;
                 o_bn[i] = O.base_net; o_ex[i] = O.expected; o_sv[i] = O.served;
-                q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission; q_rw[i] += rw;
+                // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)
+                q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
+                q_rw[i] += marl_partial ? cl::marl_reward(O.net, 1.0f) : rw;
             }
             if (batt) {
                 vstore<VEC>(a.state + CLS_B_SOC * plane + off, s_soc);
@@ -242,6 +261,34 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     }
 
     district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+}
+
+// Second pass for building-chunked launches: add the per-chunk partial district sums in chunk order.
+__global__ void cl_finish_kernel(const StepArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n_env) return;
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
+    const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    float s[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s[q] = 0.0f;
+    for (int c = 0; c < a.n_chunks; ++c) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s[q] += scratch[((long long)c * NQ + q) * a.n_env + e];
+    }
+    if (rkind == CLR_MARL) s[CLQ_REWARD] *= fmaxf(0.0f, s[CLQ_NET]);     // partials carried sign(-net) * 0.01 * net^2
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a.out_env[(long long)q * a.n_env + e] = s[q];
+}
+
+// Third pass, MARL only: per-building rewards need the finished district net.
+__global__ void cl_marl_reward_kernel(const StepArgs a) {
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const int e = (int)(i % a.n_env);
+    a.out_bldg[CLO_REWARD * plane + i] = cl::marl_reward(a.out_bldg[CLO_NET * plane + i], a.out_env[(long long)CLQ_NET * a.n_env + e]);
 }
 
 __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __restrict__ state,
@@ -310,6 +357,7 @@ int pick_vec(int n_env, int n_bldg, bool unit_stride) {
 
 int g_force_vec = 0;   // test / tuning hooks (cl_debug_set_vec / cl_debug_set_lean)
 int g_force_nw = 0;
+int g_no_chunks = 0;
 
 }  // namespace
 
@@ -320,7 +368,7 @@ int cl_abi_version(void) { return CL_ABI_VERSION; }
 const char* cl_last_error(void) { return g_err; }
 
 void cl_debug_set_vec(int vec) { g_force_vec = vec; }
-void cl_debug_set_lean(int unused, int nw) { (void)unused; g_force_nw = nw; }
+void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks; g_force_nw = nw; }
 
 int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, float* kpi_bldg, float* kpi_env,
                  void* stream) {
@@ -364,23 +412,42 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
     a.nw = g_force_nw ? g_force_nw : pick_nw(dims->n_bldg, 1);
     const int vec = g_force_vec ? g_force_vec : (full ? 1 : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1));
     const int tile = 64 * vec;
-    const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
+    const unsigned grid_x = (unsigned)((dims->n_env + tile - 1) / tile);
+    // Large districts (e.g. 1024 buildings x 1024 envs per GPU): a 1-D grid over env tiles would leave most CUs idle, so
+    // the buildings are cut into chunks along gridDim.y and the district sums are finished by a second tiny kernel.
+    a.b_chunk = dims->n_bldg; a.n_chunks = 1;
+    if (dims->n_bldg > 32 && grid_x < 2048 && !g_no_chunks) {
+        long long r = ((long long)dims->n_bldg * grid_x) / (16ll * 2048);
+        if (r < 1) r = 1;
+        a.b_chunk = (int)(16 * r);
+        a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
+        if (a.n_chunks == 1) a.b_chunk = dims->n_bldg;
+        else a.nw = 16;
+    }
+    const dim3 grid(grid_x, a.n_chunks);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
     if (full) {
         switch (vec) {
-        case 1: hipLaunchKernelGGL((cl_step_kernel<1, true>), dim3(grid), block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL((cl_step_kernel<2, true>), dim3(grid), block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL((cl_step_kernel<4, true>), dim3(grid), block, lds, s, a); break;
+        case 1: hipLaunchKernelGGL((cl_step_kernel<1, true>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((cl_step_kernel<2, true>), grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((cl_step_kernel<4, true>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else {
         switch (vec) {
-        case 1: hipLaunchKernelGGL((cl_step_kernel<1, false>), dim3(grid), block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL((cl_step_kernel<2, false>), dim3(grid), block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL((cl_step_kernel<4, false>), dim3(grid), block, lds, s, a); break;
+        case 1: hipLaunchKernelGGL((cl_step_kernel<1, false>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((cl_step_kernel<2, false>), grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((cl_step_kernel<4, false>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
+        }
+    }
+    if (a.n_chunks > 1) {
+        hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 255) / 256), dim3(256), 0, s, a);
+        if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL) {
+            const long long n = (long long)dims->n_env * dims->n_bldg;
+            hipLaunchKernelGGL(cl_marl_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
         }
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");
@@ -416,7 +483,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     a.kpi_bldg = nullptr; a.kpi_env = nullptr;
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
-    a.flags = dims->flags; a.t = t0;
+    a.flags = dims->flags; a.t = t0; a.b_chunk = dims->n_bldg; a.n_chunks = 1;
     r.act_stride_step = act_stride_step; r.act_low = act_low; r.act_high = act_high; r.ret_env = ret_env; r.seed = seed;
     r.t0 = t0; r.k_steps = k_steps;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);

@@ -191,3 +191,50 @@ def test_errors_surface_as_exceptions():
     assert e.value.code == abi.CL_ERANGE
     with pytest.raises(ValueError):
         StepEngine(tab, 62)
+
+
+@pytest.mark.parametrize('fixture,kind,B', [('g2020_cz1', 'IndependentSACReward', 80), ('g2022_all', 'MARL', 100),
+                                            ('g2023_p2', 'RewardFunction', 48)])
+def test_large_district_building_chunked_grid(fixture, kind, B):
+    """Synthetic large districts (tiled + jittered buildings): the building axis is cut into gridDim.y chunks and the
+    district sums are finished by a second kernel.  Checked against the C oracle (teacher-forced) and against the
+    single-chunk launch of the same kernel."""
+    import ctypes
+    from citylearn_amd.synthetic import tile_district
+    from oracle.c_oracle import COracle, OS, OO
+    g = golden(fixture)
+    spec = tile_district(g.spec(), B)
+    tab = spec.episode_tables(0)
+    E = 192
+    lib = _lib.load()
+    lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
+    eng, ref1 = StepEngine(tab, E, reward=kind), StepEngine(tab, E, reward=kind)
+    ora = COracle(spec, tab, E, reward=kind)
+    low, high = spec.action_limits()
+    rng = np.random.RandomState(8)
+    worst = 0.0
+    try:
+        for t in range(12):
+            a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
+            for pl, key in ((abi.CLS_B_SOC, 'SOC'), (abi.CLS_B_EFF, 'EFF'), (abi.CLS_B_DEGCAP, 'DEGCAP'), (abi.CLS_CS_SOC, 'CS'),
+                            (abi.CLS_HS_SOC, 'HS'), (abi.CLS_DS_SOC, 'DS')):
+                st = torch.from_numpy(ora.state[:, :, OS[key]].T.astype(np.float32)).cuda()
+                eng.state[pl] = st
+                ref1.state[pl] = st
+            a_dev = torch.from_numpy(a).cuda()
+            lib.cl_debug_set_lean(0, 0)
+            eng.step(a_dev, t)                                          # chunked (B > 32, few env tiles)
+            lib.cl_debug_set_lean(1, 0)
+            ref1.step(a_dev, t)                                         # one workgroup row per env tile
+            out, oe = ora.step(a, t)
+            worst = max(worst, _err(eng.soc.cpu().numpy(), ora.state[:, :, OS['SOC']].T, 1e-4, 1e-4),
+                        _err(eng.net.cpu().numpy(), out[:, :, OO['NET']].T, 1e-4, 1e-4),
+                        _err(eng.reward_bldg.cpu().numpy(), out[:, :, OO['REWARD']].T, 1e-3, 2e-4),
+                        _err(eng.district_net.cpu().numpy(), oe[:, 0], 1e-2, 1e-4),
+                        _err(eng.district_reward.cpu().numpy(), oe[:, 3], 1e-2, 2e-4))
+            assert torch.equal(eng.state, ref1.state) and torch.equal(eng.net, ref1.net)
+            torch.testing.assert_close(eng.out_env, ref1.out_env, rtol=1e-5, atol=1e-3)
+            torch.testing.assert_close(eng.reward_bldg, ref1.reward_bldg, rtol=1e-5, atol=1e-4)
+    finally:
+        lib.cl_debug_set_lean(0, 0)
+    assert worst < 1.0, worst
