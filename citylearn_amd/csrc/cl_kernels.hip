@@ -157,7 +157,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
     }
 }
 
-template <int VEC, bool FULL>
+template <int VEC, bool FULL, bool DETAIL>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     const long long plane = (long long)a.n_bldg * a.n_env;
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     const bool quirk = a.flags & CLD_REF_T0_QUIRK;
-    const bool detail = a.flags & CLD_WRITE_DETAIL;
+    constexpr bool detail = DETAIL;
 
     float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
 #pragma unroll
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
             }
             vstore<VEC>(a.out_bldg + CLO_NET * plane + off, o_net);
             if (rkind != CLR_MARL) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
-            if (FULL && detail) {
+            if constexpr (FULL && DETAIL) {
                 vstore<VEC>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
                 vstore<VEC>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
                 vstore<VEC>(a.out_bldg + CLO_C_COOL * plane + off, o_cc);
@@ -263,23 +263,43 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
 }
 
-// Second pass for building-chunked launches: add the per-chunk partial district sums in chunk order.
-__global__ void cl_finish_kernel(const StepArgs a) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= a.n_env) return;
+// Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x 16
+// waves; wave w adds chunks w, w+16, ... (independent loads, one round trip), then the 16 wave partials are summed in
+// a fixed order through LDS -- deterministic, and ~10x faster than one thread walking all chunks.
+__global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a) {
+    __shared__ float part[16][NQ][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     const long long plane = (long long)a.n_bldg * a.n_env;
     const float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     float s[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) s[q] = 0.0f;
-    for (int c = 0; c < a.n_chunks; ++c) {
+    if (e < a.n_env) {
+#pragma unroll 4
+        for (int c = w; c < a.n_chunks; c += 16) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s[q] += scratch[((long long)c * NQ + q) * a.n_env + e];
+            for (int q = 0; q < NQ; ++q) s[q] += scratch[((long long)c * NQ + q) * a.n_env + e];
+        }
     }
-    if (rkind == CLR_MARL) s[CLQ_REWARD] *= fmaxf(0.0f, s[CLQ_NET]);     // partials carried sign(-net) * 0.01 * net^2
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) a.out_env[(long long)q * a.n_env + e] = s[q];
+    for (int q = 0; q < NQ; ++q) part[w][q][lane] = s[q];
+    __syncthreads();
+    if (threadIdx.x < NQ * 64) {
+        const int q = threadIdx.x >> 6;
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][q][lane];
+        part[0][q][lane] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ * 64 && e < a.n_env) {
+        const int q = threadIdx.x >> 6;
+        float t = part[0][q][lane];
+        if (rkind == CLR_MARL && q == CLQ_REWARD) t *= fmaxf(0.0f, part[0][CLQ_NET][lane]);   // partials carried sign(-net)*0.01*net^2
+        a.out_env[(long long)q * a.n_env + e] = t;
+    }
 }
 
 // Third pass, MARL only: per-building rewards need the finished district net.
@@ -410,7 +430,15 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
     a.flags = dims->flags; a.t = t;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
     a.nw = g_force_nw ? g_force_nw : pick_nw(dims->n_bldg, 1);
-    const int vec = g_force_vec ? g_force_vec : (full ? 1 : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1));
+    // general kernel: two buildings per wave measured fastest for the 6..16-building thermal schemas (fewer, longer waves)
+    if (!g_force_nw && full && dims->n_bldg >= 6 && dims->n_bldg <= 16) a.nw = (dims->n_bldg + 1) / 2;
+    const bool will_chunk = dims->n_bldg > 32 && !g_no_chunks;
+    int vec = full ? 1 : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1);
+    if (will_chunk && act_stride_env == 1) {               // few envs, many buildings: width from the unit count
+        const long long units = (long long)dims->n_env * dims->n_bldg;
+        vec = full ? (units >= (1ll << 19) && dims->n_env >= 256 ? 2 : 1) : (units >= (1ll << 19) && dims->n_env >= 512 ? 4 : 1);
+    }
+    if (g_force_vec) vec = g_force_vec;
     const int tile = 64 * vec;
     const unsigned grid_x = (unsigned)((dims->n_env + tile - 1) / tile);
     // Large districts (e.g. 1024 buildings x 1024 envs per GPU): a 1-D grid over env tiles would leave most CUs idle, so
@@ -428,23 +456,30 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
-    if (full) {
+    const bool det = dims->flags & CLD_WRITE_DETAIL;
+    if (full && det) {
         switch (vec) {
-        case 1: hipLaunchKernelGGL((cl_step_kernel<1, true>), grid, block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL((cl_step_kernel<2, true>), grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL((cl_step_kernel<4, true>), grid, block, lds, s, a); break;
+        case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, true>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, true>), grid, block, lds, s, a); break;
+        default: return fail(CL_EINVAL, "bad vec %d", vec);
+        }
+    } else if (full) {
+        switch (vec) {
+        case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, false>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, false>), grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((cl_step_kernel<4, true, false>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else {
         switch (vec) {
-        case 1: hipLaunchKernelGGL((cl_step_kernel<1, false>), grid, block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL((cl_step_kernel<2, false>), grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL((cl_step_kernel<4, false>), grid, block, lds, s, a); break;
+        case 1: hipLaunchKernelGGL((cl_step_kernel<1, false, false>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((cl_step_kernel<2, false, false>), grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((cl_step_kernel<4, false, false>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     }
     if (a.n_chunks > 1) {
-        hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 255) / 256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
         if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL) {
             const long long n = (long long)dims->n_env * dims->n_bldg;
             hipLaunchKernelGGL(cl_marl_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);

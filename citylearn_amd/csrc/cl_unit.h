@@ -50,29 +50,29 @@ CL_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 namespace cl {
 
-// Per-building parameters, wave-uniform (SGPRs).
-struct Bp {
-    // ---- lean block (battery + reward) ----
-    uint32_t flags;
-    int a_es;
+// Per-building parameters, wave-uniform (SGPRs).  They are loaded in groups right where they are used (each group
+// sits in its own basic block behind a wave-uniform flag test) so that the general kernel never holds all ~90
+// parameter words at once: SGPR pressure, not arithmetic, was what limited its occupancy.
+struct BattP {      // battery block of the CLP_L_* words
     float r, pdt, pow, cap, capl, inv_cap, inv_pow, omd, degk;
     float cpc_x1, cpc_a0, cpc_b0, cpc_a1, cpc_b1;
     float pec_x1, pec_x2, pec_x3, pec_a0, pec_b0, pec_a1, pec_b1, pec_a2, pec_b2, pec_a3, pec_b3;
-    float rw_exponent;
-    // ---- full block ----
-    float dt;
-    float cs_cap, cs_capl, cs_rte, cs_irte, cs_icap, cs_maxin, cs_maxout;
-    float hs_cap, hs_capl, hs_rte, hs_irte, hs_icap, hs_maxin, hs_maxout;
-    float ds_cap, ds_capl, ds_rte, ds_irte, ds_icap, ds_maxin, ds_maxout;
-    float cd_pow, hd_pow, dd_pow, t0_iheat_div, dyn_warmup;
+};
+struct TankP { float cap, capl, rte, irte, icap, maxin, maxout; };
+struct Bp {         // what stays live for the whole unit
+    const uint32_t* __restrict__ p;
+    uint32_t flags;
+    int a_es;
+    float r, rw_exponent;
+    BattP batt;     // lean kernel only (loaded up front); the general kernel loads it at the battery call site
+    // ---- general kernel head ----
+    float dt, cd_pow, hd_pow, dd_pow, t0_iheat_div, dyn_warmup;
     int a_cs, a_hs, a_ds, a_cd, a_hd, a_coh;
 };
 
 CL_DEV float pw(const uint32_t* __restrict__ p, int slot) { return __uint_as_float(p[slot]); }
 
-template <bool FULL>
-CL_DEV void load_bp(Bp& B, const uint32_t* __restrict__ p) {
-    B.flags = p[CLP_L_FLAGS]; B.a_es = (int)p[CLP_L_ACT_ES];
+CL_DEV void load_batt(BattP& B, const uint32_t* __restrict__ p) {
     B.r = pw(p, CLP_L_TSR); B.pdt = pw(p, CLP_L_PDT); B.pow = pw(p, CLP_L_POW); B.cap = pw(p, CLP_L_CAP);
     B.capl = pw(p, CLP_L_CAPL); B.inv_cap = pw(p, CLP_L_INV_CAP); B.inv_pow = pw(p, CLP_L_INV_POW);
     B.omd = pw(p, CLP_L_OMD); B.degk = pw(p, CLP_L_DEGK);
@@ -82,15 +82,22 @@ CL_DEV void load_bp(Bp& B, const uint32_t* __restrict__ p) {
     B.pec_a0 = pw(p, CLP_L_PEC_A0); B.pec_b0 = pw(p, CLP_L_PEC_B0); B.pec_a1 = pw(p, CLP_L_PEC_A1);
     B.pec_b1 = pw(p, CLP_L_PEC_B1); B.pec_a2 = pw(p, CLP_L_PEC_A2); B.pec_b2 = pw(p, CLP_L_PEC_B2);
     B.pec_a3 = pw(p, CLP_L_PEC_A3); B.pec_b3 = pw(p, CLP_L_PEC_B3);
-    B.rw_exponent = pw(p, CLP_L_RW_EXPONENT);
-    if constexpr (FULL) {
+}
+
+CL_DEV void load_tank(TankP& T, const uint32_t* __restrict__ p, int raw, int der) {
+    T.cap = pw(p, raw); T.rte = pw(p, raw + 2); T.maxin = pw(p, raw + 4); T.maxout = pw(p, raw + 5);
+    T.irte = pw(p, der); T.icap = pw(p, der + 1); T.capl = pw(p, der + 2);
+}
+
+template <bool FULL>
+CL_DEV void load_bp(Bp& B, const uint32_t* __restrict__ p) {
+    B.p = p;
+    B.flags = p[CLP_L_FLAGS]; B.a_es = (int)p[CLP_L_ACT_ES];
+    B.r = pw(p, CLP_L_TSR); B.rw_exponent = pw(p, CLP_L_RW_EXPONENT);
+    if constexpr (!FULL) {
+        load_batt(B.batt, p);
+    } else {
         B.dt = pw(p, CLP_DT_HOURS);
-#define CL_TANK(px, raw, der)                                                                              \
-    B.px##_cap = pw(p, raw); B.px##_rte = pw(p, raw + 2); B.px##_maxin = pw(p, raw + 4);                   \
-    B.px##_maxout = pw(p, raw + 5); B.px##_irte = pw(p, der); B.px##_icap = pw(p, der + 1);                \
-    B.px##_capl = pw(p, der + 2);
-        CL_TANK(cs, CLP_CS_CAP, CLP_CS_IRTE) CL_TANK(hs, CLP_HS_CAP, CLP_HS_IRTE) CL_TANK(ds, CLP_DS_CAP, CLP_DS_IRTE)
-#undef CL_TANK
         B.cd_pow = pw(p, CLP_CD_POW); B.hd_pow = pw(p, CLP_HD_POW); B.dd_pow = pw(p, CLP_DD_POW);
         B.t0_iheat_div = pw(p, CLP_T0_IHEAT_DIV); B.dyn_warmup = pw(p, CLP_DYN_WARMUP);
         B.a_cs = (int)p[CLP_ACT_COOL_STO]; B.a_hs = (int)p[CLP_ACT_HEAT_STO]; B.a_ds = (int)p[CLP_ACT_DHW_STO];
@@ -137,7 +144,7 @@ CL_DEV float flexibility(const Bp& B, const Row& R, const Acc& A) {
 // Battery.charge (energy_model.py:1027-1057) on top of update_electrical_storage (building.py:1791-1812).
 // `flex` is downward_electrical_flexibility at the moment of the call; the battery's own
 // electricity_consumption[t] is still 0 there (one charge() per step), so available_nominal_power == P.
-CL_DEV float battery_step(const Bp& B, float a_es, float flex, State& S) {
+CL_DEV float battery_step(const BattP& B, float a_es, float flex, State& S) {
     const float E = fminf(a_es * B.pdt, flex);
     const float prev = S.soc;
     const float e_init = fmaxf(0.0f, prev * B.capl);                                    // energy_model.py:661-666
@@ -191,13 +198,13 @@ CL_DEV void tank_charge(float e, float prev_soc, float cap, float capl, float rt
 
 // One end use (cooling / heating / dhw): device + storage in the order given by the storage action's sign.
 CL_DEV void end_use(const Bp& B, const Row& R, Acc& A, float& c, float demand, float a_sto, float cscale,
-                    float dev_pow, float cop, float icop, float prev_soc, float cap, float capl, float rte,
-                    float irte, float icap, float maxin, float maxout, float ir, float& soc, float& eb, float& e_dev) {
+                    float dev_pow, float cop, float icop, const TankP& T, float ir, float& soc, float& eb, float& e_dev) {
+    const float prev_soc = soc;
     const float energy = a_sto * cscale;
     const bool disc = a_sto < 0.0f;                         // storage first (building.py:1611-1622)
     // storage-first lanes discharge now; the others see an untouched tank (energy_balance[t] == 0)
     float soc_a, eb_a;
-    tank_charge(fmaxf(-demand, energy) * ir, prev_soc, cap, capl, rte, irte, icap, maxin, maxout, B.r, soc_a, eb_a);
+    tank_charge(fmaxf(-demand, energy) * ir, prev_soc, T.cap, T.capl, T.rte, T.irte, T.icap, T.maxin, T.maxout, B.r, soc_a, eb_a);
     eb_a = disc ? eb_a : 0.0f;
     // device (building.py:1641-1661): `c` is this end use's accumulator inside A
     float max_out = fminf(flexibility(B, R, A), dev_pow - c * B.r) * cop;
@@ -208,7 +215,7 @@ CL_DEV void end_use(const Bp& B, const Row& R, Acc& A, float& c, float demand, f
     max_out = fminf(flexibility(B, R, A), dev_pow - c * B.r) * cop;
     const float e_c = energy > 0.0f ? fminf(max_out, energy) : fmaxf(-demand, energy);
     float soc_c, eb_c;
-    tank_charge(e_c * ir, prev_soc, cap, capl, rte, irte, icap, maxin, maxout, B.r, soc_c, eb_c);
+    tank_charge(e_c * ir, prev_soc, T.cap, T.capl, T.rte, T.irte, T.icap, T.maxin, T.maxout, B.r, soc_c, eb_c);
     soc = disc ? soc_a : soc_c;
     eb = disc ? eb_a : eb_c;
     c += fmaxf(eb, 0.0f) * icop;
@@ -222,7 +229,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
     if constexpr (!FULL) {
         // battery + PV + non-shiftable load only: no outage, no thermal end uses.
         float eb = 0.0f;
-        if (has_batt) eb = battery_step(B, a.es, INFINITY, S);
+        if (has_batt) eb = battery_step(B.batt, a.es, INFINITY, S);
         // t = 0: the load is booked at reset, by the step, and again by update_variables
         const float c_ns = first ? 3.0f * R.nsl : R.nsl;
         const float c_b = first ? 2.0f * eb : eb;
@@ -255,24 +262,36 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         float eb_b = 0.0f;
         const bool es_first = a.es < 0.0f;                         // building.py:1606-1609
         if (has_batt && R.outage) {                                // the order only matters through `flexibility`
-            if (es_first) { eb_b = battery_step(B, a.es, flexibility(B, R, A), S); A.c_b += eb_b; }
+            if (es_first) {
+                BattP bp; load_batt(bp, B.p);
+                eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); A.c_b += eb_b;
+            }
         }
         float eb_cs = 0.0f, eb_hs = 0.0f, eb_ds = 0.0f, e_cool = cool_dem, e_heat = heat_dem, e_dhw = R.dhw;
-        if (B.flags & CLF_THERMAL) {
-            const float ir = rcp(B.r);
-            end_use(B, R, A, A.c_cool, cool_dem, a.cs, B.cs_cap, B.cd_pow, R.cop_c, R.icop_c, S.cs, B.cs_cap, B.cs_capl,
-                    B.cs_rte, B.cs_irte, B.cs_icap, B.cs_maxin, B.cs_maxout, ir, S.cs, eb_cs, e_cool);
-            end_use(B, R, A, A.c_heat, heat_dem, a.hs, B.cs_cap * B.dt /* sic, building.py:1720 */, B.hd_pow, R.cop_h,
-                    R.icop_h, S.hs, B.hs_cap, B.hs_capl, B.hs_rte, B.hs_irte, B.hs_icap, B.hs_maxin, B.hs_maxout, ir,
-                    S.hs, eb_hs, e_heat);
-            end_use(B, R, A, A.c_dhw, R.dhw, a.ds, B.hs_cap * B.dt /* sic, building.py:1765 */, B.dd_pow, R.cop_d,
-                    R.icop_d, S.ds, B.ds_cap, B.ds_capl, B.ds_rte, B.ds_irte, B.ds_icap, B.ds_maxin, B.ds_maxout, ir,
-                    S.ds, eb_ds, e_dhw);
+        const float ir = rcp(B.r);
+        // each end use is skipped when the building has neither the device nor the tank (its demand is then zero in
+        // every valid schema: the reference asserts demand <= device output, building.py:1825-1829)
+        if (B.flags & (CLF_COOL_DEV | CLF_COOL_STO)) {
+            TankP T; load_tank(T, B.p, CLP_CS_CAP, CLP_CS_IRTE);
+            end_use(B, R, A, A.c_cool, cool_dem, a.cs, T.cap, B.cd_pow, R.cop_c, R.icop_c, T, ir, S.cs, eb_cs, e_cool);
+        }
+        if (B.flags & (CLF_HEAT_DEV | CLF_HEAT_STO)) {
+            TankP T; load_tank(T, B.p, CLP_HS_CAP, CLP_HS_IRTE);
+            end_use(B, R, A, A.c_heat, heat_dem, a.hs, pw(B.p, CLP_CS_CAP) * B.dt /* sic, building.py:1720 */, B.hd_pow, R.cop_h,
+                    R.icop_h, T, ir, S.hs, eb_hs, e_heat);
+        }
+        if (B.flags & (CLF_DHW_DEV | CLF_DHW_STO)) {
+            TankP T; load_tank(T, B.p, CLP_DS_CAP, CLP_DS_IRTE);
+            end_use(B, R, A, A.c_dhw, R.dhw, a.ds, pw(B.p, CLP_HS_CAP) * B.dt /* sic, building.py:1765 */, B.dd_pow, R.cop_d,
+                    R.icop_d, T, ir, S.ds, eb_ds, e_dhw);
         }
         // non-shiftable load (building.py:1784-1789)
         const float e_ns = fminf(R.nsl, flexibility(B, R, A));
         A.c_ns += e_ns;
-        if (has_batt && !(R.outage && es_first)) { eb_b = battery_step(B, a.es, flexibility(B, R, A), S); A.c_b += eb_b; }
+        if (has_batt && !(R.outage && es_first)) {
+            BattP bp; load_batt(bp, B.p);
+            eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); A.c_b += eb_b;
+        }
         if (first) {
             // the first step's update_variables runs the t == 0 block again (building.py:2618-2652)
             A.c_cool += (e_cool + eb_cs) * R.icop_c;
@@ -304,11 +323,11 @@ CL_DEV float unit_reward(int kind, const Bp& B, const State& S, float net) {
     case CLR_INDEPENDENT_SAC: return fminf(-net, 0.0f);
     case CLR_SOLAR_PENALTY: {
         const float sg = net > 0.0f ? 1.0f : (net < 0.0f ? -1.0f : 0.0f), an = fabsf(net);
-        float rw = B.cap > CL_ZDP ? -(1.0f + sg * S.soc) * an : 0.0f;
+        float rw = pw(B.p, CLP_L_CAP) > CL_ZDP ? -(1.0f + sg * S.soc) * an : 0.0f;
         if constexpr (FULL) {
-            rw += B.cs_cap > CL_ZDP ? -(1.0f + sg * S.cs) * an : 0.0f;
-            rw += B.hs_cap > CL_ZDP ? -(1.0f + sg * S.hs) * an : 0.0f;
-            rw += B.ds_cap > CL_ZDP ? -(1.0f + sg * S.ds) * an : 0.0f;
+            rw += pw(B.p, CLP_CS_CAP) > CL_ZDP ? -(1.0f + sg * S.cs) * an : 0.0f;
+            rw += pw(B.p, CLP_HS_CAP) > CL_ZDP ? -(1.0f + sg * S.hs) * an : 0.0f;
+            rw += pw(B.p, CLP_DS_CAP) > CL_ZDP ? -(1.0f + sg * S.ds) * an : 0.0f;
         }
         return rw;
     }

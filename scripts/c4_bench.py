@@ -24,15 +24,16 @@ def measure(eng, acts, steps=60, reps=5):
         ev1.record(stream); stream.synchronize()
     return ev0.elapsed_time(ev1) / (steps * reps) * 1e3
 
-for label, fixture, B, E in (('C3 2023 schema', 'g2023_p2', None, 65536), ('2020 schema', 'g2020_cz1', None, 65536),
-                             ('C4 synthetic (2020 devices)', 'g2020_cz1', 1024, 1024), ('C4 synthetic (2022 devices)', 'g2022_all', 1024, 1024)):
-    spec = golden(fixture).spec()
-    if B: spec = tile_district(spec, B)
-    tab = spec.episode_tables(0)
-    eng = StepEngine(tab, E)
-    low, high = spec.action_limits()
-    lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
-    acts = [lo[:, None] + torch.rand((len(low), E), device='cuda') * (hi - lo)[:, None] for _ in range(2)]
-    us = measure(eng, acts)
-    units = E * eng.n_bldg; bpu = eng.algorithmic_bytes_per_unit()
-    print(f'{label}: B={eng.n_bldg} E={E} lean={eng.lean}: {us:.1f} us/step  {units/us*1e6:.3e} building-timesteps/s  {units*bpu/us/1e3:.0f} GB/s ({bpu:.1f} B/unit)', flush=True)
+if __name__ == "__main__":
+  for label, fixture, B, E in (('C3 2023 schema', 'g2023_p2', None, 65536), ('2020 schema', 'g2020_cz1', None, 65536),
+                               ('C4 synthetic (2020 devices)', 'g2020_cz1', 1024, 1024), ('C4 synthetic (2022 devices)', 'g2022_all', 1024, 1024)):
+      spec = golden(fixture).spec()
+      if B: spec = tile_district(spec, B)
+      tab = spec.episode_tables(0)
+      eng = StepEngine(tab, E)
+      low, high = spec.action_limits()
+      lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+      acts = [lo[:, None] + torch.rand((len(low), E), device='cuda') * (hi - lo)[:, None] for _ in range(2)]
+      us = measure(eng, acts)
+      units = E * eng.n_bldg; bpu = eng.algorithmic_bytes_per_unit()
+      print(f'{label}: B={eng.n_bldg} E={E} lean={eng.lean}: {us:.1f} us/step  {units/us*1e6:.3e} building-timesteps/s  {units*bpu/us/1e3:.0f} GB/s ({bpu:.1f} B/unit)', flush=True)
