@@ -302,6 +302,75 @@ __global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a) {
     }
 }
 
+// ---- streaming KPI accumulators (CLD_KPI): two small passes over the detail planes the step kernel just wrote ----
+__global__ void cl_kpi_bldg_kernel(const StepArgs a) {
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const int b = (int)(i / a.n_env);
+    const float* q = a.ts + ((long long)a.t * a.n_bldg + b) * CL_NF;
+    const float price = q[CLT_PRICE], carbon = q[CLT_CARBON];
+    const bool outage = q[CLT_OUTAGE] != 0.0f;
+    const float net = a.out_bldg[CLO_NET * plane + i], base = a.out_bldg[CLO_BASE_NET * plane + i];
+    const float ex = a.out_bldg[CLO_EXPECTED * plane + i], sv = a.out_bldg[CLO_SERVED * plane + i];
+    float* k = a.kpi_bldg + i;
+    k[CLK_C_POS * plane] += fmaxf(net, 0.0f);
+    k[CLK_C_NET * plane] += net;
+    k[CLK_C_EMISSION * plane] += fmaxf(net * carbon, 0.0f);
+    k[CLK_C_COST * plane] += fmaxf(net * price, 0.0f);
+    k[CLK_B_POS * plane] += fmaxf(base, 0.0f);
+    k[CLK_B_NET * plane] += base;
+    k[CLK_B_EMISSION * plane] += fmaxf(base * carbon, 0.0f);
+    k[CLK_B_COST * plane] += fmaxf(base * price, 0.0f);
+    if (outage) { k[CLK_UNSERVED_OUTAGE * plane] += ex - sv; k[CLK_EXPECTED_OUTAGE * plane] += ex; }
+    k[CLK_UNSERVED_ALL * plane] += ex - sv;
+    k[CLK_EXPECTED_ALL * plane] += ex;
+}
+
+CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, float v) {
+    // one more sample `v` (index t) of a district series: ramping, 24- and 730-step load factor / peak groups
+    float prev = k[CLKE_PREV * n_env];
+    if (t > 0) k[CLKE_RAMP * n_env] += fmaxf(v - prev, 0.0f);
+    k[CLKE_PREV * n_env] = v;
+    float dsum = k[CLKE_DAY_SUM * n_env], dmax = k[CLKE_DAY_MAX * n_env];
+    if (t > 0 && t % 24 == 0) {
+        k[CLKE_DAY_LF_SUM * n_env] += 1.0f - (dsum * (1.0f / 24.0f)) / dmax;
+        k[CLKE_DAY_PEAK_SUM * n_env] += dmax;
+        k[CLKE_DAY_N * n_env] += 1.0f;
+        dsum = 0.0f; dmax = -INFINITY;
+    }
+    k[CLKE_DAY_SUM * n_env] = dsum + v; k[CLKE_DAY_MAX * n_env] = fmaxf(dmax, v);
+    float msum = k[CLKE_MON_SUM * n_env], mmax = k[CLKE_MON_MAX * n_env];
+    if (t > 0 && t % 730 == 0) {
+        k[CLKE_MON_LF_SUM * n_env] += 1.0f - (msum * (1.0f / 730.0f)) / mmax;
+        k[CLKE_MON_N * n_env] += 1.0f;
+        msum = 0.0f; mmax = -INFINITY;
+    }
+    k[CLKE_MON_SUM * n_env] = msum + v; k[CLKE_MON_MAX * n_env] = fmaxf(mmax, v);
+    k[CLKE_ALL_MAX * n_env] = fmaxf(k[CLKE_ALL_MAX * n_env], v);
+}
+
+// District series: control = out_env net; baseline = sum over buildings of the baseline plane (16 waves share the
+// building loop, fixed-order LDS sum).
+__global__ void __launch_bounds__(1024) cl_kpi_env_kernel(const StepArgs a) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    float s = 0.0f;
+    if (e < a.n_env)
+        for (int b = w; b < a.n_bldg; b += 16) s += a.out_bldg[CLO_BASE_NET * plane + (long long)b * a.n_env + e];
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < a.n_env) {
+        float base = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) base += part[k][lane];
+        kpi_series_update(a.kpi_env + e, a.n_env, a.t, a.out_env[(long long)CLQ_NET * a.n_env + e]);
+        kpi_series_update(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + e, a.n_env, a.t, base);
+    }
+}
+
 // Third pass, MARL only: per-building rewards need the finished district net.
 __global__ void cl_marl_reward_kernel(const StepArgs a) {
     const long long plane = (long long)a.n_bldg * a.n_env;
@@ -330,7 +399,11 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
             for (int k = 0; k < CL_NKB; ++k) kpi_bldg[k * plane + i] = 0.0f;
     }
     if (kpi_env && i < n_env)
-        for (int k = 0; k < CL_NKE; ++k) kpi_env[(long long)k * n_env + i] = 0.0f;
+        for (int k = 0; k < CL_NKE; ++k) {
+            const int kk = k % CLKE_PER_COND;
+            const bool is_max = kk == CLKE_DAY_MAX || kk == CLKE_MON_MAX || kk == CLKE_ALL_MAX;
+            kpi_env[(long long)k * n_env + i] = is_max ? -INFINITY : 0.0f;
+        }
 }
 
 }  // namespace
@@ -416,7 +489,11 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
     if (int rc = check_ptr(actions, "actions", dims->n_act_cols > 0)) return rc;
     if (int rc = check_ptr(out_bldg, "out_bldg")) return rc;
     if (int rc = check_ptr(out_env, "out_env")) return rc;
-    if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "CLD_KPI is not implemented in this build");
+    if (dims->flags & CLD_KPI) {
+        if (!(dims->flags & CLD_WRITE_DETAIL)) return fail(CL_EINVAL, "CLD_KPI requires CLD_WRITE_DETAIL");
+        if (int rc = check_ptr(kpi_bldg, "kpi_bldg")) return rc;
+        if (int rc = check_ptr(kpi_env, "kpi_env")) return rc;
+    }
     if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
     if (act_stride_env == 1 && (act_stride_col % 4) != 0)
         return fail(CL_EALIGN, "act_stride_col=%lld must be a multiple of 4 floats for the coalesced layout",
@@ -484,6 +561,11 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
             const long long n = (long long)dims->n_env * dims->n_bldg;
             hipLaunchKernelGGL(cl_marl_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
         }
+    }
+    if (dims->flags & CLD_KPI) {
+        const long long n = (long long)dims->n_env * dims->n_bldg;
+        hipLaunchKernelGGL(cl_kpi_bldg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(cl_kpi_env_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");
     return CL_OK;

@@ -36,7 +36,7 @@ class StepEngine:
     """
 
     def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
-                 t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None):
+                 t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False):
         self.lib = _lib.load()                      # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
@@ -53,7 +53,9 @@ class StepEngine:
         self.reward = reward
         flags = (REWARD_KINDS[reward] << abi.CLD_REWARD_SHIFT)
         flags |= abi.CLD_REF_T0_QUIRK if t0_quirk else 0
-        flags |= abi.CLD_WRITE_DETAIL if detail else 0
+        flags |= abi.CLD_WRITE_DETAIL if (detail or kpi) else 0
+        flags |= abi.CLD_KPI if kpi else 0
+        self.kpi = kpi
         bflags = tables.params[:, abi.CLP_FLAGS]
         heavy = abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS
         self.lean = not bool(np.any(bflags & heavy)) and not bool(np.any(tables.ts[:, :, [abi.CLT_COOL_DEM, abi.CLT_HEAT_DEM, abi.CLT_DHW_DEM]]))
@@ -65,6 +67,8 @@ class StepEngine:
             self.state = torch.zeros((abi.CL_NS, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device)
             self.out_bldg = torch.zeros((abi.CL_NO, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device)
             self.out_env = torch.zeros((abi.CL_NQ, self.n_env), dtype=torch.float32, device=self.device)
+            self.kpi_bldg = torch.zeros((abi.CL_NKB, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
+            self.kpi_env = torch.zeros((abi.CL_NKE, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
         self.t = 0
         self.reset()
 
@@ -74,7 +78,7 @@ class StepEngine:
 
     def reset(self):
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.cl_reset_f32(ctypes.byref(self.dims), _ptr(self.params), _ptr(self.state), None, None,
+            _lib.check(self.lib.cl_reset_f32(ctypes.byref(self.dims), _ptr(self.params), _ptr(self.state), _ptr(self.kpi_bldg), _ptr(self.kpi_env),
                                              self._stream()))
         self.t = 0
 
@@ -90,7 +94,7 @@ class StepEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cl_step_f32(
                 ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), sc, se,
-                _ptr(self.out_bldg), _ptr(self.out_env), None, None, int(t), self._stream()))
+                _ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env), int(t), self._stream()))
         self.t = t + 1
 
     def set_action_limits(self, low, high):

@@ -89,3 +89,92 @@ def evaluate_district(spec, tables, K: int, net, base, cost, emission, expected,
     district_level['level'] = 'district'
     return pd.concat([district_level, building_level], ignore_index=True, sort=False)
 
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# streaming accumulators (CLD_KPI) -> KPI ratios for every env of a batch
+# ------------------------------------------------------------------------------------------------------------------
+
+def _safe_div_t(c, b):
+    """`_safe_div` of citylearn.py:1172-1189 on tensors: 0/0 -> 1, x/0 -> NaN."""
+    import torch
+    out = c / b
+    zero_b = b == 0
+    out = torch.where(zero_b & (c == 0), torch.ones_like(out), out)
+    return torch.where(zero_b & (c != 0), torch.full_like(out, float('nan')), out)
+
+
+def _series_update(k, t: int, v):
+    """Host mirror of `kpi_series_update` (cl_kernels.hip) for one extra sample of a district series."""
+    import torch
+    P = abi
+    if t > 0:
+        k[P.CLKE_RAMP] += torch.clamp(v - k[P.CLKE_PREV], min=0)
+    k[P.CLKE_PREV] = v
+    for window, s_, m_, lf_, n_, peak_ in ((24, P.CLKE_DAY_SUM, P.CLKE_DAY_MAX, P.CLKE_DAY_LF_SUM, P.CLKE_DAY_N, P.CLKE_DAY_PEAK_SUM),
+                                            (730, P.CLKE_MON_SUM, P.CLKE_MON_MAX, P.CLKE_MON_LF_SUM, P.CLKE_MON_N, None)):
+        if t > 0 and t % window == 0:
+            k[lf_] += 1 - (k[s_] / window) / k[m_]
+            if peak_ is not None:
+                k[peak_] += k[m_]
+            k[n_] += 1
+            k[s_] = torch.zeros_like(k[s_])
+            k[m_] = torch.full_like(k[m_], float('-inf'))
+        k[s_] = k[s_] + v
+        k[m_] = torch.maximum(k[m_], v)
+    k[P.CLKE_ALL_MAX] = torch.maximum(k[P.CLKE_ALL_MAX], v)
+
+
+def finalize_streaming(kpi_bldg, kpi_env, steps_done: int, episode_rows: int, next_expected=None, next_outage=None):
+    """Turn the device accumulators into the KPI ratios of `CityLearnEnv.evaluate` for every env.
+
+    Returns ``(building, district)``: dicts name -> tensor ``[n_bldg, n_env]`` / ``[n_env]``; `district` also holds the
+    mean over buildings of every building-level KPI (citylearn.py:1317-1318).  The control district series has
+    `steps_done` samples, the baseline one more (the untouched zero slot of the next step, App. A.7) unless the
+    data ran out.  `next_expected` / `next_outage` (``[n_bldg]``): expected energy and outage flag of that extra row
+    (the reference's series include it in the normalisation, citylearn.py:1216 + cost_function.py:384)."""
+    import torch
+    P = abi
+    kb = kpi_bldg.double().clone()
+    if next_expected is not None and steps_done < episode_rows:
+        ne = torch.as_tensor(next_expected, dtype=kb.dtype, device=kb.device)[:, None]
+        kb[P.CLK_EXPECTED_ALL] += ne
+        if next_outage is not None:
+            kb[P.CLK_EXPECTED_OUTAGE] += ne * torch.as_tensor(next_outage, dtype=kb.dtype, device=kb.device)[:, None]
+    building = {
+        'electricity_consumption_total': _safe_div_t(kb[P.CLK_C_POS], kb[P.CLK_B_POS]),
+        'zero_net_energy': _safe_div_t(kb[P.CLK_C_NET], kb[P.CLK_B_NET]),
+        'carbon_emissions_total': _safe_div_t(kb[P.CLK_C_EMISSION], kb[P.CLK_B_EMISSION]),
+        'cost_total': _safe_div_t(kb[P.CLK_C_COST], kb[P.CLK_B_COST]),
+        'power_outage_normalized_unserved_energy_total': kb[P.CLK_UNSERVED_OUTAGE] / kb[P.CLK_EXPECTED_OUTAGE],
+        'annual_normalized_unserved_energy_total': kb[P.CLK_UNSERVED_ALL] / kb[P.CLK_EXPECTED_ALL],
+    }
+    n = P.CLKE_PER_COND
+    conds = []
+    for c, extra_zero in ((0, False), (1, steps_done < episode_rows)):
+        k = [kpi_env[c * n + j].double().clone() for j in range(n)]
+        count = steps_done
+        if extra_zero:
+            _series_update(k, steps_done, torch.zeros_like(k[0]))
+            count += 1
+        # close the open groups with their actual sample count (pandas groupby mean / max of a partial group)
+        out = {'ramp': k[P.CLKE_RAMP], 'all_max': k[P.CLKE_ALL_MAX]}
+        for window, s_, m_, lf_, n_, key in ((24, P.CLKE_DAY_SUM, P.CLKE_DAY_MAX, P.CLKE_DAY_LF_SUM, P.CLKE_DAY_N, 'day'),
+                                             (730, P.CLKE_MON_SUM, P.CLKE_MON_MAX, P.CLKE_MON_LF_SUM, P.CLKE_MON_N, 'mon')):
+            open_cnt = count - window * ((count - 1) // window)
+            groups = k[n_] + 1
+            out[key + '_lf'] = (k[lf_] + 1 - (k[s_] / open_cnt) / k[m_]) / groups
+            if key == 'day':
+                out['day_peak'] = (k[P.CLKE_DAY_PEAK_SUM] + k[m_]) / groups
+        conds.append(out)
+    c, b = conds
+    district = {
+        'ramping_average': _safe_div_t(c['ramp'], b['ramp']),
+        'daily_one_minus_load_factor_average': _safe_div_t(c['day_lf'], b['day_lf']),
+        'monthly_one_minus_load_factor_average': _safe_div_t(c['mon_lf'], b['mon_lf']),
+        'daily_peak_average': _safe_div_t(c['day_peak'], b['day_peak']),
+        'all_time_peak_average': _safe_div_t(c['all_max'], b['all_max']),
+    }
+    for name, v in building.items():
+        district[name] = torch.nanmean(v, dim=0)
+    return building, district

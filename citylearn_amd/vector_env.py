@@ -29,11 +29,12 @@ class VectorCityLearnEnv:
     """
 
     def __init__(self, schema: Union[str, Mapping[str, Any], DistrictSpec], n_envs: int, device: str = 'cuda:0',
-                 reference_quirks: bool = True, **kwargs: Any):
+                 reference_quirks: bool = True, kpi: bool = False, **kwargs: Any):
         self.spec = schema if isinstance(schema, DistrictSpec) else load_district(schema, **kwargs)
         self.n_envs = int(n_envs)
         self.device = torch.device(device)
         self.reference_quirks = reference_quirks
+        self.kpi = kpi
         self.central_agent = self.spec.central_agent
         rf_cls = resolve_reward(self.spec.reward_function.get('type'))
         kind = getattr(rf_cls, 'device_kind', None)
@@ -72,7 +73,7 @@ class VectorCityLearnEnv:
         self._episode += 1
         self.tables = self.spec.episode_tables(self._episode, seed, reward_exponent=self.reward_exponent)
         self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
-                                 t0_quirk=self.reference_quirks)
+                                 t0_quirk=self.reference_quirks, kpi=self.kpi)
         self._t = 0
         self._exo = self.engine.ts            # [T, B, CL_NF] on device: exogenous values per (t, building)
         return self._obs(), {}
@@ -94,6 +95,21 @@ class VectorCityLearnEnv:
         self._t += 1
         reward = e.district_reward if self.central_agent else e.reward_bldg
         return self._obs(), reward, self.terminated, False, {}
+
+    def evaluate(self):
+        """Per-env KPI ratios of `CityLearnEnv.evaluate` (citylearn.py:1136-1323) from the on-device streaming
+        accumulators (construct with ``kpi=True``).  Returns ``(building, district)`` dicts of tensors."""
+        if not self.kpi:
+            raise RuntimeError('construct VectorCityLearnEnv(..., kpi=True) to accumulate KPIs on the device')
+        from .kpi import finalize_streaming
+        nxt_e = nxt_o = None
+        if self._t < self.time_steps:
+            row = self.tables.start + self._t
+            nxt_e = np.array([float(b.series['cooling_demand'][row]) + float(b.series['heating_demand'][row])
+                              + float(b.series['dhw_demand'][row]) + float(b.series['non_shiftable_load'][row])
+                              for b in self.spec.buildings])
+            nxt_o = (self.tables.outage[self._t] != 0).astype(np.float64)
+        return finalize_streaming(self.engine.kpi_bldg, self.engine.kpi_env, self._t, self.time_steps, nxt_e, nxt_o)
 
     def sample_actions(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """Uniform random actions inside the action space (the device analogue of `Agent.predict`, agents/base.py:188-209)."""

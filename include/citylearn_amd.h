@@ -53,7 +53,7 @@ extern "C" {
 #define CL_NS    6   /* state planes */
 #define CL_NO   12   /* per-building output planes */
 #define CL_NQ    4   /* per-env (district) output planes */
-#define CL_NKB   8   /* per-building KPI accumulator planes */
+#define CL_NKB  12   /* per-building KPI accumulator planes */
 #define CL_NKE  24   /* per-env KPI accumulator planes */
 
 /* ---- per-building parameter slots (`params[b][slot]`, f32 unless noted) ---- */
@@ -171,10 +171,32 @@ enum cl_envout {
     CLQ_REWARD                                         /* sum over buildings (central_agent reward) */
 };
 
+/* ---- streaming KPI accumulators (CLD_KPI; what CityLearnEnv.evaluate needs, citylearn.py:1136-1323) ---- */
+enum cl_kpi_bldg {            /* kpi_bldg[plane][b][env]: running sums over the episode */
+    CLK_C_POS = 0,            /* sum max(net, 0)            -> electricity_consumption_total (cost_function.py:114) */
+    CLK_C_NET,                /* sum net                    -> zero_net_energy               (cost_function.py:136) */
+    CLK_C_EMISSION,           /* sum max(emission, 0)       -> carbon_emissions_total        (cost_function.py:159) */
+    CLK_C_COST,               /* sum max(cost, 0)           -> cost_total                    (cost_function.py:179) */
+    CLK_B_POS, CLK_B_NET, CLK_B_EMISSION, CLK_B_COST,   /* the same on the baseline (no-storage) series */
+    CLK_UNSERVED_OUTAGE, CLK_EXPECTED_OUTAGE,            /* normalized_unserved_energy, outage steps (cost_function.py:356) */
+    CLK_UNSERVED_ALL, CLK_EXPECTED_ALL                   /* ... all steps */
+};
+enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control district net, 1 = baseline district net */
+    CLKE_PREV = 0,            /* previous value (for ramping, cost_function.py:10) */
+    CLKE_RAMP,                /* sum of positive first differences */
+    CLKE_DAY_SUM, CLKE_DAY_MAX,      /* open 24-step group */
+    CLKE_DAY_LF_SUM,          /* sum over closed days of 1 - mean/max (cost_function.py:62) */
+    CLKE_DAY_PEAK_SUM,        /* sum over closed days of the daily max (cost_function.py:89) */
+    CLKE_DAY_N,               /* closed days */
+    CLKE_MON_SUM, CLKE_MON_MAX, CLKE_MON_LF_SUM, CLKE_MON_N,   /* the same for 730-step groups */
+    CLKE_ALL_MAX,             /* all-time peak */
+    CLKE_PER_COND
+};
+
 /* ---- step flags (`cl_dims.flags`) ---- */
 #define CLD_REF_T0_QUIRK   (1u << 0)  /* replicate the reference's repeated t=0 update_variables (SURVEY App.B1) */
 #define CLD_WRITE_DETAIL   (1u << 1)  /* also write CLO_B_EB .. CLO_C_NSL planes (parity / KPI baselines) */
-#define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators */
+#define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators (requires CLD_WRITE_DETAIL) */
 #define CLD_LEAN           (1u << 3)  /* caller asserts: no building has a thermal device / tank, outage or dynamics
                                          flag (battery + PV + non-shiftable load only, e.g. the 2022 schemas) ->
                                          the specialised lean kernel may be used */

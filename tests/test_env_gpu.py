@@ -114,3 +114,52 @@ def test_vector_env():
     assert torch.isfinite(total).all() and (total < 0).all()
     assert (obs['electrical_storage_soc'] >= 0).all() and (obs['electrical_storage_soc'] <= 1).all()
     torch.testing.assert_close(env.engine.district_reward, reward.sum(dim=0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('name,K', [('g2022_all', 719), ('g2023_p2', 400), ('g2020_cz1', 100)])
+def test_streaming_kpi_accumulators(name, K):
+    """On-device streaming KPI accumulators (CLD_KPI) of a batch == the KPI library applied to the per-step series of
+    the same run, for several envs with different actions; env 0 replays the golden actions, so its ratios are also
+    close to the reference's `evaluate()`."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    from citylearn_amd.kpi import evaluate_district
+    from citylearn_amd import abi
+    g = golden(name)
+    env = VectorCityLearnEnv(g.schema_path, n_envs=8, kpi=True, reward_function='citylearn.reward_function.RewardFunction')
+    eng = env.engine
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    acts_g = torch.from_numpy(g.ref['actions']).cuda()
+    B, E = eng.n_bldg, 8
+    hist = {k: np.zeros((K, B, E), dtype='float32') for k in ('net', 'base', 'exp', 'srv')}
+    d_net = np.zeros((K, E))
+    for t in range(K):
+        a = env.sample_actions(gen)
+        a[:, 0] = acts_g[t]
+        env.step(a)
+        ob = eng.out_bldg.cpu().numpy()
+        hist['net'][t], hist['base'][t] = ob[abi.CLO_NET], ob[abi.CLO_BASE_NET]
+        hist['exp'][t], hist['srv'][t] = ob[abi.CLO_EXPECTED], ob[abi.CLO_SERVED]
+        d_net[t] = eng.out_env[abi.CLQ_NET].cpu().numpy()
+    building, district = env.evaluate()
+    tab = env.tables
+    for e in (0, 3, 7):
+        net = hist['net'][:, :, e]
+        cost = (net.astype(np.float64) * tab.ts[:K, :, abi.CLT_PRICE]).astype('float32')
+        em = np.maximum(0, net.astype(np.float64) * tab.ts[:K, :, abi.CLT_CARBON]).astype('float32')
+        frame = evaluate_district(env.spec, tab, K, net, hist['base'][:, :, e], cost, em, hist['exp'][:, :, e], hist['srv'][:, :, e], d_net[:, e])
+        ref = {(r.level, r.name, r.cost_function): r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
+        n = 0
+        for (level, bname, fn), v in ref.items():
+            if fn.startswith(('discomfort', 'one_minus_thermal')):
+                continue
+            if level == 'district':
+                got = float(district[fn][e])
+            else:
+                got = float(building[fn][[b.name for b in env.spec.buildings].index(bname), e])
+            np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-5, err_msg=f'{fn} {bname} env {e}')
+            n += 1
+        assert n >= 9 + 4 * B
+    if K == g.facts['steps']:
+        gref = dict(zip([str(x) for x in g.ref['kpi_names']], g.ref['kpi_values']))
+        for fn in ('ramping_average', 'daily_peak_average', 'electricity_consumption_total', 'cost_total'):
+            np.testing.assert_allclose(float(district[fn][0]), gref[f'district|District|{fn}'], rtol=5e-3)
