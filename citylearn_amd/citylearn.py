@@ -270,17 +270,26 @@ class CityLearnEnv:
         exponent = getattr(self.reward_function, 'exponent', 1.0)
         self._tables = self.spec.episode_tables(self._episode, self.random_seed, reward_exponent=float(exponent))
         kind = getattr(type(self.reward_function), 'device_kind', None)
-        fused = kind is not None and type(self.reward_function).calculate is _stock_calculate(type(self.reward_function))
+        stock = type(self.reward_function).calculate is _stock_calculate(type(self.reward_function))
+        self._fused_comfort = stock and kind == 'comfort'
+        fused = stock and kind is not None and not self._fused_comfort
         self._fused_reward = fused
         names = {v: k for k, v in REWARD_KINDS.items()}
         self._engine = StepEngine(self._tables, 4, device=self.device, reward=names[kind] if fused else 'RewardFunction',
                                   t0_quirk=self.reference_quirks, detail=True)
+        # adjacent LSTM indoor-temperature stage (LSTMDynamicsBuilding, building.py:3000-3078) with the fused ComfortReward
+        self._stage = None
+        if any(b.is_dynamics for b in self.spec.buildings):
+            from .dynamics import LSTMStage
+            rf = self.reward_function
+            self._stage = LSTMStage(self.spec, self._tables, self._engine, getattr(rf, 'band', None),
+                                    getattr(rf, 'lower_exponent', 2.0), getattr(rf, 'higher_exponent', 2.0))
         self._torch = torch
         self._t = 0
         self.reward_function.reset()
         self.__rewards = [[]]
         self._hist: Dict[str, list] = {k: [] for k in ('net', 'base_net', 'soc', 'cost', 'emission', 'expected', 'served',
-                                                       'd_net', 'd_cost', 'd_emission')}
+                                                       'd_net', 'd_cost', 'd_emission', 'indoor_temp')}
         self._obs_table = [self._observation_table(i) for i in range(len(self.spec.buildings))]
         return self.observations, self.get_info()
 
@@ -321,7 +330,17 @@ class CityLearnEnv:
         h['cost'].append((net64 * ts[:, abi.CLT_PRICE]).astype('float32'))
         h['emission'].append(np.maximum(0.0, net64 * ts[:, abi.CLT_CARBON]).astype('float32'))
         h['d_net'].append(float(oe[abi.CLQ_NET])); h['d_cost'].append(float(oe[abi.CLQ_COST])); h['d_emission'].append(float(oe[abi.CLQ_EMISSION]))
-        if self._fused_reward:
+        w_row = self._tables.start + t
+        temps = np.array([b.series['indoor_dry_bulb_temperature'][w_row] for b in self.spec.buildings], dtype='float32')
+        comfort = None
+        if self._stage is not None:
+            temps = self._stage.step(t)[:, 0].cpu().numpy()
+            comfort = self._stage.comfort[:, 0].cpu().numpy()
+        h['indoor_temp'].append(temps)
+        self._last_temps = temps
+        if self._fused_comfort and comfort is not None:
+            reward = [float(comfort.sum())] if self.central_agent else [float(x) for x in comfort]
+        elif self._fused_reward:
             reward = [float(oe[abi.CLQ_REWARD])] if self.central_agent else [float(x) for x in ob[abi.CLO_REWARD]]
         else:
             reward = self.reward_function.calculate(observations=self._reward_observations(t, st, ob))
@@ -421,6 +440,7 @@ class CityLearnEnv:
                     d[k] = v[tab.start + t]
             ts = tab.ts[t, i]
             d.update({
+                'indoor_dry_bulb_temperature': float(self._last_temps[i]),
                 'solar_generation': abs(float(ts[abi.CLT_SOLAR])), 'power_outage': float(tab.outage[t, i]),
                 'cooling_storage_soc': float(st[abi.CLS_CS_SOC, i]), 'heating_storage_soc': float(st[abi.CLS_HS_SOC, i]),
                 'dhw_storage_soc': float(st[abi.CLS_DS_SOC, i]), 'electrical_storage_soc': float(st[abi.CLS_B_SOC, i]),
@@ -445,7 +465,8 @@ class CityLearnEnv:
         from .kpi import evaluate_district
         h = self._history_array
         return evaluate_district(self.spec, self._tables, self._t, h('net'), h('base_net'), h('cost'), h('emission'),
-                                 h('expected'), h('served'), np.array(self._hist['d_net'], dtype=np.float64), comfort_band)
+                                 h('expected'), h('served'), np.array(self._hist['d_net'], dtype=np.float64), comfort_band,
+                                 indoor_temp=h('indoor_temp'))
 
     def close(self):
         self._engine = None

@@ -409,6 +409,7 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
 }  // namespace
 
 #include "cl_rollout.h"
+#include "cl_lstm.h"
 
 namespace {
 
@@ -624,6 +625,37 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     default: return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_kernel launch");
+    return CL_OK;
+}
+
+int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(hist, "hist")) return rc;
+    if (int rc = check_ptr(hidden, "hidden")) return rc;
+    const size_t plane = (size_t)dims->n_env * dims->n_bldg * sizeof(float);
+    if (hipError_t e = hipMemsetAsync(hist, 0, CL_LSTM_NHIST * plane, (hipStream_t)stream); e != hipSuccess) return hip_fail(e, "memset hist");
+    if (hipError_t e = hipMemsetAsync(hidden, 0, CL_LSTM_NHIDDEN * plane, (hipStream_t)stream); e != hipSuccess) return hip_fail(e, "memset hidden");
+    return CL_OK;
+}
+
+int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* cool_dem,
+                     const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort, int32_t t,
+                     void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(lstm_w, "lstm_w")) return rc;
+    if (int rc = check_ptr(dyn_pre, "dyn_pre")) return rc;
+    if (int rc = check_ptr(cool_dem, "cool_dem")) return rc;
+    if (int rc = check_ptr(hist, "hist")) return rc;
+    if (int rc = check_ptr(hidden, "hidden")) return rc;
+    if (int rc = check_ptr(indoor_temp, "indoor_temp")) return rc;
+    if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
+    LstmArgs a;
+    a.lstm_w = lstm_w; a.dyn_pre = dyn_pre; a.cool_dem = cool_dem; a.hist = hist; a.hidden = hidden; a.indoor_temp = indoor_temp;
+    a.heat_dem = heat_dem; a.comfort = comfort;
+    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t;
+    const dim3 grid((dims->n_env + 255) / 256, dims->n_bldg);
+    hipLaunchKernelGGL(cl_lstm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_kernel launch");
     return CL_OK;
 }
 

@@ -1,0 +1,123 @@
+"""LSTM indoor-temperature stage of `LSTMDynamicsBuilding` on the GPU (adjacent to the energy step).
+
+Host side: packs the per-building LSTM weights (``Building_k.pth``, reference `LSTMDynamics`, citylearn/dynamics.py:50-127)
+and the env-independent part of the layer-0 gates per (t, building) -- eleven of the thirteen model inputs (weather,
+calendar sin/cos, set point, occupancy; building.py:3057-3078, 1191-1201) do not depend on the env, so
+``W_ih0[:, exo] @ x_exo(t) + b_ih0 + b_hh0`` is a table.  Device side: `cl_lstm_step_f32` (csrc/cl_lstm.h).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, abi
+from .schema import DistrictSpec, EpisodeTables
+
+_PERIODIC = {'month': 12, 'hour': 24, 'day_type': 7}     # building.py:1493-1498 (max of the ranges)
+
+# offsets inside `lstm_w` (csrc/cl_lstm.h)
+WC, WT, WHH0, WIH1, WHH1, B1, WLIN, BLIN, TMIN, TMAX, CMIN, CMAX, ACTIVE = 0, 64, 128, 1152, 2176, 3200, 3264, 3280, 3281, 3282, 3283, 3284, 3285
+PRE_TNORM, PRE_TRAW, PRE_HVAC, PRE_CSP, PRE_HSP, PRE_BAND = 64, 65, 66, 67, 68, 69
+RW_BAND, RW_LOEXP, RW_HIEXP = 3286, 3287, 3288
+
+
+def _exo_feature(b, name: str, w: slice) -> np.ndarray:
+    """Env-independent model input `name` over the episode window, as `Building.observations(periodic_normalization=True)`
+    reports it (building.py:1191-1201; preprocessing.py:68-72)."""
+    for base, x_max in _PERIODIC.items():
+        if name in (f'{base}_sin', f'{base}_cos'):
+            x = 2 * np.pi * b.series[base][w] / x_max
+            return np.sin(x) if name.endswith('_sin') else np.cos(x)
+    return np.asarray(b.series[name][w], dtype=np.float64)
+
+
+def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_exponent: float = 2.0, higher_exponent: float = 2.0):
+    """Returns ``(lstm_w [B, CL_LSTM_NW] f32, dyn_pre [T, B, CL_LSTM_NPRE] f32)``; `band` / exponents are the
+    ComfortReward parameters of the fused reward epilogue."""
+    B, T = len(spec.buildings), tables.n_steps
+    w = slice(tables.start, tables.end + 1)
+    lstm_w = np.zeros((B, abi.CL_LSTM_NW), dtype=np.float32)
+    dyn_pre = np.zeros((T, B, abi.CL_LSTM_NPRE), dtype=np.float32)
+    for i, b in enumerate(spec.buildings):
+        dyn_pre[:, i, PRE_TRAW] = b.series['indoor_dry_bulb_temperature'][w]
+        dyn_pre[:, i, PRE_HVAC] = b.series['hvac_mode'][w]
+        dyn_pre[:, i, PRE_CSP] = b.series['indoor_dry_bulb_temperature_cooling_set_point'][w]
+        dyn_pre[:, i, PRE_HSP] = b.series['indoor_dry_bulb_temperature_heating_set_point'][w]
+        dyn_pre[:, i, PRE_BAND] = b.series['comfort_band'][w]
+        lstm_w[i, RW_BAND] = np.nan if band is None else band
+        lstm_w[i, RW_LOEXP], lstm_w[i, RW_HIEXP] = lower_exponent, higher_exponent
+        d = b.dynamics
+        if d is None:
+            continue
+        if (d.hidden_size, d.num_layers, d.lookback, d.input_size) != (16, 2, 12, 13):
+            raise NotImplementedError('the LSTM kernel is specialised for LSTM(13 -> 16, 2 layers, lookback 12)')
+        sd = torch.load(d.filepath, map_location='cpu')
+        sd = {k: v.double().numpy() for k, v in sd.get('model_state_dict', sd).items()}
+        names = list(d.input_observation_names)
+        lo, hi = np.array(d.input_normalization_minimum, dtype=np.float64), np.array(d.input_normalization_maximum, dtype=np.float64)
+        ic, it = names.index('cooling_demand'), names.index('indoor_dry_bulb_temperature')
+        if 'heating_demand' in names:
+            raise NotImplementedError('heating-demand driven dynamics models are not supported yet')
+        wih0, whh0 = sd['l_lstm.weight_ih_l0'], sd['l_lstm.weight_hh_l0']
+        b0 = sd['l_lstm.bias_ih_l0'] + sd['l_lstm.bias_hh_l0']
+        lstm_w[i, WC:WC + 64] = wih0[:, ic]
+        lstm_w[i, WT:WT + 64] = wih0[:, it]
+        lstm_w[i, WHH0:WHH0 + 1024] = whh0.reshape(-1)
+        lstm_w[i, WIH1:WIH1 + 1024] = sd['l_lstm.weight_ih_l1'].reshape(-1)
+        lstm_w[i, WHH1:WHH1 + 1024] = sd['l_lstm.weight_hh_l1'].reshape(-1)
+        lstm_w[i, B1:B1 + 64] = sd['l_lstm.bias_ih_l1'] + sd['l_lstm.bias_hh_l1']
+        lstm_w[i, WLIN:WLIN + 16] = sd['l_linear.weight'].reshape(-1)
+        lstm_w[i, BLIN] = sd['l_linear.bias'].reshape(-1)[0]
+        lstm_w[i, TMIN], lstm_w[i, TMAX] = lo[it], hi[it]
+        lstm_w[i, CMIN], lstm_w[i, CMAX] = lo[ic], hi[ic]
+        lstm_w[i, ACTIVE] = 1.0
+        pre = np.tile(b0[None, :], (T, 1))
+        for k, name in enumerate(names):
+            if k in (ic, it):
+                continue
+            x = (_exo_feature(b, name, w) - lo[k]) / (hi[k] - lo[k])
+            pre += x[:, None] * wih0[None, :, k]
+        dyn_pre[:, i, :64] = pre
+        dyn_pre[:, i, PRE_TNORM] = (np.asarray(b.series['indoor_dry_bulb_temperature'][w], dtype=np.float64) - lo[it]) / (hi[it] - lo[it])
+    return lstm_w, dyn_pre
+
+
+class LSTMStage:
+    """Device state + driver of the LSTM stage for one env shard (pairs with a `StepEngine` built with detail=True)."""
+
+    def __init__(self, spec: DistrictSpec, tables: EpisodeTables, engine, band=None, lower_exponent: float = 2.0,
+                 higher_exponent: float = 2.0):
+        self.lib = _lib.load()
+        self.engine = engine
+        lstm_w, dyn_pre = pack_lstm(spec, tables, band, lower_exponent, higher_exponent)
+        dev = engine.device
+        self.any_active = bool(lstm_w[:, ACTIVE].any())
+        self.lstm_w = torch.from_numpy(lstm_w).to(dev)
+        self.dyn_pre = torch.from_numpy(dyn_pre).to(dev)
+        B, E = engine.n_bldg, engine.n_env
+        self.hist = torch.zeros((abi.CL_LSTM_NHIST, B, E), dtype=torch.float32, device=dev)
+        self.hidden = torch.zeros((abi.CL_LSTM_NHIDDEN, B, E), dtype=torch.float32, device=dev)
+        self.indoor_temp = torch.zeros((B, E), dtype=torch.float32, device=dev)
+        self.comfort = torch.zeros((B, E), dtype=torch.float32, device=dev)
+        self.lib.cl_lstm_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_void_p]
+        self.lib.cl_lstm_reset_f32.argtypes = [ctypes.POINTER(_lib.Dims), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.reset()
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.engine.device).cuda_stream
+
+    def reset(self):
+        with torch.cuda.device(self.engine.device):
+            _lib.check(self.lib.cl_lstm_reset_f32(ctypes.byref(self.engine.dims), self.hist.data_ptr(), self.hidden.data_ptr(), self._stream()))
+
+    def step(self, t: int, cool_dem: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t."""
+        cd = self.engine.out_bldg[abi.CLO_COOL_DEM] if cool_dem is None else cool_dem
+        with torch.cuda.device(self.engine.device):
+            _lib.check(self.lib.cl_lstm_step_f32(ctypes.byref(self.engine.dims), self.lstm_w.data_ptr(), self.dyn_pre.data_ptr(),
+                                                 cd.data_ptr(), None, self.hist.data_ptr(), self.hidden.data_ptr(),
+                                                 self.indoor_temp.data_ptr(), self.comfort.data_ptr(), int(t), self._stream()))
+        return self.indoor_temp

@@ -7,10 +7,12 @@ from . import abi
 from .cost_function import CostFunction
 
 
-def evaluate_district(spec, tables, K: int, net, base, cost, emission, expected, served, d_net, comfort_band: float = None):
+def evaluate_district(spec, tables, K: int, net, base, cost, emission, expected, served, d_net, comfort_band: float = None,
+                      indoor_temp=None):
     """`net`, `base`, `cost`, `emission`, `expected`, `served`: float arrays ``[K, n_bldg]`` for the K completed steps
     (control net, baseline net, control cost / emission, expected / served energy); `d_net`: the K district sums.
-    Returns the reference's ``DataFrame[cost_function, value, name, level]``."""
+    `indoor_temp` (optional ``[K, n_bldg]``): simulated indoor temperatures (LSTM stage) for the comfort KPIs; the
+    data-file temperatures are used otherwise.  Returns the reference's ``DataFrame[cost_function, value, name, level]``."""
     import pandas as pd
     net, base, cost, emission = (np.asarray(a, dtype='float32') for a in (net, base, cost, emission))
     expected, served = np.asarray(expected, dtype='float32').copy(), np.asarray(served, dtype='float32').copy()
@@ -54,7 +56,10 @@ def evaluate_district(spec, tables, K: int, net, base, cost, emission, expected,
             'cost_total': safe_div(CostFunction.cost(cost_c[:, i])[-1],
                                    CostFunction.cost(base_cost)[-1] if float(np.sum(b.series['electricity_pricing'][tab.start:tab.end + 1])) != 0 else 0),
         }
-        kw = dict(indoor_dry_bulb_temperature=b.series['indoor_dry_bulb_temperature'][w],
+        temp_series = np.array(b.series['indoor_dry_bulb_temperature'][w], dtype=np.float64)
+        if indoor_temp is not None and len(indoor_temp):
+            temp_series[:K] = np.asarray(indoor_temp, dtype=np.float64)[:K, i]
+        kw = dict(indoor_dry_bulb_temperature=temp_series,
                   dry_bulb_temperature_cooling_set_point=b.series['indoor_dry_bulb_temperature_cooling_set_point'][w],
                   dry_bulb_temperature_heating_set_point=b.series['indoor_dry_bulb_temperature_heating_set_point'][w],
                   band=comfort_band, occupant_count=b.series['occupant_count'][w])

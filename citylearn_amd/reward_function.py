@@ -99,10 +99,10 @@ class SolarPenaltyReward(RewardFunction):
 
 
 class ComfortReward(RewardFunction):
-    """Thermal-comfort reward (reference reward_function.py:216-334).  Host path only: it needs the indoor
-    dry-bulb temperature, which the reference predicts with the per-building LSTM (adjacent stage)."""
+    """Thermal-comfort reward (reference reward_function.py:216-334).  Fused into the LSTM indoor-temperature
+    kernel (`cl_lstm_step_f32`, csrc/cl_lstm.h: comfort_reward) when the env's reward function is exactly this class."""
 
-    device_kind = None
+    device_kind = 'comfort'
 
     def __init__(self, env_metadata: Mapping[str, Any], band: float = None, lower_exponent: float = None,
                  higher_exponent: float = None):

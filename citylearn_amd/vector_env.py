@@ -38,6 +38,10 @@ class VectorCityLearnEnv:
         self.central_agent = self.spec.central_agent
         rf_cls = resolve_reward(self.spec.reward_function.get('type'))
         kind = getattr(rf_cls, 'device_kind', None)
+        self._comfort = kind == 'comfort'
+        self._rf_attrs = dict(self.spec.reward_function.get('attributes') or {})
+        if self._comfort:
+            kind = abi.CLR_DEFAULT                      # the energy step still writes net / district sums
         if kind is None:
             raise NotImplementedError(f'{rf_cls.__name__} has no fused device epilogue; use reward_function='
                                       "'citylearn.reward_function.RewardFunction' | MARL | IndependentSACReward | SolarPenaltyReward")
@@ -73,7 +77,14 @@ class VectorCityLearnEnv:
         self._episode += 1
         self.tables = self.spec.episode_tables(self._episode, seed, reward_exponent=self.reward_exponent)
         self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
-                                 t0_quirk=self.reference_quirks, kpi=self.kpi)
+                                 t0_quirk=self.reference_quirks, kpi=self.kpi,
+                                 detail=any(b.is_dynamics for b in self.spec.buildings))
+        self.stage = None
+        if any(b.is_dynamics for b in self.spec.buildings):
+            from .dynamics import LSTMStage
+            a = self._rf_attrs if self._comfort else {}
+            self.stage = LSTMStage(self.spec, self.tables, self.engine, a.get('band'), a.get('lower_exponent') or 2.0,
+                                   a.get('higher_exponent') or 2.0)
         self._t = 0
         self._exo = self.engine.ts            # [T, B, CL_NF] on device: exogenous values per (t, building)
         return self._obs(), {}
@@ -83,7 +94,8 @@ class VectorCityLearnEnv:
         return {'exogenous': self._exo[min(self._t, e.n_steps - 1)],
                 'electrical_storage_soc': e.state[abi.CLS_B_SOC], 'cooling_storage_soc': e.state[abi.CLS_CS_SOC],
                 'heating_storage_soc': e.state[abi.CLS_HS_SOC], 'dhw_storage_soc': e.state[abi.CLS_DS_SOC],
-                'net_electricity_consumption': e.out_bldg[abi.CLO_NET]}
+                'net_electricity_consumption': e.out_bldg[abi.CLO_NET],
+                **({'indoor_dry_bulb_temperature': self.stage.indoor_temp} if getattr(self, 'stage', None) is not None else {})}
 
     def step(self, actions: torch.Tensor):
         if self.terminated:
@@ -92,8 +104,13 @@ class VectorCityLearnEnv:
         if actions.shape == (e.n_env, e.n_act_cols) and e.n_env != e.n_act_cols:
             actions = actions.t()                       # strided view, no copy
         e.step(actions, self._t)
+        if self.stage is not None:
+            self.stage.step(self._t)                    # indoor temperature (+ ComfortReward) of this step
         self._t += 1
-        reward = e.district_reward if self.central_agent else e.reward_bldg
+        if self._comfort and self.stage is not None:
+            reward = self.stage.comfort.sum(dim=0) if self.central_agent else self.stage.comfort
+        else:
+            reward = e.district_reward if self.central_agent else e.reward_bldg
         return self._obs(), reward, self.terminated, False, {}
 
     def evaluate(self):

@@ -252,6 +252,31 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
                    float* out_bldg, float* out_env, float* ret_env, float* kpi_bldg, float* kpi_env,
                    int32_t t0, int32_t k_steps, void* stream);
 
+/* ---- adjacent stage: LSTM indoor-temperature dynamics of LSTMDynamicsBuilding (building.py:3000-3078, dynamics.py) ----
+ * lstm_w  [n_bldg][CL_LSTM_NW]            packed LSTM(13->16, 2 layers) + Linear(16->1) weights per building
+ * dyn_pre [n_steps][n_bldg][CL_LSTM_NPRE]  host-precomputed env-independent part of the layer-0 gates per (t, building)
+ * hist    [24][n_bldg][n_env]              rings of the last 12 normalised cooling demands and indoor temperatures
+ * hidden  [64][n_bldg][n_env]              h0, c0, h1, c1 carried across env steps
+ * (layouts: citylearn_amd/csrc/cl_lstm.h, packer: citylearn_amd/dynamics.py) */
+#define CL_LSTM_NW   3296
+#define CL_LSTM_NPRE 80
+#define CL_LSTM_NHIST 24
+#define CL_LSTM_NHIDDEN 64
+
+/* Episode start: zero `hist` and `hidden` (LSTMDynamics.reset, dynamics.py:112-127). */
+int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, void* stream);
+
+/* After cl_step_f32 of step `t`: push the delivered cooling `cool_dem` [n_bldg][n_env] (out_bldg plane CLO_COOL_DEM)
+ * into the window and, once lookback+1 samples exist (t >= 12), run the LSTM over the 12-step window and write the
+ * predicted indoor dry-bulb temperature of step t to `indoor_temp` [n_bldg][n_env] (data-file value before that / for
+ * buildings without a dynamics model).  Replaces LSTMDynamicsBuilding._update_dynamics_input +
+ * update_indoor_dry_bulb_temperature (building.py:3000-3078).
+ * `comfort` (optional) receives ComfortReward.calculate per building (reward_function.py:269-334) evaluated on that
+ * temperature; `heat_dem` (optional) is the delivered heating plane it compares the cooling demand with. */
+int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* cool_dem,
+                     const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort, int32_t t,
+                     void* stream);
+
 /* Philox4x32-10 reference draw used by cl_rollout_f32 (host-callable so tests can reproduce the policy):
  * returns u in [0,1) for (seed, env, col, t). */
 float cl_philox_uniform(uint64_t seed, uint32_t env, uint32_t col, uint32_t t);

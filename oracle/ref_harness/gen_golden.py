@@ -115,7 +115,11 @@ def run_reference(name: str):
     reset_net = np.array([b.net_electricity_consumption[0] for b in env.buildings], dtype='float32')
     K = steps
     per_b = ['net', 'soc', 'eb', 'eff', 'degcap', 'cs_soc', 'hs_soc', 'ds_soc', 'c_cool', 'c_heat', 'c_dhw', 'c_ns',
-             'c_b', 'cool_dem', 'cost', 'emission', 'e_cool_dev', 'e_dhw_dev', 'e_ns']
+             'c_b', 'cool_dem', 'cost', 'emission', 'e_cool_dev', 'e_dhw_dev', 'e_ns', 'indoor_temp']
+    if md.get('reward_function_type', '') or type(env.reward_function).__name__ == 'ComfortReward':
+        rfn = env.reward_function
+        extra_rewards['ComfortReward'] = rf.ComfortReward(md, band=rfn.band, lower_exponent=rfn.lower_exponent,
+                                                          higher_exponent=rfn.higher_exponent)
     traj = {k: np.zeros((K, B), dtype='float32') for k in per_b}
     traj['actions'] = np.zeros((K, len(low)), dtype='float32')
     traj['reward_default'] = None
@@ -160,6 +164,7 @@ def run_reference(name: str):
             traj['e_cool_dev'][t, i] = b._Building__energy_from_cooling_device[t]
             traj['e_dhw_dev'][t, i] = b._Building__energy_from_dhw_device[t]
             traj['e_ns'][t, i] = b._Building__energy_to_non_shiftable_load[t]
+            traj['indoor_temp'][t, i] = b.energy_simulation.indoor_dry_bulb_temperature[t]
         if terminated:
             assert t == K - 1, (t, K)
     assert env.terminated == (K == rows - 1)

@@ -1,0 +1,36 @@
+"""LSTM stage: worst errors vs the reference and kernel timing (GPU box)."""
+import sys
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
+from golden_util import golden
+from citylearn_amd.engine import StepEngine
+from citylearn_amd.dynamics import LSTMStage
+g = golden('g2023_p2'); spec = g.spec(); tab = spec.episode_tables(0); attrs = spec.reward_function['attributes']
+E = 64
+eng = StepEngine(tab, E, detail=True)
+stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'])
+cool = torch.from_numpy(g.ref['cool_dem']).cuda()
+wt = wr = 0.0
+for t in range(g.facts['steps']):
+    temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous())
+    tt, rr = temp.cpu().numpy(), stage.comfort.cpu().numpy()
+    wt = max(wt, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t]))))
+    ref = g.ref['reward_ComfortReward'][t]
+    wr = max(wr, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
+print('teacher-fed: worst |dT| =', wt, 'C ; worst comfort reward err / (1e-4 + 1e-4|ref|) =', wr)
+for E in (4096, 65536):
+    eng = StepEngine(tab, E, detail=True)
+    stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0)
+    cd = torch.rand((3, E), device='cuda') * 5
+    for t in range(12, 16): stage.step(t, cd)
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    n = 20
+    for t in range(20, 20 + n): stage.step(t, cd)
+    ev1.record(); torch.cuda.synchronize()
+    us = ev0.elapsed_time(ev1) / n * 1e3
+    flop = 3 * E * 12 * (64 * 18 + 64 * 32) * 2
+    print(f'E={E}: {us:.1f} us per LSTM step  {3*E/us*1e6:.3e} building-timesteps/s  {flop/us/1e6:.1f} TFLOP/s fp32')

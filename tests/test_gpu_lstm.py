@@ -1,0 +1,97 @@
+"""LSTM indoor-temperature stage + fused ComfortReward (`cl_lstm_step_f32`) against the reference's predicted
+temperatures / comfort rewards on the 2023 schema.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden
+from citylearn_amd import abi
+from citylearn_amd.engine import StepEngine
+from citylearn_amd.dynamics import LSTMStage
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lstm_stage_fed_with_reference_cooling():
+    """Isolates the stage: the delivered cooling of every step comes from the reference; temperatures within 1e-4 C
+    relative and ComfortReward within 1e-4 (+1e-4) of the reference for all 719 steps x 3 buildings."""
+    g = golden('g2023_p2')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    attrs = spec.reward_function['attributes']
+    E = 64
+    eng = StepEngine(tab, E, detail=True)
+    stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'])
+    cool = torch.from_numpy(g.ref['cool_dem']).cuda()
+    worst_t = worst_r = 0.0
+    for t in range(g.facts['steps']):
+        temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous())
+        tt, rr = temp.cpu().numpy(), stage.comfort.cpu().numpy()
+        assert (tt[:, :1] == tt).all()
+        worst_t = max(worst_t, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t]))))
+        ref = g.ref['reward_ComfortReward'][t]
+        worst_r = max(worst_r, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
+    assert worst_t < 2e-3, worst_t          # deg C on ~25 C: < 1e-4 relative
+    assert worst_r < 10.0, worst_r
+
+
+def test_energy_step_plus_lstm_free_running():
+    """Energy step + LSTM stage chained on the GPU with the golden action sequence, free-running."""
+    g = golden('g2023_p2')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    attrs = spec.reward_function['attributes']
+    E = 64
+    eng = StepEngine(tab, E, detail=True)
+    stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'])
+    acts = torch.from_numpy(g.ref['actions']).cuda()
+    K = g.facts['steps']
+    temps = np.zeros((K, 3)); rews = np.zeros((K, 3))
+    for t in range(K):
+        eng.step(acts[t][:, None].expand(-1, E).contiguous(), t)
+        temps[t] = stage.step(t).cpu().numpy()[:, 0]
+        rews[t] = stage.comfort.cpu().numpy()[:, 0]
+    assert np.max(np.abs(temps - g.ref['indoor_temp'][:K])) < 5e-3
+    # episode return (central agent: sum over buildings) within 1e-3 relative
+    np.testing.assert_allclose(rews.sum(), g.ref['env_rewards'][:K].sum(), rtol=1e-3)
+    err = np.abs(rews - g.ref['reward_ComfortReward'][:K]) / (1e-3 + 1e-3 * np.abs(g.ref['reward_ComfortReward'][:K]))
+    assert err.max() < 10.0, err.max()
+
+
+def test_env_default_comfort_reward_and_comfort_kpis():
+    """`CityLearnEnv` on the 2023 schema with its default reward (ComfortReward, central agent): rewards and the
+    discomfort / thermal-resilience KPIs of `evaluate()` against the reference, full 719-step episode."""
+    from citylearn_amd.citylearn import CityLearnEnv
+    g = golden('g2023_p2')
+    env = CityLearnEnv(g.schema_path)
+    assert type(env.reward_function).__name__ == 'ComfortReward' and env._fused_comfort and env.central_agent
+    K = g.facts['steps']
+    got = np.zeros(K)
+    for t in range(K):
+        _, r, term, _, _ = env.step([[float(x) for x in g.ref['actions'][t]]])
+        got[t] = r[0]
+    ref = g.ref['env_rewards'][:K, 0]
+    assert np.max(np.abs(got - ref) / (1e-3 + 1e-3 * np.abs(ref))) < 10.0
+    np.testing.assert_allclose(got.sum(), ref.sum(), rtol=1e-3)
+    frame = env.evaluate()
+    mine = {f'{r.level}|{r.name}|{r.cost_function}': r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
+    gref = dict(zip([str(x) for x in g.ref['kpi_names']], g.ref['kpi_values']))
+    n = 0
+    for k, v in gref.items():
+        if k.split('|')[-1].startswith(('discomfort', 'one_minus_thermal')):
+            np.testing.assert_allclose(mine[k], v, rtol=5e-3, atol=2e-3, err_msg=k)
+            n += 1
+    assert n >= 30
+
+
+def test_vector_env_comfort_reward():
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden('g2023_p2')
+    env = VectorCityLearnEnv(g.schema_path, n_envs=128)
+    acts = torch.from_numpy(g.ref['actions']).cuda()
+    tot = torch.zeros(128, device='cuda')
+    for t in range(60):
+        obs, reward, *_ = env.step(acts[t][:, None].expand(-1, 128).contiguous())
+        assert reward.shape == (128,) and obs['indoor_dry_bulb_temperature'].shape == (3, 128)
+        tot += reward
+    np.testing.assert_allclose(float(tot[0]), g.ref['env_rewards'][:60, 0].sum(), rtol=2e-3)
