@@ -653,7 +653,7 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_
     a.lstm_w = lstm_w; a.dyn_pre = dyn_pre; a.cool_dem = cool_dem; a.hist = hist; a.hidden = hidden; a.indoor_temp = indoor_temp;
     a.heat_dem = heat_dem; a.comfort = comfort;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t;
-    const dim3 grid((dims->n_env + 255) / 256, dims->n_bldg);
+    const dim3 grid((dims->n_env + 127) / 128, dims->n_bldg);          // 4 waves x 32 envs per workgroup
     hipLaunchKernelGGL(cl_lstm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_kernel launch");
     return CL_OK;

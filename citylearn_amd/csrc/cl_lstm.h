@@ -8,16 +8,21 @@
 //   LSTMDynamics.forward        dynamics.py:95-101      (2-layer LSTM(13 -> 16), last time step, Linear(16 -> 1);
 //       the hidden / cell state is carried from one env step's call to the next, building.py:3023-3024)
 //
-// Mapping: one wavefront = 64 envs of ONE building, so all 3.3 k weights of that building are wave-uniform: they are
-// fetched with scalar loads and enter the v_fmac_f32 as the SGPR operand -- no LDS, no VGPRs for weights.  Eleven of
-// the thirteen input features do not depend on the env (weather, calendar, set point, occupancy); their
-// contribution to the layer-0 gates, W_ih0[:, exo] . x_exo(t) + b0, is precomputed on the host per (t, building)
-// (`dyn_pre`), leaving 2 per-lane inputs (delivered cooling, previous indoor temperature) for layer 0.
-// Per unit and env step: 12 window steps x (64 x 18 + 64 x 32) fused multiply-adds ~ 77 kFLOP, fp32 VALU-bound.
+// Mapping: see cl_lstm_kernel below -- the 64 x K gate pre-activations of a cell are a small GEMM over the env batch and
+// run on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, bit-for-bit an fmaf chain).  Eleven of the thirteen
+// input features do not depend on the env (weather, calendar, set point, occupancy); their contribution to the
+// layer-0 gates, W_ih0[:, exo] . x_exo(t) + b0, is precomputed on the host per (t, building) (`dyn_pre`) and seeds the
+// accumulators, leaving 2 per-env inputs (delivered cooling, previous indoor temperature) for layer 0.
+// Per unit and env step: 12 window steps x (64 x 18 + 64 x 32) fused multiply-adds ~ 77 kFLOP -> MFMA-bound.
+// Two VALU variants were measured first on MI355X at 3 buildings x 65 536 envs: lane = env with the weights streamed
+// through SGPRs (555 us per step, scalar-load latency bound) and lane = (env, hidden unit) with the weights resident in
+// 200 VGPRs and ds_swizzle broadcasts (467 us, dependent-FMA latency bound at 1-2 waves per SIMD); the MFMA form
+// below runs the same step in 220 us at better accuracy (the K order is the only numerical difference).
 #pragma once
 
 #define CL_LSTM_H 16            /* hidden size */
 #define CL_LSTM_LOOKBACK 12
+#define CL_LSTM_NHIDDEN_ 64      /* h0, c0, h1, c1 per (building, env): hidden[b][e][64] */
 #define CL_LSTM_NW 3296         /* floats per building in `lstm_w` */
 #define CL_LSTM_NPRE 80         /* floats per (t, building) in `dyn_pre` */
 // lstm_w layout
@@ -48,44 +53,8 @@
 #ifdef __HIPCC__
 namespace {
 
-// Weights are read through the constant address space: loads from it are invariant by definition, so a wave-uniform
-// address always becomes an s_load (through a plain global pointer the stores to `hist` / `hidden` make the compiler
-// fall back to vector loads -- 3 k weights in VGPRs).
-typedef const float __attribute__((address_space(4)))* cptr;
-CL_DEV cptr as_const(const float* p) { return (cptr)(unsigned long long)p; }
-// a zero the optimiser cannot see through: added to the weight base once per window step so that the (loop-invariant)
-// weight loads are not hoisted out of the 12-step loop into thousands of live registers
-CL_DEV int opaque_zero() { int z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
-
 CL_DEV float sigmoidf_(float x) { return cl::rcp(1.0f + __expf(-x)); }
 CL_DEV float tanhf_(float x) { return 2.0f * cl::rcp(1.0f + __expf(-2.0f * x)) - 1.0f; }
-
-// One LSTM cell for 64 envs (one per lane).  gates[j] row order as in torch.nn.LSTM: i, f, g, o blocks of 16 rows.
-// `pre(row)` = bias (+ env-independent input contribution); NX per-lane inputs x, weight of (row, k) at Wx[row*SR + k*SK].
-template <int NX, int SR, int SK, typename Pre>
-CL_DEV void lstm_cell(Pre pre, cptr Wx, const float (&x)[NX], cptr Wh,
-                      float (&h)[CL_LSTM_H], float (&c)[CL_LSTM_H]) {
-    float hn[CL_LSTM_H];
-#pragma unroll
-    for (int j = 0; j < CL_LSTM_H; ++j) {
-        float g[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = q * CL_LSTM_H + j;
-            float acc = pre(row);
-#pragma unroll
-            for (int k = 0; k < NX; ++k) acc = fmaf(Wx[row * SR + k * SK], x[k], acc);
-#pragma unroll
-            for (int k = 0; k < CL_LSTM_H; ++k) acc = fmaf(Wh[row * CL_LSTM_H + k], h[k], acc);
-            g[q] = acc;
-        }
-        const float cn = sigmoidf_(g[1]) * c[j] + sigmoidf_(g[0]) * tanhf_(g[2]);
-        c[j] = cn;
-        hn[j] = sigmoidf_(g[3]) * tanhf_(cn);
-    }
-#pragma unroll
-    for (int j = 0; j < CL_LSTM_H; ++j) h[j] = hn[j];
-}
 
 // ComfortReward.calculate for one building (reward_function.py:269-334).
 CL_DEV float comfort_reward(float temp, float cool_dem, float heat_dem, float mode, float csp, float hsp, float band,
@@ -112,75 +81,141 @@ struct LstmArgs {
     const float* __restrict__ dyn_pre;    // [T][B][CL_LSTM_NPRE]
     const float* __restrict__ cool_dem;   // [B][E] delivered cooling of this step (out_bldg plane CLO_COOL_DEM)
     float* __restrict__ hist;             // [24][B][E]: rings of the last 12 normalised cooling demands / temperatures
-    float* __restrict__ hidden;           // [64][B][E]: h0, c0, h1, c1
+    float* __restrict__ hidden;           // [B][E][64]: h0[16], c0[16], h1[16], c1[16] of every (building, env)
     float* __restrict__ indoor_temp;      // [B][E] out: indoor dry-bulb temperature of step t [C]
     const float* __restrict__ heat_dem;   // [B][E] delivered heating (may be NULL = 0)
     float* __restrict__ comfort;          // [B][E] out: ComfortReward of step t (may be NULL)
     int n_env, n_bldg, t;
 };
 
-CL_DEV float lstm_predict(const LstmArgs& a, cptr W, int b, long long plane, long long off) {
-    float h0[CL_LSTM_H], c0[CL_LSTM_H], h1[CL_LSTM_H], c1[CL_LSTM_H];
+// ---- the gate pre-activations on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) ---------------------------
+// G[64 gates x 32 envs] = W[64 x K] . X[K x 32 envs] per cell, two 32-row blocks {i, f} and {g, o}.  A wavefront owns 32
+// envs of one building.  In the C/D layout (col = lane & 31 = env, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) a lane
+// ends up with gates i, f, g, o of the SAME eight hidden units u(m) = (m & 3) + 8 (m >> 2) + 4 (lane >> 5), so the
+// cell update is lane-local; and because the K order of a dot product is free, k-slot (2 kk + (lane >> 5)) is DEFINED
+// to be hidden unit u(kk): the B operand of MFMA kk is then simply the lane's own h[kk] -- no cross-lane traffic at
+// all.  The A operands (the weights, K-permuted the same way) are 18 + 32 VGPRs loaded once per wave.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+CL_DEV int lstm_unit(int m, int hh) { return (m & 3) + 8 * (m >> 2) + 4 * hh; }
+
+CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&h)[8]) {
 #pragma unroll
-    for (int j = 0; j < CL_LSTM_H; ++j) {
-        h0[j] = a.hidden[(long long)(0 * CL_LSTM_H + j) * plane + off];
-        c0[j] = a.hidden[(long long)(1 * CL_LSTM_H + j) * plane + off];
-        h1[j] = a.hidden[(long long)(2 * CL_LSTM_H + j) * plane + off];
-        c1[j] = a.hidden[(long long)(3 * CL_LSTM_H + j) * plane + off];
+    for (int m = 0; m < 8; ++m) {
+        const float cn = sigmoidf_(d0[8 + m]) * c[m] + sigmoidf_(d0[m]) * tanhf_(d1[m]);     // f c + i g
+        c[m] = cn;
+        h[m] = sigmoidf_(d1[8 + m]) * tanhf_(cn);                                            // o tanh(c)
     }
-    for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
-        const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;                    // every feature but the temperature: t-11 .. t
-        const cptr pre = as_const(a.dyn_pre + ((long long)time * a.n_bldg + b) * CL_LSTM_NPRE);
-        const cptr Ws = W + opaque_zero();
-        float x[2];
-        x[0] = a.hist[(long long)(time % CL_LSTM_LOOKBACK) * plane + off];                         // cooling demand at `time`
-        x[1] = a.hist[(long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) * plane + off]; // temperature at `time - 1`
-        lstm_cell<2, 1, 64>([&](int row) { return pre[row]; }, Ws + CLW_WC, x, Ws + CLW_WHH0, h0, c0);
-        lstm_cell<CL_LSTM_H, CL_LSTM_H, 1>([&](int row) { return Ws[CLW_B1 + row]; }, Ws + CLW_WIH1, h0, Ws + CLW_WHH1, h1, c1);
-    }
-    float y = W[CLW_BLIN];
-#pragma unroll
-    for (int k = 0; k < CL_LSTM_H; ++k) y = fmaf(W[CLW_WLIN + k], h1[k], y);
-#pragma unroll
-    for (int j = 0; j < CL_LSTM_H; ++j) {
-        a.hidden[(long long)(0 * CL_LSTM_H + j) * plane + off] = h0[j];
-        a.hidden[(long long)(1 * CL_LSTM_H + j) * plane + off] = c0[j];
-        a.hidden[(long long)(2 * CL_LSTM_H + j) * plane + off] = h1[j];
-        a.hidden[(long long)(3 * CL_LSTM_H + j) * plane + off] = c1[j];
-    }
-    return y;
 }
 
 __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, hh = lane >> 5;
+    const int wv = threadIdx.x >> 6;
     const int b = blockIdx.y;
-    const int e = (blockIdx.x * 4 + wv) * 64 + lane;
-    if (e >= a.n_env) return;
+    const int e = (blockIdx.x * 4 + wv) * 32 + col;
+    const bool live = e < a.n_env;
+    const int ec = live ? e : a.n_env - 1;
     const long long plane = (long long)a.n_bldg * a.n_env;
-    const long long off = (long long)b * a.n_env + e;
-    const cptr W = as_const(a.lstm_w + (long long)b * CL_LSTM_NW);
-    const cptr pre_t = as_const(a.dyn_pre + ((long long)a.t * a.n_bldg + b) * CL_LSTM_NPRE);
+    const long long off = (long long)b * a.n_env + ec;
+    const float* __restrict__ W = a.lstm_w + (long long)b * CL_LSTM_NW;
+    const float* __restrict__ pre_t = a.dyn_pre + ((long long)a.t * a.n_bldg + b) * CL_LSTM_NPRE;
     const float cool = a.cool_dem[off];
     float temp = pre_t[CLPRE_TRAW];
-    if (W[CLW_ACTIVE] != 0.0f) {
+    if (W[CLW_ACTIVE] != 0.0f) {                                  // block-uniform
         const float tmin = W[CLW_TMIN], tmax = W[CLW_TMAX], cmin = W[CLW_CMIN], cmax = W[CLW_CMAX];
+        const float cool_n = (cool - cmin) / (cmax - cmin);
         const int slot = a.t % CL_LSTM_LOOKBACK;
-        // newest cooling-demand sample enters its ring (building.py:3068-3078)
-        a.hist[(long long)slot * plane + off] = (cool - cmin) / (cmax - cmin);
-        float y = pre_t[CLPRE_TNORM];      // warm-up: no prediction yet, the window keeps the data-file temperature
-        if (a.t >= CL_LSTM_LOOKBACK) {     // lookback + 1 samples exist (building.py:2996-2999)
-            y = lstm_predict(a, W, b, plane, off);
-            temp = fmaf(y, tmax - tmin, tmin);                                          // building.py:3031-3037
+        if (live && hh == 0) a.hist[(long long)slot * plane + off] = cool_n;         // building.py:3068-3078
+        float y = pre_t[CLPRE_TNORM];
+        if (a.t >= CL_LSTM_LOOKBACK) {                            // lookback + 1 samples exist (building.py:2996-2999)
+            // A operands: row = 32 rb + col of the torch gate matrix, k-slot 2 kk + hh -> hidden unit u(kk)
+            float a_hh0[2][8], a_x0[2], a_ih1[2][8], a_hh1[2][8];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int row = 32 * rb + col;
+                a_x0[rb] = hh ? W[CLW_WT + row] : W[CLW_WC + row];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int u = lstm_unit(kk, hh);
+                    a_hh0[rb][kk] = W[CLW_WHH0 + row * CL_LSTM_H + u];
+                    a_ih1[rb][kk] = W[CLW_WIH1 + row * CL_LSTM_H + u];
+                    a_hh1[rb][kk] = W[CLW_WHH1 + row * CL_LSTM_H + u];
+                }
+            }
+            // carried state of this lane's eight units
+            float* hid = a.hidden + ((long long)b * a.n_env + ec) * CL_LSTM_NHIDDEN_;
+            float h0[8], c0[8], h1[8], c1[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int u = lstm_unit(m, hh);
+                h0[m] = hid[0 * CL_LSTM_H + u]; c0[m] = hid[1 * CL_LSTM_H + u];
+                h1[m] = hid[2 * CL_LSTM_H + u]; c1[m] = hid[3 * CL_LSTM_H + u];
+            }
+            for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
+                const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
+                const float* __restrict__ pre = a.dyn_pre + ((long long)time * a.n_bldg + b) * CL_LSTM_NPRE;
+                // extra k-pair of layer 0: slot 0 = cooling demand at `time`, slot 1 = temperature at `time - 1`
+                const long long hrow = hh ? (long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) : (long long)(time % CL_LSTM_LOOKBACK);
+                float xin = a.hist[hrow * plane + off];
+                if (!hh && s == CL_LSTM_LOOKBACK - 1) xin = cool_n;      // the newest cooling sample was produced by this launch
+                f32x16 d0, d1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                           // accumulators start from the env-independent part
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    d0[r] = pre[row]; d1[r] = pre[32 + row];
+                }
+                d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_x0[0], xin, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_x0[1], xin, d1, 0, 0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hh0[0][kk], h0[kk], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hh0[1][kk], h0[kk], d1, 0, 0, 0);
+                }
+                lstm_act(d0, d1, c0, h0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    d0[r] = W[CLW_B1 + row]; d1[r] = W[CLW_B1 + 32 + row];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ih1[0][kk], h0[kk], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ih1[1][kk], h0[kk], d1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hh1[0][kk], h1[kk], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hh1[1][kk], h1[kk], d1, 0, 0, 0);
+                }
+                lstm_act(d0, d1, c1, h1);
+            }
+            if (live) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int u = lstm_unit(m, hh);
+                    hid[0 * CL_LSTM_H + u] = h0[m]; hid[1 * CL_LSTM_H + u] = c0[m];
+                    hid[2 * CL_LSTM_H + u] = h1[m]; hid[3 * CL_LSTM_H + u] = c1[m];
+                }
+            }
+            // Linear(16 -> 1): this lane's eight units, then the other half of the env (lane ^ 32)
+            float part = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) part = fmaf(W[CLW_WLIN + lstm_unit(m, hh)], h1[m], part);
+            const float other = __shfl_xor(part, 32);
+            y = W[CLW_BLIN] + (hh ? other + part : part + other);
+            temp = fmaf(y, tmax - tmin, tmin);                           // building.py:3031-3037
         }
-        a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;                 // building.py:3027-3028
+        if (live && hh == 0) a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;   // building.py:3027-3028
     }
-    a.indoor_temp[off] = temp;
-    if (a.comfort) {
-        const float band_p = W[CLW_RW_BAND];
-        const float band = band_p == band_p ? band_p : pre_t[CLPRE_BAND];
-        a.comfort[off] = comfort_reward(temp, cool, a.heat_dem ? a.heat_dem[off] : 0.0f, pre_t[CLPRE_HVAC], pre_t[CLPRE_CSP],
-                                        pre_t[CLPRE_HSP], band, W[CLW_RW_LOEXP], W[CLW_RW_HIEXP]);
+    if (live && hh == 0) {
+        a.indoor_temp[off] = temp;
+        if (a.comfort) {
+            const float band_p = W[CLW_RW_BAND];
+            const float band = band_p == band_p ? band_p : pre_t[CLPRE_BAND];
+            a.comfort[off] = comfort_reward(temp, cool, a.heat_dem ? a.heat_dem[off] : 0.0f, pre_t[CLPRE_HVAC], pre_t[CLPRE_CSP],
+                                            pre_t[CLPRE_HSP], band, W[CLW_RW_LOEXP], W[CLW_RW_HIEXP]);
+        }
     }
 }
 

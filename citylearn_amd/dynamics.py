@@ -99,7 +99,7 @@ class LSTMStage:
         self.dyn_pre = torch.from_numpy(dyn_pre).to(dev)
         B, E = engine.n_bldg, engine.n_env
         self.hist = torch.zeros((abi.CL_LSTM_NHIST, B, E), dtype=torch.float32, device=dev)
-        self.hidden = torch.zeros((abi.CL_LSTM_NHIDDEN, B, E), dtype=torch.float32, device=dev)
+        self.hidden = torch.zeros((B, E, abi.CL_LSTM_NHIDDEN), dtype=torch.float32, device=dev)
         self.indoor_temp = torch.zeros((B, E), dtype=torch.float32, device=dev)
         self.comfort = torch.zeros((B, E), dtype=torch.float32, device=dev)
         self.lib.cl_lstm_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_void_p]

@@ -256,7 +256,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
  * lstm_w  [n_bldg][CL_LSTM_NW]            packed LSTM(13->16, 2 layers) + Linear(16->1) weights per building
  * dyn_pre [n_steps][n_bldg][CL_LSTM_NPRE]  host-precomputed env-independent part of the layer-0 gates per (t, building)
  * hist    [24][n_bldg][n_env]              rings of the last 12 normalised cooling demands and indoor temperatures
- * hidden  [64][n_bldg][n_env]              h0, c0, h1, c1 carried across env steps
+ * hidden  [n_bldg][n_env][64]              h0[16], c0[16], h1[16], c1[16] carried across env steps
  * (layouts: citylearn_amd/csrc/cl_lstm.h, packer: citylearn_amd/dynamics.py) */
 #define CL_LSTM_NW   3296
 #define CL_LSTM_NPRE 80
