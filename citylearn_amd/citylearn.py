@@ -23,18 +23,9 @@ import numpy as np
 from . import abi
 from .cost_function import CostFunction
 from .reward_function import RewardFunction, resolve as resolve_reward
+from .observations import ObservationLayout
 from .schema import DistrictSpec, load_district
 from .spaces import Box
-
-# observation names whose value depends on the environment's own trajectory (everything else is a pure
-# function of the data files and the time step)
-_ENV_DEPENDENT = {
-    'cooling_storage_soc', 'heating_storage_soc', 'dhw_storage_soc', 'electrical_storage_soc',
-    'net_electricity_consumption', 'cooling_electricity_consumption', 'heating_electricity_consumption',
-    'dhw_electricity_consumption', 'cooling_storage_electricity_consumption', 'heating_storage_electricity_consumption',
-    'dhw_storage_electricity_consumption', 'electrical_storage_electricity_consumption',
-    'washing_machine_electricity_consumption',
-}
 
 
 class _BuildingView:
@@ -109,40 +100,15 @@ class CityLearnEnv:
         self._engine = None
         self.__rewards: List[List[float]] = [[]]
         self.__episode_rewards: List[Mapping[str, Any]] = []
-        self._obs_names = [self._building_observation_names(b) for b in self.spec.buildings]
+        self._layout = ObservationLayout(self.spec, observation_mode, False, reference_quirks)
+        self._obs_names = self._layout.raw_names
         self.reward_function.env_metadata = self.get_metadata()
         self.reset()
 
     # ---- static structure ------------------------------------------------------------------------------------
-    @staticmethod
-    def _available_observations(b) -> set:
-        keys = {k for k, v in b.series.items() if isinstance(v, np.ndarray)}
-        keys |= {'solar_generation', 'cooling_storage_soc', 'heating_storage_soc', 'dhw_storage_soc', 'electrical_storage_soc',
-                 'cooling_demand', 'heating_demand', 'dhw_demand', 'net_electricity_consumption', 'cooling_electricity_consumption',
-                 'heating_electricity_consumption', 'dhw_electricity_consumption', 'cooling_storage_electricity_consumption',
-                 'heating_storage_electricity_consumption', 'dhw_storage_electricity_consumption',
-                 'electrical_storage_electricity_consumption', 'washing_machine_electricity_consumption',
-                 'cooling_device_efficiency', 'heating_device_efficiency', 'dhw_device_efficiency',
-                 'indoor_dry_bulb_temperature_cooling_set_point', 'indoor_dry_bulb_temperature_heating_set_point',
-                 'indoor_dry_bulb_temperature_cooling_delta', 'indoor_dry_bulb_temperature_heating_delta', 'comfort_band',
-                 'occupant_count', 'power_outage'}
-        return keys
-
-    def _building_observation_names(self, b) -> List[str]:
-        """Active observations in schema order, restricted to what a building can report (building.py:1146-1153)."""
-        available = self._available_observations(b)
-        return [k for k in b.active_observations if k in available]
-
     @property
     def observation_names(self) -> List[List[str]]:
-        if not self.central_agent:
-            return [list(n) for n in self._obs_names]
-        names: List[str] = []
-        for i, bn in enumerate(self._obs_names):
-            for k in bn:
-                if i == 0 or k not in self.shared_observations or k not in names:
-                    names.append(k)
-        return [names]
+        return self._layout.names
 
     @property
     def action_names(self) -> List[List[str]]:
@@ -159,39 +125,9 @@ class CityLearnEnv:
 
     @property
     def observation_space(self) -> List[Box]:
-        """Observation limits.  Exogenous observations: min / max of the data series over the simulation period;
-        SoC observations [0, 1]; electricity observations: loose bounds from device sizes.  (The reference's exact
-        estimates, building.py:1836-2158, are an agent-side normalisation aid and are not part of the hot path.)"""
-        per_b = []
-        for i, b in enumerate(self.spec.buildings):
-            lo, hi = [], []
-            w = slice(self.spec.simulation_start_time_step, self.spec.simulation_end_time_step + 1)
-            peak = float(np.max(b.series['non_shiftable_load'][w]) + b.cooling_device.nominal_power + b.heating_device.nominal_power
-                         + b.dhw_device.nominal_power + b.electrical_storage.nominal_power)
-            for k in self._obs_names[i]:
-                if k.endswith('_soc'):
-                    lo.append(0.0); hi.append(1.0)
-                elif k == 'solar_generation':
-                    lo.append(0.0); hi.append(float(np.max(b.pv_nominal_power * b.series['solar_generation'][w] / 1000.0)))
-                elif k in _ENV_DEPENDENT or k.endswith('_electricity_consumption'):
-                    lo.append(-peak - b.pv_nominal_power); hi.append(peak)
-                elif k in b.series and isinstance(b.series[k], np.ndarray):
-                    s = np.asarray(b.series[k][w], dtype=float)
-                    lo.append(float(np.nanmin(s)) if np.any(~np.isnan(s)) else 0.0)
-                    hi.append(float(np.nanmax(s)) if np.any(~np.isnan(s)) else 0.0)
-                else:
-                    lo.append(-np.inf); hi.append(np.inf)
-            per_b.append((np.array(lo, dtype='float32'), np.array(hi, dtype='float32')))
-        if not self.central_agent:
-            return [Box(low=lo, high=hi, dtype=np.float32) for lo, hi in per_b]
-        lo_all, hi_all, seen = [], [], []
-        for i, (lo, hi) in enumerate(per_b):
-            for l, h, k in zip(lo, hi, self._obs_names[i]):
-                if i == 0 or k not in self.shared_observations or k not in seen:
-                    lo_all.append(l); hi_all.append(h)
-                if k in self.shared_observations and k not in seen:
-                    seen.append(k)
-        return [Box(low=np.array(lo_all, dtype='float32'), high=np.array(hi_all, dtype='float32'), dtype=np.float32)]
+        """`Building.estimate_observation_space` limits (building.py:1836-2106) merged per agent like
+        `CityLearnEnv.observation_space` (citylearn.py:385-425); see observations.space_limits."""
+        return [Box(low=lo, high=hi, dtype=np.float32) for lo, hi in self._layout.space()]
 
     def get_metadata(self) -> Mapping[str, Any]:
         """Static information handed to the reward function (`env_metadata`, citylearn.py:243, 897-937)."""
@@ -290,7 +226,7 @@ class CityLearnEnv:
         self.__rewards = [[]]
         self._hist: Dict[str, list] = {k: [] for k in ('net', 'base_net', 'soc', 'cost', 'emission', 'expected', 'served',
                                                        'd_net', 'd_cost', 'd_emission', 'indoor_temp')}
-        self._obs_table = [self._observation_table(i) for i in range(len(self.spec.buildings))]
+        self._obs_tables = self._layout.episode(self._tables)
         return self.observations, self.get_info()
 
     def _parse_actions(self, actions: Sequence[Sequence[float]]) -> np.ndarray:
@@ -353,81 +289,16 @@ class CityLearnEnv:
         return self.observations, reward, self.terminated, self.truncated, self.get_info()
 
     # ---- observations ----------------------------------------------------------------------------------------
-    def _observation_table(self, i: int) -> np.ndarray:
-        """[T, n_obs] table of the env-independent observation values of building `i` for the current episode.
-        Env-dependent columns hold what the reference reports when it reads step t+1 before computing it
-        (zero-initialised series), with the t = 0 row holding the reset-time values."""
-        b = self.spec.buildings[i]
-        tab = self._tables
-        T = tab.n_steps
-        w = slice(tab.start, tab.end + 1)
-        names = self._obs_names[i]
-        out = np.zeros((T, len(names)), dtype=np.float64)
-        ts = tab.ts[:, i]
-        outage0 = bool(ts[0, abi.CLT_OUTAGE])
-        for j, k in enumerate(names):
-            if k == 'solar_generation':
-                out[:, j] = np.abs(ts[:, abi.CLT_SOLAR])
-            elif k == 'power_outage':
-                out[:, j] = tab.outage[:, i]
-            elif k in ('cooling_demand', 'heating_demand', 'dhw_demand', 'occupant_count', 'comfort_band',
-                       'indoor_dry_bulb_temperature_cooling_set_point', 'indoor_dry_bulb_temperature_heating_set_point'):
-                out[:, j] = b.series[k][w]
-            elif k == 'indoor_dry_bulb_temperature_cooling_delta':
-                out[:, j] = b.series['indoor_dry_bulb_temperature'][w] - b.series['indoor_dry_bulb_temperature_cooling_set_point'][w]
-            elif k == 'indoor_dry_bulb_temperature_heating_delta':
-                out[:, j] = b.series['indoor_dry_bulb_temperature'][w] - b.series['indoor_dry_bulb_temperature_heating_set_point'][w]
-            elif k == 'cooling_device_efficiency':
-                out[:, j] = ts[:, abi.CLT_COP_COOL]
-            elif k == 'heating_device_efficiency':
-                out[:, j] = ts[:, abi.CLT_COP_HEAT]
-            elif k == 'dhw_device_efficiency':
-                out[:, j] = ts[:, abi.CLT_COP_DHW]
-            elif k in _ENV_DEPENDENT:
-                pf = tab.params_f32()[i]
-                first = {'electrical_storage_soc': pf[abi.CLP_B_SOC0], 'cooling_storage_soc': pf[abi.CLP_CS_SOC0],
-                         'heating_storage_soc': pf[abi.CLP_HS_SOC0], 'dhw_storage_soc': pf[abi.CLP_DS_SOC0]}
-                if self.reference_quirks:
-                    c_cool = ts[0, abi.CLT_COOL_DEM] * ts[0, abi.CLT_ICOP_COOL]
-                    c_heat = ts[0, abi.CLT_HEAT_DEM] * pf[abi.CLP_T0_IHEAT_DIV]
-                    c_dhw = ts[0, abi.CLT_DHW_DEM] * ts[0, abi.CLT_ICOP_DHW]
-                    first.update({
-                        'cooling_electricity_consumption': c_cool, 'heating_electricity_consumption': c_heat,
-                        'dhw_electricity_consumption': c_dhw,
-                        'net_electricity_consumption': 0.0 if outage0 else c_cool + c_heat + c_dhw + ts[0, abi.CLT_NSL] + ts[0, abi.CLT_SOLAR]})
-                out[0, j] = first.get(k, 0.0)
-            elif k in b.series and isinstance(b.series[k], np.ndarray):
-                out[:, j] = b.series[k][w]
-            else:
-                raise KeyError(f'observation {k!r} cannot be produced for building {b.name}')
-        return out
-
-    def _building_observations(self, i: int) -> List[float]:
-        row = self._obs_table[i][self._t].tolist()
-        if self.observation_mode == 'current' and self._t > 0:
-            st, ob = self._last_state, self._last_out
-            cur = {'electrical_storage_soc': st[abi.CLS_B_SOC, i], 'cooling_storage_soc': st[abi.CLS_CS_SOC, i],
-                   'heating_storage_soc': st[abi.CLS_HS_SOC, i], 'dhw_storage_soc': st[abi.CLS_DS_SOC, i],
-                   'net_electricity_consumption': ob[abi.CLO_NET, i], 'cooling_electricity_consumption': ob[abi.CLO_C_COOL, i],
-                   'heating_electricity_consumption': ob[abi.CLO_C_HEAT, i], 'dhw_electricity_consumption': ob[abi.CLO_C_DHW, i]}
-            for j, k in enumerate(self._obs_names[i]):
-                if k in cur:
-                    row[j] = float(cur[k])
-        return row
+    def _observation_vector(self) -> np.ndarray:
+        """All agents' observations of the current time step, flat (columns of `ObservationLayout`)."""
+        if self._t == 0 or self.observation_mode == 'reference':
+            return self._obs_tables.table[self._t]
+        return self._obs_tables.host_row(self._t, self._last_state, self._last_out, self._last_temps)
 
     @property
     def observations(self) -> List[List[float]]:
-        per_b = [self._building_observations(i) for i in range(len(self.spec.buildings))]
-        if not self.central_agent:
-            return per_b
-        flat, seen = [], []
-        for i, (vals, names) in enumerate(zip(per_b, self._obs_names)):       # citylearn.py:462-480
-            for v, k in zip(vals, names):
-                if i == 0 or k not in self.shared_observations or k not in seen:
-                    flat.append(v)
-                if k in self.shared_observations and k not in seen:
-                    seen.append(k)
-        return [flat]
+        v = self._observation_vector()
+        return [v[s].tolist() for s in self._layout.agent_slices]
 
     def _reward_observations(self, t: int, st: np.ndarray, ob: np.ndarray) -> List[Dict[str, float]]:
         """`Building.observations(include_all=True)` at step t for host-side reward plugins (citylearn.py:1022)."""
@@ -444,7 +315,8 @@ class CityLearnEnv:
                 'solar_generation': abs(float(ts[abi.CLT_SOLAR])), 'power_outage': float(tab.outage[t, i]),
                 'cooling_storage_soc': float(st[abi.CLS_CS_SOC, i]), 'heating_storage_soc': float(st[abi.CLS_HS_SOC, i]),
                 'dhw_storage_soc': float(st[abi.CLS_DS_SOC, i]), 'electrical_storage_soc': float(st[abi.CLS_B_SOC, i]),
-                'cooling_demand': float(ob[abi.CLO_COOL_DEM, i]), 'net_electricity_consumption': float(ob[abi.CLO_NET, i]),
+                'cooling_demand': float(ob[abi.CLO_COOL_DEM, i]), 'heating_demand': float(ob[abi.CLO_HEAT_DEM, i]),
+                'dhw_demand': float(ob[abi.CLO_DHW_DEM, i]), 'net_electricity_consumption': float(ob[abi.CLO_NET, i]),
                 'cooling_electricity_consumption': float(ob[abi.CLO_C_COOL, i]),
                 'heating_electricity_consumption': float(ob[abi.CLO_C_HEAT, i]),
                 'dhw_electricity_consumption': float(ob[abi.CLO_C_DHW, i]),

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                     load_action<VEC>(a_hd, a, B.a_hd, env0);
                 }
             }
-            float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC];
+            float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_hd[VEC], o_dd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 cl::State S;
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 cl::unit_step<FULL>(B, R, a.t, quirk, act, S, O);
                 const float rw = cl::unit_reward<FULL>(rkind, B, S, O.net);
                 s_soc[i] = S.soc; s_eff[i] = S.eff; s_deg[i] = S.degcap; s_cs[i] = S.cs; s_hs[i] = S.hs; s_ds[i] = S.ds;
-                o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem;
+                o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem; o_hd[i] = O.heat_dem; o_dd[i] = O.dhw_dem;
                 o_cc[i] = O.c_cool; o_ch[i] = O.c_heat; o_cw[i] = O.c_dhw; o_cn[i] = O.c_ns;
                 o_bn[i] = O.base_net; o_ex[i] = O.expected; o_sv[i] = O.served;
                 // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)
@@ -249,6 +249,8 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
             if constexpr (FULL && DETAIL) {
                 vstore<VEC>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
                 vstore<VEC>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
+                vstore<VEC>(a.out_bldg + CLO_HEAT_DEM * plane + off, o_hd);
+                vstore<VEC>(a.out_bldg + CLO_DHW_DEM * plane + off, o_dd);
                 vstore<VEC>(a.out_bldg + CLO_C_COOL * plane + off, o_cc);
                 vstore<VEC>(a.out_bldg + CLO_C_HEAT * plane + off, o_ch);
                 vstore<VEC>(a.out_bldg + CLO_C_DHW * plane + off, o_cw);
@@ -410,6 +412,7 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
 
 #include "cl_rollout.h"
 #include "cl_lstm.h"
+#include "cl_observe.h"
 
 namespace {
 
@@ -656,6 +659,34 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_
     const dim3 grid((dims->n_env + 127) / 128, dims->n_bldg);          // 4 waves x 32 envs per workgroup
     hipLaunchKernelGGL(cl_lstm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_kernel launch");
+    return CL_OK;
+}
+
+int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* col_src, const float* col_scale,
+                   const float* state, const float* out_bldg, const float* indoor_temp, float* obs, int32_t n_cols,
+                   int32_t n_rows, int32_t row, uint32_t flags, void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(obs_table, "obs_table")) return rc;
+    if (int rc = check_ptr(obs, "obs")) return rc;
+    if (n_cols <= 0 || n_rows <= 0) return fail(CL_EINVAL, "bad observation table shape [%d][%d]", n_rows, n_cols);
+    if (row < 0 || row >= n_rows) return fail(CL_ERANGE, "row=%d outside [0, %d)", row, n_rows);
+    const bool all_exo = (flags & CLOB_ALL_EXOGENOUS) != 0;
+    if (!all_exo) {
+        if (int rc = check_ptr(col_src, "col_src")) return rc;
+        if (int rc = check_ptr(col_scale, "col_scale")) return rc;
+        if (int rc = check_ptr(state, "state")) return rc;
+        if (int rc = check_ptr(out_bldg, "out_bldg")) return rc;
+        if (int rc = check_ptr(indoor_temp, "indoor_temp", false)) return rc;
+    }
+    ObsArgs a;
+    a.row = obs_table + (size_t)row * n_cols; a.col_src = col_src; a.col_scale = col_scale; a.state = state;
+    a.out_bldg = out_bldg; a.indoor_temp = indoor_temp; a.obs = obs;
+    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_cols = n_cols; a.all_exo = all_exo ? 1 : 0;
+    const int n_seg = (n_cols + OBS_SEG - 1) / OBS_SEG;
+    const dim3 grid((dims->n_env + OBS_TILE - 1) / OBS_TILE, n_seg);
+    if (n_seg == 1) hipLaunchKernelGGL(cl_observe_kernel<true>, grid, dim3(OBS_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(cl_observe_kernel<false>, grid, dim3(OBS_THREADS), 0, (hipStream_t)stream, a);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_observe_kernel launch");
     return CL_OK;
 }
 

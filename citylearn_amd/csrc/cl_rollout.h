@@ -241,6 +241,7 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
                     CL_PUT(a.out_bldg, CLO_C_DHW, last[m][i].c_dhw) CL_PUT(a.out_bldg, CLO_C_NSL, last[m][i].c_ns)
                     CL_PUT(a.out_bldg, CLO_BASE_NET, last[m][i].base_net) CL_PUT(a.out_bldg, CLO_EXPECTED, last[m][i].expected)
                     CL_PUT(a.out_bldg, CLO_SERVED, last[m][i].served)
+                    CL_PUT(a.out_bldg, CLO_HEAT_DEM, last[m][i].heat_dem) CL_PUT(a.out_bldg, CLO_DHW_DEM, last[m][i].dhw_dem)
                 }
             }
 #undef CL_PUT

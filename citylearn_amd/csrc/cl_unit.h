@@ -130,7 +130,7 @@ struct State { float soc, eff, degcap, cs, hs, ds; };
 // Actions of one unit (inactive -> 0 for storages / ignored for devices, building.py:1557-1564).
 struct Act { float cs, hs, ds, es, cd, hd; };
 // Per-unit results of the step.
-struct Out { float net, cost, emission, eb, cool_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served; };
+struct Out { float net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served; };
 // Running electricity_consumption[t] of the five electric devices.
 struct Acc { float c_cool, c_heat, c_dhw, c_ns, c_b; };
 
@@ -235,7 +235,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         const float c_b = first ? 2.0f * eb : eb;
         const float net = (c_ns + c_b) * B.r + R.sol;
         O.net = net; O.cost = net * R.price; O.emission = fmaxf(0.0f, net * R.carbon);
-        O.eb = eb; O.cool_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns;
+        O.eb = eb; O.cool_dem = 0.0f; O.heat_dem = 0.0f; O.dhw_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns;
         O.base_net = net - c_b * B.r; O.expected = R.nsl; O.served = R.nsl;
         return;
     } else {
@@ -303,7 +303,9 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         const float net = R.outage ? 0.0f : (A.c_cool + A.c_heat + A.c_dhw + A.c_ns + A.c_b) * B.r + R.sol;
         O.net = net; O.cost = net * R.price; O.emission = fmaxf(0.0f, net * R.carbon);
         O.eb = eb_b;
-        O.cool_dem = e_cool + fabsf(fminf(eb_cs, 0.0f));          // building.py:1435
+        O.cool_dem = e_cool + fabsf(fminf(eb_cs, 0.0f));          // building.py:1435-1437
+        O.heat_dem = e_heat + fabsf(fminf(eb_hs, 0.0f));
+        O.dhw_dem = e_dhw + fabsf(fminf(eb_ds, 0.0f));
         O.c_cool = A.c_cool; O.c_heat = A.c_heat; O.c_dhw = A.c_dhw; O.c_ns = A.c_ns;
         // evaluate()'s baseline: remove what the storages did (building.py:345-366, 413-463) and, for dynamics
         // buildings, add back the ideal-vs-delivered load difference (building.py:2877-2905)

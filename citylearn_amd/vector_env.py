@@ -29,13 +29,27 @@ class VectorCityLearnEnv:
     """
 
     def __init__(self, schema: Union[str, Mapping[str, Any], DistrictSpec], n_envs: int, device: str = 'cuda:0',
-                 reference_quirks: bool = True, kpi: bool = False, **kwargs: Any):
+                 reference_quirks: bool = True, kpi: bool = False, observations: str = 'planes',
+                 normalize_observations: bool = False, observation_mode: str = 'current', **kwargs: Any):
+        """`observations`: ``'planes'`` (default) returns the dict of device tensors described above without
+        materialising anything; ``'tensor'`` returns the Gym observation tensor ``[n_envs, n_obs]`` written by
+        `cl_observe_f32` -- columns = `observation_names` (the reference's central-agent order when
+        ``central_agent``, else the agents' vectors concatenated), optionally min-max / sin-cos normalised like
+        `NormalizedObservationWrapper` (`normalize_observations`).  `observation_mode`: ``'current'`` pairs the
+        exogenous values of step t+1 with the SoC / net just computed; ``'reference'`` reproduces the reference's
+        stale read of the t+1 slots."""
+        if observations not in ('planes', 'tensor'):
+            raise ValueError("observations must be 'planes' or 'tensor'")
         self.spec = schema if isinstance(schema, DistrictSpec) else load_district(schema, **kwargs)
         self.n_envs = int(n_envs)
         self.device = torch.device(device)
         self.reference_quirks = reference_quirks
         self.kpi = kpi
         self.central_agent = self.spec.central_agent
+        self.layout = None
+        if observations == 'tensor':
+            from .observations import ObservationLayout
+            self.layout = ObservationLayout(self.spec, observation_mode, normalize_observations, reference_quirks)
         rf_cls = resolve_reward(self.spec.reward_function.get('type'))
         kind = getattr(rf_cls, 'device_kind', None)
         self._comfort = kind == 'comfort'
@@ -76,9 +90,10 @@ class VectorCityLearnEnv:
     def reset(self, seed: Optional[int] = None) -> Tuple[Dict[str, torch.Tensor], dict]:
         self._episode += 1
         self.tables = self.spec.episode_tables(self._episode, seed, reward_exponent=self.reward_exponent)
+        obs_tables = self.layout.episode(self.tables) if self.layout is not None else None
         self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
                                  t0_quirk=self.reference_quirks, kpi=self.kpi,
-                                 detail=any(b.is_dynamics for b in self.spec.buildings))
+                                 detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail))
         self.stage = None
         if any(b.is_dynamics for b in self.spec.buildings):
             from .dynamics import LSTMStage
@@ -87,10 +102,27 @@ class VectorCityLearnEnv:
                                    a.get('higher_exponent') or 2.0)
         self._t = 0
         self._exo = self.engine.ts            # [T, B, CL_NF] on device: exogenous values per (t, building)
+        self.writer = None
+        if obs_tables is not None:
+            from .observe import ObservationWriter
+            self.writer = ObservationWriter(self.engine, obs_tables, self.stage)
         return self._obs(), {}
 
-    def _obs(self) -> Dict[str, torch.Tensor]:
+    @property
+    def observation_names(self):
+        if self.layout is None:
+            raise RuntimeError("construct VectorCityLearnEnv(..., observations='tensor') for named observation columns")
+        return self.layout.names
+
+    @property
+    def observation_space(self):
+        from .spaces import Box
+        return [Box(low=lo, high=hi, dtype=np.float32) for lo, hi in self.layout.space()]
+
+    def _obs(self):
         e = self.engine
+        if self.writer is not None:
+            return self.writer.write(min(self._t, e.n_steps - 1))
         return {'exogenous': self._exo[min(self._t, e.n_steps - 1)],
                 'electrical_storage_soc': e.state[abi.CLS_B_SOC], 'cooling_storage_soc': e.state[abi.CLS_CS_SOC],
                 'heating_storage_soc': e.state[abi.CLS_HS_SOC], 'dhw_storage_soc': e.state[abi.CLS_DS_SOC],

@@ -51,7 +51,7 @@ extern "C" {
 #define CL_NP  128   /* words per building in `params` */
 #define CL_NF   16   /* floats per (t, building) row in `ts` */
 #define CL_NS    6   /* state planes */
-#define CL_NO   12   /* per-building output planes */
+#define CL_NO   14   /* per-building output planes */
 #define CL_NQ    4   /* per-env (district) output planes */
 #define CL_NKB  12   /* per-building KPI accumulator planes */
 #define CL_NKE  24   /* per-env KPI accumulator planes */
@@ -162,6 +162,8 @@ enum cl_out {
                          or ..._and_partial_load for dynamics buildings (building.py:2877-2905) */
     CLO_EXPECTED,     /* cooling + heating + dhw demand + non_shiftable_load (citylearn.py:1216) */
     CLO_SERVED,       /* energy from devices + storages + energy_to_non_shiftable_load (citylearn.py:1217-1220) */
+    CLO_HEAT_DEM,     /* delivered heating: energy_from_heating_device + |min(eb_hs,0)| (building.py:1436) */
+    CLO_DHW_DEM,      /* delivered dhw:     energy_from_dhw_device + |min(eb_ds,0)|     (building.py:1437) */
     CLO_RESERVED
 };
 
@@ -276,6 +278,25 @@ int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, void* str
 int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* cool_dem,
                      const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort, int32_t t,
                      void* stream);
+
+/* ---- observation epilogue ----
+ * Writes the observation tensor obs[n_env][n_cols] (one contiguous vector per environment, the layout a policy
+ * network consumes) for observation row `row` of the episode.  Replaces the per-building dictionary building of
+ * Building.observations / CityLearnEnv.observations (building.py:1115-1219, citylearn.py:451-485) and, when the
+ * host packs normalised tables, NormalizedObservationWrapper.observation (wrappers.py:131-160).
+ *   obs_table [n_rows][n_cols] f32  env-independent value of every column (offset of the affine map for the others)
+ *   col_src   [n_cols] i32          -1: env-independent column; else CLOB_SRC(kind, plane, building)
+ *   col_scale [n_cols] f32          obs = plane[building][env] * col_scale + obs_table[row][col]
+ *   indoor_temp [n_bldg][n_env]     output of cl_lstm_step_f32 (nullable when no column uses CLOB_KIND_TEMP)
+ * flags: CLOB_ALL_EXOGENOUS -> every column comes from the table (the observation returned by reset()). */
+#define CLOB_KIND_STATE 0           /* plane = enum cl_state */
+#define CLOB_KIND_OUT   1           /* plane = enum cl_out */
+#define CLOB_KIND_TEMP  2           /* indoor_temp */
+#define CLOB_SRC(kind, plane, building) (((kind) << 28) | ((plane) << 20) | (building))
+#define CLOB_ALL_EXOGENOUS (1u << 0)
+int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* col_src, const float* col_scale,
+                   const float* state, const float* out_bldg, const float* indoor_temp, float* obs, int32_t n_cols,
+                   int32_t n_rows, int32_t row, uint32_t flags, void* stream);
 
 /* Philox4x32-10 reference draw used by cl_rollout_f32 (host-callable so tests can reproduce the policy):
  * returns u in [0,1) for (seed, env, col, t). */

@@ -225,7 +225,89 @@ def run_reference(name: str):
     print(f'{name}: {B} buildings x {K} steps, reward {facts["reward_type"]}, fixture {size / 1e6:.2f} MB')
 
 
+ROBS_KEYS = ['cooling_demand', 'heating_demand', 'dhw_demand', 'net_electricity_consumption', 'cooling_electricity_consumption',
+             'heating_electricity_consumption', 'dhw_electricity_consumption', 'cooling_storage_electricity_consumption',
+             'heating_storage_electricity_consumption', 'dhw_storage_electricity_consumption',
+             'electrical_storage_electricity_consumption', 'indoor_dry_bulb_temperature', 'electrical_storage_soc',
+             'cooling_storage_soc', 'heating_storage_soc', 'dhw_storage_soc']
+
+
+def run_observations(name: str, steps: int = None):
+    """Second fixture file ``observations.npz``: what `CityLearnEnv.reset/step` *return* as observations (flat: the
+    per-agent lists concatenated), the observation-space limits, the `NormalizedObservationWrapper` view of the same
+    (names, values, space) and the reward-observation dictionaries (values of step t after it was computed) of the
+    env-dependent keys.  Same mini dataset, same seeded actions as `run_reference`."""
+    dataset, rows, K, seed, gz, env_kwargs = FIXTURES[name]
+    K = K if steps is None else min(K, steps)
+    out_dir = GOLDEN / name
+    ref_env.setup_reference()
+    from citylearn.citylearn import CityLearnEnv
+    from citylearn.wrappers import NormalizedObservationWrapper
+
+    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'), **env_kwargs)
+    wrapped = NormalizedObservationWrapper(env)
+    B = len(env.buildings)
+    low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
+    high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
+    sizes = [b.action_space.shape[0] for b in env.buildings]
+    rng = np.random.RandomState(seed)
+    captured = {}
+    original_calculate = env.reward_function.calculate
+
+    def capture(observations):
+        captured['obs'] = observations
+        return original_calculate(observations)
+
+    env.reward_function.calculate = capture
+    flat = lambda ll: np.array([x for l in ll for x in l], dtype='float64')
+    obs0, _ = env.reset()
+    obs, obs_norm = [flat(obs0)], [flat(wrapped.observation(obs0))]
+    robs = {k: np.zeros((K, B), dtype='float64') for k in ROBS_KEYS}
+    for t in range(K):
+        a = rng.uniform(low, high).astype('float32')
+        al = [float(x) for x in a]
+        if env.central_agent:
+            acts = [al]
+        else:
+            acts, p = [], 0
+            for s in sizes:
+                acts.append(al[p:p + s])
+                p += s
+        o, _, _, _, _ = env.step(acts)
+        obs.append(flat(o))
+        obs_norm.append(flat(wrapped.observation(o)))
+        for k in ROBS_KEYS:
+            robs[k][t] = [captured['obs'][i].get(k, np.nan) for i in range(B)]
+    facts = {
+        'observation_names': env.observation_names, 'norm_observation_names': wrapped.observation_names,
+        'steps': K, 'central_agent': bool(env.central_agent),
+        'building_observation_names': [list(b.observations().keys()) for b in env.buildings],
+        'building_norm_observation_names': [list(b.observations(normalize=True, periodic_normalization=True).keys()) for b in env.buildings],
+    }
+    np.savez_compressed(
+        out_dir / 'observations.npz', facts=json.dumps(facts), obs=np.array(obs), obs_norm=np.array(obs_norm),
+        space_low=np.concatenate([s.low for s in env.observation_space]).astype('float64'),
+        space_high=np.concatenate([s.high for s in env.observation_space]).astype('float64'),
+        norm_space_low=np.concatenate([s.low for s in wrapped.observation_space]).astype('float64'),
+        norm_space_high=np.concatenate([s.high for s in wrapped.observation_space]).astype('float64'),
+        bldg_low=np.concatenate([b.observation_space.low for b in env.buildings]).astype('float64'),
+        bldg_high=np.concatenate([b.observation_space.high for b in env.buildings]).astype('float64'),
+        **{f'robs_{k}': v for k, v in robs.items()})
+    print(f'{name}: observations {np.array(obs).shape}, normalised {np.array(obs_norm).shape}')
+
+
+OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300}
+
+
 if __name__ == '__main__':
-    names = sys.argv[1:] or list(FIXTURES)
+    args = sys.argv[1:]
+    if args and args[0] == 'observations':
+        for n in (args[1:] or list(OBS_FIXTURES)):
+            run_observations(n, OBS_FIXTURES.get(n))
+        sys.exit(0)
+    names = args or list(FIXTURES)
     for n in names:
         run_reference(n)
+    for n in names:
+        if n in OBS_FIXTURES:
+            run_observations(n, OBS_FIXTURES[n])

@@ -16,6 +16,15 @@ class Golden:
         self.schema_path = str(self.dir / 'dataset' / 'schema.json')
         self.ref = np.load(self.dir / 'reference.npz', allow_pickle=False)
         self.facts = json.loads(str(self.ref['facts']))
+        self._obs = None
+
+    @property
+    def obs(self):
+        """observations.npz: what the reference's reset()/step() return + NormalizedObservationWrapper view."""
+        if self._obs is None:
+            self._obs = np.load(self.dir / 'observations.npz', allow_pickle=False)
+            self.obs_facts = json.loads(str(self._obs['facts']))
+        return self._obs
 
     @property
     def reward_kind(self) -> str:

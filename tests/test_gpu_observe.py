@@ -1,0 +1,152 @@
+"""Observation epilogue `cl_observe_f32` on the GPU: against the host statement of the same affine map
+(`ObservationTables.host_row`), and -- through `CityLearnEnv` / `NormalizedObservationWrapper` /
+`VectorCityLearnEnv(observations='tensor')` -- against the observations the reference itself returned
+(tests/golden/*/observations.npz).  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(name, n_env, detail=True):
+    from citylearn_amd.engine import StepEngine
+    g = golden(name)
+    spec = g.spec()
+    tables = spec.episode_tables(0)
+    return g, spec, tables, StepEngine(tables, n_env, reward='RewardFunction', detail=detail)
+
+
+@pytest.mark.parametrize('n_env,n_cols,n_dep', [(64, 52, 9), (100, 476, 34), (256, 527, 80), (68, 1500, 90), (192, 2600, 300), (4, 3, 3)])
+def test_kernel_matches_host_statement(n_env, n_cols, n_dep):
+    """Synthetic column maps: single-segment (16-byte store path) and multi-segment shapes, ragged env tile, more
+    dependent columns in a segment than the LDS staging holds (direct-read fallback)."""
+    from citylearn_amd import abi
+    from citylearn_amd.observations import ObservationTables, SRC_OUT, SRC_STATE, SRC_TEMP
+    from citylearn_amd.observe import ObservationWriter
+    from citylearn_amd.dynamics import LSTMStage
+    g, spec, tables, eng = _engine('g2023_p2', n_env)
+    stage = LSTMStage(spec, tables, eng)
+    rng = np.random.RandomState(n_cols)
+    B = eng.n_bldg
+    eng.state.copy_(torch.from_numpy(rng.uniform(-1, 1, eng.state.shape).astype('float32')))
+    eng.out_bldg.copy_(torch.from_numpy(rng.uniform(-5, 5, eng.out_bldg.shape).astype('float32')))
+    stage.indoor_temp.copy_(torch.from_numpy(rng.uniform(15, 30, stage.indoor_temp.shape).astype('float32')))
+    table = rng.uniform(-2, 2, (5, n_cols))
+    src = np.full(n_cols, -1, dtype=np.int32)
+    scale = np.zeros(n_cols, dtype=np.float32)
+    for c in rng.choice(n_cols, size=n_dep, replace=False):
+        kind = rng.randint(3)
+        plane = rng.randint(abi.CL_NS) if kind == SRC_STATE else rng.randint(abi.CL_NO) if kind == SRC_OUT else 0
+        src[c] = (kind << 28) | (plane << 20) | rng.randint(B)
+        scale[c] = rng.uniform(0.1, 3.0)
+    ot = ObservationTables(table, src, scale, needs_detail=False)
+    w = ObservationWriter(eng, ot, stage)
+    st, ob, tp = eng.state.cpu().numpy(), eng.out_bldg.cpu().numpy(), stage.indoor_temp.cpu().numpy()
+    t32 = table.astype('float32').astype('float64')
+    for row in (0, 3):
+        got = w.write(row).cpu().numpy()
+        assert got.shape == (n_env, n_cols)
+        for e in (0, 1, n_env // 2, n_env - 1):
+            want = ObservationTables(t32, src, scale, False).host_row(row, st[:, :, e], ob[:, :, e], tp[:, e])
+            np.testing.assert_allclose(got[e], want, rtol=1e-6, atol=1e-6)
+    # every env row of an all-exogenous write is the table row, bit for bit
+    assert np.array_equal(w.write(0).cpu().numpy(), np.broadcast_to(table[0].astype('float32'), (n_env, n_cols)))
+
+
+def test_observe_validates_arguments():
+    import ctypes
+    from citylearn_amd import _lib, abi
+    from citylearn_amd.observations import ObservationLayout
+    from citylearn_amd.observe import ObservationWriter
+    g, spec, tables, eng = _engine('g2022_all', 64)
+    ot = ObservationLayout(spec, 'current').episode(tables)
+    w = ObservationWriter(eng, ot)
+    with pytest.raises(_lib.EngineError, match='row'):
+        w.write(w.n_rows)
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), None, None, None, None, None, w.obs.data_ptr(),
+                              w.n_cols, w.n_rows, 1, 0, None)
+    assert rc == abi.CL_ENULL
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr() + 4, None, None, None, None, None, w.obs.data_ptr(),
+                              w.n_cols, w.n_rows, 0, abi.CLOB_ALL_EXOGENOUS, None)
+    assert rc == abi.CL_EALIGN
+    from citylearn_amd.engine import StepEngine
+    lean = StepEngine(tables, 64, reward='RewardFunction', detail=False)
+    spec2 = g.spec()
+    for b in spec2.buildings:
+        b.observation_metadata['electrical_storage_electricity_consumption'] = True
+    with pytest.raises(ValueError, match='detail'):
+        ObservationWriter(lean, ObservationLayout(spec2, 'current').episode(tables))
+
+
+def _actions(g, env, t):
+    a = [float(x) for x in g.ref['actions'][t]]
+    if env.central_agent:
+        return [a]
+    out, p = [], 0
+    for names in env.action_names:
+        out.append(a[p:p + len(names)]); p += len(names)
+    return out
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+def test_env_returns_the_reference_observations(name):
+    """reset()/step() observations, observation_space and the NormalizedObservationWrapper view of `CityLearnEnv`
+    equal what the reference returned for the same schema and actions (reference semantics)."""
+    from citylearn_amd.citylearn import CityLearnEnv
+    from citylearn_amd.wrappers import NormalizedObservationWrapper
+    g = golden(name)
+    o = g.obs
+    env = CityLearnEnv(g.schema_path)
+    wrapped = NormalizedObservationWrapper(env)
+    assert env.observation_names == g.obs_facts['observation_names']
+    assert wrapped.observation_names == g.obs_facts['norm_observation_names']
+    np.testing.assert_array_equal(np.concatenate([s.low for s in env.observation_space]), o['space_low'].astype('float32'))
+    np.testing.assert_array_equal(np.concatenate([s.high for s in env.observation_space]), o['space_high'].astype('float32'))
+    np.testing.assert_array_equal(np.concatenate([s.high for s in wrapped.observation_space]), o['norm_space_high'].astype('float32'))
+    flat = lambda ll: np.array([x for l in ll for x in l])
+    obs, _ = wrapped.reset()
+    np.testing.assert_allclose(flat(obs), o['obs_norm'][0], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(flat(env.observations), o['obs'][0], rtol=1e-6, atol=1e-6)
+    for t in range(40):
+        obs, *_ = wrapped.step(_actions(g, env, t))
+        np.testing.assert_allclose(flat(obs), o['obs_norm'][t + 1], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(flat(env.observations), o['obs'][t + 1], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+@pytest.mark.parametrize('normalize', [False, True])
+def test_vector_env_observation_tensor(name, normalize):
+    """`VectorCityLearnEnv(observations='tensor')`: exogenous columns equal the reference's returned observations, the
+    env-dependent ones equal the reference's own series of the step just simulated (free-running fp32: 1e-3)."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden(name)
+    o = g.obs
+    kw = {'reward_function': 'citylearn.reward_function.RewardFunction'} if g.facts['reward_type'] == 'ComfortReward' else {}
+    env = VectorCityLearnEnv(g.schema_path, 64, observations='tensor', normalize_observations=normalize, **kw)
+    lay = env.layout
+    lo, hi = lay.limits()
+    ref = o['obs_norm' if normalize else 'obs']
+    assert env.observation_names == g.obs_facts['norm_observation_names' if normalize else 'observation_names']
+    obs, _ = env.reset()
+    assert tuple(obs.shape) == (64, lay.n_cols)
+    np.testing.assert_allclose(obs[5].cpu().numpy(), ref[0], rtol=1e-5, atol=1e-5)
+    acts = torch.from_numpy(g.ref['actions']).cuda()
+    dep = env.writer.col_src.cpu().numpy() >= 0
+    for t in range(60):
+        obs, *_ = env.step(acts[t][:, None].expand(-1, 64).contiguous())
+        got = obs.cpu().numpy()
+        assert np.array_equal(got[0], got[63])                     # identical actions -> identical envs
+        np.testing.assert_allclose(got[0][~dep], ref[t + 1][~dep], rtol=1e-5, atol=1e-5)
+        for c in np.nonzero(dep)[0]:
+            i, k = lay.columns[c]
+            if k.endswith('_delta'):
+                sp = env.spec.buildings[i].series[k.replace('_delta', '_set_point')][t]
+                want = float(o['robs_indoor_dry_bulb_temperature'][t, i]) - float(sp)
+            else:
+                want = float(o[f'robs_{k}'][t, i])
+            if normalize:
+                want = (want - lo[c]) / (hi[c] - lo[c])
+            assert got[0][c] == pytest.approx(want, rel=1e-3, abs=1e-3), (t, i, k)

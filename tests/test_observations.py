@@ -1,0 +1,98 @@
+"""Host observation layout vs the reference's own observations (tests/golden/*/observations.npz, produced by
+oracle/ref_harness/gen_golden.py `observations`): names, central-agent de-duplication, observation-space limits,
+raw values and the NormalizedObservationWrapper view."""
+import numpy as np
+import pytest
+
+from citylearn_amd.observations import ObservationLayout
+from golden_util import golden
+
+FIX = ('g2022_all', 'g2020_cz1', 'g2023_p2')
+
+
+def _flat(ll):
+    return [k for l in ll for k in l]
+
+
+@pytest.mark.parametrize('name', FIX)
+@pytest.mark.parametrize('normalize', [False, True])
+def test_reference_mode_tables_match_the_reference(name, normalize):
+    g = golden(name)
+    o = g.obs
+    spec = g.spec()
+    lay = ObservationLayout(spec, 'reference', normalize=normalize)
+    ref_names = g.obs_facts['norm_observation_names' if normalize else 'observation_names']
+    assert lay.names == ref_names
+    tab = lay.episode(spec.episode_tables(0))
+    ref = o['obs_norm' if normalize else 'obs']
+    got = tab.table[:ref.shape[0]]
+    # the reference hands out float64 arithmetic on float32 series; the table is the same arithmetic
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-6)
+    assert tab.n_dependent == 0                     # reference semantics: nothing is read from the device
+
+
+@pytest.mark.parametrize('name', FIX)
+def test_observation_space_limits_match_the_reference(name):
+    g = golden(name)
+    o = g.obs
+    spec = g.spec()
+    lay = ObservationLayout(spec, 'reference')
+    low = np.concatenate([lo for lo, _ in lay.space()])
+    high = np.concatenate([hi for _, hi in lay.space()])
+    np.testing.assert_array_equal(low, o['space_low'].astype('float32'))
+    np.testing.assert_array_equal(high, o['space_high'].astype('float32'))
+    lay_n = ObservationLayout(spec, 'reference', normalize=True)
+    low = np.concatenate([lo for lo, _ in lay_n.space()])
+    high = np.concatenate([hi for _, hi in lay_n.space()])
+    np.testing.assert_array_equal(low, o['norm_space_low'].astype('float32'))
+    np.testing.assert_array_equal(high, o['norm_space_high'].astype('float32'))
+
+
+@pytest.mark.parametrize('name', FIX)
+@pytest.mark.parametrize('normalize', [False, True])
+def test_current_mode_device_map_reproduces_the_reference_series(name, normalize):
+    """'current' semantics: row r = exogenous values of r + env-dependent values simulated at r-1.  Feed `host_row`
+    (the host statement of what cl_observe_f32 computes) with the reference's own state of step r-1 and compare the
+    env-dependent columns with the reference's reward observations of that step, the others with its returned row."""
+    from citylearn_amd import abi
+    g = golden(name)
+    o, r = g.obs, g.ref
+    spec = g.spec()
+    lay = ObservationLayout(spec, 'current', normalize=normalize)
+    tab = lay.episode(spec.episode_tables(0))
+    lo, hi = lay.limits()
+    B = len(spec.buildings)
+    ref = o['obs_norm' if normalize else 'obs']
+    assert tab.n_dependent > 0
+    for row in (1, 2, 13, 14, 57, ref.shape[0] - 1):
+        t = row - 1
+        state = np.zeros((abi.CL_NS, B)); out = np.zeros((abi.CL_NO, B))
+        state[abi.CLS_B_SOC], state[abi.CLS_CS_SOC], state[abi.CLS_HS_SOC], state[abi.CLS_DS_SOC] = r['soc'][t], r['cs_soc'][t], r['hs_soc'][t], r['ds_soc'][t]
+        out[abi.CLO_NET], out[abi.CLO_B_EB] = r['net'][t], r['c_b'][t]
+        out[abi.CLO_C_COOL], out[abi.CLO_C_HEAT], out[abi.CLO_C_DHW] = r['c_cool'][t], r['c_heat'][t], r['c_dhw'][t]
+        out[abi.CLO_COOL_DEM], out[abi.CLO_HEAT_DEM], out[abi.CLO_DHW_DEM] = (o[f'robs_{k}'][t] for k in ('cooling_demand', 'heating_demand', 'dhw_demand'))
+        temps = o['robs_indoor_dry_bulb_temperature'][t]
+        got = tab.host_row(row, state, out, temps)
+        for c, (i, k) in enumerate(lay.columns):
+            if tab.col_src[c] < 0:
+                assert got[c] == pytest.approx(ref[row, c], rel=1e-6, abs=1e-6), (row, k)
+                continue
+            raw = k
+            if raw.endswith('_delta'):
+                sp = spec.buildings[i].series[raw.replace('_delta', '_set_point')][t]
+                want = float(o['robs_indoor_dry_bulb_temperature'][t, i]) - float(sp)
+            else:
+                want = float(o[f'robs_{raw}'][t, i])
+            if normalize:
+                want = (want - lo[c]) / (hi[c] - lo[c])
+            assert got[c] == pytest.approx(want, rel=2e-6, abs=2e-6), (row, i, k)
+
+
+def test_unsupported_current_mode_columns_fail_loudly():
+    g = golden('g2020_cz1')
+    spec = g.spec()
+    spec.buildings[0].observation_metadata['dhw_storage_electricity_consumption'] = True
+    lay = ObservationLayout(spec, 'current')
+    with pytest.raises(NotImplementedError, match='dhw_storage_electricity_consumption'):
+        lay.episode(spec.episode_tables(0))
+    ObservationLayout(spec, 'reference').episode(spec.episode_tables(0))       # stale semantics need no plane
