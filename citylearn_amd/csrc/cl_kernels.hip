@@ -455,6 +455,8 @@ int pick_vec(int n_env, int n_bldg, bool unit_stride) {
 int g_force_vec = 0;   // test / tuning hooks (cl_debug_set_vec / cl_debug_set_lean)
 int g_force_nw = 0;
 int g_no_chunks = 0;
+int g_obs_variant = 0;   // 1 / 2: force the row-wise / LDS-tile observation kernel (tests, tuning)
+int g_obs_rows = 0;      // tile kernel: envs per block (tuning)
 
 }  // namespace
 
@@ -466,6 +468,7 @@ const char* cl_last_error(void) { return g_err; }
 
 void cl_debug_set_vec(int vec) { g_force_vec = vec; }
 void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks; g_force_nw = nw; }
+void cl_debug_set_observe(int variant, int rows) { g_obs_variant = variant; g_obs_rows = rows; }
 
 int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, float* kpi_bldg, float* kpi_env,
                  void* stream) {
@@ -663,12 +666,13 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_
 }
 
 int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* col_src, const float* col_scale,
-                   const float* state, const float* out_bldg, const float* indoor_temp, float* obs, int32_t n_cols,
-                   int32_t n_rows, int32_t row, uint32_t flags, void* stream) {
+                   const cl_obs_dep* deps, int32_t n_deps, const float* state, const float* out_bldg, const float* indoor_temp, float* obs, int32_t n_cols,
+                   int32_t obs_pitch, int32_t n_rows, int32_t row, uint32_t flags, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     if (int rc = check_ptr(obs_table, "obs_table")) return rc;
     if (int rc = check_ptr(obs, "obs")) return rc;
     if (n_cols <= 0 || n_rows <= 0) return fail(CL_EINVAL, "bad observation table shape [%d][%d]", n_rows, n_cols);
+    if (obs_pitch < n_cols) return fail(CL_EINVAL, "obs_pitch=%d < n_cols=%d", obs_pitch, n_cols);
     if (row < 0 || row >= n_rows) return fail(CL_ERANGE, "row=%d outside [0, %d)", row, n_rows);
     const bool all_exo = (flags & CLOB_ALL_EXOGENOUS) != 0;
     if (!all_exo) {
@@ -682,10 +686,32 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
     a.row = obs_table + (size_t)row * n_cols; a.col_src = col_src; a.col_scale = col_scale; a.state = state;
     a.out_bldg = out_bldg; a.indoor_temp = indoor_temp; a.obs = obs;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_cols = n_cols; a.all_exo = all_exo ? 1 : 0;
+    const bool vec4 = obs_pitch % 4 == 0;            // 16-byte stores need 16-byte aligned rows
+    a.pitch = obs_pitch;
     const int n_seg = (n_cols + OBS_SEG - 1) / OBS_SEG;
     const dim3 grid((dims->n_env + OBS_TILE - 1) / OBS_TILE, n_seg);
-    if (n_seg == 1) hipLaunchKernelGGL(cl_observe_kernel<true>, grid, dim3(OBS_THREADS), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(cl_observe_kernel<false>, grid, dim3(OBS_THREADS), 0, (hipStream_t)stream, a);
+    const int padded = obs_pitch < ((n_cols + 3) & ~3) ? obs_pitch : ((n_cols + 3) & ~3);   // columns written per row
+    a.padded = padded;
+    const bool listed = all_exo || (deps != nullptr && n_deps >= 0 && n_deps <= OBS_DEP_MAX);
+    if (listed && !all_exo)
+        for (int d = 0; d < n_deps; ++d)
+            if (deps[d].col < 0 || deps[d].col >= n_cols || deps[d].src < 0)
+                return fail(CL_EINVAL, "deps[%d]: col=%d src=%d", d, deps[d].col, deps[d].src);
+    // narrow observation vectors (half a wave of 16-byte column groups per row or less): LDS-tile kernel; else row-wise
+    const bool narrow = g_obs_variant == 2 || (g_obs_variant == 0 && padded <= 128);
+    if (n_seg == 1 && padded == obs_pitch && listed && narrow) {
+        static_assert(OBS_DEP_MAX == CLOB_MAX_DEPS, "header and kernel disagree");
+        ObsTileArgs t;
+        int r = g_obs_rows ? g_obs_rows : 16;          // 16 envs = one 64-byte line of every dependent plane
+        while (r * obs_pitch > OBS_BUF) r >>= 1;       // pitch <= OBS_SEG + 3 -> r >= 4
+        a.sub_rows = r;
+        t.o = a;
+        t.n_deps = all_exo ? 0 : n_deps;
+        for (int d = 0; d < t.n_deps; ++d) t.deps[d] = deps[d];
+        const int n_blocks = (dims->n_env + r - 1) / r, per_wg = OBS_TILE / r;
+        hipLaunchKernelGGL(cl_observe_tile_kernel, dim3((n_blocks + per_wg - 1) / per_wg), dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
+    } else if (vec4) hipLaunchKernelGGL(cl_observe_kernel<4>, grid, dim3(OBS_THREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(cl_observe_kernel<1>, grid, dim3(OBS_THREADS), 0, (hipStream_t)stream, a);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_observe_kernel launch");
     return CL_OK;
 }

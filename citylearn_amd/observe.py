@@ -13,6 +13,11 @@ from . import _lib, abi
 from .observations import ObservationTables
 
 
+class ObsDep(ctypes.Structure):
+    """`cl_obs_dep` (include/citylearn_amd.h)."""
+    _fields_ = [('col', ctypes.c_int32), ('src', ctypes.c_int32), ('scale', ctypes.c_float)]
+
+
 class ObservationWriter:
     def __init__(self, engine, tables: ObservationTables, stage=None):
         self.lib = _lib.load()
@@ -27,20 +32,31 @@ class ObservationWriter:
         self.table = torch.from_numpy(np.ascontiguousarray(tables.table, dtype=np.float32)).to(dev)
         self.col_src = torch.from_numpy(np.ascontiguousarray(tables.col_src, dtype=np.int32)).to(dev)
         self.col_scale = torch.from_numpy(np.ascontiguousarray(tables.col_scale, dtype=np.float32)).to(dev)
-        self.obs = torch.empty((engine.n_env, self.n_cols), dtype=torch.float32, device=dev)
-        self.lib.cl_observe_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 7 + [ctypes.c_int32] * 3 + [
-            ctypes.c_uint32, ctypes.c_void_p]
+        # rows padded to a multiple of 4 floats (16-byte stores); `obs` is the [n_env, n_cols] view of that buffer
+        self.pitch = (self.n_cols + 3) // 4 * 4
+        self._buffer = torch.zeros((engine.n_env, self.pitch), dtype=torch.float32, device=dev)
+        self.obs = self._buffer[:, :self.n_cols]
+        # compacted host-side list of the dependent columns: travels in the kernel arguments (fast path)
+        cols = np.nonzero(tables.col_src >= 0)[0]
+        self.n_deps = len(cols) if len(cols) <= abi.CLOB_MAX_DEPS else -1
+        self._deps = None
+        if self.n_deps >= 0:
+            self._deps = (ObsDep * max(self.n_deps, 1))(*[ObsDep(int(c), int(tables.col_src[c]), float(tables.col_scale[c])) for c in cols])
+        self.lib.cl_observe_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 4 + [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [
+            ctypes.c_int32] * 4 + [ctypes.c_uint32, ctypes.c_void_p]
 
     def write(self, row: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Observation returned when ``time_step == row`` (row 0: the reset observation, all columns from the table;
         row r >= 1: exogenous values of r + env-dependent values of the step just simulated)."""
         e = self.engine
         out = self.obs if out is None else out
+        if out.dtype != torch.float32 or out.device != e.device or tuple(out.shape) != (e.n_env, self.n_cols) or out.stride(1) != 1:
+            raise ValueError(f'observation buffer must be float32 [{e.n_env}, {self.n_cols}] with unit column stride')
         temp = None if self.stage is None else self.stage.indoor_temp.data_ptr()
         with torch.cuda.device(e.device):
             _lib.check(self.lib.cl_observe_f32(
                 ctypes.byref(e.dims), self.table.data_ptr(), self.col_src.data_ptr(), self.col_scale.data_ptr(),
-                e.state.data_ptr(), e.out_bldg.data_ptr(), temp, out.data_ptr(), self.n_cols, self.n_rows, int(row),
+                ctypes.cast(self._deps, ctypes.c_void_p) if self._deps is not None else None, self.n_deps, e.state.data_ptr(), e.out_bldg.data_ptr(), temp, out.data_ptr(), self.n_cols, out.stride(0), self.n_rows, int(row),
                 abi.CLOB_ALL_EXOGENOUS if row == 0 else 0, torch.cuda.current_stream(e.device).cuda_stream))
         return out
 

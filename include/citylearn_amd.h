@@ -288,15 +288,23 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_
  *   col_src   [n_cols] i32          -1: env-independent column; else CLOB_SRC(kind, plane, building)
  *   col_scale [n_cols] f32          obs = plane[building][env] * col_scale + obs_table[row][col]
  *   indoor_temp [n_bldg][n_env]     output of cl_lstm_step_f32 (nullable when no column uses CLOB_KIND_TEMP)
+ *   obs [n_env][obs_pitch] f32      obs_pitch >= n_cols floats between rows; a multiple of 4 selects the 16-byte store
+ *                                   path; pad columns up to the next multiple of 4 (bounded by obs_pitch) are written as 0
  * flags: CLOB_ALL_EXOGENOUS -> every column comes from the table (the observation returned by reset()). */
 #define CLOB_KIND_STATE 0           /* plane = enum cl_state */
 #define CLOB_KIND_OUT   1           /* plane = enum cl_out */
 #define CLOB_KIND_TEMP  2           /* indoor_temp */
 #define CLOB_SRC(kind, plane, building) (((kind) << 28) | ((plane) << 20) | (building))
 #define CLOB_ALL_EXOGENOUS (1u << 0)
+#define CLOB_MAX_DEPS 64
+/* One env-dependent column, for the optional HOST-side list `deps` (a compacted copy of col_src / col_scale): when it
+ * is given, has n_deps <= CLOB_MAX_DEPS entries and n_cols <= 1024, the list travels in the kernel arguments and the
+ * launch takes the fast path (no column-map walk on the device).  Pass deps = NULL, n_deps = -1 otherwise. */
+typedef struct cl_obs_dep { int32_t col; int32_t src; float scale; } cl_obs_dep;
 int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* col_src, const float* col_scale,
+                   const cl_obs_dep* deps /* host memory, nullable */, int32_t n_deps,
                    const float* state, const float* out_bldg, const float* indoor_temp, float* obs, int32_t n_cols,
-                   int32_t n_rows, int32_t row, uint32_t flags, void* stream);
+                   int32_t obs_pitch, int32_t n_rows, int32_t row, uint32_t flags, void* stream);
 
 /* Philox4x32-10 reference draw used by cl_rollout_f32 (host-callable so tests can reproduce the policy):
  * returns u in [0,1) for (seed, env, col, t). */

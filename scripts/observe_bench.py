@@ -22,6 +22,14 @@ def timed(fn, n=50, warm=5):
     return e0.elapsed_time(e1) / n * 1e3
 
 
+x = torch.empty((65536, 476), device='cuda'); y = torch.empty_like(x)
+us = timed(lambda: x.fill_(1.0)); print(f'torch fill_ of {x.numel()*4/1e6:.0f} MB: {us:.1f} us  {x.numel()*4/us/1e3:.0f} GB/s written')
+us = timed(lambda: y.copy_(x)); print(f'torch copy_ of {x.numel()*4/1e6:.0f} MB: {us:.1f} us  {2*x.numel()*4/us/1e3:.0f} GB/s read+written')
+del x, y
+x = torch.empty((262144, 476), device='cuda')
+us = timed(lambda: x.fill_(1.0), n=20); print(f'torch fill_ of {x.numel()*4/1e6:.0f} MB: {us:.1f} us  {x.numel()*4/us/1e3:.0f} GB/s written')
+del x
+
 for name, E in (('g2022_all', 65536), ('g2022_all', 262144), ('g2020_cz1', 65536), ('g2023_p2', 65536)):
     g = golden(name); spec = g.spec(); tab = spec.episode_tables(0)
     for normalize in (False, True):
@@ -34,8 +42,20 @@ for name, E in (('g2022_all', 65536), ('g2022_all', 262144), ('g2020_cz1', 65536
             stage = LSTMStage(spec, tab, eng)
         w = ObservationWriter(eng, ot, stage)
         acts = torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1
+        w.lib.cl_debug_set_observe(1, 0); us_row = timed(lambda: w.write(7))
+        alt = []
+        for rows in (8, 16, 64):
+            w.lib.cl_debug_set_observe(2, rows); alt.append(f'{rows}: {timed(lambda: w.write(7)):.1f}')
+        w.lib.cl_debug_set_observe(0, 0)
         us = timed(lambda: w.write(7))
+        us0 = timed(lambda: w.write(0))
+        rowt = w.table[7]
+        dense = torch.empty((E, w.n_cols), device='cuda')
+        us_t = timed(lambda: dense.copy_(rowt.expand(E, -1)))
+        print(f'   (all-exogenous write(0): {us0:.1f} us; torch broadcast copy_ of the row: {us_t:.1f} us)')
+        del dense
         by = w.algorithmic_bytes()
+        print(f'   (row-wise kernel: {us_row:.1f} us; tile kernel by block rows: {", ".join(alt)} us)')
         both = timed(lambda: (eng.step(acts, 7), w.write(8)))
         step_b = eng.algorithmic_bytes_per_unit() * eng.n_bldg * E
         print(f'{name} E={E} n_cols={w.n_cols} dep={ot.n_dependent} norm={normalize}: observe {us:.1f} us  {by/us/1e3:.0f} GB/s '

@@ -46,9 +46,26 @@ def test_kernel_matches_host_statement(n_env, n_cols, n_dep):
     w = ObservationWriter(eng, ot, stage)
     st, ob, tp = eng.state.cpu().numpy(), eng.out_bldg.cpu().numpy(), stage.indoor_temp.cpu().numpy()
     t32 = table.astype('float32').astype('float64')
+    dense = torch.empty((n_env, n_cols), dtype=torch.float32, device='cuda')     # unpadded rows: scalar-store path
     for row in (0, 3):
         got = w.write(row).cpu().numpy()
         assert got.shape == (n_env, n_cols)
+        assert np.array_equal(got, w.write(row, out=dense).cpu().numpy())
+        assert not w._buffer[:, n_cols:].any()
+        wide = torch.full((n_env, n_cols + 9), 7.0, dtype=torch.float32, device='cuda')     # view into a wider buffer
+        assert np.array_equal(got, w.write(row, out=wide[:, :n_cols]).cpu().numpy())
+        assert bool((wide[:, (n_cols + 3) // 4 * 4:] == 7.0).all())                        # nothing beyond the pad is touched
+        deps, nd = w._deps, w.n_deps
+        w._deps, w.n_deps = None, -1                                                       # no host list: device column map
+        assert np.array_equal(got, w.write(row).cpu().numpy())
+        w._deps, w.n_deps = deps, nd
+        w.lib.cl_debug_set_observe(1, 0)                                                    # row-wise kernel on every shape
+        assert np.array_equal(got, w.write(row).cpu().numpy())
+        assert np.array_equal(got, w.write(row, out=dense).cpu().numpy())
+        for rows in (0, 4, 8, 32, 64):                                                     # LDS-tile kernel, block heights
+            w.lib.cl_debug_set_observe(2, rows)
+            assert np.array_equal(got, w.write(row).cpu().numpy())
+        w.lib.cl_debug_set_observe(0, 0)
         for e in (0, 1, n_env // 2, n_env - 1):
             want = ObservationTables(t32, src, scale, False).host_row(row, st[:, :, e], ob[:, :, e], tp[:, e])
             np.testing.assert_allclose(got[e], want, rtol=1e-6, atol=1e-6)
@@ -66,12 +83,21 @@ def test_observe_validates_arguments():
     w = ObservationWriter(eng, ot)
     with pytest.raises(_lib.EngineError, match='row'):
         w.write(w.n_rows)
-    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), None, None, None, None, None, w.obs.data_ptr(),
-                              w.n_cols, w.n_rows, 1, 0, None)
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), None, None, None, -1, None, None, None, w.obs.data_ptr(),
+                              w.n_cols, w.pitch, w.n_rows, 1, 0, None)
     assert rc == abi.CL_ENULL
-    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr() + 4, None, None, None, None, None, w.obs.data_ptr(),
-                              w.n_cols, w.n_rows, 0, abi.CLOB_ALL_EXOGENOUS, None)
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr() + 4, None, None, None, -1, None, None, None, w.obs.data_ptr(),
+                              w.n_cols, w.pitch, w.n_rows, 0, abi.CLOB_ALL_EXOGENOUS, None)
     assert rc == abi.CL_EALIGN
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), None, None, None, -1, None, None, None, w.obs.data_ptr(),
+                              w.n_cols, w.n_cols - 1, w.n_rows, 0, abi.CLOB_ALL_EXOGENOUS, None)
+    assert rc == abi.CL_EINVAL
+    from citylearn_amd.observe import ObsDep
+    bad = (ObsDep * 1)(ObsDep(w.n_cols, 0, 1.0))                                         # column outside the table
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), w.col_src.data_ptr(), w.col_scale.data_ptr(),
+                              ctypes.cast(bad, ctypes.c_void_p), 1, eng.state.data_ptr(), eng.out_bldg.data_ptr(), None,
+                              w.obs.data_ptr(), w.n_cols, w.pitch, w.n_rows, 1, 0, None)
+    assert rc == abi.CL_EINVAL
     from citylearn_amd.engine import StepEngine
     lean = StepEngine(tables, 64, reward='RewardFunction', detail=False)
     spec2 = g.spec()
