@@ -235,7 +235,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         const float c_b = first ? 2.0f * eb : eb;
         const float net = (c_ns + c_b) * B.r + R.sol;
         O.net = net; O.cost = net * R.price; O.emission = fmaxf(0.0f, net * R.carbon);
-        O.eb = eb; O.cool_dem = 0.0f; O.heat_dem = 0.0f; O.dhw_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns;
+        O.eb = eb; O.cool_dem = 0.0f; O.heat_dem = 0.0f; O.dhw_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns * B.r;
         O.base_net = net - c_b * B.r; O.expected = R.nsl; O.served = R.nsl;
         return;
     } else {
@@ -306,7 +306,8 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         O.cool_dem = e_cool + fabsf(fminf(eb_cs, 0.0f));          // building.py:1435-1437
         O.heat_dem = e_heat + fabsf(fminf(eb_hs, 0.0f));
         O.dhw_dem = e_dhw + fabsf(fminf(eb_ds, 0.0f));
-        O.c_cool = A.c_cool; O.c_heat = A.c_heat; O.c_dhw = A.c_dhw; O.c_ns = A.c_ns;
+        // what Device.electricity_consumption reports: accumulator * time_step_ratio (energy_model.py:118)
+        O.c_cool = A.c_cool * B.r; O.c_heat = A.c_heat * B.r; O.c_dhw = A.c_dhw * B.r; O.c_ns = A.c_ns * B.r;
         // evaluate()'s baseline: remove what the storages did (building.py:345-366, 413-463) and, for dynamics
         // buildings, add back the ideal-vs-delivered load difference (building.py:2877-2905)
         float base = net - (eb_cs * R.icop_c + eb_hs * R.icop_h + eb_ds * R.icop_d + A.c_b * B.r);

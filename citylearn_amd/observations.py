@@ -287,6 +287,9 @@ class ObservationLayout:
             if self.normalize and name.rsplit('_', 1)[0] in PERIODIC and name.rsplit('_', 1)[-1] in ('cos', 'sin'):
                 raw, part = name.rsplit('_', 1)
             values, source, offset = self._raw_column(i, raw, tab)
+            # CLO_B_EB holds the battery's energy balance; the observation is its electricity consumption, i.e. the
+            # balance times time_step_ratio (energy_model.py:118)
+            gain = float(self.spec.buildings[i].time_step_ratio) if raw == 'electrical_storage_electricity_consumption' else 1.0
             if part is not None:
                 x = 2 * np.pi * values / PERIODIC[raw]
                 values = np.cos(x) if part == 'cos' else np.sin(x)
@@ -302,7 +305,7 @@ class ObservationLayout:
                 if kind == SRC_OUT and plane in _DETAIL_PLANES:
                     needs_detail = True
                 src[c] = (kind << 28) | (plane << 20) | i
-                scale[c] = a
+                scale[c] = a * gain
                 table[1:, c] = a * offset[:-1] + b0
                 table[0, c] = a * values[0] + b0
             else:

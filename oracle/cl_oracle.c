@@ -276,7 +276,8 @@ void cl_oracle_step(int n_env, int n_bldg, const double* params, const double* t
             S[OS_SOC] = es.soc; S[OS_EFF] = eff; S[OS_DEGCAP] = degcap; S[OS_CS] = cs.soc; S[OS_HS] = hs.soc; S[OS_DS] = ds.soc;
             O[OO_NET] = net32; O[OO_EB] = es.eb;
             O[OO_COOL_DEM] = e_cool + fabs(cs.eb < 0 ? cs.eb : 0.0);
-            O[OO_C_COOL] = u.c_cool; O[OO_C_HEAT] = u.c_heat; O[OO_C_DHW] = u.c_dhw; O[OO_C_NS] = u.c_ns;
+            /* Device.electricity_consumption = accumulator * time_step_ratio (energy_model.py:118) */
+            O[OO_C_COOL] = u.c_cool * u.r; O[OO_C_HEAT] = u.c_heat * u.r; O[OO_C_DHW] = u.c_dhw * u.r; O[OO_C_NS] = u.c_ns * u.r;
             O[OO_COST] = f32(net * row[OT_PRICE]);
             double em = net * row[OT_CARBON];
             O[OO_EMISSION] = f32(em > 0 ? em : 0);

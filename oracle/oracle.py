@@ -488,10 +488,11 @@ class DistrictOracle:
                     out['cs_soc'][b, e] = u.cs.soc
                     out['hs_soc'][b, e] = u.hs.soc
                     out['ds_soc'][b, e] = u.ds.soc
-                    out['c_cool'][b, e] = u.c_cool
-                    out['c_heat'][b, e] = u.c_heat
-                    out['c_dhw'][b, e] = u.c_dhw
-                    out['c_ns'][b, e] = u.c_ns
+                    # what `Device.electricity_consumption` reports: the accumulator times time_step_ratio (energy_model.py:118)
+                    out['c_cool'][b, e] = u.c_cool * u.r
+                    out['c_heat'][b, e] = u.c_heat * u.r
+                    out['c_dhw'][b, e] = u.c_dhw * u.r
+                    out['c_ns'][b, e] = u.c_ns * u.r
                     out['cool_dem'][b, e] = u.delivered_cooling()
                     out['base_net'][b, e] = u.net_without_storage_and_partial_load() if u.spec.is_dynamics \
                         else u.net_without_storage()

@@ -43,10 +43,12 @@ FIXTURES = {
     'g2022_p1_year': ('citylearn_challenge_2022_phase_1', 8760, 8759, 0, True, {}),
     'g2020_cz1': ('citylearn_challenge_2020_climate_zone_1', 744, 743, 2020, False, {}),
     'g2023_p2': ('citylearn_challenge_2023_phase_2_local_evaluation', 720, 719, 2023, False, {}),
+    # sub-hourly control of hourly data files: time_step_ratio = 0.25 paths (data.py:427-455; energy_model.py:732, 863, 1036, 1139)
+    'g2020_15min': ('citylearn_challenge_2020_climate_zone_1', 400, 399, 15, False, {'seconds_per_time_step': 900}),
 }
 
 
-def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool):
+def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict = None):
     import pandas as pd
     dst.mkdir(parents=True, exist_ok=True)
     schema = json.loads((src / 'schema.json').read_text())
@@ -54,6 +56,7 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool):
     schema['simulation_end_time_step'] = rows - 1
     schema['root_directory'] = None
     schema.pop('agent', None)
+    schema.update(overrides or {})          # top-level schema keys (same effect as the constructor kwargs, citylearn.py:2006-2051)
     files = set()
     for b in schema['buildings'].values():
         for k in ('energy_simulation', 'weather', 'carbon_intensity', 'pricing'):
@@ -82,7 +85,7 @@ def run_reference(name: str):
     out_dir = GOLDEN / name
     if out_dir.exists():
         shutil.rmtree(out_dir)
-    make_mini_dataset(ref_env.REFERENCE_ROOT / 'data' / 'datasets' / dataset, out_dir / 'dataset', rows, gz)
+    make_mini_dataset(ref_env.REFERENCE_ROOT / 'data' / 'datasets' / dataset, out_dir / 'dataset', rows, gz, env_kwargs)
 
     ref_env.setup_reference()
     from citylearn.citylearn import CityLearnEnv
@@ -90,7 +93,7 @@ def run_reference(name: str):
     from citylearn.building import DynamicsBuilding
     from citylearn.energy_model import HeatPump
 
-    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'), **env_kwargs)
+    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
     B = len(env.buildings)
     low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
     high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
@@ -244,7 +247,7 @@ def run_observations(name: str, steps: int = None):
     from citylearn.citylearn import CityLearnEnv
     from citylearn.wrappers import NormalizedObservationWrapper
 
-    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'), **env_kwargs)
+    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
     wrapped = NormalizedObservationWrapper(env)
     B = len(env.buildings)
     low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')

@@ -6,7 +6,7 @@ from pathlib import Path
 import numpy as np
 
 GOLDEN = Path(__file__).resolve().parent / 'golden'
-FIXTURES = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2022_p1_year')
+FIXTURES = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2022_p1_year', 'g2020_15min')
 
 
 class Golden:

@@ -73,7 +73,7 @@ def test_lean_kernel_teacher_forced(kind, vec):
     assert max(worst.values()) < 1.0, worst
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
 @pytest.mark.parametrize('kind', REWARDS)
 def test_full_kernel_teacher_forced(name, kind):
     """Heat pump / heater / tanks (2020), outage + partial-load cooling (2023), and the 2022 schema through the
@@ -89,7 +89,7 @@ def test_full_kernel_vec2(name):
     assert max(worst.values()) < 1.0, worst
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
 def test_free_running_whole_fixture(name):
     worst, _ = _run(name, 'RewardFunction', 1, detail=False, teach=False, atol=1e-3, rtol=1e-3)
     assert max(worst.values()) < 1.0, worst

@@ -10,7 +10,7 @@ from citylearn_amd import abi
 from citylearn_amd.schema import load_district
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
 def test_loader_matches_reference_facts(name):
     g = golden(name)
     spec = g.spec()
