@@ -39,6 +39,7 @@ struct StepArgs {
     float* __restrict__ kpi_bldg;
     float* __restrict__ kpi_env;
     long long act_stride_col, act_stride_env;
+    const int32_t* __restrict__ env_row0;   // per-env-block episode offsets (cl_dims.env_row0) or null
     int n_env, n_bldg, n_steps, n_act_cols;
     uint32_t flags;
     int t;
@@ -177,11 +178,13 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     const int b_lo = blockIdx.y * a.b_chunk;
     const int b_hi = min(a.n_bldg, b_lo + a.b_chunk);
     const bool marl_partial = rkind == CLR_MARL && a.n_chunks > 1;
+    // table row of this env tile: TILE divides CL_ROW0_BLOCK, so the offset is workgroup-uniform (scalar load)
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
     for (int b = b_lo + w; b < b_hi; b += a.nw) {
         cl::Bp B;
         cl::load_bp<FULL>(B, a.params + (long long)b * CL_NP);
         cl::Row R;
-        cl::load_row<FULL>(R, a.ts + ((long long)a.t * a.n_bldg + b) * CL_NF, B.flags);
+        cl::load_row<FULL>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags);
         if (live) {
             const long long off = (long long)b * a.n_env + env0;
             float s_soc[VEC], s_eff[VEC], s_deg[VEC], s_cs[VEC], s_hs[VEC], s_ds[VEC];
@@ -310,7 +313,8 @@ __global__ void cl_kpi_bldg_kernel(const StepArgs a) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= plane) return;
     const int b = (int)(i / a.n_env);
-    const float* q = a.ts + ((long long)a.t * a.n_bldg + b) * CL_NF;
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(int)(i - (long long)b * a.n_env) / CL_ROW0_BLOCK] : 0);
+    const float* q = a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF;
     const float price = q[CLT_PRICE], carbon = q[CLT_CARBON];
     const bool outage = q[CLT_OUTAGE] != 0.0f;
     const float net = a.out_bldg[CLO_NET * plane + i], base = a.out_bldg[CLO_BASE_NET * plane + i];
@@ -422,6 +426,9 @@ int check_dims(const cl_dims* d) {
         return fail(CL_EINVAL, "bad dims: n_env=%d n_bldg=%d n_steps=%d n_act_cols=%d", d->n_env, d->n_bldg,
                     d->n_steps, d->n_act_cols);
     if (d->n_env % 4 != 0) return fail(CL_EALIGN, "n_env=%d must be a multiple of 4 (pad the env batch)", d->n_env);
+    if (d->n_ts_rows != 0 && d->n_ts_rows < d->n_steps)
+        return fail(CL_EINVAL, "n_ts_rows=%d < n_steps=%d", d->n_ts_rows, d->n_steps);
+    if (reinterpret_cast<uintptr_t>(d->env_row0) & 3) return fail(CL_EALIGN, "env_row0 is not 4-byte aligned");
     const uint32_t rk = (d->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     if (rk > CLR_SOLAR_PENALTY) return fail(CL_EINVAL, "unknown reward kind %u", rk);
     return CL_OK;
@@ -511,7 +518,7 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
     a.kpi_bldg = kpi_bldg; a.kpi_env = kpi_env;
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
-    a.flags = dims->flags; a.t = t;
+    a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
     a.nw = g_force_nw ? g_force_nw : pick_nw(dims->n_bldg, 1);
     // general kernel: two buildings per wave measured fastest for the 6..16-building thermal schemas (fewer, longer waves)
@@ -607,7 +614,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     a.kpi_bldg = nullptr; a.kpi_env = nullptr;
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
-    a.flags = dims->flags; a.t = t0; a.b_chunk = dims->n_bldg; a.n_chunks = 1;
+    a.flags = dims->flags; a.t = t0; a.b_chunk = dims->n_bldg; a.n_chunks = 1; a.env_row0 = dims->env_row0;
     r.act_stride_step = act_stride_step; r.act_low = act_low; r.act_high = act_high; r.ret_env = ret_env; r.seed = seed;
     r.t0 = t0; r.k_steps = k_steps;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
@@ -658,7 +665,7 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_
     LstmArgs a;
     a.lstm_w = lstm_w; a.dyn_pre = dyn_pre; a.cool_dem = cool_dem; a.hist = hist; a.hidden = hidden; a.indoor_temp = indoor_temp;
     a.heat_dem = heat_dem; a.comfort = comfort;
-    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t;
+    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t; a.env_row0 = dims->env_row0;
     const dim3 grid((dims->n_env + 127) / 128, dims->n_bldg);          // 4 waves x 32 envs per workgroup
     hipLaunchKernelGGL(cl_lstm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_kernel launch");
@@ -686,6 +693,7 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
     a.row = obs_table + (size_t)row * n_cols; a.col_src = col_src; a.col_scale = col_scale; a.state = state;
     a.out_bldg = out_bldg; a.indoor_temp = indoor_temp; a.obs = obs;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_cols = n_cols; a.all_exo = all_exo ? 1 : 0;
+    a.env_row0 = dims->env_row0;
     const bool vec4 = obs_pitch % 4 == 0;            // 16-byte stores need 16-byte aligned rows
     a.pitch = obs_pitch;
     const int n_seg = (n_cols + OBS_SEG - 1) / OBS_SEG;
@@ -699,7 +707,7 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
                 return fail(CL_EINVAL, "deps[%d]: col=%d src=%d", d, deps[d].col, deps[d].src);
     // narrow observation vectors (half a wave of 16-byte column groups per row or less): LDS-tile kernel; else row-wise
     const bool narrow = g_obs_variant == 2 || (g_obs_variant == 0 && padded <= 128);
-    if (n_seg == 1 && padded == obs_pitch && listed && narrow) {
+    if (n_seg == 1 && padded == obs_pitch && listed && narrow && dims->env_row0 == nullptr) {   // one template row per launch
         static_assert(OBS_DEP_MAX == CLOB_MAX_DEPS, "header and kernel disagree");
         ObsTileArgs t;
         int r = g_obs_rows ? g_obs_rows : 16;          // 16 envs = one 64-byte line of every dependent plane

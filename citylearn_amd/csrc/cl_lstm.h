@@ -85,6 +85,7 @@ struct LstmArgs {
     float* __restrict__ indoor_temp;      // [B][E] out: indoor dry-bulb temperature of step t [C]
     const float* __restrict__ heat_dem;   // [B][E] delivered heating (may be NULL = 0)
     float* __restrict__ comfort;          // [B][E] out: ComfortReward of step t (may be NULL)
+    const int32_t* __restrict__ env_row0;  // per-env-block episode offsets (cl_dims.env_row0) or null
     int n_env, n_bldg, t;
 };
 
@@ -119,7 +120,8 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const long long plane = (long long)a.n_bldg * a.n_env;
     const long long off = (long long)b * a.n_env + ec;
     const float* __restrict__ W = a.lstm_w + (long long)b * CL_LSTM_NW;
-    const float* __restrict__ pre_t = a.dyn_pre + ((long long)a.t * a.n_bldg + b) * CL_LSTM_NPRE;
+    const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * 128) / CL_ROW0_BLOCK] : 0;      // workgroup = 128 envs: uniform
+    const float* __restrict__ pre_t = a.dyn_pre + ((long long)(a.t + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
     const float cool = a.cool_dem[off];
     float temp = pre_t[CLPRE_TRAW];
     if (W[CLW_ACTIVE] != 0.0f) {                                  // block-uniform
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             }
             for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
                 const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
-                const float* __restrict__ pre = a.dyn_pre + ((long long)time * a.n_bldg + b) * CL_LSTM_NPRE;
+                const float* __restrict__ pre = a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
                 // extra k-pair of layer 0: slot 0 = cooling demand at `time`, slot 1 = temperature at `time - 1`
                 const long long hrow = hh ? (long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) : (long long)(time % CL_LSTM_LOOKBACK);
                 float xin = a.hist[hrow * plane + off];

@@ -21,6 +21,7 @@ constexpr int OBS_THREADS = 256;
 
 struct ObsArgs {
     const float* __restrict__ row;          // obs_table + row * n_cols
+    const int32_t* __restrict__ env_row0;   // per-env-block episode offsets (cl_dims.env_row0) or null: row += env_row0[block]
     const int32_t* __restrict__ col_src;    // [n_cols] -1: env-independent; else kind << 28 | plane << 20 | building
     const float* __restrict__ col_scale;    // [n_cols]
     const float* __restrict__ state;        // [CL_NS][B][E]
@@ -58,6 +59,8 @@ __global__ __launch_bounds__(OBS_THREADS) void cl_observe_kernel(ObsArgs a) {
     const int seg_n = min(OBS_SEG, a.n_cols - c0);                 // logical columns of this segment
     const int seg_w = min(OBS_SEG, a.padded - c0);                 // incl. the pad columns of the last segment
     const int n_rows = min(OBS_TILE, a.n_env - env0);
+    // OBS_TILE divides CL_ROW0_BLOCK: the table row of this tile is workgroup-uniform
+    const float* __restrict__ trow = a.row + (a.env_row0 ? (long long)a.env_row0[env0 / CL_ROW0_BLOCK] * a.n_cols : 0);
     if (tid == 0) n_dep_s = 0;
     __syncthreads();
     for (int c = tid; c < seg_n; c += OBS_THREADS) {
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(OBS_THREADS) void cl_observe_kernel(ObsArgs a) {
         int slot = -1;
         if (s >= 0) {
             slot = atomicAdd(&n_dep_s, 1);
-            if (slot < OBS_DEP_MAX) { dep_src_s[slot] = s; dep_scale_s[slot] = a.col_scale[c0 + c]; dep_base_s[slot] = a.row[c0 + c]; }
+            if (slot < OBS_DEP_MAX) { dep_src_s[slot] = s; dep_scale_s[slot] = a.col_scale[c0 + c]; dep_base_s[slot] = trow[c0 + c]; }
         }
         slot_s[c] = slot;
     }
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(OBS_THREADS) void cl_observe_kernel(ObsArgs a) {
         for (int v = 0; v < VEC; ++v) {
             const int c = (lane + 64 * k) * VEC + v;
             const bool live = c < seg_n;
-            exo[k][v] = live ? a.row[c0 + c] : 0.0f;
+            exo[k][v] = live ? trow[c0 + c] : 0.0f;
             slot[k][v] = live ? slot_s[c] : -1;
             any_dep[k] |= slot[k][v] >= 0;
         }

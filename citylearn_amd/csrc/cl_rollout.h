@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
     float last_rw[MB][VEC];
     cl::U4 rnd[MB][VEC];
 
+    const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * 64 * VEC) / CL_ROW0_BLOCK] : 0;   // workgroup-uniform
     for (int k = 0; k < r.k_steps; ++k) {
         const int t = r.t0 + k;
 #pragma unroll
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
             if (!own[m]) continue;                                       // wave-uniform
             const int b = w + m * a.nw;
             cl::Row R;
-            cl::load_row<FULL>(R, a.ts + ((long long)t * a.n_bldg + b) * CL_NF, B[m].flags);
+            cl::load_row<FULL>(R, a.ts + ((long long)(t + row0) * a.n_bldg + b) * CL_NF, B[m].flags);
             float a_es[VEC], a_cs[VEC], a_hs[VEC], a_ds[VEC], a_cd[VEC], a_hd[VEC];
             rollout_action_cached<VEC>(a_es, rnd[m], r, B[m].a_es, env0, t, k);
             if constexpr (FULL) {

@@ -36,7 +36,11 @@ class StepEngine:
     """
 
     def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
-                 t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False):
+                 t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False,
+                 n_steps: Optional[int] = None, env_row0=None):
+        """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
+        simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
+        at table row ``env_row0[g]`` -- different blocks replay different windows at once."""
         self.lib = _lib.load()                      # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
@@ -45,7 +49,21 @@ class StepEngine:
         self.device = torch.device(device)
         self.n_env = int(n_env)
         self.n_bldg = int(tables.params.shape[0])
-        self.n_steps = int(tables.ts.shape[0])
+        self.n_ts_rows = int(tables.ts.shape[0])
+        self.n_steps = self.n_ts_rows if n_steps is None else int(n_steps)
+        if not 0 < self.n_steps <= self.n_ts_rows:
+            raise ValueError(f'n_steps={self.n_steps} outside (0, {self.n_ts_rows}]')
+        self.env_row0 = None
+        if env_row0 is not None:
+            row0 = np.asarray(env_row0, dtype=np.int64).reshape(-1)
+            n_blocks = -(-self.n_env // abi.CL_ROW0_BLOCK)
+            if row0.shape[0] != n_blocks:
+                raise ValueError(f'env_row0 needs {n_blocks} entries (one per {abi.CL_ROW0_BLOCK} envs), got {row0.shape[0]}')
+            if row0.min() < 0 or row0.max() + self.n_steps > self.n_ts_rows:
+                raise ValueError(f'env_row0 + n_steps must stay inside the {self.n_ts_rows} table rows')
+            if kpi:
+                raise NotImplementedError('streaming KPIs are defined for one common episode window')
+            self.env_row0_host = row0.astype(np.int32)
         if n_act_cols is None:
             cols = tables.params.view(np.int32)[:, abi.CLP_ACT_COOL_STO:abi.CLP_ACT_COH_DEV + 1]
             n_act_cols = int(cols.max()) + 1
@@ -60,7 +78,11 @@ class StepEngine:
         heavy = abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS
         self.lean = not bool(np.any(bflags & heavy)) and not bool(np.any(tables.ts[:, :, [abi.CLT_COOL_DEM, abi.CLT_HEAT_DEM, abi.CLT_DHW_DEM]]))
         flags |= abi.CLD_LEAN if self.lean else 0
-        self.dims = _lib.Dims(self.n_env, self.n_bldg, self.n_steps, self.n_act_cols, flags)
+        with torch.cuda.device(self.device):
+            if env_row0 is not None:
+                self.env_row0 = torch.from_numpy(self.env_row0_host).to(self.device)
+        self.dims = _lib.Dims(self.n_env, self.n_bldg, self.n_steps, self.n_act_cols, flags, self.n_ts_rows,
+                              None if self.env_row0 is None else self.env_row0.data_ptr())
         with torch.cuda.device(self.device):
             self.params = torch.from_numpy(tables.params.view(np.int32).copy()).to(self.device)
             self.ts = torch.from_numpy(np.ascontiguousarray(tables.ts)).to(self.device)

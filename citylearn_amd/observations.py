@@ -249,34 +249,41 @@ class ObservationLayout:
             return np.asarray(b.series[k][w], dtype=np.float64), _DEVICE_SOURCE[k], zeros
         if k in ENV_DEPENDENT:
             stale = zeros.copy()                 # the reference reads the not-yet-simulated (zero) slot of t+1 (App. B3)
-            pf = tab.params_f32()[i].astype(np.float64)
-            first = {'electrical_storage_soc': pf[abi.CLP_B_SOC0], 'cooling_storage_soc': pf[abi.CLP_CS_SOC0],
-                     'heating_storage_soc': pf[abi.CLP_HS_SOC0], 'dhw_storage_soc': pf[abi.CLP_DS_SOC0]}
-            first.update(self._reset_values(i, tab))
-            stale[0] = first.get(k, 0.0)
+            stale[0] = self._reset_series(i, k, tab)[0]
             return stale, _DEVICE_SOURCE.get(k), zeros
         if k in b.series and isinstance(b.series[k], np.ndarray):
             return np.asarray(b.series[k][w], dtype=np.float64), None, zeros
         raise KeyError(f'observation {k!r} cannot be produced for building {b.name}')
 
-    def _reset_values(self, i: int, tab: EpisodeTables) -> Dict[str, float]:
-        """Env-dependent observation values right after `reset()` (the reference's `update_variables` at t = 0)."""
-        ts = tab.ts[0, i].astype(np.float64)
+    def _reset_series(self, i: int, k: str, tab: EpisodeTables) -> Optional[np.ndarray]:
+        """Value of env-dependent observation `k` right after `reset()` (the reference's `update_variables` at t = 0,
+        building.py:2618-2652) for an episode starting at each table row; None for env-independent observations."""
+        if k not in ENV_DEPENDENT or k in ('cooling_demand', 'heating_demand', 'dhw_demand'):
+            return None
+        ts = tab.ts[:, i].astype(np.float64)
         pf = tab.params_f32()[i].astype(np.float64)
+        ones = np.ones(tab.n_steps)
+        const = {'electrical_storage_soc': pf[abi.CLP_B_SOC0], 'cooling_storage_soc': pf[abi.CLP_CS_SOC0],
+                 'heating_storage_soc': pf[abi.CLP_HS_SOC0], 'dhw_storage_soc': pf[abi.CLP_DS_SOC0]}
+        if k in const:
+            return const[k] * ones
         if not self.reference_quirks:
-            return {}
-        outage0 = bool(ts[abi.CLT_OUTAGE])
-        c_cool = ts[abi.CLT_COOL_DEM] * ts[abi.CLT_ICOP_COOL]
-        c_heat = ts[abi.CLT_HEAT_DEM] * pf[abi.CLP_T0_IHEAT_DIV]
-        c_dhw = ts[abi.CLT_DHW_DEM] * ts[abi.CLT_ICOP_DHW]
+            return 0.0 * ones
+        heat_hp = bool(tab.params[i, abi.CLP_FLAGS] & abi.CLF_HEAT_IS_HP)
+        c_cool = ts[:, abi.CLT_COOL_DEM] * ts[:, abi.CLT_ICOP_COOL]
+        c_heat = ts[:, abi.CLT_HEAT_DEM] * (ts[:, abi.CLT_ICOP_HEAT] if heat_hp else pf[abi.CLP_T0_IHEAT_DIV])
+        c_dhw = ts[:, abi.CLT_DHW_DEM] * ts[:, abi.CLT_ICOP_DHW]
+        net = np.where(ts[:, abi.CLT_OUTAGE] != 0, 0.0, c_cool + c_heat + c_dhw + ts[:, abi.CLT_NSL] + ts[:, abi.CLT_SOLAR])
         return {'cooling_electricity_consumption': c_cool, 'heating_electricity_consumption': c_heat,
-                'dhw_electricity_consumption': c_dhw,
-                'net_electricity_consumption': 0.0 if outage0 else c_cool + c_heat + c_dhw + ts[abi.CLT_NSL] + ts[abi.CLT_SOLAR]}
+                'dhw_electricity_consumption': c_dhw, 'net_electricity_consumption': net}.get(k, 0.0 * ones)
 
-    def episode(self, tab: EpisodeTables) -> 'ObservationTables':
-        """Pack the episode window: host table (row r = observation returned when ``time_step == r``) and device map."""
+    def episode(self, tab: EpisodeTables, reset_table: bool = False) -> 'ObservationTables':
+        """Pack the episode window: host table (row r = observation returned when ``time_step == r``) and device map.
+        `reset_table`: also pack, for every table row r, the observation `reset()` returns for an episode that STARTS at
+        row r (per-env-block episode windows, `cl_dims.env_row0`): rows >= 1 of `table` are start-independent, row 0 is not."""
         T, N = tab.n_steps, self.n_cols
         table = np.zeros((T, N), dtype=np.float64)
+        resets = np.zeros((T, N), dtype=np.float64) if reset_table else None
         src = np.full(N, -1, dtype=np.int32)
         scale = np.zeros(N, dtype=np.float64)
         needs_detail = False
@@ -299,6 +306,9 @@ class ObservationLayout:
                     a, b0 = 0.0, 0.0                           # preprocessing.py:143-144
                 else:
                     a, b0 = 1.0 / (hi[c] - lo[c]), -lo[c] / (hi[c] - lo[c])
+            if resets is not None:
+                rv = self._reset_series(i, raw, tab)
+                resets[:, c] = a * (values if rv is None else rv) + b0
             if self.mode == 'current' and source is not None:
                 # row r (r >= 1) pairs exogenous values of r with env-dependent values computed at r - 1
                 kind, plane = source
@@ -314,12 +324,15 @@ class ObservationLayout:
                 table[:, c] = a * values + b0
         if unsupported:
             raise NotImplementedError(f"observation_mode='current' has no device plane for {sorted(set(unsupported))}")
-        return ObservationTables(table=table, col_src=src, col_scale=scale.astype(np.float32), needs_detail=needs_detail)
+        return ObservationTables(table=table, col_src=src, col_scale=scale.astype(np.float32), needs_detail=needs_detail,
+                                 reset_table=resets)
 
 
 class ObservationTables:
-    def __init__(self, table: np.ndarray, col_src: np.ndarray, col_scale: np.ndarray, needs_detail: bool):
+    def __init__(self, table: np.ndarray, col_src: np.ndarray, col_scale: np.ndarray, needs_detail: bool,
+                 reset_table: Optional[np.ndarray] = None):
         self.table, self.col_src, self.col_scale, self.needs_detail = table, col_src, col_scale, needs_detail
+        self.reset_table = reset_table
 
     @property
     def n_dependent(self) -> int:

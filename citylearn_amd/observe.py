@@ -30,6 +30,11 @@ class ObservationWriter:
         dev = engine.device
         self.n_rows, self.n_cols = tables.table.shape
         self.table = torch.from_numpy(np.ascontiguousarray(tables.table, dtype=np.float32)).to(dev)
+        self.reset_table = None
+        if engine.env_row0 is not None:
+            if tables.reset_table is None:
+                raise ValueError('per-env-block episode windows need ObservationLayout.episode(tables, reset_table=True)')
+            self.reset_table = torch.from_numpy(np.ascontiguousarray(tables.reset_table, dtype=np.float32)).to(dev)
         self.col_src = torch.from_numpy(np.ascontiguousarray(tables.col_src, dtype=np.int32)).to(dev)
         self.col_scale = torch.from_numpy(np.ascontiguousarray(tables.col_scale, dtype=np.float32)).to(dev)
         # rows padded to a multiple of 4 floats (16-byte stores); `obs` is the [n_env, n_cols] view of that buffer
@@ -55,7 +60,8 @@ class ObservationWriter:
         temp = None if self.stage is None else self.stage.indoor_temp.data_ptr()
         with torch.cuda.device(e.device):
             _lib.check(self.lib.cl_observe_f32(
-                ctypes.byref(e.dims), self.table.data_ptr(), self.col_src.data_ptr(), self.col_scale.data_ptr(),
+                ctypes.byref(e.dims), (self.reset_table if row == 0 and self.reset_table is not None else self.table).data_ptr(),
+                self.col_src.data_ptr(), self.col_scale.data_ptr(),
                 ctypes.cast(self._deps, ctypes.c_void_p) if self._deps is not None else None, self.n_deps, e.state.data_ptr(), e.out_bldg.data_ptr(), temp, out.data_ptr(), self.n_cols, out.stride(0), self.n_rows, int(row),
                 abi.CLOB_ALL_EXOGENOUS if row == 0 else 0, torch.cuda.current_stream(e.device).cuda_stream))
         return out

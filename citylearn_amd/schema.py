@@ -403,8 +403,12 @@ class DistrictSpec:
 
     # ---- packing -------------------------------------------------------------------------------------------
     def episode_tables(self, episode: int = 0, random_seed: Optional[int] = None,
-                       reward_exponent: float = 1.0) -> EpisodeTables:
-        start, end = self.episode_window(episode, random_seed)
+                       reward_exponent: float = 1.0, window: Optional[Tuple[int, int]] = None) -> EpisodeTables:
+        """Pack one episode window (`EpisodeTracker.next_episode`, base.py:100-129), or an explicit ``window=(start, end)``
+        of data-file rows -- e.g. the whole simulation period for per-env-block episode offsets (`cl_dims.env_row0`)."""
+        start, end = self.episode_window(episode, random_seed) if window is None else window
+        if not self.simulation_start_time_step <= start <= end <= self.simulation_end_time_step:
+            raise ValueError(f'window {(start, end)} outside the simulation period')
         T, B = end - start + 1, len(self.buildings)
         params = np.zeros((B, abi.CL_NP), dtype=np.uint32)
         pf = params.view(np.float32)

@@ -30,14 +30,19 @@ class VectorCityLearnEnv:
 
     def __init__(self, schema: Union[str, Mapping[str, Any], DistrictSpec], n_envs: int, device: str = 'cuda:0',
                  reference_quirks: bool = True, kpi: bool = False, observations: str = 'planes',
-                 normalize_observations: bool = False, observation_mode: str = 'current', **kwargs: Any):
+                 normalize_observations: bool = False, observation_mode: str = 'current',
+                 env_episode_offsets=None, **kwargs: Any):
         """`observations`: ``'planes'`` (default) returns the dict of device tensors described above without
         materialising anything; ``'tensor'`` returns the Gym observation tensor ``[n_envs, n_obs]`` written by
         `cl_observe_f32` -- columns = `observation_names` (the reference's central-agent order when
         ``central_agent``, else the agents' vectors concatenated), optionally min-max / sin-cos normalised like
         `NormalizedObservationWrapper` (`normalize_observations`).  `observation_mode`: ``'current'`` pairs the
         exogenous values of step t+1 with the SoC / net just computed; ``'reference'`` reproduces the reference's
-        stale read of the t+1 slots."""
+        stale read of the t+1 slots.
+        `env_episode_offsets`: ``None`` -- every env replays the same episode window (the reference's sequential episodes);
+        ``'rolling'`` / ``'random'`` / an int array with one entry per block of ``abi.CL_ROW0_BLOCK`` envs -- blocks replay
+        DIFFERENT windows of ``episode_time_steps`` rows of the simulation period at once (start rows relative to
+        ``simulation_start_time_step``; ``'random'`` redraws them at every `reset`)."""
         if observations not in ('planes', 'tensor'):
             raise ValueError("observations must be 'planes' or 'tensor'")
         self.spec = schema if isinstance(schema, DistrictSpec) else load_district(schema, **kwargs)
@@ -46,6 +51,12 @@ class VectorCityLearnEnv:
         self.reference_quirks = reference_quirks
         self.kpi = kpi
         self.central_agent = self.spec.central_agent
+        self.env_episode_offsets = env_episode_offsets
+        if env_episode_offsets is not None:
+            if not isinstance(self.spec.episode_time_steps, int):
+                raise ValueError('env_episode_offsets needs an integer episode_time_steps (schema or kwarg)')
+            if kpi:
+                raise NotImplementedError('streaming KPIs are defined for one common episode window')
         self.layout = None
         if observations == 'tensor':
             from .observations import ObservationLayout
@@ -89,10 +100,19 @@ class VectorCityLearnEnv:
 
     def reset(self, seed: Optional[int] = None) -> Tuple[Dict[str, torch.Tensor], dict]:
         self._episode += 1
-        self.tables = self.spec.episode_tables(self._episode, seed, reward_exponent=self.reward_exponent)
-        obs_tables = self.layout.episode(self.tables) if self.layout is not None else None
+        n_steps, row0 = None, None
+        if self.env_episode_offsets is None:
+            self.tables = self.spec.episode_tables(self._episode, seed, reward_exponent=self.reward_exponent)
+        else:
+            sp = self.spec
+            self.tables = sp.episode_tables(reward_exponent=self.reward_exponent,
+                                            window=(sp.simulation_start_time_step, sp.simulation_end_time_step))
+            n_steps = int(sp.episode_time_steps)
+            row0 = self._block_offsets(n_steps, self.tables.n_steps, seed)
+        self.episode_row0 = row0
+        obs_tables = self.layout.episode(self.tables, reset_table=row0 is not None) if self.layout is not None else None
         self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
-                                 t0_quirk=self.reference_quirks, kpi=self.kpi,
+                                 t0_quirk=self.reference_quirks, kpi=self.kpi, n_steps=n_steps, env_row0=row0,
                                  detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail))
         self.stage = None
         if any(b.is_dynamics for b in self.spec.buildings):
@@ -107,6 +127,25 @@ class VectorCityLearnEnv:
             from .observe import ObservationWriter
             self.writer = ObservationWriter(self.engine, obs_tables, self.stage)
         return self._obs(), {}
+
+    def _block_offsets(self, n_steps: int, n_rows: int, seed: Optional[int]) -> np.ndarray:
+        n_blocks = -(-self.n_envs // abi.CL_ROW0_BLOCK)
+        latest = n_rows - n_steps
+        if latest < 0:
+            raise ValueError(f'episode_time_steps={n_steps} exceeds the {n_rows} rows of the simulation period')
+        mode = self.env_episode_offsets
+        if isinstance(mode, str):
+            if mode == 'rolling':                         # block g starts g episodes (or g rows when they run out) further
+                stride = n_steps if n_blocks * n_steps <= latest + n_steps else max(1, latest // max(n_blocks - 1, 1))
+                return (np.arange(n_blocks) * stride) % (latest + 1)
+            if mode == 'random':
+                s = self.spec.random_seed if seed is None else seed
+                return np.random.RandomState(int(s) * (self._episode + 1) % (2 ** 32)).randint(0, latest + 1, size=n_blocks)
+            raise ValueError("env_episode_offsets must be None, 'rolling', 'random' or an array")
+        row0 = np.asarray(mode, dtype=np.int64).reshape(-1)
+        if row0.shape[0] != n_blocks:
+            raise ValueError(f'env_episode_offsets needs {n_blocks} entries (one per {abi.CL_ROW0_BLOCK} envs)')
+        return row0
 
     @property
     def observation_names(self):
@@ -123,7 +162,10 @@ class VectorCityLearnEnv:
         e = self.engine
         if self.writer is not None:
             return self.writer.write(min(self._t, e.n_steps - 1))
-        return {'exogenous': self._exo[min(self._t, e.n_steps - 1)],
+        t_row = min(self._t, e.n_steps - 1)
+        # per-env-block episode windows: one exogenous row per block, [n_blocks, n_bldg, CL_NF]
+        exo = self._exo[t_row] if e.env_row0 is None else self._exo[e.env_row0.long() + t_row]
+        return {'exogenous': exo,
                 'electrical_storage_soc': e.state[abi.CLS_B_SOC], 'cooling_storage_soc': e.state[abi.CLS_CS_SOC],
                 'heating_storage_soc': e.state[abi.CLS_HS_SOC], 'dhw_storage_soc': e.state[abi.CLS_DS_SOC],
                 'net_electricity_consumption': e.out_bldg[abi.CLO_NET],

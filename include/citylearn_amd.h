@@ -196,6 +196,8 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 };
 
 /* ---- step flags (`cl_dims.flags`) ---- */
+#define CL_ROW0_BLOCK 256   /* envs per episode-offset block (cl_dims.env_row0); every kernel's env tile divides it */
+
 #define CLD_REF_T0_QUIRK   (1u << 0)  /* replicate the reference's repeated t=0 update_variables (SURVEY App.B1) */
 #define CLD_WRITE_DETAIL   (1u << 1)  /* also write CLO_B_EB .. CLO_C_NSL planes (parity / KPI baselines) */
 #define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators (requires CLD_WRITE_DETAIL) */
@@ -214,10 +216,15 @@ enum cl_reward_kind {
 typedef struct cl_dims {
     int32_t n_env;        /* envs in this shard (multiple of 4) */
     int32_t n_bldg;       /* buildings per district */
-    int32_t n_steps;      /* rows in `ts` (episode_time_steps) */
+    int32_t n_steps;      /* episode_time_steps: valid t are 0 .. n_steps-1 */
     int32_t n_act_cols;   /* action columns */
     uint32_t flags;       /* CLD_* */
-    int32_t reserved[3];
+    int32_t n_ts_rows;    /* rows in `ts` / `dyn_pre` / `obs_table`; 0 means n_steps */
+    const int32_t* env_row0;  /* nullable DEVICE pointer [ceil(n_env / CL_ROW0_BLOCK)]: per-env-block episode offset.
+                                 Env block g (CL_ROW0_BLOCK consecutive envs) reads table row env_row0[g] + t at step t, so
+                                 different blocks replay different windows of the simulation period at once (the batched
+                                 analogue of EpisodeTracker's rolling / random episode splits, base.py:100-129).  The caller
+                                 guarantees 0 <= env_row0[g] and env_row0[g] + n_steps <= n_ts_rows. */
 } cl_dims;
 
 /* ABI version of the loaded library (== CL_ABI_VERSION of the header it was built from). */

@@ -1,0 +1,122 @@
+"""Per-env-block episode windows (`cl_dims.env_row0`): every block of CL_ROW0_BLOCK envs replays its own window of the
+simulation period.  Oracle: the same engine run on tables cut to that window (itself pinned on the reference by the
+parity suites) -- results must be bit-identical.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _cut(tables, start, n):
+    from citylearn_amd.schema import EpisodeTables
+    return EpisodeTables(params=tables.params, ts=np.ascontiguousarray(tables.ts[start:start + n]), start=tables.start + start,
+                         end=tables.start + start + n - 1, outage=tables.outage[start:start + n])
+
+
+@pytest.mark.parametrize('name,kind', [('g2022_all', 'MARL'), ('g2020_cz1', 'RewardFunction'), ('g2023_p2', 'SolarPenaltyReward')])
+def test_step_and_rollout_with_block_offsets(name, kind):
+    from citylearn_amd import abi
+    from citylearn_amd.engine import StepEngine
+    g = golden(name)
+    spec = g.spec()
+    tables = spec.episode_tables(0)
+    K, offsets = 30, [0, 7, 113, 250]
+    E = abi.CL_ROW0_BLOCK * len(offsets)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    low, high = (torch.from_numpy(x).cuda() for x in spec.action_limits())
+    for detail in (False, True):
+        eng = StepEngine(tables, E, reward=kind, detail=detail, n_steps=K, env_row0=offsets)
+        refs = [StepEngine(_cut(tables, o, K), abi.CL_ROW0_BLOCK, reward=kind, detail=detail) for o in offsets]
+        for t in range(K):
+            a = low[:, None] + torch.rand((eng.n_act_cols, E), device='cuda', generator=gen) * (high - low)[:, None]
+            eng.step(a, t)
+            for j, r in enumerate(refs):
+                sl = slice(j * abi.CL_ROW0_BLOCK, (j + 1) * abi.CL_ROW0_BLOCK)
+                r.step(a[:, sl].contiguous(), t)
+                assert torch.equal(eng.state[:, :, sl], r.state), (t, j)
+                assert torch.equal(eng.out_env[:, sl], r.out_env), (t, j)
+                planes = range(abi.CL_NO - 1) if detail else (abi.CLO_NET, abi.CLO_REWARD)
+                for p in planes:
+                    assert torch.equal(eng.out_bldg[p][:, sl], r.out_bldg[p]), (t, j, p)
+        with pytest.raises(Exception):
+            eng.step(a, K)                                   # t outside the episode
+    # fused rollout with the on-device policy: same Philox stream (keyed by env index) -> compare against K single steps
+    if name != 'g2020_cz1':
+        eng = StepEngine(tables, E, reward=kind, n_steps=K, env_row0=offsets)
+        eng.set_action_limits(*spec.action_limits())
+        ret = torch.zeros(E, device='cuda')
+        eng.rollout(K, seed=11, ret_env=ret)
+        one = StepEngine(tables, E, reward=kind, n_steps=K, env_row0=offsets)
+        acc = torch.zeros(E, device='cuda')
+        lib = one.lib
+        import ctypes
+        lib.cl_philox_uniform.restype = ctypes.c_float
+        lib.cl_philox_uniform.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+        lo, hi = spec.action_limits()
+        envs = [0, 255, 256, 700, E - 1]
+        for t in range(K):
+            a = torch.zeros((one.n_act_cols, E), device='cuda')
+            u = np.array([[lib.cl_philox_uniform(11, e, c, t) for e in envs] for c in range(one.n_act_cols)], dtype=np.float32)
+            a[:, envs] = torch.from_numpy(lo[:, None] + u * (hi - lo)[:, None]).cuda()
+            one.step(a, t)
+            acc += one.district_reward
+        for p in (abi.CLS_B_SOC, abi.CLS_DS_SOC):
+            np.testing.assert_allclose(eng.state[p][:, envs].cpu().numpy(), one.state[p][:, envs].cpu().numpy(), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(ret[envs].cpu().numpy(), acc[envs].cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_engine_validates_offsets():
+    from citylearn_amd.engine import StepEngine
+    g = golden('g2022_all')
+    tables = g.spec().episode_tables(0)
+    with pytest.raises(ValueError, match='entries'):
+        StepEngine(tables, 512, n_steps=10, env_row0=[0])
+    with pytest.raises(ValueError, match='inside'):
+        StepEngine(tables, 512, n_steps=10, env_row0=[0, tables.n_steps - 9])
+    with pytest.raises(NotImplementedError):
+        StepEngine(tables, 512, n_steps=10, env_row0=[0, 1], kpi=True)
+
+
+@pytest.mark.parametrize('normalize', [False, True])
+def test_vector_env_with_episode_offsets_matches_windowed_envs(normalize):
+    """2023 schema (LSTM temperature stage, ComfortReward, outage): the observation matrix, rewards and indoor
+    temperatures of block g equal those of a plain env whose simulation period starts at that block's offset."""
+    from citylearn_amd import abi
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden('g2023_p2')
+    K, offsets = 40, [0, 31, 200]
+    E = abi.CL_ROW0_BLOCK * len(offsets)
+    env = VectorCityLearnEnv(g.schema_path, E, observations='tensor', normalize_observations=normalize, episode_time_steps=K,
+                             env_episode_offsets=offsets, simulate_power_outage=False)   # outage draws depend on the window length
+    assert env.time_steps == K
+    refs = [VectorCityLearnEnv(g.schema_path, abi.CL_ROW0_BLOCK, observations='tensor', normalize_observations=normalize,
+                               simulation_start_time_step=o, simulation_end_time_step=o + K - 1,
+                               simulate_power_outage=False) for o in offsets]
+    obs, _ = env.reset()
+    sl = [slice(j * abi.CL_ROW0_BLOCK, (j + 1) * abi.CL_ROW0_BLOCK) for j in range(len(offsets))]
+    # observation limits follow the simulation period, which differs between `env` and the windowed references: compare
+    # normalised observations through the un-normalised value
+    lo_e, hi_e = env.layout.limits()
+    def denorm(x, layout):
+        if not normalize:
+            return x
+        lo, hi = layout.limits()
+        return x * torch.from_numpy(hi - lo).float().cuda() + torch.from_numpy(lo).float().cuda()
+    for j, r in enumerate(refs):
+        o_r, _ = r.reset()
+        np.testing.assert_allclose(denorm(obs[sl[j]], env.layout).cpu().numpy(), denorm(o_r, r.layout).cpu().numpy(), rtol=2e-5, atol=2e-4)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    for t in range(K - 1):
+        a = env.sample_actions(gen)
+        obs, rew, term, _, _ = env.step(a)
+        for j, r in enumerate(refs):
+            o_r, rew_r, term_r, _, _ = r.step(a[:, sl[j]].contiguous())
+            assert term == term_r
+            assert torch.equal(env.stage.indoor_temp[:, sl[j]], r.stage.indoor_temp), (t, j)
+            assert torch.equal(rew[sl[j]], rew_r), (t, j)
+            np.testing.assert_allclose(denorm(obs[sl[j]], env.layout).cpu().numpy(), denorm(o_r, r.layout).cpu().numpy(),
+                                       rtol=2e-5, atol=2e-4, err_msg=f'{t} {j}')
+    assert env.terminated
