@@ -52,8 +52,9 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         d = b.dynamics
         if d is None:
             continue
-        if (d.hidden_size, d.num_layers, d.lookback, d.input_size) != (16, 2, 12, 13):
-            raise NotImplementedError('the LSTM kernel is specialised for LSTM(13 -> 16, 2 layers, lookback 12)')
+        H = d.hidden_size
+        if d.num_layers != 2 or d.lookback != 12 or not 1 <= H <= 16:
+            raise NotImplementedError('the LSTM kernel is specialised for 2 layers, lookback 12 and hidden size <= 16')
         sd = torch.load(d.filepath, map_location='cpu')
         sd = {k: v.double().numpy() for k, v in sd.get('model_state_dict', sd).items()}
         names = list(d.input_observation_names)
@@ -61,15 +62,29 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         ic, it = names.index('cooling_demand'), names.index('indoor_dry_bulb_temperature')
         if 'heating_demand' in names:
             raise NotImplementedError('heating-demand driven dynamics models are not supported yet')
-        wih0, whh0 = sd['l_lstm.weight_ih_l0'], sd['l_lstm.weight_hh_l0']
-        b0 = sd['l_lstm.bias_ih_l0'] + sd['l_lstm.bias_hh_l0']
+
+        # A hidden size below 16 is embedded exactly: the padded units have zero weights and biases, so their cell and
+        # hidden state stay 0 (c = 0.5 c + 0.5 tanh(0) = 0, h = 0.5 tanh(0) = 0) and nothing reads them.
+        def gates(m):                                   # torch rows [i; f; g; o] x H  ->  [i; f; g; o] x 16
+            m = np.asarray(m, dtype=np.float64)
+            out = np.zeros((4, 16) + m.shape[1:])
+            out[:, :H] = m.reshape((4, H) + m.shape[1:])
+            return out.reshape((64,) + m.shape[1:])
+
+        def cols(m):                                    # [rows, H] -> [rows, 16]
+            out = np.zeros((m.shape[0], 16))
+            out[:, :H] = m
+            return out
+
+        wih0, whh0 = gates(sd['l_lstm.weight_ih_l0']), cols(gates(sd['l_lstm.weight_hh_l0']))
+        b0 = gates(sd['l_lstm.bias_ih_l0'] + sd['l_lstm.bias_hh_l0'])
         lstm_w[i, WC:WC + 64] = wih0[:, ic]
         lstm_w[i, WT:WT + 64] = wih0[:, it]
         lstm_w[i, WHH0:WHH0 + 1024] = whh0.reshape(-1)
-        lstm_w[i, WIH1:WIH1 + 1024] = sd['l_lstm.weight_ih_l1'].reshape(-1)
-        lstm_w[i, WHH1:WHH1 + 1024] = sd['l_lstm.weight_hh_l1'].reshape(-1)
-        lstm_w[i, B1:B1 + 64] = sd['l_lstm.bias_ih_l1'] + sd['l_lstm.bias_hh_l1']
-        lstm_w[i, WLIN:WLIN + 16] = sd['l_linear.weight'].reshape(-1)
+        lstm_w[i, WIH1:WIH1 + 1024] = cols(gates(sd['l_lstm.weight_ih_l1'])).reshape(-1)
+        lstm_w[i, WHH1:WHH1 + 1024] = cols(gates(sd['l_lstm.weight_hh_l1'])).reshape(-1)
+        lstm_w[i, B1:B1 + 64] = gates(sd['l_lstm.bias_ih_l1'] + sd['l_lstm.bias_hh_l1'])
+        lstm_w[i, WLIN:WLIN + 16] = cols(sd['l_linear.weight'].reshape(1, -1)).reshape(-1)
         lstm_w[i, BLIN] = sd['l_linear.bias'].reshape(-1)[0]
         lstm_w[i, TMIN], lstm_w[i, TMAX] = lo[it], hi[it]
         lstm_w[i, CMIN], lstm_w[i, CMAX] = lo[ic], hi[ic]

@@ -45,6 +45,13 @@ FIXTURES = {
     'g2023_p2': ('citylearn_challenge_2023_phase_2_local_evaluation', 720, 719, 2023, False, {}),
     # sub-hourly control of hourly data files: time_step_ratio = 0.25 paths (data.py:427-455; energy_model.py:732, 863, 1036, 1139)
     'g2020_15min': ('citylearn_challenge_2020_climate_zone_1', 400, 399, 15, False, {'seconds_per_time_step': 900}),
+    # dataset sweep: short runs of the remaining dataset families the loader supports (different device mixes, autosizing,
+    # heating end uses, 15-minute data files, six-building outage district)
+    's_baeda': ('baeda_3dem', 96, 95, 31, False, {}),
+    's_2021': ('citylearn_challenge_2021', 96, 95, 32, False, {}),
+    's_2020_cz3': ('citylearn_challenge_2020_climate_zone_3', 96, 95, 33, False, {}),
+    's_2023_p1': ('citylearn_challenge_2023_phase_1', 96, 95, 34, False, {}),
+    's_2023_p3': ('citylearn_challenge_2023_phase_3_1', 96, 95, 35, False, {}),
 }
 
 

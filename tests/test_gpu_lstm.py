@@ -12,24 +12,35 @@ from citylearn_amd.dynamics import LSTMStage
 pytestmark = pytest.mark.gpu
 
 
-def test_lstm_stage_fed_with_reference_cooling():
+@pytest.mark.parametrize('name', ['g2023_p2', 's_baeda', 's_2023_p1', 's_2023_p3'])
+def test_lstm_stage_fed_with_reference_cooling(name):
     """Isolates the stage: the delivered cooling of every step comes from the reference; temperatures within 1e-4 C
-    relative and ComfortReward within 1e-4 (+1e-4) of the reference for all 719 steps x 3 buildings."""
-    g = golden('g2023_p2')
+    relative and ComfortReward within 1e-4 (+1e-4) of the reference for every step and building (2023: LSTM(13 -> 16),
+    3 and 6 buildings; baeda_3dem: LSTM(11 -> 8) embedded in the 16-wide kernel)."""
+    g = golden(name)
     spec = g.spec()
+    cols = list(range(len(spec.buildings)))
+    if name == 's_baeda':
+        # the fourth baeda building uses a one-layer LSTM(11 -> 50): outside what the MFMA kernel is specialised for
+        # (2 layers, hidden <= 16) -- `pack_lstm` refuses it loudly; run the stage on the other three
+        from citylearn_amd.dynamics import pack_lstm
+        with pytest.raises(NotImplementedError, match='specialised'):
+            pack_lstm(spec, spec.episode_tables(0))
+        cols = [0, 1, 2]
+        spec = g.spec(buildings=[spec.buildings[i].name for i in cols])
     tab = spec.episode_tables(0)
-    attrs = spec.reward_function['attributes']
+    attrs = spec.reward_function.get('attributes') or {}
     E = 64
     eng = StepEngine(tab, E, detail=True)
-    stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'])
-    cool = torch.from_numpy(g.ref['cool_dem']).cuda()
+    stage = LSTMStage(spec, tab, eng, attrs.get('band'), attrs.get('lower_exponent') or 2.0, attrs.get('higher_exponent') or 2.0)
+    cool = torch.from_numpy(g.ref['cool_dem'][:, cols]).cuda()
     worst_t = worst_r = 0.0
     for t in range(g.facts['steps']):
         temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous())
         tt, rr = temp.cpu().numpy(), stage.comfort.cpu().numpy()
         assert (tt[:, :1] == tt).all()
-        worst_t = max(worst_t, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t]))))
-        ref = g.ref['reward_ComfortReward'][t]
+        worst_t = max(worst_t, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t][cols]))))
+        ref = g.ref['reward_ComfortReward'][t][cols]
         worst_r = max(worst_r, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
     assert worst_t < 2e-3, worst_t          # deg C on ~25 C: < 1e-4 relative
     assert worst_r < 10.0, worst_r
