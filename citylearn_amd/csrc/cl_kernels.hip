@@ -462,7 +462,7 @@ int pick_vec(int n_env, int n_bldg, bool unit_stride) {
 int g_force_vec = 0;   // test / tuning hooks (cl_debug_set_vec / cl_debug_set_lean)
 int g_force_nw = 0;
 int g_no_chunks = 0;
-int g_obs_variant = 0;   // 1 / 2: force the row-wise / LDS-tile observation kernel (tests, tuning)
+int g_obs_variant = 0;   // 1 / 2 / 3: force the row-wise / LDS-tile / wave-independent observation kernel (tests, tuning)
 int g_obs_rows = 0;      // tile kernel: envs per block (tuning)
 
 }  // namespace
@@ -705,17 +705,36 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
         for (int d = 0; d < n_deps; ++d)
             if (deps[d].col < 0 || deps[d].col >= n_cols || deps[d].src < 0)
                 return fail(CL_EINVAL, "deps[%d]: col=%d src=%d", d, deps[d].col, deps[d].src);
-    // narrow observation vectors (half a wave of 16-byte column groups per row or less): LDS-tile kernel; else row-wise
-    const bool narrow = g_obs_variant == 2 || (g_obs_variant == 0 && padded <= 128);
-    if (n_seg == 1 && padded == obs_pitch && listed && narrow && dims->env_row0 == nullptr) {   // one template row per launch
+    // Kernel choice (measured on MI355X, scripts/observe_bench.py / profiles/):
+    //  * narrow vectors (half a wave of 16-byte column groups per row or less): LDS-tile kernel (52 columns: 11 vs 15 us);
+    //  * wide vectors when the launch runs in more than ~one round of resident waves (> 96k envs) and the host-side list
+    //    leaves no lane with more than OBS_WSLOTS dependent columns: wave-independent kernel -- its waves never
+    //    synchronise, so the read latency of starting waves hides behind the stores of running ones
+    //    (262 144 x 476: 112 vs 120 us row-wise; 65 536 x 476, a single round: 30 vs 27 us);
+    //  * everything else (no list, > 1024 columns, odd pitch, crowded lanes): row-wise kernel.
+    ObsTileArgs t;
+    if (n_seg == 1 && listed) {
         static_assert(OBS_DEP_MAX == CLOB_MAX_DEPS, "header and kernel disagree");
-        ObsTileArgs t;
+        t.n_deps = all_exo ? 0 : n_deps;
+        for (int d = 0; d < t.n_deps; ++d) t.deps[d] = deps[d];
+    }
+    const bool narrow = g_obs_variant == 2 || (g_obs_variant == 0 && padded <= 128);
+    bool wide = n_seg == 1 && listed && vec4 && (g_obs_variant == 3 || (g_obs_variant == 0 && !narrow && dims->n_env > 98304));
+    if (wide) {
+        int owned[256] = {0};
+        for (int d = 0; d < t.n_deps && wide; ++d) wide = ++owned[(deps[d].col >> 2) & 63] <= OBS_WSLOTS;
+    }
+    if (wide) {
+        t.o = a;
+        const int n_waves = (dims->n_env + OBS_WROWS - 1) / OBS_WROWS, per_wg = OBS_THREADS / 64;
+        const dim3 wgrid((n_waves + per_wg - 1) / per_wg);
+        if (padded <= 512) hipLaunchKernelGGL(cl_observe_wave_kernel<2>, wgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
+        else hipLaunchKernelGGL(cl_observe_wave_kernel<4>, wgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
+    } else if (n_seg == 1 && padded == obs_pitch && listed && narrow && dims->env_row0 == nullptr) {   // one template row per launch
         int r = g_obs_rows ? g_obs_rows : 16;          // 16 envs = one 64-byte line of every dependent plane
         while (r * obs_pitch > OBS_BUF) r >>= 1;       // pitch <= OBS_SEG + 3 -> r >= 4
         a.sub_rows = r;
         t.o = a;
-        t.n_deps = all_exo ? 0 : n_deps;
-        for (int d = 0; d < t.n_deps; ++d) t.deps[d] = deps[d];
         const int n_blocks = (dims->n_env + r - 1) / r, per_wg = OBS_TILE / r;
         hipLaunchKernelGGL(cl_observe_tile_kernel, dim3((n_blocks + per_wg - 1) / per_wg), dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
     } else if (vec4) hipLaunchKernelGGL(cl_observe_kernel<4>, grid, dim3(OBS_THREADS), 0, (hipStream_t)stream, a);

@@ -202,4 +202,96 @@ __global__ __launch_bounds__(OBS_THREADS) void cl_observe_tile_kernel(ObsTileArg
     }
 }
 
+// Wave-independent kernel (wide observation vectors with a host-side dependent-column list): no LDS, no barriers, no
+// atomics.  A wave owns OBS_WROWS consecutive envs; lane l owns the 16-byte column groups l, l + 64, ... whose
+// env-independent values stay in registers.  A lane that owns a dependent column fetches that plane's values for the
+// wave's envs itself -- OBS_WROWS x 4 B = one 64-byte line -- so every load of the kernel is issued at wave start in one
+// batch (one memory round trip before the first store) and waves never wait for each other: the hardware overlaps the
+// read latency of starting waves with the stores of running ones.
+constexpr int OBS_WROWS = 16;       // envs per wave
+constexpr int OBS_WSLOTS = 4;       // dependent columns a lane can own (host falls back to the row-wise kernel beyond)
+// OBS_WGROUPS = 16-byte column groups per lane: 2 covers 512 columns (every shipped schema), 4 covers OBS_SEG
+template <int OBS_WGROUPS>
+__global__ __launch_bounds__(OBS_THREADS) void cl_observe_wave_kernel(ObsTileArgs t) {
+    const ObsArgs& a = t.o;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * (OBS_THREADS / 64) + (threadIdx.x >> 6);
+    const int env0 = gw * OBS_WROWS;
+    if (env0 >= a.n_env) return;                                     // wave-uniform
+    const int rows = min(OBS_WROWS, a.n_env - env0);
+    const float* __restrict__ trow = a.row + (a.env_row0 ? (long long)a.env_row0[env0 / CL_ROW0_BLOCK] * a.n_cols : 0);
+    const int n_deps = a.all_exo ? 0 : t.n_deps;
+
+    float exo[OBS_WGROUPS][4];
+#pragma unroll
+    for (int k = 0; k < OBS_WGROUPS; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (lane + 64 * k) * 4 + j;
+            exo[k][j] = c < a.n_cols ? trow[c] : 0.0f;
+        }
+    }
+    // this lane's dependent columns (scalar walk over the kernel-argument list)
+    int s_kj[OBS_WSLOTS];                       // k * 4 + j of the slot, -1 = empty
+    int s_src[OBS_WSLOTS];
+    float s_scale[OBS_WSLOTS];
+#pragma unroll
+    for (int s = 0; s < OBS_WSLOTS; ++s) { s_kj[s] = -1; s_src[s] = 0; s_scale[s] = 0.0f; }
+    int cnt = 0;
+    for (int d = 0; d < n_deps; ++d) {
+        const cl_obs_dep dep = t.deps[d];                            // scalar loads
+        const int grp = dep.col >> 2;
+        if ((grp & 63) == lane) {
+            const int kj = (grp >> 6) * 4 + (dep.col & 3);
+#pragma unroll
+            for (int s = 0; s < OBS_WSLOTS; ++s)
+                if (cnt == s) { s_kj[s] = kj; s_src[s] = dep.src; s_scale[s] = dep.scale; }
+            ++cnt;
+        }
+    }
+    // fetch the dependent values: one 64-byte line per owned column (n_env % 4 == 0: whole float4s are in range)
+    float val[OBS_WSLOTS][OBS_WROWS];
+#pragma unroll
+    for (int s = 0; s < OBS_WSLOTS; ++s) {
+        if (s_kj[s] >= 0) {
+            const float4* p = reinterpret_cast<const float4*>(obs_plane(a, s_src[s]) + env0);
+#pragma unroll
+            for (int q = 0; q < OBS_WROWS / 4; ++q) {
+                const float4 v = 4 * q < rows ? p[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                val[s][4 * q] = v.x; val[s][4 * q + 1] = v.y; val[s][4 * q + 2] = v.z; val[s][4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < OBS_WROWS; ++e) val[s][e] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < OBS_WSLOTS; ++s) {
+        float base = 0.0f;
+#pragma unroll
+        for (int k = 0; k < OBS_WGROUPS; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) base = s_kj[s] == k * 4 + j ? exo[k][j] : base;
+#pragma unroll
+        for (int e = 0; e < OBS_WROWS; ++e) val[s][e] = fmaf(val[s][e], s_scale[s], base);
+    }
+    float* out = a.obs + (long long)env0 * a.pitch;
+#pragma unroll
+    for (int e = 0; e < OBS_WROWS; ++e) {
+#pragma unroll
+        for (int k = 0; k < OBS_WGROUPS; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (e >= rows || c >= a.padded) continue;                 // `e >= rows` is wave-uniform
+            float v[4] = {exo[k][0], exo[k][1], exo[k][2], exo[k][3]};
+            if (cnt) {
+#pragma unroll
+                for (int s = 0; s < OBS_WSLOTS; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = s_kj[s] == k * 4 + j ? val[s][e] : v[j];
+            }
+            *reinterpret_cast<float4*>(out + (long long)e * a.pitch + c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 }  // namespace

@@ -43,6 +43,7 @@ for name, E in (('g2022_all', 65536), ('g2022_all', 262144), ('g2020_cz1', 65536
         w = ObservationWriter(eng, ot, stage)
         acts = torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1
         w.lib.cl_debug_set_observe(1, 0); us_row = timed(lambda: w.write(7))
+        w.lib.cl_debug_set_observe(3, 0); us_wave = timed(lambda: w.write(7))
         alt = []
         for rows in (8, 16, 64):
             w.lib.cl_debug_set_observe(2, rows); alt.append(f'{rows}: {timed(lambda: w.write(7)):.1f}')
@@ -55,7 +56,7 @@ for name, E in (('g2022_all', 65536), ('g2022_all', 262144), ('g2020_cz1', 65536
         print(f'   (all-exogenous write(0): {us0:.1f} us; torch broadcast copy_ of the row: {us_t:.1f} us)')
         del dense
         by = w.algorithmic_bytes()
-        print(f'   (row-wise kernel: {us_row:.1f} us; tile kernel by block rows: {", ".join(alt)} us)')
+        print(f'   (row-wise kernel: {us_row:.1f} us; wave-independent kernel: {us_wave:.1f} us; tile kernel by block rows: {", ".join(alt)} us)')
         both = timed(lambda: (eng.step(acts, 7), w.write(8)))
         step_b = eng.algorithmic_bytes_per_unit() * eng.n_bldg * E
         print(f'{name} E={E} n_cols={w.n_cols} dep={ot.n_dependent} norm={normalize}: observe {us:.1f} us  {by/us/1e3:.0f} GB/s '

@@ -65,6 +65,8 @@ def test_kernel_matches_host_statement(n_env, n_cols, n_dep):
         for rows in (0, 4, 8, 32, 64):                                                     # LDS-tile kernel, block heights
             w.lib.cl_debug_set_observe(2, rows)
             assert np.array_equal(got, w.write(row).cpu().numpy())
+        w.lib.cl_debug_set_observe(3, 0)                                                   # wave-independent kernel
+        assert np.array_equal(got, w.write(row).cpu().numpy())
         w.lib.cl_debug_set_observe(0, 0)
         for e in (0, 1, n_env // 2, n_env - 1):
             want = ObservationTables(t32, src, scale, False).host_row(row, st[:, :, e], ob[:, :, e], tp[:, e])
