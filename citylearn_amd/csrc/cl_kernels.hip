@@ -641,19 +641,33 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     return CL_OK;
 }
 
-int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, void* stream) {
+__global__ void cl_kpi_comfort_reset_kernel(float* k, long long plane) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    for (int p = 0; p < CL_NKC; ++p) k[p * plane + i] = 0.0f;
+    k[CLKC_COLD_MIN * plane + i] = INFINITY; k[CLKC_HOT_MIN * plane + i] = INFINITY;
+    k[CLKC_COLD_MAX * plane + i] = -INFINITY; k[CLKC_HOT_MAX * plane + i] = -INFINITY;
+}
+
+int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, float* kpi_comfort, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     if (int rc = check_ptr(hist, "hist")) return rc;
     if (int rc = check_ptr(hidden, "hidden")) return rc;
     const size_t plane = (size_t)dims->n_env * dims->n_bldg * sizeof(float);
     if (hipError_t e = hipMemsetAsync(hist, 0, CL_LSTM_NHIST * plane, (hipStream_t)stream); e != hipSuccess) return hip_fail(e, "memset hist");
     if (hipError_t e = hipMemsetAsync(hidden, 0, CL_LSTM_NHIDDEN * plane, (hipStream_t)stream); e != hipSuccess) return hip_fail(e, "memset hidden");
+    if (kpi_comfort) {
+        if (int rc = check_ptr(kpi_comfort, "kpi_comfort")) return rc;
+        const long long units = (long long)dims->n_env * dims->n_bldg;
+        hipLaunchKernelGGL(cl_kpi_comfort_reset_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, kpi_comfort, units);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_kpi_comfort_reset_kernel launch");
+    }
     return CL_OK;
 }
 
 int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* cool_dem,
-                     const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort, int32_t t,
-                     void* stream) {
+                     const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,
+                     float* kpi_comfort, int32_t t, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     if (int rc = check_ptr(lstm_w, "lstm_w")) return rc;
     if (int rc = check_ptr(dyn_pre, "dyn_pre")) return rc;
@@ -664,7 +678,8 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_
     if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
     LstmArgs a;
     a.lstm_w = lstm_w; a.dyn_pre = dyn_pre; a.cool_dem = cool_dem; a.hist = hist; a.hidden = hidden; a.indoor_temp = indoor_temp;
-    a.heat_dem = heat_dem; a.comfort = comfort;
+    a.heat_dem = heat_dem; a.comfort = comfort; a.kpi_comfort = kpi_comfort;
+    if (int rc = check_ptr(kpi_comfort, "kpi_comfort", false)) return rc;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t; a.env_row0 = dims->env_row0;
     const dim3 grid((dims->n_env + 127) / 128, dims->n_bldg);          // 4 waves x 32 envs per workgroup
     hipLaunchKernelGGL(cl_lstm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);

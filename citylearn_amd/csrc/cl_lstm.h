@@ -42,6 +42,7 @@
 #define CLW_RW_BAND 3286        /* ComfortReward band (NaN = use the data-file comfort band), exponents */
 #define CLW_RW_LOEXP 3287
 #define CLW_RW_HIEXP 3288
+#define CLW_KPI_BAND 3289        /* comfort band of the discomfort KPIs (evaluate()'s scalar, citylearn.py:1191) */
 // dyn_pre layout: [0..63] layer-0 pre-gates, [64] data-file temperature (normalised), [65] data-file temperature [C]
 #define CLPRE_TNORM 64
 #define CLPRE_TRAW 65
@@ -49,6 +50,8 @@
 #define CLPRE_CSP 67
 #define CLPRE_HSP 68
 #define CLPRE_BAND 69
+#define CLPRE_OCC 70            /* occupant_count and power-outage signal of the data file at t (comfort KPIs) */
+#define CLPRE_OUTAGE 71
 
 #ifdef __HIPCC__
 namespace {
@@ -85,6 +88,7 @@ struct LstmArgs {
     float* __restrict__ indoor_temp;      // [B][E] out: indoor dry-bulb temperature of step t [C]
     const float* __restrict__ heat_dem;   // [B][E] delivered heating (may be NULL = 0)
     float* __restrict__ comfort;          // [B][E] out: ComfortReward of step t (may be NULL)
+    float* __restrict__ kpi_comfort;      // [CL_NKC][B][E] streaming discomfort accumulators (may be NULL)
     const int32_t* __restrict__ env_row0;  // per-env-block episode offsets (cl_dims.env_row0) or null
     int n_env, n_bldg, t;
 };
@@ -217,6 +221,26 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             const float band = band_p == band_p ? band_p : pre_t[CLPRE_BAND];
             a.comfort[off] = comfort_reward(temp, cool, a.heat_dem ? a.heat_dem[off] : 0.0f, pre_t[CLPRE_HVAC], pre_t[CLPRE_CSP],
                                             pre_t[CLPRE_HSP], band, W[CLW_RW_LOEXP], W[CLW_RW_HIEXP]);
+        }
+        if (a.kpi_comfort) {
+            // CostFunction.discomfort / one_minus_thermal_resilience as running sums (cost_function.py:224-353):
+            // deltas count only while the building is occupied; band = evaluate()'s scalar comfort band
+            const bool occupied = pre_t[CLPRE_OCC] > 0.0f;
+            const float band = W[CLW_KPI_BAND];
+            const float cd = occupied ? temp - pre_t[CLPRE_CSP] : 0.0f, hd = occupied ? temp - pre_t[CLPRE_HSP] : 0.0f;
+            const bool hot = cd > band, cold = hd < -band;
+            const float cmag = fabsf(fminf(hd, 0.0f)), hmag = fabsf(fmaxf(cd, 0.0f));
+            float* k = a.kpi_comfort + off;
+            k[CLKC_UNMET * plane] += (hot || cold) ? 1.0f : 0.0f;
+            k[CLKC_COLD * plane] += cold ? 1.0f : 0.0f;
+            k[CLKC_HOT * plane] += hot ? 1.0f : 0.0f;
+            k[CLKC_COLD_MIN * plane] = fminf(k[CLKC_COLD_MIN * plane], cmag);
+            k[CLKC_COLD_MAX * plane] = fmaxf(k[CLKC_COLD_MAX * plane], cmag);
+            k[CLKC_COLD_SUM * plane] += cmag;
+            k[CLKC_HOT_MIN * plane] = fminf(k[CLKC_HOT_MIN * plane], hmag);
+            k[CLKC_HOT_MAX * plane] = fmaxf(k[CLKC_HOT_MAX * plane], hmag);
+            k[CLKC_HOT_SUM * plane] += hmag;
+            k[CLKC_UNMET_OUTAGE * plane] += ((hot || cold) && pre_t[CLPRE_OUTAGE] != 0.0f) ? 1.0f : 0.0f;
         }
     }
 }

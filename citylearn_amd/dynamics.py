@@ -20,8 +20,8 @@ _PERIODIC = {'month': 12, 'hour': 24, 'day_type': 7}     # building.py:1493-1498
 
 # offsets inside `lstm_w` (csrc/cl_lstm.h)
 WC, WT, WHH0, WIH1, WHH1, B1, WLIN, BLIN, TMIN, TMAX, CMIN, CMAX, ACTIVE = 0, 64, 128, 1152, 2176, 3200, 3264, 3280, 3281, 3282, 3283, 3284, 3285
-PRE_TNORM, PRE_TRAW, PRE_HVAC, PRE_CSP, PRE_HSP, PRE_BAND = 64, 65, 66, 67, 68, 69
-RW_BAND, RW_LOEXP, RW_HIEXP = 3286, 3287, 3288
+PRE_TNORM, PRE_TRAW, PRE_HVAC, PRE_CSP, PRE_HSP, PRE_BAND, PRE_OCC, PRE_OUTAGE = 64, 65, 66, 67, 68, 69, 70, 71
+RW_BAND, RW_LOEXP, RW_HIEXP, KPI_BAND = 3286, 3287, 3288, 3289
 
 
 def _exo_feature(b, name: str, w: slice) -> np.ndarray:
@@ -34,7 +34,8 @@ def _exo_feature(b, name: str, w: slice) -> np.ndarray:
     return np.asarray(b.series[name][w], dtype=np.float64)
 
 
-def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_exponent: float = 2.0, higher_exponent: float = 2.0):
+def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_exponent: float = 2.0, higher_exponent: float = 2.0,
+              kpi_band: float = 2.0):
     """Returns ``(lstm_w [B, CL_LSTM_NW] f32, dyn_pre [T, B, CL_LSTM_NPRE] f32)``; `band` / exponents are the
     ComfortReward parameters of the fused reward epilogue."""
     B, T = len(spec.buildings), tables.n_steps
@@ -47,8 +48,11 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         dyn_pre[:, i, PRE_CSP] = b.series['indoor_dry_bulb_temperature_cooling_set_point'][w]
         dyn_pre[:, i, PRE_HSP] = b.series['indoor_dry_bulb_temperature_heating_set_point'][w]
         dyn_pre[:, i, PRE_BAND] = b.series['comfort_band'][w]
+        dyn_pre[:, i, PRE_OCC] = b.series['occupant_count'][w]
+        dyn_pre[:, i, PRE_OUTAGE] = tables.outage[:, i]
         lstm_w[i, RW_BAND] = np.nan if band is None else band
         lstm_w[i, RW_LOEXP], lstm_w[i, RW_HIEXP] = lower_exponent, higher_exponent
+        lstm_w[i, KPI_BAND] = kpi_band
         d = b.dynamics
         if d is None:
             continue
@@ -104,10 +108,13 @@ class LSTMStage:
     """Device state + driver of the LSTM stage for one env shard (pairs with a `StepEngine` built with detail=True)."""
 
     def __init__(self, spec: DistrictSpec, tables: EpisodeTables, engine, band=None, lower_exponent: float = 2.0,
-                 higher_exponent: float = 2.0):
+                 higher_exponent: float = 2.0, kpi: bool = False, kpi_band: float = 2.0):
+        """`kpi`: accumulate the discomfort KPIs on the device (`kpi_comfort`, finalised by `kpi.finalize_comfort`) with the
+        scalar comfort band `kpi_band` (`CityLearnEnv.evaluate`'s ``comfort_band``, default 2.0 C -- data.py:399)."""
         self.lib = _lib.load()
         self.engine = engine
-        lstm_w, dyn_pre = pack_lstm(spec, tables, band, lower_exponent, higher_exponent)
+        lstm_w, dyn_pre = pack_lstm(spec, tables, band, lower_exponent, higher_exponent, kpi_band)
+        self.kpi_band = kpi_band
         dev = engine.device
         self.any_active = bool(lstm_w[:, ACTIVE].any())
         self.lstm_w = torch.from_numpy(lstm_w).to(dev)
@@ -117,8 +124,9 @@ class LSTMStage:
         self.hidden = torch.zeros((B, E, abi.CL_LSTM_NHIDDEN), dtype=torch.float32, device=dev)
         self.indoor_temp = torch.zeros((B, E), dtype=torch.float32, device=dev)
         self.comfort = torch.zeros((B, E), dtype=torch.float32, device=dev)
-        self.lib.cl_lstm_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 8 + [ctypes.c_int32, ctypes.c_void_p]
-        self.lib.cl_lstm_reset_f32.argtypes = [ctypes.POINTER(_lib.Dims), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.kpi_comfort = torch.zeros((abi.CL_NKC, B, E), dtype=torch.float32, device=dev) if kpi else None
+        self.lib.cl_lstm_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 9 + [ctypes.c_int32, ctypes.c_void_p]
+        self.lib.cl_lstm_reset_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 4
         self.reset()
 
     def _stream(self) -> int:
@@ -126,7 +134,8 @@ class LSTMStage:
 
     def reset(self):
         with torch.cuda.device(self.engine.device):
-            _lib.check(self.lib.cl_lstm_reset_f32(ctypes.byref(self.engine.dims), self.hist.data_ptr(), self.hidden.data_ptr(), self._stream()))
+            _lib.check(self.lib.cl_lstm_reset_f32(ctypes.byref(self.engine.dims), self.hist.data_ptr(), self.hidden.data_ptr(),
+                                                  None if self.kpi_comfort is None else self.kpi_comfort.data_ptr(), self._stream()))
 
     def step(self, t: int, cool_dem: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t."""
@@ -134,5 +143,6 @@ class LSTMStage:
         with torch.cuda.device(self.engine.device):
             _lib.check(self.lib.cl_lstm_step_f32(ctypes.byref(self.engine.dims), self.lstm_w.data_ptr(), self.dyn_pre.data_ptr(),
                                                  cd.data_ptr(), None, self.hist.data_ptr(), self.hidden.data_ptr(),
-                                                 self.indoor_temp.data_ptr(), self.comfort.data_ptr(), int(t), self._stream()))
+                                                 self.indoor_temp.data_ptr(), self.comfort.data_ptr(),
+                                                 None if self.kpi_comfort is None else self.kpi_comfort.data_ptr(), int(t), self._stream()))
         return self.indoor_temp

@@ -183,3 +183,50 @@ def finalize_streaming(kpi_bldg, kpi_env, steps_done: int, episode_rows: int, ne
     for name, v in building.items():
         district[name] = torch.nanmean(v, dim=0)
     return building, district
+
+
+COMFORT_KPIS = ('discomfort_proportion', 'discomfort_cold_proportion', 'discomfort_hot_proportion',
+                'discomfort_cold_delta_minimum', 'discomfort_cold_delta_maximum', 'discomfort_cold_delta_average',
+                'discomfort_hot_delta_minimum', 'discomfort_hot_delta_maximum', 'discomfort_hot_delta_average',
+                'one_minus_thermal_resilience_proportion')
+
+
+def finalize_comfort(kpi_comfort, spec, tables, steps_done: int, band: float = 2.0):
+    """Discomfort KPIs of `CityLearnEnv.evaluate` (citylearn.py:1199-1215 -> cost_function.py:224-353) for every env from the
+    device accumulators of the LSTM stage (`cl_lstm_step_f32`, `kpi_comfort [CL_NKC, n_bldg, n_env]`).  Like the reference's
+    series, the statistics cover the `steps_done` simulated steps plus -- unless the data ran out -- the untouched data-file
+    row of the next step; occupancy counts are env-independent.  Returns name -> tensor ``[n_bldg, n_env]``."""
+    import torch
+    P = abi
+    k = kpi_comfort.double().clone()
+    B = k.shape[1]
+    n = min(steps_done + 1, tables.n_steps)
+    occupied = torch.zeros((B, 1), dtype=k.dtype, device=k.device)
+    occupied_outage = torch.zeros_like(occupied)
+    for i, b in enumerate(spec.buildings):
+        w = slice(tables.start, tables.start + n)
+        occ = np.asarray(b.series['occupant_count'][w], dtype=np.float64) > 0.0
+        out = np.asarray(tables.outage[:n, i]) != 0.0
+        occupied[i] = occ.sum()
+        occupied_outage[i] = (occ & out).sum()
+        if n > steps_done:                                  # the extra row: data-file temperature, same for every env
+            r = tables.start + steps_done
+            temp = float(b.series['indoor_dry_bulb_temperature'][r])
+            cd = temp - float(b.series['indoor_dry_bulb_temperature_cooling_set_point'][r]) if occ[-1] else 0.0
+            hd = temp - float(b.series['indoor_dry_bulb_temperature_heating_set_point'][r]) if occ[-1] else 0.0
+            hot, cold = cd > band, hd < -band
+            cmag, hmag = abs(min(hd, 0.0)), abs(max(cd, 0.0))
+            k[P.CLKC_UNMET, i] += float(hot or cold); k[P.CLKC_COLD, i] += float(cold); k[P.CLKC_HOT, i] += float(hot)
+            k[P.CLKC_COLD_MIN, i] = torch.clamp(k[P.CLKC_COLD_MIN, i], max=cmag); k[P.CLKC_COLD_MAX, i] = torch.clamp(k[P.CLKC_COLD_MAX, i], min=cmag)
+            k[P.CLKC_HOT_MIN, i] = torch.clamp(k[P.CLKC_HOT_MIN, i], max=hmag); k[P.CLKC_HOT_MAX, i] = torch.clamp(k[P.CLKC_HOT_MAX, i], min=hmag)
+            k[P.CLKC_COLD_SUM, i] += cmag; k[P.CLKC_HOT_SUM, i] += hmag
+            k[P.CLKC_UNMET_OUTAGE, i] += float((hot or cold) and out[-1])
+    return {
+        'discomfort_proportion': k[P.CLKC_UNMET] / occupied, 'discomfort_cold_proportion': k[P.CLKC_COLD] / occupied,
+        'discomfort_hot_proportion': k[P.CLKC_HOT] / occupied,
+        'discomfort_cold_delta_minimum': k[P.CLKC_COLD_MIN], 'discomfort_cold_delta_maximum': k[P.CLKC_COLD_MAX],
+        'discomfort_cold_delta_average': k[P.CLKC_COLD_SUM] / n,
+        'discomfort_hot_delta_minimum': k[P.CLKC_HOT_MIN], 'discomfort_hot_delta_maximum': k[P.CLKC_HOT_MAX],
+        'discomfort_hot_delta_average': k[P.CLKC_HOT_SUM] / n,
+        'one_minus_thermal_resilience_proportion': k[P.CLKC_UNMET_OUTAGE] / occupied_outage,
+    }

@@ -119,7 +119,7 @@ class VectorCityLearnEnv:
             from .dynamics import LSTMStage
             a = self._rf_attrs if self._comfort else {}
             self.stage = LSTMStage(self.spec, self.tables, self.engine, a.get('band'), a.get('lower_exponent') or 2.0,
-                                   a.get('higher_exponent') or 2.0)
+                                   a.get('higher_exponent') or 2.0, kpi=self.kpi)
         self._t = 0
         self._exo = self.engine.ts            # [T, B, CL_NF] on device: exogenous values per (t, building)
         self.writer = None
@@ -200,7 +200,14 @@ class VectorCityLearnEnv:
                               + float(b.series['dhw_demand'][row]) + float(b.series['non_shiftable_load'][row])
                               for b in self.spec.buildings])
             nxt_o = (self.tables.outage[self._t] != 0).astype(np.float64)
-        return finalize_streaming(self.engine.kpi_bldg, self.engine.kpi_env, self._t, self.time_steps, nxt_e, nxt_o)
+        building, district = finalize_streaming(self.engine.kpi_bldg, self.engine.kpi_env, self._t, self.time_steps, nxt_e, nxt_o)
+        if self.stage is not None and self.stage.kpi_comfort is not None:
+            from .kpi import finalize_comfort
+            comfort = finalize_comfort(self.stage.kpi_comfort, self.spec, self.tables, self._t, self.stage.kpi_band)
+            building.update(comfort)
+            for name, v in comfort.items():
+                district[name] = torch.nanmean(v, dim=0)
+        return building, district
 
     def sample_actions(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """Uniform random actions inside the action space (the device analogue of `Agent.predict`, agents/base.py:188-209)."""

@@ -272,8 +272,20 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
 #define CL_LSTM_NHIST 24
 #define CL_LSTM_NHIDDEN 64
 
-/* Episode start: zero `hist` and `hidden` (LSTMDynamics.reset, dynamics.py:112-127). */
-int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, void* stream);
+/* Streaming comfort KPI accumulators `kpi_comfort[CL_NKC][n_bldg][n_env]` (row K of SURVEY 8a for dynamics buildings):
+ * running sums / extrema of CostFunction.discomfort and one_minus_thermal_resilience (cost_function.py:224-353),
+ * updated by cl_lstm_step_f32 with the temperature it just predicted; finalised on the host (kpi.finalize_comfort). */
+#define CL_NKC 10
+enum cl_kpi_comfort {
+    CLKC_UNMET = 0, CLKC_COLD, CLKC_HOT,                 /* occupied steps outside / below / above the comfort band */
+    CLKC_COLD_MIN, CLKC_COLD_MAX, CLKC_COLD_SUM,         /* |min(T - heating set point, 0)| */
+    CLKC_HOT_MIN, CLKC_HOT_MAX, CLKC_HOT_SUM,            /* |max(T - cooling set point, 0)| */
+    CLKC_UNMET_OUTAGE                                    /* occupied steps outside the band during a power outage */
+};
+
+/* Episode start: zero `hist` and `hidden` (LSTMDynamics.reset, dynamics.py:112-127) and, when given, initialise
+ * `kpi_comfort` (sums 0, minima +inf, maxima -inf). */
+int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, float* kpi_comfort, void* stream);
 
 /* After cl_step_f32 of step `t`: push the delivered cooling `cool_dem` [n_bldg][n_env] (out_bldg plane CLO_COOL_DEM)
  * into the window and, once lookback+1 samples exist (t >= 12), run the LSTM over the 12-step window and write the
@@ -281,10 +293,11 @@ int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, void* str
  * buildings without a dynamics model).  Replaces LSTMDynamicsBuilding._update_dynamics_input +
  * update_indoor_dry_bulb_temperature (building.py:3000-3078).
  * `comfort` (optional) receives ComfortReward.calculate per building (reward_function.py:269-334) evaluated on that
- * temperature; `heat_dem` (optional) is the delivered heating plane it compares the cooling demand with. */
+ * temperature; `heat_dem` (optional) is the delivered heating plane it compares the cooling demand with;
+ * `kpi_comfort` (optional) accumulates the discomfort KPIs. */
 int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* cool_dem,
-                     const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort, int32_t t,
-                     void* stream);
+                     const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,
+                     float* kpi_comfort, int32_t t, void* stream);
 
 /* ---- observation epilogue ----
  * Writes the observation tensor obs[n_env][n_cols] (one contiguous vector per environment, the layout a policy

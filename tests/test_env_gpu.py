@@ -130,7 +130,7 @@ def test_streaming_kpi_accumulators(name, K):
     gen = torch.Generator(device='cuda').manual_seed(1)
     acts_g = torch.from_numpy(g.ref['actions']).cuda()
     B, E = eng.n_bldg, 8
-    hist = {k: np.zeros((K, B, E), dtype='float32') for k in ('net', 'base', 'exp', 'srv')}
+    hist = {k: np.zeros((K, B, E), dtype='float32') for k in ('net', 'base', 'exp', 'srv', 'temp')}
     d_net = np.zeros((K, E))
     for t in range(K):
         a = env.sample_actions(gen)
@@ -139,6 +139,8 @@ def test_streaming_kpi_accumulators(name, K):
         ob = eng.out_bldg.cpu().numpy()
         hist['net'][t], hist['base'][t] = ob[abi.CLO_NET], ob[abi.CLO_BASE_NET]
         hist['exp'][t], hist['srv'][t] = ob[abi.CLO_EXPECTED], ob[abi.CLO_SERVED]
+        if env.stage is not None:
+            hist['temp'][t] = env.stage.indoor_temp.cpu().numpy()
         d_net[t] = eng.out_env[abi.CLQ_NET].cpu().numpy()
     building, district = env.evaluate()
     tab = env.tables
@@ -146,12 +148,13 @@ def test_streaming_kpi_accumulators(name, K):
         net = hist['net'][:, :, e]
         cost = (net.astype(np.float64) * tab.ts[:K, :, abi.CLT_PRICE]).astype('float32')
         em = np.maximum(0, net.astype(np.float64) * tab.ts[:K, :, abi.CLT_CARBON]).astype('float32')
-        frame = evaluate_district(env.spec, tab, K, net, hist['base'][:, :, e], cost, em, hist['exp'][:, :, e], hist['srv'][:, :, e], d_net[:, e])
+        frame = evaluate_district(env.spec, tab, K, net, hist['base'][:, :, e], cost, em, hist['exp'][:, :, e], hist['srv'][:, :, e], d_net[:, e],
+                                  indoor_temp=hist['temp'][:, :, e] if env.stage is not None else None)
         ref = {(r.level, r.name, r.cost_function): r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
         n = 0
         for (level, bname, fn), v in ref.items():
-            if fn.startswith(('discomfort', 'one_minus_thermal')):
-                continue
+            if fn.startswith(('discomfort', 'one_minus_thermal')) and env.stage is None:
+                continue                                   # no dynamics building: env-independent constants of the data files
             if level == 'district':
                 got = float(district[fn][e])
             else:
