@@ -463,9 +463,23 @@ int g_force_vec = 0;   // test / tuning hooks (cl_debug_set_vec / cl_debug_set_l
 int g_force_nw = 0;
 int g_no_chunks = 0;
 int g_obs_variant = 0;   // 1 / 2 / 3: force the row-wise / LDS-tile / wave-independent observation kernel (tests, tuning)
+int g_lstm_dbg = 0;
 int g_obs_rows = 0;      // tile kernel: envs per block (tuning)
 
 }  // namespace
+
+
+// ---- layout probe for v_mfma_f32_32x32x16_bf16 (tests/test_gpu_lstm.py::test_bf16_mfma_operand_layout) ----
+typedef __bf16 cl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float cl_f32x16 __attribute__((ext_vector_type(16)));
+__global__ void cl_mfma_bf16_probe_kernel(const uint16_t* A, const uint16_t* B, float* D) {
+    const int l = threadIdx.x, i = l & 31, kh = l >> 5;
+    union { cl_bf16x8 v; uint16_t u[8]; } a, b;
+    for (int j = 0; j < 8; ++j) { a.u[j] = A[i * 16 + 8 * kh + j]; b.u[j] = B[(8 * kh + j) * 32 + i]; }
+    cl_f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + i] = c[r];
+}
 
 extern "C" {
 
@@ -475,6 +489,12 @@ const char* cl_last_error(void) { return g_err; }
 
 void cl_debug_set_vec(int vec) { g_force_vec = vec; }
 void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks; g_force_nw = nw; }
+void cl_debug_set_lstm(int dbg) { g_lstm_dbg = dbg; }
+int cl_debug_mfma_bf16_probe(const uint16_t* A, const uint16_t* B, float* D, void* stream) {
+    hipLaunchKernelGGL(cl_mfma_bf16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "probe launch");
+    return CL_OK;
+}
 void cl_debug_set_observe(int variant, int rows) { g_obs_variant = variant; g_obs_rows = rows; }
 
 int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, float* kpi_bldg, float* kpi_env,
@@ -682,7 +702,11 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_
     if (int rc = check_ptr(kpi_comfort, "kpi_comfort", false)) return rc;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t; a.env_row0 = dims->env_row0;
     const dim3 grid((dims->n_env + 127) / 128, dims->n_bldg);          // 4 waves x 32 envs per workgroup
-    hipLaunchKernelGGL(cl_lstm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    switch (g_lstm_dbg) {            // timing experiments (scripts/lstm_check.py); 0 in production
+    case 1: hipLaunchKernelGGL(cl_lstm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(cl_lstm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(cl_lstm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_kernel launch");
     return CL_OK;
 }

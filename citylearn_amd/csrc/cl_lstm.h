@@ -104,7 +104,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 CL_DEV int lstm_unit(int m, int hh) { return (m & 3) + 8 * (m >> 2) + 4 * hh; }
 
+template <int DBG = 0>
 CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&h)[8]) {
+    if constexpr (DBG & 1) {                     // timing experiment: no activations (keeps the data dependence)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { c[m] = d0[8 + m] + d1[m]; h[m] = d1[8 + m] * 0.001f + d0[m] * 0.001f; }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const float cn = sigmoidf_(d0[8 + m]) * c[m] + sigmoidf_(d0[m]) * tanhf_(d1[m]);     // f c + i g
@@ -113,6 +119,7 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
     }
 }
 
+template <int DBG>
 __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const int lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
@@ -158,44 +165,70 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
                 h0[m] = hid[0 * CL_LSTM_H + u]; c0[m] = hid[1 * CL_LSTM_H + u];
                 h1[m] = hid[2 * CL_LSTM_H + u]; c1[m] = hid[3 * CL_LSTM_H + u];
             }
-            for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
+            // The window loop issues no memory instruction on its critical path:
+            //  * the env-independent layer-0 pre-gates and the layer-1 bias enter the accumulators through one extra MFMA
+            //    (A = the 64 values, B = 1 in k-slot 0) instead of 32 loads + accumulator writes per cell;
+            //  * the three per-lane inputs of step s+1 (two pre-gate values, one history sample) are fetched at the top of
+            //    step s, a whole step ahead of their use.
+            // Layer 1's recurrent half W_hh1 h1 does not need this step's layer-0 output and is issued first.  MFMA chains
+            // are kept free of interleaved VALU (an extra issue slot between MFMAs costs far more than the instruction,
+            // MI355X_MICROARCH.md); the second wave of the SIMD fills the matrix pipe during this wave's activations.
+#define CL_MFMA(A, B, C) ((DBG & 2) ? (C) + (A) * (B) : __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0))
+            const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const float one_b = hh ? 0.0f : 1.0f;
+            const float a_b1[2] = {W[CLW_B1 + col], W[CLW_B1 + 32 + col]};
+            auto fetch = [&](int s, float (&ap)[2], float& xin) {
                 const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
                 const float* __restrict__ pre = a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
+                ap[0] = pre[col]; ap[1] = pre[32 + col];
                 // extra k-pair of layer 0: slot 0 = cooling demand at `time`, slot 1 = temperature at `time - 1`
                 const long long hrow = hh ? (long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) : (long long)(time % CL_LSTM_LOOKBACK);
-                float xin = a.hist[hrow * plane + off];
-                if (!hh && s == CL_LSTM_LOOKBACK - 1) xin = cool_n;      // the newest cooling sample was produced by this launch
-                f32x16 d0, d1;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {                           // accumulators start from the env-independent part
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    d0[r] = pre[row]; d1[r] = pre[32 + row];
-                }
-                d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_x0[0], xin, d0, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_x0[1], xin, d1, 0, 0, 0);
+                xin = a.hist[hrow * plane + off];                          // (step 11, slot 0 is overridden at the point of use)
+            };
+            auto layer0 = [&](const float (&ap)[2], float xin, f32x16& d0, f32x16& d1) {
+                d0 = CL_MFMA(ap[0], one_b, zero16);
+                d1 = CL_MFMA(ap[1], one_b, zero16);
+                d0 = CL_MFMA(a_x0[0], xin, d0);
+                d1 = CL_MFMA(a_x0[1], xin, d1);
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hh0[0][kk], h0[kk], d0, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hh0[1][kk], h0[kk], d1, 0, 0, 0);
+                    d0 = CL_MFMA(a_hh0[0][kk], h0[kk], d0);
+                    d1 = CL_MFMA(a_hh0[1][kk], h0[kk], d1);
                 }
-                lstm_act(d0, d1, c0, h0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    d0[r] = W[CLW_B1 + row]; d1[r] = W[CLW_B1 + 32 + row];
-                }
+            };
+            // Two waves share a SIMD.  With equal priority they contend fairly for the matrix pipe, leave their MFMA blocks
+            // together and run their activations together: MFMA time + VALU time, no overlap (measured: 153 us + 74 us =
+            // 218 us).  A static priority difference (by hardware wave slot) lets one wave own the pipe while the other
+            // computes activations, and vice versa.
+            if (__builtin_amdgcn_s_getreg(6148 /* HW_REG_HW_ID, wave_id [3:0] */) & 1) __builtin_amdgcn_s_setprio(3);
+            f32x16 d0, d1, e0, e1;
+            float ap[2], xin, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f;
+            fetch(0, ap, xin);
+            layer0(ap, xin, d0, d1);
+            for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
+                fetch(min(s + 1, CL_LSTM_LOOKBACK - 1), ap_n, xin_n);    // unconditional: no wait is forced at a join
+                e0 = CL_MFMA(a_b1[0], one_b, zero16);
+                e1 = CL_MFMA(a_b1[1], one_b, zero16);
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ih1[0][kk], h0[kk], d0, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_ih1[1][kk], h0[kk], d1, 0, 0, 0);
+                    e0 = CL_MFMA(a_hh1[0][kk], h1[kk], e0);
+                    e1 = CL_MFMA(a_hh1[1][kk], h1[kk], e1);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                lstm_act<DBG>(d0, d1, c0, h0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
-                    d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hh1[0][kk], h1[kk], d0, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hh1[1][kk], h1[kk], d1, 0, 0, 0);
+                    e0 = CL_MFMA(a_ih1[0][kk], h0[kk], e0);
+                    e1 = CL_MFMA(a_ih1[1][kk], h0[kk], e1);
                 }
-                lstm_act(d0, d1, c1, h1);
+                // the newest cooling sample (step 11, k-slot 0) was produced by this launch, not read from the ring
+                if (s + 1 < CL_LSTM_LOOKBACK) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
+                __builtin_amdgcn_sched_barrier(0);
+                lstm_act<DBG>(e0, e1, c1, h1);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#undef CL_MFMA
             if (live) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {

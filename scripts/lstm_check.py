@@ -20,8 +20,9 @@ for t in range(g.facts['steps']):
     ref = g.ref['reward_ComfortReward'][t]
     wr = max(wr, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
 print('teacher-fed: worst |dT| =', wt, 'C ; worst comfort reward err / (1e-4 + 1e-4|ref|) =', wr)
-for E in (4096, 65536):
+for E, dbg in ((4096, 0), (65536, 0), (65536, 1), (65536, 2), (4096, 1), (4096, 2)):
     eng = StepEngine(tab, E, detail=True)
+    eng.lib.cl_debug_set_lstm(dbg)
     stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0)
     cd = torch.rand((3, E), device='cuda') * 5
     for t in range(12, 16): stage.step(t, cd)
@@ -33,4 +34,4 @@ for E in (4096, 65536):
     ev1.record(); torch.cuda.synchronize()
     us = ev0.elapsed_time(ev1) / n * 1e3
     flop = 3 * E * 12 * (64 * 18 + 64 * 32) * 2
-    print(f'E={E}: {us:.1f} us per LSTM step  {3*E/us*1e6:.3e} building-timesteps/s  {flop/us/1e6:.1f} TFLOP/s fp32')
+    print(f'E={E}{["", " [experiment: no activations]", " [experiment: no MFMA]"][dbg]}: {us:.1f} us per LSTM step  {3*E/us*1e6:.3e} building-timesteps/s  {flop/us/1e6:.1f} TFLOP/s fp32')

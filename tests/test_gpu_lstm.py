@@ -106,3 +106,21 @@ def test_vector_env_comfort_reward():
         assert reward.shape == (128,) and obs['indoor_dry_bulb_temperature'].shape == (3, 128)
         tot += reward
     np.testing.assert_allclose(float(tot[0]), g.ref['env_rewards'][:60, 0].sum(), rtol=2e-3)
+
+
+def test_bf16_mfma_operand_layout():
+    """Known-answer test of the operand layout the split-bf16 LSTM kernel relies on: lane l of
+    v_mfma_f32_32x32x16_bf16 supplies A[l & 31][8 (l >> 5) + 0..7] and B[8 (l >> 5) + 0..7][l & 31]; D[row][col] with
+    col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).  Asymmetric random operands (bf16-exact values)."""
+    import ctypes
+    from citylearn_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(0)
+    A = rng.randint(-64, 64, size=(32, 16)).astype(np.float32) / 16.0          # exact in bf16
+    B = rng.randint(-64, 64, size=(16, 32)).astype(np.float32) / 8.0
+    to_bf16 = lambda x: (x.view(np.uint32) >> 16).astype(np.uint16)
+    a = torch.from_numpy(to_bf16(A).astype(np.int16)).cuda(); b = torch.from_numpy(to_bf16(B).astype(np.int16)).cuda()
+    d = torch.zeros((32, 32), device='cuda')
+    lib.cl_debug_mfma_bf16_probe.argtypes = [ctypes.c_void_p] * 4
+    _lib.check(lib.cl_debug_mfma_bf16_probe(a.data_ptr(), b.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    np.testing.assert_array_equal(d.cpu().numpy(), (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32))
