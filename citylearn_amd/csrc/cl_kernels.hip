@@ -481,6 +481,37 @@ __global__ void cl_mfma_bf16_probe_kernel(const uint16_t* A, const uint16_t* B, 
     for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + i] = c[r];
 }
 
+// ---- issue-rate microbenchmark (scripts/mfma_bench.py): how MFMA chains and transcendental VALU work share a SIMD ----
+template <int MODE>
+__global__ void __launch_bounds__(256) cl_mfma_bench_kernel(float* out, int iters) {
+    const int l = threadIdx.x & 63;
+    union { cl_bf16x8 v; uint16_t u[8]; } a, b;
+    for (int j = 0; j < 8; ++j) { a.u[j] = 0x3c00 + l + j; b.u[j] = 0x3b80 + l * 3 + j; }
+    const float af = 1.0f + l * 1e-3f, bfv = 0.5f + l * 1e-3f;
+    cl_f32x16 c0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    float x0 = l * 1e-3f, x1 = x0 + 0.1f, x2 = x0 + 0.2f, x3 = x0 + 0.3f;
+#define BF(C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, C, 0, 0, 0);
+#define F32(C) C = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bfv, C, 0, 0, 0);
+#define VX x0 = __expf(-x0); x1 = __expf(-x1); x2 = __expf(-x2); x3 = __expf(-x3);
+    for (int i = 0; i < iters; ++i) {
+        if constexpr (MODE == 0) { BF(c0) BF(c0) BF(c0) BF(c0) BF(c0) BF(c0) BF(c0) BF(c0) }
+        if constexpr (MODE == 1) { BF(c0) BF(c1) BF(c0) BF(c1) BF(c0) BF(c1) BF(c0) BF(c1) }
+        if constexpr (MODE == 2) { BF(c0) BF(c1) BF(c2) BF(c3) BF(c0) BF(c1) BF(c2) BF(c3) }
+        if constexpr (MODE == 3) { BF(c0) VX BF(c1) VX BF(c0) VX BF(c1) VX BF(c0) VX BF(c1) VX BF(c0) VX BF(c1) VX }
+        if constexpr (MODE == 4) { VX VX VX VX VX VX VX VX }
+        if constexpr (MODE == 5) { F32(c0) F32(c1) F32(c0) F32(c1) F32(c0) F32(c1) F32(c0) F32(c1) }
+        if constexpr (MODE == 6) { F32(c0) VX F32(c1) VX F32(c0) VX F32(c1) VX F32(c0) VX F32(c1) VX F32(c0) VX F32(c1) VX }
+        if constexpr (MODE == 7) { BF(c0) BF(c1) BF(c0) BF(c1) BF(c0) BF(c1) BF(c0) BF(c1) VX VX VX VX VX VX VX VX }   // blocks, not interleaved
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef BF
+#undef F32
+#undef VX
+    float r = x0 + x1 + x2 + x3;
+    for (int k = 0; k < 16; ++k) r += c0[k] + c1[k] + c2[k] + c3[k];
+    if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
 extern "C" {
 
 int cl_abi_version(void) { return CL_ABI_VERSION; }
@@ -490,6 +521,17 @@ const char* cl_last_error(void) { return g_err; }
 void cl_debug_set_vec(int vec) { g_force_vec = vec; }
 void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks; g_force_nw = nw; }
 void cl_debug_set_lstm(int dbg) { g_lstm_dbg = dbg; }
+int cl_debug_mfma_bench(int mode, int waves_per_simd, int iters, float* out, void* stream) {
+    const dim3 grid(256 * waves_per_simd), block(256);
+    switch (mode) {
+#define CL_CASE(M) case M: hipLaunchKernelGGL(cl_mfma_bench_kernel<M>, grid, block, 0, (hipStream_t)stream, out, iters); break;
+    CL_CASE(0) CL_CASE(1) CL_CASE(2) CL_CASE(3) CL_CASE(4) CL_CASE(5) CL_CASE(6) CL_CASE(7)
+#undef CL_CASE
+    default: return fail(CL_EINVAL, "mode");
+    }
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "bench launch");
+    return CL_OK;
+}
 int cl_debug_mfma_bf16_probe(const uint16_t* A, const uint16_t* B, float* D, void* stream) {
     hipLaunchKernelGGL(cl_mfma_bf16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "probe launch");
@@ -685,7 +727,7 @@ int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, float* kp
     return CL_OK;
 }
 
-int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* cool_dem,
+int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* lstm_wb, const float* dyn_pre, const float* cool_dem,
                      const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,
                      float* kpi_comfort, int32_t t, void* stream) {
     if (int rc = check_dims(dims)) return rc;
@@ -702,10 +744,17 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_
     if (int rc = check_ptr(kpi_comfort, "kpi_comfort", false)) return rc;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t; a.env_row0 = dims->env_row0;
     const dim3 grid((dims->n_env + 127) / 128, dims->n_bldg);          // 4 waves x 32 envs per workgroup
+    a.lstm_wb = lstm_wb;
+    if (int rc = check_ptr(lstm_wb, "lstm_wb", false)) return rc;
     switch (g_lstm_dbg) {            // timing experiments (scripts/lstm_check.py); 0 in production
-    case 1: hipLaunchKernelGGL(cl_lstm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(cl_lstm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL(cl_lstm_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    case 1: hipLaunchKernelGGL((cl_lstm_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL((cl_lstm_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL((cl_lstm_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;   // f32 MFMA path
+    case 5: hipLaunchKernelGGL((cl_lstm_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 6: hipLaunchKernelGGL((cl_lstm_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    default:
+        if (lstm_wb) hipLaunchKernelGGL((cl_lstm_kernel<0, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((cl_lstm_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_kernel launch");
     return CL_OK;

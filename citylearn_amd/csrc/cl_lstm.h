@@ -81,6 +81,7 @@ CL_DEV float comfort_reward(float temp, float cool_dem, float heat_dem, float mo
 
 struct LstmArgs {
     const float* __restrict__ lstm_w;     // [B][CL_LSTM_NW]
+    const uint16_t* __restrict__ lstm_wb; // [B][CL_LSTM_NWB] bf16 split-weight fragments (see CL_LSTM_NWB) or null
     const float* __restrict__ dyn_pre;    // [T][B][CL_LSTM_NPRE]
     const float* __restrict__ cool_dem;   // [B][E] delivered cooling of this step (out_bldg plane CLO_COOL_DEM)
     float* __restrict__ hist;             // [24][B][E]: rings of the last 12 normalised cooling demands / temperatures
@@ -119,7 +120,47 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
     }
 }
 
-template <int DBG>
+
+// ---- split-bf16 path ---------------------------------------------------------------------------------------------
+// The f32-input MFMA runs at the f32 VECTOR rate and -- measured -- does not overlap with VALU work: with it the kernel
+// costs MFMA time + activation time (153 us + 74 us at 3 x 65 536).  The bf16 matrix cores are 16x faster and run
+// beside the VALU, so the recurrent products W h go through v_mfma_f32_32x32x16_bf16 with both operands split into
+// three bf16 terms (x = x0 + x1 + x2, |x_i| <= 2^-8 |x_{i-1}|, round-to-nearest) and the six partial products with
+// i + j <= 2 accumulated in fp32: the dropped terms are <= 2^-24 |W||h|, i.e. fp32-level.  The weights are split on
+// the host (dynamics.pack_lstm_bf16), h is split in registers after every cell.  The two env-dependent layer-0 inputs,
+// the pre-gates and the bias keep the exact f32 MFMA (K = 2).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+/* lstm_wb layout (CL_LSTM_NWB = 18 * 64 * 8 bf16 per building): fragment f = 6 * matrix{hh0, ih1, hh1} + 3 * row_block + term,
+   then [lane][8]: W[32 row_block + (lane & 31)][unit u(j, lane >> 5)], j = 0..7 */
+
+CL_DEV void lstm_split3(const float (&h)[8], bf16x8 (&t)[3]) {
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = h[j];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 q = (__bf16)r[j];                 // round to nearest even (v_cvt_pk_bf16_f32)
+            t[k][j] = q;
+            r[j] -= (float)q;                              // exact
+        }
+    }
+}
+
+// acc_r += sum_{i + j <= 2} A_r,i B_j for the two row blocks r, smallest terms first; the two accumulators alternate so
+// that consecutive MFMAs are independent
+template <int DBG = 0>
+CL_DEV void lstm_mma6(const bf16x8 (&A0)[3], const bf16x8 (&A1)[3], const bf16x8 (&B)[3], f32x16& acc0, f32x16& acc1) {
+    if constexpr (DBG & 2) { acc0[0] += (float)B[0][0]; acc1[0] += (float)B[1][0] + (float)B[2][0]; return; }   // timing experiment
+#define CL_MMA2(I, J)                                                                   \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[I], B[J], acc0, 0, 0, 0);          \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[I], B[J], acc1, 0, 0, 0);
+    CL_MMA2(2, 0) CL_MMA2(1, 1) CL_MMA2(0, 2) CL_MMA2(1, 0) CL_MMA2(0, 1) CL_MMA2(0, 0)
+#undef CL_MMA2
+}
+
+template <int DBG, bool SPLIT>
 __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const int lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
@@ -144,16 +185,27 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
         if (a.t >= CL_LSTM_LOOKBACK) {                            // lookback + 1 samples exist (building.py:2996-2999)
             // A operands: row = 32 rb + col of the torch gate matrix, k-slot 2 kk + hh -> hidden unit u(kk)
             float a_hh0[2][8], a_x0[2], a_ih1[2][8], a_hh1[2][8];
+            bf16x8 A_hh0[2][3], A_ih1[2][3], A_hh1[2][3];
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int row = 32 * rb + col;
                 a_x0[rb] = hh ? W[CLW_WT + row] : W[CLW_WC + row];
+                if constexpr (SPLIT) {
+                    const bf16x8* __restrict__ F = reinterpret_cast<const bf16x8*>(a.lstm_wb + (long long)b * CL_LSTM_NWB);
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const int u = lstm_unit(kk, hh);
-                    a_hh0[rb][kk] = W[CLW_WHH0 + row * CL_LSTM_H + u];
-                    a_ih1[rb][kk] = W[CLW_WIH1 + row * CL_LSTM_H + u];
-                    a_hh1[rb][kk] = W[CLW_WHH1 + row * CL_LSTM_H + u];
+                    for (int k = 0; k < 3; ++k) {
+                        A_hh0[rb][k] = F[(0 * 6 + rb * 3 + k) * 64 + lane];
+                        A_ih1[rb][k] = F[(1 * 6 + rb * 3 + k) * 64 + lane];
+                        A_hh1[rb][k] = F[(2 * 6 + rb * 3 + k) * 64 + lane];
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int u = lstm_unit(kk, hh);
+                        a_hh0[rb][kk] = W[CLW_WHH0 + row * CL_LSTM_H + u];
+                        a_ih1[rb][kk] = W[CLW_WIH1 + row * CL_LSTM_H + u];
+                        a_hh1[rb][kk] = W[CLW_WHH1 + row * CL_LSTM_H + u];
+                    }
                 }
             }
             // carried state of this lane's eight units
@@ -185,48 +237,55 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
                 const long long hrow = hh ? (long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) : (long long)(time % CL_LSTM_LOOKBACK);
                 xin = a.hist[hrow * plane + off];                          // (step 11, slot 0 is overridden at the point of use)
             };
+            bf16x8 H0[3], H1[3];                                          // split hidden states (B operands)
             auto layer0 = [&](const float (&ap)[2], float xin, f32x16& d0, f32x16& d1) {
                 d0 = CL_MFMA(ap[0], one_b, zero16);
                 d1 = CL_MFMA(ap[1], one_b, zero16);
                 d0 = CL_MFMA(a_x0[0], xin, d0);
                 d1 = CL_MFMA(a_x0[1], xin, d1);
+                if constexpr (SPLIT) lstm_mma6<DBG>(A_hh0[0], A_hh0[1], H0, d0, d1);
+                else {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    d0 = CL_MFMA(a_hh0[0][kk], h0[kk], d0);
-                    d1 = CL_MFMA(a_hh0[1][kk], h0[kk], d1);
+                    for (int kk = 0; kk < 8; ++kk) {
+                        d0 = CL_MFMA(a_hh0[0][kk], h0[kk], d0);
+                        d1 = CL_MFMA(a_hh0[1][kk], h0[kk], d1);
+                    }
                 }
             };
-            // Two waves share a SIMD.  With equal priority they contend fairly for the matrix pipe, leave their MFMA blocks
-            // together and run their activations together: MFMA time + VALU time, no overlap (measured: 153 us + 74 us =
-            // 218 us).  A static priority difference (by hardware wave slot) lets one wave own the pipe while the other
-            // computes activations, and vice versa.
-            if (__builtin_amdgcn_s_getreg(6148 /* HW_REG_HW_ID, wave_id [3:0] */) & 1) __builtin_amdgcn_s_setprio(3);
             f32x16 d0, d1, e0, e1;
             float ap[2], xin, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f;
+            if constexpr (SPLIT) { lstm_split3(h0, H0); lstm_split3(h1, H1); }
             fetch(0, ap, xin);
             layer0(ap, xin, d0, d1);
             for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
                 fetch(min(s + 1, CL_LSTM_LOOKBACK - 1), ap_n, xin_n);    // unconditional: no wait is forced at a join
                 e0 = CL_MFMA(a_b1[0], one_b, zero16);
                 e1 = CL_MFMA(a_b1[1], one_b, zero16);
+                if constexpr (SPLIT) lstm_mma6<DBG>(A_hh1[0], A_hh1[1], H1, e0, e1);
+                else {
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    e0 = CL_MFMA(a_hh1[0][kk], h1[kk], e0);
-                    e1 = CL_MFMA(a_hh1[1][kk], h1[kk], e1);
+                    for (int kk = 0; kk < 8; ++kk) {
+                        e0 = CL_MFMA(a_hh1[0][kk], h1[kk], e0);
+                        e1 = CL_MFMA(a_hh1[1][kk], h1[kk], e1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 lstm_act<DBG>(d0, d1, c0, h0);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SPLIT) { lstm_split3(h0, H0); lstm_mma6<DBG>(A_ih1[0], A_ih1[1], H0, e0, e1); }
+                else {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    e0 = CL_MFMA(a_ih1[0][kk], h0[kk], e0);
-                    e1 = CL_MFMA(a_ih1[1][kk], h0[kk], e1);
+                    for (int kk = 0; kk < 8; ++kk) {
+                        e0 = CL_MFMA(a_ih1[0][kk], h0[kk], e0);
+                        e1 = CL_MFMA(a_ih1[1][kk], h0[kk], e1);
+                    }
                 }
                 // the newest cooling sample (step 11, k-slot 0) was produced by this launch, not read from the ring
                 if (s + 1 < CL_LSTM_LOOKBACK) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!SPLIT) __builtin_amdgcn_sched_barrier(0);
                 lstm_act<DBG>(e0, e1, c1, h1);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SPLIT) lstm_split3(h1, H1);
+                else __builtin_amdgcn_sched_barrier(0);
             }
 #undef CL_MFMA
             if (live) {

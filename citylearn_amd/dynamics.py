@@ -104,11 +104,43 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
     return lstm_w, dyn_pre
 
 
+def _bf16_split3(x: np.ndarray) -> np.ndarray:
+    """x (float64 / float32) -> [3, ...] uint16: three round-to-nearest-even bf16 terms with x ~= t0 + t1 + t2."""
+    r = np.asarray(x, dtype=np.float32).copy()
+    out = []
+    for _ in range(3):
+        bits = r.view(np.uint32).astype(np.uint64)
+        q = ((bits + 0x7FFF + ((bits >> 16) & 1)) >> 16).astype(np.uint32)          # RNE to the upper 16 bits
+        out.append(q.astype(np.uint16))
+        r = (r - (q << 16).astype(np.uint32).view(np.float32)).astype(np.float32)    # exact residual
+    return np.stack(out)
+
+
+def pack_lstm_bf16(lstm_w: np.ndarray) -> np.ndarray:
+    """The three recurrent matrices of `lstm_w` ([B, CL_LSTM_NW], padded 64 x 16 layout) as split-bf16 MFMA A-operand
+    fragments: ``[B, 18, 64, 8]`` uint16, fragment ``6 * matrix{hh0, ih1, hh1} + 3 * row_block + term``, element
+    ``[lane][j] = W[32 row_block + (lane & 31)][unit (j & 3) + 8 (j >> 2) + 4 (lane >> 5)]`` (csrc/cl_lstm.h)."""
+    B = lstm_w.shape[0]
+    out = np.zeros((B, 18, 64, 8), dtype=np.uint16)
+    lane = np.arange(64)
+    j = np.arange(8)
+    unit = (j[None, :] & 3) + 8 * (j[None, :] >> 2) + 4 * (lane[:, None] >> 5)      # [64, 8]
+    for m, base in enumerate((WHH0, WIH1, WHH1)):
+        Wm = lstm_w[:, base:base + 1024].reshape(B, 64, 16)
+        for rb in range(2):
+            rows = 32 * rb + (lane & 31)                                             # [64]
+            frag = Wm[:, rows[:, None], unit]                                        # [B, 64, 8]
+            split = _bf16_split3(frag)                                               # [3, B, 64, 8]
+            for k in range(3):
+                out[:, m * 6 + rb * 3 + k] = split[k]
+    return out
+
+
 class LSTMStage:
     """Device state + driver of the LSTM stage for one env shard (pairs with a `StepEngine` built with detail=True)."""
 
     def __init__(self, spec: DistrictSpec, tables: EpisodeTables, engine, band=None, lower_exponent: float = 2.0,
-                 higher_exponent: float = 2.0, kpi: bool = False, kpi_band: float = 2.0):
+                 higher_exponent: float = 2.0, kpi: bool = False, kpi_band: float = 2.0, split_bf16: bool = True):
         """`kpi`: accumulate the discomfort KPIs on the device (`kpi_comfort`, finalised by `kpi.finalize_comfort`) with the
         scalar comfort band `kpi_band` (`CityLearnEnv.evaluate`'s ``comfort_band``, default 2.0 C -- data.py:399)."""
         self.lib = _lib.load()
@@ -118,6 +150,8 @@ class LSTMStage:
         dev = engine.device
         self.any_active = bool(lstm_w[:, ACTIVE].any())
         self.lstm_w = torch.from_numpy(lstm_w).to(dev)
+        # split-bf16 fragments of the recurrent matrices (bf16 matrix-core path); int16 storage of the raw bf16 bits
+        self.lstm_wb = torch.from_numpy(pack_lstm_bf16(lstm_w).view(np.int16)).to(dev) if split_bf16 else None
         self.dyn_pre = torch.from_numpy(dyn_pre).to(dev)
         B, E = engine.n_bldg, engine.n_env
         self.hist = torch.zeros((abi.CL_LSTM_NHIST, B, E), dtype=torch.float32, device=dev)
@@ -125,7 +159,7 @@ class LSTMStage:
         self.indoor_temp = torch.zeros((B, E), dtype=torch.float32, device=dev)
         self.comfort = torch.zeros((B, E), dtype=torch.float32, device=dev)
         self.kpi_comfort = torch.zeros((abi.CL_NKC, B, E), dtype=torch.float32, device=dev) if kpi else None
-        self.lib.cl_lstm_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 9 + [ctypes.c_int32, ctypes.c_void_p]
+        self.lib.cl_lstm_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 10 + [ctypes.c_int32, ctypes.c_void_p]
         self.lib.cl_lstm_reset_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 4
         self.reset()
 
@@ -141,7 +175,8 @@ class LSTMStage:
         """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t."""
         cd = self.engine.out_bldg[abi.CLO_COOL_DEM] if cool_dem is None else cool_dem
         with torch.cuda.device(self.engine.device):
-            _lib.check(self.lib.cl_lstm_step_f32(ctypes.byref(self.engine.dims), self.lstm_w.data_ptr(), self.dyn_pre.data_ptr(),
+            _lib.check(self.lib.cl_lstm_step_f32(ctypes.byref(self.engine.dims), self.lstm_w.data_ptr(),
+                                                 None if self.lstm_wb is None else self.lstm_wb.data_ptr(), self.dyn_pre.data_ptr(),
                                                  cd.data_ptr(), None, self.hist.data_ptr(), self.hidden.data_ptr(),
                                                  self.indoor_temp.data_ptr(), self.comfort.data_ptr(),
                                                  None if self.kpi_comfort is None else self.kpi_comfort.data_ptr(), int(t), self._stream()))

@@ -294,8 +294,12 @@ int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, float* kp
  * update_indoor_dry_bulb_temperature (building.py:3000-3078).
  * `comfort` (optional) receives ComfortReward.calculate per building (reward_function.py:269-334) evaluated on that
  * temperature; `heat_dem` (optional) is the delivered heating plane it compares the cooling demand with;
- * `kpi_comfort` (optional) accumulates the discomfort KPIs. */
-int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* cool_dem,
+ * `kpi_comfort` (optional) accumulates the discomfort KPIs.
+ * `lstm_wb` (optional, [n_bldg][CL_LSTM_NWB] bf16): the recurrent weight matrices split into three bf16 terms and laid
+ * out as MFMA A-operand fragments (dynamics.pack_lstm_bf16).  When given, the recurrent products run on the bf16 matrix
+ * cores with split operands (fp32-level accuracy, csrc/cl_lstm.h); NULL selects the exact f32-MFMA kernel. */
+#define CL_LSTM_NWB 9216
+int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* lstm_wb, const float* dyn_pre, const float* cool_dem,
                      const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,
                      float* kpi_comfort, int32_t t, void* stream);
 

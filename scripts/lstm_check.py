@@ -20,7 +20,7 @@ for t in range(g.facts['steps']):
     ref = g.ref['reward_ComfortReward'][t]
     wr = max(wr, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
 print('teacher-fed: worst |dT| =', wt, 'C ; worst comfort reward err / (1e-4 + 1e-4|ref|) =', wr)
-for E, dbg in ((4096, 0), (65536, 0), (65536, 1), (65536, 2), (4096, 1), (4096, 2)):
+for E, dbg in ((4096, 0), (65536, 0), (4096, 3), (65536, 3), (65536, 1), (65536, 2), (65536, 5), (65536, 6)):
     eng = StepEngine(tab, E, detail=True)
     eng.lib.cl_debug_set_lstm(dbg)
     stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0)
@@ -34,4 +34,6 @@ for E, dbg in ((4096, 0), (65536, 0), (65536, 1), (65536, 2), (4096, 1), (4096, 
     ev1.record(); torch.cuda.synchronize()
     us = ev0.elapsed_time(ev1) / n * 1e3
     flop = 3 * E * 12 * (64 * 18 + 64 * 32) * 2
-    print(f'E={E}{["", " [experiment: no activations]", " [experiment: no MFMA]"][dbg]}: {us:.1f} us per LSTM step  {3*E/us*1e6:.3e} building-timesteps/s  {flop/us/1e6:.1f} TFLOP/s fp32')
+    label = {0: ' split-bf16 matrix-core path', 1: ' [f32 MFMA, experiment: no activations]', 2: ' [f32 MFMA, experiment: no MFMA]',
+             3: ' f32-MFMA path', 5: ' [split-bf16, experiment: no activations]', 6: ' [split-bf16, experiment: no MFMA]'}[dbg]
+    print(f'E={E}{label}: {us:.1f} us per LSTM step  {3*E/us*1e6:.3e} building-timesteps/s  {flop/us/1e6:.1f} TFLOP/s fp32')
