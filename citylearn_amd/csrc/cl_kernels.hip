@@ -271,6 +271,80 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
 }
 
+// Lean districts (battery + PV + load), at most two buildings per wave, one chunk: the headline shape.  Same arithmetic
+// as cl_step_kernel<VEC, false, false>; the memory operations are re-ordered for latency.  A kernel with this launch
+// shape and these byte counts but no energy model runs in 5.4 us at 17 x 65 536 (scripts/copy_floor.py) against 8.1 us
+// for the generic kernel, whose every wave walks a dependent chain  parameter block (scalar) -> action column ->
+// state / action loads -> compute -> stores  once per building.  Here a wave issues the state loads of BOTH its
+// buildings (and the action loads, when the column of building b is b: CLD_ES_COL_IS_BLDG) before it touches a parameter.
+template <int VEC>
+__global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
+    constexpr int TILE = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env0 = blockIdx.x * TILE + lane * VEC;
+    const bool live = env0 < a.n_env;
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    const bool quirk = a.flags & CLD_REF_T0_QUIRK;
+    const bool act_by_bldg = (a.flags & CLD_ES_COL_IS_BLDG) && a.act_stride_env == 1;
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
+    const int bb[2] = {w, w + a.nw};
+    const bool own[2] = {bb[0] < a.n_bldg, bb[1] < a.n_bldg};       // wave-uniform
+
+    float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
+    float s_soc[2][VEC], s_eff[2][VEC], s_deg[2][VEC], a_es[2][VEC];
+    if (live) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (!own[m]) continue;
+            const long long off = (long long)bb[m] * a.n_env + env0;       // every building has its state rows: no flag test
+            vload<VEC>(s_soc[m], a.state + CLS_B_SOC * plane + off);
+            vload<VEC>(s_eff[m], a.state + CLS_B_EFF * plane + off);
+            vload<VEC>(s_deg[m], a.state + CLS_B_DEGCAP * plane + off);
+            if (act_by_bldg) vload<VEC>(a_es[m], a.actions + (long long)bb[m] * a.act_stride_col + env0);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (!own[m]) continue;
+        const int b = bb[m];
+        cl::Bp B;
+        cl::load_bp<false>(B, a.params + (long long)b * CL_NP);
+        cl::Row R;
+        cl::load_row<false>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags);
+        if (!live) continue;
+        const long long off = (long long)b * a.n_env + env0;
+        const bool batt = B.flags & CLF_BATTERY;
+        if (!act_by_bldg) load_action<VEC>(a_es[m], a, B.a_es, env0);
+        float o_net[VEC], o_rw[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            cl::State S;
+            S.soc = batt ? s_soc[m][i] : 0.0f; S.eff = batt ? s_eff[m][i] : 1.0f; S.degcap = batt ? s_deg[m][i] : 0.0f;
+            S.cs = S.hs = S.ds = 0.0f;
+            const cl::Act act = {0.0f, 0.0f, 0.0f, B.a_es >= 0 ? a_es[m][i] : 0.0f, 0.0f, 0.0f};
+            cl::Out O;
+            cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
+            const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
+            s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap;
+            o_net[i] = O.net; o_rw[i] = rw;
+            q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission; q_rw[i] += rw;
+        }
+        if (batt) {
+            vstore<VEC>(a.state + CLS_B_SOC * plane + off, s_soc[m]);
+            vstore<VEC>(a.state + CLS_B_EFF * plane + off, s_eff[m]);
+            vstore<VEC>(a.state + CLS_B_DEGCAP * plane + off, s_deg[m]);
+        }
+        vstore<VEC>(a.out_bldg + CLO_NET * plane + off, o_net);
+        if (rkind != CLR_MARL) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+    }
+    district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+}
+
 // Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x 16
 // waves; wave w adds chunks w, w+16, ... (independent loads, one round trip), then the 16 wave partials are summed in
 // a fixed order through LDS -- deterministic, and ~10x faster than one thread walking all chunks.
@@ -465,6 +539,7 @@ int pick_vec(int n_env, int n_bldg, bool unit_stride) {
 int g_force_vec = 0;   // test / tuning hooks (cl_debug_set_vec / cl_debug_set_lean)
 int g_force_nw = 0;
 int g_no_chunks = 0;
+int g_lean_variant = 0;   // 1: generic kernel for lean districts too; 2: latency-ordered kernel at any grid size (tests, tuning)
 int g_obs_variant = 0;   // 1 / 2 / 3: force the row-wise / LDS-tile / wave-independent observation kernel (tests, tuning)
 int g_lstm_dbg = 0;
 int g_obs_rows = 0;      // tile kernel: envs per block (tuning)
@@ -515,6 +590,29 @@ __global__ void __launch_bounds__(256) cl_mfma_bench_kernel(float* out, int iter
     if (r == 12345.678f) out[threadIdx.x] = r;
 }
 
+// ---- streaming floor of the headline step (scripts/copy_floor.py): same launch shape and byte counts, no arithmetic ----
+// 17 buildings x 65 536 envs: per (building, 256-env tile) read 3 state planes + 1 action plane, write 3 state planes + net +
+// reward; 16 waves per workgroup, 16-byte accesses -- what cl_step_kernel<4, lean> moves, with the energy model replaced by adds.
+__global__ void __launch_bounds__(1024) cl_copy_floor_kernel(const float* __restrict__ st_in, const float* __restrict__ act,
+                                                            float* __restrict__ st_out, float* __restrict__ out2, int n_bldg, int n_env) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int env0 = blockIdx.x * 256 + lane * 4;
+    const long long plane = (long long)n_bldg * n_env;
+    for (int b = w; b < n_bldg; b += nw) {
+        const long long off = (long long)b * n_env + env0;
+        const float4 s0 = *reinterpret_cast<const float4*>(st_in + 0 * plane + off);
+        const float4 s1 = *reinterpret_cast<const float4*>(st_in + 1 * plane + off);
+        const float4 s2 = *reinterpret_cast<const float4*>(st_in + 2 * plane + off);
+        const float4 a = *reinterpret_cast<const float4*>(act + off);
+        const float4 x = make_float4(s0.x + a.x, s0.y + a.y, s0.z + a.z, s0.w + a.w);
+        *reinterpret_cast<float4*>(st_out + 0 * plane + off) = x;
+        *reinterpret_cast<float4*>(st_out + 1 * plane + off) = s1;
+        *reinterpret_cast<float4*>(st_out + 2 * plane + off) = s2;
+        *reinterpret_cast<float4*>(out2 + 0 * plane + off) = make_float4(s1.x + a.x, s1.y + a.y, s1.z + a.z, s1.w + a.w);
+        *reinterpret_cast<float4*>(out2 + 1 * plane + off) = make_float4(s2.x + a.x, s2.y + a.y, s2.z + a.z, s2.w + a.w);
+    }
+}
+
 extern "C" {
 
 int cl_abi_version(void) { return CL_ABI_VERSION; }
@@ -522,8 +620,13 @@ int cl_abi_version(void) { return CL_ABI_VERSION; }
 const char* cl_last_error(void) { return g_err; }
 
 void cl_debug_set_vec(int vec) { g_force_vec = vec; }
-void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks; g_force_nw = nw; }
+void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks & 1; g_lean_variant = (no_chunks >> 2) & 3; g_force_nw = nw; }
 void cl_debug_set_lstm(int dbg) { g_lstm_dbg = dbg; }
+int cl_debug_copy_floor(const float* st_in, const float* act, float* st_out, float* out2, int n_bldg, int n_env, void* stream) {
+    hipLaunchKernelGGL(cl_copy_floor_kernel, dim3(n_env / 256), dim3(1024), 0, (hipStream_t)stream, st_in, act, st_out, out2, n_bldg, n_env);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "copy floor launch");
+    return CL_OK;
+}
 int cl_debug_mfma_bench(int mode, int waves_per_simd, int iters, float* out, void* stream) {
     const dim3 grid(256 * waves_per_simd), block(256);
     switch (mode) {
@@ -624,6 +727,15 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, false>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, false>), grid, block, lds, s, a); break;
         case 4: hipLaunchKernelGGL((cl_step_kernel<4, true, false>), grid, block, lds, s, a); break;
+        default: return fail(CL_EINVAL, "bad vec %d", vec);
+        }
+    } else if (a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (g_lean_variant & 2)) && !(g_lean_variant & 1)) {
+        // one workgroup per CU at most: with more rounds the generic kernel's smaller register file (52 vs 88 VGPRs, two
+        // workgroups per CU) wins again -- 17 x 262 144: 30.8 us vs 33.0 us
+        switch (vec) {                                   // latency-ordered lean kernel (two buildings per wave at most)
+        case 1: hipLaunchKernelGGL(cl_step_lean_kernel<1>, grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL(cl_step_lean_kernel<2>, grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL(cl_step_lean_kernel<4>, grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else {

@@ -78,6 +78,9 @@ class StepEngine:
         heavy = abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS
         self.lean = not bool(np.any(bflags & heavy)) and not bool(np.any(tables.ts[:, :, [abi.CLT_COOL_DEM, abi.CLT_HEAT_DEM, abi.CLT_DHW_DEM]]))
         flags |= abi.CLD_LEAN if self.lean else 0
+        es_cols = tables.params.view(np.int32)[:, abi.CLP_ACT_ELEC_STO]
+        if np.array_equal(es_cols, np.arange(self.n_bldg)):          # one battery action per building, building order
+            flags |= abi.CLD_ES_COL_IS_BLDG
         with torch.cuda.device(self.device):
             if env_row0 is not None:
                 self.env_row0 = torch.from_numpy(self.env_row0_host).to(self.device)

@@ -201,6 +201,8 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 #define CLD_REF_T0_QUIRK   (1u << 0)  /* replicate the reference's repeated t=0 update_variables (SURVEY App.B1) */
 #define CLD_WRITE_DETAIL   (1u << 1)  /* also write CLO_B_EB .. CLO_C_NSL planes (parity / KPI baselines) */
 #define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators (requires CLD_WRITE_DETAIL) */
+#define CLD_ES_COL_IS_BLDG   (1u << 4)  /* hint: the electrical_storage action column of building b is column b (one action per
+                                          building, building order) -- lets the step issue its action loads before the parameters */
 #define CLD_LEAN           (1u << 3)  /* caller asserts: no building has a thermal device / tank, outage or dynamics
                                          flag (battery + PV + non-shiftable load only, e.g. the 2022 schemas) ->
                                          the specialised lean kernel may be used */

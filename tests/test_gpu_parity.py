@@ -79,6 +79,34 @@ def test_lean_kernel_teacher_forced(kind, vec):
     assert max(worst.values()) < 1.0, worst
 
 
+@pytest.mark.parametrize('kind', ['RewardFunction', 'MARL'])
+@pytest.mark.parametrize('vec', [1, 2, 4])
+def test_lean_kernel_variants_are_bit_identical(kind, vec):
+    """The latency-ordered lean kernel (with and without the action-column hint) and the generic kernel run the same
+    arithmetic: identical bits on state, nets, rewards and district sums over a free-running episode, ragged env tile."""
+    import ctypes
+    g = golden('g2022_all')
+    tab = g.spec().episode_tables(0)
+    lib = _lib.load()
+    lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
+    E = 516
+    engines = [StepEngine(tab, E, reward=kind) for _ in range(3)]
+    assert engines[0].dims.flags & abi.CLD_ES_COL_IS_BLDG
+    engines[2].dims.flags &= ~abi.CLD_ES_COL_IS_BLDG
+    gen = torch.Generator(device='cuda').manual_seed(vec)
+    lib.cl_debug_set_vec(vec)
+    try:
+        for t in range(40):
+            a = torch.rand((engines[0].n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+            lib.cl_debug_set_lean(8, 0); engines[0].step(a, t); engines[2].step(a, t)
+            lib.cl_debug_set_lean(4, 0); engines[1].step(a, t)
+            for e in engines[1:]:
+                assert torch.equal(e.state, engines[0].state) and torch.equal(e.out_env, engines[0].out_env), t
+                assert torch.equal(e.out_bldg[:2], engines[0].out_bldg[:2]), t
+    finally:
+        lib.cl_debug_set_vec(0); lib.cl_debug_set_lean(0, 0)
+
+
 @pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
 @pytest.mark.parametrize('kind', REWARDS)
 def test_full_kernel_teacher_forced(name, kind):
