@@ -129,7 +129,9 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
 // i + j <= 2 accumulated in fp32: the dropped terms are <= 2^-24 |W||h|, i.e. fp32-level.  The weights are split on
 // the host (dynamics.pack_lstm_bf16), h is split in registers after every cell.  The two env-dependent layer-0 inputs,
 // the pre-gates and the bias keep the exact f32 MFMA (K = 2).
-// (Tried: weight fragments in LDS with a 3-waves-per-SIMD register budget -- 33 spilled VGPRs, 191 us vs 176 us.)
+// (Tried: weight fragments in LDS with a 3-waves-per-SIMD register budget -- with the pipelined loop 33 spilled VGPRs,
+// 191 us vs 176 us; with one accumulator pair live at a time 7 spills, 177 us vs 166 us on the same box: more resident
+// waves do not help, the SIMD's VALU issue slots are the shared resource.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 /* lstm_wb layout (CL_LSTM_NWB = 18 * 64 * 8 bf16 per building): fragment f = 6 * matrix{hh0, ih1, hh1} + 3 * row_block + term,
    then [lane][8]: W[32 row_block + (lane & 31)][unit u(j, lane >> 5)], j = 0..7 */
