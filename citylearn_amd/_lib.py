@@ -16,7 +16,9 @@ from . import abi
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / 'libcitylearn_amd.so'
 CSRC = PKG / 'csrc'
-HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC']
+# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs (gfx950's register file is unified), which removes the
+# v_accvgpr_read copies in front of the LSTM activations (64 per window step)
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-mllvm', '-amdgpu-mfma-vgpr-form']
 
 
 class EngineUnavailable(RuntimeError):
