@@ -270,10 +270,11 @@ class ObservationLayout:
         if not self.reference_quirks:
             return 0.0 * ones
         heat_hp = bool(tab.params[i, abi.CLP_FLAGS] & abi.CLF_HEAT_IS_HP)
-        c_cool = ts[:, abi.CLT_COOL_DEM] * ts[:, abi.CLT_ICOP_COOL]
-        c_heat = ts[:, abi.CLT_HEAT_DEM] * (ts[:, abi.CLT_ICOP_HEAT] if heat_hp else pf[abi.CLP_T0_IHEAT_DIV])
-        c_dhw = ts[:, abi.CLT_DHW_DEM] * ts[:, abi.CLT_ICOP_DHW]
-        net = np.where(ts[:, abi.CLT_OUTAGE] != 0, 0.0, c_cool + c_heat + c_dhw + ts[:, abi.CLT_NSL] + ts[:, abi.CLT_SOLAR])
+        r = float(self.spec.buildings[i].time_step_ratio)      # Device.electricity_consumption = accumulator * ratio (energy_model.py:118)
+        c_cool = ts[:, abi.CLT_COOL_DEM] * ts[:, abi.CLT_ICOP_COOL] * r
+        c_heat = ts[:, abi.CLT_HEAT_DEM] * (ts[:, abi.CLT_ICOP_HEAT] if heat_hp else pf[abi.CLP_T0_IHEAT_DIV]) * r
+        c_dhw = ts[:, abi.CLT_DHW_DEM] * ts[:, abi.CLT_ICOP_DHW] * r
+        net = np.where(ts[:, abi.CLT_OUTAGE] != 0, 0.0, c_cool + c_heat + c_dhw + ts[:, abi.CLT_NSL] * r + ts[:, abi.CLT_SOLAR])
         return {'cooling_electricity_consumption': c_cool, 'heating_electricity_consumption': c_heat,
                 'dhw_electricity_consumption': c_dhw, 'net_electricity_consumption': net}.get(k, 0.0 * ones)
 

@@ -306,18 +306,26 @@ def run_observations(name: str, steps: int = None):
     print(f'{name}: observations {np.array(obs).shape}, normalised {np.array(obs_norm).shape}')
 
 
-OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300}
+OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300, 'g2020_15min': 120, 's_baeda': 95, 's_2021': 95,
+                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95}
 
 
 if __name__ == '__main__':
+    # ONE FIXTURE PER PROCESS: the reference keeps process-global state (EnergySimulation's mutable default
+    # `time_step_ratios=[]`, data.py:403) -- a 15-minute run leaves its ratio behind for every env built afterwards.
+    import subprocess
     args = sys.argv[1:]
-    if args and args[0] == 'observations':
-        for n in (args[1:] or list(OBS_FIXTURES)):
-            run_observations(n, OBS_FIXTURES.get(n))
+    if args and args[0] == '--one':
+        kind, name = args[1], args[2]
+        if kind == 'observations':
+            run_observations(name, OBS_FIXTURES.get(name))
+        else:
+            run_reference(name)
         sys.exit(0)
-    names = args or list(FIXTURES)
-    for n in names:
-        run_reference(n)
-    for n in names:
-        if n in OBS_FIXTURES:
-            run_observations(n, OBS_FIXTURES[n])
+    if args and args[0] == 'observations':
+        jobs = [('observations', n) for n in (args[1:] or list(OBS_FIXTURES))]
+    else:
+        names = args or list(FIXTURES)
+        jobs = [('reference', n) for n in names] + [('observations', n) for n in names if n in OBS_FIXTURES]
+    for kind, n in jobs:
+        subprocess.run([sys.executable, __file__, '--one', kind, n], check=True)
