@@ -817,5 +817,7 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
         seconds_per_time_step=seconds, simulation_start_time_step=sim_start, simulation_end_time_step=sim_end,
         episode_time_steps=_pick(kwargs, sc, 'episode_time_steps'),
         rolling_episode_split=bool(_pick(kwargs, sc, 'rolling_episode_split', False)),
-        random_episode_split=bool(_pick(kwargs, sc, 'random_episode_split', False)),
+        # reference quirk: the constructor forwards its `random_episode_split` under the wrong name (citylearn.py:191 vs
+        # 2045), so only the SCHEMA's value is ever used -- mirrored here (tests/golden/overrides.json)
+        random_episode_split=bool(sc.get('random_episode_split') or False),
         reward_function=rf, root_directory=str(root), schema=sc)

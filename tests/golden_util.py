@@ -33,8 +33,11 @@ class Golden:
         k = self.facts['reward_type']
         return k if k in ('RewardFunction', 'MARL', 'IndependentSACReward', 'SolarPenaltyReward') else 'RewardFunction'
 
-    def spec(self, **kwargs):
+    def spec(self, schema_overrides=None, **kwargs):
         from citylearn_amd.schema import load_district
+        if schema_overrides:            # schema as a dictionary with top-level keys replaced
+            schema = {**json.loads(open(self.schema_path).read()), **schema_overrides, 'root_directory': str(self.dir / 'dataset')}
+            return load_district(schema, **kwargs)
         return load_district(self.schema_path, **kwargs)
 
 
