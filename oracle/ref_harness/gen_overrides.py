@@ -30,6 +30,11 @@ CASES = {
                                   'active_actions': ['electrical_storage']}),
     'no_outage': ('g2023_p2', {'simulate_power_outage': False}),
     'no_pv': ('g2022_all', {'solar_generation': False, 'buildings': ['Building_1', 'Building_3']}),
+    # stochastic outage signals are redrawn every episode (building.py:2566-2594)
+    'episodes_outage': ('g2023_p2', {'episode_time_steps': 240}),
+    'episodes_outage_seeded': ('g2023_p2', {'episode_time_steps': 240, 'random_seed': 11}),
+    # reset(seed=...) re-seeds the episode choice and the outage draws (citylearn.py:1855-1866)
+    'reset_seeds': ('g2023_p2', {'episode_time_steps': 240}, {'random_episode_split': True}, [None, 5, 5, 9, None, 2, 13]),
 }
 
 
@@ -40,22 +45,24 @@ def run_case(name: str):
     from citylearn.citylearn import CityLearnEnv
     fixture, kwargs, *rest = CASES[name]
     schema_overrides = rest[0] if rest else {}
+    seeds = rest[1] if len(rest) > 1 else [None] * 7
     schema = str(REPO / 'tests' / 'golden' / fixture / 'dataset' / 'schema.json')
     if schema_overrides:                              # schema handed over as a dictionary with the overrides applied
         schema = {**json.loads(Path(schema).read_text()), **schema_overrides,
                   'root_directory': str(REPO / 'tests' / 'golden' / fixture / 'dataset')}
     env = CityLearnEnv(schema, **kwargs)
-    out = {'fixture': fixture, 'kwargs': kwargs, 'schema_overrides': schema_overrides, 'central_agent': bool(env.central_agent),
+    out = {'fixture': fixture, 'kwargs': kwargs, 'schema_overrides': schema_overrides, 'reset_seeds': seeds, 'central_agent': bool(env.central_agent),
            'building_names': [b.name for b in env.buildings], 'observation_names': env.observation_names,
            'action_names': env.action_names, 'time_steps': int(env.time_steps),
            'action_low': [s.low.tolist() for s in env.action_space], 'action_high': [s.high.tolist() for s in env.action_space],
            'obs_low': [s.low.astype(float).tolist() for s in env.observation_space],
            'obs_high': [s.high.astype(float).tolist() for s in env.observation_space], 'episodes': []}
     for ep in range(7):
-        obs, _ = env.reset()
+        obs, _ = env.reset(seed=seeds[ep])
         tr = env.episode_tracker
         out['episodes'].append({'start': int(tr.episode_start_time_step), 'end': int(tr.episode_end_time_step),
-                                'obs0': [[float(x) for x in o] for o in obs]})
+                                'obs0': [[float(x) for x in o] for o in obs],
+                                'outage': [np.flatnonzero(np.array(b._Building__power_outage_signal)).tolist() for b in env.buildings]})
         if ep == 0:
             rng = np.random.RandomState(7)
             acts = [[float(x) for x in rng.uniform(s.low, s.high).astype('float32')] for s in env.action_space]
