@@ -65,7 +65,15 @@ class VectorCityLearnEnv:
         kind = getattr(rf_cls, 'device_kind', None)
         self._comfort = kind == 'comfort'
         self._rf_attrs = dict(self.spec.reward_function.get('attributes') or {})
-        if self._comfort:
+        # SolarPenaltyAndComfortReward (reward_function.py:336-386): coefficient-weighted sum of the SolarPenaltyReward the
+        # energy step writes and the ComfortReward the LSTM stage writes -- combined on the device, no extra kernel of ours
+        self._combo = None
+        if rf_cls.__name__ == 'SolarPenaltyAndComfortReward' and rf_cls.__module__.endswith('reward_function'):
+            if not any(b.is_dynamics for b in self.spec.buildings):
+                raise NotImplementedError('SolarPenaltyAndComfortReward needs the LSTM temperature stage (dynamics buildings)')
+            self._combo = tuple(float(c) for c in (self._rf_attrs.get('coefficients') or (1.0, 1.0)))
+            self._comfort, kind = True, abi.CLR_SOLAR_PENALTY
+        elif self._comfort:
             kind = abi.CLR_DEFAULT                      # the energy step still writes net / district sums
         if kind is None:
             raise NotImplementedError(f'{rf_cls.__name__} has no fused device epilogue; use reward_function='
@@ -181,7 +189,11 @@ class VectorCityLearnEnv:
         if self.stage is not None:
             self.stage.step(self._t)                    # indoor temperature (+ ComfortReward) of this step
         self._t += 1
-        if self._comfort and self.stage is not None:
+        if self._combo is not None:
+            # float32 like the reference's np.array(..., dtype='float32') (reward_function.py:383-386)
+            r = self._combo[0] * e.reward_bldg + self._combo[1] * self.stage.comfort
+            reward = r.sum(dim=0) if self.central_agent else r
+        elif self._comfort and self.stage is not None:
             reward = self.stage.comfort.sum(dim=0) if self.central_agent else self.stage.comfort
         else:
             reward = e.district_reward if self.central_agent else e.reward_bldg

@@ -74,6 +74,10 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict
         if b.get('dynamics'):
             fn = b['dynamics']['attributes']['filename']
             shutil.copyfile(src / fn, dst / fn)
+        for c in (b.get('chargers') or {}).values():                    # EV charger schedules / washing machine cycles
+            files.add(c['charger_simulation'])
+        for wmach in (b.get('washing_machines') or {}).values():
+            files.add(wmach['washing_machine_energy_simulation'])
     for fn in sorted(files):
         frame = pd.read_csv(src / fn).iloc[:rows]
         text = frame.to_csv(index=False)

@@ -108,6 +108,23 @@ def test_vector_env_comfort_reward():
     np.testing.assert_allclose(float(tot[0]), g.ref['env_rewards'][:60, 0].sum(), rtol=2e-3)
 
 
+def test_vector_env_solar_penalty_and_comfort_reward():
+    """`SolarPenaltyAndComfortReward` = coefficient-weighted sum of the two stock rewards (reward_function.py:381-386):
+    expected values from the reference's own per-building SolarPenaltyReward / ComfortReward of the same run."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden('g2023_p2')
+    spec_attrs = g.spec().reward_function['attributes']
+    coeff = (0.4, 1.7)
+    env = VectorCityLearnEnv(g.schema_path, n_envs=64, central_agent=False,
+                             reward_function='citylearn.reward_function.SolarPenaltyAndComfortReward',
+                             reward_function_kwargs={**spec_attrs, 'coefficients': coeff})
+    acts = torch.from_numpy(g.ref['actions']).cuda()
+    for t in range(80):
+        _, reward, *_ = env.step(acts[t][:, None].expand(-1, 64).contiguous())
+        want = coeff[0] * g.ref['reward_SolarPenaltyReward'][t] + coeff[1] * g.ref['reward_ComfortReward'][t]
+        np.testing.assert_allclose(reward[:, 0].cpu().numpy(), want, rtol=2e-3, atol=2e-3)      # free-running fp32
+
+
 def test_bf16_mfma_operand_layout():
     """Known-answer test of the operand layout the split-bf16 LSTM kernel relies on: lane l of
     v_mfma_f32_32x32x16_bf16 supplies A[l & 31][8 (l >> 5) + 0..7] and B[8 (l >> 5) + 0..7][l & 31]; D[row][col] with
