@@ -61,8 +61,6 @@ class StepEngine:
                 raise ValueError(f'env_row0 needs {n_blocks} entries (one per {abi.CL_ROW0_BLOCK} envs), got {row0.shape[0]}')
             if row0.min() < 0 or row0.max() + self.n_steps > self.n_ts_rows:
                 raise ValueError(f'env_row0 + n_steps must stay inside the {self.n_ts_rows} table rows')
-            if kpi:
-                raise NotImplementedError('streaming KPIs are defined for one common episode window')
             self.env_row0_host = row0.astype(np.int32)
         if n_act_cols is None:
             cols = tables.params.view(np.int32)[:, abi.CLP_ACT_COOL_STO:abi.CLP_ACT_COH_DEV + 1]

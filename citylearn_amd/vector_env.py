@@ -55,8 +55,6 @@ class VectorCityLearnEnv:
         if env_episode_offsets is not None:
             if not isinstance(self.spec.episode_time_steps, int):
                 raise ValueError('env_episode_offsets needs an integer episode_time_steps (schema or kwarg)')
-            if kpi:
-                raise NotImplementedError('streaming KPIs are defined for one common episode window')
         self.layout = None
         if observations == 'tensor':
             from .observations import ObservationLayout
@@ -204,21 +202,39 @@ class VectorCityLearnEnv:
         accumulators (construct with ``kpi=True``).  Returns ``(building, district)`` dicts of tensors."""
         if not self.kpi:
             raise RuntimeError('construct VectorCityLearnEnv(..., kpi=True) to accumulate KPIs on the device')
-        from .kpi import finalize_streaming
-        nxt_e = nxt_o = None
-        if self._t < self.time_steps:
-            row = self.tables.start + self._t
-            nxt_e = np.array([float(b.series['cooling_demand'][row]) + float(b.series['heating_demand'][row])
-                              + float(b.series['dhw_demand'][row]) + float(b.series['non_shiftable_load'][row])
-                              for b in self.spec.buildings])
-            nxt_o = (self.tables.outage[self._t] != 0).astype(np.float64)
-        building, district = finalize_streaming(self.engine.kpi_bldg, self.engine.kpi_env, self._t, self.time_steps, nxt_e, nxt_o)
-        if self.stage is not None and self.stage.kpi_comfort is not None:
-            from .kpi import finalize_comfort
-            comfort = finalize_comfort(self.stage.kpi_comfort, self.spec, self.tables, self._t, self.stage.kpi_band)
-            building.update(comfort)
-            for name, v in comfort.items():
-                district[name] = torch.nanmean(v, dim=0)
+        from .kpi import finalize_comfort, finalize_streaming
+        from .schema import EpisodeTables
+
+        def block(tables, sl):
+            """KPIs of the envs `sl`, which all replay the episode window `tables`."""
+            nxt_e = nxt_o = None
+            if self._t < self.time_steps:
+                row = tables.start + self._t
+                nxt_e = np.array([float(b.series['cooling_demand'][row]) + float(b.series['heating_demand'][row])
+                                  + float(b.series['dhw_demand'][row]) + float(b.series['non_shiftable_load'][row])
+                                  for b in self.spec.buildings])
+                nxt_o = (tables.outage[self._t] != 0).astype(np.float64)
+            building, district = finalize_streaming(self.engine.kpi_bldg[:, :, sl], self.engine.kpi_env[:, sl], self._t, self.time_steps,
+                                                    nxt_e, nxt_o)
+            if self.stage is not None and self.stage.kpi_comfort is not None:
+                comfort = finalize_comfort(self.stage.kpi_comfort[:, :, sl], self.spec, tables, self._t, self.stage.kpi_band)
+                building.update(comfort)
+                for name, v in comfort.items():
+                    district[name] = torch.nanmean(v, dim=0)
+            return building, district
+
+        if self.episode_row0 is None:
+            return block(self.tables, slice(None))
+        # per-env-block episode windows: finalise every block against its own window of the tables
+        parts = []
+        K, tab = self.time_steps, self.tables
+        for g, o in enumerate(self.episode_row0):
+            o = int(o)
+            cut = EpisodeTables(params=tab.params, ts=tab.ts[o:o + K], start=tab.start + o, end=tab.start + o + K - 1,
+                                outage=tab.outage[o:o + K])
+            parts.append(block(cut, slice(g * abi.CL_ROW0_BLOCK, min((g + 1) * abi.CL_ROW0_BLOCK, self.n_envs))))
+        building = {k: torch.cat([p[0][k] for p in parts], dim=-1) for k in parts[0][0]}
+        district = {k: torch.cat([p[1][k] for p in parts], dim=-1) for k in parts[0][1]}
         return building, district
 
     def sample_actions(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:

@@ -76,8 +76,6 @@ def test_engine_validates_offsets():
         StepEngine(tables, 512, n_steps=10, env_row0=[0])
     with pytest.raises(ValueError, match='inside'):
         StepEngine(tables, 512, n_steps=10, env_row0=[0, tables.n_steps - 9])
-    with pytest.raises(NotImplementedError):
-        StepEngine(tables, 512, n_steps=10, env_row0=[0, 1], kpi=True)
 
 
 @pytest.mark.parametrize('normalize', [False, True])
@@ -120,3 +118,32 @@ def test_vector_env_with_episode_offsets_matches_windowed_envs(normalize):
             np.testing.assert_allclose(denorm(obs[sl[j]], env.layout).cpu().numpy(), denorm(o_r, r.layout).cpu().numpy(),
                                        rtol=2e-5, atol=2e-4, err_msg=f'{t} {j}')
     assert env.terminated
+
+
+def test_streaming_kpis_with_episode_offsets():
+    """`evaluate()` of a batch whose blocks replay different windows == `evaluate()` of windowed envs fed the same actions
+    (energy KPIs and the comfort KPIs of the LSTM stage)."""
+    from citylearn_amd import abi
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden('g2023_p2')
+    K, offsets = 60, [3, 150]
+    E = abi.CL_ROW0_BLOCK * len(offsets)
+    kw = dict(kpi=True, simulate_power_outage=False, reward_function='citylearn.reward_function.RewardFunction')
+    env = VectorCityLearnEnv(g.schema_path, E, episode_time_steps=K, env_episode_offsets=offsets, **kw)
+    refs = [VectorCityLearnEnv(g.schema_path, abi.CL_ROW0_BLOCK, simulation_start_time_step=o, simulation_end_time_step=o + K - 1, **kw)
+            for o in offsets]
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    for t in range(K - 1):
+        a = env.sample_actions(gen)
+        env.step(a)
+        for j, r in enumerate(refs):
+            r.step(a[:, j * abi.CL_ROW0_BLOCK:(j + 1) * abi.CL_ROW0_BLOCK].contiguous())
+    building, district = env.evaluate()
+    for j, r in enumerate(refs):
+        sl = slice(j * abi.CL_ROW0_BLOCK, (j + 1) * abi.CL_ROW0_BLOCK)
+        b_ref, d_ref = r.evaluate()
+        assert set(b_ref) == set(building) and set(d_ref) == set(district)
+        for k, v in b_ref.items():
+            torch.testing.assert_close(building[k][:, sl], v, rtol=1e-6, atol=1e-9, equal_nan=True, msg=k)
+        for k, v in d_ref.items():
+            torch.testing.assert_close(district[k][sl], v, rtol=1e-6, atol=1e-9, equal_nan=True, msg=k)
