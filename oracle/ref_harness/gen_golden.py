@@ -47,6 +47,10 @@ FIXTURES = {
     'g2020_15min': ('citylearn_challenge_2020_climate_zone_1', 400, 399, 15, False, {'seconds_per_time_step': 900}),
     # dataset sweep: short runs of the remaining dataset families the loader supports (different device mixes, autosizing,
     # heating end uses, 15-minute data files, six-building outage district)
+    # EV chargers + washing machine (groundwork: oracle only).  The reference draws EV initial SoCs from Python's
+    # global `random` and the unconnected-EV drift from numpy's global RNG, both unseeded: the harness seeds them with the
+    # action seed (see run_reference)
+    'g2022_evs': ('citylearn_challenge_2022_phase_all_plus_evs', 240, 239, 77, False, {}),
     's_baeda': ('baeda_3dem', 96, 95, 31, False, {}),
     's_2021': ('citylearn_challenge_2021', 96, 95, 32, False, {}),
     's_2020_cz3': ('citylearn_challenge_2020_climate_zone_3', 96, 95, 33, False, {}),
@@ -103,9 +107,15 @@ def run_reference(name: str):
     from citylearn import reward_function as rf
     from citylearn.building import DynamicsBuilding
     from citylearn.energy_model import HeatPump
+    import random as py_random
+    py_random.seed(seed)                 # EV initial SoC defaults (citylearn.py:2563)
+    np.random.seed(seed)                 # unconnected-EV SoC drift (citylearn.py:1468)
 
     env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
     B = len(env.buildings)
+    evs = list(getattr(env, 'electric_vehicles', []) or [])
+    chargers = [(i, c) for i, b in enumerate(env.buildings) for c in (b.electric_vehicle_chargers or [])]
+    wms = [(i, w) for i, b in enumerate(env.buildings) for w in (b.washing_machines or [])]
     low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
     high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
     sizes = [b.action_space.shape[0] for b in env.buildings]
@@ -137,6 +147,13 @@ def run_reference(name: str):
     traj = {k: np.zeros((K, B), dtype='float32') for k in per_b}
     traj['actions'] = np.zeros((K, len(low)), dtype='float32')
     traj['reward_default'] = None
+    if evs or wms:
+        traj['ev_soc'] = np.zeros((K, len(evs)), dtype='float32')
+        traj['charger_consumption'] = np.zeros((K, len(chargers)), dtype='float32')
+        traj['charger_energy'] = np.zeros((K, len(chargers)), dtype='float32')
+        traj['wm_consumption'] = np.zeros((K, len(wms)), dtype='float32')
+        traj['chargers_total'] = np.zeros((K, B), dtype='float32')
+        traj['wms_total'] = np.zeros((K, B), dtype='float32')
     rewards_all = {k: np.zeros((K, B), dtype='float64') for k in extra_rewards}
     env_rewards = []
     for t in range(K):
@@ -179,6 +196,13 @@ def run_reference(name: str):
             traj['e_dhw_dev'][t, i] = b._Building__energy_from_dhw_device[t]
             traj['e_ns'][t, i] = b._Building__energy_to_non_shiftable_load[t]
             traj['indoor_temp'][t, i] = b.energy_simulation.indoor_dry_bulb_temperature[t]
+        if evs or wms:
+            traj['ev_soc'][t] = [ev.battery.soc[t] for ev in evs]
+            traj['charger_consumption'][t] = [c.electricity_consumption[t] for _, c in chargers]
+            traj['charger_energy'][t] = [c.past_charging_action_values_kwh[t] for _, c in chargers]
+            traj['wm_consumption'][t] = [w.electricity_consumption[t] for _, w in wms]
+            traj['chargers_total'][t] = [b.chargers_electricity_consumption[t] for b in env.buildings]
+            traj['wms_total'][t] = [b.washing_machines_electricity_consumption[t] for b in env.buildings]
         if terminated:
             assert t == K - 1, (t, K)
     assert env.terminated == (K == rows - 1)
@@ -202,6 +226,16 @@ def run_reference(name: str):
         'action_names': env.action_names, 'observation_names': env.observation_names,
         'shared_observations': env.shared_observations,
         'time_steps': int(env.time_steps), 'time_step_ratio': float(env.time_step_ratio),
+        'electric_vehicles': [{'name': ev.name, 'capacity': float(ev.battery.capacity), 'nominal_power': float(ev.battery.nominal_power),
+                               'initial_soc': float(ev.battery.initial_soc), 'depth_of_discharge': float(ev.battery.depth_of_discharge),
+                               'efficiency': float(ev.battery.efficiency_history[0]), 'loss_coefficient': float(ev.battery.loss_coefficient),
+                               'capacity_loss_coefficient': float(ev.battery.capacity_loss_coefficient),
+                               'power_efficiency_curve': np.asarray(ev.battery.power_efficiency_curve, dtype=float).tolist(),
+                               'capacity_power_curve': np.asarray(ev.battery.capacity_power_curve, dtype=float).tolist()} for ev in evs],
+        'chargers': [{'building': i, 'id': c.charger_id, 'max_charging_power': float(c.max_charging_power),
+                      'min_charging_power': float(c.min_charging_power), 'max_discharging_power': float(c.max_discharging_power),
+                      'min_discharging_power': float(c.min_discharging_power), 'efficiency': float(c.efficiency)} for i, c in chargers],
+        'washing_machines': [{'building': i, 'name': w.name} for i, w in wms],
         'devices': [{
             'cooling_device': {'nominal_power': float(b.cooling_device.nominal_power), 'efficiency': float(b.cooling_device.efficiency),
                                'target_cooling_temperature': float(b.cooling_device.target_cooling_temperature)},
