@@ -38,10 +38,21 @@ class Dims(ctypes.Structure):
                 ('env_row0', ctypes.c_void_p)]
 
 
+class Flex(ctypes.Structure):
+    """``cl_flex`` (include/citylearn_amd.h): EV chargers / washing machines tables and state."""
+    _fields_ = [('n_ev', ctypes.c_int32), ('n_charger', ctypes.c_int32), ('n_wm', ctypes.c_int32),
+                ('n_flex_bldg', ctypes.c_int32), ('n_rows', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('ev_params', ctypes.c_void_p), ('ev_ts', ctypes.c_void_p), ('charger_params', ctypes.c_void_p),
+                ('charger_ts', ctypes.c_void_p), ('wm_params', ctypes.c_void_p), ('wm_ts', ctypes.c_void_p),
+                ('flex_bldg', ctypes.c_void_p), ('ev_state', ctypes.c_void_p), ('wm_state', ctypes.c_void_p),
+                ('flex_out', ctypes.c_void_p), ('charger_out', ctypes.c_void_p), ('drift', ctypes.c_void_p),
+                ('seed', ctypes.c_uint64), ('weights', ctypes.c_float * 8)]
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP sources for gfx950 into the in-tree shared library (cross-compiles without a GPU)."""
     sources = [CSRC / 'cl_kernels.hip']
-    deps = sources + [CSRC / 'cl_unit.h', abi.HEADER]
+    deps = sources + sorted(CSRC.glob('*.h')) + [abi.HEADER]
     if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -71,6 +82,11 @@ def load() -> ctypes.CDLL:
     lib.cl_reset_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, vp]
     lib.cl_step_f32.restype = ctypes.c_int
     lib.cl_step_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, f32p, f32p, f32p, f32p, i32, vp]
+    lib.cl_flex_reset_f32.restype = ctypes.c_int
+    lib.cl_flex_reset_f32.argtypes = [ctypes.POINTER(Dims), ctypes.POINTER(Flex), vp]
+    lib.cl_step_flex_f32.restype = ctypes.c_int
+    lib.cl_step_flex_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, f32p, f32p, f32p, f32p,
+                                     ctypes.POINTER(Flex), i32, vp]
     lib.cl_rollout_f32.restype = ctypes.c_int
     lib.cl_rollout_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, i64, f32p, f32p, u64,
                                    f32p, f32p, f32p, f32p, f32p, i32, i32, vp]

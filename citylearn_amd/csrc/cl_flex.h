@@ -1,0 +1,179 @@
+// cl_flex.h -- EV chargers, electric vehicles and washing machines; included by cl_kernels.hip.
+//
+// One launch per env step, BEFORE the building step kernel: it leaves, for every building that owns a charger or a
+// washing machine, the electricity they drew this step (cl_flex_out planes) and the net-independent part of
+// Electric_Vehicles_Reward_Function; the step kernel adds the load to the net and finishes the reward.
+//
+// Work decomposition: a wave owns 64 consecutive envs of ONE unit, so every table read is wave-uniform (scalar) and
+// every plane access is one coalesced request.  Units are
+//   [0, n_flex_bldg)         a building: its chargers in order, then its washing machines (the summation order of
+//                            Building.update_variables, building.py:2657-2680), each charger advancing the EV it holds;
+//   [n_flex_bldg, +n_ev)     an EV that no charger holds on this row: the arrival / drift rules of
+//                            CityLearnEnv.simulate_unconnected_ev_soc (citylearn.py:1416-1474).
+// An EV is advanced by exactly one unit per step (CLEV_CONNECTED decides which), so no two waves touch the same state.
+//
+// SoC bookkeeping.  The reference keeps soc[t] series that start at zero and are written only by Battery.charge or
+// force_set_soc -- nothing carries a value forward.  ev_state's SoC plane holds the entry of the LAST step (soc[t-1]);
+// the entry of step t starts from the host-packed rule of (row, EV) (0, an arrival SoC, or the drift of soc[t-1]) and
+// is replaced by Battery.charge only when the connected charger's action is non-zero
+// (electric_vehicle_charger.py:306, 331-334): a zero action on a connected EV leaves the rule value, usually 0.
+#pragma once
+
+namespace {
+
+struct FlexArgs {
+    cl_flex f;
+    const float* __restrict__ actions;
+    long long act_stride_col, act_stride_env;
+    const int32_t* __restrict__ env_row0;
+    int n_env, n_steps, t;
+};
+
+CL_DEV float flex_action(const FlexArgs& a, int col, int env) {
+    if (col < 0) return 0.0f;
+    return a.actions[(long long)col * a.act_stride_col + (long long)env * a.act_stride_env];
+}
+
+// N(1, 0.2) multiplier of the SoC drift for (env, EV, t): Box-Muller on two Philox words; its own counter space
+// (column bit 31 set) so it never collides with the rollout policy stream of cl_rollout.h.
+CL_DEV float flex_drift_multiplier(unsigned long long seed, int env, int ev, int t) {
+    const cl::U4 b = cl::philox_block(seed, (uint32_t)env, 0x80000000u | (uint32_t)ev, (uint32_t)t);
+    const float u1 = 1.0f - cl::u01(b.w[0]), u2 = cl::u01(b.w[1]);      // u1 in (0, 1]
+    return fmaf(0.2f, sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2), 1.0f);
+}
+
+// soc[t] before any charger action: the rule of (row, EV) applied to soc[t - 1] (citylearn.py:1416-1474, 1353-1414)
+CL_DEV float flex_begin_soc(const FlexArgs& a, const float* __restrict__ ev_row, int row, int ev, int env, float prev) {
+    const bool last = a.t + 1 >= a.n_steps;
+    const float rule = ev_row[last ? CLEV_RULE_LAST : CLEV_RULE_STEP];
+    if (rule >= 0.0f) return rule;
+    if (rule == CLEV_ZERO) return 0.0f;
+    const float m = a.f.drift ? a.f.drift[(long long)row * a.f.n_ev + ev] : flex_drift_multiplier(a.f.seed, env, ev, a.t);
+    return fminf(fmaxf(prev * fminf(fmaxf(m, 0.6f), 1.4f), 0.0f), 1.0f);
+}
+
+__global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int u = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+    const int env = blockIdx.x * 64 + lane;
+    const cl_flex& f = a.f;
+    if (u >= f.n_flex_bldg + f.n_ev) return;
+    const bool live = env < a.n_env;
+    const int row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * 64) / CL_ROW0_BLOCK] : 0);
+    const long long ev_plane = (long long)f.n_ev * a.n_env;
+
+    if (u >= f.n_flex_bldg) {
+        // ---- an EV nobody holds on this row ----
+        const int k = u - f.n_flex_bldg;
+        const float* __restrict__ er = f.ev_ts + ((long long)row * f.n_ev + k) * CL_NEVF;
+        if (a.t == 0 || er[CLEV_CONNECTED] != 0.0f || !live) return;     // t = 0: cl_flex_reset_f32 wrote soc[0]
+        float* soc = f.ev_state + (long long)k * a.n_env + env;
+        *soc = flex_begin_soc(a, er, row, k, env, *soc);
+        return;
+    }
+
+    // ---- a building: chargers, then washing machines ----
+    const int32_t* __restrict__ fb = f.flex_bldg + (long long)u * CL_NFB;
+    const int c0 = fb[1], nc = fb[2], w0 = fb[3], nwm = fb[4];
+    float chargers = 0.0f, wms = 0.0f, k0 = 0.0f, kneg = 0.0f, kpos = 0.0f;
+    for (int c = c0; c < c0 + nc; ++c) {
+        const uint32_t* __restrict__ cp = f.charger_params + (long long)c * CL_NCP;
+        const float* __restrict__ cr = f.charger_ts + ((long long)row * f.n_charger + c) * CL_NCF;
+        const int k = (int)cr[CLCT_EV];
+        const float eff = cl::pw(cp, CLC_EFF), inv_eff = cl::pw(cp, CLC_INV_EFF), dt = cl::pw(cp, CLC_DT_HOURS);
+        const float max_c = cl::pw(cp, CLC_MAX_CHARGE), min_c = cl::pw(cp, CLC_MIN_CHARGE);
+        const float max_d = cl::pw(cp, CLC_MAX_DISCHARGE), min_d = cl::pw(cp, CLC_MIN_DISCHARGE);
+        if (!live) continue;
+        const float act = flex_action(a, (int)cp[CLC_ACT_COL], env);
+        // electric_vehicle_charger.py:306-322: requested energy, clamped to the charger's power range
+        float energy = 0.0f, to_battery = 0.0f;
+        if (act > 0.0f) {
+            energy = fmaxf(fminf(act * max_c * dt, max_c), min_c);
+            to_battery = energy * eff;
+        } else if (act < 0.0f) {
+            energy = fmaxf(fminf(act * max_d * dt, -min_d), -max_d);
+            to_battery = energy * inv_eff;
+        }
+        float cons = 0.0f;
+        if (k >= 0) {
+            const uint32_t* __restrict__ ep = f.ev_params + (long long)k * CL_NP;
+            const float* __restrict__ er = f.ev_ts + ((long long)row * f.n_ev + k) * CL_NEVF;
+            float* sp = f.ev_state + (long long)k * a.n_env + env;
+            cl::State S;
+            S.soc = sp[0]; S.eff = sp[ev_plane]; S.degcap = sp[2 * ev_plane];
+            S.cs = S.hs = S.ds = 0.0f;
+            const float prev = S.soc;                                  // soc[t - 1]; at t = 0 soc[0] itself (energy_model.py:661-666)
+            float now = a.t == 0 ? prev : flex_begin_soc(a, er, row, k, env, prev);
+            if (act != 0.0f) {
+                cl::BattP P;
+                cl::load_batt(P, ep);
+                const float eb = cl::battery_energy(P, to_battery * P.r, S);      // Battery.charge (energy_model.py:1027-1057)
+                now = S.soc;
+                cons = eb >= 0.0f ? eb * inv_eff : eb * eff;                        // electric_vehicle_charger.py:329
+                sp[ev_plane] = S.eff; sp[2 * ev_plane] = S.degcap;
+            }
+            sp[0] = now;
+            // ---- Electric_Vehicles_Reward_Function.calculate_ev_penalty, everything but the 1/(1+|MARL|) factor and
+            //      the sign of the building net (reward_function.py:466-529) ----
+            const float cap = cl::pw(ep, CLP_L_CAP), min_cap = cl::pw(ep, CLP_L_OMD) * cap;
+            const float soc_prev = a.t == 0 ? cl::pw(ep, CLP_L_SOC0) : prev;          // building.py:1355
+            const float required = cr[CLCT_REQUIRED_SOC], hours = cr[CLCT_DEPARTURE];
+            const float held = fmaf(soc_prev, cap, energy);
+            if (held > cap || held < min_cap) k0 += f.weights[CLEW_BATTERY_LIMITS];
+            const float diff = now - required, diff_kwh = diff * cap;
+            const float reach_c = max_c * hours, reach_d = max_d * hours;
+            if (diff_kwh > reach_c) k0 += f.weights[CLEW_SOC_IMPOSSIBLE];
+            if (hours == 0.0f) {
+                if (diff > -0.25f && diff <= -0.10f) k0 += 2.0f * f.weights[CLEW_SOC_UNDER];
+                else if (diff <= -0.25f) k0 += f.weights[CLEW_SOC_UNDER] * f.weights[CLEW_SOC_UNDER];
+                else if (diff > -0.10f && diff <= 0.10f) k0 += f.weights[CLEW_CLOSE_SOC];
+            }
+            if (fabsf(diff_kwh) <= fmaxf(reach_c, reach_d)) k0 += f.weights[CLEW_CLOSE_SOC] / (hours + 0.1f);
+            if (energy > 0.0f) { kneg += f.weights[CLEW_EXTRA_SELF_PRODUCTION]; kpos += -0.5f * f.weights[CLEW_SELF_EV_CONSUMPTION]; }
+            else if (energy < 0.0f) { kneg += -0.5f * f.weights[CLEW_EXTRA_SELF_PRODUCTION]; kpos += f.weights[CLEW_SELF_EV_CONSUMPTION]; }
+        }
+        chargers += cons;
+        if (f.charger_out) {
+            f.charger_out[(long long)c * a.n_env + env] = cons;
+            f.charger_out[((long long)f.n_charger + c) * a.n_env + env] = energy;
+        }
+    }
+    for (int w = w0; w < w0 + nwm; ++w) {
+        const float* __restrict__ wr = f.wm_ts + ((long long)row * f.n_wm + w) * CL_NWF;
+        const int col = (int)f.wm_params[(long long)w * CL_NWP];
+        if (!live) continue;
+        float* st = f.wm_state + (long long)w * a.n_env + env;
+        bool initiated = *st != 0.0f;
+        if (a.t > 0 && wr[CLWT_NEW_WINDOW] != 0.0f) initiated = false;          // energy_model.py:1303-1312
+        const float act = flex_action(a, col, env);
+        if (!initiated && act > 0.0f && wr[CLWT_OPEN] != 0.0f) {                // energy_model.py:1320-1330
+            initiated = true;
+            wms += wr[CLWT_LOAD];
+        }
+        *st = initiated ? 1.0f : 0.0f;
+    }
+    if (!live) return;
+    const long long fp = (long long)f.n_flex_bldg * a.n_env, o = (long long)u * a.n_env + env;
+    f.flex_out[CLX_LOAD * fp + o] = chargers + wms;
+    f.flex_out[CLX_CHARGERS * fp + o] = chargers;
+    f.flex_out[CLX_RW_K0 * fp + o] = k0;
+    f.flex_out[CLX_RW_KNEG * fp + o] = kneg;
+    f.flex_out[CLX_RW_KPOS * fp + o] = kpos;
+}
+
+__global__ void cl_flex_reset_kernel(const cl_flex f, const int32_t* __restrict__ env_row0, int n_env) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_ev_cells = (long long)f.n_ev * n_env, n_wm_cells = (long long)f.n_wm * n_env;
+    if (i < n_ev_cells) {
+        const int k = (int)(i / n_env), env = (int)(i - (long long)k * n_env);
+        const int row = env_row0 ? env_row0[env / CL_ROW0_BLOCK] : 0;
+        const uint32_t* ep = f.ev_params + (long long)k * CL_NP;
+        const float rule = f.ev_ts[((long long)row * f.n_ev + k) * CL_NEVF + CLEV_RULE_RESET];
+        f.ev_state[i] = rule >= 0.0f ? rule : cl::pw(ep, CLP_L_SOC0);
+        f.ev_state[n_ev_cells + i] = cl::pw(ep, CLP_L_EFF0);
+        f.ev_state[2 * n_ev_cells + i] = cl::pw(ep, CLP_L_CAP);
+    }
+    if (i < n_wm_cells) f.wm_state[i] = 0.0f;
+}
+
+}  // namespace

@@ -40,6 +40,8 @@ struct StepArgs {
     float* __restrict__ kpi_env;
     long long act_stride_col, act_stride_env;
     const int32_t* __restrict__ env_row0;   // per-env-block episode offsets (cl_dims.env_row0) or null
+    const float* __restrict__ flex_out;     // cl_flex.flex_out planes [CL_NX][n_flex_bldg][n_env] or null (cl_flex.h)
+    int n_flex_bldg;
     int n_env, n_bldg, n_steps, n_act_cols;
     uint32_t flags;
     int t;
@@ -96,7 +98,7 @@ constexpr int NQ = CL_NQ;
 
 // District sums over buildings: wave partials -> LDS -> fixed-order serial sum over waves (deterministic).
 // `stride` is the building stride used by the caller's loop (needed by the MARL second sweep).
-template <int VEC>
+template <int VEC, bool FLEX = false>
 CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int env0, bool live, long long plane, int rkind,
                             const float (&q_net)[VEC], const float (&q_cost)[VEC], const float (&q_em)[VEC],
                             const float (&q_rw)[VEC], int stride) {
@@ -108,6 +110,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
     vstore<VEC>(mine + 3 * TILE, q_rw);
     __syncthreads();
     const int tile_env0 = blockIdx.x * TILE;
+    const bool coupled = rkind == CLR_MARL || (FLEX && rkind == CLR_EV);   // rewards that need the district net
     if (a.n_chunks > 1) {
         // large districts: this workgroup only saw buildings [y*b_chunk, (y+1)*b_chunk).  Its partial sums go to the
         // scratch rows of out_bldg's reserved plane; cl_finish_kernel adds the chunks in order (deterministic).
@@ -127,11 +130,11 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
         const int q = i / TILE, e = i - q * TILE;
         float s = 0.0f;
         for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
-        if (rkind == CLR_MARL && q == CLQ_REWARD) continue;    // finished below
+        if (coupled && q == CLQ_REWARD) continue;              // finished below
         if (tile_env0 + e < a.n_env) a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
-        if (rkind == CLR_MARL && q == CLQ_NET) lds[i] = s;     // wave-0 slot now holds the district net
+        if (coupled && q == CLQ_NET) lds[i] = s;               // wave-0 slot now holds the district net
     }
-    if (rkind == CLR_MARL) {
+    if (coupled) {
         // MARL couples every building to the district net (reward_function.py:132-143): second sweep over the
         // nets this same thread wrote a moment ago (L1/L2 hits), then a second LDS reduction for the reward sum.
         __syncthreads();
@@ -147,7 +150,23 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
                 float n[VEC], rw[VEC];
                 vload<VEC>(n, a.out_bldg + CLO_NET * plane + off);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) { rw[i] = cl::marl_reward(n[i], dnet[i]); r_sum[i] += rw[i]; }
+                for (int i = 0; i < VEC; ++i) rw[i] = cl::marl_reward(n[i], dnet[i]);
+                if (FLEX && rkind == CLR_EV) {
+                    // Electric_Vehicles_Reward_Function: MARL only scales the charger terms cl_flex_kernel prepared
+                    const uint32_t* __restrict__ bp = a.params + (long long)b * CL_NP;
+                    const int fbi = (bp[CLP_L_FLAGS] & CLF_FLEX) ? (int)bp[CLP_FLEX_INDEX] : -1;
+                    float k0[VEC], kn[VEC], kp[VEC];
+                    if (fbi >= 0) {
+                        const long long fp = (long long)a.n_flex_bldg * a.n_env, fo = (long long)fbi * a.n_env + env0;
+                        vload<VEC>(k0, a.flex_out + CLX_RW_K0 * fp + fo);
+                        vload<VEC>(kn, a.flex_out + CLX_RW_KNEG * fp + fo);
+                        vload<VEC>(kp, a.flex_out + CLX_RW_KPOS * fp + fo);
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) rw[i] = fbi >= 0 ? cl::ev_reward(true, rw[i], n[i], k0[i], kn[i], kp[i]) : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) r_sum[i] += rw[i];
                 vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, rw);
             }
         }
@@ -161,7 +180,9 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
     }
 }
 
-template <int VEC, bool FULL, bool DETAIL>
+// FLEX: the district has EV chargers / washing machines (cl_flex.h ran just before); a separate instantiation so that
+// districts without them keep their register budget.
+template <int VEC, bool FULL, bool DETAIL, bool FLEX = false>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
@@ -217,6 +238,14 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 }
             }
             float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_hd[VEC], o_dd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC];
+            // chargers / washing machines of this building, advanced by cl_flex_kernel just before this launch
+            const int fbi = (FLEX && (B.flags & CLF_FLEX)) ? (int)B.p[CLP_FLEX_INDEX] : -1;
+            float x_load[VEC], x_chg[VEC];
+            if (FLEX && fbi >= 0) {
+                const long long fp = (long long)a.n_flex_bldg * a.n_env, fo = (long long)fbi * a.n_env + env0;
+                vload<VEC>(x_load, a.flex_out + CLX_LOAD * fp + fo);
+                vload<VEC>(x_chg, a.flex_out + CLX_CHARGERS * fp + fo);
+            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 cl::State S;
@@ -231,6 +260,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 }
                 cl::Out O;
                 cl::unit_step<FULL>(B, R, a.t, quirk, act, S, O);
+                if (FLEX && fbi >= 0) cl::apply_flex(R.outage, R.price, R.carbon, x_load[i], x_chg[i], O);
                 const float rw = cl::unit_reward<FULL>(rkind, B, S, O.net);
                 s_soc[i] = S.soc; s_eff[i] = S.eff; s_deg[i] = S.degcap; s_cs[i] = S.cs; s_hs[i] = S.hs; s_ds[i] = S.ds;
                 o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem; o_hd[i] = O.heat_dem; o_dd[i] = O.dhw_dem;
@@ -251,7 +281,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 if (B.flags & CLF_DHW_STO) vstore<VEC>(a.state + CLS_DS_SOC * plane + off, s_ds);
             }
             vstore<VEC>(a.out_bldg + CLO_NET * plane + off, o_net);
-            if (rkind != CLR_MARL) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+            if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
             if constexpr (FULL && DETAIL) {
                 vstore<VEC>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
                 vstore<VEC>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
@@ -268,7 +298,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
         }
     }
 
-    district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    district_reduce<VEC, FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
 }
 
 // Lean districts (battery + PV + load), at most two buildings per wave, one chunk: the headline shape.  Same arithmetic
@@ -494,6 +524,7 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
 #include "cl_rollout.h"
 #include "cl_lstm.h"
 #include "cl_observe.h"
+#include "cl_flex.h"
 
 namespace {
 
@@ -664,6 +695,45 @@ int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, floa
 int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
                 int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg,
                 float* kpi_env, int32_t t, void* stream) {
+    return cl_step_flex_f32(dims, params, ts, state, actions, act_stride_col, act_stride_env, out_bldg, out_env, kpi_bldg,
+                            kpi_env, nullptr, t, stream);
+}
+
+static int check_flex(const cl_dims* dims, const cl_flex* f) {
+    if (f->n_ev < 0 || f->n_charger < 0 || f->n_wm < 0 || f->n_flex_bldg <= 0)
+        return fail(CL_EINVAL, "cl_flex: bad counts (ev %d, chargers %d, washing machines %d, buildings %d)", f->n_ev, f->n_charger,
+                    f->n_wm, f->n_flex_bldg);
+    const int rows = dims->n_ts_rows ? dims->n_ts_rows : dims->n_steps;
+    if (f->n_rows < rows) return fail(CL_ERANGE, "cl_flex.n_rows=%d but the step tables have %d rows", f->n_rows, rows);
+    if (int rc = check_ptr(f->flex_bldg, "flex.flex_bldg")) return rc;
+    if (int rc = check_ptr(f->flex_out, "flex.flex_out")) return rc;
+    if (int rc = check_ptr(f->ev_params, "flex.ev_params", f->n_ev > 0)) return rc;
+    if (int rc = check_ptr(f->ev_ts, "flex.ev_ts", f->n_ev > 0)) return rc;
+    if (int rc = check_ptr(f->ev_state, "flex.ev_state", f->n_ev > 0)) return rc;
+    if (int rc = check_ptr(f->charger_params, "flex.charger_params", f->n_charger > 0)) return rc;
+    if (int rc = check_ptr(f->charger_ts, "flex.charger_ts", f->n_charger > 0)) return rc;
+    if (int rc = check_ptr(f->wm_params, "flex.wm_params", f->n_wm > 0)) return rc;
+    if (int rc = check_ptr(f->wm_ts, "flex.wm_ts", f->n_wm > 0)) return rc;
+    if (int rc = check_ptr(f->wm_state, "flex.wm_state", f->n_wm > 0)) return rc;
+    return CL_OK;
+}
+
+int cl_flex_reset_f32(const cl_dims* dims, const cl_flex* flex, void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (!flex) return fail(CL_ENULL, "flex is NULL");
+    if (int rc = check_flex(dims, flex)) return rc;
+    const long long n = (long long)dims->n_env * (flex->n_ev > flex->n_wm ? flex->n_ev : flex->n_wm);
+    if (n > 0) {
+        hipLaunchKernelGGL(cl_flex_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *flex,
+                           dims->env_row0, dims->n_env);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_flex_reset_kernel launch");
+    }
+    return CL_OK;
+}
+
+int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+                     int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg,
+                     float* kpi_env, const cl_flex* flex, int32_t t, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     if (int rc = check_ptr(params, "params")) return rc;
     if (int rc = check_ptr(ts, "ts")) return rc;
@@ -687,6 +757,19 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0;
+    a.flex_out = nullptr; a.n_flex_bldg = 0;
+    const int rkind_host = (dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    if (rkind_host == CLR_EV && !flex) return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_step_flex_f32)");
+    if (flex) {
+        if (int rc = check_flex(dims, flex)) return rc;
+        FlexArgs fa;
+        fa.f = *flex; fa.actions = actions; fa.act_stride_col = act_stride_col; fa.act_stride_env = act_stride_env;
+        fa.env_row0 = dims->env_row0; fa.n_env = dims->n_env; fa.n_steps = dims->n_steps; fa.t = t;
+        const int units = flex->n_flex_bldg + flex->n_ev;
+        hipLaunchKernelGGL(cl_flex_kernel, dim3((unsigned)((dims->n_env + 63) / 64), (unsigned)((units + 3) / 4)), dim3(256), 0,
+                           (hipStream_t)stream, fa);
+        a.flex_out = flex->flex_out; a.n_flex_bldg = flex->n_flex_bldg;
+    }
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
     a.nw = g_force_nw ? g_force_nw : pick_nw(dims->n_bldg, 1);
     // general kernel: two buildings per wave measured fastest for the 6..16-building thermal schemas (fewer, longer waves)
@@ -698,6 +781,7 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
         vec = full ? (units >= (1ll << 19) && dims->n_env >= 256 ? 2 : 1) : (units >= (1ll << 19) && dims->n_env >= 512 ? 4 : 1);
     }
     if (g_force_vec) vec = g_force_vec;
+    if (flex && vec > 2) vec = 2;            // FLEX instantiations exist for 1 and 2 envs per lane
     const int tile = 64 * vec;
     const unsigned grid_x = (unsigned)((dims->n_env + tile - 1) / tile);
     // Large districts (e.g. 1024 buildings x 1024 envs per GPU): a 1-D grid over env tiles would leave most CUs idle, so
@@ -711,12 +795,29 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
         if (a.n_chunks == 1) a.b_chunk = dims->n_bldg;
         else a.nw = 16;
     }
+    if (a.n_chunks > 1 && rkind_host == CLR_EV)
+        return fail(CL_EINVAL, "reward kind CLR_EV is not implemented for building-chunked launches (n_bldg=%d)", dims->n_bldg);
     const dim3 grid(grid_x, a.n_chunks);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
     const bool det = dims->flags & CLD_WRITE_DETAIL;
-    if (full && det) {
+    if (flex) {
+        // districts with chargers / washing machines: the FLEX instantiations (one env per lane; the flexible-load
+        // planes are read per building that owns some)
+        const dim3& grid_f = grid;
+        const size_t lds_f = lds;
+        if (full && det) {
+            if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, true, true, true>), grid_f, block, lds_f, s, a);
+            else hipLaunchKernelGGL((cl_step_kernel<2, true, true, true>), grid_f, block, lds_f, s, a);
+        } else if (full) {
+            if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, true, false, true>), grid_f, block, lds_f, s, a);
+            else hipLaunchKernelGGL((cl_step_kernel<2, true, false, true>), grid_f, block, lds_f, s, a);
+        } else {
+            if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, true>), grid_f, block, lds_f, s, a);
+            else hipLaunchKernelGGL((cl_step_kernel<2, false, false, true>), grid_f, block, lds_f, s, a);
+        }
+    } else if (full && det) {
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, true>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, true>), grid, block, lds, s, a); break;

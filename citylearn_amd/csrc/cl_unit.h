@@ -144,8 +144,14 @@ CL_DEV float flexibility(const Bp& B, const Row& R, const Acc& A) {
 // Battery.charge (energy_model.py:1027-1057) on top of update_electrical_storage (building.py:1791-1812).
 // `flex` is downward_electrical_flexibility at the moment of the call; the battery's own
 // electricity_consumption[t] is still 0 there (one charge() per step), so available_nominal_power == P.
+CL_DEV float battery_energy(const BattP& B, float E, State& S);
 CL_DEV float battery_step(const BattP& B, float a_es, float flex, State& S) {
-    const float E = fminf(a_es * B.pdt, flex);
+    return battery_energy(B, fminf(a_es * B.pdt, flex), S);
+}
+
+// Battery.charge(E) for an energy E [kWh] that already carries Battery.charge's own `* time_step_ratio`
+// (energy_model.py:1036); also the entry point of the EV batteries (cl_flex.h).
+CL_DEV float battery_energy(const BattP& B, float E, State& S) {
     const float prev = S.soc;
     const float e_init = fmaxf(0.0f, prev * B.capl);                                    // energy_model.py:661-666
     const float socn = e_init * B.inv_cap;
@@ -318,6 +324,27 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
     }
 }
 
+// Chargers + washing machines of this building (cl_flex.h planes): added to the net after every other device
+// (building.py:2657-2693; a power outage zeroes the net, chargers included) and the chargers' part removed again from
+// evaluate()'s baseline (building.py:345-366).
+CL_DEV void apply_flex(bool outage, float price, float carbon, float load, float chargers, Out& O) {
+    if (!outage) {
+        O.net += load;
+        O.cost = O.net * price;
+        O.emission = fmaxf(0.0f, O.net * carbon);
+        O.base_net += load;
+    }
+    O.base_net -= chargers;
+}
+
+// Electric_Vehicles_Reward_Function for one building (reward_function.py:415-531): `marl` is MARL's reward for it,
+// K* the net-independent sums cl_flex_kernel left; buildings without chargers get 0.
+CL_DEV float ev_reward(bool has_chargers, float marl, float net, float k0, float kneg, float kpos) {
+    if (!has_chargers) return 0.0f;
+    const float k = k0 + (net < 0.0f ? kneg : (net > 0.0f ? kpos : 0.0f));
+    return k / (1.0f + fabsf(marl));
+}
+
 // Per-building reward from this unit's own quantities (reward_function.py); MARL needs the district sum
 // and is finished by the caller.  `kind` is wave-uniform.
 template <bool FULL>
@@ -334,7 +361,7 @@ CL_DEV float unit_reward(int kind, const Bp& B, const State& S, float net) {
         }
         return rw;
     }
-    case CLR_MARL: return net;   // placeholder, finished with the district sum
+    case CLR_MARL: case CLR_EV: return net;   // placeholder, finished with the district sum
     default: {
         const float m = fmaxf(net, 0.0f);
         return B.rw_exponent == 1.0f ? -m : -__powf(m, B.rw_exponent);

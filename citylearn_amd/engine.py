@@ -21,6 +21,7 @@ REWARD_KINDS = {
     'MARL': abi.CLR_MARL,
     'IndependentSACReward': abi.CLR_INDEPENDENT_SAC,
     'SolarPenaltyReward': abi.CLR_SOLAR_PENALTY,
+    'Electric_Vehicles_Reward_Function': abi.CLR_EV,
 }
 
 
@@ -37,10 +38,15 @@ class StepEngine:
 
     def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
                  t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False,
-                 n_steps: Optional[int] = None, env_row0=None):
+                 n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0):
         """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
         simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
-        at table row ``env_row0[g]`` -- different blocks replay different windows at once."""
+        at table row ``env_row0[g]`` -- different blocks replay different windows at once.
+
+        Districts with EV chargers / washing machines (``tables.flex``): ``ev_reward_weights`` are the `weights` of
+        Electric_Vehicles_Reward_Function, ``ev_seed`` keys the on-device N(1, 0.2) stream of the unconnected-EV SoC
+        drift (citylearn.py:1468-1472) and ``ev_drift`` ([table rows, n_ev], optional) replays given multipliers instead
+        (what the parity tests do: the reference draws them from the unseeded global ``np.random``)."""
         self.lib = _lib.load()                      # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
@@ -62,9 +68,12 @@ class StepEngine:
             if row0.min() < 0 or row0.max() + self.n_steps > self.n_ts_rows:
                 raise ValueError(f'env_row0 + n_steps must stay inside the {self.n_ts_rows} table rows')
             self.env_row0_host = row0.astype(np.int32)
+        self.flex_tables = tables.flex
+        if reward == 'Electric_Vehicles_Reward_Function' and self.flex_tables is None:
+            raise ValueError('Electric_Vehicles_Reward_Function needs a district with EV chargers')
         if n_act_cols is None:
             cols = tables.params.view(np.int32)[:, abi.CLP_ACT_COOL_STO:abi.CLP_ACT_COH_DEV + 1]
-            n_act_cols = int(cols.max()) + 1
+            n_act_cols = int(cols.max()) + 1 if self.flex_tables is None else self.flex_tables.n_act_cols
         self.n_act_cols = n_act_cols
         self.reward = reward
         flags = (REWARD_KINDS[reward] << abi.CLD_REWARD_SHIFT)
@@ -92,8 +101,40 @@ class StepEngine:
             self.out_env = torch.zeros((abi.CL_NQ, self.n_env), dtype=torch.float32, device=self.device)
             self.kpi_bldg = torch.zeros((abi.CL_NKB, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
             self.kpi_env = torch.zeros((abi.CL_NKE, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
+            self.flex = None
+            if self.flex_tables is not None:
+                self._init_flex(ev_reward_weights, ev_drift, ev_seed)
         self.t = 0
         self.reset()
+
+    def _init_flex(self, weights, drift, seed: int):
+        """Device copies of the flexible-load tables + their state planes (`cl_flex`, include/citylearn_amd.h)."""
+        from .flex import reward_weights
+        ft = self.flex_tables
+        if ft.n_rows < self.n_ts_rows:
+            raise ValueError('flexible-load tables are shorter than the step tables')
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        n_ev, n_c, n_w, n_fb = len(ft.ev_names), len(ft.charger_ids), len(ft.wm_names), ft.flex_bldg.shape[0]
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
+        self._flex_buffers = dict(
+            ev_params=dev(ft.ev_params.view(np.int32)), ev_ts=dev(ft.ev_ts), charger_params=dev(ft.charger_params.view(np.int32)),
+            charger_ts=dev(ft.charger_ts), wm_params=dev(ft.wm_params.view(np.int32)), wm_ts=dev(ft.wm_ts), flex_bldg=dev(ft.flex_bldg),
+            ev_state=z(abi.CL_NEVS, max(n_ev, 1), self.n_env), wm_state=z(max(n_w, 1), self.n_env),
+            flex_out=z(abi.CL_NX, n_fb, self.n_env), charger_out=z(2, max(n_c, 1), self.n_env))
+        self.ev_drift = None
+        if drift is not None:
+            drift = np.asarray(drift, dtype=np.float32)
+            if drift.shape != (ft.n_rows, n_ev):
+                raise ValueError(f'ev_drift shape {drift.shape} != {(ft.n_rows, n_ev)}')
+            self.ev_drift = dev(drift)
+        b = self._flex_buffers
+        self.flex = _lib.Flex(
+            n_ev, n_c, n_w, n_fb, ft.n_rows, 0, _ptr(b['ev_params']), _ptr(b['ev_ts']), _ptr(b['charger_params']),
+            _ptr(b['charger_ts']), _ptr(b['wm_params']), _ptr(b['wm_ts']), _ptr(b['flex_bldg']), _ptr(b['ev_state']),
+            _ptr(b['wm_state']), _ptr(b['flex_out']), _ptr(b['charger_out']), _ptr(self.ev_drift), int(seed) & (2 ** 64 - 1),
+            (ctypes.c_float * 8)(*reward_weights(weights).tolist()))
+        self.ev_state, self.wm_state = b['ev_state'], b['wm_state']
+        self.flex_out, self.charger_out = b['flex_out'], b['charger_out']
 
     # ---------------------------------------------------------------------------------------------------
     def _stream(self) -> int:
@@ -103,6 +144,8 @@ class StepEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cl_reset_f32(ctypes.byref(self.dims), _ptr(self.params), _ptr(self.state), _ptr(self.kpi_bldg), _ptr(self.kpi_env),
                                              self._stream()))
+            if self.flex is not None:
+                _lib.check(self.lib.cl_flex_reset_f32(ctypes.byref(self.dims), ctypes.byref(self.flex), self._stream()))
         self.t = 0
 
     def step(self, actions: torch.Tensor, t: Optional[int] = None):
@@ -115,9 +158,15 @@ class StepEngine:
             raise ValueError(f'actions shape {tuple(actions.shape)} != {(self.n_act_cols, self.n_env)}')
         sc, se = actions.stride()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.cl_step_f32(
-                ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), sc, se,
-                _ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env), int(t), self._stream()))
+            if self.flex is not None:
+                _lib.check(self.lib.cl_step_flex_f32(
+                    ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), sc, se,
+                    _ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env), ctypes.byref(self.flex),
+                    int(t), self._stream()))
+            else:
+                _lib.check(self.lib.cl_step_f32(
+                    ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), sc, se,
+                    _ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env), int(t), self._stream()))
         self.t = t + 1
 
     def set_action_limits(self, low, high):
@@ -133,6 +182,8 @@ class StepEngine:
         ``actions``: open-loop float32 tensor ``[k_steps, n_act_cols, n_env]`` (any strides), or ``None`` for the
         on-device policy ``a = low + u (high - low)``, ``u = Philox4x32-10(seed; env, column, t)``.
         ``ret_env`` (``[n_env]``, optional) accumulates the district reward summed over the K steps."""
+        if self.flex is not None:
+            raise NotImplementedError('the fused rollout does not advance EV chargers / washing machines yet; use step()')
         t0 = self.t if t0 is None else t0
         st = (0, 0, 0)
         if actions is not None:

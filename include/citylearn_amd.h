@@ -113,6 +113,7 @@ enum cl_param {
     CLP_HS_IRTE, CLP_HS_ICAP, CLP_HS_CAPL,
     CLP_DS_IRTE, CLP_DS_ICAP, CLP_DS_CAPL,
     CLP_T0_IHEAT_DIV,     /* 1 / CLP_T0_HEAT_DIV */
+    CLP_FLEX_INDEX,       /* i32: row of this building in the flexible-load planes (cl_flex.flex_out), -1 = no charger / washing machine */
     CLP_USED
 };
 
@@ -128,6 +129,7 @@ enum cl_param {
 #define CLF_DHW_IS_HP    (1u << 8)
 #define CLF_OUTAGE       (1u << 9)   /* simulate_power_outage (building.py:671-674) */
 #define CLF_DYNAMICS     (1u << 10)  /* LSTMDynamicsBuilding: partial-load cooling/heating demand (building.py:3080-3158) */
+#define CLF_FLEX         (1u << 11)  /* building has EV chargers and / or washing machines (cl_flex; CLP_FLEX_INDEX >= 0) */
 #define CLF_THERMAL      (CLF_COOL_DEV | CLF_HEAT_DEV | CLF_DHW_DEV | CLF_COOL_STO | CLF_HEAT_STO | CLF_DHW_STO)
 
 /* ---- time-series row (`ts[t][b][feat]`) ---- */
@@ -212,7 +214,8 @@ enum cl_reward_kind {
     CLR_DEFAULT = 0,          /* RewardFunction: -max(net,0)**exponent          (reward_function.py:65-88)  */
     CLR_MARL = 1,             /* MARL                                            (reward_function.py:132-143) */
     CLR_INDEPENDENT_SAC = 2,  /* IndependentSACReward: min(-net, 0)             (reward_function.py:159-168) */
-    CLR_SOLAR_PENALTY = 3     /* SolarPenaltyReward                              (reward_function.py:189-214) */
+    CLR_SOLAR_PENALTY = 3,    /* SolarPenaltyReward                              (reward_function.py:189-214) */
+    CLR_EV = 4                /* Electric_Vehicles_Reward_Function (needs cl_flex)  (reward_function.py:389-531) */
 };
 
 typedef struct cl_dims {
@@ -331,6 +334,97 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
                    const cl_obs_dep* deps /* host memory, nullable */, int32_t n_deps,
                    const float* state, const float* out_bldg, const float* indoor_temp, float* obs, int32_t n_cols,
                    int32_t obs_pitch, int32_t n_rows, int32_t row, uint32_t flags, void* stream);
+
+/* ---- flexible loads: EV chargers and washing machines ----
+ * Replaces, for a whole env batch, Charger.update_connected_electric_vehicle_soc (electric_vehicle_charger.py:297-334),
+ * WashingMachine.start_cycle / next_time_step (energy_model.py:1289-1330), the chargers / washing-machine terms of
+ * Building.update_variables (building.py:2657-2693), CityLearnEnv.simulate_unconnected_ev_soc and
+ * associate_chargers_to_electric_vehicles (citylearn.py:1353-1474) and Electric_Vehicles_Reward_Function
+ * (reward_function.py:389-531).  Everything that depends only on the charger schedules is folded into the tables by
+ * the host packer (citylearn_amd/flex.py); the device keeps the per-(EV, env) battery state.
+ *
+ *   ev_params      [n_ev][CL_NP]                 battery block of an EV: the CLP_L_* words of a `params` row
+ *   ev_ts          [n_rows][n_ev][CL_NEVF]       begin-of-step SoC rule of (row, EV)            (cl_ev_feat)
+ *   charger_params [n_charger][CL_NCP]           (cl_charger_param)
+ *   charger_ts     [n_rows][n_charger][CL_NCF]   (cl_charger_feat)
+ *   wm_params      [n_wm][CL_NWP]                word 0: action column (i32, -1 = inactive)
+ *   wm_ts          [n_rows][n_wm][CL_NWF]        (cl_wm_feat)
+ *   flex_bldg      [n_flex_bldg][CL_NFB] i32     building, first charger, chargers, first washing machine, washing machines
+ *   ev_state       [CL_NEVS][n_ev][n_env]        soc written last, Battery.efficiency, degraded capacity (same meaning as CLS_B_*)
+ *   wm_state       [n_wm][n_env]                 WashingMachine.initiated (0 / 1)
+ *   flex_out       [CL_NX][n_flex_bldg][n_env]   per-building results consumed by the step kernel (cl_flex_out)
+ *   charger_out    [2][n_charger][n_env]         optional detail: charger electricity_consumption[t], past_charging_action_values_kwh[t]
+ *   drift          [n_rows][n_ev]                optional: multipliers of the unconnected-EV SoC drift (citylearn.py:1468-1472) to
+ *                                                replay; NULL draws N(1, 0.2) per (env, EV, t) from Philox4x32-10 keyed by `seed`
+ * Rows: step t of env block g reads row t + env_row0[g] (row t without offsets), exactly like `ts`. */
+#define CL_NEVF 4
+enum cl_ev_feat {
+    CLEV_RULE_STEP = 0,   /* how soc[row] starts when the step is entered from row - 1:  v >= 0: v,  CLEV_ZERO, CLEV_DRIFT */
+    CLEV_RULE_LAST,       /* the same on the last step of an episode (no simulate_unconnected_ev_soc there, citylearn.py:1419-1420) */
+    CLEV_RULE_RESET,      /* ... when the episode starts on this row:  v >= 0: v,  CLEV_KEEP: battery initial_soc */
+    CLEV_CONNECTED        /* 1 when a charger holds this EV on this row (its charger advances it), else 0 */
+};
+#define CLEV_ZERO  (-1.0f)
+#define CLEV_DRIFT (-2.0f)
+#define CLEV_KEEP  (-3.0f)
+#define CL_NCP 8
+enum cl_charger_param {
+    CLC_ACT_COL = 0,      /* i32 action column, -1 = inactive */
+    CLC_MAX_CHARGE, CLC_MIN_CHARGE, CLC_MAX_DISCHARGE, CLC_MIN_DISCHARGE,   /* kW */
+    CLC_EFF, CLC_INV_EFF, /* Charger.efficiency and its reciprocal */
+    CLC_DT_HOURS          /* seconds_per_time_step / 3600 */
+};
+#define CL_NCF 4
+enum cl_charger_feat {
+    CLCT_EV = 0,          /* index of the connected EV (state 1 and a known id) as a float, -1 = none */
+    CLCT_REQUIRED_SOC,    /* electric_vehicle_required_soc_departure */
+    CLCT_DEPARTURE        /* electric_vehicle_departure_time [steps] */
+};
+#define CL_NWP 2
+#define CL_NWF 4
+enum cl_wm_feat {
+    CLWT_OPEN = 0,        /* 1 when start/end are set and start <= step <= end on this row */
+    CLWT_NEW_WINDOW,      /* 1 when (start, end) differ from the previous row: clears `initiated` (energy_model.py:1303-1312) */
+    CLWT_LOAD             /* what start_cycle books on this row: the load profile summed over the offsets still inside the episode */
+};
+#define CL_NFB 8
+#define CL_NEVS 3
+#define CL_NX 5
+enum cl_flex_out {
+    CLX_LOAD = 0,         /* chargers + washing machines electricity [kWh], added to the building's net */
+    CLX_CHARGERS,         /* chargers only (removed again for evaluate()'s baseline, building.py:345-366) */
+    CLX_RW_K0, CLX_RW_KNEG, CLX_RW_KPOS   /* Electric_Vehicles_Reward_Function: reward_b = (K0 + [net<0] KNEG + [net>0] KPOS) / (1 + |MARL_b|) */
+};
+enum cl_ev_weight { CLEW_BATTERY_LIMITS = 0, CLEW_SOC_IMPOSSIBLE, CLEW_SOC_UNDER, CLEW_CLOSE_SOC, CLEW_SELF_EV_CONSUMPTION,
+                    CLEW_EXTRA_SELF_PRODUCTION, CL_NEW };
+typedef struct cl_flex {
+    int32_t n_ev, n_charger, n_wm, n_flex_bldg, n_rows, reserved;
+    const uint32_t* ev_params;
+    const float* ev_ts;
+    const uint32_t* charger_params;
+    const float* charger_ts;
+    const uint32_t* wm_params;
+    const float* wm_ts;
+    const int32_t* flex_bldg;
+    float* ev_state;
+    float* wm_state;
+    float* flex_out;
+    float* charger_out;       /* nullable */
+    const float* drift;       /* nullable */
+    uint64_t seed;
+    float weights[8];         /* cl_ev_weight */
+} cl_flex;
+
+/* Episode start: EV SoC = CLEV_RULE_RESET of each env block's first row, nominal efficiency / capacity, washing
+ * machines idle (ElectricVehicle.reset, Charger.reset, WashingMachine.reset + the reset-time association, citylearn.py:1871-1874). */
+int cl_flex_reset_f32(const cl_dims* dims, const cl_flex* flex, void* stream);
+
+/* cl_step_f32 for a district with flexible loads: advances chargers / EVs / washing machines of step `t` (one extra
+ * launch), then runs the step with their load added to the flagged buildings' nets.  flex == NULL is cl_step_f32. */
+int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
+                     const float* actions, int64_t act_stride_col, int64_t act_stride_env,
+                     float* out_bldg, float* out_env, float* kpi_bldg, float* kpi_env, const cl_flex* flex,
+                     int32_t t, void* stream);
 
 /* Philox4x32-10 reference draw used by cl_rollout_f32 (host-callable so tests can reproduce the policy):
  * returns u in [0,1) for (seed, env, col, t). */

@@ -185,6 +185,9 @@ class UnitOracle:
         self.hs = _Tank(bspec.heating_storage, self.r)
         self.ds = _Tank(bspec.dhw_storage, self.r)
         self.es = _Battery(bspec.electrical_storage, self.r)
+        # chargers / washing machines of this building at the current step (oracle/flex_oracle.py sets them; 0 otherwise)
+        self.chargers_total = F32(0.0)
+        self.wms_total = F32(0.0)
         self.reset()
 
     # -- helpers ------------------------------------------------------------------------------------------
@@ -386,7 +389,7 @@ class UnitOracle:
         net = 0.0
         if not self.outage():
             net = self.c_cool * r + self.c_heat * r + self.c_dhw * r + self.c_ns * r + self.es.consumption() \
-                + self.solar[self.t] + F32(0.0) + F32(0.0)
+                + self.solar[self.t] + self.chargers_total + self.wms_total     # building.py:2685-2693
         self.net = F32(net)
         self.cost = F32(net * self.price[self.t])
         self.emission = F32(max(0.0, net * self.carbon[self.t]))
@@ -401,7 +404,7 @@ class UnitOracle:
 
     def net_without_storage(self):          # building.py:345-366 at the current step
         return self.net - np.sum([self.storage_electricity('cooling'), self.storage_electricity('heating'),
-                                  self.storage_electricity('dhw'), self.es.consumption(), F32(0.0)], axis=0)
+                                  self.storage_electricity('dhw'), self.es.consumption(), self.chargers_total], axis=0)
 
     def net_without_storage_and_partial_load(self):   # building.py:2877-2905 at the current step
         sp = self.spec

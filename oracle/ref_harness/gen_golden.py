@@ -95,6 +95,22 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict
     return schema
 
 
+def _action_drawer(seed: int, low, high, action_names):
+    """Seeded uniform actions (every fixture).  Districts with EV chargers / washing machines additionally get exact
+    zeros on ~20% of those columns from a second stream: `Charger.update_connected_electric_vehicle_soc` skips the
+    battery call for a zero action (electric_vehicle_charger.py:300-334), which leaves that step's SoC entry at 0."""
+    rng = np.random.RandomState(seed)
+    flex = np.array([('electric_vehicle_storage' in n) or ('washing_machine' in n) for n in action_names])
+    rng2 = np.random.RandomState(seed + 1) if flex.any() else None
+
+    def draw():
+        a = rng.uniform(low, high).astype('float32')
+        if rng2 is not None:
+            a[flex & (rng2.uniform(size=len(a)) < 0.2)] = 0.0
+        return a
+    return draw
+
+
 def run_reference(name: str):
     dataset, rows, steps, seed, gz, env_kwargs = FIXTURES[name]
     out_dir = GOLDEN / name
@@ -119,7 +135,7 @@ def run_reference(name: str):
     low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
     high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
     sizes = [b.action_space.shape[0] for b in env.buildings]
-    rng = np.random.RandomState(seed)
+    draw = _action_drawer(seed, low, high, [n for l in env.action_names for n in l])
 
     md = env.get_metadata()
     extra_rewards = {
@@ -154,10 +170,13 @@ def run_reference(name: str):
         traj['wm_consumption'] = np.zeros((K, len(wms)), dtype='float32')
         traj['chargers_total'] = np.zeros((K, B), dtype='float32')
         traj['wms_total'] = np.zeros((K, B), dtype='float32')
+        traj['ev_soc_next'] = np.zeros((K, len(evs)), dtype='float32')      # soc[t + 1] right after step t (arrival / drift values)
+        traj['ev_degcap'] = np.zeros((K, len(evs)), dtype='float64')
+        traj['ev_soc0'] = np.array([ev.battery.soc[0] for ev in evs], dtype='float32')   # after reset()'s charger association
     rewards_all = {k: np.zeros((K, B), dtype='float64') for k in extra_rewards}
     env_rewards = []
     for t in range(K):
-        a = rng.uniform(low, high).astype('float32')
+        a = draw()
         traj['actions'][t] = a
         al = [float(x) for x in a]
         if env.central_agent:
@@ -203,6 +222,9 @@ def run_reference(name: str):
             traj['wm_consumption'][t] = [w.electricity_consumption[t] for _, w in wms]
             traj['chargers_total'][t] = [b.chargers_electricity_consumption[t] for b in env.buildings]
             traj['wms_total'][t] = [b.washing_machines_electricity_consumption[t] for b in env.buildings]
+            traj['ev_degcap'][t] = [ev.battery.capacity_history[-1] for ev in evs]
+            if t + 1 < env.time_steps:
+                traj['ev_soc_next'][t] = [ev.battery.soc[t + 1] for ev in evs]
         if terminated:
             assert t == K - 1, (t, K)
     assert env.terminated == (K == rows - 1)
@@ -291,6 +313,9 @@ def run_observations(name: str, steps: int = None):
     ref_env.setup_reference()
     from citylearn.citylearn import CityLearnEnv
     from citylearn.wrappers import NormalizedObservationWrapper
+    import random as py_random
+    py_random.seed(seed)
+    np.random.seed(seed)
 
     env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
     wrapped = NormalizedObservationWrapper(env)
@@ -298,7 +323,7 @@ def run_observations(name: str, steps: int = None):
     low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
     high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
     sizes = [b.action_space.shape[0] for b in env.buildings]
-    rng = np.random.RandomState(seed)
+    draw = _action_drawer(seed, low, high, [n for l in env.action_names for n in l])
     captured = {}
     original_calculate = env.reward_function.calculate
 
@@ -312,7 +337,7 @@ def run_observations(name: str, steps: int = None):
     obs, obs_norm = [flat(obs0)], [flat(wrapped.observation(obs0))]
     robs = {k: np.zeros((K, B), dtype='float64') for k in ROBS_KEYS}
     for t in range(K):
-        a = rng.uniform(low, high).astype('float32')
+        a = draw()
         al = [float(x) for x in a]
         if env.central_agent:
             acts = [al]
@@ -345,7 +370,7 @@ def run_observations(name: str, steps: int = None):
 
 
 OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300, 'g2020_15min': 120, 's_baeda': 95, 's_2021': 95,
-                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95}
+                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239}
 
 
 if __name__ == '__main__':

@@ -38,7 +38,13 @@ class Golden:
         if schema_overrides:            # schema as a dictionary with top-level keys replaced
             schema = {**json.loads(open(self.schema_path).read()), **schema_overrides, 'root_directory': str(self.dir / 'dataset')}
             return load_district(schema, **kwargs)
-        return load_district(self.schema_path, **kwargs)
+        spec = load_district(self.schema_path, **kwargs)
+        # EVs without an `initial_soc` get one draw of Python's global `random` in the reference (citylearn.py:2564), which
+        # other libraries also consume during construction: the fixture records the values the reference ended up with
+        for ev, fact in zip(spec.electric_vehicles, self.facts.get('electric_vehicles', [])):
+            assert ev.name == fact['name']
+            ev.battery.initial_soc = fact['initial_soc']
+        return spec
 
 
 @lru_cache(maxsize=None)
