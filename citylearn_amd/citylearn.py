@@ -78,14 +78,20 @@ class CityLearnEnv:
     """One CityLearn district stepped on the GPU.  See the module docstring for the mirrored interface."""
 
     def __init__(self, schema: Union[str, Path, Mapping[str, Any]], device: str = 'cuda:0',
-                 observation_mode: str = 'reference', reference_quirks: bool = True, **kwargs: Any):
+                 observation_mode: str = 'reference', reference_quirks: bool = True, ev_seed: int = None,
+                 ev_soc_drift=None, **kwargs: Any):
         """`schema` and `**kwargs` exactly as the reference constructor (citylearn.py:133-205).  Extra arguments:
         `device`; `observation_mode`: ``'reference'`` returns the reference's observation semantics (values of step
         t+1 read before they are computed -- SoC / net read 0), ``'current'`` returns the SoC / net
-        just computed; `reference_quirks`: replicate the repeated t = 0 bookkeeping."""
+        just computed; `reference_quirks`: replicate the repeated t = 0 bookkeeping.
+        Districts with EVs: `ev_seed` keys the device's N(1, 0.2) stream of the unconnected-EV SoC drift (the reference
+        draws it from the global, unseeded ``np.random``, citylearn.py:1468-1472; default: the schema's random_seed);
+        `ev_soc_drift` ([episode steps, n_ev]) replays given multipliers instead."""
         if observation_mode not in ('reference', 'current'):
             raise ValueError("observation_mode must be 'reference' or 'current'")
         self.spec: DistrictSpec = load_district(schema, **kwargs)
+        self.electric_vehicles = list(self.spec.electric_vehicles)
+        self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
         self.device = device
         self.observation_mode = observation_mode
         self.reference_quirks = reference_quirks
@@ -212,7 +218,10 @@ class CityLearnEnv:
         self._fused_reward = fused
         names = {v: k for k, v in REWARD_KINDS.items()}
         self._engine = StepEngine(self._tables, 4, device=self.device, reward=names[kind] if fused else 'RewardFunction',
-                                  t0_quirk=self.reference_quirks, detail=True)
+                                  t0_quirk=self.reference_quirks, detail=True,
+                                  ev_reward_weights=getattr(self.reward_function, 'weights', None), ev_drift=self._ev_drift,
+                                  ev_seed=(self.random_seed if self._ev_seed is None else self._ev_seed) + self._episode)
+        self._prev_ev_soc = None
         # adjacent LSTM indoor-temperature stage (LSTMDynamicsBuilding, building.py:3000-3078) with the fused ComfortReward
         self._stage = None
         if any(b.is_dynamics for b in self.spec.buildings):
@@ -253,6 +262,8 @@ class CityLearnEnv:
             raise RuntimeError('episode has terminated: call reset()')
         a = torch.from_numpy(flat).to(eng.device)[:, None].expand(-1, eng.n_env).contiguous()
         t = self._t
+        if eng.flex is not None:
+            self._prev_ev_soc = eng.ev_state[0, :, 0].cpu().numpy()
         eng.step(a, t)
         ob = eng.out_bldg[:, :, 0].cpu().numpy()
         oe = eng.out_env[:, 0].cpu().numpy()
@@ -325,7 +336,42 @@ class CityLearnEnv:
                 'dhw_device_efficiency': float(ts[abi.CLT_COP_DHW]),
             })
             out.append(d)
+        if self._engine.flex is not None:
+            self._flex_reward_observations(t, out)
         return out
+
+    def _flex_reward_observations(self, t: int, out: List[Dict[str, Any]]) -> None:
+        """`electric_vehicles_chargers_dict` / `washing_machines_dict` / washing-machine consumption of
+        `Building._get_observations_data` (building.py:1340-1459) from the device's charger and EV planes."""
+        eng, ft = self._engine, self._tables.flex
+        charger_out = eng.charger_out[:, :, 0].cpu().numpy()
+        ev_soc = eng.ev_state[0, :, 0].cpu().numpy()
+        flex_out = eng.flex_out[:, :, 0].cpu().numpy()
+        for d in out:
+            d['electric_vehicles_chargers_dict'], d['washing_machines_dict'] = {}, {}
+            d['washing_machine_electricity_consumption'] = 0.0
+        for fb, row in enumerate(ft.flex_bldg):
+            out[row[0]]['washing_machine_electricity_consumption'] = float(flex_out[abi.CLX_LOAD, fb] - flex_out[abi.CLX_CHARGERS, fb])
+        chargers = [c for b in self.spec.buildings for c in b.chargers]
+        for j, ((i, cid), c) in enumerate(zip(ft.charger_ids, chargers)):
+            k = int(ft.charger_ts[t, j, abi.CLCT_EV])
+            info = {'connected': k >= 0, 'last_charged_kwh': float(charger_out[1, j]) if k >= 0 else 0.0, 'previous_battery_soc': None,
+                    'battery_soc': None, 'battery_capacity': None, 'min_capacity': None, 'required_soc': None,
+                    'hours_until_departure': None, 'max_charging_power': c.max_charging_power,
+                    'max_discharging_power': c.max_discharging_power}
+            if k >= 0:
+                battery = self.spec.electric_vehicles[k].battery
+                info.update(previous_battery_soc=battery.initial_soc if t == 0 else float(self._prev_ev_soc[k]),
+                            battery_soc=float(ev_soc[k]), battery_capacity=battery.capacity,
+                            min_capacity=(1 - battery.depth_of_discharge) * battery.capacity,
+                            required_soc=float(ft.charger_ts[t, j, abi.CLCT_REQUIRED_SOC]),
+                            hours_until_departure=int(ft.charger_ts[t, j, abi.CLCT_DEPARTURE]))
+            out[i]['electric_vehicles_chargers_dict'][cid] = info
+        wms = [w for b in self.spec.buildings for w in b.washing_machines]
+        for (i, name), w in zip(ft.wm_names, wms):
+            out[i]['washing_machines_dict'][name] = {'wm_start_time_step': int(w.series['wm_start_time_step'][t]),
+                                                     'wm_end_time_step': int(w.series['wm_end_time_step'][t]),
+                                                     'load_profile': w.series['load_profile'][t]}
 
     # ---- evaluate --------------------------------------------------------------------------------------------
     def evaluate(self, control_condition=None, baseline_condition=None, comfort_band: float = None):

@@ -538,7 +538,7 @@ int check_dims(const cl_dims* d) {
         return fail(CL_EINVAL, "n_ts_rows=%d < n_steps=%d", d->n_ts_rows, d->n_steps);
     if (reinterpret_cast<uintptr_t>(d->env_row0) & 3) return fail(CL_EALIGN, "env_row0 is not 4-byte aligned");
     const uint32_t rk = (d->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
-    if (rk > CLR_SOLAR_PENALTY) return fail(CL_EINVAL, "unknown reward kind %u", rk);
+    if (rk > CLR_EV) return fail(CL_EINVAL, "unknown reward kind %u", rk);
     return CL_OK;
 }
 

@@ -71,7 +71,23 @@ def available_observations(b: BuildingSpec) -> set:
              'indoor_dry_bulb_temperature_cooling_set_point', 'indoor_dry_bulb_temperature_heating_set_point',
              'indoor_dry_bulb_temperature_cooling_delta', 'indoor_dry_bulb_temperature_heating_delta', 'comfort_band',
              'occupant_count', 'power_outage'}
-    return keys
+    return keys | set(flexible_load_observations(b))
+
+
+def flexible_load_observations(b: BuildingSpec) -> List[str]:
+    """Per-charger / per-washing-machine observation names (`update_ev_charger_observations`,
+    `update_washing_machine_observations`, building.py:1221-1334); values come from `flex.FlexTables.observations`."""
+    out: List[str] = []
+    for c in b.chargers:
+        i = c.charger_id
+        out += [f'electric_vehicle_charger_{i}_connected_state', f'connected_electric_vehicle_at_charger_{i}_departure_time',
+                f'connected_electric_vehicle_at_charger_{i}_required_soc_departure', f'connected_electric_vehicle_at_charger_{i}_soc',
+                f'connected_electric_vehicle_at_charger_{i}_battery_capacity', f'electric_vehicle_charger_{i}_incoming_state',
+                f'incoming_electric_vehicle_at_charger_{i}_estimated_arrival_time',
+                f'incoming_electric_vehicle_at_charger_{i}_estimated_soc_arrival']
+    for w in b.washing_machines:
+        out += [f'{w.name}_start_time_step', f'{w.name}_end_time_step']
+    return out
 
 
 def building_observation_names(b: BuildingSpec) -> List[str]:
@@ -110,8 +126,21 @@ def space_limits(spec: DistrictSpec, b: BuildingSpec, names: Sequence[str], peri
                 return demand / dev.cop(t_out, heating=heating)
         return np.array(demand) / dev.efficiency
 
+    flex_names = set(flexible_load_observations(b))
     for key in names:
-        if key == 'net_electricity_consumption':
+        if key in flex_names:
+            # building.py:1968-2010: matched by substrings of the expanded names
+            if 'connected_state' in key or '_incoming_state' in key:
+                low[key], high[key] = 0, 1
+            elif '_departure_time' in key or '_estimated_arrival_time' in key:
+                low[key], high[key] = -1, 24
+            elif '_soc' in key and '_electric_vehicle' in key:
+                low[key], high[key] = -0.1, 1.0
+            elif key.endswith('_battery_capacity'):
+                low[key], high[key] = -1, 100
+            else:                                   # washing machine start / end step
+                low[key], high[key] = -1, 24
+        elif key == 'net_electricity_consumption':
             lo = nsl - (+es.nominal_power + gen)
             hi = nsl + cd.nominal_power + hd.nominal_power + dd.nominal_power + es.nominal_power - gen
             low[key], high[key] = min(lo.min(), 0.0), hi.max()
@@ -226,6 +255,11 @@ class ObservationLayout:
         ts = tab.ts[:, i].astype(np.float64)
         zeros = np.zeros(T)
         dyn = b.is_dynamics and b.dynamics is not None
+        if tab.flex is not None and k in tab.flex.observations:
+            # charger / washing-machine observations are functions of the schedule row (flex.py); row 0 is what reset() returns
+            values = np.array(tab.flex.observations[k][:T], dtype=np.float64)
+            values[0] = tab.flex.reset_observations[k][0]
+            return values, None, zeros
         if k == 'solar_generation':
             return np.abs(ts[:, abi.CLT_SOLAR]), None, zeros
         if k == 'power_outage':
@@ -258,6 +292,8 @@ class ObservationLayout:
     def _reset_series(self, i: int, k: str, tab: EpisodeTables) -> Optional[np.ndarray]:
         """Value of env-dependent observation `k` right after `reset()` (the reference's `update_variables` at t = 0,
         building.py:2618-2652) for an episode starting at each table row; None for env-independent observations."""
+        if tab.flex is not None and k in tab.flex.reset_observations:
+            return np.array(tab.flex.reset_observations[k][:tab.n_steps], dtype=np.float64)
         if k not in ENV_DEPENDENT or k in ('cooling_demand', 'heating_demand', 'dhw_demand'):
             return None
         ts = tab.ts[:, i].astype(np.float64)

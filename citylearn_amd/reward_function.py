@@ -167,8 +167,79 @@ class SolarPenaltyAndComfortReward(RewardFunction):
         return (r * np.reshape(self.coefficients, (2, 1))).sum(axis=0).tolist()
 
 
+class Electric_Vehicles_Reward_Function(MARL):
+    """EV-charging reward on top of :class:`MARL` (reference reward_function.py:389-531): per building with chargers,
+    the sum over its *connected* chargers of the weighted terms below, scaled by ``1 / (1 + |MARL reward|)``; buildings
+    without chargers get 0.  (The 'no_car_charging' term is computed for unconnected chargers and then skipped by the
+    reference's ``continue`` -- it never reaches the total.)  On the device: `cl_flex_kernel` + the step kernel's
+    district sweep (csrc/cl_flex.h, cl_unit.h: ev_reward) when the env's reward function is exactly this class."""
+
+    device_kind = abi.CLR_EV
+
+    def __init__(self, env_metadata: Mapping[str, Any], weights: Mapping[str, float] = None):
+        super().__init__(env_metadata)
+        self.weights = weights or {
+            'no_car_charging': -5.0, 'battery_limits': -2.0, 'soc_impossible': -10.0, 'soc_under': -5.0,
+            'close_soc': 10.0, 'self_ev_consumption': 5.0, 'extra_self_production': 5.0,
+        }
+
+    def calculate(self, observations):
+        current = MARL.calculate(self, observations)
+        out = []
+        for i, o in enumerate(observations):
+            info = o.get('electric_vehicles_chargers_dict', {})
+            if not info:
+                reward = 0
+            else:
+                reward = self.calculate_ev_penalty(o, current[0] if self.central_agent else current[i])
+            violation = float(o.get('charging_constraint_violation_kwh', 0.0) or 0.0)
+            reward -= violation if violation > 0.0 else 0.0
+            out.append(reward)
+        return [sum(out)] if self.central_agent else out
+
+    def calculate_ev_penalty(self, o: Mapping[str, Any], current_reward: float) -> float:
+        w = self.weights
+        net = o.get('net_electricity_consumption', 0)
+        mult = 1.0 / (1.0 + abs(current_reward))
+        total = 0.0
+        for data in o.get('electric_vehicles_chargers_dict', {}).values():
+            if not data['connected']:
+                continue
+            capacity, last = data['battery_capacity'], data.get('last_charged_kwh') or 0.0
+            hours = data.get('hours_until_departure', 0)
+            k = 0.0
+            held = data['previous_battery_soc'] * capacity + last
+            if held > capacity or held < data['min_capacity']:
+                k += w['battery_limits'] * mult
+            if data.get('required_soc') is not None:
+                diff = data['battery_soc'] - data['required_soc']
+                diff_kwh = diff * capacity
+                reach_c, reach_d = data.get('max_charging_power', 0) * hours, data.get('max_discharging_power', 0) * hours
+                if diff_kwh > reach_c:
+                    k += w['soc_impossible'] * mult
+                if hours == 0:
+                    if -0.25 < diff <= -0.10:
+                        k += 2 * w['soc_under'] * mult
+                    elif diff <= -0.25:
+                        k += (w['soc_under'] ** 2) * mult
+                    elif -0.10 < diff <= 0.10:
+                        k += w['close_soc'] * mult
+                if abs(diff_kwh) <= max(reach_c, reach_d):
+                    k += w['close_soc'] * mult * (1.0 / (hours + 0.1))
+            if last > 0 and net < 0:
+                k += w['extra_self_production'] * mult
+            elif last < 0 and net < 0:
+                k += -0.5 * w['extra_self_production'] * mult
+            if last < 0 and net > 0:
+                k += w['self_ev_consumption'] * mult
+            elif last > 0 and net > 0:
+                k += -0.5 * w['self_ev_consumption'] * mult
+            total += k
+        return total
+
+
 BUILTIN = {c.__name__: c for c in (RewardFunction, MARL, IndependentSACReward, SolarPenaltyReward, ComfortReward,
-                                    SolarPenaltyAndComfortReward)}
+                                    SolarPenaltyAndComfortReward, Electric_Vehicles_Reward_Function)}
 
 
 def resolve(reward_type: Union[str, type, None]):

@@ -31,7 +31,7 @@ class VectorCityLearnEnv:
     def __init__(self, schema: Union[str, Mapping[str, Any], DistrictSpec], n_envs: int, device: str = 'cuda:0',
                  reference_quirks: bool = True, kpi: bool = False, observations: str = 'planes',
                  normalize_observations: bool = False, observation_mode: str = 'current',
-                 env_episode_offsets=None, **kwargs: Any):
+                 env_episode_offsets=None, ev_seed: Optional[int] = None, ev_soc_drift=None, **kwargs: Any):
         """`observations`: ``'planes'`` (default) returns the dict of device tensors described above without
         materialising anything; ``'tensor'`` returns the Gym observation tensor ``[n_envs, n_obs]`` written by
         `cl_observe_f32` -- columns = `observation_names` (the reference's central-agent order when
@@ -42,7 +42,10 @@ class VectorCityLearnEnv:
         `env_episode_offsets`: ``None`` -- every env replays the same episode window (the reference's sequential episodes);
         ``'rolling'`` / ``'random'`` / an int array with one entry per block of ``abi.CL_ROW0_BLOCK`` envs -- blocks replay
         DIFFERENT windows of ``episode_time_steps`` rows of the simulation period at once (start rows relative to
-        ``simulation_start_time_step``; ``'random'`` redraws them at every `reset`)."""
+        ``simulation_start_time_step``; ``'random'`` redraws them at every `reset`).
+        Districts with EV chargers / washing machines (SURVEY 8f-4) run the extra `cl_flex_kernel` launch per step;
+        `ev_seed` keys the per-(env, EV, step) N(1, 0.2) drift of unconnected EVs (default: the schema's random_seed, advanced
+        per episode), `ev_soc_drift` ([table rows, n_ev]) replays given multipliers for every env instead."""
         if observations not in ('planes', 'tensor'):
             raise ValueError("observations must be 'planes' or 'tensor'")
         self.spec = schema if isinstance(schema, DistrictSpec) else load_district(schema, **kwargs)
@@ -52,6 +55,7 @@ class VectorCityLearnEnv:
         self.kpi = kpi
         self.central_agent = self.spec.central_agent
         self.env_episode_offsets = env_episode_offsets
+        self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
         if env_episode_offsets is not None:
             if not isinstance(self.spec.episode_time_steps, int):
                 raise ValueError('env_episode_offsets needs an integer episode_time_steps (schema or kwarg)')
@@ -119,7 +123,9 @@ class VectorCityLearnEnv:
         obs_tables = self.layout.episode(self.tables, reset_table=row0 is not None) if self.layout is not None else None
         self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
                                  t0_quirk=self.reference_quirks, kpi=self.kpi, n_steps=n_steps, env_row0=row0,
-                                 detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail))
+                                 detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail),
+                                 ev_reward_weights=self._rf_attrs.get('weights'), ev_drift=self._ev_drift,
+                                 ev_seed=(self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode)
         self.stage = None
         if any(b.is_dynamics for b in self.spec.buildings):
             from .dynamics import LSTMStage
@@ -175,6 +181,7 @@ class VectorCityLearnEnv:
                 'electrical_storage_soc': e.state[abi.CLS_B_SOC], 'cooling_storage_soc': e.state[abi.CLS_CS_SOC],
                 'heating_storage_soc': e.state[abi.CLS_HS_SOC], 'dhw_storage_soc': e.state[abi.CLS_DS_SOC],
                 'net_electricity_consumption': e.out_bldg[abi.CLO_NET],
+                **({'electric_vehicle_soc': e.ev_state[0]} if e.flex is not None else {}),
                 **({'indoor_dry_bulb_temperature': self.stage.indoor_temp} if getattr(self, 'stage', None) is not None else {})}
 
     def step(self, actions: torch.Tensor):

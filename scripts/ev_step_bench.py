@@ -1,0 +1,52 @@
+"""Step time of the EV district (2022 + EVs schema: 17 buildings, 8 chargers, 8 EVs, 1 washing machine) against the same
+district without its flexible loads: what the extra `cl_flex_kernel` launch and the FLEX step instantiation cost.
+Run on the GPU box: python scripts/ev_step_bench.py [n_env]"""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / 'tests'))
+
+from citylearn_amd.engine import StepEngine     # noqa: E402
+from golden_util import golden                  # noqa: E402
+
+
+def timed(eng, a, steps=200, warm=20):
+    T = eng.n_steps
+    for i in range(warm):
+        eng.step(a, (i % (T - 1)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.step(a, 1 + (i % (T - 2)))
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e6
+
+
+def main():
+    E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    g = golden('g2022_evs')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    out = {'n_env': E}
+    for reward in ('MARL', 'Electric_Vehicles_Reward_Function'):
+        eng = StepEngine(tab, E, reward=reward)
+        a = (torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1).contiguous()
+        out[f'flex/{reward}'] = round(timed(eng, a), 2)
+    import copy
+    plain = copy.copy(tab)
+    plain.flex = None
+    eng = StepEngine(plain, E, reward='MARL', n_act_cols=tab.flex.n_act_cols)
+    a = (torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1).contiguous()
+    out['no_flex/MARL'] = round(timed(eng, a), 2)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

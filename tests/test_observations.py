@@ -14,7 +14,7 @@ def _flat(ll):
     return [k for l in ll for k in l]
 
 
-@pytest.mark.parametrize('name', FIX)
+@pytest.mark.parametrize('name', FIX + ('g2022_evs',))
 @pytest.mark.parametrize('normalize', [False, True])
 def test_reference_mode_tables_match_the_reference(name, normalize):
     g = golden(name)
@@ -31,7 +31,7 @@ def test_reference_mode_tables_match_the_reference(name, normalize):
     assert tab.n_dependent == 0                     # reference semantics: nothing is read from the device
 
 
-@pytest.mark.parametrize('name', FIX)
+@pytest.mark.parametrize('name', FIX + ('g2022_evs',))
 def test_observation_space_limits_match_the_reference(name):
     g = golden(name)
     o = g.obs
