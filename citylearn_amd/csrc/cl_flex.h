@@ -27,6 +27,8 @@ struct FlexArgs {
     long long act_stride_col, act_stride_env;
     const int32_t* __restrict__ env_row0;
     int n_env, n_steps, t;
+    bool want_reward;      // reward kind is CLR_EV: leave the K planes
+    bool want_chargers;    // the step writes evaluate()'s baseline (CLD_WRITE_DETAIL): leave the chargers-only plane
 };
 
 CL_DEV float flex_action(const FlexArgs& a, int col, int env) {
@@ -52,113 +54,153 @@ CL_DEV float flex_begin_soc(const FlexArgs& a, const float* __restrict__ ev_row,
     return fminf(fmaxf(prev * fminf(fmaxf(m, 0.6f), 1.4f), 0.0f), 1.0f);
 }
 
+// VEC consecutive envs per lane (float4 plane accesses at VEC = 4: a quarter of the waves walk the scalar table chain).
+template <int VEC>
 __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
+    constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int u = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-    const int env = blockIdx.x * 64 + lane;
+    const int env0 = blockIdx.x * TILE + lane * VEC;
     const cl_flex& f = a.f;
     if (u >= f.n_flex_bldg + f.n_ev) return;
-    const bool live = env < a.n_env;
-    const int row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * 64) / CL_ROW0_BLOCK] : 0);
+    const bool live = env0 < a.n_env;                     // n_env % 4 == 0 (check_dims): a lane's VEC envs are all in or all out
+    const int row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
     const long long ev_plane = (long long)f.n_ev * a.n_env;
+    const bool coalesced = a.act_stride_env == 1;
 
     if (u >= f.n_flex_bldg) {
         // ---- an EV nobody holds on this row ----
         const int k = u - f.n_flex_bldg;
         const float* __restrict__ er = f.ev_ts + ((long long)row * f.n_ev + k) * CL_NEVF;
         if (a.t == 0 || er[CLEV_CONNECTED] != 0.0f || !live) return;     // t = 0: cl_flex_reset_f32 wrote soc[0]
-        float* soc = f.ev_state + (long long)k * a.n_env + env;
-        *soc = flex_begin_soc(a, er, row, k, env, *soc);
+        float* sp = f.ev_state + (long long)k * a.n_env + env0;
+        float soc[VEC];
+        vload<VEC>(soc, sp);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) soc[i] = flex_begin_soc(a, er, row, k, env0 + i, soc[i]);
+        vstore<VEC>(sp, soc);
         return;
     }
 
     // ---- a building: chargers, then washing machines ----
     const int32_t* __restrict__ fb = f.flex_bldg + (long long)u * CL_NFB;
     const int c0 = fb[1], nc = fb[2], w0 = fb[3], nwm = fb[4];
-    float chargers = 0.0f, wms = 0.0f, k0 = 0.0f, kneg = 0.0f, kpos = 0.0f;
+    float chargers[VEC], wms[VEC], k0[VEC], kneg[VEC], kpos[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) chargers[i] = wms[i] = k0[i] = kneg[i] = kpos[i] = 0.0f;
     for (int c = c0; c < c0 + nc; ++c) {
         const uint32_t* __restrict__ cp = f.charger_params + (long long)c * CL_NCP;
         const float* __restrict__ cr = f.charger_ts + ((long long)row * f.n_charger + c) * CL_NCF;
         const int k = (int)cr[CLCT_EV];
+        const int col = (int)cp[CLC_ACT_COL];
         const float eff = cl::pw(cp, CLC_EFF), inv_eff = cl::pw(cp, CLC_INV_EFF), dt = cl::pw(cp, CLC_DT_HOURS);
         const float max_c = cl::pw(cp, CLC_MAX_CHARGE), min_c = cl::pw(cp, CLC_MIN_CHARGE);
         const float max_d = cl::pw(cp, CLC_MAX_DISCHARGE), min_d = cl::pw(cp, CLC_MIN_DISCHARGE);
         if (!live) continue;
-        const float act = flex_action(a, (int)cp[CLC_ACT_COL], env);
-        // electric_vehicle_charger.py:306-322: requested energy, clamped to the charger's power range
-        float energy = 0.0f, to_battery = 0.0f;
-        if (act > 0.0f) {
-            energy = fmaxf(fminf(act * max_c * dt, max_c), min_c);
-            to_battery = energy * eff;
-        } else if (act < 0.0f) {
-            energy = fmaxf(fminf(act * max_d * dt, -min_d), -max_d);
-            to_battery = energy * inv_eff;
+        float act[VEC], energy[VEC], cons[VEC];
+        if (col >= 0 && coalesced) vload<VEC>(act, a.actions + (long long)col * a.act_stride_col + env0);
+        else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) act[i] = flex_action(a, col, env0 + i);
         }
-        float cons = 0.0f;
+        // electric_vehicle_charger.py:306-322: requested energy, clamped to the charger's power range
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            energy[i] = act[i] > 0.0f ? fmaxf(fminf(act[i] * max_c * dt, max_c), min_c)
+                      : act[i] < 0.0f ? fmaxf(fminf(act[i] * max_d * dt, -min_d), -max_d) : 0.0f;
+            cons[i] = 0.0f;
+        }
         if (k >= 0) {
             const uint32_t* __restrict__ ep = f.ev_params + (long long)k * CL_NP;
             const float* __restrict__ er = f.ev_ts + ((long long)row * f.n_ev + k) * CL_NEVF;
-            float* sp = f.ev_state + (long long)k * a.n_env + env;
-            cl::State S;
-            S.soc = sp[0]; S.eff = sp[ev_plane]; S.degcap = sp[2 * ev_plane];
-            S.cs = S.hs = S.ds = 0.0f;
-            const float prev = S.soc;                                  // soc[t - 1]; at t = 0 soc[0] itself (energy_model.py:661-666)
-            float now = a.t == 0 ? prev : flex_begin_soc(a, er, row, k, env, prev);
-            if (act != 0.0f) {
-                cl::BattP P;
-                cl::load_batt(P, ep);
-                const float eb = cl::battery_energy(P, to_battery * P.r, S);      // Battery.charge (energy_model.py:1027-1057)
-                now = S.soc;
-                cons = eb >= 0.0f ? eb * inv_eff : eb * eff;                        // electric_vehicle_charger.py:329
-                sp[ev_plane] = S.eff; sp[2 * ev_plane] = S.degcap;
-            }
-            sp[0] = now;
-            // ---- Electric_Vehicles_Reward_Function.calculate_ev_penalty, everything but the 1/(1+|MARL|) factor and
-            //      the sign of the building net (reward_function.py:466-529) ----
-            const float cap = cl::pw(ep, CLP_L_CAP), min_cap = cl::pw(ep, CLP_L_OMD) * cap;
-            const float soc_prev = a.t == 0 ? cl::pw(ep, CLP_L_SOC0) : prev;          // building.py:1355
+            float* sp = f.ev_state + (long long)k * a.n_env + env0;
+            float soc[VEC], ef[VEC], deg[VEC];
+            vload<VEC>(soc, sp); vload<VEC>(ef, sp + ev_plane); vload<VEC>(deg, sp + 2 * ev_plane);
+            cl::BattP P;
+            cl::load_batt(P, ep);
+            const float cap = P.cap, min_cap = P.omd * cap, soc0 = cl::pw(ep, CLP_L_SOC0);
             const float required = cr[CLCT_REQUIRED_SOC], hours = cr[CLCT_DEPARTURE];
-            const float held = fmaf(soc_prev, cap, energy);
-            if (held > cap || held < min_cap) k0 += f.weights[CLEW_BATTERY_LIMITS];
-            const float diff = now - required, diff_kwh = diff * cap;
             const float reach_c = max_c * hours, reach_d = max_d * hours;
-            if (diff_kwh > reach_c) k0 += f.weights[CLEW_SOC_IMPOSSIBLE];
-            if (hours == 0.0f) {
-                if (diff > -0.25f && diff <= -0.10f) k0 += 2.0f * f.weights[CLEW_SOC_UNDER];
-                else if (diff <= -0.25f) k0 += f.weights[CLEW_SOC_UNDER] * f.weights[CLEW_SOC_UNDER];
-                else if (diff > -0.10f && diff <= 0.10f) k0 += f.weights[CLEW_CLOSE_SOC];
+            bool charged = false;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float prev = soc[i];                          // soc[t - 1]; at t = 0 soc[0] itself (energy_model.py:661-666)
+                float now = a.t == 0 ? prev : flex_begin_soc(a, er, row, k, env0 + i, prev);
+                if (act[i] != 0.0f) {
+                    cl::State S;
+                    S.soc = prev; S.eff = ef[i]; S.degcap = deg[i]; S.cs = S.hs = S.ds = 0.0f;
+                    const float to_battery = energy[i] * (act[i] > 0.0f ? eff : inv_eff);
+                    const float eb = cl::battery_energy(P, to_battery * P.r, S);      // Battery.charge (energy_model.py:1027-1057)
+                    now = S.soc; ef[i] = S.eff; deg[i] = S.degcap;
+                    cons[i] = eb >= 0.0f ? eb * inv_eff : eb * eff;                     // electric_vehicle_charger.py:329
+                    charged = true;
+                }
+                soc[i] = now;
+                if (a.want_reward) {
+                    // Electric_Vehicles_Reward_Function.calculate_ev_penalty, everything but the 1/(1+|MARL|) factor and the
+                    // sign of the building net (reward_function.py:466-529)
+                    const float soc_prev = a.t == 0 ? soc0 : prev;                      // building.py:1355
+                    const float held = fmaf(soc_prev, cap, energy[i]);
+                    if (held > cap || held < min_cap) k0[i] += f.weights[CLEW_BATTERY_LIMITS];
+                    const float diff = now - required, diff_kwh = diff * cap;
+                    if (diff_kwh > reach_c) k0[i] += f.weights[CLEW_SOC_IMPOSSIBLE];
+                    if (hours == 0.0f) {
+                        if (diff > -0.25f && diff <= -0.10f) k0[i] += 2.0f * f.weights[CLEW_SOC_UNDER];
+                        else if (diff <= -0.25f) k0[i] += f.weights[CLEW_SOC_UNDER] * f.weights[CLEW_SOC_UNDER];
+                        else if (diff > -0.10f && diff <= 0.10f) k0[i] += f.weights[CLEW_CLOSE_SOC];
+                    }
+                    if (fabsf(diff_kwh) <= fmaxf(reach_c, reach_d)) k0[i] += f.weights[CLEW_CLOSE_SOC] / (hours + 0.1f);
+                    if (energy[i] > 0.0f) { kneg[i] += f.weights[CLEW_EXTRA_SELF_PRODUCTION]; kpos[i] += -0.5f * f.weights[CLEW_SELF_EV_CONSUMPTION]; }
+                    else if (energy[i] < 0.0f) { kneg[i] += -0.5f * f.weights[CLEW_EXTRA_SELF_PRODUCTION]; kpos[i] += f.weights[CLEW_SELF_EV_CONSUMPTION]; }
+                }
             }
-            if (fabsf(diff_kwh) <= fmaxf(reach_c, reach_d)) k0 += f.weights[CLEW_CLOSE_SOC] / (hours + 0.1f);
-            if (energy > 0.0f) { kneg += f.weights[CLEW_EXTRA_SELF_PRODUCTION]; kpos += -0.5f * f.weights[CLEW_SELF_EV_CONSUMPTION]; }
-            else if (energy < 0.0f) { kneg += -0.5f * f.weights[CLEW_EXTRA_SELF_PRODUCTION]; kpos += f.weights[CLEW_SELF_EV_CONSUMPTION]; }
+            vstore<VEC>(sp, soc);
+            if (charged) { vstore<VEC>(sp + ev_plane, ef); vstore<VEC>(sp + 2 * ev_plane, deg); }
         }
-        chargers += cons;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) chargers[i] += cons[i];
         if (f.charger_out) {
-            f.charger_out[(long long)c * a.n_env + env] = cons;
-            f.charger_out[((long long)f.n_charger + c) * a.n_env + env] = energy;
+            vstore<VEC>(f.charger_out + (long long)c * a.n_env + env0, cons);
+            vstore<VEC>(f.charger_out + ((long long)f.n_charger + c) * a.n_env + env0, energy);
         }
     }
     for (int w = w0; w < w0 + nwm; ++w) {
         const float* __restrict__ wr = f.wm_ts + ((long long)row * f.n_wm + w) * CL_NWF;
         const int col = (int)f.wm_params[(long long)w * CL_NWP];
+        const bool new_window = a.t > 0 && wr[CLWT_NEW_WINDOW] != 0.0f, open = wr[CLWT_OPEN] != 0.0f;
+        const float load = wr[CLWT_LOAD];
         if (!live) continue;
-        float* st = f.wm_state + (long long)w * a.n_env + env;
-        bool initiated = *st != 0.0f;
-        if (a.t > 0 && wr[CLWT_NEW_WINDOW] != 0.0f) initiated = false;          // energy_model.py:1303-1312
-        const float act = flex_action(a, col, env);
-        if (!initiated && act > 0.0f && wr[CLWT_OPEN] != 0.0f) {                // energy_model.py:1320-1330
-            initiated = true;
-            wms += wr[CLWT_LOAD];
+        float* st = f.wm_state + (long long)w * a.n_env + env0;
+        float init[VEC], act[VEC];
+        vload<VEC>(init, st);
+        if (col >= 0 && coalesced) vload<VEC>(act, a.actions + (long long)col * a.act_stride_col + env0);
+        else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) act[i] = flex_action(a, col, env0 + i);
         }
-        *st = initiated ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            bool initiated = init[i] != 0.0f && !new_window;                  // energy_model.py:1303-1312
+            if (!initiated && act[i] > 0.0f && open) {                         // energy_model.py:1320-1330
+                initiated = true;
+                wms[i] += load;
+            }
+            init[i] = initiated ? 1.0f : 0.0f;
+        }
+        vstore<VEC>(st, init);
     }
     if (!live) return;
-    const long long fp = (long long)f.n_flex_bldg * a.n_env, o = (long long)u * a.n_env + env;
-    f.flex_out[CLX_LOAD * fp + o] = chargers + wms;
-    f.flex_out[CLX_CHARGERS * fp + o] = chargers;
-    f.flex_out[CLX_RW_K0 * fp + o] = k0;
-    f.flex_out[CLX_RW_KNEG * fp + o] = kneg;
-    f.flex_out[CLX_RW_KPOS * fp + o] = kpos;
+    const long long fp = (long long)f.n_flex_bldg * a.n_env, o = (long long)u * a.n_env + env0;
+    float total[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) total[i] = chargers[i] + wms[i];
+    vstore<VEC>(f.flex_out + CLX_LOAD * fp + o, total);
+    if (a.want_chargers) vstore<VEC>(f.flex_out + CLX_CHARGERS * fp + o, chargers);
+    if (a.want_reward) {
+        vstore<VEC>(f.flex_out + CLX_RW_K0 * fp + o, k0);
+        vstore<VEC>(f.flex_out + CLX_RW_KNEG * fp + o, kneg);
+        vstore<VEC>(f.flex_out + CLX_RW_KPOS * fp + o, kpos);
+    }
 }
 
 __global__ void cl_flex_reset_kernel(const cl_flex f, const int32_t* __restrict__ env_row0, int n_env) {

@@ -244,7 +244,11 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
             if (FLEX && fbi >= 0) {
                 const long long fp = (long long)a.n_flex_bldg * a.n_env, fo = (long long)fbi * a.n_env + env0;
                 vload<VEC>(x_load, a.flex_out + CLX_LOAD * fp + fo);
-                vload<VEC>(x_chg, a.flex_out + CLX_CHARGERS * fp + fo);
+                if constexpr (DETAIL) vload<VEC>(x_chg, a.flex_out + CLX_CHARGERS * fp + fo);   // only the baseline needs it
+                else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) x_chg[i] = 0.0f;
+                }
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
@@ -307,7 +311,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 // for the generic kernel, whose every wave walks a dependent chain  parameter block (scalar) -> action column ->
 // state / action loads -> compute -> stores  once per building.  Here a wave issues the state loads of BOTH its
 // buildings (and the action loads, when the column of building b is b: CLD_ES_COL_IS_BLDG) before it touches a parameter.
-template <int VEC>
+template <int VEC, bool FLEX = false>
 __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
@@ -351,6 +355,10 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
         const bool batt = B.flags & CLF_BATTERY;
         if (!act_by_bldg) load_action<VEC>(a_es[m], a, B.a_es, env0);
         float o_net[VEC], o_rw[VEC];
+        // chargers / washing machines of this building (cl_flex_kernel ran just before this launch)
+        const int fbi = (FLEX && (B.flags & CLF_FLEX)) ? (int)B.p[CLP_FLEX_INDEX] : -1;
+        float x_load[VEC];
+        if (FLEX && fbi >= 0) vload<VEC>(x_load, a.flex_out + (long long)CLX_LOAD * a.n_flex_bldg * a.n_env + (long long)fbi * a.n_env + env0);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             cl::State S;
@@ -359,6 +367,7 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
             const cl::Act act = {0.0f, 0.0f, 0.0f, B.a_es >= 0 ? a_es[m][i] : 0.0f, 0.0f, 0.0f};
             cl::Out O;
             cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
+            if (FLEX && fbi >= 0) cl::apply_flex(false, R.price, R.carbon, x_load[i], 0.0f, O);
             const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
             s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap;
             o_net[i] = O.net; o_rw[i] = rw;
@@ -370,9 +379,9 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
             vstore<VEC>(a.state + CLS_B_DEGCAP * plane + off, s_deg[m]);
         }
         vstore<VEC>(a.out_bldg + CLO_NET * plane + off, o_net);
-        if (rkind != CLR_MARL) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+        if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
     }
-    district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    district_reduce<VEC, FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
 }
 
 // Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x 16
@@ -573,6 +582,7 @@ int g_no_chunks = 0;
 int g_lean_variant = 0;   // 1: generic kernel for lean districts too; 2: latency-ordered kernel at any grid size (tests, tuning)
 int g_obs_variant = 0;   // 1 / 2 / 3: force the row-wise / LDS-tile / wave-independent observation kernel (tests, tuning)
 int g_lstm_dbg = 0;
+int g_flex_vec = 0;      // 1 / 2 / 4: envs per lane of cl_flex_kernel (tuning)
 int g_obs_rows = 0;      // tile kernel: envs per block (tuning)
 
 }  // namespace
@@ -653,6 +663,7 @@ const char* cl_last_error(void) { return g_err; }
 void cl_debug_set_vec(int vec) { g_force_vec = vec; }
 void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks & 1; g_lean_variant = (no_chunks >> 2) & 3; g_force_nw = nw; }
 void cl_debug_set_lstm(int dbg) { g_lstm_dbg = dbg; }
+void cl_debug_set_flex(int vec) { g_flex_vec = vec; }
 int cl_debug_copy_floor(const float* st_in, const float* act, float* st_out, float* out2, int n_bldg, int n_env, void* stream) {
     hipLaunchKernelGGL(cl_copy_floor_kernel, dim3(n_env / 256), dim3(1024), 0, (hipStream_t)stream, st_in, act, st_out, out2, n_bldg, n_env);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "copy floor launch");
@@ -765,9 +776,19 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         FlexArgs fa;
         fa.f = *flex; fa.actions = actions; fa.act_stride_col = act_stride_col; fa.act_stride_env = act_stride_env;
         fa.env_row0 = dims->env_row0; fa.n_env = dims->n_env; fa.n_steps = dims->n_steps; fa.t = t;
+        fa.want_reward = rkind_host == CLR_EV;
+        fa.want_chargers = (dims->flags & CLD_WRITE_DETAIL) != 0;
         const int units = flex->n_flex_bldg + flex->n_ev;
-        hipLaunchKernelGGL(cl_flex_kernel, dim3((unsigned)((dims->n_env + 63) / 64), (unsigned)((units + 3) / 4)), dim3(256), 0,
-                           (hipStream_t)stream, fa);
+        const unsigned gy = (unsigned)((units + 3) / 4);
+        // four envs per lane once there are enough envs to fill the chip that way (and plane rows stay 16-byte aligned)
+        int fvec = dims->n_env >= 16384 ? 4 : 1;
+        if (g_flex_vec) fvec = g_flex_vec;
+        const dim3 fgrid((unsigned)((dims->n_env + 64 * fvec - 1) / (64 * fvec)), gy);
+        switch (fvec) {
+        case 4: hipLaunchKernelGGL(cl_flex_kernel<4>, fgrid, dim3(256), 0, (hipStream_t)stream, fa); break;
+        case 2: hipLaunchKernelGGL(cl_flex_kernel<2>, fgrid, dim3(256), 0, (hipStream_t)stream, fa); break;
+        default: hipLaunchKernelGGL(cl_flex_kernel<1>, fgrid, dim3(256), 0, (hipStream_t)stream, fa); break;
+        }
         a.flex_out = flex->flex_out; a.n_flex_bldg = flex->n_flex_bldg;
     }
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
@@ -781,7 +802,8 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         vec = full ? (units >= (1ll << 19) && dims->n_env >= 256 ? 2 : 1) : (units >= (1ll << 19) && dims->n_env >= 512 ? 4 : 1);
     }
     if (g_force_vec) vec = g_force_vec;
-    if (flex && vec > 2) vec = 2;            // FLEX instantiations exist for 1 and 2 envs per lane
+    if (flex && vec > 2 && !(!full && dims->n_bldg <= 2 * a.nw && !will_chunk && (dims->n_env + 64 * vec - 1) / (64 * vec) <= 256 && !(g_lean_variant & 1)))
+        vec = 2;                             // general-kernel FLEX instantiations exist for 1 and 2 envs per lane
     const int tile = 64 * vec;
     const unsigned grid_x = (unsigned)((dims->n_env + tile - 1) / tile);
     // Large districts (e.g. 1024 buildings x 1024 envs per GPU): a 1-D grid over env tiles would leave most CUs idle, so
@@ -802,9 +824,17 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
     const bool det = dims->flags & CLD_WRITE_DETAIL;
-    if (flex) {
-        // districts with chargers / washing machines: the FLEX instantiations (one env per lane; the flexible-load
-        // planes are read per building that owns some)
+    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (g_lean_variant & 2)) && !(g_lean_variant & 1);
+    if (flex && !full && lean_shape) {
+        switch (vec) {
+        case 1: hipLaunchKernelGGL((cl_step_lean_kernel<1, true>), grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((cl_step_lean_kernel<2, true>), grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((cl_step_lean_kernel<4, true>), grid, block, lds, s, a); break;
+        default: return fail(CL_EINVAL, "bad vec %d", vec);
+        }
+    } else if (flex) {
+        // districts with chargers / washing machines: the FLEX instantiations of the general kernel
+        if (vec > 2) return fail(CL_EINVAL, "bad vec %d for the flexible-load step", vec);
         const dim3& grid_f = grid;
         const size_t lds_f = lds;
         if (full && det) {
@@ -830,7 +860,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         case 4: hipLaunchKernelGGL((cl_step_kernel<4, true, false>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
-    } else if (a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (g_lean_variant & 2)) && !(g_lean_variant & 1)) {
+    } else if (lean_shape) {
         // one workgroup per CU at most: with more rounds the generic kernel's smaller register file (52 vs 88 VGPRs, two
         // workgroups per CU) wins again -- 17 x 262 144: 30.8 us vs 33.0 us
         switch (vec) {                                   // latency-ordered lean kernel (two buildings per wave at most)

@@ -35,10 +35,15 @@ def main():
     spec = g.spec()
     tab = spec.episode_tables(0)
     out = {'n_env': E}
+    from citylearn_amd import _lib
+    lib = _lib.load()
     for reward in ('MARL', 'Electric_Vehicles_Reward_Function'):
         eng = StepEngine(tab, E, reward=reward)
         a = (torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1).contiguous()
-        out[f'flex/{reward}'] = round(timed(eng, a), 2)
+        for fv in (1, 2, 4):
+            lib.cl_debug_set_flex(fv)
+            out[f'flex{fv}/{reward}'] = round(timed(eng, a), 2)
+        lib.cl_debug_set_flex(0)
     import copy
     plain = copy.copy(tab)
     plain.flex = None
