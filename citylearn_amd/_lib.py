@@ -40,11 +40,10 @@ class Dims(ctypes.Structure):
 
 class Flex(ctypes.Structure):
     """``cl_flex`` (include/citylearn_amd.h): EV chargers / washing machines tables and state."""
-    _fields_ = [('n_ev', ctypes.c_int32), ('n_charger', ctypes.c_int32), ('n_wm', ctypes.c_int32),
-                ('n_flex_bldg', ctypes.c_int32), ('n_rows', ctypes.c_int32), ('reserved', ctypes.c_int32),
+    _fields_ = [('n_ev', ctypes.c_int32), ('n_flex_bldg', ctypes.c_int32), ('n_rows', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('ev_params', ctypes.c_void_p), ('ev_ts', ctypes.c_void_p), ('charger_params', ctypes.c_void_p),
                 ('charger_ts', ctypes.c_void_p), ('wm_params', ctypes.c_void_p), ('wm_ts', ctypes.c_void_p),
-                ('flex_bldg', ctypes.c_void_p), ('ev_state', ctypes.c_void_p), ('wm_state', ctypes.c_void_p),
+                ('ev_state', ctypes.c_void_p), ('wm_state', ctypes.c_void_p),
                 ('flex_out', ctypes.c_void_p), ('charger_out', ctypes.c_void_p), ('drift', ctypes.c_void_p),
                 ('seed', ctypes.c_uint64), ('weights', ctypes.c_float * 8)]
 

@@ -218,7 +218,7 @@ class CityLearnEnv:
         self._fused_reward = fused
         names = {v: k for k, v in REWARD_KINDS.items()}
         self._engine = StepEngine(self._tables, 4, device=self.device, reward=names[kind] if fused else 'RewardFunction',
-                                  t0_quirk=self.reference_quirks, detail=True,
+                                  t0_quirk=self.reference_quirks, detail=True, charger_detail=True,
                                   ev_reward_weights=getattr(self.reward_function, 'weights', None), ev_drift=self._ev_drift,
                                   ev_seed=(self.random_seed if self._ev_seed is None else self._ev_seed) + self._episode)
         self._prev_ev_soc = None
@@ -350,11 +350,11 @@ class CityLearnEnv:
         for d in out:
             d['electric_vehicles_chargers_dict'], d['washing_machines_dict'] = {}, {}
             d['washing_machine_electricity_consumption'] = 0.0
-        for fb, row in enumerate(ft.flex_bldg):
-            out[row[0]]['washing_machine_electricity_consumption'] = float(flex_out[abi.CLX_LOAD, fb] - flex_out[abi.CLX_CHARGERS, fb])
+        for fb, bldg in enumerate(ft.flex_bldg):
+            out[bldg]['washing_machine_electricity_consumption'] = float(flex_out[abi.CLX_LOAD, fb] - flex_out[abi.CLX_CHARGERS, fb])
         chargers = [c for b in self.spec.buildings for c in b.chargers]
         for j, ((i, cid), c) in enumerate(zip(ft.charger_ids, chargers)):
-            k = int(ft.charger_ts[t, j, abi.CLCT_EV])
+            k = int(ft.charger_row(j)[t, abi.CLCT_EV])
             info = {'connected': k >= 0, 'last_charged_kwh': float(charger_out[1, j]) if k >= 0 else 0.0, 'previous_battery_soc': None,
                     'battery_soc': None, 'battery_capacity': None, 'min_capacity': None, 'required_soc': None,
                     'hours_until_departure': None, 'max_charging_power': c.max_charging_power,
@@ -364,8 +364,8 @@ class CityLearnEnv:
                 info.update(previous_battery_soc=battery.initial_soc if t == 0 else float(self._prev_ev_soc[k]),
                             battery_soc=float(ev_soc[k]), battery_capacity=battery.capacity,
                             min_capacity=(1 - battery.depth_of_discharge) * battery.capacity,
-                            required_soc=float(ft.charger_ts[t, j, abi.CLCT_REQUIRED_SOC]),
-                            hours_until_departure=int(ft.charger_ts[t, j, abi.CLCT_DEPARTURE]))
+                            required_soc=float(ft.charger_row(j)[t, abi.CLCT_REQUIRED_SOC]),
+                            hours_until_departure=int(ft.charger_row(j)[t, abi.CLCT_DEPARTURE]))
             out[i]['electric_vehicles_chargers_dict'][cid] = info
         wms = [w for b in self.spec.buildings for w in b.washing_machines]
         for (i, name), w in zip(ft.wm_names, wms):

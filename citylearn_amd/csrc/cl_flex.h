@@ -83,39 +83,71 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
     }
 
     // ---- a building: chargers, then washing machines ----
-    const int32_t* __restrict__ fb = f.flex_bldg + (long long)u * CL_NFB;
-    const int c0 = fb[1], nc = fb[2], w0 = fb[3], nwm = fb[4];
+    // Phase 1: the slot headers (scalar; every address depends on (u, row) only).  Phase 2: every plane / action read of
+    // every occupied slot, issued back to back BEFORE any store -- the compiler may not move a load above an earlier
+    // store to a possibly aliasing plane, so interleaving load / compute / store per slot serialised one HBM round trip
+    // per slot.  Phase 3: arithmetic and stores.
+    const uint32_t* __restrict__ cp0 = f.charger_params + (long long)u * CL_MAXC * CL_NCP;
+    const float* __restrict__ cr0 = f.charger_ts + ((long long)row * f.n_flex_bldg + u) * CL_MAXC * CL_NCF;
+    const uint32_t* __restrict__ wp0 = f.wm_params + (long long)u * CL_MAXW * CL_NWP;
+    const float* __restrict__ wr0 = f.wm_ts + ((long long)row * f.n_flex_bldg + u) * CL_MAXW * CL_NWF;
+    float hdr[CL_MAXC], whdr[CL_MAXW];
+    int ccol[CL_MAXC], wcol[CL_MAXW];
+#pragma unroll
+    for (int j = 0; j < CL_MAXC; ++j) { hdr[j] = cr0[j * CL_NCF + CLCT_EV]; ccol[j] = (int)cp0[j * CL_NCP + CLC_ACT_COL]; }
+#pragma unroll
+    for (int j = 0; j < CL_MAXW; ++j) { whdr[j] = wr0[j * CL_NWF + CLWT_OPEN]; wcol[j] = (int)wp0[j * CL_NWP]; }
+    if (!live) return;
+    float act[CL_MAXC][VEC], soc[CL_MAXC][VEC], ef[CL_MAXC][VEC], deg[CL_MAXC][VEC], winit[CL_MAXW][VEC], wact[CL_MAXW][VEC];
+#pragma unroll
+    for (int j = 0; j < CL_MAXC; ++j) {
+        if (hdr[j] == CLCT_EMPTY) continue;
+        if (ccol[j] >= 0 && coalesced) vload<VEC>(act[j], a.actions + (long long)ccol[j] * a.act_stride_col + env0);
+        else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) act[j][i] = flex_action(a, ccol[j], env0 + i);
+        }
+        if (hdr[j] >= 0.0f) {
+            const float* sp = f.ev_state + (long long)(int)hdr[j] * a.n_env + env0;
+            vload<VEC>(soc[j], sp); vload<VEC>(ef[j], sp + ev_plane); vload<VEC>(deg[j], sp + 2 * ev_plane);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CL_MAXW; ++j) {
+        if (whdr[j] == CLWT_EMPTY) continue;
+        vload<VEC>(winit[j], f.wm_state + (long long)(u * CL_MAXW + j) * a.n_env + env0);
+        if (wcol[j] >= 0 && coalesced) vload<VEC>(wact[j], a.actions + (long long)wcol[j] * a.act_stride_col + env0);
+        else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) wact[j][i] = flex_action(a, wcol[j], env0 + i);
+        }
+    }
+
     float chargers[VEC], wms[VEC], k0[VEC], kneg[VEC], kpos[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) chargers[i] = wms[i] = k0[i] = kneg[i] = kpos[i] = 0.0f;
-    for (int c = c0; c < c0 + nc; ++c) {
-        const uint32_t* __restrict__ cp = f.charger_params + (long long)c * CL_NCP;
-        const float* __restrict__ cr = f.charger_ts + ((long long)row * f.n_charger + c) * CL_NCF;
-        const int k = (int)cr[CLCT_EV];
-        const int col = (int)cp[CLC_ACT_COL];
+#pragma unroll
+    for (int j = 0; j < CL_MAXC; ++j) {
+        if (hdr[j] == CLCT_EMPTY) continue;
+        const int c = u * CL_MAXC + j;
+        const uint32_t* __restrict__ cp = cp0 + j * CL_NCP;
+        const float* __restrict__ cr = cr0 + j * CL_NCF;
+        const int k = (int)hdr[j];
         const float eff = cl::pw(cp, CLC_EFF), inv_eff = cl::pw(cp, CLC_INV_EFF), dt = cl::pw(cp, CLC_DT_HOURS);
         const float max_c = cl::pw(cp, CLC_MAX_CHARGE), min_c = cl::pw(cp, CLC_MIN_CHARGE);
         const float max_d = cl::pw(cp, CLC_MAX_DISCHARGE), min_d = cl::pw(cp, CLC_MIN_DISCHARGE);
-        if (!live) continue;
-        float act[VEC], energy[VEC], cons[VEC];
-        if (col >= 0 && coalesced) vload<VEC>(act, a.actions + (long long)col * a.act_stride_col + env0);
-        else {
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) act[i] = flex_action(a, col, env0 + i);
-        }
+        float energy[VEC], cons[VEC];
         // electric_vehicle_charger.py:306-322: requested energy, clamped to the charger's power range
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            energy[i] = act[i] > 0.0f ? fmaxf(fminf(act[i] * max_c * dt, max_c), min_c)
-                      : act[i] < 0.0f ? fmaxf(fminf(act[i] * max_d * dt, -min_d), -max_d) : 0.0f;
+            energy[i] = act[j][i] > 0.0f ? fmaxf(fminf(act[j][i] * max_c * dt, max_c), min_c)
+                      : act[j][i] < 0.0f ? fmaxf(fminf(act[j][i] * max_d * dt, -min_d), -max_d) : 0.0f;
             cons[i] = 0.0f;
         }
         if (k >= 0) {
             const uint32_t* __restrict__ ep = f.ev_params + (long long)k * CL_NP;
-            const float* __restrict__ er = f.ev_ts + ((long long)row * f.n_ev + k) * CL_NEVF;
+            const float* __restrict__ er = cr + CLCT_RULE_STEP - CLEV_RULE_STEP;      // the EV's rules, copied into the charger row
             float* sp = f.ev_state + (long long)k * a.n_env + env0;
-            float soc[VEC], ef[VEC], deg[VEC];
-            vload<VEC>(soc, sp); vload<VEC>(ef, sp + ev_plane); vload<VEC>(deg, sp + 2 * ev_plane);
             cl::BattP P;
             cl::load_batt(P, ep);
             const float cap = P.cap, min_cap = P.omd * cap, soc0 = cl::pw(ep, CLP_L_SOC0);
@@ -124,18 +156,18 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
             bool charged = false;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                const float prev = soc[i];                          // soc[t - 1]; at t = 0 soc[0] itself (energy_model.py:661-666)
+                const float prev = soc[j][i];                       // soc[t - 1]; at t = 0 soc[0] itself (energy_model.py:661-666)
                 float now = a.t == 0 ? prev : flex_begin_soc(a, er, row, k, env0 + i, prev);
-                if (act[i] != 0.0f) {
+                if (act[j][i] != 0.0f) {
                     cl::State S;
-                    S.soc = prev; S.eff = ef[i]; S.degcap = deg[i]; S.cs = S.hs = S.ds = 0.0f;
-                    const float to_battery = energy[i] * (act[i] > 0.0f ? eff : inv_eff);
+                    S.soc = prev; S.eff = ef[j][i]; S.degcap = deg[j][i]; S.cs = S.hs = S.ds = 0.0f;
+                    const float to_battery = energy[i] * (act[j][i] > 0.0f ? eff : inv_eff);
                     const float eb = cl::battery_energy(P, to_battery * P.r, S);      // Battery.charge (energy_model.py:1027-1057)
-                    now = S.soc; ef[i] = S.eff; deg[i] = S.degcap;
+                    now = S.soc; ef[j][i] = S.eff; deg[j][i] = S.degcap;
                     cons[i] = eb >= 0.0f ? eb * inv_eff : eb * eff;                     // electric_vehicle_charger.py:329
                     charged = true;
                 }
-                soc[i] = now;
+                soc[j][i] = now;
                 if (a.want_reward) {
                     // Electric_Vehicles_Reward_Function.calculate_ev_penalty, everything but the 1/(1+|MARL|) factor and the
                     // sign of the building net (reward_function.py:466-529)
@@ -154,40 +186,32 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
                     else if (energy[i] < 0.0f) { kneg[i] += -0.5f * f.weights[CLEW_EXTRA_SELF_PRODUCTION]; kpos[i] += f.weights[CLEW_SELF_EV_CONSUMPTION]; }
                 }
             }
-            vstore<VEC>(sp, soc);
-            if (charged) { vstore<VEC>(sp + ev_plane, ef); vstore<VEC>(sp + 2 * ev_plane, deg); }
+            vstore<VEC>(sp, soc[j]);
+            if (charged) { vstore<VEC>(sp + ev_plane, ef[j]); vstore<VEC>(sp + 2 * ev_plane, deg[j]); }
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) chargers[i] += cons[i];
         if (f.charger_out) {
             vstore<VEC>(f.charger_out + (long long)c * a.n_env + env0, cons);
-            vstore<VEC>(f.charger_out + ((long long)f.n_charger + c) * a.n_env + env0, energy);
+            vstore<VEC>(f.charger_out + ((long long)f.n_flex_bldg * CL_MAXC + c) * a.n_env + env0, energy);
         }
     }
-    for (int w = w0; w < w0 + nwm; ++w) {
-        const float* __restrict__ wr = f.wm_ts + ((long long)row * f.n_wm + w) * CL_NWF;
-        const int col = (int)f.wm_params[(long long)w * CL_NWP];
-        const bool new_window = a.t > 0 && wr[CLWT_NEW_WINDOW] != 0.0f, open = wr[CLWT_OPEN] != 0.0f;
-        const float load = wr[CLWT_LOAD];
-        if (!live) continue;
-        float* st = f.wm_state + (long long)w * a.n_env + env0;
-        float init[VEC], act[VEC];
-        vload<VEC>(init, st);
-        if (col >= 0 && coalesced) vload<VEC>(act, a.actions + (long long)col * a.act_stride_col + env0);
-        else {
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) act[i] = flex_action(a, col, env0 + i);
-        }
+    for (int j = 0; j < CL_MAXW; ++j) {
+        if (whdr[j] == CLWT_EMPTY) continue;
+        const float* __restrict__ wr = wr0 + j * CL_NWF;
+        const bool new_window = a.t > 0 && wr[CLWT_NEW_WINDOW] != 0.0f, open = whdr[j] != 0.0f;
+        const float load = wr[CLWT_LOAD];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            bool initiated = init[i] != 0.0f && !new_window;                  // energy_model.py:1303-1312
-            if (!initiated && act[i] > 0.0f && open) {                         // energy_model.py:1320-1330
+            bool initiated = winit[j][i] != 0.0f && !new_window;              // energy_model.py:1303-1312
+            if (!initiated && wact[j][i] > 0.0f && open) {                     // energy_model.py:1320-1330
                 initiated = true;
                 wms[i] += load;
             }
-            init[i] = initiated ? 1.0f : 0.0f;
+            winit[j][i] = initiated ? 1.0f : 0.0f;
         }
-        vstore<VEC>(st, init);
+        vstore<VEC>(f.wm_state + (long long)(u * CL_MAXW + j) * a.n_env + env0, winit[j]);
     }
     if (!live) return;
     const long long fp = (long long)f.n_flex_bldg * a.n_env, o = (long long)u * a.n_env + env0;
@@ -205,7 +229,7 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
 
 __global__ void cl_flex_reset_kernel(const cl_flex f, const int32_t* __restrict__ env_row0, int n_env) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long n_ev_cells = (long long)f.n_ev * n_env, n_wm_cells = (long long)f.n_wm * n_env;
+    const long long n_ev_cells = (long long)f.n_ev * n_env, n_wm_cells = (long long)f.n_flex_bldg * CL_MAXW * n_env;
     if (i < n_ev_cells) {
         const int k = (int)(i / n_env), env = (int)(i - (long long)k * n_env);
         const int row = env_row0 ? env_row0[env / CL_ROW0_BLOCK] : 0;

@@ -711,21 +711,19 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
 }
 
 static int check_flex(const cl_dims* dims, const cl_flex* f) {
-    if (f->n_ev < 0 || f->n_charger < 0 || f->n_wm < 0 || f->n_flex_bldg <= 0)
-        return fail(CL_EINVAL, "cl_flex: bad counts (ev %d, chargers %d, washing machines %d, buildings %d)", f->n_ev, f->n_charger,
-                    f->n_wm, f->n_flex_bldg);
+    if (f->n_ev < 0 || f->n_flex_bldg <= 0)
+        return fail(CL_EINVAL, "cl_flex: bad counts (ev %d, buildings %d)", f->n_ev, f->n_flex_bldg);
     const int rows = dims->n_ts_rows ? dims->n_ts_rows : dims->n_steps;
     if (f->n_rows < rows) return fail(CL_ERANGE, "cl_flex.n_rows=%d but the step tables have %d rows", f->n_rows, rows);
-    if (int rc = check_ptr(f->flex_bldg, "flex.flex_bldg")) return rc;
     if (int rc = check_ptr(f->flex_out, "flex.flex_out")) return rc;
     if (int rc = check_ptr(f->ev_params, "flex.ev_params", f->n_ev > 0)) return rc;
     if (int rc = check_ptr(f->ev_ts, "flex.ev_ts", f->n_ev > 0)) return rc;
     if (int rc = check_ptr(f->ev_state, "flex.ev_state", f->n_ev > 0)) return rc;
-    if (int rc = check_ptr(f->charger_params, "flex.charger_params", f->n_charger > 0)) return rc;
-    if (int rc = check_ptr(f->charger_ts, "flex.charger_ts", f->n_charger > 0)) return rc;
-    if (int rc = check_ptr(f->wm_params, "flex.wm_params", f->n_wm > 0)) return rc;
-    if (int rc = check_ptr(f->wm_ts, "flex.wm_ts", f->n_wm > 0)) return rc;
-    if (int rc = check_ptr(f->wm_state, "flex.wm_state", f->n_wm > 0)) return rc;
+    if (int rc = check_ptr(f->charger_params, "flex.charger_params")) return rc;
+    if (int rc = check_ptr(f->charger_ts, "flex.charger_ts")) return rc;
+    if (int rc = check_ptr(f->wm_params, "flex.wm_params")) return rc;
+    if (int rc = check_ptr(f->wm_ts, "flex.wm_ts")) return rc;
+    if (int rc = check_ptr(f->wm_state, "flex.wm_state")) return rc;
     return CL_OK;
 }
 
@@ -733,7 +731,8 @@ int cl_flex_reset_f32(const cl_dims* dims, const cl_flex* flex, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     if (!flex) return fail(CL_ENULL, "flex is NULL");
     if (int rc = check_flex(dims, flex)) return rc;
-    const long long n = (long long)dims->n_env * (flex->n_ev > flex->n_wm ? flex->n_ev : flex->n_wm);
+    const int wm_slots = flex->n_flex_bldg * CL_MAXW;
+    const long long n = (long long)dims->n_env * (flex->n_ev > wm_slots ? flex->n_ev : wm_slots);
     if (n > 0) {
         hipLaunchKernelGGL(cl_flex_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *flex,
                            dims->env_row0, dims->n_env);

@@ -38,7 +38,8 @@ class StepEngine:
 
     def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
                  t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False,
-                 n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0):
+                 n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0,
+                 charger_detail: bool = False):
         """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
         simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
         at table row ``env_row0[g]`` -- different blocks replay different windows at once.
@@ -46,7 +47,8 @@ class StepEngine:
         Districts with EV chargers / washing machines (``tables.flex``): ``ev_reward_weights`` are the `weights` of
         Electric_Vehicles_Reward_Function, ``ev_seed`` keys the on-device N(1, 0.2) stream of the unconnected-EV SoC
         drift (citylearn.py:1468-1472) and ``ev_drift`` ([table rows, n_ev], optional) replays given multipliers instead
-        (what the parity tests do: the reference draws them from the unseeded global ``np.random``)."""
+        (what the parity tests do: the reference draws them from the unseeded global ``np.random``); ``charger_detail``
+        also keeps every charger's electricity consumption and requested energy of the step (``charger_out``)."""
         self.lib = _lib.load()                      # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
@@ -103,24 +105,26 @@ class StepEngine:
             self.kpi_env = torch.zeros((abi.CL_NKE, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
             self.flex = None
             if self.flex_tables is not None:
-                self._init_flex(ev_reward_weights, ev_drift, ev_seed)
+                self._init_flex(ev_reward_weights, ev_drift, ev_seed, charger_detail)
         self.t = 0
         self.reset()
 
-    def _init_flex(self, weights, drift, seed: int):
+    def _init_flex(self, weights, drift, seed: int, charger_detail: bool):
         """Device copies of the flexible-load tables + their state planes (`cl_flex`, include/citylearn_amd.h)."""
         from .flex import reward_weights
         ft = self.flex_tables
         if ft.n_rows < self.n_ts_rows:
             raise ValueError('flexible-load tables are shorter than the step tables')
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
-        n_ev, n_c, n_w, n_fb = len(ft.ev_names), len(ft.charger_ids), len(ft.wm_names), ft.flex_bldg.shape[0]
+        n_ev, n_fb = len(ft.ev_names), ft.flex_bldg.shape[0]
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=self.device)
         self._flex_buffers = dict(
             ev_params=dev(ft.ev_params.view(np.int32)), ev_ts=dev(ft.ev_ts), charger_params=dev(ft.charger_params.view(np.int32)),
-            charger_ts=dev(ft.charger_ts), wm_params=dev(ft.wm_params.view(np.int32)), wm_ts=dev(ft.wm_ts), flex_bldg=dev(ft.flex_bldg),
-            ev_state=z(abi.CL_NEVS, max(n_ev, 1), self.n_env), wm_state=z(max(n_w, 1), self.n_env),
-            flex_out=z(abi.CL_NX, n_fb, self.n_env), charger_out=z(2, max(n_c, 1), self.n_env))
+            charger_ts=dev(ft.charger_ts), wm_params=dev(ft.wm_params.view(np.int32)), wm_ts=dev(ft.wm_ts),
+            ev_state=z(abi.CL_NEVS, max(n_ev, 1), self.n_env), wm_state=z(n_fb * abi.CL_MAXW, self.n_env),
+            flex_out=z(abi.CL_NX, n_fb, self.n_env),
+            charger_out=z(2, n_fb * abi.CL_MAXC, self.n_env) if charger_detail else None)
+        self._charger_slot = torch.from_numpy(ft.charger_slot.astype(np.int64)).to(self.device)
         self.ev_drift = None
         if drift is not None:
             drift = np.asarray(drift, dtype=np.float32)
@@ -129,12 +133,21 @@ class StepEngine:
             self.ev_drift = dev(drift)
         b = self._flex_buffers
         self.flex = _lib.Flex(
-            n_ev, n_c, n_w, n_fb, ft.n_rows, 0, _ptr(b['ev_params']), _ptr(b['ev_ts']), _ptr(b['charger_params']),
-            _ptr(b['charger_ts']), _ptr(b['wm_params']), _ptr(b['wm_ts']), _ptr(b['flex_bldg']), _ptr(b['ev_state']),
+            n_ev, n_fb, ft.n_rows, 0, _ptr(b['ev_params']), _ptr(b['ev_ts']), _ptr(b['charger_params']),
+            _ptr(b['charger_ts']), _ptr(b['wm_params']), _ptr(b['wm_ts']), _ptr(b['ev_state']),
             _ptr(b['wm_state']), _ptr(b['flex_out']), _ptr(b['charger_out']), _ptr(self.ev_drift), int(seed) & (2 ** 64 - 1),
             (ctypes.c_float * 8)(*reward_weights(weights).tolist()))
         self.ev_state, self.wm_state = b['ev_state'], b['wm_state']
-        self.flex_out, self.charger_out = b['flex_out'], b['charger_out']
+        self.flex_out = b['flex_out']
+
+    @property
+    def charger_out(self) -> torch.Tensor:
+        """``[2, n_charger, n_env]``: electricity consumption and requested energy of every charger at the last step
+        (chargers in building order; construct with ``charger_detail=True``)."""
+        raw = self._flex_buffers['charger_out']
+        if raw is None:
+            raise RuntimeError('construct StepEngine(..., charger_detail=True) to keep per-charger outputs')
+        return raw[:, self._charger_slot]
 
     # ---------------------------------------------------------------------------------------------------
     def _stream(self) -> int:

@@ -36,18 +36,25 @@ class FlexTables:
     wm_names: List[Tuple[int, str]]
     ev_params: np.ndarray                       # uint32 [n_ev, CL_NP]
     ev_ts: np.ndarray                           # float32 [R, n_ev, CL_NEVF]
-    charger_params: np.ndarray                  # uint32 [n_charger, CL_NCP]
-    charger_ts: np.ndarray                      # float32 [R, n_charger, CL_NCF]
-    wm_params: np.ndarray                       # uint32 [n_wm, CL_NWP]
-    wm_ts: np.ndarray                           # float32 [R, n_wm, CL_NWF]
-    flex_bldg: np.ndarray                       # int32 [n_flex_bldg, CL_NFB]
+    charger_params: np.ndarray                  # uint32 [n_flex_bldg, CL_MAXC, CL_NCP]   (slot tables, see the header)
+    charger_ts: np.ndarray                      # float32 [R, n_flex_bldg, CL_MAXC, CL_NCF]
+    wm_params: np.ndarray                       # uint32 [n_flex_bldg, CL_MAXW, CL_NWP]
+    wm_ts: np.ndarray                           # float32 [R, n_flex_bldg, CL_MAXW, CL_NWF]
+    flex_bldg: np.ndarray                       # int32 [n_flex_bldg]: building index of every row of the flexible-load planes
+    charger_slot: np.ndarray                    # int32 [n_charger]: flex row * CL_MAXC + slot of charger j (index into charger_out / the tables)
+    wm_slot: np.ndarray                         # int32 [n_wm]
     n_act_cols: int
     observations: Dict[str, np.ndarray] = field(default_factory=dict)   # name -> [R] values after a step; see `reset_observations`
     reset_observations: Dict[str, np.ndarray] = field(default_factory=dict)   # name -> [R] values when the episode starts on that row
 
     @property
     def n_rows(self) -> int:
-        return self.ev_ts.shape[0] if self.ev_ts.shape[1] else max(self.charger_ts.shape[0], self.wm_ts.shape[0])
+        return self.charger_ts.shape[0]
+
+    def charger_row(self, j: int) -> np.ndarray:
+        """[R, CL_NCF] schedule rows of charger j."""
+        fb, slot = divmod(int(self.charger_slot[j]), abi.CL_MAXC)
+        return self.charger_ts[:, fb, slot]
 
 
 def _battery_block(battery, r: float) -> np.ndarray:
@@ -126,11 +133,25 @@ def pack_flex(spec, start: int, n_rows: int, aligned: bool = False) -> Optional[
     ev_ts[:, :, abi.CLEV_RULE_STEP] = RULE_ZERO
     ev_ts[:, :, abi.CLEV_RULE_LAST] = RULE_ZERO
     ev_ts[:, :, abi.CLEV_RULE_RESET] = RULE_KEEP
-    charger_params = np.zeros((n_c, abi.CL_NCP), dtype=np.uint32)
+    flex_b = [i for i, b in enumerate(spec.buildings) if b.chargers or b.washing_machines]
+    n_fb = len(flex_b)
+    for i in flex_b:
+        b = spec.buildings[i]
+        if len(b.chargers) > abi.CL_MAXC or len(b.washing_machines) > abi.CL_MAXW:
+            raise NotImplementedError(f'{b.name}: at most {abi.CL_MAXC} chargers and {abi.CL_MAXW} washing machines per building '
+                                      f'(got {len(b.chargers)} / {len(b.washing_machines)})')
+    charger_slot = np.array([flex_b.index(i) * abi.CL_MAXC + [id(x) for x in spec.buildings[i].chargers].index(id(c))
+                             for i, c in chargers], dtype=np.int32)
+    wm_slot = np.array([flex_b.index(i) * abi.CL_MAXW + [id(x) for x in spec.buildings[i].washing_machines].index(id(w))
+                        for i, w in wms], dtype=np.int32)
+    charger_params = np.zeros((n_fb * abi.CL_MAXC, abi.CL_NCP), dtype=np.uint32)
+    charger_params.view(np.int32)[:, abi.CLC_ACT_COL] = -1
+    charger_ts = np.zeros((R, n_fb * abi.CL_MAXC, abi.CL_NCF), dtype=np.float32)
+    charger_ts[:, :, abi.CLCT_EV] = -2.0                       # CLCT_EMPTY
+    charger_ts[:, charger_slot, abi.CLCT_EV] = -1.0
     cpf, cpi = charger_params.view(np.float32), charger_params.view(np.int32)
-    charger_ts = np.zeros((R, n_c, abi.CL_NCF), dtype=np.float32)
-    charger_ts[:, :, abi.CLCT_EV] = -1.0
-    for j, (i, c) in enumerate(chargers):
+    for jj, (i, c) in enumerate(chargers):
+        j = int(charger_slot[jj])
         cpi[j, abi.CLC_ACT_COL] = col_of.get((i, c.action_name), -1)
         cpf[j, abi.CLC_MAX_CHARGE], cpf[j, abi.CLC_MIN_CHARGE] = c.max_charging_power, c.min_charging_power
         cpf[j, abi.CLC_MAX_DISCHARGE], cpf[j, abi.CLC_MIN_DISCHARGE] = c.max_discharging_power, c.min_discharging_power
@@ -175,7 +196,7 @@ def pack_flex(spec, start: int, n_rows: int, aligned: bool = False) -> Optional[
                 if holder[rho, k] >= 0:
                     raise NotImplementedError(f'{name} is plugged into two chargers on schedule row {first + rho}')
                 holder[rho, k] = j
-                charger_ts[rho, j, abi.CLCT_EV] = k
+                charger_ts[rho, charger_slot[j], abi.CLCT_EV] = k
                 prev_state = sim['electric_vehicle_charger_state'][rho - 1] if rho > 0 else np.nan
                 prev_id = sim['electric_vehicle_id'][rho - 1] if rho > 0 else None
                 if prev_state != 1 or not isinstance(prev_id, str) or prev_id != ev_id:
@@ -188,10 +209,16 @@ def pack_flex(spec, start: int, n_rows: int, aligned: bool = False) -> Optional[
             if rho + 1 >= R:
                 step_rule = last_rule
             ev_ts[rho, k] = (step_rule, last_rule, reset_rule, 1.0 if holder[rho, k] >= 0 else 0.0)
+            if holder[rho, k] >= 0:            # the charger row carries its EV's rules: no dependent table read on the device
+                charger_ts[rho, charger_slot[holder[rho, k]], abi.CLCT_RULE_STEP] = step_rule
+                charger_ts[rho, charger_slot[holder[rho, k]], abi.CLCT_RULE_LAST] = last_rule
 
-    wm_params = np.zeros((n_w, abi.CL_NWP), dtype=np.uint32)
-    wm_ts = np.zeros((R, n_w, abi.CL_NWF), dtype=np.float32)
-    for j, (i, w) in enumerate(wms):
+    wm_params = np.zeros((n_fb * abi.CL_MAXW, abi.CL_NWP), dtype=np.uint32)
+    wm_params.view(np.int32)[:, 0] = -1
+    wm_ts = np.zeros((R, n_fb * abi.CL_MAXW, abi.CL_NWF), dtype=np.float32)
+    wm_ts[:, :, abi.CLWT_OPEN] = -1.0                          # CLWT_EMPTY
+    for jj, (i, w) in enumerate(wms):
+        j = int(wm_slot[jj])
         wm_params.view(np.int32)[j, 0] = col_of.get((i, w.name), -1)
         s = w.series['wm_start_time_step'][first:first + R]
         e = w.series['wm_end_time_step'][first:first + R]
@@ -203,19 +230,12 @@ def pack_flex(spec, start: int, n_rows: int, aligned: bool = False) -> Optional[
             wm_ts[rho, j, abi.CLWT_NEW_WINDOW] = float(rho > 0 and (s[rho - 1] != s[rho] or e[rho - 1] != e[rho]))
             wm_ts[rho, j, abi.CLWT_LOAD] = float(np.float32(sum(np.float32(v) for o, v in enumerate(profiles[rho]) if rho + o < R))) if has else 0.0
 
-    fb_rows = []
-    c_first = w_first = 0
-    for i, b in enumerate(spec.buildings):
-        nc, nwm = len(b.chargers), len(b.washing_machines)
-        if nc or nwm:
-            fb_rows.append([i, c_first, nc, w_first, nwm, 0, 0, 0])
-        c_first += nc
-        w_first += nwm
-    flex_bldg = np.array(fb_rows, dtype=np.int32).reshape(-1, abi.CL_NFB)
-
     out = FlexTables(ev_names=names, charger_ids=[(i, c.charger_id) for i, c in chargers], wm_names=[(i, w.name) for i, w in wms],
-                     ev_params=ev_params, ev_ts=ev_ts, charger_params=charger_params, charger_ts=charger_ts,
-                     wm_params=wm_params, wm_ts=wm_ts, flex_bldg=flex_bldg, n_act_cols=col)
+                     ev_params=ev_params, ev_ts=ev_ts,
+                     charger_params=charger_params.reshape(n_fb, abi.CL_MAXC, abi.CL_NCP),
+                     charger_ts=charger_ts.reshape(R, n_fb, abi.CL_MAXC, abi.CL_NCF),
+                     wm_params=wm_params.reshape(n_fb, abi.CL_MAXW, abi.CL_NWP), wm_ts=wm_ts.reshape(R, n_fb, abi.CL_MAXW, abi.CL_NWF),
+                     flex_bldg=np.array(flex_b, dtype=np.int32), charger_slot=charger_slot, wm_slot=wm_slot, n_act_cols=col)
     _pack_observations(out, spec, sims, chargers, wms, first, R)
     return out
 
@@ -228,7 +248,7 @@ def _pack_observations(tab: FlexTables, spec, sims, chargers, wms, first: int, R
         for j, (i, c) in enumerate(chargers):
             sim, cid = sims[j], c.charger_id
             state = sim['electric_vehicle_charger_state']
-            ev = tab.charger_ts[:, j, abi.CLCT_EV].astype(int)
+            ev = tab.charger_row(j)[:, abi.CLCT_EV].astype(int)
             connected = (state == 1) & (ev >= 0)
             incoming_ids = np.array([isinstance(v, str) and v in tab.ev_names for v in sim['electric_vehicle_id']])
             incoming = (state == 2) & incoming_ids

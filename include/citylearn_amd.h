@@ -345,15 +345,16 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
  *
  *   ev_params      [n_ev][CL_NP]                 battery block of an EV: the CLP_L_* words of a `params` row
  *   ev_ts          [n_rows][n_ev][CL_NEVF]       begin-of-step SoC rule of (row, EV)            (cl_ev_feat)
- *   charger_params [n_charger][CL_NCP]           (cl_charger_param)
- *   charger_ts     [n_rows][n_charger][CL_NCF]   (cl_charger_feat)
- *   wm_params      [n_wm][CL_NWP]                word 0: action column (i32, -1 = inactive)
- *   wm_ts          [n_rows][n_wm][CL_NWF]        (cl_wm_feat)
- *   flex_bldg      [n_flex_bldg][CL_NFB] i32     building, first charger, chargers, first washing machine, washing machines
+ *   charger_params [n_flex_bldg][CL_MAXC][CL_NCP]           (cl_charger_param) one slot per charger of the building
+ *   charger_ts     [n_rows][n_flex_bldg][CL_MAXC][CL_NCF]   (cl_charger_feat)
+ *   wm_params      [n_flex_bldg][CL_MAXW][CL_NWP]           word 0: action column (i32, -1 = inactive)
+ *   wm_ts          [n_rows][n_flex_bldg][CL_MAXW][CL_NWF]   (cl_wm_feat)
+ * (slot tables: every address a wave needs depends only on its building and row, so the table reads of a step are ONE
+ *  round of independent scalar loads -- a first/count indirection per building cost two more dependent round trips)
  *   ev_state       [CL_NEVS][n_ev][n_env]        soc written last, Battery.efficiency, degraded capacity (same meaning as CLS_B_*)
- *   wm_state       [n_wm][n_env]                 WashingMachine.initiated (0 / 1)
+ *   wm_state       [n_flex_bldg * CL_MAXW][n_env]  WashingMachine.initiated (0 / 1), by slot
  *   flex_out       [CL_NX][n_flex_bldg][n_env]   per-building results consumed by the step kernel (cl_flex_out)
- *   charger_out    [2][n_charger][n_env]         optional detail: charger electricity_consumption[t], past_charging_action_values_kwh[t]
+ *   charger_out    [2][n_flex_bldg * CL_MAXC][n_env]  optional detail by slot: charger electricity_consumption[t], past_charging_action_values_kwh[t]
  *   drift          [n_rows][n_ev]                optional: multipliers of the unconnected-EV SoC drift (citylearn.py:1468-1472) to
  *                                                replay; NULL draws N(1, 0.2) per (env, EV, t) from Philox4x32-10 keyed by `seed`
  * Rows: step t of env block g reads row t + env_row0[g] (row t without offsets), exactly like `ts`. */
@@ -374,20 +375,25 @@ enum cl_charger_param {
     CLC_EFF, CLC_INV_EFF, /* Charger.efficiency and its reciprocal */
     CLC_DT_HOURS          /* seconds_per_time_step / 3600 */
 };
-#define CL_NCF 4
+#define CL_MAXC 4           /* charger slots per building */
+#define CL_MAXW 2           /* washing-machine slots per building */
+#define CL_NCF 8
 enum cl_charger_feat {
-    CLCT_EV = 0,          /* index of the connected EV (state 1 and a known id) as a float, -1 = none */
+    CLCT_EV = 0,          /* index of the connected EV (state 1 and a known id) as a float, -1 = none, CLCT_EMPTY = no charger in this slot */
     CLCT_REQUIRED_SOC,    /* electric_vehicle_required_soc_departure */
-    CLCT_DEPARTURE        /* electric_vehicle_departure_time [steps] */
+    CLCT_DEPARTURE,       /* electric_vehicle_departure_time [steps] */
+    CLCT_RULE_STEP,       /* copies of the connected EV's CLEV_RULE_STEP / CLEV_RULE_LAST on this row */
+    CLCT_RULE_LAST
 };
+#define CLCT_EMPTY (-2.0f)
 #define CL_NWP 2
 #define CL_NWF 4
 enum cl_wm_feat {
-    CLWT_OPEN = 0,        /* 1 when start/end are set and start <= step <= end on this row */
+    CLWT_OPEN = 0,        /* 1 when start/end are set and start <= step <= end on this row; CLWT_EMPTY = no washing machine in this slot */
     CLWT_NEW_WINDOW,      /* 1 when (start, end) differ from the previous row: clears `initiated` (energy_model.py:1303-1312) */
     CLWT_LOAD             /* what start_cycle books on this row: the load profile summed over the offsets still inside the episode */
 };
-#define CL_NFB 8
+#define CLWT_EMPTY (-1.0f)
 #define CL_NEVS 3
 #define CL_NX 5
 enum cl_flex_out {
@@ -398,14 +404,13 @@ enum cl_flex_out {
 enum cl_ev_weight { CLEW_BATTERY_LIMITS = 0, CLEW_SOC_IMPOSSIBLE, CLEW_SOC_UNDER, CLEW_CLOSE_SOC, CLEW_SELF_EV_CONSUMPTION,
                     CLEW_EXTRA_SELF_PRODUCTION, CL_NEW };
 typedef struct cl_flex {
-    int32_t n_ev, n_charger, n_wm, n_flex_bldg, n_rows, reserved;
+    int32_t n_ev, n_flex_bldg, n_rows, reserved;
     const uint32_t* ev_params;
     const float* ev_ts;
     const uint32_t* charger_params;
     const float* charger_ts;
     const uint32_t* wm_params;
     const float* wm_ts;
-    const int32_t* flex_bldg;
     float* ev_state;
     float* wm_state;
     float* flex_out;

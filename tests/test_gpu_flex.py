@@ -31,13 +31,13 @@ def test_flex_step_matches_oracle_and_reference():
     tab = spec.episode_tables(0)
     drift = _drift(g, spec, tab)
     E = 8
-    eng = StepEngine(tab, E, reward='Electric_Vehicles_Reward_Function', detail=True, ev_drift=drift)
+    eng = StepEngine(tab, E, reward='Electric_Vehicles_Reward_Function', detail=True, ev_drift=drift, charger_detail=True)
     assert eng.flex is not None and eng.n_act_cols == g.ref['actions'].shape[1]
     o = FlexDistrictOracle(spec, tab, 1, reward='Electric_Vehicles_Reward_Function', drift=drift.astype(np.float64))
     o.reset()
     np.testing.assert_allclose(eng.ev_state[0, :, 0].cpu().numpy(), g.ref['ev_soc0'], rtol=1e-6)
     K = g.ref['actions'].shape[0]
-    flex_b = tab.flex.flex_bldg[:, 0]
+    flex_b = tab.flex.flex_bldg
     worst = {}
 
     def close(name, got, exp, rtol=2e-4, atol=2e-4):
