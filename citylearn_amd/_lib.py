@@ -43,6 +43,7 @@ class Flex(ctypes.Structure):
     _fields_ = [('n_ev', ctypes.c_int32), ('n_flex_bldg', ctypes.c_int32), ('n_rows', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('ev_params', ctypes.c_void_p), ('ev_ts', ctypes.c_void_p), ('charger_params', ctypes.c_void_p),
                 ('charger_ts', ctypes.c_void_p), ('wm_params', ctypes.c_void_p), ('wm_ts', ctypes.c_void_p),
+                ('cons_params', ctypes.c_void_p),
                 ('ev_state', ctypes.c_void_p), ('wm_state', ctypes.c_void_p),
                 ('flex_out', ctypes.c_void_p), ('charger_out', ctypes.c_void_p), ('drift', ctypes.c_void_p),
                 ('seed', ctypes.c_uint64), ('weights', ctypes.c_float * 8)]

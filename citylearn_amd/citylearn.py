@@ -220,6 +220,7 @@ class CityLearnEnv:
         self._engine = StepEngine(self._tables, 4, device=self.device, reward=names[kind] if fused else 'RewardFunction',
                                   t0_quirk=self.reference_quirks, detail=True, charger_detail=True,
                                   ev_reward_weights=getattr(self.reward_function, 'weights', None), ev_drift=self._ev_drift,
+                                  ev_penalty_coefficient=getattr(self.reward_function, 'charging_constraint_penalty_coefficient', 1.0),
                                   ev_seed=(self.random_seed if self._ev_seed is None else self._ev_seed) + self._episode)
         self._prev_ev_soc = None
         # adjacent LSTM indoor-temperature stage (LSTMDynamicsBuilding, building.py:3000-3078) with the fused ComfortReward
@@ -302,9 +303,10 @@ class CityLearnEnv:
     # ---- observations ----------------------------------------------------------------------------------------
     def _observation_vector(self) -> np.ndarray:
         """All agents' observations of the current time step, flat (columns of `ObservationLayout`)."""
-        if self._t == 0 or self.observation_mode == 'reference':
+        if self._t == 0 or (self.observation_mode == 'reference' and self._obs_tables.n_dependent == 0):
             return self._obs_tables.table[self._t]
-        return self._obs_tables.host_row(self._t, self._last_state, self._last_out, self._last_temps)
+        extra = None if self._engine.flex is None else self._engine.flex_out[:, :, 0].cpu().numpy()
+        return self._obs_tables.host_row(self._t, self._last_state, self._last_out, self._last_temps, extra)
 
     @property
     def observations(self) -> List[List[float]]:

@@ -123,6 +123,74 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
         }
     }
 
+    // ---- charging constraints (Building._apply_charging_constraints_to_actions, building.py:901-989): scale the positive
+    //      requests action * max_charging_power under the building limit, then under every phase limit in order ----
+    const uint32_t* __restrict__ cc = f.cons_params ? f.cons_params + (long long)u * CL_NCC : nullptr;
+    if (cc && (cc[CLCC_FLAGS] & 1u)) {
+        const float limit_b = cl::pw(cc, CLCC_BUILDING_LIMIT);
+        float limit_p[CL_MAXPH], maxc[CL_MAXC];
+        uint32_t mask_p[CL_MAXPH];
+#pragma unroll
+        for (int p = 0; p < CL_MAXPH; ++p) { limit_p[p] = cl::pw(cc, CLCC_PHASE_LIMIT0 + p); mask_p[p] = cc[CLCC_PHASE_MASK0 + p]; }
+#pragma unroll
+        for (int j = 0; j < CL_MAXC; ++j) maxc[j] = hdr[j] == CLCT_EMPTY ? 0.0f : cl::pw(cp0 + j * CL_NCP, CLC_MAX_CHARGE);
+        const float dt = cl::pw(cp0, CLC_DT_HOURS);
+        float viol[VEC], head_b[VEC], head_p[CL_MAXPH][VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float req[CL_MAXC], sc[CL_MAXC], total = 0.0f, v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CL_MAXC; ++j) {
+                const bool pos = hdr[j] != CLCT_EMPTY && act[j][i] > 0.0f && maxc[j] > 0.0f;
+                req[j] = pos ? act[j][i] * maxc[j] : 0.0f;
+                sc[j] = 1.0f;
+                total += req[j];
+            }
+            if (limit_b >= 0.0f && total > limit_b) {
+                const float s = limit_b == 0.0f ? 0.0f : limit_b / total;
+#pragma unroll
+                for (int j = 0; j < CL_MAXC; ++j) sc[j] *= s;
+                v += total - limit_b;
+            }
+#pragma unroll
+            for (int p = 0; p < CL_MAXPH; ++p) {
+                if (!(limit_p[p] >= 0.0f)) continue;
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CL_MAXC; ++j) sum += (mask_p[p] >> j & 1u) ? req[j] * sc[j] : 0.0f;
+                if (sum > limit_p[p]) {
+                    const float s = limit_p[p] == 0.0f ? 0.0f : limit_p[p] / sum;
+#pragma unroll
+                    for (int j = 0; j < CL_MAXC; ++j) sc[j] *= (mask_p[p] >> j & 1u) ? s : 1.0f;
+                    v += sum - limit_p[p];
+                }
+            }
+            float used = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CL_MAXC; ++j) {
+                const float scaled = req[j] * sc[j];
+                used += scaled;
+                if (hdr[j] != CLCT_EMPTY && act[j][i] > 0.0f)
+                    act[j][i] = maxc[j] > 0.0f ? fmaxf(0.0f, fminf(act[j][i], scaled / maxc[j])) : 0.0f;
+                req[j] = scaled;
+            }
+            viol[i] = v * dt;
+            head_b[i] = limit_b - used;
+#pragma unroll
+            for (int p = 0; p < CL_MAXPH; ++p) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CL_MAXC; ++j) sum += (mask_p[p] >> j & 1u) ? req[j] : 0.0f;
+                head_p[p][i] = limit_p[p] - sum;
+            }
+        }
+        const long long fpc = (long long)f.n_flex_bldg * a.n_env, oc = (long long)u * a.n_env + env0;
+        vstore<VEC>(f.flex_out + CLX_VIOLATION * fpc + oc, viol);
+        vstore<VEC>(f.flex_out + CLX_HEADROOM * fpc + oc, head_b);
+#pragma unroll
+        for (int p = 0; p < CL_MAXPH; ++p) vstore<VEC>(f.flex_out + (CLX_HEADROOM_PHASE0 + p) * fpc + oc, head_p[p]);
+    }
+
     float chargers[VEC], wms[VEC], k0[VEC], kneg[VEC], kpos[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) chargers[i] = wms[i] = k0[i] = kneg[i] = kpos[i] = 0.0f;

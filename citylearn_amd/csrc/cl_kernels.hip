@@ -42,6 +42,7 @@ struct StepArgs {
     const int32_t* __restrict__ env_row0;   // per-env-block episode offsets (cl_dims.env_row0) or null
     const float* __restrict__ flex_out;     // cl_flex.flex_out planes [CL_NX][n_flex_bldg][n_env] or null (cl_flex.h)
     int n_flex_bldg;
+    float ev_penalty_coef;                  // > 0: some building has charging constraints; CLR_EV subtracts coef * violation
     int n_env, n_bldg, n_steps, n_act_cols;
     uint32_t flags;
     int t;
@@ -164,6 +165,12 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
                     }
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) rw[i] = fbi >= 0 ? cl::ev_reward(true, rw[i], n[i], k0[i], kn[i], kp[i]) : 0.0f;
+                    if (fbi >= 0 && a.ev_penalty_coef > 0.0f) {            // reward_function.py:431-434
+                        float viol[VEC];
+                        vload<VEC>(viol, a.flex_out + CLX_VIOLATION * ((long long)a.n_flex_bldg * a.n_env) + (long long)fbi * a.n_env + env0);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) rw[i] -= viol[i] > 0.0f ? viol[i] * a.ev_penalty_coef : 0.0f;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) r_sum[i] += rw[i];
@@ -767,7 +774,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0;
-    a.flex_out = nullptr; a.n_flex_bldg = 0;
+    a.flex_out = nullptr; a.n_flex_bldg = 0; a.ev_penalty_coef = 0.0f;
     const int rkind_host = (dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     if (rkind_host == CLR_EV && !flex) return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_step_flex_f32)");
     if (flex) {
@@ -789,6 +796,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         default: hipLaunchKernelGGL(cl_flex_kernel<1>, fgrid, dim3(256), 0, (hipStream_t)stream, fa); break;
         }
         a.flex_out = flex->flex_out; a.n_flex_bldg = flex->n_flex_bldg;
+        a.ev_penalty_coef = flex->cons_params ? flex->weights[CLEW_PENALTY_COEFFICIENT] : 0.0f;
     }
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
     a.nw = g_force_nw ? g_force_nw : pick_nw(dims->n_bldg, 1);
@@ -1006,7 +1014,8 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
 }
 
 int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* col_src, const float* col_scale,
-                   const cl_obs_dep* deps, int32_t n_deps, const float* state, const float* out_bldg, const float* indoor_temp, float* obs, int32_t n_cols,
+                   const cl_obs_dep* deps, int32_t n_deps, const float* state, const float* out_bldg, const float* indoor_temp,
+                   const float* extra, int32_t n_extra_rows, float* obs, int32_t n_cols,
                    int32_t obs_pitch, int32_t n_rows, int32_t row, uint32_t flags, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     if (int rc = check_ptr(obs_table, "obs_table")) return rc;
@@ -1024,7 +1033,7 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
     }
     ObsArgs a;
     a.row = obs_table + (size_t)row * n_cols; a.col_src = col_src; a.col_scale = col_scale; a.state = state;
-    a.out_bldg = out_bldg; a.indoor_temp = indoor_temp; a.obs = obs;
+    a.out_bldg = out_bldg; a.indoor_temp = indoor_temp; a.obs = obs; a.extra = extra; a.n_extra_rows = n_extra_rows;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_cols = n_cols; a.all_exo = all_exo ? 1 : 0;
     a.env_row0 = dims->env_row0;
     const bool vec4 = obs_pitch % 4 == 0;            // 16-byte stores need 16-byte aligned rows

@@ -27,6 +27,8 @@ struct ObsArgs {
     const float* __restrict__ state;        // [CL_NS][B][E]
     const float* __restrict__ out_bldg;     // [CL_NO][B][E]
     const float* __restrict__ indoor_temp;  // [B][E] or null
+    const float* __restrict__ extra;        // [planes][n_extra_rows][E] or null (CLOB_KIND_EXTRA)
+    int n_extra_rows;
     float* __restrict__ obs;                // [E][pitch]
     int n_env, n_bldg, n_cols, pitch;
     int padded;                             // columns written per row: n_cols rounded up to 4, at most pitch
@@ -37,7 +39,8 @@ struct ObsArgs {
 CL_DEV const float* obs_plane(const ObsArgs& a, int s) {
     const int kind = s >> 28, plane = (s >> 20) & 0xFF, b = s & 0xFFFFF;
     const long long pl = (long long)a.n_env * a.n_bldg;
-    const float* base = kind == 0 ? a.state + plane * pl : kind == 1 ? a.out_bldg + plane * pl : a.indoor_temp;
+    const float* base = kind == 0 ? a.state + plane * pl : kind == 1 ? a.out_bldg + plane * pl
+                      : kind == 2 ? a.indoor_temp : a.extra + (long long)plane * a.n_extra_rows * a.n_env;
     return base + (long long)b * a.n_env;
 }
 

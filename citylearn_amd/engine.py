@@ -39,7 +39,7 @@ class StepEngine:
     def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
                  t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False,
                  n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0,
-                 charger_detail: bool = False):
+                 charger_detail: bool = False, ev_penalty_coefficient: float = 1.0):
         """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
         simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
         at table row ``env_row0[g]`` -- different blocks replay different windows at once.
@@ -105,11 +105,11 @@ class StepEngine:
             self.kpi_env = torch.zeros((abi.CL_NKE, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
             self.flex = None
             if self.flex_tables is not None:
-                self._init_flex(ev_reward_weights, ev_drift, ev_seed, charger_detail)
+                self._init_flex(ev_reward_weights, ev_drift, ev_seed, charger_detail, ev_penalty_coefficient)
         self.t = 0
         self.reset()
 
-    def _init_flex(self, weights, drift, seed: int, charger_detail: bool):
+    def _init_flex(self, weights, drift, seed: int, charger_detail: bool, penalty_coefficient: float):
         """Device copies of the flexible-load tables + their state planes (`cl_flex`, include/citylearn_amd.h)."""
         from .flex import reward_weights
         ft = self.flex_tables
@@ -121,6 +121,7 @@ class StepEngine:
         self._flex_buffers = dict(
             ev_params=dev(ft.ev_params.view(np.int32)), ev_ts=dev(ft.ev_ts), charger_params=dev(ft.charger_params.view(np.int32)),
             charger_ts=dev(ft.charger_ts), wm_params=dev(ft.wm_params.view(np.int32)), wm_ts=dev(ft.wm_ts),
+            cons_params=None if ft.cons_params is None else dev(ft.cons_params.view(np.int32)),
             ev_state=z(abi.CL_NEVS, max(n_ev, 1), self.n_env), wm_state=z(n_fb * abi.CL_MAXW, self.n_env),
             flex_out=z(abi.CL_NX, n_fb, self.n_env),
             charger_out=z(2, n_fb * abi.CL_MAXC, self.n_env) if charger_detail else None)
@@ -134,9 +135,9 @@ class StepEngine:
         b = self._flex_buffers
         self.flex = _lib.Flex(
             n_ev, n_fb, ft.n_rows, 0, _ptr(b['ev_params']), _ptr(b['ev_ts']), _ptr(b['charger_params']),
-            _ptr(b['charger_ts']), _ptr(b['wm_params']), _ptr(b['wm_ts']), _ptr(b['ev_state']),
+            _ptr(b['charger_ts']), _ptr(b['wm_params']), _ptr(b['wm_ts']), _ptr(b['cons_params']), _ptr(b['ev_state']),
             _ptr(b['wm_state']), _ptr(b['flex_out']), _ptr(b['charger_out']), _ptr(self.ev_drift), int(seed) & (2 ** 64 - 1),
-            (ctypes.c_float * 8)(*reward_weights(weights).tolist()))
+            (ctypes.c_float * 8)(*reward_weights(weights, penalty_coefficient).tolist()))
         self.ev_state, self.wm_state = b['ev_state'], b['wm_state']
         self.flex_out = b['flex_out']
 

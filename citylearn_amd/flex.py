@@ -41,6 +41,7 @@ class FlexTables:
     wm_params: np.ndarray                       # uint32 [n_flex_bldg, CL_MAXW, CL_NWP]
     wm_ts: np.ndarray                           # float32 [R, n_flex_bldg, CL_MAXW, CL_NWF]
     flex_bldg: np.ndarray                       # int32 [n_flex_bldg]: building index of every row of the flexible-load planes
+    cons_params: Optional[np.ndarray]           # uint32 [n_flex_bldg, CL_NCC] charging constraints, None when no building has any
     charger_slot: np.ndarray                    # int32 [n_charger]: flex row * CL_MAXC + slot of charger j (index into charger_out / the tables)
     wm_slot: np.ndarray                         # int32 [n_wm]
     n_act_cols: int
@@ -230,12 +231,29 @@ def pack_flex(spec, start: int, n_rows: int, aligned: bool = False) -> Optional[
             wm_ts[rho, j, abi.CLWT_NEW_WINDOW] = float(rho > 0 and (s[rho - 1] != s[rho] or e[rho - 1] != e[rho]))
             wm_ts[rho, j, abi.CLWT_LOAD] = float(np.float32(sum(np.float32(v) for o, v in enumerate(profiles[rho]) if rho + o < R))) if has else 0.0
 
+    cons_params = None
+    if any(spec.buildings[i].charging_constraints is not None for i in flex_b):
+        cons_params = np.zeros((n_fb, abi.CL_NCC), dtype=np.uint32)
+        cf = cons_params.view(np.float32)
+        cf[:, abi.CLCC_BUILDING_LIMIT:abi.CLCC_PHASE_LIMIT0 + abi.CL_MAXPH] = -1.0
+        for fb, i in enumerate(flex_b):
+            b = spec.buildings[i]
+            cc = b.charging_constraints
+            if cc is None:
+                continue
+            ids = [c.charger_id for c in b.chargers]
+            cons_params[fb, abi.CLCC_FLAGS] = 1
+            cf[fb, abi.CLCC_BUILDING_LIMIT] = -1.0 if cc.building_limit_kw is None else cc.building_limit_kw
+            for p_, ph in enumerate(cc.phases):
+                cf[fb, abi.CLCC_PHASE_LIMIT0 + p_] = -1.0 if ph['limit_kw'] is None else ph['limit_kw']
+                cons_params[fb, abi.CLCC_PHASE_MASK0 + p_] = sum(1 << ids.index(cid) for cid in ph['chargers'] if cid in ids)
+
     out = FlexTables(ev_names=names, charger_ids=[(i, c.charger_id) for i, c in chargers], wm_names=[(i, w.name) for i, w in wms],
                      ev_params=ev_params, ev_ts=ev_ts,
                      charger_params=charger_params.reshape(n_fb, abi.CL_MAXC, abi.CL_NCP),
                      charger_ts=charger_ts.reshape(R, n_fb, abi.CL_MAXC, abi.CL_NCF),
                      wm_params=wm_params.reshape(n_fb, abi.CL_MAXW, abi.CL_NWP), wm_ts=wm_ts.reshape(R, n_fb, abi.CL_MAXW, abi.CL_NWF),
-                     flex_bldg=np.array(flex_b, dtype=np.int32), charger_slot=charger_slot, wm_slot=wm_slot, n_act_cols=col)
+                     flex_bldg=np.array(flex_b, dtype=np.int32), cons_params=cons_params, charger_slot=charger_slot, wm_slot=wm_slot, n_act_cols=col)
     _pack_observations(out, spec, sims, chargers, wms, first, R)
     return out
 
@@ -271,7 +289,7 @@ def _pack_observations(tab: FlexTables, spec, sims, chargers, wms, first: int, R
             dst[f'{w.name}_end_time_step'] = w.series['wm_end_time_step'][first:first + R].astype(float)
 
 
-def reward_weights(weights=None) -> np.ndarray:
+def reward_weights(weights=None, penalty_coefficient: float = 1.0) -> np.ndarray:
     """`cl_flex.weights` from the `weights` mapping of Electric_Vehicles_Reward_Function (reward_function.py:396-407)."""
     w = dict(DEFAULT_EV_REWARD_WEIGHTS if not weights else weights)
     out = np.zeros(8, dtype=np.float32)
@@ -281,4 +299,5 @@ def reward_weights(weights=None) -> np.ndarray:
     out[abi.CLEW_CLOSE_SOC] = w['close_soc']
     out[abi.CLEW_SELF_EV_CONSUMPTION] = w['self_ev_consumption']
     out[abi.CLEW_EXTRA_SELF_PRODUCTION] = w['extra_self_production']
+    out[abi.CLEW_PENALTY_COEFFICIENT] = 1.0 if penalty_coefficient is None else penalty_coefficient   # reward_function.py:49-58
     return out

@@ -41,7 +41,7 @@ OBSERVATION_SPACE_LIMIT_DELTA = 0.0       # building.py:1012
 DEMAND_OBSERVATION_LIMIT_FACTOR = 2.0     # building.py:1032 (the setter's default, not the docstring's)
 
 # kinds of device source (col_src = kind << 28 | plane << 20 | building)
-SRC_STATE, SRC_OUT, SRC_TEMP = 0, 1, 2
+SRC_STATE, SRC_OUT, SRC_TEMP, SRC_EXTRA = 0, 1, 2, 3      # SRC_EXTRA: cl_flex.flex_out planes, row = flexible-load row of the building
 
 # env-dependent observation -> (kind, plane) for every building
 _DEVICE_SOURCE = {
@@ -71,7 +71,20 @@ def available_observations(b: BuildingSpec) -> set:
              'indoor_dry_bulb_temperature_cooling_set_point', 'indoor_dry_bulb_temperature_heating_set_point',
              'indoor_dry_bulb_temperature_cooling_delta', 'indoor_dry_bulb_temperature_heating_delta', 'comfort_band',
              'occupant_count', 'power_outage'}
-    return keys | set(flexible_load_observations(b))
+    return keys | set(flexible_load_observations(b)) | set(charging_constraint_observations(b))
+
+
+def charging_constraint_observations(b: BuildingSpec) -> Dict[str, float]:
+    """Observation -> value right after reset() of the charging-constraint observations (building.py:1462-1481):
+    headroom = the limit, violation = 0, phase one-hot = constant."""
+    cc = b.charging_constraints
+    if cc is None:
+        return {}
+    out = dict(cc.one_hot_keys([c.charger_id for c in b.chargers]))
+    out.update(dict(cc.headroom_keys()))
+    if cc.expose_violation:
+        out['charging_constraint_violation_kwh'] = 0.0
+    return out
 
 
 def flexible_load_observations(b: BuildingSpec) -> List[str]:
@@ -91,7 +104,17 @@ def flexible_load_observations(b: BuildingSpec) -> List[str]:
 
 
 def building_observation_names(b: BuildingSpec) -> List[str]:
-    """Active observations in schema order, restricted to what a building can report (building.py:1146-1153)."""
+    """Active observations in the order `Building.observations` returns them (building.py:1146-1158): the keys of
+    `_get_observations_data` in metadata order, then the charger and washing-machine keys the two update_* helpers append."""
+    available = available_observations(b)
+    appended = flexible_load_observations(b)
+    active = [k for k in b.active_observations if k in available]
+    return [k for k in active if k not in appended] + [k for k in appended if k in active]
+
+
+def building_space_names(b: BuildingSpec) -> List[str]:
+    """Order of `Building.observation_space` (`estimate_observation_space`, building.py:1836-1865): plain metadata order --
+    it differs from the order of the returned values when charging-constraint observations exist."""
     available = available_observations(b)
     return [k for k in b.active_observations if k in available]
 
@@ -127,8 +150,17 @@ def space_limits(spec: DistrictSpec, b: BuildingSpec, names: Sequence[str], peri
         return np.array(demand) / dev.efficiency
 
     flex_names = set(flexible_load_observations(b))
+    cc_names = charging_constraint_observations(b)
     for key in names:
-        if key in flex_names:
+        if key in cc_names:
+            # building.py:1908-1916, 2139-2156
+            if key.startswith('charging_phase_one_hot_'):
+                low[key], high[key] = 0.0, 1.0
+            elif key == 'charging_constraint_violation_kwh':
+                low[key], high[key] = 0.0, sum(c.max_charging_power or 0.0 for c in b.chargers) * (spec.seconds_per_time_step / 3600)
+            else:
+                low[key] = high[key] = np.float32(cc_names[key])        # min / max of a constant float32 series
+        elif key in flex_names:
             # building.py:1968-2010: matched by substrings of the expanded names
             if 'connected_state' in key or '_incoming_state' in key:
                 low[key], high[key] = 0, 1
@@ -222,6 +254,20 @@ class ObservationLayout:
                 self.agent_slices.append(slice(len(self.columns), len(self.columns) + len(names)))
                 self.columns += [(i, k) for k in names]
         self._limits = [space_limits(spec, b, n, periodic=normalize) for b, n in zip(spec.buildings, self.raw_names)]
+        # `observation_space` follows the metadata order of every building (citylearn.py:399-420), which differs from the
+        # order of the returned values for buildings with charging-constraint observations
+        self.space_columns: List[Tuple[int, str]] = []
+        space_names = [periodic_names(building_space_names(b)) if normalize else building_space_names(b) for b in spec.buildings]
+        if self.central_agent:
+            seen = []
+            for i, names in enumerate(space_names):
+                for k in names:
+                    if i == 0 or k not in self.shared or k not in seen:
+                        self.space_columns.append((i, k))
+                    if k in self.shared and k not in seen:
+                        seen.append(k)
+        else:
+            self.space_columns = [(i, k) for i, names in enumerate(space_names) for k in names]
 
     @property
     def n_cols(self) -> int:
@@ -240,7 +286,8 @@ class ObservationLayout:
     def space(self) -> List[Tuple[np.ndarray, np.ndarray]]:
         """(low, high) float32 per agent: `CityLearnEnv.observation_space` (citylearn.py:385-425), or all [0, 1] for
         the normalised view (building.py:1856-1859)."""
-        lo, hi = self.limits()
+        lo = np.array([self._limits[i][0][k] for i, k in self.space_columns], dtype=np.float64)
+        hi = np.array([self._limits[i][1][k] for i, k in self.space_columns], dtype=np.float64)
         if self.normalize:
             lo, hi = np.zeros_like(lo), np.ones_like(hi)
         return [(lo[s].astype('float32'), hi[s].astype('float32')) for s in self.agent_slices]
@@ -255,6 +302,23 @@ class ObservationLayout:
         ts = tab.ts[:, i].astype(np.float64)
         zeros = np.zeros(T)
         dyn = b.is_dynamics and b.dynamics is not None
+        cc = charging_constraint_observations(b)
+        if k in cc:
+            # headroom / violation follow the charger actions of the step just simulated -- they are not time series, so the
+            # reference returns current values in every observation mode (building.py:1462-1481); reset(): limit / 0
+            if k.startswith('charging_phase_one_hot_'):
+                return cc[k] * np.ones(T), None, zeros
+            fb = list(tab.flex.flex_bldg).index(i)
+            names_ = [n for n, _ in b.charging_constraints.headroom_keys()]
+            if k == 'charging_constraint_violation_kwh':
+                plane = abi.CLX_VIOLATION
+            elif k == 'charging_building_headroom_kw':
+                plane = abi.CLX_HEADROOM
+            else:
+                limited = [ph['name'] for ph in b.charging_constraints.phases]
+                plane = abi.CLX_HEADROOM_PHASE0 + limited.index(k[len('charging_phase_'):-len('_headroom_kw')])
+            self._forced_sources[(i, k)] = (SRC_EXTRA, plane, fb)
+            return cc[k] * np.ones(T), None, zeros
         if tab.flex is not None and k in tab.flex.observations:
             # charger / washing-machine observations are functions of the schedule row (flex.py); row 0 is what reset() returns
             values = np.array(tab.flex.observations[k][:T], dtype=np.float64)
@@ -319,6 +383,7 @@ class ObservationLayout:
         `reset_table`: also pack, for every table row r, the observation `reset()` returns for an episode that STARTS at
         row r (per-env-block episode windows, `cl_dims.env_row0`): rows >= 1 of `table` are start-independent, row 0 is not."""
         T, N = tab.n_steps, self.n_cols
+        self._forced_sources: Dict[Tuple[int, str], Tuple[int, int, int]] = {}
         table = np.zeros((T, N), dtype=np.float64)
         resets = np.zeros((T, N), dtype=np.float64) if reset_table else None
         src = np.full(N, -1, dtype=np.int32)
@@ -346,7 +411,14 @@ class ObservationLayout:
             if resets is not None:
                 rv = self._reset_series(i, raw, tab)
                 resets[:, c] = a * (values if rv is None else rv) + b0
-            if self.mode == 'current' and source is not None:
+            if (i, raw) in self._forced_sources:
+                # current value of the step just simulated in every mode: obs = plane * a + b0 (row 0: the reset value)
+                kind, plane, fb = self._forced_sources[(i, raw)]
+                src[c] = (kind << 28) | (plane << 20) | fb
+                scale[c] = a
+                table[1:, c] = b0
+                table[0, c] = a * values[0] + b0
+            elif self.mode == 'current' and source is not None:
                 # row r (r >= 1) pairs exogenous values of r with env-dependent values computed at r - 1
                 kind, plane = source
                 if kind == SRC_OUT and plane in _DETAIL_PLANES:
@@ -376,7 +448,7 @@ class ObservationTables:
         return int((self.col_src >= 0).sum())
 
     def host_row(self, r: int, state: Optional[np.ndarray] = None, out_bldg: Optional[np.ndarray] = None,
-                 indoor_temp: Optional[np.ndarray] = None) -> np.ndarray:
+                 indoor_temp: Optional[np.ndarray] = None, extra: Optional[np.ndarray] = None) -> np.ndarray:
         """Observation vector of ONE environment at row `r` computed on the host from host copies of the device
         planes (`state [CL_NS, B]`, `out_bldg [CL_NO, B]`, `indoor_temp [B]`): what `cl_observe_f32` writes."""
         row = self.table[r].copy()
@@ -385,6 +457,7 @@ class ObservationTables:
         for c in np.nonzero(self.col_src >= 0)[0]:
             s = int(self.col_src[c])
             kind, plane, b = s >> 28, (s >> 20) & 0xFF, s & 0xFFFFF
-            x = state[plane, b] if kind == SRC_STATE else out_bldg[plane, b] if kind == SRC_OUT else indoor_temp[b]
+            x = state[plane, b] if kind == SRC_STATE else out_bldg[plane, b] if kind == SRC_OUT else \
+                indoor_temp[b] if kind == SRC_TEMP else extra[plane, b]
             row[c] = float(x) * float(self.col_scale[c]) + row[c]
         return row

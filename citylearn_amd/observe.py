@@ -48,7 +48,10 @@ class ObservationWriter:
         if self.n_deps >= 0:
             self._deps = (ObsDep * max(self.n_deps, 1))(*[ObsDep(int(c), int(tables.col_src[c]), float(tables.col_scale[c])) for c in cols])
         self.lib.cl_observe_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 4 + [ctypes.c_int32] + [ctypes.c_void_p] * 4 + [
-            ctypes.c_int32] * 4 + [ctypes.c_uint32, ctypes.c_void_p]
+            ctypes.c_int32, ctypes.c_void_p] + [ctypes.c_int32] * 4 + [ctypes.c_uint32, ctypes.c_void_p]
+        uses_extra = bool(np.any((tables.col_src >= 0) & ((tables.col_src >> 28) == abi.CLOB_KIND_EXTRA)))
+        if uses_extra and engine.flex is None:
+            raise ValueError('charging-constraint observations need the flexible-load planes of the engine')
 
     def write(self, row: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Observation returned when ``time_step == row`` (row 0: the reset observation, all columns from the table;
@@ -58,11 +61,12 @@ class ObservationWriter:
         if out.dtype != torch.float32 or out.device != e.device or tuple(out.shape) != (e.n_env, self.n_cols) or out.stride(1) != 1:
             raise ValueError(f'observation buffer must be float32 [{e.n_env}, {self.n_cols}] with unit column stride')
         temp = None if self.stage is None else self.stage.indoor_temp.data_ptr()
+        extra, n_extra = (None, 0) if e.flex is None else (e.flex_out.data_ptr(), int(e.flex_out.shape[1]))
         with torch.cuda.device(e.device):
             _lib.check(self.lib.cl_observe_f32(
                 ctypes.byref(e.dims), (self.reset_table if row == 0 and self.reset_table is not None else self.table).data_ptr(),
                 self.col_src.data_ptr(), self.col_scale.data_ptr(),
-                ctypes.cast(self._deps, ctypes.c_void_p) if self._deps is not None else None, self.n_deps, e.state.data_ptr(), e.out_bldg.data_ptr(), temp, out.data_ptr(), self.n_cols, out.stride(0), self.n_rows, int(row),
+                ctypes.cast(self._deps, ctypes.c_void_p) if self._deps is not None else None, self.n_deps, e.state.data_ptr(), e.out_bldg.data_ptr(), temp, extra, n_extra, out.data_ptr(), self.n_cols, out.stride(0), self.n_rows, int(row),
                 abi.CLOB_ALL_EXOGENOUS if row == 0 else 0, torch.cuda.current_stream(e.device).cuda_stream))
         return out
 

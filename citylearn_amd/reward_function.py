@@ -25,7 +25,8 @@ class RewardFunction:
     device_kind: Optional[int] = abi.CLR_DEFAULT
 
     def __init__(self, env_metadata: Mapping[str, Any], exponent: float = None, **kwargs):
-        kwargs.pop('charging_constraint_penalty_coefficient', None)
+        coefficient = kwargs.pop('charging_constraint_penalty_coefficient', None)     # reference reward_function.py:22-25, 49-58
+        self.charging_constraint_penalty_coefficient = 1.0 if coefficient is None else float(coefficient)
         self.env_metadata = env_metadata
         self.exponent = 1.0 if exponent is None else exponent
 
@@ -193,7 +194,7 @@ class Electric_Vehicles_Reward_Function(MARL):
             else:
                 reward = self.calculate_ev_penalty(o, current[0] if self.central_agent else current[i])
             violation = float(o.get('charging_constraint_violation_kwh', 0.0) or 0.0)
-            reward -= violation if violation > 0.0 else 0.0
+            reward -= violation * self.charging_constraint_penalty_coefficient if violation > 0.0 else 0.0
             out.append(reward)
         return [sum(out)] if self.central_agent else out
 

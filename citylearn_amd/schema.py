@@ -276,6 +276,51 @@ class WashingMachineSpec:
 
 
 @dataclass
+class ChargingConstraintsSpec:
+    """`Building._initialize_charging_constraints` (building.py:764-845): a building-level and per-phase limit [kW] on the
+    summed positive charger requests, plus which of the derived observations are exposed."""
+    building_limit_kw: Optional[float]
+    phases: List[Dict[str, Any]]                 # {'name', 'limit_kw' (None = unlimited), 'chargers': [ids]}
+    expose_headroom: bool
+    expose_violation: bool
+    phase_encoding: bool
+
+    def one_hot_keys(self, charger_ids: Sequence[str]) -> List[Tuple[str, float]]:
+        """`_update_phase_encoding_observations` (building.py:847-884): (key, value) per charger x phase name."""
+        if not self.phase_encoding or not charger_ids:
+            return []
+        phase_of = {cid: ph['name'] for ph in self.phases for cid in ph['chargers']}
+        names = sorted({ph['name'] for ph in self.phases if ph['name']})
+        unassigned = any(cid not in phase_of for cid in charger_ids)
+        if unassigned:
+            names = names + ['unassigned']
+        return [(f'charging_phase_one_hot_{cid}_{n}', 1.0 if phase_of.get(cid, 'unassigned' if unassigned else None) == n else 0.0)
+                for cid in charger_ids for n in names]
+
+    def headroom_keys(self) -> List[Tuple[str, float]]:
+        """(key, limit) of the exposed headroom observations, building first (building.py:810-817)."""
+        if not self.expose_headroom:
+            return []
+        out = [] if self.building_limit_kw is None else [('charging_building_headroom_kw', float(self.building_limit_kw))]
+        return out + [(f"charging_phase_{ph['name']}_headroom_kw", float(ph['limit_kw'])) for ph in self.phases if ph['limit_kw'] is not None]
+
+
+def _load_charging_constraints(config: Optional[Mapping[str, Any]]) -> Optional[ChargingConstraintsSpec]:
+    if not config:
+        return None
+    oc = config.get('observations', {}) or {}
+    flag = config.get('expose_observations')
+    expose = bool(oc.get('headroom', False)) if 'headroom' in oc else (bool(flag) if flag is not None else True)
+    phases = []
+    for ph in config.get('phases', []) or []:
+        phases.append({'name': ph.get('name') or f'phase_{len(phases) + 1}', 'limit_kw': ph.get('limit_kw'),
+                       'chargers': list(ph.get('chargers', []) or [])})
+    return ChargingConstraintsSpec(building_limit_kw=config.get('building_limit_kw'), phases=phases, expose_headroom=expose,
+                                   expose_violation=bool(oc.get('violation', True)),
+                                   phase_encoding=bool(oc.get('phase_encoding', False)) and bool(phases))
+
+
+@dataclass
 class BuildingSpec:
     name: str
     kind: str                                  # 'Building' | 'LSTMDynamicsBuilding'
@@ -296,6 +341,7 @@ class BuildingSpec:
     time_step_ratio: float
     chargers: List[ChargerSpec] = field(default_factory=list)
     washing_machines: List[WashingMachineSpec] = field(default_factory=list)
+    charging_constraints: Optional[ChargingConstraintsSpec] = None
 
     @property
     def active_actions(self) -> List[str]:
@@ -852,8 +898,6 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
         bs = sc['buildings'][name]
         if bs.get('occupant'):
             raise NotImplementedError(f'building {name}: \'occupant\' is outside the hot-path scope')
-        if bs.get('charging_constraints'):
-            raise NotImplementedError(f'building {name}: charging_constraints (phase / building charger limits) are not supported yet')
         if bs.get('noise_std', 0.0):
             raise NotImplementedError('noise_std > 0 (stochastic data files) is not supported yet')
         kind = _class_name(bs.get('type'), 'Building')
@@ -897,6 +941,16 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
         washing_machines = _load_washing_machines(bs, kwargs, root, sim_start, sim_end)
         _expand_flexible_load_metadata(obs_meta, act_meta, chargers, washing_machines, charger_obs_helper, wm_obs_helper,
                                        charger_act_helper, wm_act_helper, kwargs, bs, per_b)
+        constraints = _load_charging_constraints(bs.get('charging_constraints'))
+        if constraints is not None:
+            # keys `Building._initialize_charging_constraints` appends to observation_metadata, in its order (building.py:808-834)
+            if len(chargers) > 4 or len(constraints.phases) > 4:
+                raise NotImplementedError(f'building {name}: charging_constraints with more than 4 chargers / phases')
+            for k, _ in constraints.one_hot_keys([c.charger_id for c in chargers]):
+                obs_meta[k] = True
+            for k, _ in constraints.headroom_keys():
+                obs_meta.setdefault(k, True)
+            obs_meta['charging_constraint_violation_kwh'] = constraints.expose_violation
 
         # devices
         solar_on = kwargs.get('solar_generation')
@@ -989,7 +1043,7 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
             electrical_storage=dev.get('electrical_storage', BatterySpec()),
             pv_nominal_power=dev.get('pv', 0.0), outage=outage, dynamics=dynamics,
             seconds_per_time_step=seconds, time_step_ratio=1.0 if ratio is None else ratio,
-            chargers=chargers, washing_machines=washing_machines))
+            chargers=chargers, washing_machines=washing_machines, charging_constraints=constraints))
 
     # the env propagates building 0's ratio to every building and device (citylearn.py:209-210, building.py:1076-1087)
     if buildings:

@@ -323,6 +323,8 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
 #define CLOB_KIND_STATE 0           /* plane = enum cl_state */
 #define CLOB_KIND_OUT   1           /* plane = enum cl_out */
 #define CLOB_KIND_TEMP  2           /* indoor_temp */
+#define CLOB_KIND_EXTRA 3           /* caller-provided planes `extra[plane][n_extra_rows][n_env]`, row in the building field
+                                       (e.g. cl_flex.flex_out: charging headroom / violation observations) */
 #define CLOB_SRC(kind, plane, building) (((kind) << 28) | ((plane) << 20) | (building))
 #define CLOB_ALL_EXOGENOUS (1u << 0)
 #define CLOB_MAX_DEPS 64
@@ -332,7 +334,8 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
 typedef struct cl_obs_dep { int32_t col; int32_t src; float scale; } cl_obs_dep;
 int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* col_src, const float* col_scale,
                    const cl_obs_dep* deps /* host memory, nullable */, int32_t n_deps,
-                   const float* state, const float* out_bldg, const float* indoor_temp, float* obs, int32_t n_cols,
+                   const float* state, const float* out_bldg, const float* indoor_temp,
+                   const float* extra /* nullable: CLOB_KIND_EXTRA planes */, int32_t n_extra_rows, float* obs, int32_t n_cols,
                    int32_t obs_pitch, int32_t n_rows, int32_t row, uint32_t flags, void* stream);
 
 /* ---- flexible loads: EV chargers and washing machines ----
@@ -395,14 +398,29 @@ enum cl_wm_feat {
 };
 #define CLWT_EMPTY (-1.0f)
 #define CL_NEVS 3
-#define CL_NX 5
+#define CL_MAXPH 4          /* charging-constraint phases per building */
+#define CL_NX 11
 enum cl_flex_out {
     CLX_LOAD = 0,         /* chargers + washing machines electricity [kWh], added to the building's net */
     CLX_CHARGERS,         /* chargers only (removed again for evaluate()'s baseline, building.py:345-366) */
-    CLX_RW_K0, CLX_RW_KNEG, CLX_RW_KPOS   /* Electric_Vehicles_Reward_Function: reward_b = (K0 + [net<0] KNEG + [net>0] KPOS) / (1 + |MARL_b|) */
+    CLX_RW_K0, CLX_RW_KNEG, CLX_RW_KPOS,  /* Electric_Vehicles_Reward_Function: reward_b = (K0 + [net<0] KNEG + [net>0] KPOS) / (1 + |MARL_b|) - penalty */
+    /* buildings with charging constraints only (building.py:901-989): */
+    CLX_VIOLATION,        /* charging_constraint_violation_kwh of this step */
+    CLX_HEADROOM,         /* charging_building_headroom_kw: building limit - admitted charging power */
+    CLX_HEADROOM_PHASE0   /* .. + CL_MAXPH - 1: charging_phase_<name>_headroom_kw */
 };
 enum cl_ev_weight { CLEW_BATTERY_LIMITS = 0, CLEW_SOC_IMPOSSIBLE, CLEW_SOC_UNDER, CLEW_CLOSE_SOC, CLEW_SELF_EV_CONSUMPTION,
-                    CLEW_EXTRA_SELF_PRODUCTION, CL_NEW };
+                    CLEW_EXTRA_SELF_PRODUCTION, CLEW_PENALTY_COEFFICIENT /* charging_constraint_penalty_coefficient */, CL_NEW };
+/* charging constraints of a building (`cons_params[n_flex_bldg][CL_NCC]`, nullable = no building has any): the positive
+ * charger requests action * max_charging_power are scaled down so that their sum stays below the building limit and each
+ * phase's sum below the phase limit; the excess is the violation (Building._apply_charging_constraints_to_actions). */
+#define CL_NCC 12
+enum cl_cons_param {
+    CLCC_FLAGS = 0,       /* u32: bit 0 = this building has constraints */
+    CLCC_BUILDING_LIMIT,  /* kW, < 0 = none */
+    CLCC_PHASE_LIMIT0,    /* .. + CL_MAXPH - 1: kW, < 0 = none / unused */
+    CLCC_PHASE_MASK0 = CLCC_PHASE_LIMIT0 + CL_MAXPH   /* .. + CL_MAXPH - 1: u32 bit j = charger slot j is on this phase */
+};
 typedef struct cl_flex {
     int32_t n_ev, n_flex_bldg, n_rows, reserved;
     const uint32_t* ev_params;
@@ -411,6 +429,7 @@ typedef struct cl_flex {
     const float* charger_ts;
     const uint32_t* wm_params;
     const float* wm_ts;
+    const uint32_t* cons_params;  /* nullable */
     float* ev_state;
     float* wm_state;
     float* flex_out;

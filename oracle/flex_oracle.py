@@ -131,6 +131,64 @@ class _WashingMachine:
                     self.consumption = F32(self.consumption + load)
 
 
+def apply_charging_constraints(bspec, actions: Dict[str, float], dt_hours: float):
+    """`Building._apply_charging_constraints_to_actions` (building.py:901-989).  `actions`: charger id -> action.
+    Returns (actions, violation_kwh, headroom) with headroom = {'building': kW or None, phase name: kW or None}."""
+    cc = bspec.charging_constraints
+    default = {'building': None if cc.building_limit_kw is None else float(cc.building_limit_kw),
+               **{ph['name']: None if ph['limit_kw'] is None else float(ph['limit_kw']) for ph in cc.phases}}
+    if not actions:
+        return actions, 0.0, default
+    lookup = {c.charger_id: c for c in bspec.chargers}
+    requests, scales = {}, {}
+    for cid, a in actions.items():
+        if a is None or a <= 0.0 or cid not in lookup:
+            continue
+        max_power = lookup[cid].max_charging_power or 0.0
+        if max_power <= 0.0:
+            continue
+        requests[cid] = a * max_power
+        scales[cid] = 1.0
+    violation_kw = 0.0
+    if not requests:
+        return actions, 0.0, default
+    total = sum(requests.values())
+    limit = cc.building_limit_kw
+    if limit is not None and limit >= 0.0 and total > limit:
+        scale = 0.0 if limit == 0 else limit / total
+        for cid in scales:
+            scales[cid] *= scale
+        violation_kw += total - limit
+    for ph in cc.phases:
+        limit = ph['limit_kw']
+        if limit is None or limit < 0.0:
+            continue
+        phase_sum = sum(requests.get(cid, 0.0) * scales.get(cid, 1.0) for cid in ph['chargers'] if cid in requests)
+        if phase_sum > limit:
+            f = 0.0 if limit == 0 else limit / phase_sum
+            for cid in ph['chargers']:
+                if cid in scales:
+                    scales[cid] *= f
+            violation_kw += phase_sum - limit
+    scaled = {cid: requests[cid] * scales.get(cid, 1.0) for cid in requests}
+    actions = dict(actions)
+    for cid, a in list(actions.items()):
+        if a is None or a <= 0.0 or cid not in lookup:
+            continue
+        max_power = lookup[cid].max_charging_power or 0.0
+        if max_power <= 0.0:
+            actions[cid] = 0.0
+            continue
+        actions[cid] = max(0.0, min(a, scaled.get(cid, 0.0) / max_power))
+    headroom = dict(default)
+    if cc.expose_headroom:
+        used = sum(scaled.values())
+        headroom['building'] = None if cc.building_limit_kw is None else cc.building_limit_kw - used
+        for ph in cc.phases:
+            headroom[ph['name']] = None if ph['limit_kw'] is None else ph['limit_kw'] - sum(scaled.get(cid, 0.0) for cid in ph['chargers'])
+    return actions, violation_kw * dt_hours, headroom
+
+
 class _FlexEnv:
     """The EVs, chargers and washing machines of ONE environment."""
 
@@ -248,7 +306,7 @@ class _FlexEnv:
         self.associate()
 
 
-def ev_reward(env: _FlexEnv, units, base_rewards, weights=EV_REWARD_WEIGHTS) -> List[float]:
+def ev_reward(env: _FlexEnv, units, base_rewards, weights=EV_REWARD_WEIGHTS, violations=None, coefficient: float = 1.0) -> List[float]:
     """`Electric_Vehicles_Reward_Function.calculate` (reward_function.py:415-531), decentralised form.  Buildings
     without chargers get 0; the 'no_car_charging' term is computed and then dropped by the reference's `continue`."""
     t = env.t
@@ -303,6 +361,8 @@ def ev_reward(env: _FlexEnv, units, base_rewards, weights=EV_REWARD_WEIGHTS) -> 
                 k['self_ev_consumption'] += -0.5 * weights['self_ev_consumption'] * mult
             total += sum(k.values())
         out.append(total)
+    if violations is not None:                     # reward_function.py:431-434
+        out = [r - (v * coefficient if v > 0.0 else 0.0) for r, v in zip(out, violations)]
     return out
 
 
@@ -331,6 +391,8 @@ class FlexDistrictOracle(DistrictOracle):
         n_c = sum(len(b.chargers) for b in spec.buildings)
         n_w = sum(len(b.washing_machines) for b in spec.buildings)
         out = {k: np.zeros((B, E), dtype=np.float32) for k in ('net', 'reward', 'soc', 'eb', 'base_net', 'chargers_total', 'wms_total')}
+        out['cc_violation_kwh'] = np.zeros((B, E), dtype=np.float64)
+        out['cc_headroom'] = [[None] * E for _ in range(B)]
         out.update({k: np.zeros(E, dtype=np.float32) for k in ('d_net', 'd_cost', 'd_emission', 'd_reward')})
         out.update(ev_soc=np.zeros((n_ev, E), np.float32), ev_degcap=np.zeros((n_ev, E), np.float64),
                    ev_soc_next=np.zeros((n_ev, E), np.float32),
@@ -342,8 +404,14 @@ class FlexDistrictOracle(DistrictOracle):
                 per_b: List[Dict[str, float]] = [dict() for _ in env]
                 for c, (bi, name) in enumerate(self.columns):
                     per_b[bi][name] = float(actions[c, e])
+                violations = [0.0] * len(env)
                 for b, (u, a) in enumerate(zip(env, per_b)):
                     u.begin_step(t)
+                    if u.spec.charging_constraints is not None:     # building.py:1539-1540: before every device
+                        ev_a = {ch.spec.charger_id: a[ch.spec.action_name] for ch in fx.chargers[b] if ch.spec.action_name in a}
+                        ev_a, violations[b], out['cc_headroom'][b][e] = apply_charging_constraints(u.spec, ev_a, fx.chargers[b][0].dt_hours if fx.chargers[b] else 1.0)
+                        a = {**a, **{ch.spec.action_name: ev_a[ch.spec.charger_id] for ch in fx.chargers[b] if ch.spec.charger_id in ev_a}}
+                        out['cc_violation_kwh'][b, e] = violations[b]
                     u.apply_actions(a)
                     for ch in fx.chargers[b]:                       # building.py:1581-1592
                         if ch.spec.action_name in a:
@@ -362,7 +430,7 @@ class FlexDistrictOracle(DistrictOracle):
                 for u in env:
                     u.update_variables()
                 if self.reward == 'Electric_Vehicles_Reward_Function':
-                    rewards = ev_reward(fx, env, reward_values('MARL', env))
+                    rewards = ev_reward(fx, env, reward_values('MARL', env), violations=violations)
                 else:
                     rewards = reward_values(self.reward, env, self.exponent)
                 out['d_net'][e] = sum(u.net for u in env)

@@ -51,6 +51,9 @@ FIXTURES = {
     # global `random` and the unconnected-EV drift from numpy's global RNG, both unseeded: the harness seeds them with the
     # action seed (see run_reference)
     'g2022_evs': ('citylearn_challenge_2022_phase_all_plus_evs', 240, 239, 77, False, {}),
+    # the same district with charger power limits on Building_15 (building limit + two phases, headroom / violation / phase
+    # one-hot observations; building.py:764-990)
+    'g_cc_demo': ('citylearn_charging_constraints_demo', 168, 167, 78, False, {}),
     's_baeda': ('baeda_3dem', 96, 95, 31, False, {}),
     's_2021': ('citylearn_challenge_2021', 96, 95, 32, False, {}),
     's_2020_cz3': ('citylearn_challenge_2020_climate_zone_3', 96, 95, 33, False, {}),
@@ -173,6 +176,7 @@ def run_reference(name: str):
         traj['ev_soc_next'] = np.zeros((K, len(evs)), dtype='float32')      # soc[t + 1] right after step t (arrival / drift values)
         traj['ev_degcap'] = np.zeros((K, len(evs)), dtype='float64')
         traj['ev_soc0'] = np.array([ev.battery.soc[0] for ev in evs], dtype='float32')   # after reset()'s charger association
+        traj['cc_violation_kwh'] = np.zeros((K, B), dtype='float64')       # Building._charging_constraint_last_penalty_kwh
     rewards_all = {k: np.zeros((K, B), dtype='float64') for k in extra_rewards}
     env_rewards = []
     for t in range(K):
@@ -223,6 +227,7 @@ def run_reference(name: str):
             traj['chargers_total'][t] = [b.chargers_electricity_consumption[t] for b in env.buildings]
             traj['wms_total'][t] = [b.washing_machines_electricity_consumption[t] for b in env.buildings]
             traj['ev_degcap'][t] = [ev.battery.capacity_history[-1] for ev in evs]
+            traj['cc_violation_kwh'][t] = [getattr(b, '_charging_constraint_last_penalty_kwh', 0.0) for b in env.buildings]
             if t + 1 < env.time_steps:
                 traj['ev_soc_next'][t] = [ev.battery.soc[t + 1] for ev in evs]
         if terminated:
@@ -370,7 +375,7 @@ def run_observations(name: str, steps: int = None):
 
 
 OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300, 'g2020_15min': 120, 's_baeda': 95, 's_2021': 95,
-                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239}
+                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239, 'g_cc_demo': 167}
 
 
 if __name__ == '__main__':

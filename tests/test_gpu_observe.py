@@ -85,19 +85,19 @@ def test_observe_validates_arguments():
     w = ObservationWriter(eng, ot)
     with pytest.raises(_lib.EngineError, match='row'):
         w.write(w.n_rows)
-    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), None, None, None, -1, None, None, None, w.obs.data_ptr(),
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), None, None, None, -1, None, None, None, None, 0, w.obs.data_ptr(),
                               w.n_cols, w.pitch, w.n_rows, 1, 0, None)
     assert rc == abi.CL_ENULL
-    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr() + 4, None, None, None, -1, None, None, None, w.obs.data_ptr(),
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr() + 4, None, None, None, -1, None, None, None, None, 0, w.obs.data_ptr(),
                               w.n_cols, w.pitch, w.n_rows, 0, abi.CLOB_ALL_EXOGENOUS, None)
     assert rc == abi.CL_EALIGN
-    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), None, None, None, -1, None, None, None, w.obs.data_ptr(),
+    rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), None, None, None, -1, None, None, None, None, 0, w.obs.data_ptr(),
                               w.n_cols, w.n_cols - 1, w.n_rows, 0, abi.CLOB_ALL_EXOGENOUS, None)
     assert rc == abi.CL_EINVAL
     from citylearn_amd.observe import ObsDep
     bad = (ObsDep * 1)(ObsDep(w.n_cols, 0, 1.0))                                         # column outside the table
     rc = w.lib.cl_observe_f32(ctypes.byref(eng.dims), w.table.data_ptr(), w.col_src.data_ptr(), w.col_scale.data_ptr(),
-                              ctypes.cast(bad, ctypes.c_void_p), 1, eng.state.data_ptr(), eng.out_bldg.data_ptr(), None,
+                              ctypes.cast(bad, ctypes.c_void_p), 1, eng.state.data_ptr(), eng.out_bldg.data_ptr(), None, None, 0,
                               w.obs.data_ptr(), w.n_cols, w.pitch, w.n_rows, 1, 0, None)
     assert rc == abi.CL_EINVAL
     from citylearn_amd.engine import StepEngine

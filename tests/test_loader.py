@@ -86,10 +86,10 @@ def test_error_behaviour(tmp_path):
     schema['root_directory'] = str(g.dir / 'dataset')
     schema['actions']['electric_vehicle_storage'] = {'active': True}      # a helper row: expands to nothing without chargers
     assert load_district(schema).n_action_columns == load_district(g.schema_path).n_action_columns
-    schema['buildings']['Building_1']['charging_constraints'] = {'building_limit_kw': 10.0}
+    schema['buildings']['Building_1']['occupant'] = {'type': 'citylearn.occupant.LogisticRegressionOccupant'}
     with pytest.raises(NotImplementedError):
         load_district(schema)
-    schema['buildings']['Building_1'].pop('charging_constraints')
+    schema['buildings']['Building_1'].pop('occupant')
     schema['buildings']['Building_1']['electrical_storage']['autosize'] = True
     with pytest.raises(NotImplementedError):
         load_district(schema)
