@@ -218,7 +218,7 @@ class CityLearnEnv:
         self._fused_reward = fused
         names = {v: k for k, v in REWARD_KINDS.items()}
         self._engine = StepEngine(self._tables, 4, device=self.device, reward=names[kind] if fused else 'RewardFunction',
-                                  t0_quirk=self.reference_quirks, detail=True, charger_detail=True,
+                                  t0_quirk=self.reference_quirks, detail=True, charger_detail=True, central_agent=self.central_agent,
                                   ev_reward_weights=getattr(self.reward_function, 'weights', None), ev_drift=self._ev_drift,
                                   ev_penalty_coefficient=getattr(self.reward_function, 'charging_constraint_penalty_coefficient', 1.0),
                                   ev_seed=(self.random_seed if self._ev_seed is None else self._ev_seed) + self._episode)

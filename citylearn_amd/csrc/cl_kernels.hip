@@ -131,7 +131,10 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
         const int q = i / TILE, e = i - q * TILE;
         float s = 0.0f;
         for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
-        if (coupled && q == CLQ_REWARD) continue;              // finished below
+        if (coupled && q == CLQ_REWARD) {                      // finished below
+            if (FLEX && rkind == CLR_EV) lds[i] = s;           // CLR_EV accumulated sign(-net) * 0.01 * net^2: the district MARL sum / max(0, district net)
+            continue;
+        }
         if (tile_env0 + e < a.n_env) a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
         if (coupled && q == CLQ_NET) lds[i] = s;               // wave-0 slot now holds the district net
     }
@@ -139,8 +142,14 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
         // MARL couples every building to the district net (reward_function.py:132-143): second sweep over the
         // nets this same thread wrote a moment ago (L1/L2 hits), then a second LDS reduction for the reward sum.
         __syncthreads();
-        float dnet[VEC];
+        float dnet[VEC], dmarl[VEC];
         vload<VEC>(dnet, lds + CLQ_NET * TILE + lane * VEC);
+        const bool central_ev = FLEX && rkind == CLR_EV && (a.flags & CLD_CENTRAL_AGENT);
+        if (central_ev) {
+            vload<VEC>(dmarl, lds + CLQ_REWARD * TILE + lane * VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dmarl[i] *= fmaxf(0.0f, dnet[i]);
+        }
         __syncthreads();
         float r_sum[VEC];
 #pragma unroll
@@ -151,7 +160,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
                 float n[VEC], rw[VEC];
                 vload<VEC>(n, a.out_bldg + CLO_NET * plane + off);
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) rw[i] = cl::marl_reward(n[i], dnet[i]);
+                for (int i = 0; i < VEC; ++i) rw[i] = central_ev ? dmarl[i] : cl::marl_reward(n[i], dnet[i]);
                 if (FLEX && rkind == CLR_EV) {
                     // Electric_Vehicles_Reward_Function: MARL only scales the charger terms cl_flex_kernel prepared
                     const uint32_t* __restrict__ bp = a.params + (long long)b * CL_NP;
@@ -279,7 +288,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 o_bn[i] = O.base_net; o_ex[i] = O.expected; o_sv[i] = O.served;
                 // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)
                 q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
-                q_rw[i] += marl_partial ? cl::marl_reward(O.net, 1.0f) : rw;
+                q_rw[i] += (marl_partial || (FLEX && rkind == CLR_EV)) ? cl::marl_reward(O.net, 1.0f) : rw;
             }
             if (batt) {
                 vstore<VEC>(a.state + CLS_B_SOC * plane + off, s_soc);
@@ -378,7 +387,8 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
             const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
             s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap;
             o_net[i] = O.net; o_rw[i] = rw;
-            q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission; q_rw[i] += rw;
+            q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
+            q_rw[i] += (FLEX && rkind == CLR_EV) ? cl::marl_reward(O.net, 1.0f) : rw;
         }
         if (batt) {
             vstore<VEC>(a.state + CLS_B_SOC * plane + off, s_soc[m]);

@@ -39,7 +39,7 @@ class StepEngine:
     def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
                  t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False,
                  n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0,
-                 charger_detail: bool = False, ev_penalty_coefficient: float = 1.0):
+                 charger_detail: bool = False, ev_penalty_coefficient: float = 1.0, central_agent: bool = False):
         """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
         simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
         at table row ``env_row0[g]`` -- different blocks replay different windows at once.
@@ -82,6 +82,7 @@ class StepEngine:
         flags |= abi.CLD_REF_T0_QUIRK if t0_quirk else 0
         flags |= abi.CLD_WRITE_DETAIL if (detail or kpi) else 0
         flags |= abi.CLD_KPI if kpi else 0
+        flags |= abi.CLD_CENTRAL_AGENT if central_agent else 0      # only read by the CLR_EV reward
         self.kpi = kpi
         bflags = tables.params[:, abi.CLP_FLAGS]
         heavy = abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS

@@ -124,7 +124,7 @@ class VectorCityLearnEnv:
         self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
                                  t0_quirk=self.reference_quirks, kpi=self.kpi, n_steps=n_steps, env_row0=row0,
                                  detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail),
-                                 ev_reward_weights=self._rf_attrs.get('weights'), ev_drift=self._ev_drift,
+                                 ev_reward_weights=self._rf_attrs.get('weights'), ev_drift=self._ev_drift, central_agent=self.central_agent,
                                  ev_penalty_coefficient=self._rf_attrs.get('charging_constraint_penalty_coefficient') or 1.0,
                                  ev_seed=(self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode)
         self.stage = None

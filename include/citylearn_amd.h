@@ -205,6 +205,8 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 #define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators (requires CLD_WRITE_DETAIL) */
 #define CLD_ES_COL_IS_BLDG   (1u << 4)  /* hint: the electrical_storage action column of building b is column b (one action per
                                           building, building order) -- lets the step issue its action loads before the parameters */
+#define CLD_CENTRAL_AGENT  (1u << 5)  /* CLR_EV only: central_agent districts scale every building's charger terms by the DISTRICT
+                                         MARL reward (reward_function.py:423-425 takes current_reward[0], the sum) */
 #define CLD_LEAN           (1u << 3)  /* caller asserts: no building has a thermal device / tank, outage or dynamics
                                          flag (battery + PV + non-shiftable load only, e.g. the 2022 schemas) ->
                                          the specialised lean kernel may be used */

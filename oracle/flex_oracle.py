@@ -430,7 +430,10 @@ class FlexDistrictOracle(DistrictOracle):
                 for u in env:
                     u.update_variables()
                 if self.reward == 'Electric_Vehicles_Reward_Function':
-                    rewards = ev_reward(fx, env, reward_values('MARL', env), violations=violations)
+                    marl = reward_values('MARL', env)
+                    if self.spec.central_agent:             # MARL returns [sum]; every building is scaled by it (reward_function.py:423-425)
+                        marl = [sum(marl)] * len(env)
+                    rewards = ev_reward(fx, env, marl, violations=violations)
                 else:
                     rewards = reward_values(self.reward, env, self.exponent)
                 out['d_net'][e] = sum(u.net for u in env)

@@ -54,6 +54,9 @@ FIXTURES = {
     # the same district with charger power limits on Building_15 (building limit + two phases, headroom / violation / phase
     # one-hot observations; building.py:764-990)
     'g_cc_demo': ('citylearn_charging_constraints_demo', 168, 167, 78, False, {}),
+    # the EV district under 15-minute control (time_step_ratio 0.25 through the EV batteries and chargers) and with a central agent
+    'g_evs_15min': ('citylearn_challenge_2022_phase_all_plus_evs', 120, 119, 79, False, {'seconds_per_time_step': 900}),
+    'g_evs_central': ('citylearn_challenge_2022_phase_all_plus_evs', 120, 119, 80, False, {'central_agent': True}),
     's_baeda': ('baeda_3dem', 96, 95, 31, False, {}),
     's_2021': ('citylearn_challenge_2021', 96, 95, 32, False, {}),
     's_2020_cz3': ('citylearn_challenge_2020_climate_zone_3', 96, 95, 33, False, {}),
@@ -375,7 +378,7 @@ def run_observations(name: str, steps: int = None):
 
 
 OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300, 'g2020_15min': 120, 's_baeda': 95, 's_2021': 95,
-                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239, 'g_cc_demo': 167}
+                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239, 'g_cc_demo': 167, 'g_evs_15min': 119, 'g_evs_central': 119}
 
 
 if __name__ == '__main__':
