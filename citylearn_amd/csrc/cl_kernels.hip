@@ -1015,6 +1015,7 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
     case 3: hipLaunchKernelGGL((cl_lstm_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;   // f32 MFMA path
     case 5: hipLaunchKernelGGL((cl_lstm_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
     case 6: hipLaunchKernelGGL((cl_lstm_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    case 8: hipLaunchKernelGGL((cl_lstm_kernel<8, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;   // two-term split
     default:
         if (lstm_wb) hipLaunchKernelGGL((cl_lstm_kernel<0, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((cl_lstm_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a);

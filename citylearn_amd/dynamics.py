@@ -145,6 +145,7 @@ class LSTMStage:
         scalar comfort band `kpi_band` (`CityLearnEnv.evaluate`'s ``comfort_band``, default 2.0 C -- data.py:399)."""
         self.lib = _lib.load()
         self.engine = engine
+        self._args = None
         lstm_w, dyn_pre = pack_lstm(spec, tables, band, lower_exponent, higher_exponent, kpi_band)
         self.kpi_band = kpi_band
         dev = engine.device
@@ -173,11 +174,16 @@ class LSTMStage:
 
     def step(self, t: int, cool_dem: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t."""
-        cd = self.engine.out_bldg[abi.CLO_COOL_DEM] if cool_dem is None else cool_dem
-        with torch.cuda.device(self.engine.device):
-            _lib.check(self.lib.cl_lstm_step_f32(ctypes.byref(self.engine.dims), self.lstm_w.data_ptr(),
-                                                 None if self.lstm_wb is None else self.lstm_wb.data_ptr(), self.dyn_pre.data_ptr(),
-                                                 cd.data_ptr(), None, self.hist.data_ptr(), self.hidden.data_ptr(),
-                                                 self.indoor_temp.data_ptr(), self.comfort.data_ptr(),
-                                                 None if self.kpi_comfort is None else self.kpi_comfort.data_ptr(), int(t), self._stream()))
+        e = self.engine
+        if self._args is None:          # per-step arguments that never change, converted once
+            self._args = ((ctypes.byref(e.dims), self.lstm_w.data_ptr(), None if self.lstm_wb is None else self.lstm_wb.data_ptr(),
+                           self.dyn_pre.data_ptr()),
+                          (None, self.hist.data_ptr(), self.hidden.data_ptr(), self.indoor_temp.data_ptr(), self.comfort.data_ptr(),
+                           None if self.kpi_comfort is None else self.kpi_comfort.data_ptr()),
+                          e.out_bldg[abi.CLO_COOL_DEM].data_ptr())
+        head, tail, own_cd = self._args
+        with e._on_device():
+            rc = self.lib.cl_lstm_step_f32(*head, own_cd if cool_dem is None else cool_dem.data_ptr(), *tail, int(t), e._stream())
+        if rc:
+            _lib.check(rc)
         return self.indoor_temp

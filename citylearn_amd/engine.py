@@ -25,6 +25,17 @@ REWARD_KINDS = {
 }
 
 
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_CONTEXT = _NullContext()
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -107,6 +118,12 @@ class StepEngine:
             self.flex = None
             if self.flex_tables is not None:
                 self._init_flex(ev_reward_weights, ev_drift, ev_seed, charger_detail, ev_penalty_coefficient)
+        self._device_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+        # per-step call arguments that never change: computed once (ctypes conversions dominate an 8 us kernel otherwise)
+        self._step_head = (ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state))
+        self._step_tail = (_ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env))
+        self._flex_ref = None if self.flex is None else ctypes.byref(self.flex)
         self.t = 0
         self.reset()
 
@@ -153,7 +170,13 @@ class StepEngine:
 
     # ---------------------------------------------------------------------------------------------------
     def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        # raw handle of torch's current stream on this device (what torch.cuda.current_stream(...).cuda_stream returns, without
+        # building the Stream object: this runs once per env step)
+        return self._raw_stream(self._device_index)
+
+    def _on_device(self):
+        """Context that makes the engine's device current -- a no-op object when it already is (the common case)."""
+        return _NULL_CONTEXT if torch.cuda.current_device() == self._device_index else torch.cuda.device(self.device)
 
     def reset(self):
         with torch.cuda.device(self.device):
@@ -172,16 +195,14 @@ class StepEngine:
         if tuple(actions.shape) != (self.n_act_cols, self.n_env):
             raise ValueError(f'actions shape {tuple(actions.shape)} != {(self.n_act_cols, self.n_env)}')
         sc, se = actions.stride()
-        with torch.cuda.device(self.device):
-            if self.flex is not None:
-                _lib.check(self.lib.cl_step_flex_f32(
-                    ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), sc, se,
-                    _ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env), ctypes.byref(self.flex),
-                    int(t), self._stream()))
+        with self._on_device():
+            if self._flex_ref is not None:
+                rc = self.lib.cl_step_flex_f32(*self._step_head, actions.data_ptr(), sc, se, *self._step_tail, self._flex_ref,
+                                               int(t), self._stream())
             else:
-                _lib.check(self.lib.cl_step_f32(
-                    ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), sc, se,
-                    _ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env), int(t), self._stream()))
+                rc = self.lib.cl_step_f32(*self._step_head, actions.data_ptr(), sc, se, *self._step_tail, int(t), self._stream())
+        if rc:
+            _lib.check(rc)
         self.t = t + 1
 
     def set_action_limits(self, low, high):

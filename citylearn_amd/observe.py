@@ -62,12 +62,12 @@ class ObservationWriter:
             raise ValueError(f'observation buffer must be float32 [{e.n_env}, {self.n_cols}] with unit column stride')
         temp = None if self.stage is None else self.stage.indoor_temp.data_ptr()
         extra, n_extra = (None, 0) if e.flex is None else (e.flex_out.data_ptr(), int(e.flex_out.shape[1]))
-        with torch.cuda.device(e.device):
+        with e._on_device():
             _lib.check(self.lib.cl_observe_f32(
                 ctypes.byref(e.dims), (self.reset_table if row == 0 and self.reset_table is not None else self.table).data_ptr(),
                 self.col_src.data_ptr(), self.col_scale.data_ptr(),
                 ctypes.cast(self._deps, ctypes.c_void_p) if self._deps is not None else None, self.n_deps, e.state.data_ptr(), e.out_bldg.data_ptr(), temp, extra, n_extra, out.data_ptr(), self.n_cols, out.stride(0), self.n_rows, int(row),
-                abi.CLOB_ALL_EXOGENOUS if row == 0 else 0, torch.cuda.current_stream(e.device).cuda_stream))
+                abi.CLOB_ALL_EXOGENOUS if row == 0 else 0, e._stream()))
         return out
 
     def algorithmic_bytes(self) -> int:

@@ -9,18 +9,21 @@ from citylearn_amd.engine import StepEngine
 from citylearn_amd.dynamics import LSTMStage
 g = golden('g2023_p2'); spec = g.spec(); tab = spec.episode_tables(0); attrs = spec.reward_function['attributes']
 E = 64
-eng = StepEngine(tab, E, detail=True)
-stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'])
 cool = torch.from_numpy(g.ref['cool_dem']).cuda()
-wt = wr = 0.0
-for t in range(g.facts['steps']):
-    temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous())
-    tt, rr = temp.cpu().numpy(), stage.comfort.cpu().numpy()
-    wt = max(wt, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t]))))
-    ref = g.ref['reward_ComfortReward'][t]
-    wr = max(wr, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
-print('teacher-fed: worst |dT| =', wt, 'C ; worst comfort reward err / (1e-4 + 1e-4|ref|) =', wr)
-for E, dbg in ((4096, 0), (65536, 0), (4096, 3), (65536, 3), (65536, 1), (65536, 2), (65536, 5), (65536, 6)):
+for dbg in (0, 8, 3):
+    eng = StepEngine(tab, E, detail=True)
+    eng.lib.cl_debug_set_lstm(dbg)
+    stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'])
+    wt = wr = 0.0
+    for t in range(g.facts['steps']):
+        temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous())
+        tt, rr = temp.cpu().numpy(), stage.comfort.cpu().numpy()
+        wt = max(wt, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t]))))
+        ref = g.ref['reward_ComfortReward'][t]
+        wr = max(wr, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
+    print(f'variant {dbg}: teacher-fed worst |dT| =', wt, 'C ; worst comfort reward err / (1e-4 + 1e-4|ref|) =', wr)
+    eng.lib.cl_debug_set_lstm(0)
+for E, dbg in ((4096, 0), (65536, 0), (4096, 8), (65536, 8), (4096, 3), (65536, 3), (65536, 1), (65536, 2), (65536, 5), (65536, 6)):
     eng = StepEngine(tab, E, detail=True)
     eng.lib.cl_debug_set_lstm(dbg)
     stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0)
@@ -35,5 +38,5 @@ for E, dbg in ((4096, 0), (65536, 0), (4096, 3), (65536, 3), (65536, 1), (65536,
     us = ev0.elapsed_time(ev1) / n * 1e3
     flop = 3 * E * 12 * (64 * 18 + 64 * 32) * 2
     label = {0: ' split-bf16 matrix-core path', 1: ' [f32 MFMA, experiment: no activations]', 2: ' [f32 MFMA, experiment: no MFMA]',
-             3: ' f32-MFMA path', 5: ' [split-bf16, experiment: no activations]', 6: ' [split-bf16, experiment: no MFMA]'}[dbg]
+             3: ' f32-MFMA path', 8: ' two-term split-bf16 (3 partial products)', 5: ' [split-bf16, experiment: no activations]', 6: ' [split-bf16, experiment: no MFMA]'}[dbg]
     print(f'E={E}{label}: {us:.1f} us per LSTM step  {3*E/us*1e6:.3e} building-timesteps/s  {flop/us/1e6:.1f} TFLOP/s fp32')
