@@ -401,6 +401,98 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     district_reduce<VEC, FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
 }
 
+// Lean districts, one wave = 64 envs x ALL buildings ("env-major").  The wave issues every state / action load of its
+// envs -- 4 dwords per building -- before the first parameter read, then walks the buildings in order while the data streams
+// in, storing as it goes: no LDS, no barrier, no cross-wave reduction (the district sums are formed in registers, in building
+// order -- the reference's own summation order, citylearn.py:1909-1918).  With one such wave per SIMD the read stream, the
+// arithmetic and the write stream of a CU overlap, which the building-major kernels (one generation of waves in lockstep:
+// load, then compute, then store) cannot do.  NB = compile-time bound on the buildings held in flight.
+template <int NB>
+__global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a) {
+    const int env = blockIdx.x * 256 + threadIdx.x;
+    const bool live = env < a.n_env;
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    const bool quirk = a.flags & CLD_REF_T0_QUIRK;
+    const bool act_by_bldg = (a.flags & CLD_ES_COL_IS_BLDG) && a.act_stride_env == 1;
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * 256) / CL_ROW0_BLOCK] : 0);
+    // the buildings' parameter blocks and time-series rows, staged once per workgroup: a wave walking 17 buildings cannot
+    // afford a scalar-load round trip per building (16 us at any batch size), and 17 x 36 SGPRs do not exist
+    constexpr int PW = CLP_L_LAST - CLP_L_FIRST + 1;          // 32 parameter words
+    __shared__ uint32_t sp[NB][PW + 4];
+    for (int i = threadIdx.x; i < a.n_bldg * (PW + 4); i += 256) {
+        const int b = i / (PW + 4), k = i - b * (PW + 4);
+        uint32_t v;
+        if (k < PW) v = a.params[(long long)b * CL_NP + CLP_L_FIRST + k];
+        else {
+            const float* q = a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF;
+            v = __float_as_uint(k == PW ? q[CLT_NSL] : k == PW + 1 ? q[CLT_SOLAR] : k == PW + 2 ? q[CLT_PRICE] : q[CLT_CARBON]);
+        }
+        sp[b][k] = v;
+    }
+    float s_soc[NB], s_eff[NB], s_deg[NB], a_es[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        s_soc[b] = s_eff[b] = s_deg[b] = a_es[b] = 0.0f;
+        if (live && b < a.n_bldg) {               // wave-uniform in b; no `break`: it would push the arrays to scratch
+            const long long off = (long long)b * a.n_env + env;
+            s_soc[b] = a.state[CLS_B_SOC * plane + off];
+            s_eff[b] = a.state[CLS_B_EFF * plane + off];
+            s_deg[b] = a.state[CLS_B_DEGCAP * plane + off];
+            if (act_by_bldg) a_es[b] = a.actions[(long long)b * a.act_stride_col + env];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    float q_net = 0.0f, q_cost = 0.0f, q_em = 0.0f, q_rw = 0.0f;
+    float nets[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        nets[b] = 0.0f;
+        if (b >= a.n_bldg) continue;
+        cl::Bp B;
+        cl::load_bp<false>(B, &sp[b][0] - CLP_L_FIRST);           // the CLP_L_* block, from LDS (uniform address: a broadcast read)
+        cl::Row R;
+        R.nsl = __uint_as_float(sp[b][PW]); R.sol = __uint_as_float(sp[b][PW + 1]);
+        R.price = __uint_as_float(sp[b][PW + 2]); R.carbon = __uint_as_float(sp[b][PW + 3]);
+        R.outage = false;
+        const long long off = (long long)b * a.n_env + env;
+        const bool batt = B.flags & CLF_BATTERY;
+        float act_v = 0.0f;
+        if (B.a_es >= 0) act_v = act_by_bldg ? a_es[b] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)env * a.act_stride_env];
+        cl::State S;
+        S.soc = batt ? s_soc[b] : 0.0f; S.eff = batt ? s_eff[b] : 1.0f; S.degcap = batt ? s_deg[b] : 0.0f;
+        S.cs = S.hs = S.ds = 0.0f;
+        const cl::Act act = {0.0f, 0.0f, 0.0f, act_v, 0.0f, 0.0f};
+        cl::Out O;
+        cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
+        const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
+        if (batt) {
+            a.state[CLS_B_SOC * plane + off] = S.soc;
+            a.state[CLS_B_EFF * plane + off] = S.eff;
+            a.state[CLS_B_DEGCAP * plane + off] = S.degcap;
+        }
+        a.out_bldg[CLO_NET * plane + off] = O.net;
+        if (rkind != CLR_MARL) a.out_bldg[CLO_REWARD * plane + off] = rw;
+        nets[b] = O.net;
+        q_net += O.net; q_cost += O.cost; q_em += O.emission; q_rw += rw;
+    }
+    if (rkind == CLR_MARL) {                      // reward_function.py:132-143: every building against the district net
+        q_rw = 0.0f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b >= a.n_bldg) continue;
+            const float rw = cl::marl_reward(nets[b], q_net);
+            a.out_bldg[CLO_REWARD * plane + (long long)b * a.n_env + env] = rw;
+            q_rw += rw;
+        }
+    }
+    a.out_env[(long long)CLQ_NET * a.n_env + env] = q_net;
+    a.out_env[(long long)CLQ_COST * a.n_env + env] = q_cost;
+    a.out_env[(long long)CLQ_EMISSION * a.n_env + env] = q_em;
+    a.out_env[(long long)CLQ_REWARD * a.n_env + env] = q_rw;
+}
+
 // Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x 16
 // waves; wave w adds chunks w, w+16, ... (independent loads, one round trip), then the 16 wave partials are summed in
 // a fixed order through LDS -- deterministic, and ~10x faster than one thread walking all chunks.
@@ -599,6 +691,7 @@ int g_no_chunks = 0;
 int g_lean_variant = 0;   // 1: generic kernel for lean districts too; 2: latency-ordered kernel at any grid size (tests, tuning)
 int g_obs_variant = 0;   // 1 / 2 / 3: force the row-wise / LDS-tile / wave-independent observation kernel (tests, tuning)
 int g_lstm_dbg = 0;
+int g_envmajor = 0;      // env-major lean kernel: 0 = by batch size, 1 = always, 2 = never (tests, tuning)
 int g_flex_vec = 0;      // 1 / 2 / 4: envs per lane of cl_flex_kernel (tuning)
 int g_obs_rows = 0;      // tile kernel: envs per block (tuning)
 
@@ -681,6 +774,7 @@ void cl_debug_set_vec(int vec) { g_force_vec = vec; }
 void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks & 1; g_lean_variant = (no_chunks >> 2) & 3; g_force_nw = nw; }
 void cl_debug_set_lstm(int dbg) { g_lstm_dbg = dbg; }
 void cl_debug_set_flex(int vec) { g_flex_vec = vec; }
+void cl_debug_set_envmajor(int on) { g_envmajor = on; }
 int cl_debug_copy_floor(const float* st_in, const float* act, float* st_out, float* out2, int n_bldg, int n_env, void* stream) {
     hipLaunchKernelGGL(cl_copy_floor_kernel, dim3(n_env / 256), dim3(1024), 0, (hipStream_t)stream, st_in, act, st_out, out2, n_bldg, n_env);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "copy floor launch");
@@ -877,6 +971,11 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         case 4: hipLaunchKernelGGL((cl_step_kernel<4, true, false>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
+    } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && (g_envmajor == 1 || (g_envmajor == 0 && dims->n_env >= 131072))) {
+        // two or more waves per SIMD: the env-major kernel (bench.py --envs-per-gpu: 17 x 131 072 17.0 vs 18.5 us,
+        // 17 x 262 144 28.2 vs 32.5 us, 17 x 1 048 576 136 vs 157 us; at 17 x 65 536 -- one wave per SIMD, nothing to hide the
+        // per-building dependency chain behind -- 13.1 vs 8.0 us)
+        hipLaunchKernelGGL(cl_step_envmajor_kernel<20>, dim3((unsigned)((dims->n_env + 255) / 256)), dim3(256), 0, s, a);
     } else if (lean_shape) {
         // one workgroup per CU at most: with more rounds the generic kernel's smaller register file (52 vs 88 VGPRs, two
         // workgroups per CU) wins again -- 17 x 262 144: 30.8 us vs 33.0 us

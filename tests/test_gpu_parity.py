@@ -107,6 +107,34 @@ def test_lean_kernel_variants_are_bit_identical(kind, vec):
         lib.cl_debug_set_vec(0); lib.cl_debug_set_lean(0, 0)
 
 
+@pytest.mark.parametrize('kind', REWARDS)
+def test_env_major_lean_kernel(kind):
+    """The env-major lean kernel (one wave = 64 envs x every building; used from 131 072 envs up) against the reference
+    (teacher-forced) and against the building-major kernel: identical per-building planes for the per-building rewards,
+    district sums equal up to the summation order (env-major adds in building order, like the reference)."""
+    lib = _lib.load()
+    lib.cl_debug_set_envmajor(1)
+    try:
+        worst, eng = _run('g2022_all', kind, 0, detail=False, teach=True, steps=240)
+        assert eng.lean and max(worst.values()) < 1.0, worst
+        g = golden('g2022_all')
+        tab = g.spec().episode_tables(0)
+        E = 516
+        e0, e1 = StepEngine(tab, E, reward=kind), StepEngine(tab, E, reward=kind)
+        gen = torch.Generator(device='cuda').manual_seed(3)
+        for t in range(40):
+            a = torch.rand((e0.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+            lib.cl_debug_set_envmajor(2); e0.step(a, t)
+            lib.cl_debug_set_envmajor(1); e1.step(a, t)
+            assert torch.equal(e0.state, e1.state) and torch.equal(e0.out_bldg[abi.CLO_NET], e1.out_bldg[abi.CLO_NET]), t
+            if kind != 'MARL':                       # MARL multiplies by the district net, whose rounding depends on the order
+                assert torch.equal(e0.out_bldg[abi.CLO_REWARD], e1.out_bldg[abi.CLO_REWARD]), t
+            torch.testing.assert_close(e0.out_env, e1.out_env, rtol=2e-6, atol=2e-5)
+            torch.testing.assert_close(e0.out_bldg[abi.CLO_REWARD], e1.out_bldg[abi.CLO_REWARD], rtol=2e-6, atol=1e-6)
+    finally:
+        lib.cl_debug_set_envmajor(0)
+
+
 @pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
 @pytest.mark.parametrize('kind', REWARDS)
 def test_full_kernel_teacher_forced(name, kind):
