@@ -91,8 +91,14 @@ def main():
     E = args.envs_per_gpu
     eng = StepEngine(tables, E, device=device)
     assert eng.lean
-    if os.environ.get('CL_TUNE_ENVMAJOR'):        # tuning hook: the env-major lean kernel
+    if os.environ.get('CL_TUNE_ENVMAJOR'):        # tuning hooks: kernel variants
         eng.lib.cl_debug_set_envmajor(int(os.environ['CL_TUNE_ENVMAJOR']))
+    if os.environ.get('CL_TUNE_VEC'):
+        eng.lib.cl_debug_set_vec(int(os.environ['CL_TUNE_VEC']))
+    if os.environ.get('CL_TUNE_LEAN'):
+        import ctypes
+        eng.lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
+        eng.lib.cl_debug_set_lean(int(os.environ['CL_TUNE_LEAN']), int(os.environ.get('CL_TUNE_NW', '0')))
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     acts = [torch.rand((eng.n_act_cols, E), device=device, generator=gen) * 2 - 1 for _ in range(8)]
     T = eng.n_steps - 1                          # an episode of T+1 rows has T transitions
