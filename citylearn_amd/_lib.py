@@ -87,6 +87,7 @@ def load() -> ctypes.CDLL:
     lib.cl_step_flex_f32.restype = ctypes.c_int
     lib.cl_step_flex_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, f32p, f32p, f32p, f32p,
                                      ctypes.POINTER(Flex), i32, vp]
+    lib.cl_lstm_generic_step_f32.restype = ctypes.c_int
     lib.cl_rollout_f32.restype = ctypes.c_int
     lib.cl_rollout_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, i64, f32p, f32p, u64,
                                    f32p, f32p, f32p, f32p, f32p, i32, i32, vp]

@@ -1127,6 +1127,39 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
     return CL_OK;
 }
 
+int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* gen_w, int64_t gen_w_stride,
+                             const float* gen_pre, float* gen_hidden, int32_t gen_h, const float* cool_dem, const float* heat_dem,
+                             float* hist, float* indoor_temp, float* comfort, float* kpi_comfort, int32_t t, void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(lstm_w, "lstm_w")) return rc;
+    if (int rc = check_ptr(dyn_pre, "dyn_pre")) return rc;
+    if (int rc = check_ptr(gen_w, "gen_w")) return rc;
+    if (int rc = check_ptr(gen_pre, "gen_pre")) return rc;
+    if (int rc = check_ptr(gen_hidden, "gen_hidden")) return rc;
+    if (int rc = check_ptr(cool_dem, "cool_dem")) return rc;
+    if (int rc = check_ptr(hist, "hist")) return rc;
+    if (int rc = check_ptr(indoor_temp, "indoor_temp")) return rc;
+    if (int rc = check_ptr(kpi_comfort, "kpi_comfort", false)) return rc;
+    if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
+    if (gen_h < 1 || gen_h > CL_LSTM_GEN_HMAX) return fail(CL_EINVAL, "gen_h=%d outside [1, %d]", gen_h, CL_LSTM_GEN_HMAX);
+    const long long need = (long long)gen_h * 8 + 3ll * gen_h * gen_h * 4 + gen_h * 4 + gen_h;
+    if (gen_w_stride < need) return fail(CL_EINVAL, "gen_w_stride=%lld < %lld floats for hidden size %d", (long long)gen_w_stride, need, gen_h);
+    LstmGenArgs g;
+    LstmArgs& a = g.s;
+    a.lstm_w = lstm_w; a.lstm_wb = nullptr; a.dyn_pre = dyn_pre; a.cool_dem = cool_dem; a.hist = hist; a.hidden = nullptr;
+    a.indoor_temp = indoor_temp; a.heat_dem = heat_dem; a.comfort = comfort; a.kpi_comfort = kpi_comfort;
+    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t; a.env_row0 = dims->env_row0;
+    g.gen_w = gen_w; g.gen_pre = gen_pre; g.gen_hidden = gen_hidden; g.H = gen_h; g.gw = gen_w_stride;
+    const size_t lds = (size_t)6 * gen_h * 64 * sizeof(float);           // <= 96 KB of the CU's 160 KB
+    if (lds > 64 * 1024) {
+        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cl_lstm_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(cl_lstm_generic_kernel)");
+    }
+    hipLaunchKernelGGL(cl_lstm_generic_kernel, dim3((dims->n_env + 63) / 64, dims->n_bldg), dim3(64), lds, (hipStream_t)stream, g);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_generic_kernel launch");
+    return CL_OK;
+}
+
 int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* col_src, const float* col_scale,
                    const cl_obs_dep* deps, int32_t n_deps, const float* state, const float* out_bldg, const float* indoor_temp,
                    const float* extra, int32_t n_extra_rows, float* obs, int32_t n_cols,

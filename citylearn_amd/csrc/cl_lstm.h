@@ -38,7 +38,8 @@
 #define CLW_TMAX 3282
 #define CLW_CMIN 3283           /* cooling demand normalisation */
 #define CLW_CMAX 3284
-#define CLW_ACTIVE 3285         /* 1.0 if this building has a dynamics model */
+#define CLW_ACTIVE 3285         /* 0: no dynamics model; 1: LSTM(.. -> <= 16, 2 layers), the matrix-core kernel; 2 / 3: any other
+                                   shape with 1 / 2 layers, cl_lstm_generic_kernel (tables `gen_w`, `gen_pre`, `gen_hidden`) */
 #define CLW_RW_BAND 3286        /* ComfortReward band (NaN = use the data-file comfort band), exponents */
 #define CLW_RW_LOEXP 3287
 #define CLW_RW_HIEXP 3288
@@ -93,6 +94,39 @@ struct LstmArgs {
     const int32_t* __restrict__ env_row0;  // per-env-block episode offsets (cl_dims.env_row0) or null
     int n_env, n_bldg, t;
 };
+
+// What every variant of the stage leaves per (building, env): the indoor temperature, ComfortReward and the streaming
+// discomfort KPIs.
+CL_DEV void lstm_outputs(const LstmArgs& a, const float* __restrict__ W, const float* __restrict__ pre_t, long long off, long long plane,
+                         float temp, float cool) {
+    a.indoor_temp[off] = temp;
+    if (a.comfort) {
+        const float band_p = W[CLW_RW_BAND];
+        const float band = band_p == band_p ? band_p : pre_t[CLPRE_BAND];
+        a.comfort[off] = comfort_reward(temp, cool, a.heat_dem ? a.heat_dem[off] : 0.0f, pre_t[CLPRE_HVAC], pre_t[CLPRE_CSP],
+                                        pre_t[CLPRE_HSP], band, W[CLW_RW_LOEXP], W[CLW_RW_HIEXP]);
+    }
+    if (a.kpi_comfort) {
+        // CostFunction.discomfort / one_minus_thermal_resilience as running sums (cost_function.py:224-353):
+        // deltas count only while the building is occupied; band = evaluate()'s scalar comfort band
+        const bool occupied = pre_t[CLPRE_OCC] > 0.0f;
+        const float band = W[CLW_KPI_BAND];
+        const float cd = occupied ? temp - pre_t[CLPRE_CSP] : 0.0f, hd = occupied ? temp - pre_t[CLPRE_HSP] : 0.0f;
+        const bool hot = cd > band, cold = hd < -band;
+        const float cmag = fabsf(fminf(hd, 0.0f)), hmag = fabsf(fmaxf(cd, 0.0f));
+        float* k = a.kpi_comfort + off;
+        k[CLKC_UNMET * plane] += (hot || cold) ? 1.0f : 0.0f;
+        k[CLKC_COLD * plane] += cold ? 1.0f : 0.0f;
+        k[CLKC_HOT * plane] += hot ? 1.0f : 0.0f;
+        k[CLKC_COLD_MIN * plane] = fminf(k[CLKC_COLD_MIN * plane], cmag);
+        k[CLKC_COLD_MAX * plane] = fmaxf(k[CLKC_COLD_MAX * plane], cmag);
+        k[CLKC_COLD_SUM * plane] += cmag;
+        k[CLKC_HOT_MIN * plane] = fminf(k[CLKC_HOT_MIN * plane], hmag);
+        k[CLKC_HOT_MAX * plane] = fmaxf(k[CLKC_HOT_MAX * plane], hmag);
+        k[CLKC_HOT_SUM * plane] += hmag;
+        k[CLKC_UNMET_OUTAGE * plane] += ((hot || cold) && pre_t[CLPRE_OUTAGE] != 0.0f) ? 1.0f : 0.0f;
+    }
+}
 
 // ---- the gate pre-activations on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) ---------------------------
 // G[64 gates x 32 envs] = W[64 x K] . X[K x 32 envs] per cell, two 32-row blocks {i, f} and {g, o}.  A wavefront owns 32
@@ -182,6 +216,7 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const float* __restrict__ W = a.lstm_w + (long long)b * CL_LSTM_NW;
     const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * 128) / CL_ROW0_BLOCK] : 0;      // workgroup = 128 envs: uniform
     const float* __restrict__ pre_t = a.dyn_pre + ((long long)(a.t + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
+    if (W[CLW_ACTIVE] >= 2.0f) return;                           // another LSTM shape: cl_lstm_generic_kernel owns this building
     const float cool = a.cool_dem[off];
     float temp = pre_t[CLPRE_TRAW];
     if (W[CLW_ACTIVE] != 0.0f) {                                  // block-uniform
@@ -314,34 +349,114 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
         }
         if (live && hh == 0) a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;   // building.py:3027-3028
     }
-    if (live && hh == 0) {
-        a.indoor_temp[off] = temp;
-        if (a.comfort) {
-            const float band_p = W[CLW_RW_BAND];
-            const float band = band_p == band_p ? band_p : pre_t[CLPRE_BAND];
-            a.comfort[off] = comfort_reward(temp, cool, a.heat_dem ? a.heat_dem[off] : 0.0f, pre_t[CLPRE_HVAC], pre_t[CLPRE_CSP],
-                                            pre_t[CLPRE_HSP], band, W[CLW_RW_LOEXP], W[CLW_RW_HIEXP]);
+    if (live && hh == 0) lstm_outputs(a, W, pre_t, off, plane, temp, cool);
+}
+
+// ---- any other LSTM shape (hidden size <= 64, one or two layers): plain fp32 FMAs -------------------------------------
+// baeda_3dem's Building_4 is LSTM(11 -> 50, one layer).  One wave = 64 envs of one building, lane = env.  Hidden and cell
+// states live in LDS as [unit][lane] (conflict-free), the weights arrive by scalar loads in the order they are consumed:
+//   gen_w   [B][GW]       per building: WX [H][8] (gates i, f, g, o of the cooling-demand input, then of the temperature input),
+//                         WHH0 [H][H][4], WIH1 [H][H][4], WHH1 [H][H][4], B1 [H][4], WLIN [H]   (H = the padded hidden size)
+//   gen_pre [T][B][H][4]  env-independent part of the layer-0 gates of (t, building)
+//   gen_hidden [B][4][H][E]  h0, c0, h1, c1 carried across env steps
+// Padded units have zero weights: their state stays 0.  Throughput is that of a fallback (H^2 scalar-fed FMAs per cell).
+struct LstmGenArgs {
+    LstmArgs s;
+    const float* __restrict__ gen_w;
+    const float* __restrict__ gen_pre;
+    float* __restrict__ gen_hidden;
+    int H;          // padded hidden size of the tables
+    long long gw;   // floats per building in gen_w
+};
+
+CL_DEV void lstm_gen_cell(int H, const float* __restrict__ pre /* [H][4] or null */, const float* __restrict__ wx /* [H][8] or null */,
+                          float xc, float xt, const float* __restrict__ w_in /* [H][H][4] or null */, const float* in_h,
+                          const float* __restrict__ w_hh, const float* old_h, float* new_h, float* c, int lane) {
+    for (int u = 0; u < H; ++u) {
+        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+        if (pre) { g0 = pre[u * 4 + 0]; g1 = pre[u * 4 + 1]; g2 = pre[u * 4 + 2]; g3 = pre[u * 4 + 3]; }
+        if (wx) {
+            const float* q = wx + u * 8;
+            g0 = fmaf(q[0], xc, g0); g1 = fmaf(q[1], xc, g1); g2 = fmaf(q[2], xc, g2); g3 = fmaf(q[3], xc, g3);
+            g0 = fmaf(q[4], xt, g0); g1 = fmaf(q[5], xt, g1); g2 = fmaf(q[6], xt, g2); g3 = fmaf(q[7], xt, g3);
         }
-        if (a.kpi_comfort) {
-            // CostFunction.discomfort / one_minus_thermal_resilience as running sums (cost_function.py:224-353):
-            // deltas count only while the building is occupied; band = evaluate()'s scalar comfort band
-            const bool occupied = pre_t[CLPRE_OCC] > 0.0f;
-            const float band = W[CLW_KPI_BAND];
-            const float cd = occupied ? temp - pre_t[CLPRE_CSP] : 0.0f, hd = occupied ? temp - pre_t[CLPRE_HSP] : 0.0f;
-            const bool hot = cd > band, cold = hd < -band;
-            const float cmag = fabsf(fminf(hd, 0.0f)), hmag = fabsf(fmaxf(cd, 0.0f));
-            float* k = a.kpi_comfort + off;
-            k[CLKC_UNMET * plane] += (hot || cold) ? 1.0f : 0.0f;
-            k[CLKC_COLD * plane] += cold ? 1.0f : 0.0f;
-            k[CLKC_HOT * plane] += hot ? 1.0f : 0.0f;
-            k[CLKC_COLD_MIN * plane] = fminf(k[CLKC_COLD_MIN * plane], cmag);
-            k[CLKC_COLD_MAX * plane] = fmaxf(k[CLKC_COLD_MAX * plane], cmag);
-            k[CLKC_COLD_SUM * plane] += cmag;
-            k[CLKC_HOT_MIN * plane] = fminf(k[CLKC_HOT_MIN * plane], hmag);
-            k[CLKC_HOT_MAX * plane] = fmaxf(k[CLKC_HOT_MAX * plane], hmag);
-            k[CLKC_HOT_SUM * plane] += hmag;
-            k[CLKC_UNMET_OUTAGE * plane] += ((hot || cold) && pre_t[CLPRE_OUTAGE] != 0.0f) ? 1.0f : 0.0f;
+        if (w_in) {
+            const float* q = w_in + (long long)u * H * 4;
+            for (int k = 0; k < H; ++k) {
+                const float x = in_h[k * 64 + lane];
+                g0 = fmaf(q[k * 4 + 0], x, g0); g1 = fmaf(q[k * 4 + 1], x, g1); g2 = fmaf(q[k * 4 + 2], x, g2); g3 = fmaf(q[k * 4 + 3], x, g3);
+            }
         }
+        const float* q = w_hh + (long long)u * H * 4;
+        for (int k = 0; k < H; ++k) {
+            const float x = old_h[k * 64 + lane];
+            g0 = fmaf(q[k * 4 + 0], x, g0); g1 = fmaf(q[k * 4 + 1], x, g1); g2 = fmaf(q[k * 4 + 2], x, g2); g3 = fmaf(q[k * 4 + 3], x, g3);
+        }
+        const float cn = sigmoidf_(g1) * c[u * 64 + lane] + sigmoidf_(g0) * tanhf_(g2);      // f c + i g
+        c[u * 64 + lane] = cn;
+        new_h[u * 64 + lane] = sigmoidf_(g3) * tanhf_(cn);                                   // o tanh(c)
+    }
+}
+
+__global__ void __launch_bounds__(64) cl_lstm_generic_kernel(const LstmGenArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // h0 old / new, c0, h1 old / new, c1: 6 x [H][64]
+    const LstmArgs& a = g.s;
+    const int lane = threadIdx.x, b = blockIdx.y, H = g.H;
+    const int e = blockIdx.x * 64 + lane;
+    const bool live = e < a.n_env;
+    const int ec = live ? e : a.n_env - 1;
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const long long off = (long long)b * a.n_env + ec;
+    const float* __restrict__ W = a.lstm_w + (long long)b * CL_LSTM_NW;
+    const float mode = W[CLW_ACTIVE];
+    if (mode < 2.0f) return;                                      // the matrix-core kernel (or nobody) owns this building
+    const int layers = mode >= 3.0f ? 2 : 1;
+    const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * 64) / CL_ROW0_BLOCK] : 0;
+    const float* __restrict__ pre_t = a.dyn_pre + ((long long)(a.t + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
+    const float cool = a.cool_dem[off];
+    float temp = pre_t[CLPRE_TRAW];
+    const float tmin = W[CLW_TMIN], tmax = W[CLW_TMAX], cmin = W[CLW_CMIN], cmax = W[CLW_CMAX];
+    const float cool_n = (cool - cmin) / (cmax - cmin);
+    const int slot = a.t % CL_LSTM_LOOKBACK;
+    if (live) a.hist[(long long)slot * plane + off] = cool_n;                     // building.py:3068-3078
+    float y = pre_t[CLPRE_TNORM];
+    if (a.t >= CL_LSTM_LOOKBACK) {
+        float* h0 = lds, * h0n = lds + H * 64, * c0 = lds + 2 * H * 64, * h1 = lds + 3 * H * 64, * h1n = lds + 4 * H * 64, * c1 = lds + 5 * H * 64;
+        float* hid = g.gen_hidden + ((long long)b * 4 * H) * a.n_env + ec;
+        for (int u = 0; u < H; ++u) {
+            h0[u * 64 + lane] = hid[(long long)(0 * H + u) * a.n_env]; c0[u * 64 + lane] = hid[(long long)(1 * H + u) * a.n_env];
+            h1[u * 64 + lane] = hid[(long long)(2 * H + u) * a.n_env]; c1[u * 64 + lane] = hid[(long long)(3 * H + u) * a.n_env];
+        }
+        const float* __restrict__ G = g.gen_w + (long long)b * g.gw;
+        const float* wx = G, * whh0 = wx + H * 8, * wih1 = whh0 + (long long)H * H * 4, * whh1 = wih1 + (long long)H * H * 4;
+        const float* b1 = whh1 + (long long)H * H * 4, * wlin = b1 + H * 4;
+        for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
+            const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
+            const float* __restrict__ pre = g.gen_pre + ((long long)(time + row0) * a.n_bldg + b) * H * 4;
+            const float xc = s == CL_LSTM_LOOKBACK - 1 ? cool_n : a.hist[(long long)(time % CL_LSTM_LOOKBACK) * plane + off];
+            const float xt = a.hist[(long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) * plane + off];
+            lstm_gen_cell(H, pre, wx, xc, xt, nullptr, nullptr, whh0, h0, h0n, c0, lane);
+            { float* sw = h0; h0 = h0n; h0n = sw; }
+            if (layers == 2) {
+                lstm_gen_cell(H, b1, nullptr, 0.0f, 0.0f, wih1, h0, whh1, h1, h1n, c1, lane);
+                float* sw = h1; h1 = h1n; h1n = sw;
+            }
+        }
+        const float* top = layers == 2 ? h1 : h0;
+        float acc = W[CLW_BLIN];
+        for (int u = 0; u < H; ++u) acc = fmaf(wlin[u], top[u * 64 + lane], acc);
+        y = acc;
+        temp = fmaf(y, tmax - tmin, tmin);                                           // building.py:3031-3037
+        if (live) {
+            for (int u = 0; u < H; ++u) {
+                hid[(long long)(0 * H + u) * a.n_env] = h0[u * 64 + lane]; hid[(long long)(1 * H + u) * a.n_env] = c0[u * 64 + lane];
+                hid[(long long)(2 * H + u) * a.n_env] = h1[u * 64 + lane]; hid[(long long)(3 * H + u) * a.n_env] = c1[u * 64 + lane];
+            }
+        }
+    }
+    if (live) {
+        a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;              // building.py:3027-3028
+        lstm_outputs(a, W, pre_t, off, plane, temp, cool);
     }
 }
 

@@ -57,8 +57,9 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         if d is None:
             continue
         H = d.hidden_size
-        if d.num_layers != 2 or d.lookback != 12 or not 1 <= H <= 16:
-            raise NotImplementedError('the LSTM kernel is specialised for 2 layers, lookback 12 and hidden size <= 16')
+        if d.lookback != 12 or d.num_layers not in (1, 2) or not 1 <= H <= abi.CL_LSTM_GEN_HMAX:
+            raise NotImplementedError(f'LSTM dynamics need lookback 12, 1-2 layers and hidden size <= {abi.CL_LSTM_GEN_HMAX} '
+                                      f'(got lookback {d.lookback}, {d.num_layers} layers, hidden size {H})')
         sd = torch.load(d.filepath, map_location='cpu')
         sd = {k: v.double().numpy() for k, v in sd.get('model_state_dict', sd).items()}
         names = list(d.input_observation_names)
@@ -66,6 +67,15 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         ic, it = names.index('cooling_demand'), names.index('indoor_dry_bulb_temperature')
         if 'heating_demand' in names:
             raise NotImplementedError('heating-demand driven dynamics models are not supported yet')
+        if not (d.num_layers == 2 and H <= 16):
+            # another shape: the generic kernel's tables hold the weights (pack_lstm_generic); this row carries the
+            # normalisation constants, the output bias and the kernel selector
+            lstm_w[i, BLIN] = sd['l_linear.bias'].reshape(-1)[0]
+            lstm_w[i, TMIN], lstm_w[i, TMAX] = lo[it], hi[it]
+            lstm_w[i, CMIN], lstm_w[i, CMAX] = lo[ic], hi[ic]
+            lstm_w[i, ACTIVE] = 2.0 if d.num_layers == 1 else 3.0
+            dyn_pre[:, i, PRE_TNORM] = (np.asarray(b.series['indoor_dry_bulb_temperature'][w], dtype=np.float64) - lo[it]) / (hi[it] - lo[it])
+            continue
 
         # A hidden size below 16 is embedded exactly: the padded units have zero weights and biases, so their cell and
         # hidden state stay 0 (c = 0.5 c + 0.5 tanh(0) = 0, h = 0.5 tanh(0) = 0) and nothing reads them.
@@ -102,6 +112,63 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         dyn_pre[:, i, :64] = pre
         dyn_pre[:, i, PRE_TNORM] = (np.asarray(b.series['indoor_dry_bulb_temperature'][w], dtype=np.float64) - lo[it]) / (hi[it] - lo[it])
     return lstm_w, dyn_pre
+
+
+def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):
+    """Tables of `cl_lstm_generic_step_f32` for the buildings `pack_lstm` marked ACTIVE = 2 / 3 (LSTM shapes other than two
+    layers of <= 16 units): ``(gen_w [B, GW] f32, gen_pre [T, B, H, 4] f32, H)`` with H the largest hidden size among them, or
+    ``None`` when there is no such building.  Layouts: csrc/cl_lstm.h (gate order i, f, g, o)."""
+    todo = [(i, b) for i, b in enumerate(spec.buildings)
+            if b.dynamics is not None and not (b.dynamics.num_layers == 2 and b.dynamics.hidden_size <= 16)]
+    if not todo:
+        return None
+    B, T = len(spec.buildings), tables.n_steps
+    w = slice(tables.start, tables.end + 1)
+    H = max(b.dynamics.hidden_size for _, b in todo)
+    gw = H * 8 + 3 * H * H * 4 + H * 4 + H
+    gen_w = np.zeros((B, gw), dtype=np.float32)
+    gen_pre = np.zeros((T, B, H, 4), dtype=np.float32)
+    o_wx, o_hh0 = 0, H * 8
+    o_ih1, o_hh1 = o_hh0 + H * H * 4, o_hh0 + 2 * H * H * 4
+    o_b1 = o_hh0 + 3 * H * H * 4
+    o_lin = o_b1 + H * 4
+    for i, b in todo:
+        d = b.dynamics
+        h = d.hidden_size
+        sd = torch.load(d.filepath, map_location='cpu')
+        sd = {k: v.double().numpy() for k, v in sd.get('model_state_dict', sd).items()}
+        names = list(d.input_observation_names)
+        lo, hi = np.array(d.input_normalization_minimum, dtype=np.float64), np.array(d.input_normalization_maximum, dtype=np.float64)
+        ic, it = names.index('cooling_demand'), names.index('indoor_dry_bulb_temperature')
+
+        def ug(m):                                      # torch rows [i; f; g; o] x h (x cols)  ->  [unit, gate, (cols)], padded to H units
+            m = np.asarray(m, dtype=np.float64).reshape((4, h) + np.shape(m)[1:])
+            out = np.zeros((H, 4) + m.shape[2:])
+            out[:h] = np.moveaxis(m, 0, 1)
+            return out
+
+        def square(m):                                  # [4h, h] -> [unit u][input k][gate]
+            t = ug(m)                                   # [H, 4, h]
+            out = np.zeros((H, H, 4))
+            out[:, :h, :] = np.moveaxis(t, 1, 2)
+            return out
+
+        wih0 = ug(sd['l_lstm.weight_ih_l0'])            # [H, 4, n_in]
+        gen_w[i, o_wx:o_wx + H * 8] = np.concatenate([wih0[:, :, ic], wih0[:, :, it]], axis=1).reshape(-1)
+        gen_w[i, o_hh0:o_hh0 + H * H * 4] = square(sd['l_lstm.weight_hh_l0']).reshape(-1)
+        if d.num_layers == 2:
+            gen_w[i, o_ih1:o_ih1 + H * H * 4] = square(sd['l_lstm.weight_ih_l1']).reshape(-1)
+            gen_w[i, o_hh1:o_hh1 + H * H * 4] = square(sd['l_lstm.weight_hh_l1']).reshape(-1)
+            gen_w[i, o_b1:o_b1 + H * 4] = ug(sd['l_lstm.bias_ih_l1'] + sd['l_lstm.bias_hh_l1']).reshape(-1)
+        gen_w[i, o_lin:o_lin + h] = sd['l_linear.weight'].reshape(-1)
+        pre = np.tile(ug(sd['l_lstm.bias_ih_l0'] + sd['l_lstm.bias_hh_l0'])[None], (T, 1, 1))        # [T, H, 4]
+        for k, name in enumerate(names):
+            if k in (ic, it):
+                continue
+            x = (_exo_feature(b, name, w) - lo[k]) / (hi[k] - lo[k])
+            pre += x[:, None, None] * wih0[None, :, :, k]
+        gen_pre[:, i] = pre
+    return gen_w, gen_pre, H
 
 
 def _bf16_split3(x: np.ndarray) -> np.ndarray:
@@ -160,6 +227,15 @@ class LSTMStage:
         self.indoor_temp = torch.zeros((B, E), dtype=torch.float32, device=dev)
         self.comfort = torch.zeros((B, E), dtype=torch.float32, device=dev)
         self.kpi_comfort = torch.zeros((abi.CL_NKC, B, E), dtype=torch.float32, device=dev) if kpi else None
+        # buildings with another LSTM shape (ACTIVE = 2 / 3): tables and carried state of the generic kernel
+        self.generic = None
+        packed = pack_lstm_generic(spec, tables)
+        if packed is not None:
+            gen_w, gen_pre, gen_h = packed
+            self.generic = dict(w=torch.from_numpy(gen_w).to(dev), pre=torch.from_numpy(gen_pre).to(dev), h=int(gen_h),
+                                hidden=torch.zeros((B, 4, gen_h, E), dtype=torch.float32, device=dev))
+            self.lib.cl_lstm_generic_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] + [
+                ctypes.c_void_p] * 2 + [ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_void_p]
         self.lib.cl_lstm_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 10 + [ctypes.c_int32, ctypes.c_void_p]
         self.lib.cl_lstm_reset_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 4
         self.reset()
@@ -171,6 +247,8 @@ class LSTMStage:
         with torch.cuda.device(self.engine.device):
             _lib.check(self.lib.cl_lstm_reset_f32(ctypes.byref(self.engine.dims), self.hist.data_ptr(), self.hidden.data_ptr(),
                                                   None if self.kpi_comfort is None else self.kpi_comfort.data_ptr(), self._stream()))
+            if self.generic is not None:
+                self.generic['hidden'].zero_()
 
     def step(self, t: int, cool_dem: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t."""
@@ -184,6 +262,11 @@ class LSTMStage:
         head, tail, own_cd = self._args
         with e._on_device():
             rc = self.lib.cl_lstm_step_f32(*head, own_cd if cool_dem is None else cool_dem.data_ptr(), *tail, int(t), e._stream())
+            if not rc and self.generic is not None:
+                gn = self.generic
+                rc = self.lib.cl_lstm_generic_step_f32(head[0], head[1], head[3], gn['w'].data_ptr(), gn['w'].shape[1], gn['pre'].data_ptr(),
+                                                       gn['hidden'].data_ptr(), gn['h'], own_cd if cool_dem is None else cool_dem.data_ptr(),
+                                                       None, tail[1], tail[3], tail[4], tail[5], int(t), e._stream())
         if rc:
             _lib.check(rc)
         return self.indoor_temp

@@ -310,6 +310,18 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
                      const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,
                      float* kpi_comfort, int32_t t, void* stream);
 
+/* LSTM shapes the matrix-core kernel does not cover (hidden size up to CL_LSTM_GEN_HMAX, one or two layers; e.g. baeda_3dem's
+ * Building_4 = LSTM(11 -> 50, 1 layer)): buildings whose lstm_w[CLW_ACTIVE] is 2 (one layer) or 3 (two layers) are skipped by
+ * cl_lstm_step_f32 and advanced by this call (same inputs / outputs, plain fp32 FMAs; call it right after cl_lstm_step_f32).
+ *   gen_w      [n_bldg][gen_w_stride]   WX [H][8], WHH0 [H][H][4], WIH1 [H][H][4], WHH1 [H][H][4], B1 [H][4], WLIN [H]  (gate order i, f, g, o;
+ *                                        H = gen_h, the padded hidden size; csrc/cl_lstm.h, packer dynamics.pack_lstm_generic)
+ *   gen_pre    [n_ts_rows][n_bldg][gen_h][4]  env-independent part of the layer-0 gates
+ *   gen_hidden [n_bldg][4][gen_h][n_env]      h0, c0, h1, c1 carried across env steps (zero at episode start) */
+#define CL_LSTM_GEN_HMAX 64
+int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* gen_w, int64_t gen_w_stride,
+                             const float* gen_pre, float* gen_hidden, int32_t gen_h, const float* cool_dem, const float* heat_dem,
+                             float* hist, float* indoor_temp, float* comfort, float* kpi_comfort, int32_t t, void* stream);
+
 /* ---- observation epilogue ----
  * Writes the observation tensor obs[n_env][n_cols] (one contiguous vector per environment, the layout a policy
  * network consumes) for observation row `row` of the episode.  Replaces the per-building dictionary building of

@@ -16,18 +16,17 @@ pytestmark = pytest.mark.gpu
 def test_lstm_stage_fed_with_reference_cooling(name):
     """Isolates the stage: the delivered cooling of every step comes from the reference; temperatures within 1e-4 C
     relative and ComfortReward within 1e-4 (+1e-4) of the reference for every step and building (2023: LSTM(13 -> 16),
-    3 and 6 buildings; baeda_3dem: LSTM(11 -> 8) embedded in the 16-wide kernel)."""
+    3 and 6 buildings; baeda_3dem: three LSTM(11 -> 8, 2 layers) embedded in the 16-wide kernel + one LSTM(11 -> 50, 1 layer))."""
     g = golden(name)
     spec = g.spec()
     cols = list(range(len(spec.buildings)))
     if name == 's_baeda':
-        # the fourth baeda building uses a one-layer LSTM(11 -> 50): outside what the MFMA kernel is specialised for
-        # (2 layers, hidden <= 16) -- `pack_lstm` refuses it loudly; run the stage on the other three
-        from citylearn_amd.dynamics import pack_lstm
-        with pytest.raises(NotImplementedError, match='specialised'):
-            pack_lstm(spec, spec.episode_tables(0))
-        cols = [0, 1, 2]
-        spec = g.spec(buildings=[spec.buildings[i].name for i in cols])
+        # the fourth baeda building is a one-layer LSTM(11 -> 50): the generic kernel (cl_lstm_generic_step_f32) runs beside the
+        # matrix-core kernel of the other three
+        from citylearn_amd.dynamics import pack_lstm, pack_lstm_generic
+        lw, _ = pack_lstm(spec, spec.episode_tables(0))
+        assert lw[:, abi.CLW_ACTIVE if hasattr(abi, 'CLW_ACTIVE') else 3285].tolist() == [1.0, 1.0, 1.0, 2.0]
+        assert pack_lstm_generic(spec, spec.episode_tables(0))[2] == 50
     tab = spec.episode_tables(0)
     attrs = spec.reward_function.get('attributes') or {}
     E = 64
@@ -141,3 +140,27 @@ def test_bf16_mfma_operand_layout():
     lib.cl_debug_mfma_bf16_probe.argtypes = [ctypes.c_void_p] * 4
     _lib.check(lib.cl_debug_mfma_bf16_probe(a.data_ptr(), b.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream))
     np.testing.assert_array_equal(d.cpu().numpy(), (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32))
+
+
+def test_env_on_the_whole_baeda_district():
+    """baeda_3dem end to end (4 buildings; the fourth one's LSTM(11 -> 50, 1 layer) runs in the generic kernel): the
+    reference's rewards, predicted temperatures and observations for the fixture's action sequence, free-running."""
+    from citylearn_amd.citylearn import CityLearnEnv
+    g = golden('s_baeda')
+    env = CityLearnEnv(g.schema_path)
+    assert len(env.buildings) == 4 and env.observation_names == g.facts['observation_names']
+    K = g.facts['steps']
+    names = env.action_names
+    got, temps = [], []
+    for t in range(K):
+        a = [float(x) for x in g.ref['actions'][t]]
+        acts, p = [], 0
+        for n in names:
+            acts.append(a[p:p + len(n)]); p += len(n)
+        _, r, _, _, _ = env.step(acts)
+        got.append(r)
+        temps.append(env._hist['indoor_temp'][-1])
+    got, ref = np.array(got, dtype=np.float64), g.ref['env_rewards'][:K]
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref) / (1e-3 + 1e-3 * np.abs(ref))) < 10.0
+    assert np.max(np.abs(np.array(temps) - g.ref['indoor_temp'][:K])) < 5e-3
