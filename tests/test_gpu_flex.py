@@ -261,3 +261,37 @@ def test_observation_tensor_with_charging_constraint_columns():
             np.testing.assert_allclose(obs[0].cpu().numpy(), ref[t + 1], rtol=1e-5, atol=5e-4 if not normalize else 1e-4, err_msg=f't={t}')
         cols = [i for i, n in enumerate([n for l in env.observation_names for n in l]) if 'headroom' in n or 'violation' in n]
         assert len(cols) == 4 and float(obs[:, cols].std(dim=0).max()) > 0          # per-env values
+
+
+def test_flex_entry_points_validate_their_arguments():
+    """Error behaviour of the flexible-load C-ABI: negative codes + message, never a crash."""
+    import ctypes
+    from citylearn_amd import _lib, abi
+    from citylearn_amd.engine import StepEngine
+    g = golden('g2022_evs')
+    tab = g.spec().episode_tables(0)
+    eng = StepEngine(tab, 64, reward='MARL')
+    lib = eng.lib
+    a = torch.zeros((eng.n_act_cols, 64), device='cuda')
+    args = lambda flex, t=0: (ctypes.byref(eng.dims), eng.params.data_ptr(), eng.ts.data_ptr(), eng.state.data_ptr(), a.data_ptr(),
+                              a.stride(0), a.stride(1), eng.out_bldg.data_ptr(), eng.out_env.data_ptr(), None, None, flex, t, None)
+    good = eng.flex
+    assert lib.cl_step_flex_f32(*args(ctypes.byref(good))) == 0
+    bad = _lib.Flex.from_buffer_copy(good)
+    bad.flex_out = None
+    assert lib.cl_step_flex_f32(*args(ctypes.byref(bad))) == abi.CL_ENULL and b'flex_out' in lib.cl_last_error()
+    bad = _lib.Flex.from_buffer_copy(good)
+    bad.n_rows = 3                                                   # fewer schedule rows than step-table rows
+    assert lib.cl_step_flex_f32(*args(ctypes.byref(bad))) == abi.CL_ERANGE
+    bad = _lib.Flex.from_buffer_copy(good)
+    bad.n_flex_bldg = 0
+    assert lib.cl_flex_reset_f32(ctypes.byref(eng.dims), ctypes.byref(bad), None) == abi.CL_EINVAL
+    assert lib.cl_flex_reset_f32(ctypes.byref(eng.dims), None, None) == abi.CL_ENULL
+    assert lib.cl_step_flex_f32(*args(ctypes.byref(good), t=eng.n_steps)) == abi.CL_ERANGE
+    # the EV reward needs the flexible-load tables; the plain entry point refuses it
+    ev = StepEngine(tab, 64, reward='Electric_Vehicles_Reward_Function')
+    rc = lib.cl_step_f32(ctypes.byref(ev.dims), ev.params.data_ptr(), ev.ts.data_ptr(), ev.state.data_ptr(), a.data_ptr(), a.stride(0), a.stride(1),
+                         ev.out_bldg.data_ptr(), ev.out_env.data_ptr(), None, None, 0, None)
+    assert rc == abi.CL_EINVAL and b'CLR_EV' in lib.cl_last_error()
+    with pytest.raises(NotImplementedError):
+        eng.rollout(4, torch.zeros((4, eng.n_act_cols, 64), device='cuda'))
