@@ -17,8 +17,12 @@ The output of :func:`load_district` is a :class:`DistrictSpec` holding exact (fl
 parameters and the full simulation-period series; :meth:`DistrictSpec.episode_tables` packs one episode
 window into the float32 ``params`` / ``ts`` tables described in ``include/citylearn_amd.h``.
 
-Out of scope (raises ``NotImplementedError``): EV chargers, washing machines, occupant models, PV / battery
-autosizing (needs PySAM / external sizing tables) -- SURVEY.md section 2 rows 13-15.
+* EV chargers / electric vehicles / washing machines / charging constraints (specs here, device tables in ``flex.py``)
+                                                       /root/reference/citylearn/citylearn.py:2277-2308, 2558-2641,
+                                                       data.py:663-820, building.py:764-845
+
+Out of scope (raises ``NotImplementedError``): occupant models, PV / battery autosizing (needs PySAM / external sizing
+tables), stochastic data files (``noise_std``), charger efficiency curves.
 """
 from __future__ import annotations
 

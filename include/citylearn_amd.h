@@ -27,6 +27,8 @@
  *   out_bldg [CL_NO][n_bldg][n_env]    f32, per-building outputs of the step (cl_out planes)
  *   out_env  [CL_NQ][n_env]            f32, district sums over buildings (cl_envout planes)
  *   kpi_bldg [CL_NKB][n_bldg][n_env], kpi_env [CL_NKE][n_env]   optional streaming KPI accumulators
+ * Adjacent stages keep their own tables and planes, described at their entry points below: the LSTM indoor-temperature
+ * stage (cl_lstm_*), the observation epilogue (cl_observe_f32), flexible loads = EV chargers / EVs / washing machines (cl_flex).
  */
 #ifndef CITYLEARN_AMD_H
 #define CITYLEARN_AMD_H
