@@ -54,6 +54,19 @@ CL_DEV float flex_begin_soc(const FlexArgs& a, const float* __restrict__ ev_row,
     return fminf(fmaxf(prev * fminf(fmaxf(m, 0.6f), 1.4f), 0.0f), 1.0f);
 }
 
+// np.interp(x, xs, ys) over the n <= CL_CURVE_MAX points of a charger efficiency curve (end values outside the range)
+CL_DEV float flex_curve(const uint32_t* __restrict__ cp, int n_slot, int x_slot, int y_slot, float x) {
+    const int n = (int)cp[n_slot];
+    float y = cl::pw(cp, y_slot);
+    for (int k = 1; k < n; ++k) {                 // wave-uniform trip count
+        const float x0 = cl::pw(cp, x_slot + k - 1), x1 = cl::pw(cp, x_slot + k);
+        const float y0 = cl::pw(cp, y_slot + k - 1), y1 = cl::pw(cp, y_slot + k);
+        const float seg = fmaf((x - x0) * cl::rcp(x1 - x0), y1 - y0, y0);
+        y = x >= x1 ? y1 : (x > x0 ? seg : y);
+    }
+    return y;
+}
+
 // VEC consecutive envs per lane (float4 plane accesses at VEC = 4: a quarter of the waves walk the scalar table chain).
 template <int VEC>
 __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
@@ -201,7 +214,8 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
         const uint32_t* __restrict__ cp = cp0 + j * CL_NCP;
         const float* __restrict__ cr = cr0 + j * CL_NCF;
         const int k = (int)hdr[j];
-        const float eff = cl::pw(cp, CLC_EFF), inv_eff = cl::pw(cp, CLC_INV_EFF), dt = cl::pw(cp, CLC_DT_HOURS);
+        const float eff_c = cl::pw(cp, CLC_EFF), inv_eff_c = cl::pw(cp, CLC_INV_EFF), dt = cl::pw(cp, CLC_DT_HOURS);
+        const bool curved = cp[CLC_CURVE_CHARGE_N] != 0u || cp[CLC_CURVE_DISCHARGE_N] != 0u;
         const float max_c = cl::pw(cp, CLC_MAX_CHARGE), min_c = cl::pw(cp, CLC_MIN_CHARGE);
         const float max_d = cl::pw(cp, CLC_MAX_DISCHARGE), min_d = cl::pw(cp, CLC_MIN_DISCHARGE);
         float energy[VEC], cons[VEC];
@@ -229,6 +243,15 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
                 if (act[j][i] != 0.0f) {
                     cl::State S;
                     S.soc = prev; S.eff = ef[j][i]; S.degcap = deg[j][i]; S.cs = S.hs = S.ds = 0.0f;
+                    float eff = eff_c, inv_eff = inv_eff_c;
+                    if (curved) {                   // Charger.get_efficiency(|action|, charging)
+                        const bool chg = act[j][i] > 0.0f;
+                        const float on_curve = chg ? flex_curve(cp, CLC_CURVE_CHARGE_N, CLC_CURVE_CHARGE_X, CLC_CURVE_CHARGE_Y, fabsf(act[j][i]))
+                                                   : flex_curve(cp, CLC_CURVE_DISCHARGE_N, CLC_CURVE_DISCHARGE_X, CLC_CURVE_DISCHARGE_Y, fabsf(act[j][i]));
+                        const bool has = cp[chg ? CLC_CURVE_CHARGE_N : CLC_CURVE_DISCHARGE_N] != 0u;
+                        eff = has ? on_curve : eff_c;
+                        inv_eff = has ? 1.0f / on_curve : inv_eff_c;
+                    }
                     const float to_battery = energy[i] * (act[j][i] > 0.0f ? eff : inv_eff);
                     const float eb = cl::battery_energy(P, to_battery * P.r, S);      // Battery.charge (energy_model.py:1027-1057)
                     now = S.soc; ef[j][i] = S.eff; deg[j][i] = S.degcap;

@@ -158,6 +158,13 @@ def pack_flex(spec, start: int, n_rows: int, aligned: bool = False) -> Optional[
         cpf[j, abi.CLC_MAX_DISCHARGE], cpf[j, abi.CLC_MIN_DISCHARGE] = c.max_discharging_power, c.min_discharging_power
         cpf[j, abi.CLC_EFF], cpf[j, abi.CLC_INV_EFF] = c.efficiency, 1.0 / c.efficiency
         cpf[j, abi.CLC_DT_HOURS] = spec.seconds_per_time_step / 3600.0
+        for curve, n_slot, x_slot, y_slot in ((c.charge_efficiency_curve, abi.CLC_CURVE_CHARGE_N, abi.CLC_CURVE_CHARGE_X, abi.CLC_CURVE_CHARGE_Y),
+                                              (c.discharge_efficiency_curve, abi.CLC_CURVE_DISCHARGE_N, abi.CLC_CURVE_DISCHARGE_X, abi.CLC_CURVE_DISCHARGE_Y)):
+            if curve is not None:
+                k = curve.shape[1]
+                cpi[j, n_slot] = k
+                cpf[j, x_slot:x_slot + k] = curve[0]
+                cpf[j, y_slot:y_slot + k] = curve[1]
         w = slice(first, first + R)
         charger_ts[:, j, abi.CLCT_REQUIRED_SOC] = c.series['electric_vehicle_required_soc_departure'][w]
         charger_ts[:, j, abi.CLCT_DEPARTURE] = c.series['electric_vehicle_departure_time'][w]

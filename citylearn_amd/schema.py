@@ -22,7 +22,7 @@ window into the float32 ``params`` / ``ts`` tables described in ``include/cityle
                                                        data.py:663-820, building.py:764-845
 
 Out of scope (raises ``NotImplementedError``): occupant models, PV / battery autosizing (needs PySAM / external sizing
-tables), stochastic data files (``noise_std``), charger efficiency curves.
+tables), stochastic data files (``noise_std``).
 """
 from __future__ import annotations
 
@@ -266,6 +266,8 @@ class ChargerSpec:
     max_discharging_power: float
     min_discharging_power: float
     series: Dict[str, np.ndarray]
+    charge_efficiency_curve: Optional[np.ndarray] = None       # [2, N] power fractions / efficiencies (np.interp), or None
+    discharge_efficiency_curve: Optional[np.ndarray] = None
 
     @property
     def action_name(self) -> str:
@@ -714,8 +716,13 @@ def _load_chargers(bs: Mapping[str, Any], root: str, sim_start: int, sim_end: in
         if cfg.get('noise_std', 0.0):
             raise NotImplementedError('charger noise_std > 0 (stochastic schedules) is not supported yet')
         attrs = dict(cfg.get('attributes') or {})
-        if attrs.get('charge_efficiency_curve') is not None or attrs.get('discharge_efficiency_curve') is not None:
-            raise NotImplementedError('charger efficiency curves are not supported yet')
+        curves = {}
+        for key in ('charge_efficiency_curve', 'discharge_efficiency_curve'):       # electric_vehicle_charger.py:190-202
+            curve = attrs.get(key)
+            curves[key] = None if curve is None else np.array(curve, dtype=float).T
+            if curves[key] is not None and (curves[key].shape[0] != 2 or not 1 <= curves[key].shape[1] <= 8
+                                            or np.any(np.diff(curves[key][0]) <= 0)):
+                raise NotImplementedError(f'charger {charger_id}: {key} needs 1-8 points with increasing power levels')
         frame = pd.read_csv(os.path.join(root, cfg['charger_simulation'])).iloc[sim_start:sim_end + 1]
         cols = list(frame.values.T)               # positional, like the reference (citylearn.py:2289)
         state = np.array([int(str(v)) if str(v).isdigit() else np.nan for v in cols[0]], dtype=float)
@@ -736,6 +743,7 @@ def _load_chargers(bs: Mapping[str, Any], root: str, sim_start: int, sim_end: in
             min_charging_power=dflt(attrs.get('min_charging_power'), 0.0),
             max_discharging_power=dflt(attrs.get('max_discharging_power'), 50.0),
             min_discharging_power=dflt(attrs.get('min_discharging_power'), 0.0),
+            charge_efficiency_curve=curves['charge_efficiency_curve'], discharge_efficiency_curve=curves['discharge_efficiency_curve'],
             series={'electric_vehicle_charger_state': state, 'electric_vehicle_id': ev_id,
                     'electric_vehicle_battery_capacity_kwh': capacity, 'current_soc': current_soc,
                     'electric_vehicle_departure_time': departure, 'electric_vehicle_required_soc_departure': pct(cols[5]),

@@ -387,12 +387,17 @@ enum cl_ev_feat {
 #define CLEV_ZERO  (-1.0f)
 #define CLEV_DRIFT (-2.0f)
 #define CLEV_KEEP  (-3.0f)
-#define CL_NCP 8
+#define CL_NCP 48
+#define CL_CURVE_MAX 8      /* points per charger efficiency curve */
 enum cl_charger_param {
     CLC_ACT_COL = 0,      /* i32 action column, -1 = inactive */
     CLC_MAX_CHARGE, CLC_MIN_CHARGE, CLC_MAX_DISCHARGE, CLC_MIN_DISCHARGE,   /* kW */
     CLC_EFF, CLC_INV_EFF, /* Charger.efficiency and its reciprocal */
-    CLC_DT_HOURS          /* seconds_per_time_step / 3600 */
+    CLC_DT_HOURS,         /* seconds_per_time_step / 3600 */
+    /* optional charge / discharge efficiency curves over |action| (Charger.get_efficiency = np.interp,
+       electric_vehicle_charger.py:264-295): point count (i32, 0 = use CLC_EFF), then CL_CURVE_MAX x, CL_CURVE_MAX y */
+    CLC_CURVE_CHARGE_N = 8, CLC_CURVE_CHARGE_X = 9, CLC_CURVE_CHARGE_Y = 17,
+    CLC_CURVE_DISCHARGE_N = 25, CLC_CURVE_DISCHARGE_X = 26, CLC_CURVE_DISCHARGE_Y = 34
 };
 #define CL_MAXC 4           /* charger slots per building */
 #define CL_MAXW 2           /* washing-machine slots per building */

@@ -74,7 +74,8 @@ class _Charger:
         c = self.spec
         if action != 0:
             charging = action > 0
-            eff = c.efficiency
+            curve = c.charge_efficiency_curve if charging else c.discharge_efficiency_curve
+            eff = c.efficiency if curve is None else np.interp(abs(action), curve[0], curve[1])     # get_efficiency (264-295)
             if charging:
                 power = action * c.max_charging_power
                 energy = power * self.dt_hours

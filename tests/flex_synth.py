@@ -12,8 +12,12 @@ HEADER = ('electric_vehicle_charger_state,electric_vehicle_id,electric_vehicle_b
           'electric_vehicle_estimated_soc_arrival')
 
 
-def make(src: Path, dst: Path, seed: int, rows: int = 240) -> Path:
-    """Copy the mini dataset at `src` to `dst` and overwrite its charger schedules.  Returns the schema path."""
+CURVE = [[0, 0.83], [0.3, 0.83], [0.7, 0.9], [0.8, 0.9], [1, 0.85]]       # the docstring example of Charger (electric_vehicle_charger.py:31-34)
+
+
+def make(src: Path, dst: Path, seed: int, rows: int = 240, curves: bool = False) -> Path:
+    """Copy the mini dataset at `src` to `dst` and overwrite its charger schedules.  Returns the schema path.
+    `curves`: also give every other charger a charge efficiency curve and every third one a discharge curve."""
     import json
     if dst.exists():
         shutil.rmtree(dst)
@@ -51,4 +55,12 @@ def make(src: Path, dst: Path, seed: int, rows: int = 240) -> Path:
             visit += 1
     for (b, c, fname), rows_ in zip(chargers, table):
         (dst / fname).write_text(HEADER + '\n' + '\n'.join(','.join(str(x) for x in r) for r in rows_) + '\n')
+    if curves:
+        for j, (b, c, _) in enumerate(chargers):
+            attrs = schema['buildings'][b]['chargers'][c]['attributes']
+            if j % 2 == 0:
+                attrs['charge_efficiency_curve'] = CURVE
+            if j % 3 == 0:
+                attrs['discharge_efficiency_curve'] = [[0, 0.8], [0.5, 0.92], [1, 0.88]]
+        (dst / 'schema.json').write_text(json.dumps(schema))
     return dst / 'schema.json'

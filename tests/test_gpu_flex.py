@@ -297,7 +297,7 @@ def test_flex_entry_points_validate_their_arguments():
         eng.rollout(4, torch.zeros((4, eng.n_act_cols, 64), device='cuda'))
 
 
-@pytest.mark.parametrize('seed', [1, 2, 3])
+@pytest.mark.parametrize('seed', [1, 2, 3, 4])
 def test_synthetic_charger_schedules_match_the_oracle(seed, tmp_path):
     """Connection patterns the shipped dataset does not contain (tests/flex_synth.py: EVs swapping chargers, arrivals with and
     without an announced SoC, back-to-back connections, an unused charger), free-running, per-env random actions with exact
@@ -309,7 +309,7 @@ def test_synthetic_charger_schedules_match_the_oracle(seed, tmp_path):
     from oracle.flex_oracle import FlexDistrictOracle
     from flex_synth import make
     g = golden('g2022_evs')
-    schema = make(Path(g.schema_path).parent, tmp_path / 'synth', seed)
+    schema = make(Path(g.schema_path).parent, tmp_path / 'synth', seed, curves=seed % 2 == 0)     # even seeds: charger efficiency curves
     spec = load_district(str(schema))
     for k, ev in enumerate(spec.electric_vehicles):
         ev.battery.initial_soc = 0.1 + 0.1 * k
