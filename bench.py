@@ -189,7 +189,8 @@ def main():
                        'reward': 'RewardFunction'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'cl_step_kernel<VEC, lean>', 'launch_us': launch_s * 1e6,
+                         'kernel': 'cl_step_envmajor_kernel<20>' if E >= 131072 else 'cl_step_lean_kernel<4, false>',
+                         'launch_us': launch_s * 1e6,
                          'algorithmic_bytes_per_unit': bytes_per_unit, 'units_per_launch': units_per_step},
         }
         if world == 1 and not args.no_cpu_baseline:
