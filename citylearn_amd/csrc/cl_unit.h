@@ -34,6 +34,7 @@ namespace cl {
 inline float rcp(float x) { return 1.0f / x; }
 inline float rsq(float x) { return 1.0f / sqrtf(x); }
 inline float fsqrt(float x) { return sqrtf(x); }
+inline float med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline float __powf(float a, float b) { return powf(a, b); }
 }
@@ -44,6 +45,7 @@ namespace cl {
 CL_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 CL_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 CL_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+CL_DEV float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 }
 #endif
 #define CL_ZDP 1e-6f          // data.py:19 ZERO_DIVISION_PLACEHOLDER
@@ -177,9 +179,12 @@ CL_DEV float battery_energy(const BattP& B, float E, State& S) {
     const float irte = rsq(eff), rte = eff * irte;
     // StorageDevice.charge with the nominal capacity (energy_model.py:719-768)
     e *= B.r;
-    const float e_fin = e >= 0.0f ? fminf(fmaf(e, rte, e_init), B.cap) : fmaxf(0.0f, fmaf(e, irte, e_init));
-    const float d = e_fin - e_init;
-    const float eb = d * (d >= 0.0f ? irte : rte);
+    // charge: min(e_init + e rte, cap); discharge: max(0, e_init + e / rte).  0 <= e_init <= cap, so the unused bound of
+    // either branch is inactive and both collapse into one clamp of one fma (same bits, three instructions fewer per unit)
+    const bool chg = e >= 0.0f;
+    const float e_fin = med3(fmaf(e, chg ? rte : irte, e_init), 0.0f, B.cap);
+    const float d = e_fin - e_init;                                                      // d >= 0 exactly when charging (or d == 0)
+    const float eb = d * (chg ? irte : rte);
     // degrade with the pre-step degraded capacity (energy_model.py:1130-1141)
     S.degcap = fmaxf(S.degcap - B.degk * fabsf(eb) * rcp(fmaxf(S.degcap, CL_ZDP)), 0.0f);
     S.eff = eff;
