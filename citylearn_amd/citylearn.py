@@ -28,6 +28,18 @@ from .schema import DistrictSpec, load_district
 from .spaces import Box
 
 
+class EvaluationCondition:
+    """Series selectors of `CityLearnEnv.evaluate` (reference `EvaluationCondition`, citylearn.py:29-50): the value is the
+    suffix of the building property `net_electricity_consumption<suffix>` the control / baseline scenario reads."""
+    WITH_STORAGE_AND_PV = ''
+    WITHOUT_STORAGE_BUT_WITH_PV = '_without_storage'
+    WITHOUT_STORAGE_AND_PV = '_without_storage_and_pv'
+    WITH_STORAGE_AND_PARTIAL_LOAD_AND_PV = ''
+    WITHOUT_STORAGE_BUT_WITH_PARTIAL_LOAD_AND_PV = '_without_storage'
+    WITHOUT_STORAGE_AND_PARTIAL_LOAD_BUT_WITH_PV = '_without_storage_and_partial_load'
+    WITHOUT_STORAGE_AND_PARTIAL_LOAD_AND_PV = '_without_storage_and_partial_load_and_pv'
+
+
 class _BuildingView:
     """Read-only per-building accessor (`env.buildings[i]`), the subset of `citylearn.building.Building` that
     callers of the hot path use: names, metadata, spaces and the simulated series up to the current step."""
@@ -234,7 +246,7 @@ class CityLearnEnv:
         self._t = 0
         self.reward_function.reset()
         self.__rewards = [[]]
-        self._hist: Dict[str, list] = {k: [] for k in ('net', 'base_net', 'soc', 'cost', 'emission', 'expected', 'served',
+        self._hist: Dict[str, list] = {k: [] for k in ('net', 'base_net', 'net_ws', 'soc', 'cost', 'emission', 'expected', 'served',
                                                        'd_net', 'd_cost', 'd_emission', 'indoor_temp')}
         self._obs_tables = self._layout.episode(self._tables)
         return self.observations, self.get_info()
@@ -272,6 +284,7 @@ class CityLearnEnv:
         self._last_state, self._last_out = st, ob
         h = self._hist
         h['net'].append(ob[abi.CLO_NET]); h['base_net'].append(ob[abi.CLO_BASE_NET]); h['soc'].append(st[abi.CLS_B_SOC])
+        h['net_ws'].append(ob[abi.CLO_NET_WS])
         h['expected'].append(ob[abi.CLO_EXPECTED]); h['served'].append(ob[abi.CLO_SERVED])
         ts = self._tables.ts[t]
         net64 = ob[abi.CLO_NET].astype(np.float64)
@@ -377,16 +390,41 @@ class CityLearnEnv:
 
     # ---- evaluate --------------------------------------------------------------------------------------------
     def evaluate(self, control_condition=None, baseline_condition=None, comfort_band: float = None):
-        """Cost functions normalised by the no-control baseline (citylearn.py:1136-1323).  Only the default
-        evaluation conditions are supported: control = with storage (and partial load) and PV, baseline = without
-        storage (and partial load) but with PV.  Returns a ``pandas.DataFrame[cost_function, value, name, level]``."""
-        if control_condition is not None or baseline_condition is not None:
-            raise NotImplementedError('only the default evaluation conditions are implemented')
+        """Cost functions normalised by the no-control baseline (citylearn.py:1136-1323).  `control_condition` /
+        `baseline_condition`: :class:`EvaluationCondition` members (or the reference's enum members -- anything with a
+        ``.value`` suffix, or the suffix string); defaults: control = with storage (and partial load) and PV, baseline =
+        without storage (and partial load) but with PV.  Returns a ``pandas.DataFrame[cost_function, value, name, level]``."""
         from .kpi import evaluate_district
         h = self._history_array
+        series = None
+        if control_condition is not None or baseline_condition is not None:
+            suffix = lambda c: getattr(c, 'value', c)
+            dyn = any(b.is_dynamics for b in self.spec.buildings[:1])       # the first building fixes the defaults (citylearn.py:1194-1200)
+            control = '' if control_condition is None else suffix(control_condition)
+            baseline = ('_without_storage_and_partial_load' if dyn else '_without_storage') if baseline_condition is None else suffix(baseline_condition)
+            series = (self._condition_series(control), self._condition_series(baseline), control)
         return evaluate_district(self.spec, self._tables, self._t, h('net'), h('base_net'), h('cost'), h('emission'),
                                  h('expected'), h('served'), np.array(self._hist['d_net'], dtype=np.float64), comfort_band,
-                                 indoor_temp=h('indoor_temp'))
+                                 indoor_temp=h('indoor_temp'), condition_series=series)
+
+    def _condition_series(self, suffix: str) -> np.ndarray:
+        """``[K, n_bldg]`` series `Building.net_electricity_consumption<suffix>` (building.py:320-366, 2850-2905)."""
+        h = self._history_array
+        K = self._t
+        solar = self._tables.ts[:K, :, abi.CLT_SOLAR].astype(np.float32)          # solar_generation (<= 0)
+        dynamics = np.array([b.is_dynamics for b in self.spec.buildings])
+        if suffix == '':
+            return h('net')
+        if suffix in ('_without_storage', '_without_storage_and_pv'):
+            out = h('net_ws')
+        elif suffix in ('_without_storage_and_partial_load', '_without_storage_and_partial_load_and_pv'):
+            if not dynamics.all():
+                name = next(b.name for b in self.spec.buildings if not b.is_dynamics)
+                raise AttributeError(f"building {name} has no attribute 'net_electricity_consumption{suffix}' (not a dynamics building)")
+            out = h('base_net')
+        else:
+            raise ValueError(f'unknown evaluation condition {suffix!r}')
+        return out - solar if suffix.endswith('_and_pv') else out
 
     def close(self):
         self._engine = None

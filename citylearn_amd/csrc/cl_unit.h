@@ -132,7 +132,7 @@ struct State { float soc, eff, degcap, cs, hs, ds; };
 // Actions of one unit (inactive -> 0 for storages / ignored for devices, building.py:1557-1564).
 struct Act { float cs, hs, ds, es, cd, hd; };
 // Per-unit results of the step.
-struct Out { float net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served; };
+struct Out { float net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served, net_ws; };
 // Running electricity_consumption[t] of the five electric devices.
 struct Acc { float c_cool, c_heat, c_dhw, c_ns, c_b; };
 
@@ -247,7 +247,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         const float net = (c_ns + c_b) * B.r + R.sol;
         O.net = net; O.cost = net * R.price; O.emission = fmaxf(0.0f, net * R.carbon);
         O.eb = eb; O.cool_dem = 0.0f; O.heat_dem = 0.0f; O.dhw_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns * B.r;
-        O.base_net = net - c_b * B.r; O.expected = R.nsl; O.served = R.nsl;
+        O.base_net = net - c_b * B.r; O.net_ws = O.base_net; O.expected = R.nsl; O.served = R.nsl;
         return;
     } else {
         Acc A = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -322,6 +322,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         // evaluate()'s baseline: remove what the storages did (building.py:345-366, 413-463) and, for dynamics
         // buildings, add back the ideal-vs-delivered load difference (building.py:2877-2905)
         float base = net - (eb_cs * R.icop_c + eb_hs * R.icop_h + eb_ds * R.icop_d + A.c_b * B.r);
+        O.net_ws = base;
         if (B.flags & CLF_DYNAMICS) base += (R.cool - cool_dem) * R.icop_c + (R.heat - heat_dem) * t0_iheat;
         O.base_net = base;
         O.expected = cool_dem + heat_dem + R.dhw + R.nsl;
@@ -338,8 +339,10 @@ CL_DEV void apply_flex(bool outage, float price, float carbon, float load, float
         O.cost = O.net * price;
         O.emission = fmaxf(0.0f, O.net * carbon);
         O.base_net += load;
+        O.net_ws += load;
     }
     O.base_net -= chargers;
+    O.net_ws -= chargers;
 }
 
 // Electric_Vehicles_Reward_Function for one building (reward_function.py:415-531): `marl` is MARL's reward for it,

@@ -8,12 +8,22 @@ from .cost_function import CostFunction
 
 
 def evaluate_district(spec, tables, K: int, net, base, cost, emission, expected, served, d_net, comfort_band: float = None,
-                      indoor_temp=None):
+                      indoor_temp=None, condition_series=None):
     """`net`, `base`, `cost`, `emission`, `expected`, `served`: float arrays ``[K, n_bldg]`` for the K completed steps
     (control net, baseline net, control cost / emission, expected / served energy); `d_net`: the K district sums.
     `indoor_temp` (optional ``[K, n_bldg]``): simulated indoor temperatures (LSTM stage) for the comfort KPIs; the
     data-file temperatures are used otherwise.  Returns the reference's ``DataFrame[cost_function, value, name, level]``."""
     import pandas as pd
+    if condition_series is not None:
+        # non-default EvaluationCondition pair: (control, baseline) net series; cost / emission follow from them
+        # (building.py:368-411: series * price, max(0, series * carbon)) and so does the district control series
+        net, base = (np.asarray(a, dtype='float32') for a in condition_series[:2])
+        n0 = net.shape[0]
+        price0 = tables.ts[:n0, :, abi.CLT_PRICE].astype(np.float32)
+        carbon0 = tables.ts[:n0, :, abi.CLT_CARBON].astype(np.float32)
+        cost, emission = net * price0, np.clip(net * carbon0, 0, None)
+        if condition_series[2] != '':
+            d_net = None        # the env-level property is the sum of the buildings' series, K + 1 entries (citylearn.py:700-760)
     net, base, cost, emission = (np.asarray(a, dtype='float32') for a in (net, base, cost, emission))
     expected, served = np.asarray(expected, dtype='float32').copy(), np.asarray(served, dtype='float32').copy()
     comfort_band = 2.0 if comfort_band is None else comfort_band
@@ -75,7 +85,7 @@ def evaluate_district(spec, tables, K: int, net, base, cost, emission, expected,
         for k, v in vals.items():
             rows.append({'cost_function': k, 'value': v, 'name': b.name, 'level': 'building'})
     building_level = pd.DataFrame(rows)
-    d_c = np.asarray(d_net, dtype=np.float64)                    # K entries (citylearn.py:1909-1918)
+    d_c = np.asarray(d_net, dtype=np.float64) if d_net is not None else net.astype(np.float64).sum(axis=1)    # K entries (citylearn.py:1909-1918)
     d_b = base.astype(np.float64).sum(axis=1)                               # K + 1 entries (sum of building series)
     district = {
         'ramping_average': safe_div(CostFunction.ramping(d_c)[-1], CostFunction.ramping(d_b)[-1]),

@@ -53,7 +53,7 @@ extern "C" {
 #define CL_NP  128   /* words per building in `params` */
 #define CL_NF   16   /* floats per (t, building) row in `ts` */
 #define CL_NS    6   /* state planes */
-#define CL_NO   14   /* per-building output planes */
+#define CL_NO   15   /* per-building output planes */
 #define CL_NQ    4   /* per-env (district) output planes */
 #define CL_NKB  12   /* per-building KPI accumulator planes */
 #define CL_NKE  24   /* per-env KPI accumulator planes */
@@ -168,6 +168,9 @@ enum cl_out {
     CLO_SERVED,       /* energy from devices + storages + energy_to_non_shiftable_load (citylearn.py:1217-1220) */
     CLO_HEAT_DEM,     /* delivered heating: energy_from_heating_device + |min(eb_hs,0)| (building.py:1436) */
     CLO_DHW_DEM,      /* delivered dhw:     energy_from_dhw_device + |min(eb_ds,0)|     (building.py:1437) */
+    CLO_NET_WS,       /* net_electricity_consumption_without_storage (building.py:345-366): equals CLO_BASE_NET except for dynamics
+                         buildings, whose default baseline also removes the partial-load difference (evaluate()'s
+                         EvaluationCondition variants, citylearn.py:29-50) */
     CLO_RESERVED
 };
 

@@ -377,6 +377,43 @@ def run_observations(name: str, steps: int = None):
     print(f'{name}: observations {np.array(obs).shape}, normalised {np.array(obs_norm).shape}')
 
 
+
+def run_conditions(name: str):
+    """`kpi_conditions.json`: `evaluate()` under non-default EvaluationCondition pairs after the fixture's action sequence."""
+    dataset, rows, K, seed, gz, env_kwargs = FIXTURES[name]
+    out_dir = GOLDEN / name
+    ref_env.setup_reference()
+    from citylearn.citylearn import CityLearnEnv, EvaluationCondition as EC
+    from citylearn.building import DynamicsBuilding
+    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
+    low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
+    high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
+    sizes = [b.action_space.shape[0] for b in env.buildings]
+    draw = _action_drawer(seed, low, high, [n for l in env.action_names for n in l])
+    env.reset()
+    for t in range(K):
+        al = [float(x) for x in draw()]
+        if env.central_agent:
+            acts = [al]
+        else:
+            acts, p = [], 0
+            for s in sizes:
+                acts.append(al[p:p + s]); p += s
+        env.step(acts)
+    dyn = isinstance(env.buildings[0], DynamicsBuilding)
+    pairs = [('WITH_STORAGE_AND_PV', 'WITHOUT_STORAGE_AND_PV'), ('WITHOUT_STORAGE_BUT_WITH_PV', 'WITHOUT_STORAGE_AND_PV')]
+    if dyn:
+        pairs += [('WITH_STORAGE_AND_PARTIAL_LOAD_AND_PV', 'WITHOUT_STORAGE_BUT_WITH_PARTIAL_LOAD_AND_PV'),
+                  ('WITHOUT_STORAGE_BUT_WITH_PARTIAL_LOAD_AND_PV', 'WITHOUT_STORAGE_AND_PARTIAL_LOAD_AND_PV')]
+    out = {}
+    for c, b in pairs:
+        k = env.evaluate(control_condition=getattr(EC, c), baseline_condition=getattr(EC, b))
+        k = k[k['value'].notnull()]
+        out[f'{c}|{b}'] = {f'{r.level}|{r.name}|{r.cost_function}': float(r.value) for r in k.itertuples()}
+    (out_dir / 'kpi_conditions.json').write_text(json.dumps(out))
+    print(f'{name}: kpi_conditions.json with {len(pairs)} condition pairs')
+
+
 OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300, 'g2020_15min': 120, 's_baeda': 95, 's_2021': 95,
                 's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239, 'g_cc_demo': 167, 'g_evs_15min': 119, 'g_evs_central': 119}
 
@@ -388,12 +425,16 @@ if __name__ == '__main__':
     args = sys.argv[1:]
     if args and args[0] == '--one':
         kind, name = args[1], args[2]
-        if kind == 'observations':
+        if kind == 'conditions':
+            run_conditions(name)
+        elif kind == 'observations':
             run_observations(name, OBS_FIXTURES.get(name))
         else:
             run_reference(name)
         sys.exit(0)
-    if args and args[0] == 'observations':
+    if args and args[0] == 'conditions':
+        jobs = [('conditions', n) for n in (args[1:] or ['g2022_all', 'g2023_p2'])]
+    elif args and args[0] == 'observations':
         jobs = [('observations', n) for n in (args[1:] or list(OBS_FIXTURES))]
     else:
         names = args or list(FIXTURES)

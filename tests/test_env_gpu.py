@@ -166,3 +166,32 @@ def test_streaming_kpi_accumulators(name, K):
         gref = dict(zip([str(x) for x in g.ref['kpi_names']], g.ref['kpi_values']))
         for fn in ('ramping_average', 'daily_peak_average', 'electricity_consumption_total', 'cost_total'):
             np.testing.assert_allclose(float(district[fn][0]), gref[f'district|District|{fn}'], rtol=5e-3)
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2023_p2'])
+def test_evaluate_under_non_default_conditions(name):
+    """`evaluate(control_condition, baseline_condition)` with the reference's other EvaluationCondition members (series without
+    storage, without PV, with / without partial load): every non-comfort KPI of a full episode against the reference."""
+    import json
+    from citylearn_amd.citylearn import CityLearnEnv, EvaluationCondition as EC
+    g = golden(name)
+    ref_all = json.loads((g.dir / 'kpi_conditions.json').read_text())
+    kw = {'reward_function': 'citylearn.reward_function.RewardFunction'} if g.facts['reward_type'] == 'ComfortReward' else {}
+    env = CityLearnEnv(g.schema_path, **kw)
+    t = 0
+    while not env.terminated:
+        env.step(_actions(g, env, t)); t += 1
+    for pair, ref in ref_all.items():
+        c, b = pair.split('|')
+        frame = env.evaluate(control_condition=getattr(EC, c), baseline_condition=getattr(EC, b))
+        got = {f'{r.level}|{r.name}|{r.cost_function}': r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
+        n = 0
+        for k, v in ref.items():
+            if k.split('|')[-1].startswith(('discomfort', 'one_minus_thermal')) or abs(v) > 1e3:
+                continue
+            np.testing.assert_allclose(got[k], v, rtol=3e-3, atol=2e-4, err_msg=f'{pair} {k}')
+            n += 1
+        assert n >= 20, (pair, n)
+    if name == 'g2022_all':
+        with pytest.raises(AttributeError):                      # partial-load series only exist on dynamics buildings
+            env.evaluate(baseline_condition=EC.WITHOUT_STORAGE_AND_PARTIAL_LOAD_BUT_WITH_PV)
