@@ -310,3 +310,31 @@ def test_large_district_building_chunked_grid(fixture, kind, B):
     finally:
         lib.cl_debug_set_lean(0, 0)
     assert worst < 1.0, worst
+
+
+@pytest.mark.parametrize('E', [65536, 131072])
+def test_full_size_batches_through_size_independent_properties(E):
+    """BASELINE.json's headline size (17 x 65 536, the latency-ordered lean kernel at VEC = 4) and the first size served by the
+    env-major kernel (131 072): (1) replication -- the batch is 512 distinct action columns tiled along the env axis, so env e
+    must equal env e mod 512 of a 512-env engine stepped with the same actions (itself covered by the oracle / reference tests),
+    bit for bit on every per-building plane; (2) the district sums are the sums of the building planes; (3) a checksum of
+    checksums over the whole batch."""
+    g = golden('g2022_all')
+    tab = g.spec().episode_tables(0)
+    small, big = StepEngine(tab, 512, reward='RewardFunction'), StepEngine(tab, E, reward='RewardFunction')
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    reps = E // 512
+    for t in range(30):
+        a = (torch.rand((small.n_act_cols, 512), device='cuda', generator=gen) * 2 - 1).contiguous()
+        small.step(a, t)
+        big.step(a.repeat(1, reps).contiguous(), t)
+    torch.cuda.synchronize()
+    for name, s_plane, b_plane in (('state', small.state, big.state), ('net', small.out_bldg[abi.CLO_NET], big.out_bldg[abi.CLO_NET]),
+                                   ('reward', small.out_bldg[abi.CLO_REWARD], big.out_bldg[abi.CLO_REWARD])):
+        tiled = b_plane.reshape(*b_plane.shape[:-1], reps, 512)
+        assert torch.equal(tiled, s_plane.unsqueeze(-2).expand_as(tiled)), name
+    net_sum = big.out_bldg[abi.CLO_NET].double().sum(dim=0)
+    torch.testing.assert_close(big.out_env[abi.CLQ_NET].double(), net_sum, rtol=1e-6, atol=1e-4)
+    torch.testing.assert_close(big.out_env[abi.CLQ_REWARD].double(), big.out_bldg[abi.CLO_REWARD].double().sum(dim=0), rtol=1e-6, atol=1e-4)
+    total_small = small.out_bldg[abi.CLO_NET].double().sum().item()
+    assert abs(big.out_bldg[abi.CLO_NET].double().sum().item() - reps * total_small) <= 1e-9 * abs(reps * total_small) + 1e-6
