@@ -164,3 +164,26 @@ def test_env_on_the_whole_baeda_district():
     assert got.shape == ref.shape
     assert np.max(np.abs(got - ref) / (1e-3 + 1e-3 * np.abs(ref))) < 10.0
     assert np.max(np.abs(np.array(temps) - g.ref['indoor_temp'][:K])) < 5e-3
+
+
+def test_lstm_stage_at_full_batch_size_by_replication():
+    """3 x 65 536 (the C3 shape): the batch is 128 distinct delivered-cooling columns tiled along the env axis; every env must
+    reproduce, bit for bit, the corresponding env of a 128-env stage (which the reference-fed test covers)."""
+    g = golden('g2023_p2')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E, reps = 65536, 512
+    stages = []
+    for n in (128, E):
+        eng = StepEngine(tab, n, detail=True)
+        stages.append(LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0))
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    for t in range(20):
+        cool = torch.rand((3, 128), device='cuda', generator=gen) * 4
+        t_small = stages[0].step(t, cool.contiguous())
+        t_big = stages[1].step(t, cool.repeat(1, reps).contiguous())
+    torch.cuda.synchronize()
+    for small, big in ((stages[0].indoor_temp, stages[1].indoor_temp), (stages[0].comfort, stages[1].comfort)):
+        tiled = big.reshape(3, reps, 128)
+        assert torch.equal(tiled, small.unsqueeze(1).expand_as(tiled))
+    assert torch.isfinite(stages[1].indoor_temp).all() and float(stages[1].indoor_temp.std()) > 0
