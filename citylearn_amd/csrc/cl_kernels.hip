@@ -331,7 +331,8 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 // (Tried: VEC = 2 compiled for 8 waves per SIMD -- two workgroups per CU, half the per-wave chain: 64 VGPRs with 23 spilled,
 // 9.3 us vs 7.9 us for VEC = 4 at 17 x 65 536.  Tried: with 17 = 16 + 1 buildings, sharing the last building's env tile out
 // in 64-env strips to four waves at one env per lane instead of giving one wave two buildings -- 5 instead of 8 units on the
-// longest wave, 62 instead of 94 VGPRs: 7.89 vs 7.94 us, i.e. the doubled wave is not what bounds the launch.)
+// longest wave, 62 instead of 94 VGPRs: 7.89 vs 7.94 us, i.e. the doubled wave is not what bounds the launch.  Tried:
+// non-temporal stores for the net / reward planes: 7.87 - 7.91 vs 7.86 - 7.88 us, no effect.)
 template <int VEC, bool FLEX = false>
 __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
