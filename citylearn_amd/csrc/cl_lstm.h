@@ -165,7 +165,9 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
 // the pre-gates and the bias keep the exact f32 MFMA (K = 2).
 // (Tried: weight fragments in LDS with a 3-waves-per-SIMD register budget -- with the pipelined loop 33 spilled VGPRs,
 // 191 us vs 176 us; with one accumulator pair live at a time 7 spills, 177 us vs 166 us on the same box: more resident
-// waves do not help, the SIMD's VALU issue slots are the shared resource.)
+// waves do not help, the SIMD's VALU issue slots are the shared resource.  Tried: a start offset (s_sleep) for every other
+// resident workgroup so that one wave's MFMA chains meet the other's activations: 165 us without, 166 - 218 us with offsets of
+// 0.5 - 4 us -- the two phases of co-resident waves do not overlap either way.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 /* lstm_wb layout (CL_LSTM_NWB = 18 * 64 * 8 bf16 per building): fragment f = 6 * matrix{hh0, ih1, hh1} + 3 * row_block + term,
    then [lane][8]: W[32 row_block + (lane & 31)][unit u(j, lane >> 5)], j = 0..7 */
