@@ -29,6 +29,29 @@ def timed(eng, a, steps=200, warm=20):
     return (time.perf_counter() - t0) / steps * 1e6
 
 
+def timed_graph(eng, a, steps=50, reps=20):
+    """The same loop replayed as a hipGraph of `steps` consecutive env steps (what bench.py does for the headline): GPU time
+    without the Python / launch cost of eager calls."""
+    T = eng.n_steps
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for i in range(5):
+            eng.step(a, 1 + i)
+        stream.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=stream):
+            for i in range(steps):
+                eng.step(a, 1 + (i % (T - 2)))
+        gr.replay(); stream.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for _ in range(reps):
+            gr.replay()
+        ev1.record(stream)
+        stream.synchronize()
+    return ev0.elapsed_time(ev1) / (reps * steps) * 1e3
+
+
 def main():
     E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     g = golden('g2022_evs')
@@ -44,12 +67,14 @@ def main():
             lib.cl_debug_set_flex(fv)
             out[f'flex{fv}/{reward}'] = round(timed(eng, a), 2)
         lib.cl_debug_set_flex(0)
+        out[f'graph/{reward}'] = round(timed_graph(eng, a), 2)
     import copy
     plain = copy.copy(tab)
     plain.flex = None
     eng = StepEngine(plain, E, reward='MARL', n_act_cols=tab.flex.n_act_cols)
     a = (torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1).contiguous()
     out['no_flex/MARL'] = round(timed(eng, a), 2)
+    out['graph/no_flex/MARL'] = round(timed_graph(eng, a), 2)
     print(json.dumps(out))
 
 
