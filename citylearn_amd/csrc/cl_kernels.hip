@@ -8,6 +8,7 @@
 // through LDS in a fixed order (wave-partials -> serial sum over waves), so results are bit-reproducible
 // run to run -- no atomics on the step path.
 #include "cl_unit.h"
+#include "cl_philox.h"
 
 #include <stdarg.h>
 #include <string.h>
@@ -94,6 +95,8 @@ CL_DEV void load_action(float (&dst)[VEC], const StepArgs& a, int col, int env0)
         for (int i = 0; i < VEC; ++i) dst[i] = p[(long long)(env0 + i) * a.act_stride_env];
     }
 }
+
+#include "cl_flex.h"     // flexible loads (EV chargers, EVs, washing machines): device functions + the stand-alone kernel
 
 constexpr int NQ = CL_NQ;
 
@@ -648,7 +651,6 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
 #include "cl_rollout.h"
 #include "cl_lstm.h"
 #include "cl_observe.h"
-#include "cl_flex.h"
 
 namespace {
 
