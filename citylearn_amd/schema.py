@@ -21,8 +21,8 @@ window into the float32 ``params`` / ``ts`` tables described in ``include/cityle
                                                        /root/reference/citylearn/citylearn.py:2277-2308, 2558-2641,
                                                        data.py:663-820, building.py:764-845
 
-Out of scope (raises ``NotImplementedError``): occupant models, PV / battery autosizing (needs PySAM / external sizing
-tables), stochastic data files (``noise_std``).
+Out of scope (raises ``NotImplementedError``): occupant models, PV autosizing (needs PySAM), stochastic data files
+(``noise_std``).  Battery autosizing needs the manufacturer table ``battery_choices.yaml`` (see `_battery_sizing_table`).
 """
 from __future__ import annotations
 
@@ -708,6 +708,56 @@ def _weather_series(cols: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
     return out
 
 
+def _battery_sizing_table(source, root: str) -> List[Tuple[str, Dict[str, Any]]]:
+    """The manufacturer table of `Battery.autosize` (`DataSet.get_battery_sizing_data`, data.py:224-256): the reference downloads
+    ``misc/battery_choices.yaml`` into its cache; here it is a file next to the dataset (``<root>/../misc`` or
+    ``<root>/../../misc``, the reference repository's layout), a path, or rows given directly."""
+    import yaml
+    if isinstance(source, (list, tuple)):
+        return [(k, dict(v)) for k, v in source]
+    if isinstance(source, Mapping):
+        return [(k, dict(v.get('attributes', v))) for k, v in source.items()]
+    candidates = [source] if source else [os.path.join(root, '..', 'misc', 'battery_choices.yaml'), os.path.join(root, '..', '..', 'misc', 'battery_choices.yaml')]
+    for path in candidates:
+        if path and os.path.isfile(path):
+            with open(path) as f:
+                return [(k, dict(v['attributes'])) for k, v in yaml.safe_load(f).items()]
+    raise NotImplementedError('Battery.autosize needs the battery sizing table: pass battery_sizing_data=<path to battery_choices.yaml> '
+                              'or place it under <root_directory>/../misc/')
+
+
+def _autosize_battery(d: BatterySpec, dev: Mapping[str, Any], series: Mapping[str, np.ndarray], w: slice, sampler: _Sampler,
+                      akw: Mapping[str, Any], table: List[Tuple[str, Dict[str, Any]]], seconds: float) -> None:
+    """`Building.autosize_electrical_storage` + `Battery.autosize` (building.py:2405-2424, energy_model.py:1143-1226).  The
+    selected model's efficiency does not survive: `Battery.reset` rewinds `efficiency_history` to its first entry, the value the
+    constructor drew (energy_model.py:1240-1241) -- so `d.efficiency` and the curves built from it stay as constructed."""
+    t_out = series['outdoor_dry_bulb_temperature'][w]
+    cd, hd, dd = dev.get('cooling_device', HeatPumpSpec()), dev.get('heating_device', HeatPumpSpec()), dev.get('dhw_device', HeaterSpec())
+
+    def input_power(device, demand, heating):
+        demand = np.array(demand)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return demand / device.cop(t_out, heating) if device.is_heat_pump else demand / device.efficiency
+    # `_estimate_baseline_electricity_consumption` (building.py:2443-2500)
+    estimate = input_power(cd, series['cooling_demand'][w], False) + input_power(hd, series['heating_demand'][w], True) \
+        + input_power(dd, series['dhw_demand'][w], True) + series['non_shiftable_load'][w]
+    days = (np.arange(len(estimate)) / 24).astype(int)          # sic: index / 24 whatever the time step (building.py:2416)
+    demand = float(np.mean([estimate[days == k].max() for k in np.unique(days)]))
+    demand = demand * 1.0                                        # the device's time_step_ratio is still 1 at this point
+    duration = sampler.value(akw.get('duration'), (1.5, 3.5))
+    safety_factor = sampler.value(akw.get('safety_factor'), 1.0)
+    parallel = bool(akw.get('parallel') or False)
+    choices = [(k, v) for k, v in table if v['nominal_power'] <= demand] or [min(table, key=lambda kv: kv[1]['nominal_power'])]
+    names = [k for k, _ in choices]
+    pick = dict(choices)[str(np.random.RandomState(sampler.seed).choice(names))]
+    units = max(1, math.floor(demand * duration * safety_factor / pick['capacity']))
+    d.capacity = pick['capacity'] * units
+    d.nominal_power = pick['nominal_power'] * max(1.0, units * int(parallel))
+    d.depth_of_discharge = sampler.value(pick.get('depth_of_discharge'), 1.0)
+    d.loss_coefficient = sampler.value(pick.get('loss_coefficient'), (0.001, 0.009))
+    d.capacity_loss_coefficient = sampler.value(pick.get('capacity_loss_coefficient'), (1e-5, 1e-4))
+
+
 def _load_chargers(bs: Mapping[str, Any], root: str, sim_start: int, sim_end: int) -> List[ChargerSpec]:
     """`citylearn.py:2277-2298` + `ChargerSimulation.__init__` (data.py:698-768, noise_std = 0)."""
     import pandas as pd
@@ -1005,9 +1055,9 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
                     key = device_name.split('_')[0] + '_demand'
                     d.capacity = np.nanmax(series[key][w] * 1) * sf
             elif cls == 'Battery':
-                if autosize:
-                    raise NotImplementedError('Battery.autosize needs the battery sizing table (out of scope)')
                 d = _make_battery(attrs, sampler)
+                if autosize:
+                    _autosize_battery(d, dev, series, w, sampler, akw, _battery_sizing_table(kwargs.get('battery_sizing_data'), root), seconds)
             elif cls == 'PV':
                 if autosize:
                     raise NotImplementedError('PV.autosize needs PySAM (out of scope)')

@@ -57,6 +57,8 @@ FIXTURES = {
     # the EV district under 15-minute control (time_step_ratio 0.25 through the EV batteries and chargers) and with a central agent
     'g_evs_15min': ('citylearn_challenge_2022_phase_all_plus_evs', 120, 119, 79, False, {'seconds_per_time_step': 900}),
     'g_evs_central': ('citylearn_challenge_2022_phase_all_plus_evs', 120, 119, 80, False, {'central_agent': True}),
+    # autosized batteries: manufacturer model, unit count and the model's efficiency / loss figures from the sizing table
+    's_autosize': ('citylearn_challenge_2022_phase_3', 96, 95, 36, False, {'__autosize_batteries__': True}),
     's_baeda': ('baeda_3dem', 96, 95, 31, False, {}),
     's_2021': ('citylearn_challenge_2021', 96, 95, 32, False, {}),
     's_2020_cz3': ('citylearn_challenge_2020_climate_zone_3', 96, 95, 33, False, {}),
@@ -73,7 +75,17 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict
     schema['simulation_end_time_step'] = rows - 1
     schema['root_directory'] = None
     schema.pop('agent', None)
-    schema.update(overrides or {})          # top-level schema keys (same effect as the constructor kwargs, citylearn.py:2006-2051)
+    overrides = dict(overrides or {})
+    if overrides.pop('__autosize_batteries__', False):
+        # Battery.autosize (energy_model.py:1143-1226): drop the nameplate values, let the loader pick a manufacturer model from
+        # the sizing table, which travels with the fixture (<fixture>/misc/, where DataSet would cache it)
+        for b in schema['buildings'].values():
+            es = b['electrical_storage']
+            es['autosize'] = True
+            es['attributes'] = {k: v for k, v in (es.get('attributes') or {}).items() if k not in ('capacity', 'nominal_power', 'efficiency')}
+        (dst.parent / 'misc').mkdir(parents=True, exist_ok=True)
+        shutil.copyfile(src.parent.parent / 'misc' / 'battery_choices.yaml', dst.parent / 'misc' / 'battery_choices.yaml')
+    schema.update(overrides)          # top-level schema keys (same effect as the constructor kwargs, citylearn.py:2006-2051)
     files = set()
     for b in schema['buildings'].values():
         for k in ('energy_simulation', 'weather', 'carbon_intensity', 'pricing'):

@@ -8,7 +8,7 @@ import numpy as np
 GOLDEN = Path(__file__).resolve().parent / 'golden'
 FIXTURES = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2022_p1_year', 'g2020_15min')
 # dataset sweep: 95-step runs of the other dataset families (oracle/ref_harness/gen_golden.py)
-SWEEP = ('s_baeda', 's_2021', 's_2020_cz3', 's_2023_p1', 's_2023_p3')
+SWEEP = ('s_baeda', 's_2021', 's_2020_cz3', 's_2023_p1', 's_2023_p3', 's_autosize')
 
 
 class Golden:

@@ -33,7 +33,7 @@ def test_loader_matches_reference_facts(name):
         if es is not None:
             assert np.array_equal(b.electrical_storage.power_efficiency_curve, np.array(es['power_efficiency_curve']))
             assert np.array_equal(b.electrical_storage.capacity_power_curve, np.array(es['capacity_power_curve']))
-            for k in ('capacity', 'nominal_power', 'efficiency', 'capacity_loss_coefficient', 'depth_of_discharge', 'initial_soc'):
+            for k in ('capacity', 'nominal_power', 'efficiency', 'loss_coefficient', 'capacity_loss_coefficient', 'depth_of_discharge', 'initial_soc'):
                 assert float(getattr(b.electrical_storage, k)) == pytest.approx(es[k], rel=1e-12, abs=0), k
         assert float(b.cooling_device.nominal_power) == pytest.approx(d['cooling_device']['nominal_power'], rel=1e-12)   # autosized in 2020
         assert float(b.dhw_device.nominal_power) == pytest.approx(d['dhw_device']['nominal_power'], rel=1e-12)
