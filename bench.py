@@ -77,10 +77,21 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('CL_BENCH_FORCE_DIST'):       # the env hook exercises the RCCL path on a 1-GPU box (torchrun, 1 rank)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        # RCCL prints a version banner on STDOUT when the communicator comes up; stdout must carry the one JSON line only
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', device_id=torch.device(device))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from golden_util import golden
     from citylearn_amd.engine import StepEngine

@@ -21,8 +21,8 @@ window into the float32 ``params`` / ``ts`` tables described in ``include/cityle
                                                        /root/reference/citylearn/citylearn.py:2277-2308, 2558-2641,
                                                        data.py:663-820, building.py:764-845
 
-Out of scope (raises ``NotImplementedError``): occupant models, PV autosizing (needs PySAM), stochastic data files
-(``noise_std``).  Battery autosizing needs the manufacturer table ``battery_choices.yaml`` (see `_battery_sizing_table`).
+Out of scope (raises ``NotImplementedError``): occupant models, PV autosizing (needs PySAM).  ``noise_std`` perturbs the data
+files at load time from numpy's global generator, like the reference, or from ``noise_seed`` (see `_Noise`).  Battery autosizing needs the manufacturer table ``battery_choices.yaml`` (see `_battery_sizing_table`).
 """
 from __future__ import annotations
 
@@ -654,8 +654,23 @@ def _read_csv(path: str) -> Dict[str, np.ndarray]:
     return {c: frame[c].to_numpy() for c in frame.columns}
 
 
-def _energy_simulation_series(cols: Mapping[str, np.ndarray], seconds_per_time_step: float) -> Tuple[Dict[str, np.ndarray], float]:
-    """`EnergySimulation.__init__` casts / defaults (data.py:395-493) without the noise terms (noise_std = 0)."""
+class _Noise:
+    """`NoiseUtils.generate_gaussian_noise` (utilities.py:150-169): ``np.random.normal(0, noise_std, shape)`` from numpy's GLOBAL
+    generator when ``noise_std > 0``, zeros (and no draw) otherwise.  ``load_district(noise_seed=k)`` draws from
+    ``RandomState(k)`` instead, which is what the reference produces after ``np.random.seed(k)``; the draw order below is the
+    reference's (`_load_building`, citylearn.py:2180-2289)."""
+
+    def __init__(self, std: float, generator=None):
+        self.std = float(std or 0.0)
+        self.generator = np.random if generator is None else generator
+
+    def __call__(self, like) -> np.ndarray:
+        shape = np.asarray(like).shape
+        return np.zeros(shape) if self.std <= 0 else self.generator.normal(loc=0, scale=self.std, size=shape)
+
+
+def _energy_simulation_series(cols: Mapping[str, np.ndarray], seconds_per_time_step: float, noise: _Noise = _Noise(0.0)) -> Tuple[Dict[str, np.ndarray], float]:
+    """`EnergySimulation.__init__` casts / defaults / noise terms (data.py:395-493)."""
     for k in _ES_REQUIRED:
         if k not in cols:
             raise KeyError(f'energy_simulation file lacks column {k!r}')
@@ -665,8 +680,8 @@ def _energy_simulation_series(cols: Mapping[str, np.ndarray], seconds_per_time_s
     for k in ('month', 'hour', 'day_type'):
         out[k] = np.array(cols[k], dtype='int32')
     # `float32 + np.zeros(...)` in the reference promotes these two to float64 holding float32 values
-    out['indoor_dry_bulb_temperature'] = np.clip(np.array(cols['indoor_dry_bulb_temperature'], dtype='float32').astype('float64'), -90, 57)
-    out['solar_generation'] = np.array(cols['solar_generation'], dtype='float32').astype('float64')
+    out['indoor_dry_bulb_temperature'] = np.clip(np.array(cols['indoor_dry_bulb_temperature'], dtype='float32') + noise(cols['indoor_dry_bulb_temperature']), -90, 57)
+    out['solar_generation'] = np.array(cols['solar_generation'], dtype='float32') + noise(cols['indoor_dry_bulb_temperature'])   # sic, unclipped
     for k in ('non_shiftable_load', 'dhw_demand', 'cooling_demand', 'heating_demand'):
         out[k] = np.array(cols[k], dtype='float32')
     if float((out['cooling_demand'] * out['heating_demand']).sum()) != 0:
@@ -675,7 +690,7 @@ def _energy_simulation_series(cols: Mapping[str, np.ndarray], seconds_per_time_s
     out['daylight_savings_status'] = np.zeros(n, dtype='int32') if 'daylight_savings_status' not in cols else np.array(cols['daylight_savings_status'], dtype='int32')
     out['average_unmet_cooling_setpoint_difference'] = f32('average_unmet_cooling_setpoint_difference')
     out['indoor_relative_humidity'] = np.zeros(n, dtype='float32') if 'indoor_relative_humidity' not in cols else \
-        np.clip(np.array(cols['indoor_relative_humidity'], dtype='float32').astype('float64'), 0, 100)
+        np.clip(np.array(cols['indoor_relative_humidity'], dtype='float32') + noise(cols['indoor_relative_humidity']), 0, 100)
     out['occupant_count'] = f32('occupant_count')
     out['indoor_dry_bulb_temperature_cooling_set_point'] = f32('indoor_dry_bulb_temperature_cooling_set_point')
     out['indoor_dry_bulb_temperature_heating_set_point'] = f32('indoor_dry_bulb_temperature_heating_set_point')
@@ -700,11 +715,15 @@ def _energy_simulation_series(cols: Mapping[str, np.ndarray], seconds_per_time_s
     return out, ratio
 
 
-def _weather_series(cols: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+def _weather_series(cols: Mapping[str, np.ndarray], noise: _Noise = _Noise(0.0)) -> Dict[str, np.ndarray]:
     out = {}
-    for k in _WEATHER_COLUMNS:
+    for k in _WEATHER_COLUMNS:                      # the reference's draw order: the four measured columns, then the forecasts
         a = np.array(cols[k], dtype='float32')
-        out[k] = a if '_predicted_' not in k else a.astype('float64')   # data.py:567-596 promotion
+        if '_predicted_' not in k:
+            a += noise(a)                           # in place: stays float32 (data.py:573-576)
+            out[k] = a
+        else:
+            out[k] = a + noise(cols[k])             # promoted to float64 (data.py:579-595)
     return out
 
 
@@ -758,13 +777,12 @@ def _autosize_battery(d: BatterySpec, dev: Mapping[str, Any], series: Mapping[st
     d.capacity_loss_coefficient = sampler.value(pick.get('capacity_loss_coefficient'), (1e-5, 1e-4))
 
 
-def _load_chargers(bs: Mapping[str, Any], root: str, sim_start: int, sim_end: int) -> List[ChargerSpec]:
-    """`citylearn.py:2277-2298` + `ChargerSimulation.__init__` (data.py:698-768, noise_std = 0)."""
+def _load_chargers(bs: Mapping[str, Any], root: str, sim_start: int, sim_end: int, noise_generator=None) -> List[ChargerSpec]:
+    """`citylearn.py:2277-2298` + `ChargerSimulation.__init__` (data.py:698-768)."""
     import pandas as pd
     out: List[ChargerSpec] = []
     for charger_id, cfg in (bs.get('chargers') or {}).items():
-        if cfg.get('noise_std', 0.0):
-            raise NotImplementedError('charger noise_std > 0 (stochastic schedules) is not supported yet')
+        noise = _Noise(cfg.get('noise_std', 0.0), noise_generator)     # percent points on the two SoC columns (data.py:753, 764)
         attrs = dict(cfg.get('attributes') or {})
         curves = {}
         for key in ('charge_efficiency_curve', 'discharge_efficiency_curve'):       # electric_vehicle_charger.py:190-202
@@ -784,7 +802,7 @@ def _load_chargers(bs: Mapping[str, Any], root: str, sim_start: int, sim_end: in
         departure = nan_to(np.array(cols[4], dtype=float), -1).astype(int)
         arrival = nan_to(np.array(cols[6], dtype=float), -1).astype(int)
         pct = lambda a: np.where(nan_to(np.array(a, dtype=float), -0.1) != -0.1,
-                                 np.clip(nan_to(np.array(a, dtype=float), -0.1) / 100 + 0.0 / 100, 0, 1), -0.1)
+                                 np.clip(nan_to(np.array(a, dtype=float), -0.1) / 100 + noise(a) / 100, 0, 1), -0.1)
         eff = attrs.get('efficiency')
         dflt = lambda v, d: d if v is None else v
         out.append(ChargerSpec(
@@ -931,6 +949,7 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
     central_agent = bool(_pick(kwargs, sc, 'central_agent', False))
     seconds = float(_pick(kwargs, sc, 'seconds_per_time_step', 3600.0))
     sim_start = int(_pick(kwargs, sc, 'simulation_start_time_step'))
+    noise_generator = None if kwargs.get('noise_seed') is None else np.random.RandomState(int(kwargs['noise_seed']))   # see `_Noise`
     sim_end = int(_pick(kwargs, sc, 'simulation_end_time_step'))
     # per-charger / per-washing-machine entries are expanded from these helper rows (citylearn.py:2010-2030)
     charger_obs_helper = {k: v for k, v in sc['observations'].items() if 'electric_vehicle_' in k}
@@ -960,28 +979,22 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
         bs = sc['buildings'][name]
         if bs.get('occupant'):
             raise NotImplementedError(f'building {name}: \'occupant\' is outside the hot-path scope')
-        if bs.get('noise_std', 0.0):
-            raise NotImplementedError('noise_std > 0 (stochastic data files) is not supported yet')
+        noise = _Noise(bs.get('noise_std', 0.0), noise_generator)
         kind = _class_name(bs.get('type'), 'Building')
         if kind not in ('Building', 'LSTMDynamicsBuilding'):
             raise NotImplementedError(f'building type {bs.get("type")!r} is outside the hot-path scope')
         building_type = 'citylearn.citylearn.Building' if bs.get('type') is None else bs['type']
-        es, ratio = _energy_simulation_series(_read_csv(os.path.join(root, bs['energy_simulation'])), seconds)
+        es, ratio = _energy_simulation_series(_read_csv(os.path.join(root, bs['energy_simulation'])), seconds, noise)
         series = dict(es)
-        series.update(_weather_series(_read_csv(os.path.join(root, bs['weather']))))
+        series.update(_weather_series(_read_csv(os.path.join(root, bs['weather'])), noise))
         n = len(series['hour'])
-        if bs.get('carbon_intensity') is not None:
-            ci = _read_csv(os.path.join(root, bs['carbon_intensity']))['carbon_intensity']
-            series['carbon_intensity'] = np.clip(np.array(ci, dtype='float32').astype('float64'), 0, 1)
-        else:
-            series['carbon_intensity'] = np.clip(np.zeros(n, dtype='float32').astype('float64'), 0, 1)
-        if bs.get('pricing') is not None:
-            pr = _read_csv(os.path.join(root, bs['pricing']))
-            for k in _PRICING_COLUMNS:
-                series[k] = np.clip(np.array(pr[k], dtype='float32').astype('float64'), 0, 1)
-        else:
-            for k in _PRICING_COLUMNS:
-                series[k] = np.zeros(n, dtype='float64')
+        # absent files stand in as zeros -- which still receive the noise and the [0, 1] clip (citylearn.py:2189-2207)
+        ci = _read_csv(os.path.join(root, bs['carbon_intensity']))['carbon_intensity'] if bs.get('carbon_intensity') is not None \
+            else np.zeros(n, dtype='float32')
+        series['carbon_intensity'] = np.clip(np.array(ci, dtype='float32') + noise(ci), 0, 1)
+        pr = _read_csv(os.path.join(root, bs['pricing'])) if bs.get('pricing') is not None else {k: np.zeros(n, dtype='float32') for k in _PRICING_COLUMNS}
+        for k in _PRICING_COLUMNS:
+            series[k] = np.clip(np.array(pr[k], dtype='float32') + noise(pr[k]), 0, 1)
 
         # observation / action metadata (citylearn.py:2411-2497)
         obs_meta = {k: v['active'] for k, v in observations.items()}
@@ -999,7 +1012,7 @@ def load_district(schema: Union[str, Path, Mapping[str, Any]], **kwargs: Any) ->
             act_meta = {k: k in act for k in act_meta}
         inactive = per_b(kwargs['inactive_actions']) if kwargs.get('inactive_actions') is not None else (bs.get('inactive_actions') or [])
         act_meta = {k: False if k in inactive else v for k, v in act_meta.items()}
-        chargers = _load_chargers(bs, root, sim_start, sim_end)
+        chargers = _load_chargers(bs, root, sim_start, sim_end, noise_generator)
         washing_machines = _load_washing_machines(bs, kwargs, root, sim_start, sim_end)
         _expand_flexible_load_metadata(obs_meta, act_meta, chargers, washing_machines, charger_obs_helper, wm_obs_helper,
                                        charger_act_helper, wm_act_helper, kwargs, bs, per_b)

@@ -57,6 +57,9 @@ FIXTURES = {
     # the EV district under 15-minute control (time_step_ratio 0.25 through the EV batteries and chargers) and with a central agent
     'g_evs_15min': ('citylearn_challenge_2022_phase_all_plus_evs', 120, 119, 79, False, {'seconds_per_time_step': 900}),
     'g_evs_central': ('citylearn_challenge_2022_phase_all_plus_evs', 120, 119, 80, False, {'central_agent': True}),
+    # stochastic data files: `noise_std` on every building (series) and every charger (SoC columns, percent points), drawn from
+    # numpy's global generator at load time (utilities.py:150-169) -- the harness seeds it with the action seed (run_reference)
+    'g_evs_noise': ('citylearn_challenge_2022_phase_all_plus_evs', 120, 119, 81, False, {'__noise_std__': [0.05, 5.0]}),
     # autosized batteries: manufacturer model, unit count and the model's efficiency / loss figures from the sizing table
     's_autosize': ('citylearn_challenge_2022_phase_3', 96, 95, 36, False, {'__autosize_batteries__': True}),
     's_baeda': ('baeda_3dem', 96, 95, 31, False, {}),
@@ -85,6 +88,12 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict
             es['attributes'] = {k: v for k, v in (es.get('attributes') or {}).items() if k not in ('capacity', 'nominal_power', 'efficiency')}
         (dst.parent / 'misc').mkdir(parents=True, exist_ok=True)
         shutil.copyfile(src.parent.parent / 'misc' / 'battery_choices.yaml', dst.parent / 'misc' / 'battery_choices.yaml')
+    noise = overrides.pop('__noise_std__', None)
+    if noise is not None:
+        for b in schema['buildings'].values():
+            b['noise_std'] = noise[0]
+            for c in (b.get('chargers') or {}).values():
+                c['noise_std'] = noise[1]
     schema.update(overrides)          # top-level schema keys (same effect as the constructor kwargs, citylearn.py:2006-2051)
     files = set()
     for b in schema['buildings'].values():
@@ -268,6 +277,7 @@ def run_reference(name: str):
         'action_names': env.action_names, 'observation_names': env.observation_names,
         'shared_observations': env.shared_observations,
         'time_steps': int(env.time_steps), 'time_step_ratio': float(env.time_step_ratio),
+        **({'noise_seed': seed} if '__noise_std__' in env_kwargs else {}),
         'electric_vehicles': [{'name': ev.name, 'capacity': float(ev.battery.capacity), 'nominal_power': float(ev.battery.nominal_power),
                                'initial_soc': float(ev.battery.initial_soc), 'depth_of_discharge': float(ev.battery.depth_of_discharge),
                                'efficiency': float(ev.battery.efficiency_history[0]), 'loss_coefficient': float(ev.battery.loss_coefficient),
@@ -427,7 +437,8 @@ def run_conditions(name: str):
 
 
 OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300, 'g2020_15min': 120, 's_baeda': 95, 's_2021': 95,
-                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239, 'g_cc_demo': 167, 'g_evs_15min': 119, 'g_evs_central': 119}
+                's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239, 'g_cc_demo': 167, 'g_evs_15min': 119, 'g_evs_central': 119,
+                'g_evs_noise': 119}
 
 
 if __name__ == '__main__':

@@ -38,6 +38,8 @@ class Golden:
         if schema_overrides:            # schema as a dictionary with top-level keys replaced
             schema = {**json.loads(open(self.schema_path).read()), **schema_overrides, 'root_directory': str(self.dir / 'dataset')}
             return load_district(schema, **kwargs)
+        if 'noise_seed' in self.facts:         # `noise_std` fixtures: the harness seeded numpy's global generator with this
+            kwargs.setdefault('noise_seed', self.facts['noise_seed'])
         spec = load_district(self.schema_path, **kwargs)
         # EVs without an `initial_soc` get one draw of Python's global `random` in the reference (citylearn.py:2564), which
         # other libraries also consume during construction: the fixture records the values the reference ended up with

@@ -78,10 +78,6 @@ def test_inputs_the_tables_cannot_express_are_refused(tmp_path):
     schema['buildings']['Building_1']['chargers']['charger_1_1']['attributes']['charge_efficiency_curve'] = [[0.5, 0.9], [0.2, 0.8]]
     with pytest.raises(NotImplementedError, match='increasing'):
         load_district(schema)
-    schema['buildings']['Building_1']['chargers']['charger_1_1']['attributes'].pop('charge_efficiency_curve')
-    schema['buildings']['Building_1']['chargers']['charger_1_1']['noise_std'] = 0.1
-    with pytest.raises(NotImplementedError, match='noise_std'):
-        load_district(schema)
 
 
 @pytest.mark.parametrize('seed', [1, 2, 3])

@@ -15,6 +15,9 @@ def _drift(g, spec, tab):
     by the oracle under the fixture's seed (the oracle test proves that replay reproduces the reference bit for bit)."""
     from oracle.flex_oracle import FlexDistrictOracle
     np.random.seed(g.facts['seed'])
+    if 'noise_seed' in g.facts:          # the loader's `noise_std` draws come out of the same stream first
+        spec = g.spec(noise_seed=None)
+        tab = spec.episode_tables(0)
     o = FlexDistrictOracle(spec, tab, 1, reward='Electric_Vehicles_Reward_Function')
     o.reset()
     for t in range(g.ref['actions'].shape[0]):
@@ -22,7 +25,7 @@ def _drift(g, spec, tab):
     return o.flex[0].drift_log.astype(np.float32)
 
 
-@pytest.mark.parametrize('name', ['g2022_evs', 'g_cc_demo', 'g_evs_15min', 'g_evs_central'])
+@pytest.mark.parametrize('name', ['g2022_evs', 'g_cc_demo', 'g_evs_15min', 'g_evs_central', 'g_evs_noise'])
 def test_flex_step_matches_oracle_and_reference(name):
     from citylearn_amd.engine import StepEngine
     from citylearn_amd import abi
@@ -124,7 +127,7 @@ def _acts(g, env, t):
     return out
 
 
-@pytest.mark.parametrize('name', ['g2022_evs', 'g_cc_demo', 'g_evs_15min', 'g_evs_central'])
+@pytest.mark.parametrize('name', ['g2022_evs', 'g_cc_demo', 'g_evs_15min', 'g_evs_central', 'g_evs_noise'])
 def test_env_on_the_ev_dataset_matches_the_reference(name):
     """`CityLearnEnv` on the 2022 + EVs schema: names, spaces, the observations reset()/step() return (all 534 columns,
     charger and washing-machine columns included), the Electric_Vehicles_Reward_Function rewards, district series and
@@ -133,7 +136,7 @@ def test_env_on_the_ev_dataset_matches_the_reference(name):
     g = golden(name)
     spec = g.spec()
     drift = _drift(g, spec, spec.episode_tables(0))
-    env = CityLearnEnv(g.schema_path, ev_soc_drift=drift)
+    env = CityLearnEnv(g.schema_path, ev_soc_drift=drift, noise_seed=g.facts.get('noise_seed'))
     for ev, fact in zip(env.spec.electric_vehicles, g.facts['electric_vehicles']):      # see golden_util.Golden.spec
         ev.battery.initial_soc = fact['initial_soc']
     assert type(env.reward_function).__name__ == 'Electric_Vehicles_Reward_Function' and env._fused_reward

@@ -14,7 +14,7 @@ def _flat(ll):
     return [k for l in ll for k in l]
 
 
-@pytest.mark.parametrize('name', FIX + ('g2022_evs', 'g_cc_demo', 'g_evs_15min', 'g_evs_central'))
+@pytest.mark.parametrize('name', FIX + ('g2022_evs', 'g_cc_demo', 'g_evs_15min', 'g_evs_central', 'g_evs_noise'))
 @pytest.mark.parametrize('normalize', [False, True])
 def test_reference_mode_tables_match_the_reference(name, normalize):
     g = golden(name)
@@ -35,7 +35,7 @@ def test_reference_mode_tables_match_the_reference(name, normalize):
     assert tab.n_dependent == (4 if name == 'g_cc_demo' else 0)
 
 
-@pytest.mark.parametrize('name', FIX + ('g2022_evs', 'g_cc_demo', 'g_evs_15min', 'g_evs_central'))
+@pytest.mark.parametrize('name', FIX + ('g2022_evs', 'g_cc_demo', 'g_evs_15min', 'g_evs_central', 'g_evs_noise'))
 def test_observation_space_limits_match_the_reference(name):
     g = golden(name)
     o = g.obs
