@@ -772,6 +772,23 @@ __global__ void __launch_bounds__(1024) cl_copy_floor_kernel(const float* __rest
     }
 }
 
+namespace {
+// The rollout policy of one step as a plane of actions (same stream as cl_rollout_kernel: a = low + u (high - low),
+// u = Philox4x32-10(seed; env, column, t)) -- for districts whose state machines live in HBM between steps.
+__global__ void cl_policy_kernel(float* __restrict__ actions, const float* __restrict__ low, const float* __restrict__ high,
+                                 unsigned long long seed, int n_env, int t) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (env >= n_env) return;
+    const float lo = low[col], span = high[col] - lo;
+    actions[(long long)col * n_env + env] = fmaf(cl::philox_u01(seed, (uint32_t)env, (uint32_t)col, (uint32_t)t), span, lo);
+}
+
+__global__ void cl_return_kernel(float* __restrict__ ret_env, const float* __restrict__ reward, int n_env) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < n_env) ret_env[env] += reward[env];
+}
+}  // namespace
+
 extern "C" {
 
 int cl_abi_version(void) { return CL_ABI_VERSION; }
@@ -1014,6 +1031,40 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         hipLaunchKernelGGL(cl_kpi_env_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");
+    return CL_OK;
+}
+
+int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+                        int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env, const float* act_low,
+                        const float* act_high, uint64_t seed, float* policy_actions, float* out_bldg, float* out_env,
+                        float* ret_env, const cl_flex* flex, int32_t t0, int32_t k_steps, void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(flex, "flex")) return rc;
+    if (int rc = check_ptr(actions, "actions", false)) return rc;
+    if (int rc = check_ptr(ret_env, "ret_env", false)) return rc;
+    if (!actions && dims->n_act_cols > 0) {
+        if (!act_low || !act_high) return fail(CL_ENULL, "act_low / act_high are required for the on-device policy");
+        if (int rc = check_ptr(policy_actions, "policy_actions")) return rc;
+        if (dims->n_env % 4) return fail(CL_EALIGN, "the on-device policy needs n_env to be a multiple of 4 (got %d)", dims->n_env);
+    }
+    if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "CLD_KPI is not implemented for rollouts");
+    if (k_steps < 0 || t0 < 0 || t0 + k_steps > dims->n_steps)
+        return fail(CL_ERANGE, "steps [%d, %d) outside [0, %d)", t0, t0 + k_steps, dims->n_steps);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((dims->n_env + 255) / 256);
+    for (int k = 0; k < k_steps; ++k) {
+        const int t = t0 + k;
+        const float* a = actions ? actions + (long long)k * act_stride_step : policy_actions;
+        if (!actions && dims->n_act_cols > 0)
+            hipLaunchKernelGGL(cl_policy_kernel, dim3(gx, (unsigned)dims->n_act_cols), dim3(256), 0, s, policy_actions, act_low, act_high,
+                               (unsigned long long)seed, dims->n_env, t);
+        if (int rc = cl_step_flex_f32(dims, params, ts, state, a, actions ? act_stride_col : (int64_t)dims->n_env,
+                                      actions ? act_stride_env : (int64_t)1, out_bldg, out_env, nullptr, nullptr, flex, t, stream))
+            return rc;
+        if (ret_env)
+            hipLaunchKernelGGL(cl_return_kernel, dim3(gx), dim3(256), 0, s, ret_env, out_env + (long long)CLQ_REWARD * dims->n_env, dims->n_env);
+    }
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_flex_f32 launch");
     return CL_OK;
 }
 

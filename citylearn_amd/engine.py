@@ -213,13 +213,12 @@ class StepEngine:
 
     def rollout(self, k_steps: int, actions: Optional[torch.Tensor] = None, seed: int = 0,
                 ret_env: Optional[torch.Tensor] = None, t0: Optional[int] = None):
-        """Fused K-step rollout in one launch (`cl_rollout_f32`): state stays in registers between steps.
+        """Fused K-step rollout in one launch (`cl_rollout_f32`): state stays in registers between steps.  Districts with
+        flexible loads run the same K steps as K x (policy, flex, step) launches (`cl_rollout_flex_f32`), same action streams.
 
         ``actions``: open-loop float32 tensor ``[k_steps, n_act_cols, n_env]`` (any strides), or ``None`` for the
         on-device policy ``a = low + u (high - low)``, ``u = Philox4x32-10(seed; env, column, t)``.
         ``ret_env`` (``[n_env]``, optional) accumulates the district reward summed over the K steps."""
-        if self.flex is not None:
-            raise NotImplementedError('the fused rollout does not advance EV chargers / washing machines yet; use step()')
         t0 = self.t if t0 is None else t0
         st = (0, 0, 0)
         if actions is not None:
@@ -230,6 +229,17 @@ class StepEngine:
             st = actions.stride()
         elif getattr(self, 'act_low', None) is None:
             raise ValueError('call set_action_limits(low, high) before using the on-device policy')
+        if self.flex is not None:
+            if actions is None and getattr(self, '_policy_actions', None) is None:
+                self._policy_actions = torch.empty((self.n_act_cols, self.n_env), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.cl_rollout_flex_f32(
+                    ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
+                    _ptr(getattr(self, 'act_low', None)), _ptr(getattr(self, 'act_high', None)), int(seed) & (2 ** 64 - 1),
+                    _ptr(None if actions is not None else self._policy_actions), _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env),
+                    self._flex_ref, int(t0), int(k_steps), self._stream()))
+            self.t = t0 + k_steps
+            return
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cl_rollout_f32(
                 ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],

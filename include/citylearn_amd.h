@@ -474,6 +474,18 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
                      float* out_bldg, float* out_env, float* kpi_bldg, float* kpi_env, const cl_flex* flex,
                      int32_t t, void* stream);
 
+/* cl_rollout_f32 for a district with flexible loads: charger / EV / washing-machine state lives in HBM between steps, so
+ * the K steps are K x (policy, flex, step, return) launches enqueued on `stream` (capturable in a hipGraph) rather than
+ * one fused kernel.  Same action sources as cl_rollout_f32: open-loop `actions` [k_steps][n_act_cols][n_env] (strides in
+ * floats) or, with actions == NULL, the on-device policy a = low + u (high - low), u = cl_philox_uniform(seed, env,
+ * column, t), written per step to `policy_actions` [n_act_cols][n_env] (required then; n_env a multiple of 4).
+ * `ret_env` [n_env] (optional) accumulates the district reward; out_bldg / out_env hold the LAST step's values. */
+int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
+                        const float* actions, int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env,
+                        const float* act_low, const float* act_high, uint64_t seed, float* policy_actions,
+                        float* out_bldg, float* out_env, float* ret_env, const cl_flex* flex,
+                        int32_t t0, int32_t k_steps, void* stream);
+
 /* Philox4x32-10 reference draw used by cl_rollout_f32 (host-callable so tests can reproduce the policy):
  * returns u in [0,1) for (seed, env, col, t). */
 float cl_philox_uniform(uint64_t seed, uint32_t env, uint32_t col, uint32_t t);
