@@ -85,6 +85,34 @@ class _BuildingView:
     def electrical_storage_soc(self) -> np.ndarray:
         return self._series('soc')
 
+    @property
+    def net_electricity_consumption_cost(self) -> np.ndarray:
+        return self._series('cost')
+
+    @property
+    def net_electricity_consumption_emission(self) -> np.ndarray:
+        return self._series('emission')
+
+
+def _end_use_property(key: str, doc: str):
+    return property(lambda self: self._series(key), doc=doc)
+
+
+# end-use series of the completed steps (building.py:384-470, 584-634), read back from the step kernel's detail planes
+_END_USE_SERIES = {
+    'cooling_electricity_consumption': ('c_cool', '`cooling_device` electricity consumption [kWh]'),
+    'heating_electricity_consumption': ('c_heat', '`heating_device` electricity consumption [kWh]'),
+    'dhw_electricity_consumption': ('c_dhw', '`dhw_device` electricity consumption [kWh]'),
+    'non_shiftable_load_electricity_consumption': ('c_ns', 'non-shiftable load served from the grid / storage [kWh]'),
+    'electrical_storage_electricity_consumption': ('c_b', '`electrical_storage` electricity consumption (negative = discharge) [kWh]'),
+    'cooling_demand': ('cool_dem', 'cooling demand that was met [kWh]'),
+    'heating_demand': ('heat_dem', 'heating demand that was met [kWh]'),
+    'dhw_demand': ('dhw_dem', 'domestic hot water demand that was met [kWh]'),
+    'solar_generation': ('solar', '`PV` generation (negative values) [kWh]'),
+}
+for _name, (_key, _doc) in _END_USE_SERIES.items():
+    setattr(_BuildingView, _name, _end_use_property(_key, _doc))
+
 
 class CityLearnEnv:
     """One CityLearn district stepped on the GPU.  See the module docstring for the mirrored interface."""
@@ -206,6 +234,12 @@ class CityLearnEnv:
     def net_electricity_consumption_emission(self) -> List[float]:
         return list(self._hist['d_emission'])
 
+    def __getattr__(self, name: str):
+        # district totals of the buildings' end-use series (citylearn.py:700-870): summed over buildings, completed steps only
+        if name in _END_USE_SERIES and '_hist' in self.__dict__:
+            return self._history_array(_END_USE_SERIES[name][0]).sum(axis=1)
+        raise AttributeError(f'{type(self).__name__!r} object has no attribute {name!r}')
+
     def get_info(self) -> Mapping[Any, Any]:
         return {}
 
@@ -247,7 +281,8 @@ class CityLearnEnv:
         self.reward_function.reset()
         self.__rewards = [[]]
         self._hist: Dict[str, list] = {k: [] for k in ('net', 'base_net', 'net_ws', 'soc', 'cost', 'emission', 'expected', 'served',
-                                                       'd_net', 'd_cost', 'd_emission', 'indoor_temp')}
+                                                       'd_net', 'd_cost', 'd_emission', 'indoor_temp', 'c_cool', 'c_heat', 'c_dhw', 'c_ns',
+                                                       'c_b', 'cool_dem', 'heat_dem', 'dhw_dem', 'solar')}
         self._obs_tables = self._layout.episode(self._tables)
         return self.observations, self.get_info()
 
@@ -287,6 +322,14 @@ class CityLearnEnv:
         h['net_ws'].append(ob[abi.CLO_NET_WS])
         h['expected'].append(ob[abi.CLO_EXPECTED]); h['served'].append(ob[abi.CLO_SERVED])
         ts = self._tables.ts[t]
+        for key, plane in (('c_cool', abi.CLO_C_COOL), ('c_heat', abi.CLO_C_HEAT), ('c_dhw', abi.CLO_C_DHW), ('c_ns', abi.CLO_C_NSL),
+                           ('cool_dem', abi.CLO_COOL_DEM), ('heat_dem', abi.CLO_HEAT_DEM), ('dhw_dem', abi.CLO_DHW_DEM)):
+            h[key].append(ob[plane])
+        # Battery.charge and Building.update_variables both book the energy balance at t = 0 (building.py:2650-2652 runs in
+        # reset too), and ElectricDevice.electricity_consumption is scaled by the time-step ratio like the planes above
+        ratio = np.array([b.time_step_ratio for b in self.spec.buildings], dtype='float32')
+        h['c_b'].append(ob[abi.CLO_B_EB] * ratio * (2.0 if t == 0 and self.reference_quirks else 1.0))
+        h['solar'].append(ts[:, abi.CLT_SOLAR].astype('float32'))
         net64 = ob[abi.CLO_NET].astype(np.float64)
         h['cost'].append((net64 * ts[:, abi.CLT_PRICE]).astype('float32'))
         h['emission'].append(np.maximum(0.0, net64 * ts[:, abi.CLT_CARBON]).astype('float32'))

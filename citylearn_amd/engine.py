@@ -124,6 +124,8 @@ class StepEngine:
         self._step_head = (ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state))
         self._step_tail = (_ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env))
         self._flex_ref = None if self.flex is None else ctypes.byref(self.flex)
+        self.act_low = self.act_high = None         # bounds of the on-device rollout policy (set_action_limits)
+        self._policy_actions = None                 # scratch plane of cl_rollout_flex_f32
         self.t = 0
         self.reset()
 
@@ -227,15 +229,15 @@ class StepEngine:
             if tuple(actions.shape) != (k_steps, self.n_act_cols, self.n_env):
                 raise ValueError(f'actions shape {tuple(actions.shape)} != {(k_steps, self.n_act_cols, self.n_env)}')
             st = actions.stride()
-        elif getattr(self, 'act_low', None) is None:
+        elif self.act_low is None:
             raise ValueError('call set_action_limits(low, high) before using the on-device policy')
         if self.flex is not None:
-            if actions is None and getattr(self, '_policy_actions', None) is None:
+            if actions is None and self._policy_actions is None:
                 self._policy_actions = torch.empty((self.n_act_cols, self.n_env), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.cl_rollout_flex_f32(
                     ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
-                    _ptr(getattr(self, 'act_low', None)), _ptr(getattr(self, 'act_high', None)), int(seed) & (2 ** 64 - 1),
+                    _ptr(self.act_low), _ptr(self.act_high), int(seed) & (2 ** 64 - 1),
                     _ptr(None if actions is not None else self._policy_actions), _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env),
                     self._flex_ref, int(t0), int(k_steps), self._stream()))
             self.t = t0 + k_steps
@@ -243,7 +245,7 @@ class StepEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cl_rollout_f32(
                 ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
-                _ptr(getattr(self, 'act_low', None)), _ptr(getattr(self, 'act_high', None)), int(seed) & (2 ** 64 - 1),
+                _ptr(self.act_low), _ptr(self.act_high), int(seed) & (2 ** 64 - 1),
                 _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env), None, None, int(t0), int(k_steps), self._stream()))
         self.t = t0 + k_steps
 

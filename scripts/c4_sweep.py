@@ -1,0 +1,28 @@
+import sys, os
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests')); sys.path.insert(0, str(ROOT / 'scripts'))
+import torch, ctypes
+from golden_util import golden
+from citylearn_amd.engine import StepEngine
+from citylearn_amd.synthetic import tile_district
+from c4_bench import measure
+for label, fixture, B, E in (('2020 schema', 'g2020_cz1', None, 65536), ('C4 2020 devices', 'g2020_cz1', 1024, 1024), ('C4 2022 devices', 'g2022_all', 1024, 1024), ('C3 2023', 'g2023_p2', None, 65536)):
+    spec = golden(fixture).spec()
+    if B: spec = tile_district(spec, B)
+    tab = spec.episode_tables(0)
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+    acts = [lo[:, None] + torch.rand((len(low), E), device='cuda') * (hi - lo)[:, None] for _ in range(2)]
+    for vec in (0, 1, 2, 4):
+        for nw in ((0,) if B else (0, 3, 5, 9, 16)):
+            eng = StepEngine(tab, E)
+            eng.lib.cl_debug_set_vec(vec)
+            eng.lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
+            eng.lib.cl_debug_set_lean(0, nw)
+            try:
+                us = measure(eng, acts, steps=40, reps=4)
+                print(f'{label} vec={vec} nw={nw}: {us:.2f} us', flush=True)
+            except Exception as e:
+                print(f'{label} vec={vec} nw={nw}: {type(e).__name__} {str(e)[:80]}', flush=True)
+            eng.lib.cl_debug_set_vec(0); eng.lib.cl_debug_set_lean(0, 0)

@@ -19,7 +19,7 @@ def _actions(g, env, t):
     return out
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
 def test_env_matches_reference_api_and_rewards(name):
     from citylearn_amd.citylearn import CityLearnEnv
     g = golden(name)
@@ -45,6 +45,23 @@ def test_env_matches_reference_api_and_rewards(name):
         np.testing.assert_allclose(reward, ref, rtol=1e-3, atol=1e-3)
         assert not truncated and info == {} and terminated == (t == env.time_steps - 2)
     np.testing.assert_allclose(env.net_electricity_consumption, g.ref['d_net'][:K], rtol=1e-3, atol=2e-3)
+    # end-use series of the completed steps, per building and summed (building.py:384-470, citylearn.py:700-870)
+    pairs = (('cooling_electricity_consumption', 'c_cool'), ('heating_electricity_consumption', 'c_heat'), ('dhw_electricity_consumption', 'c_dhw'),
+             ('non_shiftable_load_electricity_consumption', 'c_ns'), ('electrical_storage_electricity_consumption', 'c_b'),
+             ('cooling_demand', 'cool_dem'), ('net_electricity_consumption_cost', 'cost'), ('net_electricity_consumption_emission', 'emission'))
+    for prop, key in pairs:
+        got = np.stack([getattr(b, prop) for b in env.buildings], axis=1)
+        assert got.shape == (K, len(env.buildings))
+        np.testing.assert_allclose(got, g.ref[key][:K], rtol=1e-4, atol=2e-4, err_msg=prop)
+        if not prop.startswith('net_'):
+            np.testing.assert_allclose(getattr(env, prop), g.ref[key][:K].astype(np.float64).sum(axis=1), rtol=1e-4, atol=1e-3, err_msg=prop)
+    parts = sum(getattr(env, p) for p in ('cooling_electricity_consumption', 'heating_electricity_consumption', 'dhw_electricity_consumption',
+                                          'non_shiftable_load_electricity_consumption', 'electrical_storage_electricity_consumption', 'solar_generation'))
+    grid = g.ref['outage'][:K].sum(axis=1) == 0 if 'outage' in g.ref.files else np.ones(K, dtype=bool)
+    np.testing.assert_allclose(parts[grid], g.ref['d_net'][:K][grid], rtol=1e-4, atol=5e-3)       # building.py:2686-2693
+    assert float(env.solar_generation.min()) < 0.0 and float(env.solar_generation.max()) <= 0.0
+    with pytest.raises(AttributeError):
+        env.no_such_series
     # reference semantics: the returned SoC / net observations are the untouched slots of step t+1
     names = env.observation_names[0]
     if 'electrical_storage_soc' in names:
