@@ -139,6 +139,15 @@ class CityLearnEnv:
         self.shared_observations = list(self.spec.shared_observations)
         self.random_seed = self.spec.random_seed
         self.seconds_per_time_step = self.spec.seconds_per_time_step
+        # configuration read-backs of the reference env (citylearn.py:207-450)
+        self.schema = self.spec.schema
+        self.root_directory = self.spec.root_directory
+        self.simulation_start_time_step = self.spec.simulation_start_time_step
+        self.simulation_end_time_step = self.spec.simulation_end_time_step
+        self.episode_time_steps = self.spec.episode_time_steps
+        self.rolling_episode_split = self.spec.rolling_episode_split
+        self.random_episode_split = self.spec.random_episode_split
+        self.render_enabled = False                 # rendering / export are outside the step path
         rf_cls = resolve_reward(self.spec.reward_function.get('type'))
         self.reward_function: RewardFunction = rf_cls(None, **(self.spec.reward_function.get('attributes') or {}))
         self.buildings = [_BuildingView(self, i) for i in range(len(self.spec.buildings))]
@@ -206,6 +215,19 @@ class CityLearnEnv:
         return self._episode
 
     @property
+    def time_step_ratio(self) -> float:
+        """Control step over data-file step (the value the reference env hands every building, citylearn.py:2183, 939-944)."""
+        return float(self.spec.buildings[0].time_step_ratio)
+
+    @property
+    def episode_tracker(self):
+        """Start / end time step of the running episode in simulation time (`EpisodeTracker`, base.py:9-98)."""
+        from types import SimpleNamespace
+        return SimpleNamespace(episode=self._episode, episode_start_time_step=self._tables.start, episode_end_time_step=self._tables.end,
+                               episode_time_steps=self.time_steps, simulation_start_time_step=self.simulation_start_time_step,
+                               simulation_end_time_step=self.simulation_end_time_step)
+
+    @property
     def terminated(self) -> bool:
         return self._t == self.time_steps - 1          # citylearn.py:373-376
 
@@ -239,6 +261,15 @@ class CityLearnEnv:
         if name in _END_USE_SERIES and '_hist' in self.__dict__:
             return self._history_array(_END_USE_SERIES[name][0]).sum(axis=1)
         raise AttributeError(f'{type(self).__name__!r} object has no attribute {name!r}')
+
+    @staticmethod
+    def get_default_shared_observations() -> List[str]:
+        """Observations a central agent sees once rather than once per building (citylearn.py:951-976): calendar, weather and
+        its forecasts, carbon intensity, price and its forecasts."""
+        horizons = ('', '_predicted_1', '_predicted_2', '_predicted_3')
+        weather = ('outdoor_dry_bulb_temperature', 'outdoor_relative_humidity', 'diffuse_solar_irradiance', 'direct_solar_irradiance')
+        return ['month', 'day_type', 'hour', 'minutes', 'daylight_savings_status'] + [k + h for k in weather for h in horizons] \
+            + ['carbon_intensity'] + ['electricity_pricing' + h for h in horizons]
 
     def get_info(self) -> Mapping[Any, Any]:
         return {}

@@ -62,6 +62,13 @@ def test_env_matches_reference_api_and_rewards(name):
     assert float(env.solar_generation.min()) < 0.0 and float(env.solar_generation.max()) <= 0.0
     with pytest.raises(AttributeError):
         env.no_such_series
+    # configuration read-backs (citylearn.py:207-450)
+    tr = env.episode_tracker
+    assert (tr.episode_start_time_step, tr.episode_end_time_step, tr.episode_time_steps) == (0, g.facts['time_steps'] - 1, g.facts['time_steps'])
+    assert env.time_step_ratio == g.facts['time_step_ratio'] and env.root_directory and isinstance(env.schema, dict)
+    shared = env.get_default_shared_observations()
+    assert len(shared) == 26 and set(env.shared_observations) <= set(shared) and shared[5:7] == ['outdoor_dry_bulb_temperature', 'outdoor_dry_bulb_temperature_predicted_1']
+    assert env.episode_time_steps is None and not env.rolling_episode_split and not env.random_episode_split and not env.render_enabled
     # reference semantics: the returned SoC / net observations are the untouched slots of step t+1
     names = env.observation_names[0]
     if 'electrical_storage_soc' in names:
