@@ -77,9 +77,16 @@ class _BuildingView:
     def net_electricity_consumption(self) -> np.ndarray:
         return self._series('net')
 
-    @property
-    def net_electricity_consumption_without_storage(self) -> np.ndarray:
-        return self._series('base_net')
+    def _condition(self, suffix: str, kind: str) -> np.ndarray:
+        """`net_electricity_consumption[_cost|_emission]<suffix>` (building.py:320-411, 2850-2905): the counterfactual net series
+        of an `EvaluationCondition`, priced / weighted like the reference (series * price, max(0, series * carbon))."""
+        env = self._env
+        net = env._condition_series(suffix, only=self._i).astype(np.float64)
+        if kind == '':
+            return net.astype('float32')
+        col = abi.CLT_PRICE if kind == '_cost' else abi.CLT_CARBON
+        weighted = net * env._tables.ts[:len(net), self._i, col]
+        return (weighted if kind == '_cost' else np.maximum(0.0, weighted)).astype('float32')
 
     @property
     def electrical_storage_soc(self) -> np.ndarray:
@@ -112,6 +119,11 @@ _END_USE_SERIES = {
 }
 for _name, (_key, _doc) in _END_USE_SERIES.items():
     setattr(_BuildingView, _name, _end_use_property(_key, _doc))
+_CONDITION_SUFFIXES = ('_without_storage', '_without_storage_and_pv', '_without_storage_and_partial_load', '_without_storage_and_partial_load_and_pv')
+for _suffix in _CONDITION_SUFFIXES:
+    for _kind in ('', '_cost', '_emission'):
+        setattr(_BuildingView, f'net_electricity_consumption{_kind}{_suffix}',
+                property(lambda self, s=_suffix, k=_kind: self._condition(s, k)))
 
 
 class CityLearnEnv:
@@ -260,6 +272,8 @@ class CityLearnEnv:
         # district totals of the buildings' end-use series (citylearn.py:700-870): summed over buildings, completed steps only
         if name in _END_USE_SERIES and '_hist' in self.__dict__:
             return self._history_array(_END_USE_SERIES[name][0]).sum(axis=1)
+        if name.startswith('net_electricity_consumption') and name.endswith(_CONDITION_SUFFIXES) and '_hist' in self.__dict__:
+            return np.sum([getattr(b, name).astype(np.float64) for b in self.buildings], axis=0)
         raise AttributeError(f'{type(self).__name__!r} object has no attribute {name!r}')
 
     @staticmethod
@@ -481,8 +495,15 @@ class CityLearnEnv:
                                  h('expected'), h('served'), np.array(self._hist['d_net'], dtype=np.float64), comfort_band,
                                  indoor_temp=h('indoor_temp'), condition_series=series)
 
-    def _condition_series(self, suffix: str) -> np.ndarray:
-        """``[K, n_bldg]`` series `Building.net_electricity_consumption<suffix>` (building.py:320-366, 2850-2905)."""
+    def _condition_series(self, suffix: str, only: int = None) -> np.ndarray:
+        """``[K, n_bldg]`` series `Building.net_electricity_consumption<suffix>` (building.py:320-366, 2850-2905); ``only``: one
+        building's column (the partial-load conditions exist on dynamics buildings only)."""
+        if only is not None:
+            if 'partial_load' in suffix and not self.spec.buildings[only].is_dynamics:
+                raise AttributeError(f"building {self.spec.buildings[only].name} has no attribute 'net_electricity_consumption{suffix}' (not a dynamics building)")
+            key = {'': 'net', '_without_storage': 'net_ws', '_without_storage_and_pv': 'net_ws'}.get(suffix, 'base_net')
+            out = self._history_array(key)[:, only]
+            return out - self._tables.ts[:self._t, only, abi.CLT_SOLAR].astype(np.float32) if suffix.endswith('_and_pv') else out
         h = self._history_array
         K = self._t
         solar = self._tables.ts[:K, :, abi.CLT_SOLAR].astype(np.float32)          # solar_generation (<= 0)

@@ -62,6 +62,22 @@ def test_env_matches_reference_api_and_rewards(name):
     assert float(env.solar_generation.min()) < 0.0 and float(env.solar_generation.max()) <= 0.0
     with pytest.raises(AttributeError):
         env.no_such_series
+    # counterfactual series of the evaluation conditions (building.py:320-411, 2850-2905); `base_net` in the fixture is the
+    # reference's baseline series: without storage (and, on dynamics buildings, without partial load)
+    dyn = env.buildings[0].spec.is_dynamics
+    base_name = 'net_electricity_consumption_without_storage' + ('_and_partial_load' if dyn else '')
+    base = np.stack([getattr(b, base_name) for b in env.buildings], axis=1)
+    np.testing.assert_allclose(base, g.ref['base_net'][:K], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(getattr(env, base_name), g.ref['base_net'][:K].sum(axis=1), rtol=1e-4, atol=2e-3)
+    b0 = env.buildings[0]
+    no_pv = getattr(b0, base_name + '_and_pv')
+    np.testing.assert_allclose(no_pv, base[:, 0] - b0.solar_generation, rtol=1e-6, atol=1e-5)
+    price = np.array(b0.spec.series['electricity_pricing'][:K], dtype=np.float64)
+    np.testing.assert_allclose(getattr(b0, base_name.replace('consumption', 'consumption_cost')), base[:, 0] * price, rtol=1e-5, atol=1e-5)
+    assert float(getattr(b0, base_name.replace('consumption', 'consumption_emission')).min()) >= 0.0
+    if not dyn:
+        with pytest.raises(AttributeError, match='not a dynamics building'):
+            b0.net_electricity_consumption_without_storage_and_partial_load
     # configuration read-backs (citylearn.py:207-450)
     tr = env.episode_tracker
     assert (tr.episode_start_time_step, tr.episode_end_time_step, tr.episode_time_steps) == (0, g.facts['time_steps'] - 1, g.facts['time_steps'])
