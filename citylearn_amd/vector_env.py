@@ -205,6 +205,24 @@ class VectorCityLearnEnv:
             reward = e.district_reward if self.central_agent else e.reward_bldg
         return self._obs(), reward, self.terminated, False, {}
 
+    def rollout(self, k_steps: int, actions: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
+        """Advance ``k_steps`` steps without returning to Python in between (`StepEngine.rollout`: one fused launch, or a launch
+        sequence for districts with flexible loads) with open-loop ``actions`` ``[k_steps, n_act_cols, n_envs]`` or the uniform
+        random policy keyed by ``seed`` (the device analogue of `Agent.predict`, agents/base.py:188-209).  Returns the district
+        reward summed over those steps, ``[n_envs]``.  Not available with the LSTM temperature stage or streaming KPIs, which
+        need their own kernels between steps -- use :meth:`step` there."""
+        if self.stage is not None or self.engine.kpi:
+            raise NotImplementedError('rollout() needs a district without the LSTM temperature stage and kpi=False; use step()')
+        if self._t + k_steps > self.time_steps - 1:
+            raise RuntimeError(f'{k_steps} steps from t={self._t} run past the episode end ({self.time_steps - 1} steps)')
+        e = self.engine
+        if actions is None and e.act_low is None:
+            e.set_action_limits(self.action_low.cpu().numpy(), self.action_high.cpu().numpy())
+        ret = torch.zeros(self.n_envs, dtype=torch.float32, device=self.device)
+        e.rollout(k_steps, actions=actions, seed=seed, ret_env=ret, t0=self._t)
+        self._t += k_steps
+        return ret
+
     def evaluate(self):
         """Per-env KPI ratios of `CityLearnEnv.evaluate` (citylearn.py:1136-1323) from the on-device streaming
         accumulators (construct with ``kpi=True``).  Returns ``(building, district)`` dicts of tensors."""

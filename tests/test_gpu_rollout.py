@@ -80,3 +80,31 @@ def test_rollout_errors():
     with pytest.raises(_lib.EngineError) as e:
         eng.rollout(10 ** 6, actions=None, seed=1) if eng.set_action_limits(*g.spec().action_limits()) is None else None
     assert e.value.code == abi.CL_ERANGE
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2022_evs'])
+def test_vector_env_rollout_matches_stepping(name):
+    """`VectorCityLearnEnv.rollout` (fused kernel, or the launch sequence on the EV district) against `step()` fed with the host
+    restatement of the same Philox policy stream: same episode return, same state, and the env carries on from there."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden(name)
+    E, K, seed = 64, 12, 21
+    kw = dict(reward_function='citylearn.reward_function.RewardFunction', ev_seed=5) if name == 'g2022_evs' else {}
+    a, b = VectorCityLearnEnv(g.schema_path, E, **kw), VectorCityLearnEnv(g.schema_path, E, **kw)
+    lib = _lib.load()
+    low, high = a.action_low.cpu().numpy(), a.action_high.cpu().numpy()
+    u = np.array([[[lib.cl_philox_uniform(seed, e, c, t) for e in range(E)] for c in range(len(low))] for t in range(K)], dtype=np.float32)
+    acts = torch.from_numpy((low[None, :, None] + u * (high - low)[None, :, None]).astype(np.float32)).cuda()
+    ret_ref = torch.zeros(E, device='cuda')
+    for k in range(K):
+        _, reward, *_ = a.step(acts[k])
+        ret_ref += reward.sum(dim=0)
+    ret = b.rollout(K, seed=seed)
+    assert b.time_step == a.time_step == K
+    torch.testing.assert_close(ret, ret_ref, rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(b.engine.state, a.engine.state, rtol=2e-5, atol=2e-5)
+    nxt = a.sample_actions(torch.Generator(device='cuda').manual_seed(1))
+    ra, rb = a.step(nxt)[1], b.step(nxt)[1]
+    torch.testing.assert_close(rb, ra, rtol=1e-4, atol=1e-3)
+    with pytest.raises(RuntimeError, match='past the episode end'):
+        b.rollout(b.time_steps)
