@@ -417,3 +417,35 @@ def test_flex_rollout_equals_single_steps(reward):
     d.set_action_limits(low, high)
     d.rollout(K, seed=seed + 1)
     assert not torch.equal(d.ev_state, c.ev_state)
+
+
+def test_flex_rollout_replays_from_a_hip_graph():
+    """`cl_rollout_flex_f32` only enqueues kernels on the caller's stream, so a whole K-step rollout of an EV district can be
+    captured once and replayed: same state as the eager call."""
+    from citylearn_amd.engine import StepEngine
+    g = golden('g2022_evs')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E, K = 256, 24
+    low, high = spec.action_limits()
+    eng, ref = StepEngine(tab, E, reward='MARL', ev_seed=3), StepEngine(tab, E, reward='MARL', ev_seed=3)
+    for e in (eng, ref):
+        e.set_action_limits(low, high)
+    ret, ret_ref = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        eng.rollout(2, seed=1)                      # allocates the policy plane outside the capture
+        eng.reset()
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            eng.rollout(K, seed=9, ret_env=ret, t0=0)
+        for _ in range(2):                          # replaying twice from a fresh episode gives the same episode twice
+            eng.reset()
+            ret.zero_()
+            graph.replay()
+        stream.synchronize()
+    ref.rollout(K, seed=9, ret_env=ret_ref)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.state, ref.state) and torch.equal(eng.ev_state, ref.ev_state) and torch.equal(eng.wm_state, ref.wm_state)
+    assert torch.equal(ret, ret_ref) and float(ret.abs().sum()) > 0
