@@ -773,14 +773,19 @@ __global__ void __launch_bounds__(1024) cl_copy_floor_kernel(const float* __rest
 }
 
 namespace {
-// The rollout policy of one step as a plane of actions (same stream as cl_rollout_kernel: a = low + u (high - low),
-// u = Philox4x32-10(seed; env, column, t)) -- for districts whose state machines live in HBM between steps.
+// The rollout policy as planes of actions (same stream as cl_rollout_kernel: a = low + u (high - low),
+// u = Philox4x32-10(seed; env, column, t)) -- for districts whose state machines live in HBM between steps.  One Philox
+// block holds the draws of four consecutive steps (word t & 3 of block t >> 2), so one launch fills the four planes
+// actions[t & 3][column][env] of steps 4 tq .. 4 tq + 3 (one plane per launch measured 19 us at 26 x 65 536: the ten
+// rounds of quarter-rate 32-bit multiplies, three of four words thrown away).
 __global__ void cl_policy_kernel(float* __restrict__ actions, const float* __restrict__ low, const float* __restrict__ high,
-                                 unsigned long long seed, int n_env, int t) {
+                                 unsigned long long seed, int n_env, int n_cols, int tq) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
     if (env >= n_env) return;
     const float lo = low[col], span = high[col] - lo;
-    actions[(long long)col * n_env + env] = fmaf(cl::philox_u01(seed, (uint32_t)env, (uint32_t)col, (uint32_t)t), span, lo);
+    const cl::U4 blk = cl::philox_block(seed, (uint32_t)env, (uint32_t)col, (uint32_t)tq);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) actions[((long long)w * n_cols + col) * n_env + env] = fmaf(cl::u01(blk.w[w]), span, lo);
 }
 
 __global__ void cl_return_kernel(float* __restrict__ ret_env, const float* __restrict__ reward, int n_env) {
@@ -1054,10 +1059,11 @@ int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float
     const unsigned gx = (unsigned)((dims->n_env + 255) / 256);
     for (int k = 0; k < k_steps; ++k) {
         const int t = t0 + k;
-        const float* a = actions ? actions + (long long)k * act_stride_step : policy_actions;
-        if (!actions && dims->n_act_cols > 0)
+        const float* a = actions ? actions + (long long)k * act_stride_step
+                                 : policy_actions + (long long)(t & 3) * dims->n_act_cols * dims->n_env;
+        if (!actions && dims->n_act_cols > 0 && (k == 0 || (t & 3) == 0))
             hipLaunchKernelGGL(cl_policy_kernel, dim3(gx, (unsigned)dims->n_act_cols), dim3(256), 0, s, policy_actions, act_low, act_high,
-                               (unsigned long long)seed, dims->n_env, t);
+                               (unsigned long long)seed, dims->n_env, dims->n_act_cols, t >> 2);
         if (int rc = cl_step_flex_f32(dims, params, ts, state, a, actions ? act_stride_col : (int64_t)dims->n_env,
                                       actions ? act_stride_env : (int64_t)1, out_bldg, out_env, nullptr, nullptr, flex, t, stream))
             return rc;

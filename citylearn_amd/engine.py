@@ -125,7 +125,7 @@ class StepEngine:
         self._step_tail = (_ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env))
         self._flex_ref = None if self.flex is None else ctypes.byref(self.flex)
         self.act_low = self.act_high = None         # bounds of the on-device rollout policy (set_action_limits)
-        self._policy_actions = None                 # scratch plane of cl_rollout_flex_f32
+        self._policy_actions = None                 # scratch planes of cl_rollout_flex_f32 (four steps of policy draws)
         self.t = 0
         self.reset()
 
@@ -233,7 +233,7 @@ class StepEngine:
             raise ValueError('call set_action_limits(low, high) before using the on-device policy')
         if self.flex is not None:
             if actions is None and self._policy_actions is None:
-                self._policy_actions = torch.empty((self.n_act_cols, self.n_env), dtype=torch.float32, device=self.device)
+                self._policy_actions = torch.empty((4, self.n_act_cols, self.n_env), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.cl_rollout_flex_f32(
                     ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],

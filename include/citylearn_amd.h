@@ -478,7 +478,8 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
  * the K steps are K x (policy, flex, step, return) launches enqueued on `stream` (capturable in a hipGraph) rather than
  * one fused kernel.  Same action sources as cl_rollout_f32: open-loop `actions` [k_steps][n_act_cols][n_env] (strides in
  * floats) or, with actions == NULL, the on-device policy a = low + u (high - low), u = cl_philox_uniform(seed, env,
- * column, t), written per step to `policy_actions` [n_act_cols][n_env] (required then; n_env a multiple of 4).
+ * column, t), generated four steps at a time into the scratch planes `policy_actions` [4][n_act_cols][n_env] (required then;
+ * n_env a multiple of 4).
  * `ret_env` [n_env] (optional) accumulates the district reward; out_bldg / out_env hold the LAST step's values. */
 int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
                         const float* actions, int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env,

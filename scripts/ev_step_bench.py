@@ -68,6 +68,25 @@ def main():
             out[f'flex{fv}/{reward}'] = round(timed(eng, a), 2)
         lib.cl_debug_set_flex(0)
         out[f'graph/{reward}'] = round(timed_graph(eng, a), 2)
+    # K-step rollout with the on-device policy (cl_rollout_flex_f32: policy plane + flex + step + return per step), one graph
+    eng = StepEngine(tab, E, reward='MARL')
+    low, high = spec.action_limits()
+    eng.set_action_limits(low, high)
+    ret = torch.zeros(E, device='cuda')
+    K, reps = 24, 20
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        eng.rollout(2, seed=1); eng.reset(); stream.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=stream):
+            eng.rollout(K, seed=2, ret_env=ret, t0=1)
+        gr.replay(); stream.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        for _ in range(reps):
+            gr.replay()
+        ev1.record(stream); stream.synchronize()
+    out['graph/rollout24/MARL'] = round(ev0.elapsed_time(ev1) / (reps * K) * 1e3, 2)
     import copy
     plain = copy.copy(tab)
     plain.flex = None
