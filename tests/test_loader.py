@@ -164,3 +164,22 @@ def test_noise_std_draws_follow_the_reference_stream():
                 assert np.array_equal(x.series[k], y.series[k])
                 assert np.array_equal(x.series[k] == -0.1, z.series[k] == -0.1)        # placeholders stay placeholders
                 assert not np.array_equal(x.series[k], z.series[k]) or np.all(z.series[k] == -0.1)
+
+
+def test_noise_lands_on_the_stand_in_series_of_absent_files():
+    """A building without a pricing / carbon-intensity file gets zeros in the reference -- built through the same constructors,
+    so `noise_std` perturbs (and clips) those zeros too (citylearn.py:2189-2207)."""
+    g = golden('g_evs_noise')
+    schema = json.load(open(g.schema_path))
+    first = next(iter(schema['buildings']))
+    def variant(std):
+        b = {k: dict(v) for k, v in schema['buildings'].items()}
+        b[first]['pricing'] = None
+        b[first]['carbon_intensity'] = None
+        b[first]['noise_std'] = std
+        return g.spec(schema_overrides={'buildings': b}, noise_seed=3).buildings[0].series
+    quiet, noisy = variant(0.0), variant(0.05)
+    for k in ('electricity_pricing', 'electricity_pricing_predicted_2', 'carbon_intensity'):
+        assert not quiet[k].any() and quiet[k].dtype == noisy[k].dtype == np.float64
+        assert noisy[k].min() == 0.0 and 0.0 < noisy[k].max() <= 1.0            # clip(0 + N(0, std), 0, 1): about half stay 0
+        assert 0.3 < float((noisy[k] > 0).mean()) < 0.7
