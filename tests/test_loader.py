@@ -183,3 +183,24 @@ def test_noise_lands_on_the_stand_in_series_of_absent_files():
         assert not quiet[k].any() and quiet[k].dtype == noisy[k].dtype == np.float64
         assert noisy[k].min() == 0.0 and 0.0 < noisy[k].max() <= 1.0            # clip(0 + N(0, std), 0, 1): about half stay 0
         assert 0.3 < float((noisy[k] > 0).mean()) < 0.7
+
+
+def test_battery_sizing_table_sources(tmp_path):
+    """`Battery.autosize` reads the manufacturer table from next to the dataset, from a path, or from rows handed in; without
+    one the loader says what is missing instead of guessing."""
+    import shutil
+    import yaml
+    g = golden('s_autosize')
+    table_path = g.dir / 'misc' / 'battery_choices.yaml'
+    default = [b.electrical_storage for b in g.spec().buildings]
+    rows = yaml.safe_load(open(table_path))
+    for source in (str(table_path), rows, [(k, v['attributes']) for k, v in rows.items()]):
+        got = [b.electrical_storage for b in g.spec(battery_sizing_data=source).buildings]
+        assert [(e.capacity, e.nominal_power, e.loss_coefficient) for e in got] == [(e.capacity, e.nominal_power, e.loss_coefficient) for e in default]
+    lonely = tmp_path / 'deep' / 'er' / 'dataset'
+    shutil.copytree(g.dir / 'dataset', lonely)
+    with pytest.raises(NotImplementedError, match='battery_choices.yaml'):
+        load_district(str(lonely / 'schema.json'))
+    one = [(k, v['attributes']) for k, v in rows.items()][:1]            # a single model: every building must pick it
+    sized = [b.electrical_storage for b in g.spec(battery_sizing_data=one).buildings]
+    assert all(e.capacity % one[0][1]['capacity'] < 1e-9 or abs(e.capacity % one[0][1]['capacity'] - one[0][1]['capacity']) < 1e-9 for e in sized)
