@@ -9,16 +9,26 @@ Workload (BASELINE.json `metric`): the 17-building `citylearn_challenge_2022_pha
 HBM, fresh actions every step).  A "step" advances every (env, building) unit by one time step.  The env batch
 is sharded across GPUs with no collective on the data path (weak scaling: per-GPU work is fixed).
 
+Timing protocol: W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over
+ranks -- repeated `--reps` times on the same pre-captured, pre-replayed hipGraphs; the line reports the MEDIAN
+repetition (all repetitions are listed in `rep_ms_per_step`).  The kernel duration for the roofline comes from HIP events
+recorded on the launch stream around the same K steps.
+
 Prints ONE JSON line (rank 0).  `value` = building-timesteps/s over all GPUs with inputs resident in HBM.
-`roofline` prices the step kernel against HBM (algorithmic bytes per launch / measured launch duration);
-`cpu_baseline` is the C restatement of the reference arithmetic (oracle/cl_oracle.c, the "port") timed on this
-box's host cores on a bounded sample (rank 0, N = 1 only).
+`roofline` prices the step kernel against HBM (algorithmic bytes per launch / measured launch duration) at the headline
+shape -- whose 58 MB working set sits in the 256 MB Infinity Cache across replays -- and `roofline.hbm_streaming` repeats
+the measurement at 17 x 1 048 576 envs (0.66 GB of step traffic per launch, far beyond the cache): the figure that is
+bounded by HBM proper.  `cpu_baseline` is the C restatement of the reference arithmetic (oracle/cl_oracle.c, the "port")
+timed on this box's host cores on a bounded sample (rank 0, N = 1 only); `cpu_baseline.reference` is the reference's own
+`CityLearnEnv.step` as timed by oracle/ref_harness/time_reference.py on the host named there (the reference cannot run
+on the GPU box: /root/reference does not travel).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -28,10 +38,11 @@ import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / 'tests'))
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_MEASURED_COPY_GBS = 6290.0  # float4 device copy measured on MI355X, same guide
 ENVS_PER_GPU = 65536
+STREAMING_ENVS = 1048576        # second roofline entry: working set >> 256 MB Infinity Cache
 GRAPH_CHUNK = 100
 
 
@@ -53,8 +64,85 @@ def cpu_baseline(spec, tables, seconds: float = 12.0) -> dict:
             ora.step(acts[n % 4], 1 + n % (ora.T - 2))
             n += 1
     dt = time.perf_counter() - t0
-    return {'value': E * ora.B * n / dt, 'unit': 'building-timesteps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'oracle/cl_oracle.c (OpenMP, {cores} threads): 17 buildings x {E} envs x {n} steps in {dt:.1f} s'}
+    out = {'value': E * ora.B * n / dt, 'unit': 'building-timesteps/s', 'cores': cores, 'kind': 'port',
+           'sample': f'oracle/cl_oracle.c (OpenMP, {cores} threads): 17 buildings x {E} envs x {n} steps in {dt:.1f} s'}
+    ref = ROOT / 'profiles' / 'reference_cpu_timing.json'
+    if ref.exists():
+        # the reference's own CityLearnEnv.step (citylearn.py:978-1056), timed where /root/reference exists
+        out['reference'] = json.loads(ref.read_text())
+    return out
+
+
+class Runner:
+    """The step loop of one engine as pre-captured hipGraphs: chunk (i0, n) = steps i0 .. i0+n-1 of the action ring / episode."""
+
+    def __init__(self, eng, acts, stream, use_graph: bool):
+        self.eng, self.acts, self.stream, self.use_graph = eng, acts, stream, use_graph
+        self.T = eng.n_steps - 1                 # an episode of T+1 rows has T transitions
+        self.graphs = {}
+
+    def run(self, i0: int, n: int):
+        for i in range(i0, i0 + n):
+            self.eng.step(self.acts[i % len(self.acts)], i % self.T)
+
+    def chunks(self, i0: int, n: int):
+        i = i0
+        while i < i0 + n:
+            c = min(GRAPH_CHUNK, i0 + n - i)
+            yield i, c
+            i += c
+
+    def prepare(self, i0: int, n: int):
+        """Capture every graph steps [i0, i0+n) need and replay each once, untimed: the first launch of a graph pays its
+        upload, which must not land in the timed region."""
+        if not self.use_graph:
+            return
+        for i, c in self.chunks(i0, n):
+            key = (i % (len(self.acts) * self.T), c)
+            if key not in self.graphs:
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=self.stream):
+                    self.run(i, c)
+                gr.replay()
+                self.graphs[key] = gr
+        self.stream.synchronize()
+
+    def advance(self, i0: int, n: int):
+        for i, c in self.chunks(i0, n):
+            if self.use_graph:
+                self.graphs[(i % (len(self.acts) * self.T), c)].replay()
+            else:
+                self.run(i, c)
+
+
+def timed_reps(runner: Runner, warmup: int, steps: int, reps: int, dist, device):
+    """`reps` x (exactly `steps` steps between barrier + synchronize): per-repetition (wall seconds, HIP-event seconds)."""
+    stream = runner.stream
+    out = []
+    with torch.cuda.stream(stream):
+        runner.run(0, min(max(warmup, 1), 50))       # first touch / module load outside any capture
+        stream.synchronize()
+        runner.prepare(0, warmup)
+        runner.prepare(warmup, steps)
+        runner.eng.reset()
+        runner.advance(0, warmup)
+        stream.synchronize()
+        for _ in range(reps):
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record(stream)
+            runner.advance(warmup, steps)
+            ev1.record(stream)
+            stream.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            wall = time.perf_counter() - t0
+            out.append((wall, ev0.elapsed_time(ev1) / 1e3))
+    return out
 
 
 def main():
@@ -62,9 +150,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5000)
     ap.add_argument('--warmup', type=int, default=300)
+    ap.add_argument('--reps', type=int, default=5, help='timed repetitions of the K steps; the median is reported')
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-graph', action='store_true', help='launch every step from Python instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-streaming', action='store_true', help='skip the 17 x 1 048 576 HBM-streaming roofline entry')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -93,89 +183,36 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
 
-    from golden_util import golden
+    from citylearn_amd import load_district
+    from citylearn_amd.data import sample_schema
     from citylearn_amd.engine import StepEngine
-
-    g = golden('g2022_all')                      # 17-building 2022_phase_all tables (first 720 hours)
-    spec = g.spec()
-    tables = spec.episode_tables(0)
-    E = args.envs_per_gpu
-    eng = StepEngine(tables, E, device=device)
-    assert eng.lean
-    if os.environ.get('CL_TUNE_ENVMAJOR'):        # tuning hooks: kernel variants
-        eng.lib.cl_debug_set_envmajor(int(os.environ['CL_TUNE_ENVMAJOR']))
-    if os.environ.get('CL_TUNE_VEC'):
-        eng.lib.cl_debug_set_vec(int(os.environ['CL_TUNE_VEC']))
-    if os.environ.get('CL_TUNE_LEAN'):
-        import ctypes
-        eng.lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
-        eng.lib.cl_debug_set_lean(int(os.environ['CL_TUNE_LEAN']), int(os.environ.get('CL_TUNE_NW', '0')))
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    acts = [torch.rand((eng.n_act_cols, E), device=device, generator=gen) * 2 - 1 for _ in range(8)]
-    T = eng.n_steps - 1                          # an episode of T+1 rows has T transitions
-
-    def run(i0: int, n: int):
-        for i in range(i0, i0 + n):
-            eng.step(acts[i % 8], i % T)
-
-    use_graph = not args.no_graph
-    graphs = {}
-    stream = torch.cuda.Stream(device=device)
-    with torch.cuda.stream(stream):
-        run(0, min(args.warmup, 50))             # first-touch / module load outside any capture
-        stream.synchronize()
-        if use_graph:
-            # chunks of GRAPH_CHUNK consecutive steps, keyed by their offset in the period lcm(8, T)
-            def graph_for(i0: int, n: int):
-                key = (i0 % (8 * T), n)
-                if key not in graphs:
-                    gr = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gr, stream=stream):
-                        run(i0, n)
-                    graphs[key] = gr
-                return graphs[key]
-
-        def advance(i0: int, n: int):
-            i = i0
-            while i < i0 + n:
-                c = min(GRAPH_CHUNK, i0 + n - i)
-                if use_graph:
-                    graph_for(i, c).replay()
-                else:
-                    run(i, c)
-                i += c
-
-        if use_graph:                            # build every graph the timed region will need, untimed
-            i = 0
-            while i < args.warmup + args.steps:
-                c = min(GRAPH_CHUNK, (args.warmup if i < args.warmup else args.warmup + args.steps) - i)
-                graph_for(i, c)
-                i += c
-            eng.reset()
-        advance(0, args.warmup)
-        stream.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        advance(args.warmup, args.steps)
-        ev1.record(stream)
-        stream.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        wall = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-
     from citylearn_amd.parallel import reduce_max_seconds
-    wall_max = reduce_max_seconds(wall, dist, device)          # MAX over ranks
-    ev_max = reduce_max_seconds(ev_ms / 1e3, dist, device)
+
+    spec = load_district(sample_schema('citylearn_challenge_2022_phase_all_720h'))   # 17 buildings, first 720 hours
+    tables = spec.episode_tables(0)
+    tuning = {k[len('CL_TUNE_'):].lower(): int(v) for k, v in os.environ.items() if k.startswith('CL_TUNE_')}   # e.g. CL_TUNE_ENVMAJOR=2
+    use_graph = not args.no_graph
+
+    def measure(E: int, warmup: int, steps: int, reps: int):
+        eng = StepEngine(tables, E, device=device, tuning=tuning)
+        assert eng.lean
+        gen = torch.Generator(device=device).manual_seed(1234 + rank)
+        acts = [torch.rand((eng.n_act_cols, E), device=device, generator=gen) * 2 - 1 for _ in range(8)]
+        runner = Runner(eng, acts, torch.cuda.Stream(device=device), use_graph)
+        rep = timed_reps(runner, warmup, steps, reps, dist, device)
+        # MAX over ranks per repetition, then the median repetition
+        walls = [reduce_max_seconds(w, dist, device) for w, _ in rep]
+        evs = [reduce_max_seconds(e, dist, device) for _, e in rep]
+        return eng, walls, evs
+
+    E = args.envs_per_gpu
+    eng, walls, evs = measure(E, args.warmup, args.steps, args.reps)
+    wall_med, ev_med = statistics.median(walls), statistics.median(evs)
     units_per_step = eng.n_bldg * E
     bytes_per_unit = eng.algorithmic_bytes_per_unit()
-    launch_s = ev_max / args.steps
+    launch_s = ev_med / args.steps
     achieved = units_per_step * bytes_per_unit / launch_s / 1e9
+    kernel_name = (lambda e: 'cl_step_envmajor_kernel<20>' if e >= 131072 else 'cl_step_lean_kernel<4, false>')
 
     traffic = None
     pmc = ROOT / 'profiles' / 'r01_bench_pmc_summary.json'
@@ -184,25 +221,51 @@ def main():
         # runs, KiB units; FETCH_SIZE doubled per the gfx950 wide-load correction of MI355X_MICROARCH.md)
         c = json.loads(pmc.read_text())
         traffic = (2.0 * c['FETCH_SIZE']['mean'] + c['WRITE_SIZE']['mean']) * 1024.0
+
+    streaming = None
+    if not args.no_streaming and E == ENVS_PER_GPU:
+        del eng
+        torch.cuda.empty_cache()
+        s_steps = 20
+        eng_s, _, evs_s = measure(STREAMING_ENVS, 5, s_steps, 5)
+        launch = statistics.median(evs_s) / s_steps
+        a = eng_s.n_bldg * STREAMING_ENVS * eng_s.algorithmic_bytes_per_unit() / launch / 1e9
+        streaming = {'workload': f'same tables x {STREAMING_ENVS} envs per GPU ({eng_s.n_bldg * STREAMING_ENVS * eng_s.algorithmic_bytes_per_unit() / 1e6:.0f} MB '
+                                 f'of algorithmic traffic per launch, beyond the 256 MB Infinity Cache)',
+                     'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
+                     'frac_vs_measured_copy': a / HBM_MEASURED_COPY_GBS, 'kernel': kernel_name(STREAMING_ENVS), 'launch_us': launch * 1e6,
+                     'units_per_launch': eng_s.n_bldg * STREAMING_ENVS, 'steps': s_steps, 'reps': 5,
+                     'value': world * eng_s.n_bldg * STREAMING_ENVS / launch}
+        n_bldg = eng_s.n_bldg
+        del eng_s
+        torch.cuda.empty_cache()
+    else:
+        n_bldg = eng.n_bldg
+
     if rank == 0:
         out = {
             'metric': 'building-timesteps/sec at 17 bldgs x 65536 envs; HBM GB/s vs roofline',
-            'value': world * units_per_step * args.steps / wall_max,
+            'value': world * units_per_step * args.steps / wall_med,
             'unit': 'building-timesteps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': wall_max / args.steps * 1e3,
+            'ms_per_step': wall_med / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'citylearn_challenge_2022_phase_all tables (17 buildings, first 720 h) x {E} envs per GPU, '
                                    'cl_step_f32 mode A (one env step per launch, state in HBM, fresh uniform random actions '
                                    'from an 8-tensor ring), env batch sharded over GPUs, no collective',
-                       'envs_per_gpu': E, 'buildings': eng.n_bldg, 'launch': 'hipGraph replay' if use_graph else 'eager',
-                       'reward': 'RewardFunction'},
+                       'envs_per_gpu': E, 'buildings': n_bldg, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                       'reward': 'RewardFunction', 'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)'},
+            'rep_ms_per_step': [w / args.steps * 1e3 for w in walls],
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'cl_step_envmajor_kernel<20>' if E >= 131072 else 'cl_step_lean_kernel<4, false>',
-                         'launch_us': launch_s * 1e6,
-                         'algorithmic_bytes_per_unit': bytes_per_unit, 'units_per_launch': units_per_step},
+                         'frac_vs_measured_copy': achieved / HBM_MEASURED_COPY_GBS,
+                         'kernel': kernel_name(E), 'launch_us': launch_s * 1e6,
+                         'rep_launch_us': [e / args.steps * 1e6 for e in evs],
+                         'algorithmic_bytes_per_unit': bytes_per_unit, 'units_per_launch': units_per_step,
+                         'note': 'working set (state 13 MB + outputs 9 MB + action ring 36 MB) fits the 256 MB Infinity Cache: see hbm_streaming '
+                                 'for the HBM-resident figure',
+                         'hbm_streaming': streaming},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(spec, tables)

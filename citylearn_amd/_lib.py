@@ -15,6 +15,7 @@ from . import abi
 
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / 'libcitylearn_amd.so'
+TUNE_LIB_PATH = PKG / 'libcitylearn_amd_tune.so'
 CSRC = PKG / 'csrc'
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs (gfx950's register file is unified), which removes the
 # v_accvgpr_read copies in front of the LSTM activations (64 per window step)
@@ -31,11 +32,18 @@ class EngineError(RuntimeError):
         self.code = code
 
 
+class Tuning(ctypes.Structure):
+    """``cl_tuning`` (include/citylearn_amd.h): per-call launch-geometry overrides; all zero = library defaults."""
+    _fields_ = [('vec', ctypes.c_int32), ('nw', ctypes.c_int32), ('no_chunks', ctypes.c_int32), ('lean_variant', ctypes.c_int32),
+                ('envmajor', ctypes.c_int32), ('flex_vec', ctypes.c_int32), ('obs_variant', ctypes.c_int32),
+                ('obs_rows', ctypes.c_int32), ('lstm_variant', ctypes.c_int32), ('reserved', ctypes.c_int32 * 7)]
+
+
 class Dims(ctypes.Structure):
     """``cl_dims`` (include/citylearn_amd.h)."""
     _fields_ = [('n_env', ctypes.c_int32), ('n_bldg', ctypes.c_int32), ('n_steps', ctypes.c_int32),
                 ('n_act_cols', ctypes.c_int32), ('flags', ctypes.c_uint32), ('n_ts_rows', ctypes.c_int32),
-                ('env_row0', ctypes.c_void_p)]
+                ('env_row0', ctypes.c_void_p), ('tuning', ctypes.POINTER(Tuning))]
 
 
 class Flex(ctypes.Structure):
@@ -49,18 +57,39 @@ class Flex(ctypes.Structure):
                 ('seed', ctypes.c_uint64), ('weights', ctypes.c_float * 8)]
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP sources for gfx950 into the in-tree shared library (cross-compiles without a GPU)."""
-    sources = [CSRC / 'cl_kernels.hip']
-    deps = sources + sorted(CSRC.glob('*.h')) + [abi.HEADER]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return LIB_PATH
+def _compile(sources, out: Path, deps, force: bool, verbose: bool) -> Path:
+    if not force and out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return out
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, *HIPCC_FLAGS, *map(str, sources), '-o', str(LIB_PATH)]
+    cmd = [hipcc, *HIPCC_FLAGS, *map(str, sources), '-o', str(out)]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP sources for gfx950 into the in-tree shared library (cross-compiles without a GPU)."""
+    sources = [CSRC / 'cl_kernels.hip']
+    return _compile(sources, LIB_PATH, sources + sorted(CSRC.glob('*.h')) + [abi.HEADER], force, verbose)
+
+
+def build_tune(force: bool = False, verbose: bool = False) -> Path:
+    """The microbenchmark / layout-probe kernels (csrc/cl_tune.hip) live in their own library, which the package never loads."""
+    sources = [CSRC / 'cl_tune.hip']
+    return _compile(sources, TUNE_LIB_PATH, sources, force, verbose)
+
+
+def load_tune() -> ctypes.CDLL:
+    """``libcitylearn_amd_tune.so`` for scripts/ and the MFMA layout test (not used by the package)."""
+    import torch  # noqa: F401
+    if not TUNE_LIB_PATH.exists():
+        raise EngineUnavailable(f'{TUNE_LIB_PATH} not found (run __graft_entry__.build())')
+    lib = ctypes.CDLL(str(TUNE_LIB_PATH))
+    lib.cl_tune_copy_floor.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.cl_tune_mfma_bench.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.cl_tune_mfma_bf16_probe.argtypes = [ctypes.c_void_p] * 4
+    return lib
 
 
 _lib = None
@@ -96,9 +125,6 @@ def load() -> ctypes.CDLL:
                                         f32p, f32p, f32p, ctypes.POINTER(Flex), i32, i32, vp]
     lib.cl_philox_uniform.restype = ctypes.c_float
     lib.cl_philox_uniform.argtypes = [u64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
-    if hasattr(lib, 'cl_debug_set_vec'):
-        lib.cl_debug_set_vec.argtypes = [ctypes.c_int]
-        lib.cl_debug_set_vec.restype = None
     got = lib.cl_abi_version()
     if got != abi.CL_ABI_VERSION:
         raise EngineUnavailable(f'ABI mismatch: library {got}, header {abi.CL_ABI_VERSION}; rebuild the extension')

@@ -693,84 +693,13 @@ int pick_vec(int n_env, int n_bldg, bool unit_stride) {
     return 1;
 }
 
-int g_force_vec = 0;   // test / tuning hooks (cl_debug_set_vec / cl_debug_set_lean)
-int g_force_nw = 0;
-int g_no_chunks = 0;
-int g_lean_variant = 0;   // 1: generic kernel for lean districts too; 2: latency-ordered kernel at any grid size (tests, tuning)
-int g_obs_variant = 0;   // 1 / 2 / 3: force the row-wise / LDS-tile / wave-independent observation kernel (tests, tuning)
-int g_lstm_dbg = 0;
-int g_envmajor = 0;      // env-major lean kernel: 0 = by batch size, 1 = always, 2 = never (tests, tuning)
-int g_flex_vec = 0;      // 1 / 2 / 4: envs per lane of cl_flex_kernel (tuning)
-int g_obs_rows = 0;      // tile kernel: envs per block (tuning)
+// Launch-geometry overrides travel with every call (cl_dims.tuning, include/citylearn_amd.h): the library holds no
+// mutable state besides the thread-local error string.
+const cl_tuning k_default_tuning = {};
+const cl_tuning& tuning_of(const cl_dims* d) { return d->tuning ? *d->tuning : k_default_tuning; }
 
 }  // namespace
 
-
-// ---- layout probe for v_mfma_f32_32x32x16_bf16 (tests/test_gpu_lstm.py::test_bf16_mfma_operand_layout) ----
-typedef __bf16 cl_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float cl_f32x16 __attribute__((ext_vector_type(16)));
-__global__ void cl_mfma_bf16_probe_kernel(const uint16_t* A, const uint16_t* B, float* D) {
-    const int l = threadIdx.x, i = l & 31, kh = l >> 5;
-    union { cl_bf16x8 v; uint16_t u[8]; } a, b;
-    for (int j = 0; j < 8; ++j) { a.u[j] = A[i * 16 + 8 * kh + j]; b.u[j] = B[(8 * kh + j) * 32 + i]; }
-    cl_f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
-    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + i] = c[r];
-}
-
-// ---- issue-rate microbenchmark (scripts/mfma_bench.py): how MFMA chains and transcendental VALU work share a SIMD ----
-template <int MODE>
-__global__ void __launch_bounds__(256) cl_mfma_bench_kernel(float* out, int iters) {
-    const int l = threadIdx.x & 63;
-    union { cl_bf16x8 v; uint16_t u[8]; } a, b;
-    for (int j = 0; j < 8; ++j) { a.u[j] = 0x3c00 + l + j; b.u[j] = 0x3b80 + l * 3 + j; }
-    const float af = 1.0f + l * 1e-3f, bfv = 0.5f + l * 1e-3f;
-    cl_f32x16 c0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
-    float x0 = l * 1e-3f, x1 = x0 + 0.1f, x2 = x0 + 0.2f, x3 = x0 + 0.3f;
-#define BF(C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, C, 0, 0, 0);
-#define F32(C) C = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bfv, C, 0, 0, 0);
-#define VX x0 = __expf(-x0); x1 = __expf(-x1); x2 = __expf(-x2); x3 = __expf(-x3);
-    for (int i = 0; i < iters; ++i) {
-        if constexpr (MODE == 0) { BF(c0) BF(c0) BF(c0) BF(c0) BF(c0) BF(c0) BF(c0) BF(c0) }
-        if constexpr (MODE == 1) { BF(c0) BF(c1) BF(c0) BF(c1) BF(c0) BF(c1) BF(c0) BF(c1) }
-        if constexpr (MODE == 2) { BF(c0) BF(c1) BF(c2) BF(c3) BF(c0) BF(c1) BF(c2) BF(c3) }
-        if constexpr (MODE == 3) { BF(c0) VX BF(c1) VX BF(c0) VX BF(c1) VX BF(c0) VX BF(c1) VX BF(c0) VX BF(c1) VX }
-        if constexpr (MODE == 4) { VX VX VX VX VX VX VX VX }
-        if constexpr (MODE == 5) { F32(c0) F32(c1) F32(c0) F32(c1) F32(c0) F32(c1) F32(c0) F32(c1) }
-        if constexpr (MODE == 6) { F32(c0) VX F32(c1) VX F32(c0) VX F32(c1) VX F32(c0) VX F32(c1) VX F32(c0) VX F32(c1) VX }
-        if constexpr (MODE == 7) { BF(c0) BF(c1) BF(c0) BF(c1) BF(c0) BF(c1) BF(c0) BF(c1) VX VX VX VX VX VX VX VX }   // blocks, not interleaved
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#undef BF
-#undef F32
-#undef VX
-    float r = x0 + x1 + x2 + x3;
-    for (int k = 0; k < 16; ++k) r += c0[k] + c1[k] + c2[k] + c3[k];
-    if (r == 12345.678f) out[threadIdx.x] = r;
-}
-
-// ---- streaming floor of the headline step (scripts/copy_floor.py): same launch shape and byte counts, no arithmetic ----
-// 17 buildings x 65 536 envs: per (building, 256-env tile) read 3 state planes + 1 action plane, write 3 state planes + net +
-// reward; 16 waves per workgroup, 16-byte accesses -- what cl_step_kernel<4, lean> moves, with the energy model replaced by adds.
-__global__ void __launch_bounds__(1024) cl_copy_floor_kernel(const float* __restrict__ st_in, const float* __restrict__ act,
-                                                            float* __restrict__ st_out, float* __restrict__ out2, int n_bldg, int n_env) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int env0 = blockIdx.x * 256 + lane * 4;
-    const long long plane = (long long)n_bldg * n_env;
-    for (int b = w; b < n_bldg; b += nw) {
-        const long long off = (long long)b * n_env + env0;
-        const float4 s0 = *reinterpret_cast<const float4*>(st_in + 0 * plane + off);
-        const float4 s1 = *reinterpret_cast<const float4*>(st_in + 1 * plane + off);
-        const float4 s2 = *reinterpret_cast<const float4*>(st_in + 2 * plane + off);
-        const float4 a = *reinterpret_cast<const float4*>(act + off);
-        const float4 x = make_float4(s0.x + a.x, s0.y + a.y, s0.z + a.z, s0.w + a.w);
-        *reinterpret_cast<float4*>(st_out + 0 * plane + off) = x;
-        *reinterpret_cast<float4*>(st_out + 1 * plane + off) = s1;
-        *reinterpret_cast<float4*>(st_out + 2 * plane + off) = s2;
-        *reinterpret_cast<float4*>(out2 + 0 * plane + off) = make_float4(s1.x + a.x, s1.y + a.y, s1.z + a.z, s1.w + a.w);
-        *reinterpret_cast<float4*>(out2 + 1 * plane + off) = make_float4(s2.x + a.x, s2.y + a.y, s2.z + a.z, s2.w + a.w);
-    }
-}
 
 namespace {
 // The rollout policy as planes of actions (same stream as cl_rollout_kernel: a = low + u (high - low),
@@ -788,6 +717,14 @@ __global__ void cl_policy_kernel(float* __restrict__ actions, const float* __res
     for (int w = 0; w < 4; ++w) actions[((long long)w * n_cols + col) * n_env + env] = fmaf(cl::u01(blk.w[w]), span, lo);
 }
 
+__global__ void cl_kpi_comfort_reset_kernel(float* k, long long plane) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    for (int p = 0; p < CL_NKC; ++p) k[p * plane + i] = 0.0f;
+    k[CLKC_COLD_MIN * plane + i] = INFINITY; k[CLKC_HOT_MIN * plane + i] = INFINITY;
+    k[CLKC_COLD_MAX * plane + i] = -INFINITY; k[CLKC_HOT_MAX * plane + i] = -INFINITY;
+}
+
 __global__ void cl_return_kernel(float* __restrict__ ret_env, const float* __restrict__ reward, int n_env) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env < n_env) ret_env[env] += reward[env];
@@ -799,34 +736,6 @@ extern "C" {
 int cl_abi_version(void) { return CL_ABI_VERSION; }
 
 const char* cl_last_error(void) { return g_err; }
-
-void cl_debug_set_vec(int vec) { g_force_vec = vec; }
-void cl_debug_set_lean(int no_chunks, int nw) { g_no_chunks = no_chunks & 1; g_lean_variant = (no_chunks >> 2) & 3; g_force_nw = nw; }
-void cl_debug_set_lstm(int dbg) { g_lstm_dbg = dbg; }
-void cl_debug_set_flex(int vec) { g_flex_vec = vec; }
-void cl_debug_set_envmajor(int on) { g_envmajor = on; }
-int cl_debug_copy_floor(const float* st_in, const float* act, float* st_out, float* out2, int n_bldg, int n_env, void* stream) {
-    hipLaunchKernelGGL(cl_copy_floor_kernel, dim3(n_env / 256), dim3(1024), 0, (hipStream_t)stream, st_in, act, st_out, out2, n_bldg, n_env);
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "copy floor launch");
-    return CL_OK;
-}
-int cl_debug_mfma_bench(int mode, int waves_per_simd, int iters, float* out, void* stream) {
-    const dim3 grid(256 * waves_per_simd), block(256);
-    switch (mode) {
-#define CL_CASE(M) case M: hipLaunchKernelGGL(cl_mfma_bench_kernel<M>, grid, block, 0, (hipStream_t)stream, out, iters); break;
-    CL_CASE(0) CL_CASE(1) CL_CASE(2) CL_CASE(3) CL_CASE(4) CL_CASE(5) CL_CASE(6) CL_CASE(7)
-#undef CL_CASE
-    default: return fail(CL_EINVAL, "mode");
-    }
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "bench launch");
-    return CL_OK;
-}
-int cl_debug_mfma_bf16_probe(const uint16_t* A, const uint16_t* B, float* D, void* stream) {
-    hipLaunchKernelGGL(cl_mfma_bf16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, D);
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "probe launch");
-    return CL_OK;
-}
-void cl_debug_set_observe(int variant, int rows) { g_obs_variant = variant; g_obs_rows = rows; }
 
 int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, float* kpi_bldg, float* kpi_env,
                  void* stream) {
@@ -886,6 +795,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
                      int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg,
                      float* kpi_env, const cl_flex* flex, int32_t t, void* stream) {
     if (int rc = check_dims(dims)) return rc;
+    const cl_tuning& tun = tuning_of(dims);
     if (int rc = check_ptr(params, "params")) return rc;
     if (int rc = check_ptr(ts, "ts")) return rc;
     if (int rc = check_ptr(state, "state")) return rc;
@@ -922,7 +832,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         const unsigned gy = (unsigned)((units + 3) / 4);
         // four envs per lane once there are enough envs to fill the chip that way (and plane rows stay 16-byte aligned)
         int fvec = dims->n_env >= 16384 ? 4 : 1;
-        if (g_flex_vec) fvec = g_flex_vec;
+        if (tun.flex_vec) fvec = tun.flex_vec;
         const dim3 fgrid((unsigned)((dims->n_env + 64 * fvec - 1) / (64 * fvec)), gy);
         switch (fvec) {
         case 4: hipLaunchKernelGGL(cl_flex_kernel<4>, fgrid, dim3(256), 0, (hipStream_t)stream, fa); break;
@@ -933,24 +843,24 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         a.ev_penalty_coef = flex->cons_params ? flex->weights[CLEW_PENALTY_COEFFICIENT] : 0.0f;
     }
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
-    a.nw = g_force_nw ? g_force_nw : pick_nw(dims->n_bldg, 1);
+    a.nw = tun.nw ? tun.nw : pick_nw(dims->n_bldg, 1);
     // general kernel: two buildings per wave measured fastest for the 6..16-building thermal schemas (fewer, longer waves)
-    if (!g_force_nw && full && dims->n_bldg >= 6 && dims->n_bldg <= 16) a.nw = (dims->n_bldg + 1) / 2;
-    const bool will_chunk = dims->n_bldg > 32 && !g_no_chunks;
+    if (!tun.nw && full && dims->n_bldg >= 6 && dims->n_bldg <= 16) a.nw = (dims->n_bldg + 1) / 2;
+    const bool will_chunk = dims->n_bldg > 32 && !tun.no_chunks;
     int vec = full ? 1 : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1);
     if (will_chunk && act_stride_env == 1) {               // few envs, many buildings: width from the unit count
         const long long units = (long long)dims->n_env * dims->n_bldg;
         vec = full ? (units >= (1ll << 19) && dims->n_env >= 256 ? 2 : 1) : (units >= (1ll << 19) && dims->n_env >= 512 ? 4 : 1);
     }
-    if (g_force_vec) vec = g_force_vec;
-    if (flex && vec > 2 && !(!full && dims->n_bldg <= 2 * a.nw && !will_chunk && (dims->n_env + 64 * vec - 1) / (64 * vec) <= 256 && !(g_lean_variant & 1)))
+    if (tun.vec) vec = tun.vec;
+    if (flex && vec > 2 && !(!full && dims->n_bldg <= 2 * a.nw && !will_chunk && (dims->n_env + 64 * vec - 1) / (64 * vec) <= 256 && !(tun.lean_variant & 1)))
         vec = 2;                             // general-kernel FLEX instantiations exist for 1 and 2 envs per lane
     const int tile = 64 * vec;
     const unsigned grid_x = (unsigned)((dims->n_env + tile - 1) / tile);
     // Large districts (e.g. 1024 buildings x 1024 envs per GPU): a 1-D grid over env tiles would leave most CUs idle, so
     // the buildings are cut into chunks along gridDim.y and the district sums are finished by a second tiny kernel.
     a.b_chunk = dims->n_bldg; a.n_chunks = 1;
-    if (dims->n_bldg > 32 && grid_x < 2048 && !g_no_chunks) {
+    if (dims->n_bldg > 32 && grid_x < 2048 && !tun.no_chunks) {
         long long r = ((long long)dims->n_bldg * grid_x) / (16ll * 2048);
         if (r < 1) r = 1;
         a.b_chunk = (int)(16 * r);
@@ -965,7 +875,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
     const bool det = dims->flags & CLD_WRITE_DETAIL;
-    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (g_lean_variant & 2)) && !(g_lean_variant & 1);
+    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (tun.lean_variant & 2)) && !(tun.lean_variant & 1);
     if (flex && !full && lean_shape) {
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_lean_kernel<1, true>), grid, block, lds, s, a); break;
@@ -1001,7 +911,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         case 4: hipLaunchKernelGGL((cl_step_kernel<4, true, false>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
-    } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && (g_envmajor == 1 || (g_envmajor == 0 && dims->n_env >= 131072))) {
+    } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 131072))) {
         // two or more waves per SIMD: the env-major kernel (bench.py --envs-per-gpu: 17 x 131 072 17.0 vs 18.5 us,
         // 17 x 262 144 28.2 vs 32.5 us, 17 x 1 048 576 136 vs 157 us; at 17 x 65 536 -- one wave per SIMD, nothing to hide the
         // per-building dependency chain behind -- 13.1 vs 8.0 us)
@@ -1044,7 +954,7 @@ int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float
                         const float* act_high, uint64_t seed, float* policy_actions, float* out_bldg, float* out_env,
                         float* ret_env, const cl_flex* flex, int32_t t0, int32_t k_steps, void* stream) {
     if (int rc = check_dims(dims)) return rc;
-    if (int rc = check_ptr(flex, "flex")) return rc;
+    if (!flex) return fail(CL_ENULL, "flex is NULL");                 // a host struct: no device-alignment demand
     if (int rc = check_ptr(actions, "actions", false)) return rc;
     if (int rc = check_ptr(ret_env, "ret_env", false)) return rc;
     if (!actions && dims->n_act_cols > 0) {
@@ -1079,6 +989,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
                    const float* act_high, uint64_t seed, float* out_bldg, float* out_env, float* ret_env,
                    float* kpi_bldg, float* kpi_env, int32_t t0, int32_t k_steps, void* stream) {
     if (int rc = check_dims(dims)) return rc;
+    const cl_tuning& tun = tuning_of(dims);
     if (int rc = check_ptr(params, "params")) return rc;
     if (int rc = check_ptr(ts, "ts")) return rc;
     if (int rc = check_ptr(state, "state")) return rc;
@@ -1089,6 +1000,8 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     if (!actions && dims->n_act_cols > 0) {
         if (!act_low || !act_high) return fail(CL_ENULL, "act_low / act_high are required for the on-device policy");
     }
+    if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_EV)
+        return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_rollout_flex_f32)");
     if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "CLD_KPI is not implemented in this build");
     (void)kpi_bldg; (void)kpi_env;
     if (k_steps < 0 || t0 < 0 || t0 + k_steps > dims->n_steps)
@@ -1109,9 +1022,9 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
     const int mb = full ? 1 : (dims->n_bldg > 16 ? 2 : 1);
     if (full && dims->n_bldg > 16) return fail(CL_EINVAL, "cl_rollout_f32 (thermal districts) supports n_bldg <= 16 (got %d)", dims->n_bldg);
-    a.nw = g_force_nw ? g_force_nw : (dims->n_bldg + mb - 1) / mb;
+    a.nw = tun.nw ? tun.nw : (dims->n_bldg + mb - 1) / mb;
     if (a.nw * mb < dims->n_bldg || a.nw > 16) return fail(CL_EINVAL, "bad nw %d", a.nw);
-    const int vec = g_force_vec ? g_force_vec : ((!full && (actions == nullptr || act_stride_env == 1) && dims->n_env >= 131072) ? 2 : 1);
+    const int vec = tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && dims->n_env >= 131072) ? 2 : 1);
     const int tile = 64 * vec;
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
@@ -1128,14 +1041,6 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_kernel launch");
     return CL_OK;
-}
-
-__global__ void cl_kpi_comfort_reset_kernel(float* k, long long plane) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= plane) return;
-    for (int p = 0; p < CL_NKC; ++p) k[p * plane + i] = 0.0f;
-    k[CLKC_COLD_MIN * plane + i] = INFINITY; k[CLKC_HOT_MIN * plane + i] = INFINITY;
-    k[CLKC_COLD_MAX * plane + i] = -INFINITY; k[CLKC_HOT_MAX * plane + i] = -INFINITY;
 }
 
 int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, float* kpi_comfort, void* stream) {
@@ -1158,6 +1063,7 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
                      const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,
                      float* kpi_comfort, int32_t t, void* stream) {
     if (int rc = check_dims(dims)) return rc;
+    const cl_tuning& tun = tuning_of(dims);
     if (int rc = check_ptr(lstm_w, "lstm_w")) return rc;
     if (int rc = check_ptr(dyn_pre, "dyn_pre")) return rc;
     if (int rc = check_ptr(cool_dem, "cool_dem")) return rc;
@@ -1173,7 +1079,7 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
     const dim3 grid((dims->n_env + 127) / 128, dims->n_bldg);          // 4 waves x 32 envs per workgroup
     a.lstm_wb = lstm_wb;
     if (int rc = check_ptr(lstm_wb, "lstm_wb", false)) return rc;
-    switch (g_lstm_dbg) {            // timing experiments (scripts/lstm_check.py); 0 in production
+    switch (tun.lstm_variant) {            // timing experiments (scripts/lstm_check.py); 0 in production
     case 1: hipLaunchKernelGGL((cl_lstm_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
     case 2: hipLaunchKernelGGL((cl_lstm_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
     case 3: hipLaunchKernelGGL((cl_lstm_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;   // f32 MFMA path
@@ -1226,6 +1132,7 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
                    const float* extra, int32_t n_extra_rows, float* obs, int32_t n_cols,
                    int32_t obs_pitch, int32_t n_rows, int32_t row, uint32_t flags, void* stream) {
     if (int rc = check_dims(dims)) return rc;
+    const cl_tuning& tun = tuning_of(dims);
     if (int rc = check_ptr(obs_table, "obs_table")) return rc;
     if (int rc = check_ptr(obs, "obs")) return rc;
     if (n_cols <= 0 || n_rows <= 0) return fail(CL_EINVAL, "bad observation table shape [%d][%d]", n_rows, n_cols);
@@ -1268,8 +1175,8 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
         t.n_deps = all_exo ? 0 : n_deps;
         for (int d = 0; d < t.n_deps; ++d) t.deps[d] = deps[d];
     }
-    const bool narrow = g_obs_variant == 2 || (g_obs_variant == 0 && padded <= 128);
-    bool wide = n_seg == 1 && listed && vec4 && (g_obs_variant == 3 || (g_obs_variant == 0 && !narrow && dims->n_env > 98304));
+    const bool narrow = tun.obs_variant == 2 || (tun.obs_variant == 0 && padded <= 128);
+    bool wide = n_seg == 1 && listed && vec4 && (tun.obs_variant == 3 || (tun.obs_variant == 0 && !narrow && dims->n_env > 98304));
     if (wide) {
         int owned[256] = {0};
         for (int d = 0; d < t.n_deps && wide; ++d) wide = ++owned[(deps[d].col >> 2) & 63] <= OBS_WSLOTS;
@@ -1281,7 +1188,7 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
         if (padded <= 512) hipLaunchKernelGGL(cl_observe_wave_kernel<2>, wgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
         else hipLaunchKernelGGL(cl_observe_wave_kernel<4>, wgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
     } else if (n_seg == 1 && padded == obs_pitch && listed && narrow && dims->env_row0 == nullptr) {   // one template row per launch
-        int r = g_obs_rows ? g_obs_rows : 16;          // 16 envs = one 64-byte line of every dependent plane
+        int r = tun.obs_rows ? tun.obs_rows : 16;          // 16 envs = one 64-byte line of every dependent plane
         while (r * obs_pitch > OBS_BUF) r >>= 1;       // pitch <= OBS_SEG + 3 -> r >= 4
         a.sub_rows = r;
         t.o = a;

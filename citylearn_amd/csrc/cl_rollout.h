@@ -27,11 +27,12 @@ struct RolloutArgs {
 
 // Electrical-storage action with the Philox block cached across four steps (wave-uniform refresh).
 template <int VEC>
-CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k);
+CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k, bool live);
 
+// `live`: lanes past the end of the batch (ragged last tile) must not touch the open-loop action tensor.
 template <int VEC>
-CL_DEV void rollout_action(float (&dst)[VEC], const RolloutArgs& r, int col, int env0, int t, int k) {
-    if (col < 0) {
+CL_DEV void rollout_action(float (&dst)[VEC], const RolloutArgs& r, int col, int env0, int t, int k, bool live) {
+    if (col < 0 || (r.s.actions && !live)) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) dst[i] = 0.0f;
         return;
@@ -52,8 +53,8 @@ CL_DEV void rollout_action(float (&dst)[VEC], const RolloutArgs& r, int col, int
 }
 
 template <int VEC>
-CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k) {
-    if (col < 0 || r.s.actions) { rollout_action<VEC>(dst, r, col, env0, t, k); return; }
+CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k, bool live) {
+    if (col < 0 || r.s.actions) { rollout_action<VEC>(dst, r, col, env0, t, k, live); return; }
     if (k == 0 || (t & 3) == 0) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) cache[i] = cl::philox_block(r.seed, (uint32_t)(env0 + i), (uint32_t)col, (uint32_t)t >> 2);
@@ -129,19 +130,19 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
             cl::Row R;
             cl::load_row<FULL>(R, a.ts + ((long long)(t + row0) * a.n_bldg + b) * CL_NF, B[m].flags);
             float a_es[VEC], a_cs[VEC], a_hs[VEC], a_ds[VEC], a_cd[VEC], a_hd[VEC];
-            rollout_action_cached<VEC>(a_es, rnd[m], r, B[m].a_es, env0, t, k);
+            rollout_action_cached<VEC>(a_es, rnd[m], r, B[m].a_es, env0, t, k, live);
             if constexpr (FULL) {
-                rollout_action<VEC>(a_cs, r, B[m].a_cs, env0, t, k);
-                rollout_action<VEC>(a_hs, r, B[m].a_hs, env0, t, k);
-                rollout_action<VEC>(a_ds, r, B[m].a_ds, env0, t, k);
+                rollout_action<VEC>(a_cs, r, B[m].a_cs, env0, t, k, live);
+                rollout_action<VEC>(a_hs, r, B[m].a_hs, env0, t, k, live);
+                rollout_action<VEC>(a_ds, r, B[m].a_ds, env0, t, k, live);
                 if (B[m].a_coh >= 0) {
                     float c[VEC];
-                    rollout_action<VEC>(c, r, B[m].a_coh, env0, t, k);
+                    rollout_action<VEC>(c, r, B[m].a_coh, env0, t, k, live);
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) { a_cd[i] = fabsf(fminf(c[i], 0.0f)); a_hd[i] = fabsf(fmaxf(c[i], 0.0f)); }
                 } else {
-                    rollout_action<VEC>(a_cd, r, B[m].a_cd, env0, t, k);
-                    rollout_action<VEC>(a_hd, r, B[m].a_hd, env0, t, k);
+                    rollout_action<VEC>(a_cd, r, B[m].a_cd, env0, t, k, live);
+                    rollout_action<VEC>(a_hd, r, B[m].a_hd, env0, t, k, live);
                 }
             }
 #pragma unroll
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
                     CL_PUT(a.out_bldg, CLO_C_COOL, last[m][i].c_cool) CL_PUT(a.out_bldg, CLO_C_HEAT, last[m][i].c_heat)
                     CL_PUT(a.out_bldg, CLO_C_DHW, last[m][i].c_dhw) CL_PUT(a.out_bldg, CLO_C_NSL, last[m][i].c_ns)
                     CL_PUT(a.out_bldg, CLO_BASE_NET, last[m][i].base_net) CL_PUT(a.out_bldg, CLO_EXPECTED, last[m][i].expected)
-                    CL_PUT(a.out_bldg, CLO_SERVED, last[m][i].served)
+                    CL_PUT(a.out_bldg, CLO_SERVED, last[m][i].served) CL_PUT(a.out_bldg, CLO_NET_WS, last[m][i].net_ws)
                     CL_PUT(a.out_bldg, CLO_HEAT_DEM, last[m][i].heat_dem) CL_PUT(a.out_bldg, CLO_DHW_DEM, last[m][i].dhw_dem)
                 }
             }

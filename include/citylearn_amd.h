@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 1
+#define CL_ABI_VERSION 2
 
 /* ---- error codes ---- */
 #define CL_OK            0
@@ -225,6 +225,22 @@ enum cl_reward_kind {
     CLR_EV = 4                /* Electric_Vehicles_Reward_Function (needs cl_flex)  (reward_function.py:389-531) */
 };
 
+/* Launch-geometry overrides for tests and tuning scripts (cl_dims.tuning).  Every field 0 = the library's own choice.
+ * They travel with the call: the library keeps no mutable state of its own (re-entrant, thread-safe for disjoint buffers).
+ * Results never depend on them beyond the documented last-bit summation-order effects of the env-major kernels. */
+typedef struct cl_tuning {
+    int32_t vec;            /* envs per lane of the step / rollout kernels: 1, 2 or 4 */
+    int32_t nw;             /* waves per workgroup (= building lanes) */
+    int32_t no_chunks;      /* 1: never cut the building axis into gridDim.y chunks */
+    int32_t lean_variant;   /* lean districts: 1 = general kernel, 2 = latency-ordered lean kernel at any grid size */
+    int32_t envmajor;       /* env-major kernels (one lane = one env x all buildings): 0 = by batch size, 1 = always, 2 = never */
+    int32_t flex_vec;       /* envs per lane of the flexible-load kernel: 1, 2 or 4 */
+    int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent kernel */
+    int32_t obs_rows;       /* LDS-tile observation kernel: envs per block */
+    int32_t lstm_variant;   /* LSTM stage timing experiments (csrc/cl_lstm.h) */
+    int32_t reserved[7];
+} cl_tuning;
+
 typedef struct cl_dims {
     int32_t n_env;        /* envs in this shard (multiple of 4) */
     int32_t n_bldg;       /* buildings per district */
@@ -237,6 +253,7 @@ typedef struct cl_dims {
                                  different blocks replay different windows of the simulation period at once (the batched
                                  analogue of EpisodeTracker's rolling / random episode splits, base.py:100-129).  The caller
                                  guarantees 0 <= env_row0[g] and env_row0[g] + n_steps <= n_ts_rows. */
+    const cl_tuning* tuning;  /* nullable HOST pointer, read during the call only */
 } cl_dims;
 
 /* ABI version of the loaded library (== CL_ABI_VERSION of the header it was built from). */

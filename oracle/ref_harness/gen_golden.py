@@ -138,12 +138,22 @@ def _action_drawer(seed: int, low, high, action_names):
     return draw
 
 
+# the 2022_phase_all sample is shipped with the package (bench.py, smoke()); every other mini dataset stays next to its fixture
+PACKAGE_DATASETS = {'g2022_all': GOLDEN.parent.parent / 'citylearn_amd' / 'data' / 'citylearn_challenge_2022_phase_all_720h'}
+
+
+def dataset_dir(name: str) -> Path:
+    return PACKAGE_DATASETS.get(name, GOLDEN / name / 'dataset')
+
+
 def run_reference(name: str):
     dataset, rows, steps, seed, gz, env_kwargs = FIXTURES[name]
     out_dir = GOLDEN / name
     if out_dir.exists():
         shutil.rmtree(out_dir)
-    make_mini_dataset(ref_env.REFERENCE_ROOT / 'data' / 'datasets' / dataset, out_dir / 'dataset', rows, gz, env_kwargs)
+    if dataset_dir(name).exists():
+        shutil.rmtree(dataset_dir(name))
+    make_mini_dataset(ref_env.REFERENCE_ROOT / 'data' / 'datasets' / dataset, dataset_dir(name), rows, gz, env_kwargs)
 
     ref_env.setup_reference()
     from citylearn.citylearn import CityLearnEnv
@@ -154,7 +164,7 @@ def run_reference(name: str):
     py_random.seed(seed)                 # EV initial SoC defaults (citylearn.py:2563)
     np.random.seed(seed)                 # unconnected-EV SoC drift (citylearn.py:1468)
 
-    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
+    env = CityLearnEnv(str(dataset_dir(name) / 'schema.json'))
     B = len(env.buildings)
     evs = list(getattr(env, 'electric_vehicles', []) or [])
     chargers = [(i, c) for i, b in enumerate(env.buildings) for c in (b.electric_vehicle_chargers or [])]
@@ -347,7 +357,7 @@ def run_observations(name: str, steps: int = None):
     py_random.seed(seed)
     np.random.seed(seed)
 
-    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
+    env = CityLearnEnv(str(dataset_dir(name) / 'schema.json'))
     wrapped = NormalizedObservationWrapper(env)
     B = len(env.buildings)
     low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
@@ -407,7 +417,7 @@ def run_conditions(name: str):
     ref_env.setup_reference()
     from citylearn.citylearn import CityLearnEnv, EvaluationCondition as EC
     from citylearn.building import DynamicsBuilding
-    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
+    env = CityLearnEnv(str(dataset_dir(name) / 'schema.json'))
     low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
     high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
     sizes = [b.action_space.shape[0] for b in env.buildings]

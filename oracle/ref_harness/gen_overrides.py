@@ -46,10 +46,13 @@ def run_case(name: str):
     fixture, kwargs, *rest = CASES[name]
     schema_overrides = rest[0] if rest else {}
     seeds = rest[1] if len(rest) > 1 else [None] * 7
-    schema = str(REPO / 'tests' / 'golden' / fixture / 'dataset' / 'schema.json')
+    dataset_dir = REPO / 'tests' / 'golden' / fixture / 'dataset'
+    if not dataset_dir.exists():                      # the 2022_phase_all sample lives in the package (citylearn_amd/data)
+        dataset_dir = REPO / 'citylearn_amd' / 'data' / 'citylearn_challenge_2022_phase_all_720h'
+    schema = str(dataset_dir / 'schema.json')
     if schema_overrides:                              # schema handed over as a dictionary with the overrides applied
         schema = {**json.loads(Path(schema).read_text()), **schema_overrides,
-                  'root_directory': str(REPO / 'tests' / 'golden' / fixture / 'dataset')}
+                  'root_directory': str(dataset_dir)}
     env = CityLearnEnv(schema, **kwargs)
     out = {'fixture': fixture, 'kwargs': kwargs, 'schema_overrides': schema_overrides, 'reset_seeds': seeds, 'central_agent': bool(env.central_agent),
            'building_names': [b.name for b in env.buildings], 'observation_names': env.observation_names,

@@ -16,13 +16,9 @@ for label, fixture, B, E in (('2020 schema', 'g2020_cz1', None, 65536), ('C4 202
     acts = [lo[:, None] + torch.rand((len(low), E), device='cuda') * (hi - lo)[:, None] for _ in range(2)]
     for vec in (0, 1, 2, 4):
         for nw in ((0,) if B else (0, 3, 5, 9, 16)):
-            eng = StepEngine(tab, E)
-            eng.lib.cl_debug_set_vec(vec)
-            eng.lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
-            eng.lib.cl_debug_set_lean(0, nw)
+            eng = StepEngine(tab, E, tuning=dict(vec=vec, nw=nw))
             try:
                 us = measure(eng, acts, steps=40, reps=4)
                 print(f'{label} vec={vec} nw={nw}: {us:.2f} us', flush=True)
             except Exception as e:
                 print(f'{label} vec={vec} nw={nw}: {type(e).__name__} {str(e)[:80]}', flush=True)
-            eng.lib.cl_debug_set_vec(0); eng.lib.cl_debug_set_lean(0, 0)

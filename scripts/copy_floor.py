@@ -8,8 +8,7 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 from golden_util import golden
 from citylearn_amd import _lib
 from citylearn_amd.engine import StepEngine
-lib = _lib.load()
-lib.cl_debug_copy_floor.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+lib = _lib.load_tune()        # the floor kernel lives in libcitylearn_amd_tune.so (csrc/cl_tune.hip)
 
 
 def timed(fn, n=100, reps=10):
@@ -34,14 +33,13 @@ if __name__ == "__main__":
       st_in = torch.rand((3, B, E), device='cuda'); act = torch.rand((B, E), device='cuda')
       out2 = torch.empty((2, B, E), device='cuda')
       # in place on the state planes, like the step
-      us_c = timed(lambda: _lib.check(lib.cl_debug_copy_floor(st_in.data_ptr(), act.data_ptr(), st_in.data_ptr(), out2.data_ptr(), B, E,
-                                                             torch.cuda.current_stream().cuda_stream)))
+      us_c = timed(lambda: lib.cl_tune_copy_floor(st_in.data_ptr(), act.data_ptr(), st_in.data_ptr(), out2.data_ptr(), B, E,
+                                                             torch.cuda.current_stream().cuda_stream))
       tab = golden('g2022_all').spec().episode_tables(0)
       eng = StepEngine(tab, E)
       a = torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1
       us_s = timed(lambda: eng.step(a, 5))
-      lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
-      lib.cl_debug_set_lean(4, 0); us_g = timed(lambda: eng.step(a, 5)); lib.cl_debug_set_lean(0, 0)
+      eng.tuning.lean_variant = 1; us_g = timed(lambda: eng.step(a, 5)); eng.tuning.lean_variant = 0
       acts = torch.rand((eng.n_act_cols + 3, E), device='cuda')[3:] * 2 - 1          # same data, but not "column b = building b"
       eng2 = StepEngine(tab, E); eng2.dims.flags &= ~16
       us_n = timed(lambda: eng2.step(a, 5))

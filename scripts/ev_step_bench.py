@@ -58,15 +58,13 @@ def main():
     spec = g.spec()
     tab = spec.episode_tables(0)
     out = {'n_env': E}
-    from citylearn_amd import _lib
-    lib = _lib.load()
     for reward in ('MARL', 'Electric_Vehicles_Reward_Function'):
         eng = StepEngine(tab, E, reward=reward)
         a = (torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1).contiguous()
         for fv in (1, 2, 4):
-            lib.cl_debug_set_flex(fv)
+            eng.tuning.flex_vec = fv
             out[f'flex{fv}/{reward}'] = round(timed(eng, a), 2)
-        lib.cl_debug_set_flex(0)
+        eng.tuning.flex_vec = 0
         out[f'graph/{reward}'] = round(timed_graph(eng, a), 2)
     # K-step rollout with the on-device policy (cl_rollout_flex_f32: policy plane + flex + step + return per step), one graph
     eng = StepEngine(tab, E, reward='MARL')

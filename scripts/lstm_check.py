@@ -11,8 +11,7 @@ g = golden('g2023_p2'); spec = g.spec(); tab = spec.episode_tables(0); attrs = s
 E = 64
 cool = torch.from_numpy(g.ref['cool_dem']).cuda()
 for dbg in (0, 8, 3):
-    eng = StepEngine(tab, E, detail=True)
-    eng.lib.cl_debug_set_lstm(dbg)
+    eng = StepEngine(tab, E, detail=True, tuning=dict(lstm_variant=dbg))
     stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'])
     wt = wr = 0.0
     for t in range(g.facts['steps']):
@@ -22,10 +21,8 @@ for dbg in (0, 8, 3):
         ref = g.ref['reward_ComfortReward'][t]
         wr = max(wr, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
     print(f'variant {dbg}: teacher-fed worst |dT| =', wt, 'C ; worst comfort reward err / (1e-4 + 1e-4|ref|) =', wr)
-    eng.lib.cl_debug_set_lstm(0)
 for E, dbg in ((4096, 0), (65536, 0), (4096, 8), (65536, 8), (4096, 3), (65536, 3), (65536, 1), (65536, 2), (65536, 5), (65536, 6)):
-    eng = StepEngine(tab, E, detail=True)
-    eng.lib.cl_debug_set_lstm(dbg)
+    eng = StepEngine(tab, E, detail=True, tuning=dict(lstm_variant=dbg))
     stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0)
     cd = torch.rand((3, E), device='cuda') * 5
     for t in range(12, 16): stage.step(t, cd)

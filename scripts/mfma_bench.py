@@ -6,8 +6,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from citylearn_amd import _lib
-lib = _lib.load()
-lib.cl_debug_mfma_bench.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+lib = _lib.load_tune()
 out = torch.zeros(256, device='cuda')
 names = {0: 'bf16 32x32x16, 1 chain', 1: 'bf16, 2 chains', 2: 'bf16, 4 chains', 3: 'bf16 2 chains + 4 v_exp after each MFMA',
          4: 'the v_exp work alone (32 per iteration)', 5: 'f32 32x32x2, 2 chains', 6: 'f32 2 chains + 4 v_exp after each MFMA',
@@ -16,7 +15,7 @@ iters = 20000
 for wps in (1, 2):
     for mode in range(8):
         def run():
-            _lib.check(lib.cl_debug_mfma_bench(mode, wps, iters, out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            assert lib.cl_tune_mfma_bench(mode, wps, iters, out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); run(); e1.record(); torch.cuda.synchronize()

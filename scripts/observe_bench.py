@@ -42,12 +42,12 @@ for name, E in (('g2022_all', 65536), ('g2022_all', 262144), ('g2020_cz1', 65536
             stage = LSTMStage(spec, tab, eng)
         w = ObservationWriter(eng, ot, stage)
         acts = torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1
-        w.lib.cl_debug_set_observe(1, 0); us_row = timed(lambda: w.write(7))
-        w.lib.cl_debug_set_observe(3, 0); us_wave = timed(lambda: w.write(7))
+        eng.tuning.obs_variant = 1; us_row = timed(lambda: w.write(7))
+        eng.tuning.obs_variant = 3; us_wave = timed(lambda: w.write(7))
         alt = []
         for rows in (8, 16, 64):
-            w.lib.cl_debug_set_observe(2, rows); alt.append(f'{rows}: {timed(lambda: w.write(7)):.1f}')
-        w.lib.cl_debug_set_observe(0, 0)
+            eng.tuning.obs_variant, eng.tuning.obs_rows = 2, rows; alt.append(f'{rows}: {timed(lambda: w.write(7)):.1f}')
+        eng.tuning.obs_variant, eng.tuning.obs_rows = 0, 0
         us = timed(lambda: w.write(7))
         us0 = timed(lambda: w.write(0))
         rowt = w.table[7]

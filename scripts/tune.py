@@ -26,8 +26,6 @@ def measure(eng, acts, steps=100, reps=8):
 
 if __name__ == '__main__':
     g = golden('g2022_all'); spec = g.spec(); tab = spec.episode_tables(0)
-    lib = _lib.load()
-    lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
     Es = [int(x) for x in sys.argv[1:]] or [65536]
     for E in Es:
         eng = StepEngine(tab, E)
@@ -37,7 +35,7 @@ if __name__ == '__main__':
         for pipe in (0, 1):
             for vec in (1, 2, 4):
                 for nw in (16, 9, 6):
-                    lib.cl_debug_set_vec(vec); lib.cl_debug_set_lean(pipe, nw)
+                    eng.tuning.vec, eng.tuning.no_chunks, eng.tuning.nw = vec, pipe, nw
                     us = measure(eng, acts)
                     res.append((us, pipe, vec, nw))
                     print(f'E={E} pipe={pipe} vec={vec} nw={nw}: {us:.2f} us/step  {units*bpu/us/1e3:.0f} GB/s', flush=True)

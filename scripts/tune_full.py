@@ -11,7 +11,6 @@ from citylearn_amd.synthetic import tile_district
 from c4_bench import measure   # noqa
 
 if __name__ == '__main__':
-    lib = _lib.load(); lib.cl_debug_set_lean.argtypes = [ctypes.c_int, ctypes.c_int]
     for label, fixture, B, E, nws in (('2020', 'g2020_cz1', None, 65536, (9, 5, 3)), ('2023', 'g2023_p2', None, 65536, (3,)),
                                       ('C4-2020dev', 'g2020_cz1', 1024, 1024, (16,)), ('C4-lean', 'g2022_all', 1024, 1024, (16,))):
         spec = golden(fixture).spec()
@@ -24,7 +23,6 @@ if __name__ == '__main__':
         units = E * eng.n_bldg; bpu = eng.algorithmic_bytes_per_unit()
         for vec in (1, 2, 4):
             for nw in nws:
-                lib.cl_debug_set_vec(vec); lib.cl_debug_set_lean(0, nw if not B else 0)
+                eng.tuning.vec, eng.tuning.nw = vec, (nw if not B else 0)
                 us = measure(eng, acts)
                 print(f'{label} vec={vec} nw={nw}: {us:.1f} us/step {units*bpu/us/1e3:.0f} GB/s', flush=True)
-        lib.cl_debug_set_vec(0); lib.cl_debug_set_lean(0, 0)

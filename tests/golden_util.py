@@ -6,6 +6,7 @@ from pathlib import Path
 import numpy as np
 
 GOLDEN = Path(__file__).resolve().parent / 'golden'
+PACKAGE_DATA = {'g2022_all': GOLDEN.parent.parent / 'citylearn_amd' / 'data' / 'citylearn_challenge_2022_phase_all_720h'}
 FIXTURES = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2022_p1_year', 'g2020_15min')
 # dataset sweep: 95-step runs of the other dataset families (oracle/ref_harness/gen_golden.py)
 SWEEP = ('s_baeda', 's_2021', 's_2020_cz3', 's_2023_p1', 's_2023_p3', 's_autosize')
@@ -15,7 +16,9 @@ class Golden:
     def __init__(self, name: str):
         self.name = name
         self.dir = GOLDEN / name
-        self.schema_path = str(self.dir / 'dataset' / 'schema.json')
+        # the 2022_phase_all sample ships with the package (bench.py / smoke() load it too); every other fixture keeps its own
+        self.dataset_dir = self.dir / 'dataset' if (self.dir / 'dataset').exists() else PACKAGE_DATA[name]
+        self.schema_path = str(self.dataset_dir / 'schema.json')
         self.ref = np.load(self.dir / 'reference.npz', allow_pickle=False)
         self.facts = json.loads(str(self.ref['facts']))
         self._obs = None
@@ -36,7 +39,7 @@ class Golden:
     def spec(self, schema_overrides=None, **kwargs):
         from citylearn_amd.schema import load_district
         if schema_overrides:            # schema as a dictionary with top-level keys replaced
-            schema = {**json.loads(open(self.schema_path).read()), **schema_overrides, 'root_directory': str(self.dir / 'dataset')}
+            schema = {**json.loads(open(self.schema_path).read()), **schema_overrides, 'root_directory': str(self.dataset_dir)}
             return load_district(schema, **kwargs)
         if 'noise_seed' in self.facts:         # `noise_std` fixtures: the harness seeded numpy's global generator with this
             kwargs.setdefault('noise_seed', self.facts['noise_seed'])

@@ -22,10 +22,61 @@ def test_exports_every_declared_symbol(lib):
     assert lib.cl_abi_version() == abi.CL_ABI_VERSION
 
 
+def test_library_exports_nothing_else():
+    """The product library exports the declared entry points and nothing more: no tuning hooks, no microbenchmarks
+    (those live in libcitylearn_amd_tune.so), no process-global knobs."""
+    import subprocess
+    _lib.build()
+    out = subprocess.run(['nm', '-D', '--defined-only', str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    names = sorted(line.split()[-1] for line in out.splitlines() if ' T ' in line)
+    assert names == abi.EXPORTED_SYMBOLS, names
+
+
+def _header_struct_fields(name: str):
+    """Field names of `typedef struct <name> {...}` in the header, in declaration order."""
+    import re
+    text = abi._strip_comments(abi.HEADER.read_text())
+    body = re.search(r'typedef\s+struct\s+' + name + r'\s*\{(.*?)\}\s*' + name + r'\s*;', text, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *more = decl.split(',')
+        for part in [first.split()[-1], *more]:
+            fields.append(re.sub(r'\[.*\]|\*', '', part).strip())
+    return fields
+
+
+def _doc_struct_fields(cls: str):
+    """Field names of the ctypes stub `class <cls>(ctypes.Structure)` shown in INTEGRATION.md (executed, not pattern-matched)."""
+    import re
+    from pathlib import Path
+    text = (Path(abi.HEADER).parent.parent / 'INTEGRATION.md').read_text()
+    m = re.search(r'^class ' + cls + r'\(ctypes\.Structure\):.*?\n(    _fields_ = \[.*?\])[^\n\]]*\n(?=\S|\n)', text, flags=re.S | re.M)
+    ns = {'ctypes': ctypes}
+    exec('class S(ctypes.Structure):\n' + m.group(1), ns)      # noqa: S102 - our own documentation snippet
+    return ns['S']
+
+
+@pytest.mark.parametrize('c_name,binding,doc', [('cl_dims', _lib.Dims, '_Dims'), ('cl_flex', _lib.Flex, '_Flex'), ('cl_tuning', _lib.Tuning, None)])
+def test_struct_layouts_match_the_header(c_name, binding, doc):
+    """Field order of the ctypes bindings -- the package's and the stub INTEGRATION.md shows a reference maintainer --
+    against the header's struct declarations (a missing field shifts every later pointer)."""
+    want = _header_struct_fields(c_name)
+    assert [f for f, *_ in binding._fields_] == want
+    if doc:
+        stub = _doc_struct_fields(doc)
+        assert [f for f, *_ in stub._fields_] == want
+        assert ctypes.sizeof(stub) == ctypes.sizeof(binding)
+        for (fa, ta, *_), (fb, tb, *_) in zip(stub._fields_, binding._fields_):
+            assert ctypes.sizeof(ta) == ctypes.sizeof(tb), (fa, fb)
+
+
 def test_header_constants_are_consistent():
     assert abi.CLP_USED <= abi.CL_NP and abi.CLP_L_FIRST % 16 == 0 and abi.CLP_L_LAST - abi.CLP_L_FIRST < 32
     assert abi.CLT_ICOP_DHW < abi.CL_NF and abi.CLO_RESERVED < abi.CL_NO and abi.CLQ_REWARD < abi.CL_NQ
-    assert ctypes.sizeof(_lib.Dims) == 32
+    assert ctypes.sizeof(_lib.Dims) == 40 and ctypes.sizeof(_lib.Tuning) == 64
     assert abi.CLD_REWARD_MASK >> abi.CLD_REWARD_SHIFT >= abi.CLR_SOLAR_PENALTY
 
 

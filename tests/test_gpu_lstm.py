@@ -42,7 +42,7 @@ def test_lstm_stage_fed_with_reference_cooling(name):
         ref = g.ref['reward_ComfortReward'][t][cols]
         worst_r = max(worst_r, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
     assert worst_t < 2e-3, worst_t          # deg C on ~25 C: < 1e-4 relative
-    assert worst_r < 10.0, worst_r
+    assert worst_r < 1.0, worst_r           # BASELINE.json: reward parity within 1e-4 relative (measured: 0.09)
 
 
 def test_energy_step_plus_lstm_free_running():
@@ -130,15 +130,14 @@ def test_bf16_mfma_operand_layout():
     col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).  Asymmetric random operands (bf16-exact values)."""
     import ctypes
     from citylearn_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_tune()          # layout probes live in the tuning library, not in the product one
     rng = np.random.RandomState(0)
     A = rng.randint(-64, 64, size=(32, 16)).astype(np.float32) / 16.0          # exact in bf16
     B = rng.randint(-64, 64, size=(16, 32)).astype(np.float32) / 8.0
     to_bf16 = lambda x: (x.view(np.uint32) >> 16).astype(np.uint16)
     a = torch.from_numpy(to_bf16(A).astype(np.int16)).cuda(); b = torch.from_numpy(to_bf16(B).astype(np.int16)).cuda()
     d = torch.zeros((32, 32), device='cuda')
-    lib.cl_debug_mfma_bf16_probe.argtypes = [ctypes.c_void_p] * 4
-    _lib.check(lib.cl_debug_mfma_bf16_probe(a.data_ptr(), b.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert lib.cl_tune_mfma_bf16_probe(a.data_ptr(), b.data_ptr(), d.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
     np.testing.assert_array_equal(d.cpu().numpy(), (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32))
 
 

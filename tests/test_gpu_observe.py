@@ -59,15 +59,15 @@ def test_kernel_matches_host_statement(n_env, n_cols, n_dep):
         w._deps, w.n_deps = None, -1                                                       # no host list: device column map
         assert np.array_equal(got, w.write(row).cpu().numpy())
         w._deps, w.n_deps = deps, nd
-        w.lib.cl_debug_set_observe(1, 0)                                                    # row-wise kernel on every shape
+        eng.tuning.obs_variant, eng.tuning.obs_rows = 1, 0                                                  # row-wise kernel on every shape
         assert np.array_equal(got, w.write(row).cpu().numpy())
         assert np.array_equal(got, w.write(row, out=dense).cpu().numpy())
         for rows in (0, 4, 8, 32, 64):                                                     # LDS-tile kernel, block heights
-            w.lib.cl_debug_set_observe(2, rows)
+            eng.tuning.obs_variant, eng.tuning.obs_rows = 2, rows
             assert np.array_equal(got, w.write(row).cpu().numpy())
-        w.lib.cl_debug_set_observe(3, 0)                                                   # wave-independent kernel
+        eng.tuning.obs_variant, eng.tuning.obs_rows = 3, 0                                                 # wave-independent kernel
         assert np.array_equal(got, w.write(row).cpu().numpy())
-        w.lib.cl_debug_set_observe(0, 0)
+        eng.tuning.obs_variant, eng.tuning.obs_rows = 0, 0
         for e in (0, 1, n_env // 2, n_env - 1):
             want = ObservationTables(t32, src, scale, False).host_row(row, st[:, :, e], ob[:, :, e], tp[:, e])
             np.testing.assert_allclose(got[e], want, rtol=1e-6, atol=1e-6)

@@ -18,8 +18,11 @@ def _close(a, b, tol=2e-6):
 
 
 @pytest.mark.parametrize('name,kind,E', [('g2022_all', 'RewardFunction', 512), ('g2022_all', 'MARL', 256),
-                                         ('g2023_p2', 'SolarPenaltyReward', 192), ('g2020_cz1', 'IndependentSACReward', 128)])
+                                         ('g2023_p2', 'SolarPenaltyReward', 192), ('g2020_cz1', 'IndependentSACReward', 128),
+                                         ('g2022_all', 'MARL', 4), ('g2022_all', 'RewardFunction', 68), ('g2023_p2', 'RewardFunction', 36)])
 def test_open_loop_rollout_equals_single_steps(name, kind, E):
+    """Also batches that do not fill the last env tile (4, 68, 36 envs): the dead lanes of the ragged tile must not read the
+    open-loop action tensor (it ends with the last live env)."""
     g = golden(name)
     spec = g.spec()
     tab = spec.episode_tables(0)

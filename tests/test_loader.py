@@ -83,7 +83,7 @@ def test_error_behaviour(tmp_path):
         load_district('citylearn_challenge_2022_phase_1')            # dataset names need the network in the reference
     g = golden('g2022_all')
     schema = json.loads(open(g.schema_path).read())
-    schema['root_directory'] = str(g.dir / 'dataset')
+    schema['root_directory'] = str(g.dataset_dir)
     schema['actions']['electric_vehicle_storage'] = {'active': True}      # a helper row: expands to nothing without chargers
     assert load_district(schema).n_action_columns == load_district(g.schema_path).n_action_columns
     schema['buildings']['Building_1']['occupant'] = {'type': 'citylearn.occupant.LogisticRegressionOccupant'}
@@ -198,7 +198,7 @@ def test_battery_sizing_table_sources(tmp_path):
         got = [b.electrical_storage for b in g.spec(battery_sizing_data=source).buildings]
         assert [(e.capacity, e.nominal_power, e.loss_coefficient) for e in got] == [(e.capacity, e.nominal_power, e.loss_coefficient) for e in default]
     lonely = tmp_path / 'deep' / 'er' / 'dataset'
-    shutil.copytree(g.dir / 'dataset', lonely)
+    shutil.copytree(g.dataset_dir, lonely)
     with pytest.raises(NotImplementedError, match='battery_choices.yaml'):
         load_district(str(lonely / 'schema.json'))
     one = [(k, v['attributes']) for k, v in rows.items()][:1]            # a single model: every building must pick it
