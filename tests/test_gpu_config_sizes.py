@@ -90,7 +90,7 @@ def test_c4_shard_1024_buildings_x_1024_envs(fixture, kind):
     assert eng.n_bldg == 1024
     low, high = spec.action_limits()
     rng = np.random.RandomState(11)
-    worst = 0.0
+    worst = {}
     for t in range(12):
         a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
         a[:, 0] = 0.0
@@ -101,20 +101,21 @@ def test_c4_shard_1024_buildings_x_1024_envs(fixture, kind):
         eng.step(torch.from_numpy(a).cuda(), t)
         out, oe = ora.step(a, t)
         got_net, got_rw = eng.net.cpu().numpy(), eng.reward_bldg.cpu().numpy()
-        # district sums over 1024 buildings are O(1e3 kWh) in fp32: absolute tolerance scaled with the district size
-        worst = max(worst,
-                    _err(eng.soc.cpu().numpy(), ora.state[:, :, OS['SOC']].T, 1e-4, 1e-4),
-                    _err(eng.state[abi.CLS_DS_SOC].cpu().numpy(), ora.state[:, :, OS['DS']].T, 1e-4, 1e-4),
-                    _err(got_net, out[:, :, OO['NET']].T, 1e-4, 1e-4),
-                    _err(got_rw, out[:, :, OO['REWARD']].T, 1e-3 if kind == 'MARL' else 1e-4, 2e-4),
-                    _err(eng.district_net.cpu().numpy(), oe[:, 0], 2e-2, 1e-4),
-                    _err(eng.out_env[abi.CLQ_COST].cpu().numpy(), oe[:, 1], 2e-2, 1e-4),
-                    _err(eng.out_env[abi.CLQ_EMISSION].cpu().numpy(), oe[:, 2], 2e-2, 1e-4),
-                    _err(eng.district_reward.cpu().numpy(), oe[:, 3], 2e-2, 4e-4))
+        # district sums over 1024 buildings are O(1e3 kWh) in fp32: absolute tolerance scaled with the district size; the per-building
+        # reward tolerance is the one of test_large_district_building_chunked_grid (SolarPenaltyReward multiplies |net| by four SoCs)
+        for key, e in (('soc', _err(eng.soc.cpu().numpy(), ora.state[:, :, OS['SOC']].T, 1e-4, 1e-4)),
+                       ('ds_soc', _err(eng.state[abi.CLS_DS_SOC].cpu().numpy(), ora.state[:, :, OS['DS']].T, 1e-4, 1e-4)),
+                       ('net', _err(got_net, out[:, :, OO['NET']].T, 1e-4, 1e-4)),
+                       ('reward', _err(got_rw, out[:, :, OO['REWARD']].T, 1e-3, 2e-4)),
+                       ('d_net', _err(eng.district_net.cpu().numpy(), oe[:, 0], 2e-2, 1e-4)),
+                       ('d_cost', _err(eng.out_env[abi.CLQ_COST].cpu().numpy(), oe[:, 1], 2e-2, 1e-4)),
+                       ('d_emission', _err(eng.out_env[abi.CLQ_EMISSION].cpu().numpy(), oe[:, 2], 2e-2, 1e-4)),
+                       ('d_reward', _err(eng.district_reward.cpu().numpy(), oe[:, 3], 2e-2, 4e-4))):
+            worst[key] = max(worst.get(key, 0.0), e)
         # the finished sums are the sums of the planes the chunks wrote
         torch.testing.assert_close(eng.district_net.double(), eng.net.double().sum(dim=0), rtol=1e-5, atol=1e-2)
         torch.testing.assert_close(eng.district_reward.double(), eng.reward_bldg.double().sum(dim=0), rtol=2e-5, atol=1e-2)
-    assert worst < 1.0, (fixture, kind, worst)
+    assert max(worst.values()) < 1.0, (fixture, kind, worst)
 
 
 @pytest.mark.parametrize('kind', ['RewardFunction', 'MARL'])
