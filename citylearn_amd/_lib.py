@@ -36,7 +36,8 @@ class Tuning(ctypes.Structure):
     """``cl_tuning`` (include/citylearn_amd.h): per-call launch-geometry overrides; all zero = library defaults."""
     _fields_ = [('vec', ctypes.c_int32), ('nw', ctypes.c_int32), ('no_chunks', ctypes.c_int32), ('lean_variant', ctypes.c_int32),
                 ('envmajor', ctypes.c_int32), ('flex_vec', ctypes.c_int32), ('obs_variant', ctypes.c_int32),
-                ('obs_rows', ctypes.c_int32), ('lstm_variant', ctypes.c_int32), ('reserved', ctypes.c_int32 * 7)]
+                ('obs_rows', ctypes.c_int32), ('lstm_variant', ctypes.c_int32), ('full_variant', ctypes.c_int32),
+                ('reserved', ctypes.c_int32 * 6)]
 
 
 class Dims(ctypes.Structure):

@@ -502,43 +502,52 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
     a.out_env[(long long)CLQ_REWARD * a.n_env + env] = q_rw;
 }
 
-// Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x 16
-// waves; wave w adds chunks w, w+16, ... (independent loads, one round trip), then the 16 wave partials are summed in
-// a fixed order through LDS -- deterministic, and ~10x faster than one thread walking all chunks.
+// Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x ONE district
+// quantity x 16 waves; wave w adds chunks w, w+16, ... (independent loads issued four at a time: one memory round trip for up
+// to 64 chunks), then the 16 wave partials are summed in a fixed order through LDS -- deterministic.  (The first version let one
+// workgroup walk all four quantities of its 64 envs: 16 workgroups and four dependent rounds at 1024 envs, 4.7 us of a 22 us step.)
 __global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a) {
-    __shared__ float part[16][NQ][64];
+    __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
+    const int q = blockIdx.y;
     const long long plane = (long long)a.n_bldg * a.n_env;
     const float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
-    float s[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) s[q] = 0.0f;
+    const bool marl = rkind == CLR_MARL && q == CLQ_REWARD;      // partials carried sign(-net) * 0.01 * net^2: scale by max(0, district net)
+    float s = 0.0f, sn = 0.0f;
     if (e < a.n_env) {
-#pragma unroll 4
-        for (int c = w; c < a.n_chunks; c += 16) {
+        for (int c0 = w; c0 < a.n_chunks; c0 += 64) {
+            float v[4], vn[4];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) s[q] += scratch[((long long)c * NQ + q) * a.n_env + e];
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + 16 * j;
+                v[j] = c < a.n_chunks ? scratch[((long long)c * NQ + q) * a.n_env + e] : 0.0f;
+                vn[j] = (marl && c < a.n_chunks) ? scratch[((long long)c * NQ + CLQ_NET) * a.n_env + e] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s += v[j]; sn += vn[j]; }
         }
     }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) part[w][q][lane] = s[q];
+    part[w][lane] = s;
     __syncthreads();
-    if (threadIdx.x < NQ * 64) {
-        const int q = threadIdx.x >> 6;
-        float t = 0.0f;
+    float t = 0.0f;
+    if (w == 0) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += part[k][q][lane];
-        part[0][q][lane] = t;
+        for (int k = 0; k < 16; ++k) t += part[k][lane];
     }
-    __syncthreads();
-    if (threadIdx.x < NQ * 64 && e < a.n_env) {
-        const int q = threadIdx.x >> 6;
-        float t = part[0][q][lane];
-        if (rkind == CLR_MARL && q == CLQ_REWARD) t *= fmaxf(0.0f, part[0][CLQ_NET][lane]);   // partials carried sign(-net)*0.01*net^2
-        a.out_env[(long long)q * a.n_env + e] = t;
+    if (marl) {                                  // the district net, summed in the same order as the CLQ_NET workgroup does
+        __syncthreads();
+        part[w][lane] = sn;
+        __syncthreads();
+        if (w == 0) {
+            float n = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) n += part[k][lane];
+            t *= fmaxf(0.0f, n);
+        }
     }
+    if (w == 0 && e < a.n_env) a.out_env[(long long)q * a.n_env + e] = t;
 }
 
 // ---- streaming KPI accumulators (CLD_KPI): two small passes over the detail planes the step kernel just wrote ----
@@ -648,6 +657,7 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
 
 }  // namespace
 
+#include "cl_full.h"
 #include "cl_rollout.h"
 #include "cl_lstm.h"
 #include "cl_observe.h"
@@ -898,6 +908,18 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
             if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, true>), grid_f, block, lds_f, s, a);
             else hipLaunchKernelGGL((cl_step_kernel<2, false, false, true>), grid_f, block, lds_f, s, a);
         }
+    } else if (full && tun.full_variant != 1 && vec <= 2) {
+        // thermal / outage districts: the pack-generic kernel of cl_full.h
+        const bool small = block.x <= 576;
+        if (det) {
+            if (vec == 1) hipLaunchKernelGGL((cl_step_full_kernel<1, true, 1024, 4>), grid, block, lds, s, a);
+            else if (small) hipLaunchKernelGGL((cl_step_full_kernel<2, true, 576, 3>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((cl_step_full_kernel<2, true, 1024, 4>), grid, block, lds, s, a);
+        } else {
+            if (vec == 1) hipLaunchKernelGGL((cl_step_full_kernel<1, false, 1024, 6>), grid, block, lds, s, a);
+            else if (small) hipLaunchKernelGGL((cl_step_full_kernel<2, false, 576, 5>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((cl_step_full_kernel<2, false, 1024, 5>), grid, block, lds, s, a);
+        }
     } else if (full && det) {
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, true>), grid, block, lds, s, a); break;
@@ -934,7 +956,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         }
     }
     if (a.n_chunks > 1) {
-        hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, s, a);
         if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL) {
             const long long n = (long long)dims->n_env * dims->n_bldg;
             hipLaunchKernelGGL(cl_marl_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);

@@ -108,9 +108,11 @@ CL_DEV void load_bp(Bp& B, const uint32_t* __restrict__ p) {
 }
 
 // Time-series row of (t, building): wave-uniform.
+// (Field order: values that sit next to each other in the table -- load / solar, price / carbon -- are kept apart here.  With them
+//  adjacent the optimiser kept a 16-byte stack slot of the struct alive in the two-envs-per-lane kernel (vector-typed pair
+//  accesses it could not promote): a scratch store and two scratch loads per building.)
 struct Row {
-    float nsl, sol, price, carbon;
-    float cool, heat, dhw, cop_c, cop_h, cop_d, icop_c, icop_h, icop_d, hvac;
+    float nsl, cool, sol, heat, price, dhw, carbon, cop_c, cop_h, cop_d, icop_c, icop_h, icop_d, hvac;
     bool outage;
 };
 
@@ -124,6 +126,23 @@ CL_DEV void load_row(Row& R, const float* __restrict__ q, uint32_t flags) {
         R.icop_c = q[CLT_ICOP_COOL]; R.icop_h = q[CLT_ICOP_HEAT]; R.icop_d = q[CLT_ICOP_DHW];
         R.hvac = q[CLT_HVAC_MODE];
         R.outage = (flags & CLF_OUTAGE) && (q[CLT_OUTAGE] != 0.0f);
+    }
+}
+
+// The same row through 32-bit integer loads: float stores to the state / output planes cannot alias them (type-based alias
+// analysis), so inside a loop that also stores the row still arrives by scalar loads in SGPRs instead of 14 uniform VGPRs.
+// `ts` is read-only for every kernel, which is what makes the pun harmless.
+template <bool FULL>
+CL_DEV void load_row_scalar(Row& R, const float* __restrict__ qf, uint32_t flags) {
+    const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(qf);
+    R.nsl = pw(q, CLT_NSL); R.sol = pw(q, CLT_SOLAR); R.price = pw(q, CLT_PRICE); R.carbon = pw(q, CLT_CARBON);
+    R.outage = false;
+    if constexpr (FULL) {
+        R.cool = pw(q, CLT_COOL_DEM); R.heat = pw(q, CLT_HEAT_DEM); R.dhw = pw(q, CLT_DHW_DEM);
+        R.cop_c = pw(q, CLT_COP_COOL); R.cop_h = pw(q, CLT_COP_HEAT); R.cop_d = pw(q, CLT_COP_DHW);
+        R.icop_c = pw(q, CLT_ICOP_COOL); R.icop_h = pw(q, CLT_ICOP_HEAT); R.icop_d = pw(q, CLT_ICOP_DHW);
+        R.hvac = pw(q, CLT_HVAC_MODE);
+        R.outage = (flags & CLF_OUTAGE) && (pw(q, CLT_OUTAGE) != 0.0f);
     }
 }
 

@@ -637,11 +637,33 @@ class DistrictSpec:
                 for c_col, i_col in ((abi.CLT_COP_COOL, abi.CLT_ICOP_COOL), (abi.CLT_COP_HEAT, abi.CLT_ICOP_HEAT),
                                      (abi.CLT_COP_DHW, abi.CLT_ICOP_DHW)):
                     ts[:, i, i_col] = 1.0 / ts[:, i, c_col].astype(np.float64)
+        _pack_full_block(params)
         from .flex import pack_flex
         # an explicit window (tables spanning the simulation period for per-env-block offsets) reads the charger /
         # washing-machine schedules on the window's own rows; a plain episode reads them from row 0 like the reference
         flex = pack_flex(self, start, T, aligned=window is not None)
         return EpisodeTables(params=params, ts=ts, start=start, end=end, outage=outage, flex=flex)
+
+
+def _pack_full_block(params: np.ndarray):
+    """The compact `CLP_F_*` copy the thermal / outage step kernel reads (include/citylearn_amd.h): same bit patterns as the
+    slots it gathers, laid out in consumption order.  The heating / dhw action scales are the float32 products the kernel used
+    to form per wave (`cooling capacity * dt`, `heating capacity * dt`: the reference's wrong-capacity quirk, building.py:1720, 1765)."""
+    pf = params.view(np.float32)
+    F = abi.CLP_F_FIRST
+    params[:, abi.CLP_F_FLAGS] = params[:, abi.CLP_FLAGS]
+    params[:, abi.CLP_F_ACT:abi.CLP_F_ACT + 7] = params[:, [abi.CLP_ACT_COOL_STO, abi.CLP_ACT_HEAT_STO, abi.CLP_ACT_DHW_STO, abi.CLP_ACT_ELEC_STO,
+                                                           abi.CLP_ACT_COOL_DEV, abi.CLP_ACT_HEAT_DEV, abi.CLP_ACT_COH_DEV]]
+    params[:, abi.CLP_F_HEAD:abi.CLP_F_HEAD + 8] = params[:, [abi.CLP_DT_HOURS, abi.CLP_L_TSR, abi.CLP_CD_POW, abi.CLP_HD_POW, abi.CLP_DD_POW,
+                                                             abi.CLP_T0_IHEAT_DIV, abi.CLP_DYN_WARMUP, abi.CLP_L_RW_EXPONENT]]
+    dt = pf[:, abi.CLP_DT_HOURS]
+    scales = (pf[:, abi.CLP_CS_CAP], pf[:, abi.CLP_CS_CAP] * dt, pf[:, abi.CLP_HS_CAP] * dt)       # float32 products
+    for k, (raw, der) in enumerate(((abi.CLP_CS_CAP, abi.CLP_CS_IRTE), (abi.CLP_HS_CAP, abi.CLP_HS_IRTE), (abi.CLP_DS_CAP, abi.CLP_DS_IRTE))):
+        base = abi.CLP_F_TANK + 8 * k
+        params[:, base:base + 7] = params[:, [raw, der + 2, raw + 2, der, der + 1, raw + 4, raw + 5]]
+        pf[:, base + 7] = scales[k].astype(np.float32)
+    params[:, abi.CLP_F_BATT:abi.CLP_F_BATT + 24] = params[:, abi.CLP_L_PDT:abi.CLP_L_PDT + 24]
+    assert abi.CLP_L_PDT + 23 == abi.CLP_L_PEC_B3 and F + 63 == abi.CLP_F_LAST
 
 
 # --------------------------------------------------------------------------------------------------------------

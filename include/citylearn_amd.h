@@ -50,7 +50,7 @@ extern "C" {
 #define CL_ERANGE       -5   /* t / k_steps outside [0, n_steps) */
 
 /* ---- table widths ---- */
-#define CL_NP  128   /* words per building in `params` */
+#define CL_NP  192   /* words per building in `params` */
 #define CL_NF   16   /* floats per (t, building) row in `ts` */
 #define CL_NS    6   /* state planes */
 #define CL_NO   15   /* per-building output planes */
@@ -116,7 +116,18 @@ enum cl_param {
     CLP_DS_IRTE, CLP_DS_ICAP, CLP_DS_CAPL,
     CLP_T0_IHEAT_DIV,     /* 1 / CLP_T0_HEAT_DIV */
     CLP_FLEX_INDEX,       /* i32: row of this building in the flexible-load planes (cl_flex.flex_out), -1 = no charger / washing machine */
-    CLP_USED
+    CLP_USED,
+    /* ---- compact copy for the thermal / outage step kernel (cl_full.h): 64 words = four 64-byte lines, in the order the kernel
+     *      consumes them, so that a wave fetches a building's parameters in three batches of independent scalar loads instead of a
+     *      dozen dependent round trips scattered over the slots above.  Same bit patterns as the slots they copy. ---- */
+    CLP_F_FIRST = 128,
+    CLP_F_FLAGS = CLP_F_FIRST,                       /* CLP_FLAGS, then the seven action columns CLP_ACT_COOL_STO .. CLP_ACT_COH_DEV */
+    CLP_F_ACT = CLP_F_FIRST + 1,
+    CLP_F_HEAD = CLP_F_FIRST + 8,                    /* dt, r, cooling / heating / dhw device power, CLP_T0_IHEAT_DIV, CLP_DYN_WARMUP, reward exponent */
+    CLP_F_TANK = CLP_F_FIRST + 16,                   /* 3 x 8 (cooling, heating, dhw): capacity, capacity*(1-loss r), sqrt(eff), 1/sqrt(eff), 1/capacity,
+                                                        max input, max output, action scale [kWh per unit action] (sic: building.py:1676, 1720, 1765) */
+    CLP_F_BATT = CLP_F_FIRST + 40,                   /* the 24 words CLP_L_PDT .. CLP_L_PEC_B3 */
+    CLP_F_LAST = CLP_F_FIRST + 63
 };
 
 /* ---- building flag bits (CLP_FLAGS) ---- */
@@ -238,7 +249,8 @@ typedef struct cl_tuning {
     int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent kernel */
     int32_t obs_rows;       /* LDS-tile observation kernel: envs per block */
     int32_t lstm_variant;   /* LSTM stage timing experiments (csrc/cl_lstm.h) */
-    int32_t reserved[7];
+    int32_t full_variant;   /* thermal / outage districts: 1 = the round-1 general kernel instead of cl_step_full_kernel (tests) */
+    int32_t reserved[6];
 } cl_tuning;
 
 typedef struct cl_dims {

@@ -135,6 +135,43 @@ def test_full_kernel_vec2(name):
     assert max(worst.values()) < 1.0, worst
 
 
+@pytest.mark.parametrize('name,kind,detail', [('g2020_cz1', 'RewardFunction', False), ('g2020_cz1', 'SolarPenaltyReward', True),
+                                              ('g2023_p2', 'MARL', False), ('g2023_p2', 'IndependentSACReward', True),
+                                              ('s_2023_p3', 'RewardFunction', True), ('s_baeda', 'RewardFunction', False)])
+def test_thermal_kernel_against_the_round1_kernel(name, kind, detail):
+    """`cl_step_full_kernel` (cl_full.h: pack-generic arithmetic, one tank update per end use, outage specialisation) against the
+    general kernel it replaced (`cl_tuning.full_variant = 1`), every env with its own actions incl. zeros and bounds, outage rows
+    included: one and two envs per lane give identical bits, and both equal the round-1 kernel bit for bit on the production
+    planes.  (With the detail planes compiled in, the round-1 kernel's fused multiply-adds were chosen by the compiler per
+    instantiation, so a few last bits differ there: 2.3e-3 of the parity tolerance at most.)"""
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E = 516
+    old = StepEngine(tab, E, reward=kind, detail=detail, tuning=dict(full_variant=1, vec=1))
+    new1, new2 = (StepEngine(tab, E, reward=kind, detail=detail, tuning=dict(vec=v)) for v in (1, 2))
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda()[:, None], torch.from_numpy(high).cuda()[:, None]
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    T = min(tab.ts.shape[0] - 1, 200)
+    saw_outage = False
+    for t in range(T):
+        a = (lo + torch.rand((old.n_act_cols, E), device='cuda', generator=gen) * (hi - lo)).contiguous()
+        a[:, 0] = 0.0
+        a[:, 1], a[:, 2] = lo[:, 0], hi[:, 0]
+        saw_outage |= bool(tab.ts[t, :, abi.CLT_OUTAGE].any())
+        for e in (old, new1, new2):
+            e.step(a, t)
+        assert torch.equal(new1.state, new2.state) and torch.equal(new1.out_bldg, new2.out_bldg) and torch.equal(new1.out_env, new2.out_env), t
+        if detail:
+            for x, y in ((new1.state, old.state), (new1.out_bldg[:abi.CLO_RESERVED], old.out_bldg[:abi.CLO_RESERVED]), (new1.out_env, old.out_env)):
+                assert float(((x - y).abs() / (1e-4 + 1e-4 * y.abs())).max()) < 0.01, t
+            new1.state.copy_(old.state); new2.state.copy_(old.state)          # keep the three in lock-step
+        else:
+            assert torch.equal(new1.state, old.state) and torch.equal(new1.out_bldg[:2], old.out_bldg[:2]) and torch.equal(new1.out_env, old.out_env), t
+    assert saw_outage or name not in ('g2023_p2', 's_2023_p3')
+
+
 @pytest.mark.parametrize('name', SWEEP)
 def test_dataset_sweep_teacher_forced(name):
     """Short runs of the other dataset families (baeda_3dem, 2021, 2020 climate zone 3, 2023 phase 1 and the six-building
