@@ -140,8 +140,11 @@ def test_c5_rollout_kernel_at_131072_envs(kind):
     ret1 = torch.zeros(E, device='cuda')
     one.rollout(K, seed=seed, ret_env=ret1)
     assert torch.equal(roll.state, one.state)
-    assert torch.equal(roll.out_bldg[:2], one.out_bldg[:2]) and torch.equal(roll.out_env, one.out_env)
-    assert torch.equal(ret, ret1)
+    assert torch.equal(roll.out_bldg[:2], one.out_bldg[:2])
+    # district cost / emission are running sums of per-lane products, which the compiler may or may not fuse into the
+    # accumulation per instantiation: last-bit differences only
+    torch.testing.assert_close(roll.out_env, one.out_env, rtol=2e-6, atol=2e-5)
+    torch.testing.assert_close(ret, ret1, rtol=2e-6, atol=1e-4)
     # and directly against cl_step_f32 on the tail of the batch (last 256 envs: the highest counters / addresses)
     from citylearn_amd import _lib
     lib = _lib.load()
