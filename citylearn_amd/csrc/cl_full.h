@@ -263,7 +263,8 @@ CL_DEV void unit_step(const FP& B, const cl::Row& R, int t, bool first, const Ac
         // buildings, add back the ideal-vs-delivered load difference (building.py:2877-2905)
         F base = net - vfma(A.c_b, splat<F>(B.r), vfma(eb_ds, splat<F>(R.icop_d), vfma(eb_hs, splat<F>(R.icop_h), eb_cs * R.icop_c)));
         O.net_ws = base;
-        if (B.flags & CLF_DYNAMICS) base = base + vfma(splat<F>(R.heat) - heat_dem, splat<F>(t0_iheat), (splat<F>(R.cool) - cool_dem) * R.icop_c);
+        // (sic, building.py:2893-2898: the heating difference of every step is converted with ONE COP, the episode's last row's)
+        if (B.flags & CLF_DYNAMICS) base = base + vfma(splat<F>(R.heat) - heat_dem, splat<F>(heat_hp ? R.icop_h_eval : B.t0_iheat_div), (splat<F>(R.cool) - cool_dem) * R.icop_c);
         O.base_net = base;
         O.expected = cool_dem + heat_dem + R.dhw + R.nsl;
         O.served = e_cool + vmax(-eb_cs, zero) + e_heat + vmax(-eb_hs, zero) + e_dhw + vmax(-eb_ds, zero) + e_ns;
@@ -431,7 +432,8 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
             clv::FP B;
             clv::load_fp(B, f);
             cl::Row R;
-            cl::load_row_scalar<true>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags);
+            cl::load_row_scalar<true>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags,
+                                      DETAIL ? a.ts + ((long long)(ts_row - a.t + a.n_steps - 1) * a.n_bldg + b) * CL_NF : nullptr);
             clv::St<F> S = {cur.soc, cur.eff, cur.deg, cur.cs, cur.hs, cur.ds};
             const clv::Ac<F> act = {cur.a_cs, cur.a_hs, cur.a_ds, cur.a_es, cur.a_cd, cur.a_hd};
             clv::Ou<F> O;

@@ -227,7 +227,8 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
         cl::Bp B;
         cl::load_bp<FULL>(B, a.params + (long long)b * CL_NP);
         cl::Row R;
-        cl::load_row<FULL>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags);
+        cl::load_row<FULL>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags,
+                           (FULL && DETAIL) ? a.ts + ((long long)(ts_row - a.t + a.n_steps - 1) * a.n_bldg + b) * CL_NF : nullptr);
         if (live) {
             const long long off = (long long)b * a.n_env + env0;
             float s_soc[VEC], s_eff[VEC], s_deg[VEC], s_cs[VEC], s_hs[VEC], s_ds[VEC];

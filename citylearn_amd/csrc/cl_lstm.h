@@ -43,6 +43,7 @@
 #define CLW_RW_BAND 3286        /* ComfortReward band (NaN = use the data-file comfort band), exponents */
 #define CLW_RW_LOEXP 3287
 #define CLW_RW_HIEXP 3288
+#define CLW_DEM_HEAT 3290        /* != 0: the model's demand input is heating_demand (delivered heating plane), not cooling_demand */
 #define CLW_KPI_BAND 3289        /* comfort band of the discomfort KPIs (evaluate()'s scalar, citylearn.py:1191) */
 // dyn_pre layout: [0..63] layer-0 pre-gates, [64] data-file temperature (normalised), [65] data-file temperature [C]
 #define CLPRE_TNORM 64
@@ -223,7 +224,9 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     float temp = pre_t[CLPRE_TRAW];
     if (W[CLW_ACTIVE] != 0.0f) {                                  // block-uniform
         const float tmin = W[CLW_TMIN], tmax = W[CLW_TMAX], cmin = W[CLW_CMIN], cmax = W[CLW_CMAX];
-        const float cool_n = (cool - cmin) / (cmax - cmin);
+        // the demand the model was trained on: delivered cooling, or delivered heating for a heating-driven model
+        const float dem = (W[CLW_DEM_HEAT] != 0.0f && a.heat_dem) ? a.heat_dem[off] : cool;
+        const float cool_n = (dem - cmin) / (cmax - cmin);
         const int slot = a.t % CL_LSTM_LOOKBACK;
         if (live && hh == 0) a.hist[(long long)slot * plane + off] = cool_n;         // building.py:3068-3078
         float y = pre_t[CLPRE_TNORM];
@@ -418,7 +421,8 @@ __global__ void __launch_bounds__(64) cl_lstm_generic_kernel(const LstmGenArgs g
     const float cool = a.cool_dem[off];
     float temp = pre_t[CLPRE_TRAW];
     const float tmin = W[CLW_TMIN], tmax = W[CLW_TMAX], cmin = W[CLW_CMIN], cmax = W[CLW_CMAX];
-    const float cool_n = (cool - cmin) / (cmax - cmin);
+    const float dem = (W[CLW_DEM_HEAT] != 0.0f && a.heat_dem) ? a.heat_dem[off] : cool;
+    const float cool_n = (dem - cmin) / (cmax - cmin);
     const int slot = a.t % CL_LSTM_LOOKBACK;
     if (live) a.hist[(long long)slot * plane + off] = cool_n;                     // building.py:3068-3078
     float y = pre_t[CLPRE_TNORM];

@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
             if (!own[m]) continue;                                       // wave-uniform
             const int b = w + m * a.nw;
             cl::Row R;
-            cl::load_row<FULL>(R, a.ts + ((long long)(t + row0) * a.n_bldg + b) * CL_NF, B[m].flags);
+            cl::load_row<FULL>(R, a.ts + ((long long)(t + row0) * a.n_bldg + b) * CL_NF, B[m].flags,
+                               FULL ? a.ts + ((long long)(a.n_steps - 1 + row0) * a.n_bldg + b) * CL_NF : nullptr);
             float a_es[VEC], a_cs[VEC], a_hs[VEC], a_ds[VEC], a_cd[VEC], a_hd[VEC];
             rollout_action_cached<VEC>(a_es, rnd[m], r, B[m].a_es, env0, t, k, live);
             if constexpr (FULL) {

@@ -113,14 +113,17 @@ CL_DEV void load_bp(Bp& B, const uint32_t* __restrict__ p) {
 //  accesses it could not promote): a scratch store and two scratch loads per building.)
 struct Row {
     float nsl, cool, sol, heat, price, dhw, carbon, cop_c, cop_h, cop_d, icop_c, icop_h, icop_d, hvac;
+    float icop_h_eval;      // 1 / heating COP on the episode's LAST row: what evaluate()'s partial-load baseline divides by (sic, building.py:2893-2898)
     bool outage;
 };
 
+// `q_eval`: the same building's row at the episode's last step (only its heating COP is read; nullptr = this row)
 template <bool FULL>
-CL_DEV void load_row(Row& R, const float* __restrict__ q, uint32_t flags) {
+CL_DEV void load_row(Row& R, const float* __restrict__ q, uint32_t flags, const float* __restrict__ q_eval = nullptr) {
     R.nsl = q[CLT_NSL]; R.sol = q[CLT_SOLAR]; R.price = q[CLT_PRICE]; R.carbon = q[CLT_CARBON];
     R.outage = false;
     if constexpr (FULL) {
+        R.icop_h_eval = (q_eval ? q_eval : q)[CLT_ICOP_HEAT];
         R.cool = q[CLT_COOL_DEM]; R.heat = q[CLT_HEAT_DEM]; R.dhw = q[CLT_DHW_DEM];
         R.cop_c = q[CLT_COP_COOL]; R.cop_h = q[CLT_COP_HEAT]; R.cop_d = q[CLT_COP_DHW];
         R.icop_c = q[CLT_ICOP_COOL]; R.icop_h = q[CLT_ICOP_HEAT]; R.icop_d = q[CLT_ICOP_DHW];
@@ -133,8 +136,9 @@ CL_DEV void load_row(Row& R, const float* __restrict__ q, uint32_t flags) {
 // analysis), so inside a loop that also stores the row still arrives by scalar loads in SGPRs instead of 14 uniform VGPRs.
 // `ts` is read-only for every kernel, which is what makes the pun harmless.
 template <bool FULL>
-CL_DEV void load_row_scalar(Row& R, const float* __restrict__ qf, uint32_t flags) {
+CL_DEV void load_row_scalar(Row& R, const float* __restrict__ qf, uint32_t flags, const float* __restrict__ qf_eval = nullptr) {
     const uint32_t* __restrict__ q = reinterpret_cast<const uint32_t*>(qf);
+    if constexpr (FULL) R.icop_h_eval = pw(reinterpret_cast<const uint32_t*>(qf_eval ? qf_eval : qf), CLT_ICOP_HEAT);
     R.nsl = pw(q, CLT_NSL); R.sol = pw(q, CLT_SOLAR); R.price = pw(q, CLT_PRICE); R.carbon = pw(q, CLT_CARBON);
     R.outage = false;
     if constexpr (FULL) {
@@ -342,7 +346,8 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         // buildings, add back the ideal-vs-delivered load difference (building.py:2877-2905)
         float base = net - (eb_cs * R.icop_c + eb_hs * R.icop_h + eb_ds * R.icop_d + A.c_b * B.r);
         O.net_ws = base;
-        if (B.flags & CLF_DYNAMICS) base += (R.cool - cool_dem) * R.icop_c + (R.heat - heat_dem) * t0_iheat;
+        // (the heating difference of every step is converted with ONE COP, that of the step evaluate() is called at: building.py:2893-2898)
+        if (B.flags & CLF_DYNAMICS) base += (R.cool - cool_dem) * R.icop_c + (R.heat - heat_dem) * (heat_hp ? R.icop_h_eval : B.t0_iheat_div);
         O.base_net = base;
         O.expected = cool_dem + heat_dem + R.dhw + R.nsl;
         O.served = e_cool + fmaxf(-eb_cs, 0.0f) + e_heat + fmaxf(-eb_hs, 0.0f) + e_dhw + fmaxf(-eb_ds, 0.0f) + e_ns;

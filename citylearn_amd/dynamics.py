@@ -20,6 +20,7 @@ _PERIODIC = {'month': 12, 'hour': 24, 'day_type': 7}     # building.py:1493-1498
 
 # offsets inside `lstm_w` (csrc/cl_lstm.h)
 WC, WT, WHH0, WIH1, WHH1, B1, WLIN, BLIN, TMIN, TMAX, CMIN, CMAX, ACTIVE = 0, 64, 128, 1152, 2176, 3200, 3264, 3280, 3281, 3282, 3283, 3284, 3285
+DEM_HEAT = 3290          # csrc/cl_lstm.h CLW_DEM_HEAT
 PRE_TNORM, PRE_TRAW, PRE_HVAC, PRE_CSP, PRE_HSP, PRE_BAND, PRE_OCC, PRE_OUTAGE = 64, 65, 66, 67, 68, 69, 70, 71
 RW_BAND, RW_LOEXP, RW_HIEXP, KPI_BAND = 3286, 3287, 3288, 3289
 
@@ -64,9 +65,8 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         sd = {k: v.double().numpy() for k, v in sd.get('model_state_dict', sd).items()}
         names = list(d.input_observation_names)
         lo, hi = np.array(d.input_normalization_minimum, dtype=np.float64), np.array(d.input_normalization_maximum, dtype=np.float64)
-        ic, it = names.index('cooling_demand'), names.index('indoor_dry_bulb_temperature')
-        if 'heating_demand' in names:
-            raise NotImplementedError('heating-demand driven dynamics models are not supported yet')
+        ic, it = _demand_input(names), names.index('indoor_dry_bulb_temperature')
+        lstm_w[i, DEM_HEAT] = 1.0 if names[ic] == 'heating_demand' else 0.0
         if not (d.num_layers == 2 and H <= 16):
             # another shape: the generic kernel's tables hold the weights (pack_lstm_generic); this row carries the
             # normalisation constants, the output bias and the kernel selector
@@ -114,6 +114,15 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
     return lstm_w, dyn_pre
 
 
+def _demand_input(names) -> int:
+    """Index of the model's one env-dependent demand input: `cooling_demand`, or `heating_demand` for a heating-driven model
+    ("LSTM model only uses either cooling/heating demand not both as input variable", building.py:3013-3017)."""
+    both = [n for n in ('cooling_demand', 'heating_demand') if n in names]
+    if len(both) != 1:
+        raise NotImplementedError(f'LSTM dynamics need exactly one of cooling_demand / heating_demand among their inputs (got {both})')
+    return names.index(both[0])
+
+
 def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):
     """Tables of `cl_lstm_generic_step_f32` for the buildings `pack_lstm` marked ACTIVE = 2 / 3 (LSTM shapes other than two
     layers of <= 16 units): ``(gen_w [B, GW] f32, gen_pre [T, B, H, 4] f32, H)`` with H the largest hidden size among them, or
@@ -139,7 +148,7 @@ def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):
         sd = {k: v.double().numpy() for k, v in sd.get('model_state_dict', sd).items()}
         names = list(d.input_observation_names)
         lo, hi = np.array(d.input_normalization_minimum, dtype=np.float64), np.array(d.input_normalization_maximum, dtype=np.float64)
-        ic, it = names.index('cooling_demand'), names.index('indoor_dry_bulb_temperature')
+        ic, it = _demand_input(names), names.index('indoor_dry_bulb_temperature')
 
         def ug(m):                                      # torch rows [i; f; g; o] x h (x cols)  ->  [unit, gate, (cols)], padded to H units
             m = np.asarray(m, dtype=np.float64).reshape((4, h) + np.shape(m)[1:])
@@ -250,23 +259,28 @@ class LSTMStage:
             if self.generic is not None:
                 self.generic['hidden'].zero_()
 
-    def step(self, t: int, cool_dem: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t."""
+    def step(self, t: int, cool_dem: Optional[torch.Tensor] = None, heat_dem: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t.
+        ``cool_dem`` / ``heat_dem``: delivered cooling / heating planes to use instead of the engine's own (tests)."""
         e = self.engine
         if self._args is None:          # per-step arguments that never change, converted once
             self._args = ((ctypes.byref(e.dims), self.lstm_w.data_ptr(), None if self.lstm_wb is None else self.lstm_wb.data_ptr(),
                            self.dyn_pre.data_ptr()),
-                          (None, self.hist.data_ptr(), self.hidden.data_ptr(), self.indoor_temp.data_ptr(), self.comfort.data_ptr(),
+                          (self.hist.data_ptr(), self.hidden.data_ptr(), self.indoor_temp.data_ptr(), self.comfort.data_ptr(),
                            None if self.kpi_comfort is None else self.kpi_comfort.data_ptr()),
-                          e.out_bldg[abi.CLO_COOL_DEM].data_ptr())
-        head, tail, own_cd = self._args
+                          e.out_bldg[abi.CLO_COOL_DEM].data_ptr(), e.out_bldg[abi.CLO_HEAT_DEM].data_ptr())
+        head, tail, own_cd, own_hd = self._args
+        # delivered heating: the engine's own plane (written with the detail planes), or the caller's; with a caller-fed cooling
+        # plane and no heating plane the heating side is zero (cooling-only tests)
+        hd = heat_dem.data_ptr() if heat_dem is not None else (own_hd if cool_dem is None else None)
+        tail = (hd,) + tail
         with e._on_device():
             rc = self.lib.cl_lstm_step_f32(*head, own_cd if cool_dem is None else cool_dem.data_ptr(), *tail, int(t), e._stream())
             if not rc and self.generic is not None:
                 gn = self.generic
                 rc = self.lib.cl_lstm_generic_step_f32(head[0], head[1], head[3], gn['w'].data_ptr(), gn['w'].shape[1], gn['pre'].data_ptr(),
                                                        gn['hidden'].data_ptr(), gn['h'], own_cd if cool_dem is None else cool_dem.data_ptr(),
-                                                       None, tail[1], tail[3], tail[4], tail[5], int(t), e._stream())
+                                                       hd, tail[1], tail[3], tail[4], tail[5], int(t), e._stream())
         if rc:
             _lib.check(rc)
         return self.indoor_temp

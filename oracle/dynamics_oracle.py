@@ -35,7 +35,7 @@ class LSTMOracle:
         self.hidden = (torch.zeros(self.d.num_layers, 1, self.d.hidden_size), torch.zeros(self.d.num_layers, 1, self.d.hidden_size))
         self.window = [[None] * (self.d.lookback + 1) for _ in self.names]
 
-    def _observation(self, k: str, t: int, delivered_cooling: float):
+    def _observation(self, k: str, t: int, delivered_cooling: float, delivered_heating: float = 0.0):
         """`Building.observations(include_all=True, periodic_normalization=True)[k]` at step t (building.py:1115-1219)."""
         for base, x_max in (('month', 12), ('hour', 24), ('day_type', 7)):      # building.py:1493-1498
             if k in (f'{base}_sin', f'{base}_cos'):
@@ -43,12 +43,14 @@ class LSTMOracle:
                 return np.sin(x) if k.endswith('_sin') else np.cos(x)
         if k == 'cooling_demand':
             return delivered_cooling                                    # building.py:1435
+        if k == 'heating_demand':
+            return delivered_heating                                    # building.py:1436
         return self.series[k][t]
 
-    def step(self, t: int, delivered_cooling: float):
+    def step(self, t: int, delivered_cooling: float, delivered_heating: float = 0.0):
         """Returns the indoor dry-bulb temperature the reference holds for step t after `apply_actions`."""
         # _update_dynamics_input (building.py:3057-3078)
-        obs = [self._observation(k, t, delivered_cooling) for k in self.names]
+        obs = [self._observation(k, t, delivered_cooling, delivered_heating) for k in self.names]
         self.window = [l[-self.d.lookback:] + [(o - mn) / (mx - mn)] for l, o, mn, mx in zip(self.window, obs, self.lo, self.hi)]
         ix = self.names.index('indoor_dry_bulb_temperature')
         if self.window[0][0] is None:                                   # simulate_dynamics (building.py:2996-2999)

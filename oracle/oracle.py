@@ -410,7 +410,9 @@ class UnitOracle:
         sp = self.spec
         dc = (self.cool_dem_ideal[self.t] - self.cool_dem) / self.cop(sp.cooling_device, False)
         dh = self.heat_dem_ideal[self.t] - self.heat_dem
-        dh = dh / self.cop(sp.heating_device, True) if sp.heating_device.is_heat_pump else np.array(dh) / sp.dhw_device.efficiency
+        # sic (building.py:2893-2898): the heating difference of EVERY step is converted with the heat pump's COP at the outdoor
+        # temperature of the step the series is read at -- the episode's last one when evaluate() runs after the episode
+        dh = dh / sp.heating_device.cop(self.t_out[len(self.t_out) - 1], True) if sp.heating_device.is_heat_pump else np.array(dh) / sp.dhw_device.efficiency
         return self.net_without_storage() + np.sum([dc, dh], axis=0)
 
 

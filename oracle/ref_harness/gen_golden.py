@@ -62,6 +62,12 @@ FIXTURES = {
     'g_evs_noise': ('citylearn_challenge_2022_phase_all_plus_evs', 120, 119, 81, False, {'__noise_std__': [0.05, 5.0]}),
     # autosized batteries: manufacturer model, unit count and the model's efficiency / loss figures from the sizing table
     's_autosize': ('citylearn_challenge_2022_phase_3', 96, 95, 36, False, {'__autosize_batteries__': True}),
+    # SURVEY 8a row A11, heating half (LSTMDynamicsBuilding.update_heating_demand, building.py:3123-3158): no shipped dataset drives a
+    # heating device (the quebec ones need pickled occupant models that are not in the checkout), so the 2023 district is rewritten:
+    # every building gets a heat pump for space heating, a synthetic heating load and an hvac_mode column that cycles through
+    # off / cooling / heating / auto; Building_1 is controlled through `cooling_or_heating_device`, Building_2 through `heating_device`
+    # with its LSTM fed by `heating_demand` instead of `cooling_demand`, Building_3 stays on `cooling_device`
+    'g2023_heat': ('citylearn_challenge_2023_phase_2_local_evaluation', 264, 263, 41, False, {'__heating_synth__': True}),
     's_baeda': ('baeda_3dem', 96, 95, 31, False, {}),
     's_2021': ('citylearn_challenge_2021', 96, 95, 32, False, {}),
     's_2020_cz3': ('citylearn_challenge_2020_climate_zone_3', 96, 95, 33, False, {}),
@@ -88,6 +94,25 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict
             es['attributes'] = {k: v for k, v in (es.get('attributes') or {}).items() if k not in ('capacity', 'nominal_power', 'efficiency')}
         (dst.parent / 'misc').mkdir(parents=True, exist_ok=True)
         shutil.copyfile(src.parent.parent / 'misc' / 'battery_choices.yaml', dst.parent / 'misc' / 'battery_choices.yaml')
+    heating_synth = overrides.pop('__heating_synth__', False)
+    if heating_synth:
+        names = list(schema['buildings'])
+        for k in ('cooling_device', 'heating_device', 'cooling_or_heating_device'):
+            schema['actions'][k] = {'active': True}
+        for k in ('heating_demand',):
+            if k in schema['observations']:
+                schema['observations'][k]['active'] = True
+        off = {0: ['cooling_device', 'heating_device'], 1: ['cooling_device', 'cooling_or_heating_device'], 2: ['heating_device', 'cooling_or_heating_device']}
+        for i, bn in enumerate(names):
+            b = schema['buildings'][bn]
+            b['inactive_actions'] = sorted(set(b.get('inactive_actions') or []) | set(off[i % 3]))
+            cd = b['cooling_device']['attributes']
+            b['heating_device'] = {'type': 'citylearn.energy_model.HeatPump', 'autosize': False,
+                                   'attributes': {'nominal_power': round(cd['nominal_power'] * 0.9, 6), 'efficiency': 0.21 + 0.01 * i,
+                                                  'target_cooling_temperature': 8.0, 'target_heating_temperature': 45.0}}
+            if i % 3 == 1:         # a heating-driven temperature model: same weights, the demand input renamed
+                att = b['dynamics']['attributes']
+                att['input_observation_names'] = ['heating_demand' if n == 'cooling_demand' else n for n in att['input_observation_names']]
     noise = overrides.pop('__noise_std__', None)
     if noise is not None:
         for b in schema['buildings'].values():
@@ -109,8 +134,19 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict
             files.add(c['charger_simulation'])
         for wmach in (b.get('washing_machines') or {}).values():
             files.add(wmach['washing_machine_energy_simulation'])
+    building_files = {b['energy_simulation'].replace('.gz', '') for b in schema['buildings'].values()}
     for fn in sorted(files):
         frame = pd.read_csv(src / fn).iloc[:rows]
+        if heating_synth and fn in building_files:
+            t = np.arange(len(frame))
+            block = (t // 3) % 10
+            mode = np.array([1, 1, 2, 3, 3, 2, 0, 1, 3, 2])[block]                           # every mode, in both orders
+            heating = (mode == 2) | ((mode == 3) & (block % 2 == 0))                         # auto rows: some heat, some cool
+            cool = frame['cooling_demand'].to_numpy().copy()
+            frame['hvac_mode'] = mode
+            # never both in one row (EnergySimulation asserts it, data.py:318-319)
+            frame['heating_demand'] = np.where(heating, (0.35 * cool + 0.2).round(6), 0.0)
+            frame['cooling_demand'] = np.where(heating, 0.0, cool)
         text = frame.to_csv(index=False)
         # the mini dataset must hold the SAME float32 values the full files give: to_csv round-trips doubles exactly
         if gz:
@@ -192,7 +228,7 @@ def run_reference(name: str):
     reset_net = np.array([b.net_electricity_consumption[0] for b in env.buildings], dtype='float32')
     K = steps
     per_b = ['net', 'soc', 'eb', 'eff', 'degcap', 'cs_soc', 'hs_soc', 'ds_soc', 'c_cool', 'c_heat', 'c_dhw', 'c_ns',
-             'c_b', 'cool_dem', 'cost', 'emission', 'e_cool_dev', 'e_dhw_dev', 'e_ns', 'indoor_temp']
+             'c_b', 'cool_dem', 'heat_dem', 'cost', 'emission', 'e_cool_dev', 'e_heat_dev', 'e_dhw_dev', 'e_ns', 'indoor_temp']
     if md.get('reward_function_type', '') or type(env.reward_function).__name__ == 'ComfortReward':
         rfn = env.reward_function
         extra_rewards['ComfortReward'] = rf.ComfortReward(md, band=rfn.band, lower_exponent=rfn.lower_exponent,
@@ -249,6 +285,8 @@ def run_reference(name: str):
             traj['c_ns'][t, i] = b.non_shiftable_load_device.electricity_consumption[t]
             traj['c_b'][t, i] = es.electricity_consumption[t]
             traj['cool_dem'][t, i] = captured['obs'][i]['cooling_demand']
+            traj['heat_dem'][t, i] = captured['obs'][i]['heating_demand']
+            traj['e_heat_dev'][t, i] = b._Building__energy_from_heating_device[t]
             traj['e_cool_dev'][t, i] = b._Building__energy_from_cooling_device[t]
             traj['e_dhw_dev'][t, i] = b._Building__energy_from_dhw_device[t]
             traj['e_ns'][t, i] = b._Building__energy_to_non_shiftable_load[t]

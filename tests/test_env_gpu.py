@@ -19,7 +19,7 @@ def _actions(g, env, t):
     return out
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 'g2023_heat'])
 def test_env_matches_reference_api_and_rewards(name):
     from citylearn_amd.citylearn import CityLearnEnv
     g = golden(name)

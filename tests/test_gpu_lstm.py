@@ -12,7 +12,7 @@ from citylearn_amd.dynamics import LSTMStage
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name', ['g2023_p2', 's_baeda', 's_2023_p1', 's_2023_p3'])
+@pytest.mark.parametrize('name', ['g2023_p2', 's_baeda', 's_2023_p1', 's_2023_p3', 'g2023_heat'])
 def test_lstm_stage_fed_with_reference_cooling(name):
     """Isolates the stage: the delivered cooling of every step comes from the reference; temperatures within 1e-4 C
     relative and ComfortReward within 1e-4 (+1e-4) of the reference for every step and building (2023: LSTM(13 -> 16),
@@ -33,9 +33,11 @@ def test_lstm_stage_fed_with_reference_cooling(name):
     eng = StepEngine(tab, E, detail=True)
     stage = LSTMStage(spec, tab, eng, attrs.get('band'), attrs.get('lower_exponent') or 2.0, attrs.get('higher_exponent') or 2.0)
     cool = torch.from_numpy(g.ref['cool_dem'][:, cols]).cuda()
+    # g2023_heat (synthetic: heating device actions, hvac_mode 0-3, one heating-driven model): the delivered heating plane too
+    heat = torch.from_numpy(g.ref['heat_dem'][:, cols]).cuda() if 'heat_dem' in g.ref.files else None
     worst_t = worst_r = 0.0
     for t in range(g.facts['steps']):
-        temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous())
+        temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous(), None if heat is None else heat[t][:, None].expand(-1, E).contiguous())
         tt, rr = temp.cpu().numpy(), stage.comfort.cpu().numpy()
         assert (tt[:, :1] == tt).all()
         worst_t = max(worst_t, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t][cols]))))
@@ -45,9 +47,11 @@ def test_lstm_stage_fed_with_reference_cooling(name):
     assert worst_r < 1.0, worst_r           # BASELINE.json: reward parity within 1e-4 relative (measured: 0.09)
 
 
-def test_energy_step_plus_lstm_free_running():
-    """Energy step + LSTM stage chained on the GPU with the golden action sequence, free-running."""
-    g = golden('g2023_p2')
+@pytest.mark.parametrize('name', ['g2023_p2', 'g2023_heat'])
+def test_energy_step_plus_lstm_free_running(name):
+    """Energy step + LSTM stage chained on the GPU with the golden action sequence, free-running (g2023_heat: heating device /
+    cooling-or-heating device actions, every hvac mode, a heating-driven temperature model -- building.py:3123-3158)."""
+    g = golden(name)
     spec = g.spec()
     tab = spec.episode_tables(0)
     attrs = spec.reward_function['attributes']
@@ -68,11 +72,14 @@ def test_energy_step_plus_lstm_free_running():
     assert err.max() < 10.0, err.max()
 
 
-def test_env_default_comfort_reward_and_comfort_kpis():
+@pytest.mark.parametrize('name', ['g2023_p2', 'g2023_heat'])
+def test_env_default_comfort_reward_and_comfort_kpis(name):
     """`CityLearnEnv` on the 2023 schema with its default reward (ComfortReward, central agent): rewards and the
-    discomfort / thermal-resilience KPIs of `evaluate()` against the reference, full 719-step episode."""
+    discomfort / thermal-resilience KPIs of `evaluate()` against the reference, full episode.  g2023_heat (heating devices, every
+    hvac mode): every KPI of the table, i.e. also the cost KPIs whose baseline removes the partial-load heating difference
+    (converted with the episode-end COP, building.py:2893-2898)."""
     from citylearn_amd.citylearn import CityLearnEnv
-    g = golden('g2023_p2')
+    g = golden(name)
     env = CityLearnEnv(g.schema_path)
     assert type(env.reward_function).__name__ == 'ComfortReward' and env._fused_comfort and env.central_agent
     K = g.facts['steps']
@@ -88,7 +95,7 @@ def test_env_default_comfort_reward_and_comfort_kpis():
     gref = dict(zip([str(x) for x in g.ref['kpi_names']], g.ref['kpi_values']))
     n = 0
     for k, v in gref.items():
-        if k.split('|')[-1].startswith(('discomfort', 'one_minus_thermal')):
+        if k.split('|')[-1].startswith(('discomfort', 'one_minus_thermal')) or name == 'g2023_heat':
             np.testing.assert_allclose(mine[k], v, rtol=5e-3, atol=2e-3, err_msg=k)
             n += 1
     assert n >= 30

@@ -53,6 +53,8 @@ def _run(name, kind, vec, detail, teach, steps=None, E=64, atol=1e-4, rtol=1e-4,
         pairs['net'] = ob[abi.CLO_NET, :, 0]
         if detail:
             pairs.update({k: ob[pl, :, 0] for k, pl in DETAIL_KEYS})
+            if 'heat_dem' in g.ref.files:            # fixtures generated since round 2 carry the delivered heating too
+                pairs['heat_dem'] = ob[abi.CLO_HEAT_DEM, :, 0]
         for k, v in pairs.items():
             sel = has_battery if k == 'eff' else slice(None)
             if np.size(v[sel]):
@@ -119,7 +121,7 @@ def test_env_major_lean_kernel(kind):
         torch.testing.assert_close(e0.out_bldg[abi.CLO_REWARD], e1.out_bldg[abi.CLO_REWARD], rtol=2e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 'g2023_heat'])
 @pytest.mark.parametrize('kind', REWARDS)
 def test_full_kernel_teacher_forced(name, kind):
     """Heat pump / heater / tanks (2020), outage + partial-load cooling (2023), and the 2022 schema through the
@@ -185,7 +187,7 @@ def test_dataset_sweep_teacher_forced(name):
     assert max(worst.values()) < 1.0, worst
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min'])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 'g2023_heat'])
 def test_free_running_whole_fixture(name):
     worst, _ = _run(name, 'RewardFunction', 1, detail=False, teach=False, atol=1e-3, rtol=1e-3)
     assert max(worst.values()) < 1.0, worst
