@@ -972,12 +972,11 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     return CL_OK;
 }
 
-int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
-                        int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env, const float* act_low,
-                        const float* act_high, uint64_t seed, float* policy_actions, float* out_bldg, float* out_env,
-                        float* ret_env, const cl_flex* flex, int32_t t0, int32_t k_steps, void* stream) {
+int cl_rollout_seq_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+                       int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env, const float* act_low,
+                       const float* act_high, uint64_t seed, float* policy_actions, float* out_bldg, float* out_env,
+                       float* ret_env, float* kpi_bldg, float* kpi_env, const cl_flex* flex, int32_t t0, int32_t k_steps, void* stream) {
     if (int rc = check_dims(dims)) return rc;
-    if (!flex) return fail(CL_ENULL, "flex is NULL");                 // a host struct: no device-alignment demand
     if (int rc = check_ptr(actions, "actions", false)) return rc;
     if (int rc = check_ptr(ret_env, "ret_env", false)) return rc;
     if (!actions && dims->n_act_cols > 0) {
@@ -985,7 +984,6 @@ int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float
         if (int rc = check_ptr(policy_actions, "policy_actions")) return rc;
         if (dims->n_env % 4) return fail(CL_EALIGN, "the on-device policy needs n_env to be a multiple of 4 (got %d)", dims->n_env);
     }
-    if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "CLD_KPI is not implemented for rollouts");
     if (k_steps < 0 || t0 < 0 || t0 + k_steps > dims->n_steps)
         return fail(CL_ERANGE, "steps [%d, %d) outside [0, %d)", t0, t0 + k_steps, dims->n_steps);
     hipStream_t s = (hipStream_t)stream;
@@ -998,19 +996,19 @@ int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float
             hipLaunchKernelGGL(cl_policy_kernel, dim3(gx, (unsigned)dims->n_act_cols), dim3(256), 0, s, policy_actions, act_low, act_high,
                                (unsigned long long)seed, dims->n_env, dims->n_act_cols, t >> 2);
         if (int rc = cl_step_flex_f32(dims, params, ts, state, a, actions ? act_stride_col : (int64_t)dims->n_env,
-                                      actions ? act_stride_env : (int64_t)1, out_bldg, out_env, nullptr, nullptr, flex, t, stream))
+                                      actions ? act_stride_env : (int64_t)1, out_bldg, out_env, kpi_bldg, kpi_env, flex, t, stream))
             return rc;
         if (ret_env)
             hipLaunchKernelGGL(cl_return_kernel, dim3(gx), dim3(256), 0, s, ret_env, out_env + (long long)CLQ_REWARD * dims->n_env, dims->n_env);
     }
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_flex_f32 launch");
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_seq_f32 launch");
     return CL_OK;
 }
 
 int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
                    int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env, const float* act_low,
                    const float* act_high, uint64_t seed, float* out_bldg, float* out_env, float* ret_env,
-                   float* kpi_bldg, float* kpi_env, int32_t t0, int32_t k_steps, void* stream) {
+                   int32_t t0, int32_t k_steps, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     const cl_tuning& tun = tuning_of(dims);
     if (int rc = check_ptr(params, "params")) return rc;
@@ -1024,12 +1022,11 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
         if (!act_low || !act_high) return fail(CL_ENULL, "act_low / act_high are required for the on-device policy");
     }
     if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_EV)
-        return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_rollout_flex_f32)");
-    if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "CLD_KPI is not implemented in this build");
-    (void)kpi_bldg; (void)kpi_env;
+        return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_rollout_seq_f32)");
+    if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "the fused rollout keeps no streaming KPIs: use cl_rollout_seq_f32 with CLD_KPI");
     if (k_steps < 0 || t0 < 0 || t0 + k_steps > dims->n_steps)
         return fail(CL_ERANGE, "steps [%d, %d) outside [0, %d)", t0, t0 + k_steps, dims->n_steps);
-    if (dims->n_bldg > 32) return fail(CL_EINVAL, "cl_rollout_f32 supports n_bldg <= 32 (got %d)", dims->n_bldg);
+    if (dims->n_bldg > 32) return fail(CL_EINVAL, "the fused rollout supports n_bldg <= 32 (got %d): use cl_rollout_seq_f32", dims->n_bldg);
     if (actions && act_stride_env == 1 && ((act_stride_col % 4) != 0 || (act_stride_step % 4) != 0))
         return fail(CL_EALIGN, "action strides must be multiples of 4 floats for the coalesced layout");
 
@@ -1044,7 +1041,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     r.t0 = t0; r.k_steps = k_steps;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
     const int mb = full ? 1 : (dims->n_bldg > 16 ? 2 : 1);
-    if (full && dims->n_bldg > 16) return fail(CL_EINVAL, "cl_rollout_f32 (thermal districts) supports n_bldg <= 16 (got %d)", dims->n_bldg);
+    if (full && dims->n_bldg > 16) return fail(CL_EINVAL, "the fused rollout (thermal districts) supports n_bldg <= 16 (got %d): use cl_rollout_seq_f32", dims->n_bldg);
     a.nw = tun.nw ? tun.nw : (dims->n_bldg + mb - 1) / mb;
     if (a.nw * mb < dims->n_bldg || a.nw > 16) return fail(CL_EINVAL, "bad nw %d", a.nw);
     const int vec = tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && dims->n_env >= 131072) ? 2 : 1);

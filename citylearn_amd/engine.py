@@ -131,7 +131,7 @@ class StepEngine:
         self._step_tail = (_ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env))
         self._flex_ref = None if self.flex is None else ctypes.byref(self.flex)
         self.act_low = self.act_high = None         # bounds of the on-device rollout policy (set_action_limits)
-        self._policy_actions = None                 # scratch planes of cl_rollout_flex_f32 (four steps of policy draws)
+        self._policy_actions = None                 # scratch planes of cl_rollout_seq_f32 (four steps of policy draws)
         self.t = 0
         self.reset()
 
@@ -221,8 +221,9 @@ class StepEngine:
 
     def rollout(self, k_steps: int, actions: Optional[torch.Tensor] = None, seed: int = 0,
                 ret_env: Optional[torch.Tensor] = None, t0: Optional[int] = None):
-        """Fused K-step rollout in one launch (`cl_rollout_f32`): state stays in registers between steps.  Districts with
-        flexible loads run the same K steps as K x (policy, flex, step) launches (`cl_rollout_flex_f32`), same action streams.
+        """Fused K-step rollout in one launch (`cl_rollout_f32`): state stays in registers between steps.  Districts with flexible
+        loads, streaming KPIs (``kpi=True``) or more buildings than the fused kernel holds (32 battery + PV / 16 thermal) run the
+        same K steps as K x (policy, [flex], step, [kpi]) launches (`cl_rollout_seq_f32`), same action streams.
 
         ``actions``: open-loop float32 tensor ``[k_steps, n_act_cols, n_env]`` (any strides), or ``None`` for the
         on-device policy ``a = low + u (high - low)``, ``u = Philox4x32-10(seed; env, column, t)``.
@@ -237,22 +238,23 @@ class StepEngine:
             st = actions.stride()
         elif self.act_low is None:
             raise ValueError('call set_action_limits(low, high) before using the on-device policy')
-        if self.flex is not None:
+        full = not self.lean or bool(self.dims.flags & abi.CLD_WRITE_DETAIL)
+        if self.flex is not None or self.kpi or self.n_bldg > (16 if full else 32):
             if actions is None and self._policy_actions is None:
                 self._policy_actions = torch.empty((4, self.n_act_cols, self.n_env), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
-                _lib.check(self.lib.cl_rollout_flex_f32(
+                _lib.check(self.lib.cl_rollout_seq_f32(
                     ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
                     _ptr(self.act_low), _ptr(self.act_high), int(seed) & (2 ** 64 - 1),
                     _ptr(None if actions is not None else self._policy_actions), _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env),
-                    self._flex_ref, int(t0), int(k_steps), self._stream()))
+                    _ptr(self.kpi_bldg), _ptr(self.kpi_env), self._flex_ref, int(t0), int(k_steps), self._stream()))
             self.t = t0 + k_steps
             return
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cl_rollout_f32(
                 ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
                 _ptr(self.act_low), _ptr(self.act_high), int(seed) & (2 ** 64 - 1),
-                _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env), None, None, int(t0), int(k_steps), self._stream()))
+                _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env), int(t0), int(k_steps), self._stream()))
         self.t = t0 + k_steps
 
     # convenient views ------------------------------------------------------------------------------------

@@ -77,9 +77,18 @@ class VectorCityLearnEnv:
             self._comfort, kind = True, abi.CLR_SOLAR_PENALTY
         elif self._comfort:
             kind = abi.CLR_DEFAULT                      # the energy step still writes net / district sums
-        if kind is None:
-            raise NotImplementedError(f'{rf_cls.__name__} has no fused device epilogue; use reward_function='
-                                      "'citylearn.reward_function.RewardFunction' | MARL | IndependentSACReward | SolarPenaltyReward")
+        # User plugins (the reference's RewardFunction plugin surface, reward_function.py:65-88, for a batch): a class without a
+        # fused epilogue runs after the step kernel through `calculate_batch(planes)`, torch on the device -- see `_reward_planes`
+        self._plugin = None
+        if kind is None and self._combo is None:
+            if not callable(getattr(rf_cls, 'calculate_batch', None)):
+                raise NotImplementedError(
+                    f'{rf_cls.__name__} has neither a fused device epilogue nor a calculate_batch(planes) method: give it one '
+                    "(planes: dict of [n_bldg, n_envs] device tensors keyed by the reference's observation names -> reward [n_bldg, n_envs] "
+                    "or [n_envs]), or use RewardFunction | MARL | IndependentSACReward | SolarPenaltyReward | ComfortReward")
+            self._plugin = rf_cls(self.get_metadata(), **self._rf_attrs)
+            self._plugin.env_metadata = self.get_metadata()            # set after construction too, like the reference (citylearn.py:243)
+            kind = abi.CLR_DEFAULT                                      # the step kernel still writes net / district sums
         self.reward_name = {v: k for k, v in REWARD_KINDS.items()}[kind]
         self.reward_exponent = float((self.spec.reward_function.get('attributes') or {}).get('exponent') or 1.0)
         self._episode = -1
@@ -87,6 +96,62 @@ class VectorCityLearnEnv:
         self.action_low = torch.from_numpy(low).to(self.device)
         self.action_high = torch.from_numpy(high).to(self.device)
         self.reset()
+
+    def get_metadata(self) -> Mapping[str, Any]:
+        """`env_metadata` of the reward function (citylearn.py:243, 897-937): static facts of the district."""
+        sp = self.spec
+        return {
+            'central_agent': self.central_agent, 'shared_observations': list(getattr(sp, 'shared_observations', []) or []),
+            'seconds_per_time_step': sp.seconds_per_time_step, 'random_seed': sp.random_seed, 'n_envs': self.n_envs,
+            'buildings': [{
+                'name': b.name,
+                'cooling_storage': {'capacity': b.cooling_storage.capacity}, 'heating_storage': {'capacity': b.heating_storage.capacity},
+                'dhw_storage': {'capacity': b.dhw_storage.capacity},
+                'electrical_storage': {'capacity': b.electrical_storage.capacity, 'nominal_power': b.electrical_storage.nominal_power},
+                'cooling_device': {'nominal_power': b.cooling_device.nominal_power},
+                'heating_device': {'nominal_power': b.heating_device.nominal_power},
+                'dhw_device': {'nominal_power': b.dhw_device.nominal_power}, 'pv': {'nominal_power': b.pv_nominal_power},
+                'action_metadata': dict(b.action_metadata), 'observation_metadata': dict(b.observation_metadata),
+            } for b in sp.buildings],
+        }
+
+    def _reward_planes(self, t: int) -> Dict[str, torch.Tensor]:
+        """What a batched reward plugin sees of step `t` (just computed): the reference's reward-observation keys
+        (`Building.observations(include_all=True)`, building.py:1336-1481) as device tensors -- env-dependent ones ``[n_bldg, n_envs]``,
+        exogenous ones ``[n_bldg, 1]`` (or ``[n_bldg, n_envs]`` with per-env-block episode windows), broadcastable against each other."""
+        e = self.engine
+        if e.env_row0 is None:
+            row = self._exo[t][:, None, :]                                            # [B, 1, NF]
+        else:
+            block = torch.arange(e.n_env, device=self.device) // abi.CL_ROW0_BLOCK
+            row = self._exo[e.env_row0.long() + t][block].permute(1, 0, 2)            # [B, E, NF]
+        col = lambda c: row[:, :, c]
+        net = e.out_bldg[abi.CLO_NET]
+        planes = {
+            'net_electricity_consumption': net,
+            'net_electricity_consumption_cost': net * col(abi.CLT_PRICE),
+            'net_electricity_consumption_emission': torch.clamp(net * col(abi.CLT_CARBON), min=0.0),
+            'electrical_storage_soc': e.state[abi.CLS_B_SOC], 'cooling_storage_soc': e.state[abi.CLS_CS_SOC],
+            'heating_storage_soc': e.state[abi.CLS_HS_SOC], 'dhw_storage_soc': e.state[abi.CLS_DS_SOC],
+            'electricity_pricing': col(abi.CLT_PRICE), 'carbon_intensity': col(abi.CLT_CARBON),
+            'non_shiftable_load': col(abi.CLT_NSL), 'solar_generation': -col(abi.CLT_SOLAR),
+            'outdoor_dry_bulb_temperature': col(abi.CLT_T_OUT), 'hvac_mode': col(abi.CLT_HVAC_MODE), 'power_outage': col(abi.CLT_OUTAGE),
+        }
+        if e.dims.flags & abi.CLD_WRITE_DETAIL:
+            planes.update({'cooling_demand': e.out_bldg[abi.CLO_COOL_DEM], 'heating_demand': e.out_bldg[abi.CLO_HEAT_DEM],
+                           'dhw_demand': e.out_bldg[abi.CLO_DHW_DEM], 'cooling_electricity_consumption': e.out_bldg[abi.CLO_C_COOL],
+                           'heating_electricity_consumption': e.out_bldg[abi.CLO_C_HEAT], 'dhw_electricity_consumption': e.out_bldg[abi.CLO_C_DHW]})
+        else:
+            planes.update({'cooling_demand': col(abi.CLT_COOL_DEM), 'heating_demand': col(abi.CLT_HEAT_DEM), 'dhw_demand': col(abi.CLT_DHW_DEM)})
+        if self.stage is not None:
+            from .dynamics import PRE_BAND, PRE_CSP, PRE_HSP, PRE_OCC
+            pre = self.stage.dyn_pre
+            prow = pre[t][:, None, :] if e.env_row0 is None else pre[e.env_row0.long() + t][block].permute(1, 0, 2)
+            planes.update({'indoor_dry_bulb_temperature': self.stage.indoor_temp,
+                           'indoor_dry_bulb_temperature_cooling_set_point': prow[:, :, PRE_CSP],
+                           'indoor_dry_bulb_temperature_heating_set_point': prow[:, :, PRE_HSP],
+                           'occupant_count': prow[:, :, PRE_OCC], 'comfort_band': prow[:, :, PRE_BAND]})
+        return planes
 
     @property
     def n_act_cols(self) -> int:
@@ -110,8 +175,22 @@ class VectorCityLearnEnv:
 
     def reset(self, seed: Optional[int] = None) -> Tuple[Dict[str, torch.Tensor], dict]:
         self._episode += 1
+        if self._plugin is not None and callable(getattr(self._plugin, 'reset', None)):
+            self._plugin.reset()                                  # RewardFunction.reset (citylearn.py:1846)
         n_steps, row0 = None, None
         if self.env_episode_offsets is None:
+            window = self.spec.episode_window(self._episode, seed)
+            redrawn = any(b.outage.simulate and b.outage.stochastic and b.outage.random_seed is None for b in self.spec.buildings)
+            if getattr(self, 'engine', None) is not None and (self.tables.start, self.tables.end) == tuple(window) and not redrawn:
+                # same episode window as the last one (the common case: one split, or `episode_time_steps` unset): the packed
+                # tables, device copies and every state / output plane are reused -- only the state is re-initialised
+                if self.engine.flex is not None:
+                    self.engine.flex.seed = ((self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode) & (2 ** 64 - 1)
+                self.engine.reset()
+                if self.stage is not None:
+                    self.stage.reset()
+                self._t = 0
+                return self._obs(), {}
             self.tables = self.spec.episode_tables(self._episode, seed, reward_exponent=self.reward_exponent)
         else:
             sp = self.spec
@@ -153,7 +232,9 @@ class VectorCityLearnEnv:
                 return (np.arange(n_blocks) * stride) % (latest + 1)
             if mode == 'random':
                 s = self.spec.random_seed if seed is None else seed
-                return np.random.RandomState(int(s) * (self._episode + 1) % (2 ** 32)).randint(0, latest + 1, size=n_blocks)
+                # the episode enters the seed additively (a product would make every episode identical for seed 0, the
+                # loader's default when neither the schema nor the caller gives one)
+                return np.random.RandomState(np.random.SeedSequence([int(s) & 0xFFFFFFFF, self._episode]).generate_state(1)[0]).randint(0, latest + 1, size=n_blocks)
             raise ValueError("env_episode_offsets must be None, 'rolling', 'random' or an array")
         row0 = np.asarray(mode, dtype=np.int64).reshape(-1)
         if row0.shape[0] != n_blocks:
@@ -195,7 +276,15 @@ class VectorCityLearnEnv:
         if self.stage is not None:
             self.stage.step(self._t)                    # indoor temperature (+ ComfortReward) of this step
         self._t += 1
-        if self._combo is not None:
+        if self._plugin is not None:
+            r = self._plugin.calculate_batch(self._reward_planes(self._t - 1))
+            if r.dim() == 2 and r.shape[0] == e.n_bldg:
+                reward = (r.expand(e.n_bldg, e.n_env).sum(dim=0) if self.central_agent else r.expand(e.n_bldg, e.n_env))
+            elif r.dim() == 1 and r.shape[0] == e.n_env:
+                reward = r
+            else:
+                raise ValueError(f'calculate_batch returned shape {tuple(r.shape)}; expected [n_bldg, n_envs] (or broadcastable) or [n_envs]')
+        elif self._combo is not None:
             # float32 like the reference's np.array(..., dtype='float32') (reward_function.py:383-386)
             r = self._combo[0] * e.reward_bldg + self._combo[1] * self.stage.comfort
             reward = r.sum(dim=0) if self.central_agent else r
@@ -209,10 +298,10 @@ class VectorCityLearnEnv:
         """Advance ``k_steps`` steps without returning to Python in between (`StepEngine.rollout`: one fused launch, or a launch
         sequence for districts with flexible loads) with open-loop ``actions`` ``[k_steps, n_act_cols, n_envs]`` or the uniform
         random policy keyed by ``seed`` (the device analogue of `Agent.predict`, agents/base.py:188-209).  Returns the district
-        reward summed over those steps, ``[n_envs]``.  Not available with the LSTM temperature stage or streaming KPIs, which
-        need their own kernels between steps -- use :meth:`step` there."""
-        if self.stage is not None or self.engine.kpi:
-            raise NotImplementedError('rollout() needs a district without the LSTM temperature stage and kpi=False; use step()')
+        reward summed over those steps, ``[n_envs]``.  Streaming KPIs (``kpi=True``) are updated after every step.  Not available with
+        the LSTM temperature stage or a batched reward plugin, which run their own code between steps -- use :meth:`step` there."""
+        if self.stage is not None or self._plugin is not None:
+            raise NotImplementedError('rollout() needs a district without the LSTM temperature stage and a fused reward; use step()')
         if self._t + k_steps > self.time_steps - 1:
             raise RuntimeError(f'{k_steps} steps from t={self._t} run past the episode end ({self.time_steps - 1} steps)')
         e = self.engine

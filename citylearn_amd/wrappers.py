@@ -60,10 +60,13 @@ class NormalizedObservationWrapper:
         base = self.env.unwrapped
         tabs = self._tables()
         t = base.time_step
-        if t == 0 or base.observation_mode == 'reference':
+        # same rule as CityLearnEnv._observation_vector: the table row is complete only when no column depends on the env (the
+        # charging headroom / violation columns do in every mode: they are attributes the last apply_actions overwrote, not series)
+        if t == 0 or (base.observation_mode == 'reference' and tabs.n_dependent == 0):
             v = tabs.table[t]
         else:
-            v = tabs.host_row(t, base._last_state, base._last_out, base._last_temps)
+            extra = None if base._engine.flex is None else base._engine.flex_out[:, :, 0].cpu().numpy()
+            v = tabs.host_row(t, base._last_state, base._last_out, base._last_temps, extra)
         return [v[s].tolist() for s in self._layout.agent_slices]
 
     def reset(self, **kwargs):

@@ -295,12 +295,13 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
  * actions != NULL: open-loop action tensor, element (k, col, env) at
  * actions[k*act_stride_step + col*act_stride_col + env*act_stride_env].
  * `ret_env` [n_env] (optional) accumulates the district reward sum over the k steps (episode return);
- * out_bldg / out_env receive the values of the LAST step. */
+ * out_bldg / out_env receive the values of the LAST step.
+ * Limits of the fused kernel: battery + PV districts of up to 32 buildings, thermal / outage districts of up to 16, no streaming
+ * KPIs (CLD_KPI), no flexible loads -- cl_rollout_seq_f32 below runs the same K steps as a launch sequence for everything else. */
 int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
                    const float* actions, int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env,
                    const float* act_low, const float* act_high, uint64_t seed,
-                   float* out_bldg, float* out_env, float* ret_env, float* kpi_bldg, float* kpi_env,
-                   int32_t t0, int32_t k_steps, void* stream);
+                   float* out_bldg, float* out_env, float* ret_env, int32_t t0, int32_t k_steps, void* stream);
 
 /* ---- adjacent stage: LSTM indoor-temperature dynamics of LSTMDynamicsBuilding (building.py:3000-3078, dynamics.py) ----
  * lstm_w  [n_bldg][CL_LSTM_NW]            packed LSTM(13->16, 2 layers) + Linear(16->1) weights per building
@@ -503,18 +504,20 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
                      float* out_bldg, float* out_env, float* kpi_bldg, float* kpi_env, const cl_flex* flex,
                      int32_t t, void* stream);
 
-/* cl_rollout_f32 for a district with flexible loads: charger / EV / washing-machine state lives in HBM between steps, so
- * the K steps are K x (policy, flex, step, return) launches enqueued on `stream` (capturable in a hipGraph) rather than
- * one fused kernel.  Same action sources as cl_rollout_f32: open-loop `actions` [k_steps][n_act_cols][n_env] (strides in
- * floats) or, with actions == NULL, the on-device policy a = low + u (high - low), u = cl_philox_uniform(seed, env,
- * column, t), generated four steps at a time into the scratch planes `policy_actions` [4][n_act_cols][n_env] (required then;
- * n_env a multiple of 4).
- * `ret_env` [n_env] (optional) accumulates the district reward; out_bldg / out_env hold the LAST step's values. */
-int cl_rollout_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
-                        const float* actions, int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env,
-                        const float* act_low, const float* act_high, uint64_t seed, float* policy_actions,
-                        float* out_bldg, float* out_env, float* ret_env, const cl_flex* flex,
-                        int32_t t0, int32_t k_steps, void* stream);
+/* The same K steps as cl_rollout_f32 for everything the fused kernel does not hold in registers: districts with flexible loads
+ * (`flex`: charger / EV / washing-machine state lives in HBM between steps), streaming KPIs (CLD_KPI: `kpi_bldg` / `kpi_env`
+ * updated after every step, exactly as K calls of cl_step_f32 would), districts of any size (building-chunked launches).  The K
+ * steps are K x (policy, [flex], step, [kpi], return) launches enqueued on `stream` (capturable in a hipGraph).  Same action
+ * sources as cl_rollout_f32: open-loop `actions` [k_steps][n_act_cols][n_env] (strides in floats) or, with actions == NULL, the
+ * on-device policy a = low + u (high - low), u = cl_philox_uniform(seed, env, column, t), generated four steps at a time into the
+ * scratch planes `policy_actions` [4][n_act_cols][n_env] (required then; n_env a multiple of 4).
+ * `flex`, `kpi_bldg`, `kpi_env` are nullable; `ret_env` [n_env] (optional) accumulates the district reward; out_bldg / out_env
+ * hold the LAST step's values. */
+int cl_rollout_seq_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
+                       const float* actions, int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env,
+                       const float* act_low, const float* act_high, uint64_t seed, float* policy_actions,
+                       float* out_bldg, float* out_env, float* ret_env, float* kpi_bldg, float* kpi_env, const cl_flex* flex,
+                       int32_t t0, int32_t k_steps, void* stream);
 
 /* Philox4x32-10 reference draw used by cl_rollout_f32 (host-callable so tests can reproduce the policy):
  * returns u in [0,1) for (seed, env, col, t). */

@@ -66,7 +66,7 @@ def main():
             out[f'flex{fv}/{reward}'] = round(timed(eng, a), 2)
         eng.tuning.flex_vec = 0
         out[f'graph/{reward}'] = round(timed_graph(eng, a), 2)
-    # K-step rollout with the on-device policy (cl_rollout_flex_f32: policy plane + flex + step + return per step), one graph
+    # K-step rollout with the on-device policy (cl_rollout_seq_f32: policy plane + flex + step + return per step), one graph
     eng = StepEngine(tab, E, reward='MARL')
     low, high = spec.action_limits()
     eng.set_action_limits(low, high)

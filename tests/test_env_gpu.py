@@ -235,3 +235,66 @@ def test_evaluate_under_non_default_conditions(name):
     if name == 'g2022_all':
         with pytest.raises(AttributeError):                      # partial-load series only exist on dynamics buildings
             env.evaluate(baseline_condition=EC.WITHOUT_STORAGE_AND_PARTIAL_LOAD_BUT_WITH_PV)
+
+
+def test_batched_reward_plugin_on_the_vector_env():
+    """The reference's RewardFunction plugin surface (reward_function.py:65-88) for a batch: a user class without a fused epilogue
+    runs after the step kernel through `calculate_batch(planes)` on device tensors.  The class below is the logic of the
+    reference's examples/custom_reward_function.py (negative net_electricity_consumption_emission; one district value under a
+    central agent); expected values from the reference trajectory's own emission series."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    from citylearn_amd.reward_function import RewardFunction
+
+    class CustomReward(RewardFunction):
+        device_kind = None
+        resets = 0
+
+        def reset(self):
+            CustomReward.resets += 1
+
+        def calculate_batch(self, planes):
+            e = planes['net_electricity_consumption_emission']
+            return -e.sum(dim=0) if self.central_agent else -e
+
+    g = golden('g2022_all')
+    E = 260
+    for central in (False, True):
+        env = VectorCityLearnEnv(g.schema_path, n_envs=E, reward_function=CustomReward, central_agent=central)
+        assert env._plugin is not None and env._plugin.env_metadata['central_agent'] == central
+        acts = torch.from_numpy(g.ref['actions']).cuda()
+        for t in range(40):
+            _, reward, *_ = env.step(acts[t][:, None].expand(-1, E).contiguous())
+            want = -g.ref['emission'][t].astype(np.float64)
+            got = reward.cpu().numpy()
+            if central:
+                assert got.shape == (E,)
+                np.testing.assert_allclose(got, np.full(E, want.sum()), rtol=1e-4, atol=1e-4)
+            else:
+                assert got.shape == (17, E)
+                np.testing.assert_allclose(got, np.repeat(want[:, None], E, axis=1), rtol=1e-4, atol=1e-5)
+        n = CustomReward.resets
+        env.reset()
+        assert CustomReward.resets == n + 1 and env.time_step == 0
+    # a class with neither a fused epilogue nor calculate_batch is refused with a message that names the hook
+    class Bare(RewardFunction):
+        device_kind = None
+    with pytest.raises(NotImplementedError, match='calculate_batch'):
+        VectorCityLearnEnv(g.schema_path, n_envs=64, reward_function=Bare)
+
+
+def test_vector_env_reset_reuses_the_engine():
+    """Same episode window -> `reset()` keeps the engine (tables, planes) and only re-initialises the state; the second episode
+    reproduces the first one bit for bit."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden('g2022_all')
+    env = VectorCityLearnEnv(g.schema_path, n_envs=128)
+    acts = torch.from_numpy(g.ref['actions']).cuda()
+    eng = env.engine
+    runs = []
+    for _ in range(2):
+        for t in range(25):
+            env.step(acts[t][:, None].expand(-1, 128).contiguous())
+        runs.append((env.engine.state.clone(), env.engine.out_bldg[:2].clone()))
+        env.reset()
+        assert env.engine is eng and env.time_step == 0
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])

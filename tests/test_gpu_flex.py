@@ -146,11 +146,20 @@ def test_env_on_the_ev_dataset_matches_the_reference(name):
     obs, _ = env.reset()
     ref_obs = g.obs['obs']
     np.testing.assert_allclose(np.concatenate(obs), ref_obs[0], rtol=1e-6, atol=1e-6)
+    # the NormalizedObservationWrapper view of the same env (charging headroom / violation columns come from the flexible-load
+    # planes in every observation mode: the g_cc_demo case)
+    from citylearn_amd.wrappers import NormalizedObservationWrapper
+    wrapped = NormalizedObservationWrapper(env)
+    assert wrapped.observation_names == g.obs_facts['norm_observation_names']
+    np.testing.assert_allclose(np.concatenate(wrapped.observation()), g.obs['obs_norm'][0], rtol=1e-6, atol=1e-6)
     K = g.ref['actions'].shape[0]
     flips = 0
     for t in range(K):
         obs, reward, terminated, _, _ = env.step(_acts(g, env, t))
         np.testing.assert_allclose(np.concatenate(obs), ref_obs[t + 1], rtol=1e-6, atol=1e-6 if name == 'g2022_evs' else 5e-4, err_msg=f'obs t={t}')
+        if t < 60:
+            np.testing.assert_allclose(np.concatenate(wrapped.observation()), g.obs['obs_norm'][t + 1], rtol=1e-5, atol=1e-5 if name == 'g2022_evs' else 5e-4,
+                                       err_msg=f'normalised obs t={t}')
         bad = np.abs(np.array(reward) - g.ref['env_rewards'][t]) > 5e-4 + 5e-4 * np.abs(g.ref['env_rewards'][t])
         flips += int(bad.sum())
     assert terminated and flips <= 3, flips
@@ -297,10 +306,9 @@ def test_flex_entry_points_validate_their_arguments():
                          ev.out_bldg.data_ptr(), ev.out_env.data_ptr(), None, None, 0, None)
     assert rc == abi.CL_EINVAL and b'CLR_EV' in lib.cl_last_error()
     # the K-step launch sequence: same range / pointer checks as cl_rollout_f32
-    roll = lambda flex, actions, low, scratch, t0, k: lib.cl_rollout_flex_f32(
+    roll = lambda flex, actions, low, scratch, t0, k: lib.cl_rollout_seq_f32(
         ctypes.byref(eng.dims), eng.params.data_ptr(), eng.ts.data_ptr(), eng.state.data_ptr(), actions, 0, a.stride(0), a.stride(1), low, low, 0,
-        scratch, eng.out_bldg.data_ptr(), eng.out_env.data_ptr(), None, flex, t0, k, None)
-    assert roll(None, a.data_ptr(), None, None, 0, 1) == abi.CL_ENULL and b'flex' in lib.cl_last_error()
+        scratch, eng.out_bldg.data_ptr(), eng.out_env.data_ptr(), None, None, None, flex, t0, k, None)
     assert roll(ctypes.byref(good), a.data_ptr(), None, None, eng.n_steps - 1, 2) == abi.CL_ERANGE
     assert roll(ctypes.byref(good), None, None, None, 0, 1) == abi.CL_ENULL and b'act_low' in lib.cl_last_error()
     lim = torch.zeros(eng.n_act_cols, device='cuda')
@@ -381,7 +389,7 @@ def test_observation_tensor_with_episode_offsets_on_the_ev_district():
 
 @pytest.mark.parametrize('reward', ['MARL', 'Electric_Vehicles_Reward_Function'])
 def test_flex_rollout_equals_single_steps(reward):
-    """`StepEngine.rollout` on a district with flexible loads (`cl_rollout_flex_f32`): the K-step launch sequence leaves the
+    """`StepEngine.rollout` on a district with flexible loads (`cl_rollout_seq_f32`): the K-step launch sequence leaves the
     same building / EV / washing-machine state, last-step outputs and episode return as K `step()` calls, for open-loop
     actions and for the on-device Philox policy (host-side restatement of the same stream)."""
     from citylearn_amd.engine import StepEngine
@@ -420,7 +428,7 @@ def test_flex_rollout_equals_single_steps(reward):
 
 
 def test_flex_rollout_replays_from_a_hip_graph():
-    """`cl_rollout_flex_f32` only enqueues kernels on the caller's stream, so a whole K-step rollout of an EV district can be
+    """`cl_rollout_seq_f32` only enqueues kernels on the caller's stream, so a whole K-step rollout of an EV district can be
     captured once and replayed: same state as the eager call."""
     from citylearn_amd.engine import StepEngine
     g = golden('g2022_evs')

@@ -119,7 +119,7 @@ def _actions(g, env, t):
     return out
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 's_2021', 's_2023_p3'])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2023_heat', 'g2020_15min', 's_2021', 's_2023_p3'])
 def test_env_returns_the_reference_observations(name):
     """reset()/step() observations, observation_space and the NormalizedObservationWrapper view of `CityLearnEnv`
     equal what the reference returned for the same schema and actions (reference semantics)."""

@@ -111,3 +111,44 @@ def test_vector_env_rollout_matches_stepping(name):
     torch.testing.assert_close(rb, ra, rtol=1e-4, atol=1e-3)
     with pytest.raises(RuntimeError, match='past the episode end'):
         b.rollout(b.time_steps)
+
+
+@pytest.mark.parametrize('name,kind,B', [('g2022_all', 'MARL', 0), ('g2020_cz1', 'RewardFunction', 0), ('g2022_all', 'RewardFunction', 100),
+                                         ('g2020_cz1', 'SolarPenaltyReward', 48)])
+def test_rollout_with_streaming_kpis_and_large_districts(name, kind, B):
+    """What the fused kernel does not hold in registers runs as the launch sequence `cl_rollout_seq_f32`: streaming KPI accumulators
+    (CLD_KPI) and districts beyond 32 / 16 buildings (building-chunked launches).  K steps of it equal K calls of `cl_step_f32`
+    bit for bit -- state, last outputs, episode return and every KPI accumulator -- with the on-device Philox policy replayed on
+    the host for the stepping engine."""
+    from citylearn_amd.synthetic import tile_district
+    spec = golden(name).spec()
+    if B:
+        spec = tile_district(spec, B)
+    tab = spec.episode_tables(0)
+    E, K, seed = 192, 30, 9
+    kpi = B == 0
+    a, b = StepEngine(tab, E, reward=kind, kpi=kpi), StepEngine(tab, E, reward=kind, kpi=kpi)
+    low, high = spec.action_limits()
+    lib = _lib.load()
+    cols = len(low)
+    u = np.array([[[lib.cl_philox_uniform(seed, e, c, t) for e in range(E)] for c in range(cols)] for t in range(K)], dtype=np.float32) if cols * E * K < 400000 else None
+    b.set_action_limits(low, high)
+    ret = torch.zeros(E, device='cuda')
+    if u is not None:
+        acts = torch.from_numpy((low[None, :, None] + u * (high - low)[None, :, None]).astype(np.float32)).cuda()
+        b.rollout(K, seed=seed, ret_env=ret)
+    else:                                                       # large districts: open-loop actions on both sides
+        gen = torch.Generator(device='cuda').manual_seed(seed)
+        lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+        acts = lo[None, :, None] + torch.rand((K, cols, E), device='cuda', generator=gen) * (hi - lo)[None, :, None]
+        b.rollout(K, actions=acts, ret_env=ret)
+    ret_ref = torch.zeros(E, device='cuda')
+    for k in range(K):
+        a.step(acts[k])
+        ret_ref += a.district_reward
+    assert torch.equal(b.state, a.state) and torch.equal(b.out_bldg, a.out_bldg) and torch.equal(b.out_env, a.out_env)
+    torch.testing.assert_close(ret, ret_ref, rtol=1e-6, atol=1e-4)
+    if kpi:
+        assert torch.equal(b.kpi_bldg, a.kpi_bldg) and torch.equal(b.kpi_env, a.kpi_env)
+        assert float(b.kpi_bldg.abs().sum()) > 0
+    assert b.t == a.t == K

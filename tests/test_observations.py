@@ -7,7 +7,7 @@ import pytest
 from citylearn_amd.observations import ObservationLayout
 from golden_util import golden
 
-FIX = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 's_baeda', 's_2021', 's_2020_cz3', 's_2023_p1', 's_2023_p3')
+FIX = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2023_heat', 'g2020_15min', 's_baeda', 's_2021', 's_2020_cz3', 's_2023_p1', 's_2023_p3')
 
 
 def _flat(ll):
