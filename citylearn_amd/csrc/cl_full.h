@@ -87,7 +87,7 @@ CL_DEV void load_batt_f(cl::BattP& B, const uint32_t* __restrict__ q, float r) {
 
 template <typename F> struct St { F soc, eff, degcap, cs, hs, ds; };                     // carried state of the lane's env(s)
 template <typename F> struct Ac { F cs, hs, ds, es, cd, hd; };                            // actions (inactive -> 0)
-template <typename F> struct Ou { F net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served, net_ws; };
+template <typename F> struct Ou { F net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served, net_ws, se_cool, se_heat, se_dhw; };
 template <typename F> struct Ax { F c_cool, c_heat, c_dhw, c_ns, c_b; };                  // running electricity_consumption[t]
 
 // building.py:640-668 during an outage: max(0, |solar| - consumption so far)
@@ -261,6 +261,7 @@ CL_DEV void unit_step(const FP& B, const cl::Row& R, int t, bool first, const Ac
         O.c_cool = A.c_cool * B.r; O.c_heat = A.c_heat * B.r; O.c_dhw = A.c_dhw * B.r; O.c_ns = A.c_ns * B.r;
         // evaluate()'s baseline: remove what the storages did (building.py:345-366, 413-463) and, for dynamics
         // buildings, add back the ideal-vs-delivered load difference (building.py:2877-2905)
+        O.se_cool = eb_cs * R.icop_c; O.se_heat = eb_hs * R.icop_h; O.se_dhw = eb_ds * R.icop_d;      // *_storage_electricity_consumption (building.py:413-457)
         F base = net - vfma(A.c_b, splat<F>(B.r), vfma(eb_ds, splat<F>(R.icop_d), vfma(eb_hs, splat<F>(R.icop_h), eb_cs * R.icop_c)));
         O.net_ws = base;
         // (sic, building.py:2893-2898: the heating difference of every step is converted with ONE COP, the episode's last row's)
@@ -464,6 +465,9 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
                 full_store<VEC>(a.out_bldg + CLO_EXPECTED * plane + off, O.expected);
                 full_store<VEC>(a.out_bldg + CLO_SERVED * plane + off, O.served);
                 full_store<VEC>(a.out_bldg + CLO_NET_WS * plane + off, O.net_ws);
+                full_store<VEC>(a.out_bldg + CLO_SE_COOL * plane + off, O.se_cool);
+                full_store<VEC>(a.out_bldg + CLO_SE_HEAT * plane + off, O.se_heat);
+                full_store<VEC>(a.out_bldg + CLO_SE_DHW * plane + off, O.se_dhw);
             }
             full_accumulate<VEC>(q_net, O.net); full_accumulate<VEC>(q_cost, O.cost); full_accumulate<VEC>(q_em, O.emission);
             // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)

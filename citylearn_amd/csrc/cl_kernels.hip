@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                     load_action<VEC>(a_hd, a, B.a_hd, env0);
                 }
             }
-            float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_hd[VEC], o_dd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC], o_ws[VEC];
+            float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_hd[VEC], o_dd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC], o_ws[VEC], o_sc[VEC], o_sh[VEC], o_sd[VEC];
             // chargers / washing machines of this building, advanced by cl_flex_kernel just before this launch
             const int fbi = (FLEX && (B.flags & CLF_FLEX)) ? (int)B.p[CLP_FLEX_INDEX] : -1;
             float x_load[VEC], x_chg[VEC];
@@ -290,6 +290,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem; o_hd[i] = O.heat_dem; o_dd[i] = O.dhw_dem;
                 o_cc[i] = O.c_cool; o_ch[i] = O.c_heat; o_cw[i] = O.c_dhw; o_cn[i] = O.c_ns;
                 o_bn[i] = O.base_net; o_ex[i] = O.expected; o_sv[i] = O.served; o_ws[i] = O.net_ws;
+                o_sc[i] = O.se_cool; o_sh[i] = O.se_heat; o_sd[i] = O.se_dhw;
                 // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)
                 q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
                 q_rw[i] += (marl_partial || (FLEX && rkind == CLR_EV)) ? cl::marl_reward(O.net, 1.0f) : rw;
@@ -319,6 +320,9 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 vstore<VEC>(a.out_bldg + CLO_EXPECTED * plane + off, o_ex);
                 vstore<VEC>(a.out_bldg + CLO_SERVED * plane + off, o_sv);
                 vstore<VEC>(a.out_bldg + CLO_NET_WS * plane + off, o_ws);
+                vstore<VEC>(a.out_bldg + CLO_SE_COOL * plane + off, o_sc);
+                vstore<VEC>(a.out_bldg + CLO_SE_HEAT * plane + off, o_sh);
+                vstore<VEC>(a.out_bldg + CLO_SE_DHW * plane + off, o_sd);
             }
         }
     }

@@ -209,6 +209,8 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
                     CL_PUT(a.out_bldg, CLO_BASE_NET, last[m][i].base_net) CL_PUT(a.out_bldg, CLO_EXPECTED, last[m][i].expected)
                     CL_PUT(a.out_bldg, CLO_SERVED, last[m][i].served) CL_PUT(a.out_bldg, CLO_NET_WS, last[m][i].net_ws)
                     CL_PUT(a.out_bldg, CLO_HEAT_DEM, last[m][i].heat_dem) CL_PUT(a.out_bldg, CLO_DHW_DEM, last[m][i].dhw_dem)
+                    CL_PUT(a.out_bldg, CLO_SE_COOL, last[m][i].se_cool) CL_PUT(a.out_bldg, CLO_SE_HEAT, last[m][i].se_heat)
+                    CL_PUT(a.out_bldg, CLO_SE_DHW, last[m][i].se_dhw)
                 }
             }
 #undef CL_PUT

@@ -155,7 +155,7 @@ struct State { float soc, eff, degcap, cs, hs, ds; };
 // Actions of one unit (inactive -> 0 for storages / ignored for devices, building.py:1557-1564).
 struct Act { float cs, hs, ds, es, cd, hd; };
 // Per-unit results of the step.
-struct Out { float net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served, net_ws; };
+struct Out { float net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served, net_ws, se_cool, se_heat, se_dhw; };
 // Running electricity_consumption[t] of the five electric devices.
 struct Acc { float c_cool, c_heat, c_dhw, c_ns, c_b; };
 
@@ -271,6 +271,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         O.net = net; O.cost = net * R.price; O.emission = fmaxf(0.0f, net * R.carbon);
         O.eb = eb; O.cool_dem = 0.0f; O.heat_dem = 0.0f; O.dhw_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns * B.r;
         O.base_net = net - c_b * B.r; O.net_ws = O.base_net; O.expected = R.nsl; O.served = R.nsl;
+        O.se_cool = O.se_heat = O.se_dhw = 0.0f;
         return;
     } else {
         Acc A = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -344,6 +345,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         O.c_cool = A.c_cool * B.r; O.c_heat = A.c_heat * B.r; O.c_dhw = A.c_dhw * B.r; O.c_ns = A.c_ns * B.r;
         // evaluate()'s baseline: remove what the storages did (building.py:345-366, 413-463) and, for dynamics
         // buildings, add back the ideal-vs-delivered load difference (building.py:2877-2905)
+        O.se_cool = eb_cs * R.icop_c; O.se_heat = eb_hs * R.icop_h; O.se_dhw = eb_ds * R.icop_d;      // building.py:413-457
         float base = net - (eb_cs * R.icop_c + eb_hs * R.icop_h + eb_ds * R.icop_d + A.c_b * B.r);
         O.net_ws = base;
         // (the heating difference of every step is converted with ONE COP, that of the step evaluate() is called at: building.py:2893-2898)

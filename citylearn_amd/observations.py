@@ -51,11 +51,13 @@ _DEVICE_SOURCE = {
     'cooling_electricity_consumption': (SRC_OUT, abi.CLO_C_COOL), 'heating_electricity_consumption': (SRC_OUT, abi.CLO_C_HEAT),
     'dhw_electricity_consumption': (SRC_OUT, abi.CLO_C_DHW), 'electrical_storage_electricity_consumption': (SRC_OUT, abi.CLO_B_EB),
     'cooling_demand': (SRC_OUT, abi.CLO_COOL_DEM), 'heating_demand': (SRC_OUT, abi.CLO_HEAT_DEM), 'dhw_demand': (SRC_OUT, abi.CLO_DHW_DEM),
+    'cooling_storage_electricity_consumption': (SRC_OUT, abi.CLO_SE_COOL), 'heating_storage_electricity_consumption': (SRC_OUT, abi.CLO_SE_HEAT),
+    'dhw_storage_electricity_consumption': (SRC_OUT, abi.CLO_SE_DHW),
 }
 # planes only written with CLD_WRITE_DETAIL
-_DETAIL_PLANES = {abi.CLO_C_COOL, abi.CLO_C_HEAT, abi.CLO_C_DHW, abi.CLO_B_EB, abi.CLO_COOL_DEM, abi.CLO_HEAT_DEM, abi.CLO_DHW_DEM}
-_NO_DEVICE_PLANE = ('cooling_storage_electricity_consumption', 'heating_storage_electricity_consumption',
-                    'dhw_storage_electricity_consumption', 'washing_machine_electricity_consumption')
+_DETAIL_PLANES = {abi.CLO_C_COOL, abi.CLO_C_HEAT, abi.CLO_C_DHW, abi.CLO_B_EB, abi.CLO_COOL_DEM, abi.CLO_HEAT_DEM, abi.CLO_DHW_DEM,
+                  abi.CLO_SE_COOL, abi.CLO_SE_HEAT, abi.CLO_SE_DHW}
+_NO_DEVICE_PLANE = ('washing_machine_electricity_consumption',)      # the flexible-load planes carry chargers + washing machines together
 ENV_DEPENDENT = set(_DEVICE_SOURCE) | set(_NO_DEVICE_PLANE)
 
 

@@ -53,7 +53,7 @@ extern "C" {
 #define CL_NP  192   /* words per building in `params` */
 #define CL_NF   16   /* floats per (t, building) row in `ts` */
 #define CL_NS    6   /* state planes */
-#define CL_NO   15   /* per-building output planes */
+#define CL_NO   18   /* per-building output planes */
 #define CL_NQ    4   /* per-env (district) output planes */
 #define CL_NKB  12   /* per-building KPI accumulator planes */
 #define CL_NKE  24   /* per-env KPI accumulator planes */
@@ -182,7 +182,9 @@ enum cl_out {
     CLO_NET_WS,       /* net_electricity_consumption_without_storage (building.py:345-366): equals CLO_BASE_NET except for dynamics
                          buildings, whose default baseline also removes the partial-load difference (evaluate()'s
                          EvaluationCondition variants, citylearn.py:29-50) */
-    CLO_RESERVED
+    CLO_SE_COOL, CLO_SE_HEAT, CLO_SE_DHW,   /* cooling / heating / dhw _storage_electricity_consumption[t]: the tank's energy balance through the
+                         device's COP or efficiency (building.py:413-457); detail planes */
+    CLO_RESERVED      /* scratch of building-chunked launches (per-chunk district partial sums); keep last */
 };
 
 /* ---- district outputs (`out_env[plane][env]`) ---- */

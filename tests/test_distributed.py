@@ -51,3 +51,61 @@ def test_two_rank_gloo_sharding_and_timing():
     assert res[0][1:3] == (0, 500) and res[1][1:3] == (500, 1000)
     assert all(r[3] == 1.0 and r[4] == 1.0 for r in res)                    # disjoint and complete
     assert all(abs(r[5] - 1.5) < 1e-9 for r in res)                         # MAX over ranks
+
+
+def _oracle_worker(rank, world, port, q):
+    """Each rank steps ITS env shard of one district with the CPU oracle (the GPU engine's stand-in on a box without GPUs: same
+    table packer, same action layout, same per-env independence) and ships its planes back; rank ranges come from shard_envs."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, str(ROOT / 'tests'))
+    import numpy as np
+    from golden_util import golden
+    from oracle.c_oracle import COracle, OO, OS
+    g = golden('g2022_all')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E_total, K = 40, 12
+    lo, hi = shard_envs(E_total, rank, world)
+    acts = np.random.RandomState(3).uniform(-1, 1, size=(K, 17, E_total)).astype(np.float32)       # same global actions on every rank
+    ora = COracle(spec, tab, hi - lo, reward='MARL')
+    for t in range(K):
+        out, out_env = ora.step(np.ascontiguousarray(acts[t][:, lo:hi]), t)
+    mine = torch.zeros((3, 17, E_total), dtype=torch.float64)
+    mine[0, :, lo:hi] = torch.from_numpy(ora.state[:, :, OS['SOC']].T.copy())
+    mine[1, :, lo:hi] = torch.from_numpy(out[:, :, OO['NET']].T.copy())
+    mine[2, :, lo:hi] = torch.from_numpy(out[:, :, OO['REWARD']].T.copy())
+    dist.all_reduce(mine)                                                  # test-only gather: shards are disjoint, so the sum tiles them
+    if rank == 0:
+        q.put(mine.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_real_shards_tile_the_unsharded_district():
+    """The multi-GPU decomposition on real work: two ranks step two `shard_envs` shards of a 40-env 2022 district for 12 steps (MARL
+    reward: the only coupling is INSIDE an env, across its buildings) and together reproduce, bit for bit, the unsharded run --
+    no value ever crosses a shard boundary, which is why the step path needs no collective."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / 'tests'))
+    from golden_util import golden
+    from oracle.c_oracle import COracle, OO, OS
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_oracle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    tiled = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    g = golden('g2022_all')
+    spec = g.spec()
+    E_total, K = 40, 12
+    acts = np.random.RandomState(3).uniform(-1, 1, size=(K, 17, E_total)).astype(np.float32)
+    ora = COracle(spec, spec.episode_tables(0), E_total, reward='MARL')
+    for t in range(K):
+        out, _ = ora.step(acts[t], t)
+    assert np.array_equal(tiled[0], ora.state[:, :, OS['SOC']].T)
+    assert np.array_equal(tiled[1], out[:, :, OO['NET']].T) and np.array_equal(tiled[2], out[:, :, OO['REWARD']].T)

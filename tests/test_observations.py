@@ -75,6 +75,7 @@ def test_current_mode_device_map_reproduces_the_reference_series(name, normalize
         out[abi.CLO_NET], out[abi.CLO_B_EB] = r['net'][t], r['c_b'][t]
         out[abi.CLO_C_COOL], out[abi.CLO_C_HEAT], out[abi.CLO_C_DHW] = r['c_cool'][t], r['c_heat'][t], r['c_dhw'][t]
         out[abi.CLO_COOL_DEM], out[abi.CLO_HEAT_DEM], out[abi.CLO_DHW_DEM] = (o[f'robs_{k}'][t] for k in ('cooling_demand', 'heating_demand', 'dhw_demand'))
+        out[abi.CLO_SE_COOL], out[abi.CLO_SE_HEAT], out[abi.CLO_SE_DHW] = (o[f'robs_{k}_storage_electricity_consumption'][t] for k in ('cooling', 'heating', 'dhw'))
         temps = o['robs_indoor_dry_bulb_temperature'][t]
         got = tab.host_row(row, state, out, temps)
         for c, (i, k) in enumerate(lay.columns):
@@ -92,11 +93,28 @@ def test_current_mode_device_map_reproduces_the_reference_series(name, normalize
             assert got[c] == pytest.approx(want, rel=2e-6, abs=2e-6), (row, i, k)
 
 
-def test_unsupported_current_mode_columns_fail_loudly():
+def test_storage_electricity_consumption_columns_in_current_mode():
+    """`*_storage_electricity_consumption` (building.py:413-457) have device planes (CLO_SE_*): with the columns switched on, the
+    'current' layout maps them and the host statement reproduces the reference's reward observations of the step."""
+    from citylearn_amd import abi
     g = golden('g2020_cz1')
+    o, r = g.obs, g.ref
     spec = g.spec()
-    spec.buildings[0].observation_metadata['dhw_storage_electricity_consumption'] = True
+    keys = ('cooling_storage_electricity_consumption', 'dhw_storage_electricity_consumption', 'heating_storage_electricity_consumption')
+    for b in spec.buildings:
+        for k in keys:
+            b.observation_metadata[k] = True
     lay = ObservationLayout(spec, 'current')
-    with pytest.raises(NotImplementedError, match='dhw_storage_electricity_consumption'):
-        lay.episode(spec.episode_tables(0))
-    ObservationLayout(spec, 'reference').episode(spec.episode_tables(0))       # stale semantics need no plane
+    tab = lay.episode(spec.episode_tables(0))
+    assert tab.needs_detail
+    B = len(spec.buildings)
+    cols = [(c, i, k) for c, (i, k) in enumerate(lay.columns) if k in keys]
+    assert len(cols) == 3 * B and all(tab.col_src[c] >= 0 for c, _, _ in cols)
+    for row in (1, 5, 40):
+        t = row - 1
+        out = np.zeros((abi.CL_NO, B))
+        out[abi.CLO_SE_COOL], out[abi.CLO_SE_HEAT], out[abi.CLO_SE_DHW] = (o[f'robs_{k}_storage_electricity_consumption'][t] for k in ('cooling', 'heating', 'dhw'))
+        got = tab.host_row(row, np.zeros((abi.CL_NS, B)), out, np.zeros(B))
+        for c, i, k in cols:
+            assert got[c] == pytest.approx(float(o[f'robs_{k}'][t, i]), rel=2e-6, abs=2e-6), (row, i, k)
+    assert any(abs(float(o['robs_cooling_storage_electricity_consumption'][t, 0])) > 0 for t in range(60))
