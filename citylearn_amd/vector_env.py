@@ -36,7 +36,10 @@ class VectorCityLearnEnv:
         materialising anything; ``'tensor'`` returns the Gym observation tensor ``[n_envs, n_obs]`` written by
         `cl_observe_f32` -- columns = `observation_names` (the reference's central-agent order when
         ``central_agent``, else the agents' vectors concatenated), optionally min-max / sin-cos normalised like
-        `NormalizedObservationWrapper` (`normalize_observations`).  `observation_mode`: ``'current'`` pairs the
+        `NormalizedObservationWrapper` (`normalize_observations`); ``'compact'`` returns the same observation factorised --
+        ``{'shared': [n_obs] row of the step (one per env block with episode offsets), 'dependent': [n_envs, n_dep] values of the
+        env-dependent columns, 'columns': their indices}`` -- which moves ~7 % of the bytes of the full matrix (17 x 65 536:
+        9 MB instead of 125 MB per step); `materialize(obs)` expands it to the ``'tensor'`` form.  `observation_mode`: ``'current'`` pairs the
         exogenous values of step t+1 with the SoC / net just computed; ``'reference'`` reproduces the reference's
         stale read of the t+1 slots.
         `env_episode_offsets`: ``None`` -- every env replays the same episode window (the reference's sequential episodes);
@@ -46,8 +49,9 @@ class VectorCityLearnEnv:
         Districts with EV chargers / washing machines (SURVEY 8f-4) run the extra `cl_flex_kernel` launch per step;
         `ev_seed` keys the per-(env, EV, step) N(1, 0.2) drift of unconnected EVs (default: the schema's random_seed, advanced
         per episode), `ev_soc_drift` ([table rows, n_ev]) replays given multipliers for every env instead."""
-        if observations not in ('planes', 'tensor'):
-            raise ValueError("observations must be 'planes' or 'tensor'")
+        if observations not in ('planes', 'tensor', 'compact'):
+            raise ValueError("observations must be 'planes', 'tensor' or 'compact'")
+        self._compact = observations == 'compact'
         self.spec = schema if isinstance(schema, DistrictSpec) else load_district(schema, **kwargs)
         self.n_envs = int(n_envs)
         self.device = torch.device(device)
@@ -60,7 +64,7 @@ class VectorCityLearnEnv:
             if not isinstance(self.spec.episode_time_steps, int):
                 raise ValueError('env_episode_offsets needs an integer episode_time_steps (schema or kwarg)')
         self.layout = None
-        if observations == 'tensor':
+        if observations in ('tensor', 'compact'):
             from .observations import ObservationLayout
             self.layout = ObservationLayout(self.spec, observation_mode, normalize_observations, reference_quirks)
         rf_cls = resolve_reward(self.spec.reward_function.get('type'))
@@ -217,7 +221,15 @@ class VectorCityLearnEnv:
         self.writer = None
         if obs_tables is not None:
             from .observe import ObservationWriter
-            self.writer = ObservationWriter(self.engine, obs_tables, self.stage)
+            if self._compact:
+                dep_tables, cols = obs_tables.compact()
+                self._shared_rows = torch.from_numpy(np.ascontiguousarray(obs_tables.table, dtype=np.float32)).to(self.device)
+                self._shared_reset = None if obs_tables.reset_table is None else \
+                    torch.from_numpy(np.ascontiguousarray(obs_tables.reset_table, dtype=np.float32)).to(self.device)
+                self._dep_cols = torch.from_numpy(cols.astype(np.int64)).to(self.device)
+                self.writer = ObservationWriter(self.engine, dep_tables, self.stage) if len(cols) else None
+            else:
+                self.writer = ObservationWriter(self.engine, obs_tables, self.stage)
         return self._obs(), {}
 
     def _block_offsets(self, n_steps: int, n_rows: int, seed: Optional[int]) -> np.ndarray:
@@ -254,6 +266,12 @@ class VectorCityLearnEnv:
 
     def _obs(self):
         e = self.engine
+        if self._compact and self.layout is not None:
+            row = min(self._t, e.n_steps - 1)
+            table = self._shared_reset if (row == 0 and self._shared_reset is not None) else self._shared_rows
+            shared = table[row] if e.env_row0 is None else table[e.env_row0.long() + row]          # [n_obs] or [n_blocks, n_obs]
+            dep = self.writer.write(row) if self.writer is not None else torch.zeros((e.n_env, 0), device=self.device)
+            return {'shared': shared, 'dependent': dep, 'columns': self._dep_cols}
         if self.writer is not None:
             return self.writer.write(min(self._t, e.n_steps - 1))
         t_row = min(self._t, e.n_steps - 1)
@@ -351,6 +369,17 @@ class VectorCityLearnEnv:
         building = {k: torch.cat([p[0][k] for p in parts], dim=-1) for k in parts[0][0]}
         district = {k: torch.cat([p[1][k] for p in parts], dim=-1) for k in parts[0][1]}
         return building, district
+
+    def materialize(self, obs: Mapping[str, torch.Tensor]) -> torch.Tensor:
+        """The ``[n_envs, n_obs]`` observation matrix of a ``'compact'`` observation (what ``observations='tensor'`` returns)."""
+        shared = obs['shared']
+        if shared.dim() == 2:                                       # one row per env block (per-env-block episode windows)
+            block = torch.arange(self.n_envs, device=self.device) // abi.CL_ROW0_BLOCK
+            full = shared[block].clone()
+        else:
+            full = shared.unsqueeze(0).repeat(self.n_envs, 1)
+        full[:, obs['columns']] = obs['dependent']
+        return full
 
     def sample_actions(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """Uniform random actions inside the action space (the device analogue of `Agent.predict`, agents/base.py:188-209)."""

@@ -57,6 +57,12 @@ for name, E in (('g2022_all', 65536), ('g2022_all', 262144), ('g2020_cz1', 65536
         del dense
         by = w.algorithmic_bytes()
         print(f'   (row-wise kernel: {us_row:.1f} us; wave-independent kernel: {us_wave:.1f} us; tile kernel by block rows: {", ".join(alt)} us)')
+        dep_tables, dep_cols = ot.compact()
+        wc = ObservationWriter(eng, dep_tables, stage)
+        us_c = timed(lambda: wc.write(7))
+        both_c = timed(lambda: (eng.step(acts, 7), wc.write(8)))
+        print(f'   compact form (shared row + [E, {len(dep_cols)}] dependent matrix, {wc.algorithmic_bytes() / 1e6:.1f} MB): observe {us_c:.1f} us | '
+              f'step+observe {both_c:.1f} us  {eng.n_bldg*E/both_c*1e6:.3e} building-timesteps/s')
         both = timed(lambda: (eng.step(acts, 7), w.write(8)))
         step_b = eng.algorithmic_bytes_per_unit() * eng.n_bldg * E
         print(f'{name} E={E} n_cols={w.n_cols} dep={ot.n_dependent} norm={normalize}: observe {us:.1f} us  {by/us/1e3:.0f} GB/s '

@@ -178,3 +178,26 @@ def test_vector_env_observation_tensor(name, normalize):
             if normalize:
                 want = (want - lo[c]) / (hi[c] - lo[c])
             assert got[0][c] == pytest.approx(want, rel=1e-3, abs=1e-3), (t, i, k)
+
+
+@pytest.mark.parametrize('name,normalize', [('g2022_all', False), ('g2022_all', True), ('g2023_p2', True), ('g2020_cz1', False)])
+def test_compact_observations_expand_to_the_observation_tensor(name, normalize):
+    """`VectorCityLearnEnv(observations='compact')` -- one shared row + the `[n_envs, n_dep]` matrix of the env-dependent columns --
+    expands (`materialize`) to exactly what `observations='tensor'` writes, at reset and after every step, while moving ~7 % of
+    the bytes (building.py:1115-1219: every other column is the same for all envs of the batch)."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden(name)
+    E = 132
+    full = VectorCityLearnEnv(g.schema_path, E, observations='tensor', normalize_observations=normalize)
+    comp = VectorCityLearnEnv(g.schema_path, E, observations='compact', normalize_observations=normalize)
+    o_full, _ = full.reset()
+    o_comp, _ = comp.reset()
+    assert set(o_comp) == {'shared', 'dependent', 'columns'} and o_comp['dependent'].shape == (E, len(o_comp['columns']))
+    assert 0 < o_comp['dependent'].shape[1] < 0.2 * o_full.shape[1]
+    assert torch.equal(comp.materialize(o_comp), o_full)
+    gen = torch.Generator(device='cuda').manual_seed(4)
+    for t in range(20):
+        a = full.sample_actions(gen)
+        o_full = full.step(a)[0]
+        o_comp = comp.step(a)[0]
+        assert torch.equal(comp.materialize(o_comp), o_full), t
