@@ -1205,7 +1205,13 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
         int owned[256] = {0};
         for (int d = 0; d < t.n_deps && wide; ++d) wide = ++owned[(deps[d].col >> 2) & 63] <= OBS_WSLOTS;
     }
-    if (wide) {
+    // every column env-dependent (the compact observation form) and few of them: a plain transpose of the planes
+    const bool transpose = !all_exo && n_seg == 1 && listed && vec4 && t.n_deps == n_cols && n_cols <= OBS_TCOLS && obs_pitch <= OBS_TCOLS + 4 &&
+                           (tun.obs_variant == 0 || tun.obs_variant == 4);
+    if (transpose) {
+        t.o = a;
+        hipLaunchKernelGGL(cl_observe_transpose_kernel, dim3((dims->n_env + OBS_TILE - 1) / OBS_TILE), dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
+    } else if (wide) {
         t.o = a;
         const int n_waves = (dims->n_env + OBS_WROWS - 1) / OBS_WROWS, per_wg = OBS_THREADS / 64;
         const dim3 wgrid((n_waves + per_wg - 1) / per_wg);

@@ -158,6 +158,47 @@ CL_DEV void obs_stream_out(const float* buf, float* out, int total4, int tid) {
     for (; q < total4; q += OBS_THREADS) dst4[q] = src4[q];
 }
 
+// Every column depends on the env (the compact observation form: VectorCityLearnEnv(observations='compact') hands the kernel
+// only the env-dependent columns): the launch is a transpose of n_cols planes [E] into rows [E][pitch].  A workgroup owns 64
+// envs: wave w reads the planes of columns w, w + 4, ... (lane = env: coalesced 256-byte reads, all issued before the first
+// wait), the affine map is applied on the way into an LDS tile, and the tile -- 64 x pitch contiguous floats of `obs` -- streams
+// out in 16-byte stores.  One memory round trip, no template row, no per-block patching (the narrow-vector tile kernel spent
+// 14.9 us on the 17 x 65 536 x 34 case: latency-bound block rounds).
+constexpr int OBS_TCOLS = 64;       // most columns the transpose kernel takes (= OBS_DEP_MAX: the list travels in the kernel arguments)
+__global__ __launch_bounds__(OBS_THREADS) void cl_observe_transpose_kernel(ObsTileArgs t) {
+    __shared__ __attribute__((aligned(16))) float tile[OBS_TILE * (OBS_TCOLS + 4)];
+    const ObsArgs& a = t.o;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int env0 = blockIdx.x * OBS_TILE;
+    const int n_rows = min(OBS_TILE, a.n_env - env0);
+    const float* __restrict__ trow = a.row + (a.env_row0 ? (long long)a.env_row0[env0 / CL_ROW0_BLOCK] * a.n_cols : 0);
+    const int P = a.pitch;                                   // multiple of 4 (checked on the host): rows of the tile stay 16-byte aligned
+    constexpr int PER_WAVE = OBS_TCOLS / (OBS_THREADS / 64);
+    float v[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int d = w + k * (OBS_THREADS / 64);
+        v[k] = 0.0f;
+        if (d < t.n_deps && lane < n_rows) v[k] = obs_plane(a, t.deps[d].src)[env0 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int d = w + k * (OBS_THREADS / 64);
+        if (d < t.n_deps) tile[lane * P + t.deps[d].col] = fmaf(v[k], t.deps[d].scale, trow[t.deps[d].col]);
+    }
+    for (int c = a.n_cols + w; c < a.padded; c += OBS_THREADS / 64) tile[lane * P + c] = 0.0f;      // pad columns
+    __syncthreads();
+    if (a.padded == P) obs_stream_out(tile, a.obs + (long long)env0 * P, n_rows * P / 4, tid);
+    else {
+        // rows wider than what is written (a view into a larger buffer): row by row, 16 bytes per lane
+        const int q4 = a.padded / 4;
+        for (int i = tid; i < n_rows * q4; i += OBS_THREADS) {
+            const int r = i / q4, c = (i - r * q4) * 4;
+            *reinterpret_cast<float4*>(a.obs + (long long)(env0 + r) * P + c) = *reinterpret_cast<const float4*>(tile + r * P + c);
+        }
+    }
+}
+
 __global__ __launch_bounds__(OBS_THREADS) void cl_observe_tile_kernel(ObsTileArgs t) {
     __shared__ __attribute__((aligned(16))) float buf[OBS_BUF];
     __shared__ float dep_s[OBS_DEP_MAX][OBS_TILE];

@@ -248,7 +248,7 @@ typedef struct cl_tuning {
     int32_t lean_variant;   /* lean districts: 1 = general kernel, 2 = latency-ordered lean kernel at any grid size */
     int32_t envmajor;       /* env-major kernels (one lane = one env x all buildings): 0 = by batch size, 1 = always, 2 = never */
     int32_t flex_vec;       /* envs per lane of the flexible-load kernel: 1, 2 or 4 */
-    int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent kernel */
+    int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent, 4 plane-transpose kernel (all columns env-dependent) */
     int32_t obs_rows;       /* LDS-tile observation kernel: envs per block */
     int32_t lstm_variant;   /* LSTM stage timing experiments (csrc/cl_lstm.h) */
     int32_t full_variant;   /* thermal / outage districts: 1 = the round-1 general kernel instead of cl_step_full_kernel (tests) */

@@ -19,7 +19,8 @@ def _engine(name, n_env, detail=True):
     return g, spec, tables, StepEngine(tables, n_env, reward='RewardFunction', detail=detail)
 
 
-@pytest.mark.parametrize('n_env,n_cols,n_dep', [(64, 52, 9), (100, 476, 34), (256, 527, 80), (68, 1500, 90), (192, 2600, 300), (4, 3, 3)])
+@pytest.mark.parametrize('n_env,n_cols,n_dep', [(64, 52, 9), (100, 476, 34), (256, 527, 80), (68, 1500, 90), (192, 2600, 300), (4, 3, 3),
+                                                 (100, 34, 34), (68, 64, 64), (260, 18, 18)])       # all columns dependent: the plane-transpose kernel
 def test_kernel_matches_host_statement(n_env, n_cols, n_dep):
     """Synthetic column maps: single-segment (16-byte store path) and multi-segment shapes, ragged env tile, more
     dependent columns in a segment than the LDS staging holds (direct-read fallback)."""
