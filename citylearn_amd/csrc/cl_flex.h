@@ -27,6 +27,7 @@ struct FlexArgs {
     long long act_stride_col, act_stride_env;
     const int32_t* __restrict__ env_row0;
     int n_env, n_steps, t;
+    unsigned env_offset;   // cl_dims.env_offset: keys the drift stream by the env's index in the whole batch
     bool want_reward;      // reward kind is CLR_EV: leave the K planes
     bool want_chargers;    // the step writes evaluate()'s baseline (CLD_WRITE_DETAIL): leave the chargers-only plane
 };
@@ -50,7 +51,7 @@ CL_DEV float flex_begin_soc(const FlexArgs& a, const float* __restrict__ ev_row,
     const float rule = ev_row[last ? CLEV_RULE_LAST : CLEV_RULE_STEP];
     if (rule >= 0.0f) return rule;
     if (rule == CLEV_ZERO) return 0.0f;
-    const float m = a.f.drift ? a.f.drift[(long long)row * a.f.n_ev + ev] : flex_drift_multiplier(a.f.seed, env, ev, a.t);
+    const float m = a.f.drift ? a.f.drift[(long long)row * a.f.n_ev + ev] : flex_drift_multiplier(a.f.seed, (int)((unsigned)env + a.env_offset), ev, a.t);
     return fminf(fmaxf(prev * fminf(fmaxf(m, 0.6f), 1.4f), 0.0f), 1.0f);
 }
 

@@ -43,6 +43,7 @@ struct StepArgs {
     const int32_t* __restrict__ env_row0;   // per-env-block episode offsets (cl_dims.env_row0) or null
     const float* __restrict__ flex_out;     // cl_flex.flex_out planes [CL_NX][n_flex_bldg][n_env] or null (cl_flex.h)
     int n_flex_bldg;
+    unsigned env_offset;                    // cl_dims.env_offset (low 32 bits: the Philox counter word)
     float ev_penalty_coef;                  // > 0: some building has charging constraints; CLR_EV subtracts coef * violation
     int n_env, n_bldg, n_steps, n_act_cols;
     uint32_t flags;
@@ -723,11 +724,11 @@ namespace {
 // actions[t & 3][column][env] of steps 4 tq .. 4 tq + 3 (one plane per launch measured 19 us at 26 x 65 536: the ten
 // rounds of quarter-rate 32-bit multiplies, three of four words thrown away).
 __global__ void cl_policy_kernel(float* __restrict__ actions, const float* __restrict__ low, const float* __restrict__ high,
-                                 unsigned long long seed, int n_env, int n_cols, int tq) {
+                                 unsigned long long seed, int n_env, int n_cols, int tq, unsigned env_offset) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
     if (env >= n_env) return;
     const float lo = low[col], span = high[col] - lo;
-    const cl::U4 blk = cl::philox_block(seed, (uint32_t)env, (uint32_t)col, (uint32_t)tq);
+    const cl::U4 blk = cl::philox_block(seed, (uint32_t)env + env_offset, (uint32_t)col, (uint32_t)tq);
 #pragma unroll
     for (int w = 0; w < 4; ++w) actions[((long long)w * n_cols + col) * n_env + env] = fmaf(cl::u01(blk.w[w]), span, lo);
 }
@@ -832,7 +833,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     a.kpi_bldg = kpi_bldg; a.kpi_env = kpi_env;
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
-    a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0;
+    a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
     a.flex_out = nullptr; a.n_flex_bldg = 0; a.ev_penalty_coef = 0.0f;
     const int rkind_host = (dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     if (rkind_host == CLR_EV && !flex) return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_step_flex_f32)");
@@ -840,7 +841,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         if (int rc = check_flex(dims, flex)) return rc;
         FlexArgs fa;
         fa.f = *flex; fa.actions = actions; fa.act_stride_col = act_stride_col; fa.act_stride_env = act_stride_env;
-        fa.env_row0 = dims->env_row0; fa.n_env = dims->n_env; fa.n_steps = dims->n_steps; fa.t = t;
+        fa.env_row0 = dims->env_row0; fa.n_env = dims->n_env; fa.n_steps = dims->n_steps; fa.t = t; fa.env_offset = (unsigned)dims->env_offset;
         fa.want_reward = rkind_host == CLR_EV;
         fa.want_chargers = (dims->flags & CLD_WRITE_DETAIL) != 0;
         const int units = flex->n_flex_bldg + flex->n_ev;
@@ -998,7 +999,7 @@ int cl_rollout_seq_f32(const cl_dims* dims, const uint32_t* params, const float*
                                  : policy_actions + (long long)(t & 3) * dims->n_act_cols * dims->n_env;
         if (!actions && dims->n_act_cols > 0 && (k == 0 || (t & 3) == 0))
             hipLaunchKernelGGL(cl_policy_kernel, dim3(gx, (unsigned)dims->n_act_cols), dim3(256), 0, s, policy_actions, act_low, act_high,
-                               (unsigned long long)seed, dims->n_env, dims->n_act_cols, t >> 2);
+                               (unsigned long long)seed, dims->n_env, dims->n_act_cols, t >> 2, (unsigned)dims->env_offset);
         if (int rc = cl_step_flex_f32(dims, params, ts, state, a, actions ? act_stride_col : (int64_t)dims->n_env,
                                       actions ? act_stride_env : (int64_t)1, out_bldg, out_env, kpi_bldg, kpi_env, flex, t, stream))
             return rc;
@@ -1040,7 +1041,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     a.kpi_bldg = nullptr; a.kpi_env = nullptr;
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
-    a.flags = dims->flags; a.t = t0; a.b_chunk = dims->n_bldg; a.n_chunks = 1; a.env_row0 = dims->env_row0;
+    a.flags = dims->flags; a.t = t0; a.b_chunk = dims->n_bldg; a.n_chunks = 1; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
     r.act_stride_step = act_stride_step; r.act_low = act_low; r.act_high = act_high; r.ret_env = ret_env; r.seed = seed;
     r.t0 = t0; r.k_steps = k_steps;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);

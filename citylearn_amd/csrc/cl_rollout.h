@@ -48,7 +48,7 @@ CL_DEV void rollout_action(float (&dst)[VEC], const RolloutArgs& r, int col, int
         const float lo = r.act_low[col], span = r.act_high[col] - lo;
 #pragma unroll
         for (int i = 0; i < VEC; ++i)
-            dst[i] = fmaf(cl::philox_u01(r.seed, (uint32_t)(env0 + i), (uint32_t)col, (uint32_t)t), span, lo);
+            dst[i] = fmaf(cl::philox_u01(r.seed, (uint32_t)(env0 + i) + r.s.env_offset, (uint32_t)col, (uint32_t)t), span, lo);
     }
 }
 
@@ -57,7 +57,7 @@ CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const
     if (col < 0 || r.s.actions) { rollout_action<VEC>(dst, r, col, env0, t, k, live); return; }
     if (k == 0 || (t & 3) == 0) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) cache[i] = cl::philox_block(r.seed, (uint32_t)(env0 + i), (uint32_t)col, (uint32_t)t >> 2);
+        for (int i = 0; i < VEC; ++i) cache[i] = cl::philox_block(r.seed, (uint32_t)(env0 + i) + r.s.env_offset, (uint32_t)col, (uint32_t)t >> 2);
     }
     const float lo = r.act_low[col], span = r.act_high[col] - lo;
     const int sel = t & 3;

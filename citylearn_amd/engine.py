@@ -50,7 +50,8 @@ class StepEngine:
     def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
                  t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False,
                  n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0,
-                 charger_detail: bool = False, ev_penalty_coefficient: float = 1.0, central_agent: bool = False, tuning: Optional[dict] = None):
+                 charger_detail: bool = False, ev_penalty_coefficient: float = 1.0, central_agent: bool = False, tuning: Optional[dict] = None,
+                 env_offset: int = 0):
         """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
         simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
         at table row ``env_row0[g]`` -- different blocks replay different windows at once.
@@ -112,7 +113,7 @@ class StepEngine:
                 raise ValueError(f'unknown tuning field {key!r}')
             setattr(self.tuning, key, int(value))
         self.dims = _lib.Dims(self.n_env, self.n_bldg, self.n_steps, self.n_act_cols, flags, self.n_ts_rows,
-                              None if self.env_row0 is None else self.env_row0.data_ptr(), ctypes.pointer(self.tuning))
+                              None if self.env_row0 is None else self.env_row0.data_ptr(), ctypes.pointer(self.tuning), int(env_offset))
         with torch.cuda.device(self.device):
             self.params = torch.from_numpy(tables.params.view(np.int32).copy()).to(self.device)
             self.ts = torch.from_numpy(np.ascontiguousarray(tables.ts)).to(self.device)

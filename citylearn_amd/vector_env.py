@@ -31,7 +31,7 @@ class VectorCityLearnEnv:
     def __init__(self, schema: Union[str, Mapping[str, Any], DistrictSpec], n_envs: int, device: str = 'cuda:0',
                  reference_quirks: bool = True, kpi: bool = False, observations: str = 'planes',
                  normalize_observations: bool = False, observation_mode: str = 'current',
-                 env_episode_offsets=None, ev_seed: Optional[int] = None, ev_soc_drift=None, **kwargs: Any):
+                 env_episode_offsets=None, ev_seed: Optional[int] = None, ev_soc_drift=None, env_offset: int = 0, **kwargs: Any):
         """`observations`: ``'planes'`` (default) returns the dict of device tensors described above without
         materialising anything; ``'tensor'`` returns the Gym observation tensor ``[n_envs, n_obs]`` written by
         `cl_observe_f32` -- columns = `observation_names` (the reference's central-agent order when
@@ -48,7 +48,9 @@ class VectorCityLearnEnv:
         ``simulation_start_time_step``; ``'random'`` redraws them at every `reset`).
         Districts with EV chargers / washing machines (SURVEY 8f-4) run the extra `cl_flex_kernel` launch per step;
         `ev_seed` keys the per-(env, EV, step) N(1, 0.2) drift of unconnected EVs (default: the schema's random_seed, advanced
-        per episode), `ev_soc_drift` ([table rows, n_ev]) replays given multipliers for every env instead."""
+        per episode), `ev_soc_drift` ([table rows, n_ev]) replays given multipliers for every env instead.
+        `env_offset`: index of this shard's first env in a multi-GPU batch (`parallel.shard_envs(total, rank, world)[0]`): random streams
+        (rollout policy, EV drift) are keyed by it + the local env index, so shards with one seed draw disjoint streams."""
         if observations not in ('planes', 'tensor', 'compact'):
             raise ValueError("observations must be 'planes', 'tensor' or 'compact'")
         self._compact = observations == 'compact'
@@ -60,6 +62,7 @@ class VectorCityLearnEnv:
         self.central_agent = self.spec.central_agent
         self.env_episode_offsets = env_episode_offsets
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
+        self.env_offset = int(env_offset)      # first env of this shard in the whole batch (multi-GPU: parallel.shard_envs(...)[0])
         if env_episode_offsets is not None:
             if not isinstance(self.spec.episode_time_steps, int):
                 raise ValueError('env_episode_offsets needs an integer episode_time_steps (schema or kwarg)')
@@ -209,7 +212,7 @@ class VectorCityLearnEnv:
                                  detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail),
                                  ev_reward_weights=self._rf_attrs.get('weights'), ev_drift=self._ev_drift, central_agent=self.central_agent,
                                  ev_penalty_coefficient=self._rf_attrs.get('charging_constraint_penalty_coefficient') or 1.0,
-                                 ev_seed=(self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode)
+                                 ev_seed=(self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode, env_offset=self.env_offset)
         self.stage = None
         if any(b.is_dynamics for b in self.spec.buildings):
             from .dynamics import LSTMStage

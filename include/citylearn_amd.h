@@ -268,6 +268,9 @@ typedef struct cl_dims {
                                  analogue of EpisodeTracker's rolling / random episode splits, base.py:100-129).  The caller
                                  guarantees 0 <= env_row0[g] and env_row0[g] + n_steps <= n_ts_rows. */
     const cl_tuning* tuning;  /* nullable HOST pointer, read during the call only */
+    int64_t env_offset;       /* index of this shard's first env in the whole (multi-GPU) batch: added to the env index wherever it keys
+                                 a random stream (rollout policy, unconnected-EV drift), so that ranks given the same seed draw disjoint
+                                 streams and a sharded run reproduces the unsharded one.  0 on a single GPU. */
 } cl_dims;
 
 /* ABI version of the loaded library (== CL_ABI_VERSION of the header it was built from). */

@@ -157,3 +157,31 @@ def test_rollout_with_streaming_kpis_and_large_districts(name, kind, B):
             c.step(host[k])
         torch.testing.assert_close(d.state, c.state, rtol=2e-5, atol=2e-5)
         torch.testing.assert_close(d.kpi_bldg, c.kpi_bldg, rtol=1e-4, atol=1e-3)
+
+
+def test_sharded_rollouts_reproduce_the_unsharded_policy_stream():
+    """`cl_dims.env_offset`: two shards of a 512-env batch (envs [0, 256) and [256, 512)), rolled out with the SAME seed and their
+    shard offsets, reproduce the unsharded rollout env for env -- what makes the multi-GPU decomposition (one process per GPU,
+    contiguous env ranges, no collective) independent of the number of ranks."""
+    from citylearn_amd.parallel import shard_envs
+    g = golden('g2022_all')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    low, high = spec.action_limits()
+    E, K, seed = 512, 16, 77
+    whole = StepEngine(tab, E, reward='MARL')
+    whole.set_action_limits(low, high)
+    ret = torch.zeros(E, device='cuda')
+    whole.rollout(K, seed=seed, ret_env=ret)
+    for rank in range(2):
+        lo, hi = shard_envs(E, rank, 2)
+        part = StepEngine(tab, hi - lo, reward='MARL', env_offset=lo)
+        part.set_action_limits(low, high)
+        r = torch.zeros(hi - lo, device='cuda')
+        part.rollout(K, seed=seed, ret_env=r)
+        assert torch.equal(part.state, whole.state[:, :, lo:hi]) and torch.equal(part.out_bldg[:2], whole.out_bldg[:2, :, lo:hi])
+        assert torch.equal(r, ret[lo:hi])
+    same_seed_no_offset = StepEngine(tab, 256, reward='MARL')
+    same_seed_no_offset.set_action_limits(low, high)
+    same_seed_no_offset.rollout(K, seed=seed)
+    assert not torch.equal(same_seed_no_offset.state, whole.state[:, :, 256:])           # without the offset shard 1 would repeat shard 0's draws
