@@ -13,6 +13,10 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / 'tests'))
 
+from citylearn_amd import _lib                  # noqa: E402
+import os                                       # noqa: E402
+if os.environ.get('CL_ALT_LIB'):                # A/B experiments: a second build of the library
+    _lib.LIB_PATH = Path(os.environ['CL_ALT_LIB']).resolve()
 from citylearn_amd.engine import StepEngine     # noqa: E402
 from golden_util import golden                  # noqa: E402
 
