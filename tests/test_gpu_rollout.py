@@ -185,3 +185,25 @@ def test_sharded_rollouts_reproduce_the_unsharded_policy_stream():
     same_seed_no_offset.set_action_limits(low, high)
     same_seed_no_offset.rollout(K, seed=seed)
     assert not torch.equal(same_seed_no_offset.state, whole.state[:, :, 256:])           # without the offset shard 1 would repeat shard 0's draws
+
+
+def test_vector_env_rollout_keeps_streaming_kpis():
+    """`VectorCityLearnEnv(kpi=True).rollout` (launch sequence with the KPI passes after every step): `evaluate()` afterwards equals
+    the one of an env stepped through the same open-loop actions."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden('g2022_all')
+    E, K = 128, 48
+    a, b = VectorCityLearnEnv(g.schema_path, E, kpi=True), VectorCityLearnEnv(g.schema_path, E, kpi=True)
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    acts = torch.stack([a.sample_actions(gen) for _ in range(K)])
+    ret_ref = torch.zeros(E, device='cuda')
+    for k in range(K):
+        ret_ref += a.step(acts[k])[1].sum(dim=0)
+    ret = b.rollout(K, actions=acts)
+    torch.testing.assert_close(ret, ret_ref, rtol=1e-6, atol=1e-4)
+    (bld_a, dis_a), (bld_b, dis_b) = a.evaluate(), b.evaluate()
+    assert set(bld_a) == set(bld_b) and set(dis_a) == set(dis_b) and len(dis_a) >= 5
+    for k in bld_a:
+        torch.testing.assert_close(bld_b[k], bld_a[k], rtol=0, atol=0, equal_nan=True)
+    for k in dis_a:
+        torch.testing.assert_close(dis_b[k], dis_a[k], rtol=0, atol=0, equal_nan=True)
