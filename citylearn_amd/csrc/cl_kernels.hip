@@ -879,10 +879,16 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     if (dims->n_bldg > 32 && grid_x < 2048 && !tun.no_chunks) {
         long long r = ((long long)dims->n_bldg * grid_x) / (16ll * 2048);
         if (r < 1) r = 1;
-        a.b_chunk = (int)(16 * r);
+        // about one 16-wave workgroup per CU when the launch is small: the 1024 x 1024 thermal shard at two envs per lane then gives
+        // every wave two buildings (32 chunks x 8 env tiles = 256 workgroups, all resident at once): 16.0 vs 18.0 us with one
+        // building per wave in two generations (scripts/c4_sweep.py, profiles/r02_c4_chunk_sweep.log)
+        const long long per_cu = ((long long)dims->n_bldg * grid_x + 2048) / 4096;
+        if (per_cu >= 2 && r < 2) r = 2;
+        a.b_chunk = tun.b_chunk > 0 ? tun.b_chunk : (int)(16 * r);
         a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
         if (a.n_chunks == 1) a.b_chunk = dims->n_bldg;
-        else a.nw = 16;
+        else a.nw = (tun.b_chunk > 0 && tun.nw > 0) ? tun.nw : 16;
+        if (a.n_chunks * NQ > dims->n_bldg) return fail(CL_EINVAL, "b_chunk=%d leaves no room for the %d chunk partial sums", a.b_chunk, a.n_chunks);
     }
     if (a.n_chunks > 1 && rkind_host == CLR_EV)
         return fail(CL_EINVAL, "reward kind CLR_EV is not implemented for building-chunked launches (n_bldg=%d)", dims->n_bldg);

@@ -15,10 +15,11 @@ for label, fixture, B, E in (('2020 schema', 'g2020_cz1', None, 65536), ('C4 202
     lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
     acts = [lo[:, None] + torch.rand((len(low), E), device='cuda') * (hi - lo)[:, None] for _ in range(2)]
     for vec in (0, 1, 2, 4):
-        for nw in ((0,) if B else (0, 3, 5, 9, 16)):
-            eng = StepEngine(tab, E, tuning=dict(vec=vec, nw=nw))
+        # chunked launches (B > 32): buildings per workgroup row x waves per workgroup; others: waves per workgroup
+        for bc, nw in (((0, 0), (8, 8), (16, 8), (16, 16), (32, 16), (32, 8), (64, 16)) if B else ((0, 0), (0, 3), (0, 5), (0, 9), (0, 16))):
+            eng = StepEngine(tab, E, tuning=dict(vec=vec, nw=nw, b_chunk=bc))
             try:
                 us = measure(eng, acts, steps=40, reps=4)
-                print(f'{label} vec={vec} nw={nw}: {us:.2f} us', flush=True)
+                print(f'{label} vec={vec} b_chunk={bc} nw={nw}: {us:.2f} us', flush=True)
             except Exception as e:
-                print(f'{label} vec={vec} nw={nw}: {type(e).__name__} {str(e)[:80]}', flush=True)
+                print(f'{label} vec={vec} b_chunk={bc} nw={nw}: {type(e).__name__} {str(e)[:80]}', flush=True)
