@@ -341,7 +341,11 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 // 9.3 us vs 7.9 us for VEC = 4 at 17 x 65 536.  Tried: with 17 = 16 + 1 buildings, sharing the last building's env tile out
 // in 64-env strips to four waves at one env per lane instead of giving one wave two buildings -- 5 instead of 8 units on the
 // longest wave, 62 instead of 94 VGPRs: 7.89 vs 7.94 us, i.e. the doubled wave is not what bounds the launch.  Tried:
-// non-temporal stores for the net / reward planes: 7.87 - 7.91 vs 7.86 - 7.88 us, no effect.)
+// non-temporal stores for the net / reward planes: 7.87 - 7.91 vs 7.86 - 7.88 us, no effect.  Tried (round 2): plane accesses
+// through `float` lvalues instead of float4 ones, so that the parameter block of wave 0's SECOND building -- read after the first
+// one's stores, and therefore a uniform *vector* load behind them -- stays a scalar load: 73 instead of 88 VGPRs, and 8.14 vs
+// 7.99 us, three alternations on one box: slower.  The same trick is what made the thermal kernel's two-env pack viable
+// (cl_full.h); here the vector loads of the 17th building's parameters are issued early enough and the scalar ones are not.)
 template <int VEC, bool FLEX = false>
 __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
