@@ -295,7 +295,7 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
 
 /* Fused rollout: steps t0 .. t0+k_steps-1 in one launch with the per-unit state held in registers.
  * actions == NULL: on-device uniform random policy, a = low + u*(high-low) with
- *   u(seed; env, column, t) = word[t & 3] of Philox4x32-10(counter = (env, column, t >> 2, 0), key = seed)  (24 bits)
+ *   u(seed; env, column, t) = word[t & 3] of Philox4x32-10(counter = (cl_dims.env_offset + env, column, t >> 2, 0), key = seed)  (24 bits)
  * -- the device analogue of Agent.predict's action_space.sample()
  * (agents/base.py:188-209); `act_low/act_high` are [n_act_cols].
  * actions != NULL: open-loop action tensor, element (k, col, env) at
