@@ -244,12 +244,17 @@ def main():
         torch.cuda.empty_cache()
         s_steps = 20
         eng_s, _, _, launch = measure(STREAMING_ENVS, 5, s_steps, 3)
+        s_traffic, s_traffic_source = None, None
+        spmc = sorted((ROOT / 'profiles').glob('r*_streaming_pmc_summary.json'))
+        if spmc:
+            c = json.loads(spmc[-1].read_text())
+            s_traffic, s_traffic_source = (2.0 * c['FETCH_SIZE']['mean'] + c['WRITE_SIZE']['mean']) * 1024.0, spmc[-1].name
         a = eng_s.n_bldg * STREAMING_ENVS * eng_s.algorithmic_bytes_per_unit() / launch / 1e9
         streaming = {'workload': f'same tables x {STREAMING_ENVS} envs per GPU ({eng_s.n_bldg * STREAMING_ENVS * eng_s.algorithmic_bytes_per_unit() / 1e6:.0f} MB '
                                  f'of algorithmic traffic per launch, beyond the 256 MB Infinity Cache)',
                      'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
                      'frac_vs_measured_copy': a / HBM_MEASURED_COPY_GBS, 'kernel': kernel_name(STREAMING_ENVS), 'launch_us': launch * 1e6,
-                     'units_per_launch': eng_s.n_bldg * STREAMING_ENVS, 'steps': s_steps,
+                     'units_per_launch': eng_s.n_bldg * STREAMING_ENVS, 'steps': s_steps, 'traffic': s_traffic, 'traffic_source': s_traffic_source,
                      'value': world * eng_s.n_bldg * STREAMING_ENVS / launch}
         n_bldg = eng_s.n_bldg
         del eng_s
