@@ -374,13 +374,18 @@ CL_DEV void full_load_in(FullIn<typename Vec<VEC>::type>& in, const StepArgs& a,
     }
 }
 
-template <int VEC>
+template <int VEC, bool NT>
 CL_DEV void full_store(float* __restrict__ p, typename Vec<VEC>::type v) {
-    if constexpr (VEC == 1) p[0] = v;
-    else {
+    if constexpr (VEC == 1) {
+        if constexpr (NT) __builtin_nontemporal_store(v, p);
+        else p[0] = v;
+    } else {
         float* __restrict__ q = static_cast<float*>(__builtin_assume_aligned(p, 4 * VEC));
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) q[i] = v[i];
+        for (int i = 0; i < VEC; ++i) {
+            if constexpr (NT) __builtin_nontemporal_store(v[i], q + i);
+            else q[i] = v[i];
+        }
     }
 }
 
@@ -404,7 +409,7 @@ CL_DEV void full_accumulate(float (&q)[VEC], typename Vec<VEC>::type v) {
 //  wave's NEXT building before computing the current one -- 9.6 vs 8.8 us; one wave per SIMD walking all nine buildings, with or
 //  without that prefetch -- 18 us, i.e. 2 us per building of which 0.45 us is arithmetic: the scalar parameter round trips are
 //  what a lone wave cannot hide, so the launch wants several waves per SIMD rather than a deeper per-wave pipeline.)
-template <int VEC, bool DETAIL, int MAXT, int WPE>
+template <int VEC, bool DETAIL, int MAXT, int WPE, bool NT>
 __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     using F = typename Vec<VEC>::type;
@@ -425,6 +430,10 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
     const int b_hi = min(a.n_bldg, b_lo + a.b_chunk);
     const bool marl_partial = rkind == CLR_MARL && a.n_chunks > 1;
     const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
+    CL_TRACE_DECL;
+    CL_TRACE_ENTRY(0);
+    CL_TRACE_CYCLES_ENTRY(4);     // shader-clock cycles at entry (slot 12: at the end) -- gives the clock the launch ran at
+    [[maybe_unused]] int tr_i = 0;
     for (int b = b_lo + w; b < b_hi; b += a.nw) {
         if (live) {
             const uint32_t* __restrict__ f = a.params + (long long)b * CL_NP + CLP_F_FIRST;
@@ -435,46 +444,55 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
             cl::Row R;
             cl::load_row_scalar<true>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags,
                                       DETAIL ? a.ts + ((long long)(ts_row - a.t + a.n_steps - 1) * a.n_bldg + b) * CL_NF : nullptr);
+            CL_TRACE_INPUTS(1 + 4 * tr_i, cur);
             clv::St<F> S = {cur.soc, cur.eff, cur.deg, cur.cs, cur.hs, cur.ds};
             const clv::Ac<F> act = {cur.a_cs, cur.a_hs, cur.a_ds, cur.a_es, cur.a_cd, cur.a_hd};
             clv::Ou<F> O;
             if (R.outage) clv::unit_step<F, true, DETAIL>(B, R, a.t, first, act, S, O);
             else clv::unit_step<F, false, DETAIL>(B, R, a.t, first, act, S, O);
-            const F rw = clv::unit_reward<F>(rkind, B, S, O.net);
+            F rw = clv::unit_reward<F>(rkind, B, S, O.net);
+            CL_TRACE_AFTER(2 + 4 * tr_i, rw);
+            CL_TRACE_AFTER(2 + 4 * tr_i, S.soc);
             const long long off = (long long)b * a.n_env + env0;
             if (B.flags & CLF_BATTERY) {
-                full_store<VEC>(a.state + CLS_B_SOC * plane + off, S.soc);
-                full_store<VEC>(a.state + CLS_B_EFF * plane + off, S.eff);
-                full_store<VEC>(a.state + CLS_B_DEGCAP * plane + off, S.degcap);
+                full_store<VEC, NT>(a.state + CLS_B_SOC * plane + off, S.soc);
+                full_store<VEC, NT>(a.state + CLS_B_EFF * plane + off, S.eff);
+                full_store<VEC, NT>(a.state + CLS_B_DEGCAP * plane + off, S.degcap);
             }
-            if (B.flags & CLF_COOL_STO) full_store<VEC>(a.state + CLS_CS_SOC * plane + off, S.cs);
-            if (B.flags & CLF_HEAT_STO) full_store<VEC>(a.state + CLS_HS_SOC * plane + off, S.hs);
-            if (B.flags & CLF_DHW_STO) full_store<VEC>(a.state + CLS_DS_SOC * plane + off, S.ds);
-            full_store<VEC>(a.out_bldg + CLO_NET * plane + off, O.net);
-            if (rkind != CLR_MARL) full_store<VEC>(a.out_bldg + CLO_REWARD * plane + off, rw);
+            if (B.flags & CLF_COOL_STO) full_store<VEC, NT>(a.state + CLS_CS_SOC * plane + off, S.cs);
+            if (B.flags & CLF_HEAT_STO) full_store<VEC, NT>(a.state + CLS_HS_SOC * plane + off, S.hs);
+            if (B.flags & CLF_DHW_STO) full_store<VEC, NT>(a.state + CLS_DS_SOC * plane + off, S.ds);
+            full_store<VEC, NT>(a.out_bldg + CLO_NET * plane + off, O.net);
+            if (rkind != CLR_MARL) full_store<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, rw);
             if constexpr (DETAIL) {
-                full_store<VEC>(a.out_bldg + CLO_B_EB * plane + off, O.eb);
-                full_store<VEC>(a.out_bldg + CLO_COOL_DEM * plane + off, O.cool_dem);
-                full_store<VEC>(a.out_bldg + CLO_HEAT_DEM * plane + off, O.heat_dem);
-                full_store<VEC>(a.out_bldg + CLO_DHW_DEM * plane + off, O.dhw_dem);
-                full_store<VEC>(a.out_bldg + CLO_C_COOL * plane + off, O.c_cool);
-                full_store<VEC>(a.out_bldg + CLO_C_HEAT * plane + off, O.c_heat);
-                full_store<VEC>(a.out_bldg + CLO_C_DHW * plane + off, O.c_dhw);
-                full_store<VEC>(a.out_bldg + CLO_C_NSL * plane + off, O.c_ns);
-                full_store<VEC>(a.out_bldg + CLO_BASE_NET * plane + off, O.base_net);
-                full_store<VEC>(a.out_bldg + CLO_EXPECTED * plane + off, O.expected);
-                full_store<VEC>(a.out_bldg + CLO_SERVED * plane + off, O.served);
-                full_store<VEC>(a.out_bldg + CLO_NET_WS * plane + off, O.net_ws);
-                full_store<VEC>(a.out_bldg + CLO_SE_COOL * plane + off, O.se_cool);
-                full_store<VEC>(a.out_bldg + CLO_SE_HEAT * plane + off, O.se_heat);
-                full_store<VEC>(a.out_bldg + CLO_SE_DHW * plane + off, O.se_dhw);
+                full_store<VEC, NT>(a.out_bldg + CLO_B_EB * plane + off, O.eb);
+                full_store<VEC, NT>(a.out_bldg + CLO_COOL_DEM * plane + off, O.cool_dem);
+                full_store<VEC, NT>(a.out_bldg + CLO_HEAT_DEM * plane + off, O.heat_dem);
+                full_store<VEC, NT>(a.out_bldg + CLO_DHW_DEM * plane + off, O.dhw_dem);
+                full_store<VEC, NT>(a.out_bldg + CLO_C_COOL * plane + off, O.c_cool);
+                full_store<VEC, NT>(a.out_bldg + CLO_C_HEAT * plane + off, O.c_heat);
+                full_store<VEC, NT>(a.out_bldg + CLO_C_DHW * plane + off, O.c_dhw);
+                full_store<VEC, NT>(a.out_bldg + CLO_C_NSL * plane + off, O.c_ns);
+                full_store<VEC, NT>(a.out_bldg + CLO_BASE_NET * plane + off, O.base_net);
+                full_store<VEC, NT>(a.out_bldg + CLO_EXPECTED * plane + off, O.expected);
+                full_store<VEC, NT>(a.out_bldg + CLO_SERVED * plane + off, O.served);
+                full_store<VEC, NT>(a.out_bldg + CLO_NET_WS * plane + off, O.net_ws);
+                full_store<VEC, NT>(a.out_bldg + CLO_SE_COOL * plane + off, O.se_cool);
+                full_store<VEC, NT>(a.out_bldg + CLO_SE_HEAT * plane + off, O.se_heat);
+                full_store<VEC, NT>(a.out_bldg + CLO_SE_DHW * plane + off, O.se_dhw);
             }
             full_accumulate<VEC>(q_net, O.net); full_accumulate<VEC>(q_cost, O.cost); full_accumulate<VEC>(q_em, O.emission);
             // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)
             full_accumulate<VEC>(q_rw, marl_partial ? clv::marl_partial<F>(O.net) : rw);
+            CL_TRACE_AFTER(3 + 4 * tr_i, q_rw[0]);          // stores issued
+#ifdef CL_TRACE
+            if (tr_i < 2) ++tr_i;
+#endif
         }
     }
+    CL_TRACE_AFTER(13, q_net[0]);
     district_reduce<VEC, false>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    CL_TRACE_FLUSH();
 }
 
 }  // namespace

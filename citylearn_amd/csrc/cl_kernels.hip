@@ -7,6 +7,7 @@
 // coalesced request per plane).  District sums over buildings (net, cost, emission, reward) are reduced
 // through LDS in a fixed order (wave-partials -> serial sum over waves), so results are bit-reproducible
 // run to run -- no atomics on the step path.
+#include "cl_trace.h"
 #include "cl_unit.h"
 #include "cl_philox.h"
 
@@ -51,7 +52,11 @@ struct StepArgs {
     int nw;        // waves per workgroup == building lanes
     int b_chunk;   // buildings per workgroup row (gridDim.y = n_chunks rows); == n_bldg when the grid is 1-D
     int n_chunks;
+    int nt;        // plane stores carry the non-temporal hint (see pstore)
 };
+
+// largest launch (env x building units) whose plane stores carry the non-temporal hint (see pstore)
+constexpr long long CL_NT_MAX_UNITS = 3ll << 20;
 
 template <int VEC> struct Vec;
 template <> struct Vec<1> { using type = float; };
@@ -69,6 +74,21 @@ CL_DEV void vload(float (&dst)[VEC], const float* __restrict__ p) {
     }
 }
 
+// Load from a state / action plane in HBM; NT as in pstore (measured together with the nt stores on cl_step_lean_kernel,
+// 17 x 65 536: 7.32 -> 7.18 us; the copy-floor pattern of scripts/launch_gap.py: 5.65 -> 5.41 us).
+template <int VEC, bool NT>
+CL_DEV void pload(float (&dst)[VEC], const float* __restrict__ p) {
+    if constexpr (NT) {
+        using V = typename Vec<VEC>::type;
+        const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+        if constexpr (VEC == 1) dst[0] = v;
+        else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dst[i] = v[i];
+        }
+    } else vload<VEC>(dst, p);
+}
+
 template <int VEC>
 CL_DEV void vstore(float* __restrict__ p, const float (&src)[VEC]) {
     using V = typename Vec<VEC>::type;
@@ -80,6 +100,27 @@ CL_DEV void vstore(float* __restrict__ p, const float (&src)[VEC]) {
     }
     *reinterpret_cast<V*>(p) = v;
 }
+
+// Store to a state / output plane in HBM (never LDS).  NT = non-temporal (`global_store ... nt`): the lines stream through the
+// XCD's L2 instead of staying dirty in it until the end-of-kernel release writes them back.  scripts/launch_gap.py: for the
+// headline shape's access pattern (17.8 MB in, 22.3 MB out) the waves are alive 2.9 us either way, but the gap to the next launch's
+// first wave is 3.2 us with plain stores and 2.7 us with nt ones (1.1 us for a read-only kernel, 1.8 us period for an empty one);
+// cl_step_lean_kernel 17 x 65 536: 7.91 -> 7.20 us.  Once the launch's footprint is past the 256 MB Infinity Cache the hint costs
+// bandwidth instead (17 x 1 048 576: 125.9 -> 132.9 us), so the host sets StepArgs::nt by size.
+template <int VEC, bool NT>
+CL_DEV void pstore(float* __restrict__ p, const float (&src)[VEC]) {
+    using V = typename Vec<VEC>::type;
+    V v;
+    if constexpr (VEC == 1) v = src[0];
+    else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = src[i];
+    }
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+    else *reinterpret_cast<V*>(p) = v;
+}
+struct NtOn { static constexpr bool value = true; };
+struct NtOff { static constexpr bool value = false; };
 
 // action element (col, env): coalesced when act_stride_env == 1
 template <int VEC>
@@ -187,7 +228,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
                 }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) r_sum[i] += rw[i];
-                vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, rw);
+                pstore<VEC, false>(a.out_bldg + CLO_REWARD * plane + off, rw);
             }
         }
         vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, r_sum);
@@ -296,35 +337,39 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
                 q_rw[i] += (marl_partial || (FLEX && rkind == CLR_EV)) ? cl::marl_reward(O.net, 1.0f) : rw;
             }
-            if (batt) {
-                vstore<VEC>(a.state + CLS_B_SOC * plane + off, s_soc);
-                vstore<VEC>(a.state + CLS_B_EFF * plane + off, s_eff);
-                vstore<VEC>(a.state + CLS_B_DEGCAP * plane + off, s_deg);
-            }
-            if constexpr (FULL) {
-                if (B.flags & CLF_COOL_STO) vstore<VEC>(a.state + CLS_CS_SOC * plane + off, s_cs);
-                if (B.flags & CLF_HEAT_STO) vstore<VEC>(a.state + CLS_HS_SOC * plane + off, s_hs);
-                if (B.flags & CLF_DHW_STO) vstore<VEC>(a.state + CLS_DS_SOC * plane + off, s_ds);
-            }
-            vstore<VEC>(a.out_bldg + CLO_NET * plane + off, o_net);
-            if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
-            if constexpr (FULL && DETAIL) {
-                vstore<VEC>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
-                vstore<VEC>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
-                vstore<VEC>(a.out_bldg + CLO_HEAT_DEM * plane + off, o_hd);
-                vstore<VEC>(a.out_bldg + CLO_DHW_DEM * plane + off, o_dd);
-                vstore<VEC>(a.out_bldg + CLO_C_COOL * plane + off, o_cc);
-                vstore<VEC>(a.out_bldg + CLO_C_HEAT * plane + off, o_ch);
-                vstore<VEC>(a.out_bldg + CLO_C_DHW * plane + off, o_cw);
-                vstore<VEC>(a.out_bldg + CLO_C_NSL * plane + off, o_cn);
-                vstore<VEC>(a.out_bldg + CLO_BASE_NET * plane + off, o_bn);
-                vstore<VEC>(a.out_bldg + CLO_EXPECTED * plane + off, o_ex);
-                vstore<VEC>(a.out_bldg + CLO_SERVED * plane + off, o_sv);
-                vstore<VEC>(a.out_bldg + CLO_NET_WS * plane + off, o_ws);
-                vstore<VEC>(a.out_bldg + CLO_SE_COOL * plane + off, o_sc);
-                vstore<VEC>(a.out_bldg + CLO_SE_HEAT * plane + off, o_sh);
-                vstore<VEC>(a.out_bldg + CLO_SE_DHW * plane + off, o_sd);
-            }
+            auto put = [&](auto nt_tag) {
+                constexpr bool NT = decltype(nt_tag)::value;
+                if (batt) {
+                    pstore<VEC, NT>(a.state + CLS_B_SOC * plane + off, s_soc);
+                    pstore<VEC, NT>(a.state + CLS_B_EFF * plane + off, s_eff);
+                    pstore<VEC, NT>(a.state + CLS_B_DEGCAP * plane + off, s_deg);
+                }
+                if constexpr (FULL) {
+                    if (B.flags & CLF_COOL_STO) pstore<VEC, NT>(a.state + CLS_CS_SOC * plane + off, s_cs);
+                    if (B.flags & CLF_HEAT_STO) pstore<VEC, NT>(a.state + CLS_HS_SOC * plane + off, s_hs);
+                    if (B.flags & CLF_DHW_STO) pstore<VEC, NT>(a.state + CLS_DS_SOC * plane + off, s_ds);
+                }
+                pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
+                if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+                if constexpr (FULL && DETAIL) {
+                    pstore<VEC, NT>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
+                    pstore<VEC, NT>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
+                    pstore<VEC, NT>(a.out_bldg + CLO_HEAT_DEM * plane + off, o_hd);
+                    pstore<VEC, NT>(a.out_bldg + CLO_DHW_DEM * plane + off, o_dd);
+                    pstore<VEC, NT>(a.out_bldg + CLO_C_COOL * plane + off, o_cc);
+                    pstore<VEC, NT>(a.out_bldg + CLO_C_HEAT * plane + off, o_ch);
+                    pstore<VEC, NT>(a.out_bldg + CLO_C_DHW * plane + off, o_cw);
+                    pstore<VEC, NT>(a.out_bldg + CLO_C_NSL * plane + off, o_cn);
+                    pstore<VEC, NT>(a.out_bldg + CLO_BASE_NET * plane + off, o_bn);
+                    pstore<VEC, NT>(a.out_bldg + CLO_EXPECTED * plane + off, o_ex);
+                    pstore<VEC, NT>(a.out_bldg + CLO_SERVED * plane + off, o_sv);
+                    pstore<VEC, NT>(a.out_bldg + CLO_NET_WS * plane + off, o_ws);
+                    pstore<VEC, NT>(a.out_bldg + CLO_SE_COOL * plane + off, o_sc);
+                    pstore<VEC, NT>(a.out_bldg + CLO_SE_HEAT * plane + off, o_sh);
+                    pstore<VEC, NT>(a.out_bldg + CLO_SE_DHW * plane + off, o_sd);
+                }
+            };
+            if (a.nt) put(NtOn{}); else put(NtOff{});
         }
     }
 
@@ -346,7 +391,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 // one's stores, and therefore a uniform *vector* load behind them -- stays a scalar load: 73 instead of 88 VGPRs, and 8.14 vs
 // 7.99 us, three alternations on one box: slower.  The same trick is what made the thermal kernel's two-env pack viable
 // (cl_full.h); here the vector loads of the 17th building's parameters are issued early enough and the scalar ones are not.)
-template <int VEC, bool FLEX = false>
+template <int VEC, bool FLEX, bool NT>
 __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
@@ -366,15 +411,18 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
     float s_soc[2][VEC], s_eff[2][VEC], s_deg[2][VEC], a_es[2][VEC];
+    CL_TRACE_DECL;
+    CL_TRACE_ENTRY(0);
+    CL_TRACE_CYCLES_ENTRY(4);
     if (live) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             if (!own[m]) continue;
             const long long off = (long long)bb[m] * a.n_env + env0;       // every building has its state rows: no flag test
-            vload<VEC>(s_soc[m], a.state + CLS_B_SOC * plane + off);
-            vload<VEC>(s_eff[m], a.state + CLS_B_EFF * plane + off);
-            vload<VEC>(s_deg[m], a.state + CLS_B_DEGCAP * plane + off);
-            if (act_by_bldg) vload<VEC>(a_es[m], a.actions + (long long)bb[m] * a.act_stride_col + env0);
+            pload<VEC, NT>(s_soc[m], a.state + CLS_B_SOC * plane + off);
+            pload<VEC, NT>(s_eff[m], a.state + CLS_B_EFF * plane + off);
+            pload<VEC, NT>(s_deg[m], a.state + CLS_B_DEGCAP * plane + off);
+            if (act_by_bldg) pload<VEC, NT>(a_es[m], a.actions + (long long)bb[m] * a.act_stride_col + env0);
         }
     }
 #pragma unroll
@@ -389,35 +437,81 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
         const long long off = (long long)b * a.n_env + env0;
         const bool batt = B.flags & CLF_BATTERY;
         if (!act_by_bldg) load_action<VEC>(a_es[m], a, B.a_es, env0);
+        CL_TRACE_WAITV(1 + 4 * m, s_deg[m][0]);
         float o_net[VEC], o_rw[VEC];
         // chargers / washing machines of this building (cl_flex_kernel ran just before this launch)
         const int fbi = (FLEX && (B.flags & CLF_FLEX)) ? (int)B.p[CLP_FLEX_INDEX] : -1;
         float x_load[VEC];
         if (FLEX && fbi >= 0) vload<VEC>(x_load, a.flex_out + (long long)CLX_LOAD * a.n_flex_bldg * a.n_env + (long long)fbi * a.n_env + env0);
+        if constexpr (FLEX) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            cl::State S;
-            S.soc = batt ? s_soc[m][i] : 0.0f; S.eff = batt ? s_eff[m][i] : 1.0f; S.degcap = batt ? s_deg[m][i] : 0.0f;
-            S.cs = S.hs = S.ds = 0.0f;
-            const cl::Act act = {0.0f, 0.0f, 0.0f, B.a_es >= 0 ? a_es[m][i] : 0.0f, 0.0f, 0.0f};
-            cl::Out O;
-            cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
-            if (FLEX && fbi >= 0) cl::apply_flex(false, R.price, R.carbon, x_load[i], 0.0f, O);
-            const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
-            s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap;
-            o_net[i] = O.net; o_rw[i] = rw;
-            q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
-            q_rw[i] += (FLEX && rkind == CLR_EV) ? cl::marl_reward(O.net, 1.0f) : rw;
+            for (int i = 0; i < VEC; ++i) {
+                cl::State S;
+                S.soc = batt ? s_soc[m][i] : 0.0f; S.eff = batt ? s_eff[m][i] : 1.0f; S.degcap = batt ? s_deg[m][i] : 0.0f;
+                S.cs = S.hs = S.ds = 0.0f;
+                const cl::Act act = {0.0f, 0.0f, 0.0f, B.a_es >= 0 ? a_es[m][i] : 0.0f, 0.0f, 0.0f};
+                cl::Out O;
+                cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
+                if (FLEX && fbi >= 0) cl::apply_flex(false, R.price, R.carbon, x_load[i], 0.0f, O);
+                const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
+                s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap;
+                o_net[i] = O.net; o_rw[i] = rw;
+                q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
+                q_rw[i] += (FLEX && rkind == CLR_EV) ? cl::marl_reward(O.net, 1.0f) : rw;
+            }
+        } else {
+            // The lean unit (cl::unit_step<false> + cl::unit_reward<false>, restated with the same expressions) with everything that
+            // does not depend on the env taken out of the env loop: the t = 0 booking of the load, the battery's curve parameters
+            // (in VGPRs once per building instead of one v_mov per select per env), the has-battery and reward-kind tests.
+            // 111 -> 90 VALU instructions per unit (SQ_INSTS_VALU).
+            const bool first = quirk && a.t == 0;
+            float c_ns = first ? 3.0f * R.nsl : R.nsl;           // booked at reset, by the step and by update_variables
+            float sol = R.sol;
+            const float cbk = first ? 2.0f : 1.0f;               // c_b = first ? 2 eb : eb
+            CL_PIN_V(c_ns); CL_PIN_V(sol);
+            float soc_rw[VEC];
+            if (batt) {
+                cl::BattP Bv = B.batt;
+                CL_PIN_V(Bv.cpc_a0); CL_PIN_V(Bv.cpc_b0); CL_PIN_V(Bv.cpc_a1); CL_PIN_V(Bv.cpc_b1);
+                CL_PIN_V(Bv.pec_a0); CL_PIN_V(Bv.pec_b0); CL_PIN_V(Bv.pec_a1); CL_PIN_V(Bv.pec_b1);
+                CL_PIN_V(Bv.pec_a2); CL_PIN_V(Bv.pec_b2); CL_PIN_V(Bv.pec_a3); CL_PIN_V(Bv.pec_b3);
+                if (B.a_es < 0) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) a_es[m][i] = 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    cl::State S = {s_soc[m][i], s_eff[m][i], s_deg[m][i], 0.0f, 0.0f, 0.0f};
+                    // battery_step with flexibility = +inf (no outage in a lean district)
+                    const float eb = cl::battery_energy(Bv, a_es[m][i] * Bv.pdt, S);
+                    s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap;
+                    soc_rw[i] = S.soc;
+                    o_net[i] = fmaf(c_ns + cbk * eb, B.r, sol);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { o_net[i] = fmaf(c_ns + 0.0f, B.r, sol); soc_rw[i] = 0.0f; }
+            }
+            cl::lean_rewards<VEC>(rkind, B, soc_rw, o_net, o_rw);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                q_net[i] += o_net[i]; q_cost[i] += o_net[i] * R.price; q_em[i] += fmaxf(0.0f, o_net[i] * R.carbon);
+                q_rw[i] += o_rw[i];
+            }
         }
+        CL_TRACE_AFTER(2 + 4 * m, o_rw[VEC - 1]);
         if (batt) {
-            vstore<VEC>(a.state + CLS_B_SOC * plane + off, s_soc[m]);
-            vstore<VEC>(a.state + CLS_B_EFF * plane + off, s_eff[m]);
-            vstore<VEC>(a.state + CLS_B_DEGCAP * plane + off, s_deg[m]);
+            pstore<VEC, NT>(a.state + CLS_B_SOC * plane + off, s_soc[m]);
+            pstore<VEC, NT>(a.state + CLS_B_EFF * plane + off, s_eff[m]);
+            pstore<VEC, NT>(a.state + CLS_B_DEGCAP * plane + off, s_deg[m]);
         }
-        vstore<VEC>(a.out_bldg + CLO_NET * plane + off, o_net);
-        if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) vstore<VEC>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+        pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
+        if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+        CL_TRACE_AFTER(3 + 4 * m, q_rw[0]);
     }
+    CL_TRACE_AFTER(13, q_net[0]);
     district_reduce<VEC, FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    CL_TRACE_FLUSH();
 }
 
 // Lean districts, one wave = 64 envs x ALL buildings ("env-major").  The wave issues every state / action load of its
@@ -426,7 +520,7 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
 // order -- the reference's own summation order, citylearn.py:1909-1918).  With one such wave per SIMD the read stream, the
 // arithmetic and the write stream of a CU overlap, which the building-major kernels (one generation of waves in lockstep:
 // load, then compute, then store) cannot do.  NB = compile-time bound on the buildings held in flight.
-template <int NB>
+template <int NB, bool NT>
 __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a) {
     const int env = blockIdx.x * 256 + threadIdx.x;
     const bool live = env < a.n_env;
@@ -487,12 +581,12 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
         cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
         const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
         if (batt) {
-            a.state[CLS_B_SOC * plane + off] = S.soc;
-            a.state[CLS_B_EFF * plane + off] = S.eff;
-            a.state[CLS_B_DEGCAP * plane + off] = S.degcap;
+            pstore<1, NT>(a.state + CLS_B_SOC * plane + off, {S.soc});
+            pstore<1, NT>(a.state + CLS_B_EFF * plane + off, {S.eff});
+            pstore<1, NT>(a.state + CLS_B_DEGCAP * plane + off, {S.degcap});
         }
-        a.out_bldg[CLO_NET * plane + off] = O.net;
-        if (rkind != CLR_MARL) a.out_bldg[CLO_REWARD * plane + off] = rw;
+        pstore<1, NT>(a.out_bldg + CLO_NET * plane + off, {O.net});
+        if (rkind != CLR_MARL) pstore<1, NT>(a.out_bldg + CLO_REWARD * plane + off, {rw});
         nets[b] = O.net;
         q_net += O.net; q_cost += O.cost; q_em += O.emission; q_rw += rw;
     }
@@ -716,6 +810,11 @@ int pick_vec(int n_env, int n_bldg, bool unit_stride) {
 // Launch-geometry overrides travel with every call (cl_dims.tuning, include/citylearn_amd.h): the library holds no
 // mutable state besides the thread-local error string.
 const cl_tuning k_default_tuning = {};
+// launch K<..., NT> with NT = a.nt (expects grid, block, lds, s, a in scope)
+#define CL_LAUNCH_NT(K, ...) do { \
+    if (a.nt) hipLaunchKernelGGL((K<__VA_ARGS__, true>), grid, block, lds, s, a); \
+    else hipLaunchKernelGGL((K<__VA_ARGS__, false>), grid, block, lds, s, a); } while (0)
+
 const cl_tuning& tuning_of(const cl_dims* d) { return d->tuning ? *d->tuning : k_default_tuning; }
 
 }  // namespace
@@ -754,6 +853,11 @@ __global__ void cl_return_kernel(float* __restrict__ ret_env, const float* __res
 extern "C" {
 
 int cl_abi_version(void) { return CL_ABI_VERSION; }
+
+#ifdef CL_TRACE
+// diagnostic build only (scripts/wave_timeline.py): where cl_step_full_kernel parks its per-wave phase stamps
+int cl_trace_set(void* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_cl_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1; }
+#endif
 
 const char* cl_last_error(void) { return g_err; }
 
@@ -839,6 +943,8 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
     a.flex_out = nullptr; a.n_flex_bldg = 0; a.ev_penalty_coef = 0.0f;
+    // non-temporal plane stores while the launch's footprint (~40 - 60 B per (env, building) unit) stays inside the Infinity Cache
+    a.nt = tun.nt_stores == 1 || (tun.nt_stores == 0 && (long long)dims->n_env * dims->n_bldg <= CL_NT_MAX_UNITS);
     const int rkind_host = (dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     if (rkind_host == CLR_EV && !flex) return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_step_flex_f32)");
     if (flex) {
@@ -862,7 +968,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         a.flex_out = flex->flex_out; a.n_flex_bldg = flex->n_flex_bldg;
         a.ev_penalty_coef = flex->cons_params ? flex->weights[CLEW_PENALTY_COEFFICIENT] : 0.0f;
     }
-    const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
+    const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL) || (tun.lean_variant & 4);   // 4: lean districts through cl_step_full_kernel (experiments)
     a.nw = tun.nw ? tun.nw : pick_nw(dims->n_bldg, 1);
     // general kernel: two buildings per wave measured fastest for the 6..16-building thermal schemas (fewer, longer waves)
     if (!tun.nw && full && dims->n_bldg >= 6 && dims->n_bldg <= 16) a.nw = (dims->n_bldg + 1) / 2;
@@ -904,9 +1010,9 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (tun.lean_variant & 2)) && !(tun.lean_variant & 1);
     if (flex && !full && lean_shape) {
         switch (vec) {
-        case 1: hipLaunchKernelGGL((cl_step_lean_kernel<1, true>), grid, block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL((cl_step_lean_kernel<2, true>), grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL((cl_step_lean_kernel<4, true>), grid, block, lds, s, a); break;
+        case 1: CL_LAUNCH_NT(cl_step_lean_kernel, 1, true); break;
+        case 2: CL_LAUNCH_NT(cl_step_lean_kernel, 2, true); break;
+        case 4: CL_LAUNCH_NT(cl_step_lean_kernel, 4, true); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else if (flex) {
@@ -928,13 +1034,17 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         // thermal / outage districts: the pack-generic kernel of cl_full.h
         const bool small = block.x <= 576;
         if (det) {
-            if (vec == 1) hipLaunchKernelGGL((cl_step_full_kernel<1, true, 1024, 4>), grid, block, lds, s, a);
-            else if (small) hipLaunchKernelGGL((cl_step_full_kernel<2, true, 576, 3>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((cl_step_full_kernel<2, true, 1024, 4>), grid, block, lds, s, a);
+            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, true, 1024, 4);
+            else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 576, 3);
+            else CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 1024, 4);
         } else {
-            if (vec == 1) hipLaunchKernelGGL((cl_step_full_kernel<1, false, 1024, 6>), grid, block, lds, s, a);
-            else if (small) hipLaunchKernelGGL((cl_step_full_kernel<2, false, 576, 5>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((cl_step_full_kernel<2, false, 1024, 5>), grid, block, lds, s, a);
+#ifdef CL_TRACE                  // the stamps need a few registers: five waves per SIMD (what the 9-building launch holds) instead of six
+            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5);
+#else
+            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 6);
+#endif
+            else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5);
+            else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 5);
         }
     } else if (full && det) {
         switch (vec) {
@@ -953,14 +1063,16 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         // two or more waves per SIMD: the env-major kernel (bench.py --envs-per-gpu: 17 x 131 072 17.0 vs 18.5 us,
         // 17 x 262 144 28.2 vs 32.5 us, 17 x 1 048 576 136 vs 157 us; at 17 x 65 536 -- one wave per SIMD, nothing to hide the
         // per-building dependency chain behind -- 13.1 vs 8.0 us)
-        hipLaunchKernelGGL(cl_step_envmajor_kernel<20>, dim3((unsigned)((dims->n_env + 255) / 256)), dim3(256), 0, s, a);
+        const dim3 egrid((unsigned)((dims->n_env + 255) / 256));
+        if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<20, true>), egrid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((cl_step_envmajor_kernel<20, false>), egrid, dim3(256), 0, s, a);
     } else if (lean_shape) {
         // one workgroup per CU at most: with more rounds the generic kernel's smaller register file (52 vs 88 VGPRs, two
         // workgroups per CU) wins again -- 17 x 262 144: 30.8 us vs 33.0 us
         switch (vec) {                                   // latency-ordered lean kernel (two buildings per wave at most)
-        case 1: hipLaunchKernelGGL(cl_step_lean_kernel<1>, grid, block, lds, s, a); break;
-        case 2: hipLaunchKernelGGL(cl_step_lean_kernel<2>, grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL(cl_step_lean_kernel<4>, grid, block, lds, s, a); break;
+        case 1: CL_LAUNCH_NT(cl_step_lean_kernel, 1, false); break;
+        case 2: CL_LAUNCH_NT(cl_step_lean_kernel, 2, false); break;
+        case 4: CL_LAUNCH_NT(cl_step_lean_kernel, 4, false); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else {
@@ -1052,6 +1164,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t0; a.b_chunk = dims->n_bldg; a.n_chunks = 1; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
+    a.nt = 0;
     r.act_stride_step = act_stride_step; r.act_low = act_low; r.act_high = act_high; r.ret_env = ret_env; r.seed = seed;
     r.t0 = t0; r.k_steps = k_steps;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);

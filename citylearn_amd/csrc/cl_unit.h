@@ -49,6 +49,14 @@ CL_DEV float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a,
 }
 #endif
 #define CL_ZDP 1e-6f          // data.py:19 ZERO_DIVISION_PLACEHOLDER
+// Place a wave-uniform value in a VGPR once and keep it there.  A VALU instruction reads at most one SGPR, so selecting between two
+// parameters (`lo ? b0 : b1`) costs a v_mov per use; the compiler re-materialises that copy for every env of a lane instead of
+// keeping it, because a copy is "free" to recompute.
+#ifdef CL_HOST_SHIM
+#define CL_PIN_V(x) ((void)0)
+#else
+#define CL_PIN_V(x) asm("" : "+v"(x))
+#endif
 
 namespace cl {
 
@@ -267,7 +275,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         // t = 0: the load is booked at reset, by the step, and again by update_variables
         const float c_ns = first ? 3.0f * R.nsl : R.nsl;
         const float c_b = first ? 2.0f * eb : eb;
-        const float net = (c_ns + c_b) * B.r + R.sol;
+        const float net = fmaf(c_ns + c_b, B.r, R.sol);          // (explicit: the lean kernels restate this line)
         O.net = net; O.cost = net * R.price; O.emission = fmaxf(0.0f, net * R.carbon);
         O.eb = eb; O.cool_dem = 0.0f; O.heat_dem = 0.0f; O.dhw_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns * B.r;
         O.base_net = net - c_b * B.r; O.net_ws = O.base_net; O.expected = R.nsl; O.served = R.nsl;
@@ -400,6 +408,38 @@ CL_DEV float unit_reward(int kind, const Bp& B, const State& S, float net) {
         const float m = fmaxf(net, 0.0f);
         return B.rw_exponent == 1.0f ? -m : -__powf(m, B.rw_exponent);
     }
+    }
+}
+
+// unit_reward<false> for the N envs of a lane with the (wave-uniform) switch outside the env loop: same expressions, same bits.
+template <int N>
+CL_DEV void lean_rewards(int kind, const Bp& B, const float (&soc)[N], const float (&net)[N], float (&rw)[N]) {
+    switch (kind) {
+    case CLR_INDEPENDENT_SAC:
+#pragma unroll
+        for (int i = 0; i < N; ++i) rw[i] = fminf(-net[i], 0.0f);
+        break;
+    case CLR_SOLAR_PENALTY: {
+        const bool has = pw(B.p, CLP_L_CAP) > CL_ZDP;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float sg = net[i] > 0.0f ? 1.0f : (net[i] < 0.0f ? -1.0f : 0.0f), an = fabsf(net[i]);
+            rw[i] = has ? -(1.0f + sg * soc[i]) * an : 0.0f;
+        }
+        break;
+    }
+    case CLR_MARL: case CLR_EV:
+#pragma unroll
+        for (int i = 0; i < N; ++i) rw[i] = net[i];
+        break;
+    default:
+        if (B.rw_exponent == 1.0f) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) rw[i] = -fmaxf(net[i], 0.0f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) rw[i] = -__powf(fmaxf(net[i], 0.0f), B.rw_exponent);
+        }
     }
 }
 

@@ -253,7 +253,8 @@ typedef struct cl_tuning {
     int32_t lstm_variant;   /* LSTM stage timing experiments (csrc/cl_lstm.h) */
     int32_t full_variant;   /* thermal / outage districts: 1 = the round-1 general kernel instead of cl_step_full_kernel (tests) */
     int32_t b_chunk;        /* building-chunked launches: buildings per workgroup row (with `nw` waves per workgroup) */
-    int32_t reserved[5];
+    int32_t nt_stores;      /* non-temporal hint on the step kernels' plane stores: 0 = by launch footprint, 1 = always, 2 = never */
+    int32_t reserved[4];
 } cl_tuning;
 
 typedef struct cl_dims {
