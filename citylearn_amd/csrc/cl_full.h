@@ -62,9 +62,18 @@ struct FP {
     float dt, r, cd_pow, hd_pow, dd_pow, t0_iheat_div, dyn_warmup, rw_exponent;
 };
 
+// LP: `f` is the workgroup's LDS copy of the block (cl_step_full_kernel<.., LP = true>).  The words a wave branches on or forms
+// addresses from go back to SGPRs; the float parameters stay in VGPRs, where a VALU instruction can read any number of them.
+template <bool LP>
+CL_DEV uint32_t uword(const uint32_t* __restrict__ f, int k) {
+    if constexpr (LP) return (uint32_t)__builtin_amdgcn_readfirstlane((int)f[k]);
+    else return f[k];
+}
+
+template <bool LP = false>
 CL_DEV void load_fp(FP& P, const uint32_t* __restrict__ f) {
     P.f = f;
-    P.flags = f[0]; P.a_cd = (int)f[5]; P.a_hd = (int)f[6]; P.a_coh = (int)f[7];
+    P.flags = uword<LP>(f, 0); P.a_cd = (int)uword<LP>(f, 5); P.a_hd = (int)uword<LP>(f, 6); P.a_coh = (int)uword<LP>(f, 7);
     P.dt = cl::pw(f, 8); P.r = cl::pw(f, 9); P.cd_pow = cl::pw(f, 10); P.hd_pow = cl::pw(f, 11); P.dd_pow = cl::pw(f, 12);
     P.t0_iheat_div = cl::pw(f, 13); P.dyn_warmup = cl::pw(f, 14); P.rw_exponent = cl::pw(f, 15);
 }
@@ -344,11 +353,12 @@ CL_DEV typename Vec<VEC>::type full_action(const StepArgs& a, int col, int env0)
 
 // `f`: the building's CLP_F_* block; its first eight words (flags + the seven action columns) are read as one batch before
 // any of them is tested, so the whole load phase costs one scalar round trip.
-template <int VEC>
+template <int VEC, bool LP = false>
 CL_DEV void full_load_in(FullIn<typename Vec<VEC>::type>& in, const StepArgs& a, const uint32_t* __restrict__ f, int b, int env0, long long plane) {
     using F = typename Vec<VEC>::type;
-    const uint32_t flags = f[0];
-    const int c_cs = (int)f[1], c_hs = (int)f[2], c_ds = (int)f[3], c_es = (int)f[4], c_cd = (int)f[5], c_hd = (int)f[6], a_coh = (int)f[7];
+    const uint32_t flags = clv::uword<LP>(f, 0);
+    const int c_cs = (int)clv::uword<LP>(f, 1), c_hs = (int)clv::uword<LP>(f, 2), c_ds = (int)clv::uword<LP>(f, 3), c_es = (int)clv::uword<LP>(f, 4),
+              c_cd = (int)clv::uword<LP>(f, 5), c_hd = (int)clv::uword<LP>(f, 6), a_coh = (int)clv::uword<LP>(f, 7);
     in.flags = flags;
     const long long off = (long long)b * a.n_env + env0;
     const F zero = (F)(0.0f), one = (F)(1.0f);
@@ -408,10 +418,22 @@ CL_DEV void full_accumulate(float (&q)[VEC], typename Vec<VEC>::type v) {
 // (Measured and dropped, MI355X, 2020 schema 9 x 65 536, profiles/r02_thermal_sweep.log: issuing the state / action loads of a
 //  wave's NEXT building before computing the current one -- 9.6 vs 8.8 us; one wave per SIMD walking all nine buildings, with or
 //  without that prefetch -- 18 us, i.e. 2 us per building of which 0.45 us is arithmetic: the scalar parameter round trips are
-//  what a lone wave cannot hide, so the launch wants several waves per SIMD rather than a deeper per-wave pipeline.)
-template <int VEC, bool DETAIL, int MAXT, int WPE, bool NT>
+//  what a lone wave cannot hide, so the launch wants several waves per SIMD rather than a deeper per-wave pipeline.  Round 2, with
+//  the ISA checked this time -- the first version's loop counter had gone to a VGPR, which turns every parameter read into a vector
+//  load; with the `live` test outside the loop it stays scalar: the same prefetch on the C4 shard, 1024 x 1024 in 32-building
+//  chunks, where every wave of a SIMD is in the same phase: 16.4 vs 16.2 us without.  What a wave waits for between two buildings
+//  is the scalar parameter chain of the next one, not its plane loads.)
+// LP: the parameter blocks and time-series rows of the workgroup's buildings are staged in LDS by one cooperative round of vector
+// loads (CL_LP_WORDS words per building behind the reduction area) instead of arriving through each wave's chain of dependent
+// scalar loads -- flags -> head + row -> one tank after the other -> battery -- which is what a wave of the building-chunked launch
+// spends its time on (scripts/wave_timeline.py, 1024 x 1024: 2.1 us from entry to the first building's inputs, 1.9 us between
+// the first building's stores and the second one's inputs, next to 2 x 2.0 us of arithmetic).  As VGPR operands the parameters
+// also stop costing a v_mov per two-scalar instruction, and the SGPR file no longer spills.
+constexpr int CL_LP_WORDS = (CLP_F_LAST - CLP_F_FIRST + 1) + CL_NF;      // 64 + 16
+
+template <int VEC, bool DETAIL, int MAXT, int WPE, bool LP, bool NT>
 __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_kernel(const StepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC], then (LP) [buildings of the workgroup][CL_LP_WORDS]
     using F = typename Vec<VEC>::type;
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
@@ -434,15 +456,27 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
     CL_TRACE_ENTRY(0);
     CL_TRACE_CYCLES_ENTRY(4);     // shader-clock cycles at entry (slot 12: at the end) -- gives the clock the launch ran at
     [[maybe_unused]] int tr_i = 0;
+    [[maybe_unused]] uint32_t* stage = reinterpret_cast<uint32_t*>(lds + (size_t)a.nw * NQ * TILE);
+    if constexpr (LP) {
+        static_assert(!DETAIL, "the evaluate()-time COP row of the detail planes is not staged");
+        const int n_words = (b_hi - b_lo) * CL_LP_WORDS;
+        const uint32_t* __restrict__ tsw = reinterpret_cast<const uint32_t*>(a.ts);
+        for (int i = threadIdx.x; i < n_words; i += blockDim.x) {
+            const int j = i / CL_LP_WORDS, k = i - j * CL_LP_WORDS, b = b_lo + j;
+            stage[i] = k < CL_LP_WORDS - CL_NF ? a.params[(long long)b * CL_NP + CLP_F_FIRST + k]
+                                               : tsw[((long long)ts_row * a.n_bldg + b) * CL_NF + (k - (CL_LP_WORDS - CL_NF))];
+        }
+        __syncthreads();
+    }
     for (int b = b_lo + w; b < b_hi; b += a.nw) {
         if (live) {
-            const uint32_t* __restrict__ f = a.params + (long long)b * CL_NP + CLP_F_FIRST;
+            const uint32_t* __restrict__ f = LP ? stage + (b - b_lo) * CL_LP_WORDS : a.params + (long long)b * CL_NP + CLP_F_FIRST;
             FullIn<F> cur;
-            full_load_in<VEC>(cur, a, f, b, env0, plane);
+            full_load_in<VEC, LP>(cur, a, f, b, env0, plane);
             clv::FP B;
-            clv::load_fp(B, f);
+            clv::load_fp<LP>(B, f);
             cl::Row R;
-            cl::load_row_scalar<true>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags,
+            cl::load_row_scalar<true>(R, LP ? reinterpret_cast<const float*>(f + (CL_LP_WORDS - CL_NF)) : a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags,
                                       DETAIL ? a.ts + ((long long)(ts_row - a.t + a.n_steps - 1) * a.n_bldg + b) * CL_NF : nullptr);
             CL_TRACE_INPUTS(1 + 4 * tr_i, cur);
             clv::St<F> S = {cur.soc, cur.eff, cur.deg, cur.cs, cur.hs, cur.ds};

@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
             cl::lean_rewards<VEC>(rkind, B, soc_rw, o_net, o_rw);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                q_net[i] += o_net[i]; q_cost[i] += o_net[i] * R.price; q_em[i] += fmaxf(0.0f, o_net[i] * R.carbon);
+                q_net[i] += o_net[i]; q_cost[i] += cl::mul_rn(o_net[i], R.price); q_em[i] += fmaxf(0.0f, o_net[i] * R.carbon);
                 q_rw[i] += o_rw[i];
             }
         }
@@ -1003,10 +1003,14 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     if (a.n_chunks > 1 && rkind_host == CLR_EV)
         return fail(CL_EINVAL, "reward kind CLR_EV is not implemented for building-chunked launches (n_bldg=%d)", dims->n_bldg);
     const dim3 grid(grid_x, a.n_chunks);
-    const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
+    const bool det = dims->flags & CLD_WRITE_DETAIL;
+    // thermal kernel with the parameter blocks of the workgroup's buildings staged in LDS
+    // (for the building-chunked launches only -- a workgroup of the 9 x 65 536 launch would wait for the staging round trip before it
+    //  can issue its plane loads, while its scalar reads hit the constant cache: 10.7 vs 8.7 us; full_variant = 2 forces it, 3 forbids it)
+    const bool lp = full && !flex && !det && tun.full_variant != 1 && tun.full_variant != 3 && vec <= 2 && (a.n_chunks > 1 || tun.full_variant == 2);
+    const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float) + (lp ? (size_t)a.b_chunk * CL_LP_WORDS * sizeof(uint32_t) : 0);
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
-    const bool det = dims->flags & CLD_WRITE_DETAIL;
     const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (tun.lean_variant & 2)) && !(tun.lean_variant & 1);
     if (flex && !full && lean_shape) {
         switch (vec) {
@@ -1034,17 +1038,22 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         // thermal / outage districts: the pack-generic kernel of cl_full.h
         const bool small = block.x <= 576;
         if (det) {
-            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, true, 1024, 4);
-            else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 576, 3);
-            else CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 1024, 4);
+            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, true, 1024, 4, false);
+            else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 576, 3, false);
+            else CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 1024, 4, false);
+        } else if (lp) {
+            // parameter blocks staged in LDS (cl_full.h); full_variant = 3 keeps them in SGPRs (tests, A/B)
+            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
+            else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5, false);      // (96 VGPRs do not hold the staged operands: 61 scratch accesses)
+            else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 4, true);
         } else {
 #ifdef CL_TRACE                  // the stamps need a few registers: five waves per SIMD (what the 9-building launch holds) instead of six
-            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5);
+            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, false);
 #else
-            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 6);
+            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 6, false);
 #endif
-            else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5);
-            else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 5);
+            else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5, false);
+            else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 5, false);
         }
     } else if (full && det) {
         switch (vec) {

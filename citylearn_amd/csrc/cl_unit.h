@@ -82,6 +82,13 @@ struct Bp {         // what stays live for the whole unit
 
 CL_DEV float pw(const uint32_t* __restrict__ p, int slot) { return __uint_as_float(p[slot]); }
 
+// a * b that is never fused into a following add: the district cost is a sum of rounded per-building products (citylearn.py:1909-1918),
+// and whether `q += net * price` became an fma used to depend on the instantiation (one vs two vs four envs per lane).
+CL_DEV float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 CL_DEV void load_batt(BattP& B, const uint32_t* __restrict__ p) {
     B.r = pw(p, CLP_L_TSR); B.pdt = pw(p, CLP_L_PDT); B.pow = pw(p, CLP_L_POW); B.cap = pw(p, CLP_L_CAP);
     B.capl = pw(p, CLP_L_CAPL); B.inv_cap = pw(p, CLP_L_INV_CAP); B.inv_pow = pw(p, CLP_L_INV_POW);
@@ -276,7 +283,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         const float c_ns = first ? 3.0f * R.nsl : R.nsl;
         const float c_b = first ? 2.0f * eb : eb;
         const float net = fmaf(c_ns + c_b, B.r, R.sol);          // (explicit: the lean kernels restate this line)
-        O.net = net; O.cost = net * R.price; O.emission = fmaxf(0.0f, net * R.carbon);
+        O.net = net; O.cost = mul_rn(net, R.price); O.emission = fmaxf(0.0f, net * R.carbon);
         O.eb = eb; O.cool_dem = 0.0f; O.heat_dem = 0.0f; O.dhw_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns * B.r;
         O.base_net = net - c_b * B.r; O.net_ws = O.base_net; O.expected = R.nsl; O.served = R.nsl;
         O.se_cool = O.se_heat = O.se_dhw = 0.0f;
@@ -344,7 +351,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
             A.c_b += eb_b;
         }
         const float net = R.outage ? 0.0f : (A.c_cool + A.c_heat + A.c_dhw + A.c_ns + A.c_b) * B.r + R.sol;
-        O.net = net; O.cost = net * R.price; O.emission = fmaxf(0.0f, net * R.carbon);
+        O.net = net; O.cost = mul_rn(net, R.price); O.emission = fmaxf(0.0f, net * R.carbon);
         O.eb = eb_b;
         O.cool_dem = e_cool + fabsf(fminf(eb_cs, 0.0f));          // building.py:1435-1437
         O.heat_dem = e_heat + fabsf(fminf(eb_hs, 0.0f));
@@ -370,7 +377,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
 CL_DEV void apply_flex(bool outage, float price, float carbon, float load, float chargers, Out& O) {
     if (!outage) {
         O.net += load;
-        O.cost = O.net * price;
+        O.cost = mul_rn(O.net, price);
         O.emission = fmaxf(0.0f, O.net * carbon);
         O.base_net += load;
         O.net_ws += load;

@@ -11,10 +11,15 @@ if os.environ.get('CL_ALT_LIB'):
 from golden_util import golden
 from citylearn_amd.engine import StepEngine
 from c4_bench import measure
-SHAPES = {'thermal': ('g2020_cz1', 65536), 'c3': ('g2023_p2', 65536), 'lean': ('g2022_all', 65536), 'lean1m': ('g2022_all', 1048576)}
+SHAPES = {'thermal': ('g2020_cz1', 65536), 'c3': ('g2023_p2', 65536), 'lean': ('g2022_all', 65536), 'lean1m': ('g2022_all', 1048576),
+          'c4': ('g2020_cz1', 1024, 1024), 'c4lean': ('g2022_all', 1024, 1024), 'thermal256k': ('g2020_cz1', 262144)}
 for name in (sys.argv[1:] or ['thermal', 'c3', 'lean']):
-    fx, E = SHAPES[name]
-    spec = golden(fx).spec(); tab = spec.episode_tables(0)
+    fx, E, *tile = SHAPES[name]
+    spec = golden(fx).spec()
+    if tile:
+        from citylearn_amd.synthetic import tile_district
+        spec = tile_district(spec, tile[0])
+    tab = spec.episode_tables(0)
     low, high = spec.action_limits()
     lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
     acts = [lo[:, None] + torch.rand((len(low), E), device='cuda') * (hi - lo)[:, None] for _ in range(2)]
