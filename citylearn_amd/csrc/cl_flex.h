@@ -69,7 +69,7 @@ CL_DEV float flex_curve(const uint32_t* __restrict__ cp, int n_slot, int x_slot,
 }
 
 // VEC consecutive envs per lane (float4 plane accesses at VEC = 4: a quarter of the waves walk the scalar table chain).
-template <int VEC>
+template <int VEC, bool NT>
 __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
         vload<VEC>(soc, sp);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) soc[i] = flex_begin_soc(a, er, row, k, env0 + i, soc[i]);
-        vstore<VEC>(sp, soc);
+        pstore<VEC, NT>(sp, soc);
         return;
     }
 
@@ -199,10 +199,10 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
             }
         }
         const long long fpc = (long long)f.n_flex_bldg * a.n_env, oc = (long long)u * a.n_env + env0;
-        vstore<VEC>(f.flex_out + CLX_VIOLATION * fpc + oc, viol);
-        vstore<VEC>(f.flex_out + CLX_HEADROOM * fpc + oc, head_b);
+        pstore<VEC, NT>(f.flex_out + CLX_VIOLATION * fpc + oc, viol);
+        pstore<VEC, NT>(f.flex_out + CLX_HEADROOM * fpc + oc, head_b);
 #pragma unroll
-        for (int p = 0; p < CL_MAXPH; ++p) vstore<VEC>(f.flex_out + (CLX_HEADROOM_PHASE0 + p) * fpc + oc, head_p[p]);
+        for (int p = 0; p < CL_MAXPH; ++p) pstore<VEC, NT>(f.flex_out + (CLX_HEADROOM_PHASE0 + p) * fpc + oc, head_p[p]);
     }
 
     float chargers[VEC], wms[VEC], k0[VEC], kneg[VEC], kpos[VEC];
@@ -278,14 +278,14 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
                     else if (energy[i] < 0.0f) { kneg[i] += -0.5f * f.weights[CLEW_EXTRA_SELF_PRODUCTION]; kpos[i] += f.weights[CLEW_SELF_EV_CONSUMPTION]; }
                 }
             }
-            vstore<VEC>(sp, soc[j]);
-            if (charged) { vstore<VEC>(sp + ev_plane, ef[j]); vstore<VEC>(sp + 2 * ev_plane, deg[j]); }
+            pstore<VEC, NT>(sp, soc[j]);
+            if (charged) { pstore<VEC, NT>(sp + ev_plane, ef[j]); pstore<VEC, NT>(sp + 2 * ev_plane, deg[j]); }
         }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) chargers[i] += cons[i];
         if (f.charger_out) {
-            vstore<VEC>(f.charger_out + (long long)c * a.n_env + env0, cons);
-            vstore<VEC>(f.charger_out + ((long long)f.n_flex_bldg * CL_MAXC + c) * a.n_env + env0, energy);
+            pstore<VEC, NT>(f.charger_out + (long long)c * a.n_env + env0, cons);
+            pstore<VEC, NT>(f.charger_out + ((long long)f.n_flex_bldg * CL_MAXC + c) * a.n_env + env0, energy);
         }
     }
 #pragma unroll
@@ -303,19 +303,19 @@ __global__ void __launch_bounds__(256) cl_flex_kernel(const FlexArgs a) {
             }
             winit[j][i] = initiated ? 1.0f : 0.0f;
         }
-        vstore<VEC>(f.wm_state + (long long)(u * CL_MAXW + j) * a.n_env + env0, winit[j]);
+        pstore<VEC, NT>(f.wm_state + (long long)(u * CL_MAXW + j) * a.n_env + env0, winit[j]);
     }
     if (!live) return;
     const long long fp = (long long)f.n_flex_bldg * a.n_env, o = (long long)u * a.n_env + env0;
     float total[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) total[i] = chargers[i] + wms[i];
-    vstore<VEC>(f.flex_out + CLX_LOAD * fp + o, total);
-    if (a.want_chargers) vstore<VEC>(f.flex_out + CLX_CHARGERS * fp + o, chargers);
+    pstore<VEC, NT>(f.flex_out + CLX_LOAD * fp + o, total);
+    if (a.want_chargers) pstore<VEC, NT>(f.flex_out + CLX_CHARGERS * fp + o, chargers);
     if (a.want_reward) {
-        vstore<VEC>(f.flex_out + CLX_RW_K0 * fp + o, k0);
-        vstore<VEC>(f.flex_out + CLX_RW_KNEG * fp + o, kneg);
-        vstore<VEC>(f.flex_out + CLX_RW_KPOS * fp + o, kpos);
+        pstore<VEC, NT>(f.flex_out + CLX_RW_K0 * fp + o, k0);
+        pstore<VEC, NT>(f.flex_out + CLX_RW_KNEG * fp + o, kneg);
+        pstore<VEC, NT>(f.flex_out + CLX_RW_KPOS * fp + o, kpos);
     }
 }
 

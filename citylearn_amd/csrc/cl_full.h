@@ -70,6 +70,10 @@ CL_DEV uint32_t uword(const uint32_t* __restrict__ f, int k) {
     else return f[k];
 }
 
+// (Tried instead of LP for the launches that are not building-chunked: the tank and battery words fetched by VECTOR loads from the
+//  uniform block address -- no staging barrier, no v_mov per two-scalar select, SGPR spill traffic 80 -> 8 lane moves, 11 % fewer
+//  VALU instructions in the loop -- 2020 schema 9 x 65 536: 8.62 vs 8.65 us.  That launch is not bound by instruction issue but by
+//  its phases: scripts/wave_timeline.py shows the 21 MB read burst of the first buildings taking 2.4 us to reach the last wave.)
 template <bool LP = false>
 CL_DEV void load_fp(FP& P, const uint32_t* __restrict__ f) {
     P.f = f;

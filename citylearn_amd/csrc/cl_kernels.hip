@@ -960,11 +960,15 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         int fvec = dims->n_env >= 16384 ? 4 : 1;
         if (tun.flex_vec) fvec = tun.flex_vec;
         const dim3 fgrid((unsigned)((dims->n_env + 64 * fvec - 1) / (64 * fvec)), gy);
+#define CL_FLEX_LAUNCH(V) do { \
+            if (a.nt) hipLaunchKernelGGL((cl_flex_kernel<V, true>), fgrid, dim3(256), 0, (hipStream_t)stream, fa); \
+            else hipLaunchKernelGGL((cl_flex_kernel<V, false>), fgrid, dim3(256), 0, (hipStream_t)stream, fa); } while (0)
         switch (fvec) {
-        case 4: hipLaunchKernelGGL(cl_flex_kernel<4>, fgrid, dim3(256), 0, (hipStream_t)stream, fa); break;
-        case 2: hipLaunchKernelGGL(cl_flex_kernel<2>, fgrid, dim3(256), 0, (hipStream_t)stream, fa); break;
-        default: hipLaunchKernelGGL(cl_flex_kernel<1>, fgrid, dim3(256), 0, (hipStream_t)stream, fa); break;
+        case 4: CL_FLEX_LAUNCH(4); break;
+        case 2: CL_FLEX_LAUNCH(2); break;
+        default: CL_FLEX_LAUNCH(1); break;
         }
+#undef CL_FLEX_LAUNCH
         a.flex_out = flex->flex_out; a.n_flex_bldg = flex->n_flex_bldg;
         a.ev_penalty_coef = flex->cons_params ? flex->weights[CLEW_PENALTY_COEFFICIENT] : 0.0f;
     }

@@ -20,6 +20,8 @@ if os.environ.get('CL_ALT_LIB'):                # A/B experiments: a second buil
 from citylearn_amd.engine import StepEngine     # noqa: E402
 from golden_util import golden                  # noqa: E402
 
+TUN = dict((k, int(v)) for k, v in (kv.split('=') for kv in os.environ.get('CL_TUNING', '').split(',') if kv))   # e.g. CL_TUNING=nt_stores=2
+
 
 def timed(eng, a, steps=200, warm=20):
     T = eng.n_steps
@@ -63,7 +65,7 @@ def main():
     tab = spec.episode_tables(0)
     out = {'n_env': E}
     for reward in ('MARL', 'Electric_Vehicles_Reward_Function'):
-        eng = StepEngine(tab, E, reward=reward)
+        eng = StepEngine(tab, E, reward=reward, tuning=TUN)
         a = (torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1).contiguous()
         for fv in (1, 2, 4):
             eng.tuning.flex_vec = fv
@@ -71,7 +73,7 @@ def main():
         eng.tuning.flex_vec = 0
         out[f'graph/{reward}'] = round(timed_graph(eng, a), 2)
     # K-step rollout with the on-device policy (cl_rollout_seq_f32: policy plane + flex + step + return per step), one graph
-    eng = StepEngine(tab, E, reward='MARL')
+    eng = StepEngine(tab, E, reward='MARL', tuning=TUN)
     low, high = spec.action_limits()
     eng.set_action_limits(low, high)
     ret = torch.zeros(E, device='cuda')
@@ -92,7 +94,7 @@ def main():
     import copy
     plain = copy.copy(tab)
     plain.flex = None
-    eng = StepEngine(plain, E, reward='MARL', n_act_cols=tab.flex.n_act_cols)
+    eng = StepEngine(plain, E, reward='MARL', n_act_cols=tab.flex.n_act_cols, tuning=TUN)
     a = (torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1).contiguous()
     out['no_flex/MARL'] = round(timed(eng, a), 2)
     out['graph/no_flex/MARL'] = round(timed_graph(eng, a), 2)
