@@ -1194,7 +1194,10 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     const int key = (full ? 100 : 0) + vec * 10 + mb;
     switch (key) {
     case 11: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 1>), dim3(grid), block, lds, s, r); break;
-    case 12: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2>), dim3(grid), block, lds, s, r); break;
+    case 12:
+        if ((long long)grid * a.nw > 5 * 1024) hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2>), dim3(grid), block, lds, s, r);
+        else hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, false>), dim3(grid), block, lds, s, r);      // whole launch resident at once: see PIN
+        break;
     case 21: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 1>), dim3(grid), block, lds, s, r); break;
     case 22: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2>), dim3(grid), block, lds, s, r); break;
     case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), dim3(grid), block, lds, s, r); break;

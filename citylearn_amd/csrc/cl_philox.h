@@ -35,8 +35,19 @@ inline float u01(uint32_t word) { return (float)(word >> 8) * (1.0f / 16777216.0
 #ifdef __HIPCC__
 __host__ __device__
 #endif
+inline uint32_t philox_word(const U4& b, uint32_t sel) {
+    // two-level select, not `b.w[sel]`: a dynamically indexed array goes through scratch memory on the GPU (a 16-byte store and a load
+    // per draw inside the rollout loop)
+    const uint32_t w0 = b.w[0], w1 = b.w[1], w2 = b.w[2], w3 = b.w[3];
+    const uint32_t lo = (sel & 1u) ? w1 : w0, hi = (sel & 1u) ? w3 : w2;
+    return (sel & 2u) ? hi : lo;
+}
+
+#ifdef __HIPCC__
+__host__ __device__
+#endif
 inline float philox_u01(unsigned long long seed, uint32_t env, uint32_t col, uint32_t t) {
-    return u01(philox_block(seed, env, col, t >> 2).w[t & 3]);
+    return u01(philox_word(philox_block(seed, env, col, t >> 2), t & 3u));
 }
 
 }  // namespace cl

@@ -26,8 +26,11 @@ struct RolloutArgs {
 };
 
 // Electrical-storage action with the Philox block cached across four steps (wave-uniform refresh).
+// (The block is kept as four separate words per env: held as one `U4` the compiler turned the wave-uniform word select into a
+//  dynamically indexed array -- a 16-byte scratch store and a scratch load per env and step inside the rollout loop.)
+struct PhiloxCache { uint32_t w0, w1, w2, w3; };
 template <int VEC>
-CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k, bool live);
+CL_DEV void rollout_action_cached(float (&dst)[VEC], PhiloxCache (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k, bool live);
 
 // `live`: lanes past the end of the batch (ragged last tile) must not touch the open-loop action tensor.
 template <int VEC>
@@ -53,23 +56,30 @@ CL_DEV void rollout_action(float (&dst)[VEC], const RolloutArgs& r, int col, int
 }
 
 template <int VEC>
-CL_DEV void rollout_action_cached(float (&dst)[VEC], cl::U4 (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k, bool live) {
+CL_DEV void rollout_action_cached(float (&dst)[VEC], PhiloxCache (&cache)[VEC], const RolloutArgs& r, int col, int env0, int t, int k, bool live) {
     if (col < 0 || r.s.actions) { rollout_action<VEC>(dst, r, col, env0, t, k, live); return; }
     if (k == 0 || (t & 3) == 0) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) cache[i] = cl::philox_block(r.seed, (uint32_t)(env0 + i) + r.s.env_offset, (uint32_t)col, (uint32_t)t >> 2);
+        for (int i = 0; i < VEC; ++i) {
+            const cl::U4 blk = cl::philox_block(r.seed, (uint32_t)(env0 + i) + r.s.env_offset, (uint32_t)col, (uint32_t)t >> 2);
+            cache[i].w0 = blk.w[0]; cache[i].w1 = blk.w[1]; cache[i].w2 = blk.w[2]; cache[i].w3 = blk.w[3];
+        }
     }
     const float lo = r.act_low[col], span = r.act_high[col] - lo;
     const int sel = t & 3;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-        const uint32_t word = sel == 0 ? cache[i].w[0] : sel == 1 ? cache[i].w[1] : sel == 2 ? cache[i].w[2] : cache[i].w[3];
+        // (words copied to locals first: a select between struct members becomes a select between their ADDRESSES, which parks the
+        //  struct in scratch memory)
+        const uint32_t w0 = cache[i].w0, w1 = cache[i].w1, w2 = cache[i].w2, w3 = cache[i].w3;
+        const uint32_t lo_w = (sel & 1) ? w1 : w0, hi_w = (sel & 1) ? w3 : w2;
+        const uint32_t word = (sel & 2) ? hi_w : lo_w;
         dst[i] = fmaf(cl::u01(word), span, lo);
     }
 }
 
 // MB = buildings owned by one wave (wave w owns w, w + nw, ...): their State stays in registers for all K steps.
-template <int VEC, bool FULL, int MB>
+template <int VEC, bool FULL, int MB, bool PIN = true>
 __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     const StepArgs& a = r.s;
@@ -110,13 +120,28 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
             }
         }
     }
+    [[maybe_unused]] cl::BattP Bv[MB];
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            Bv[m] = B[m].batt;
+            // PIN: the curve parameters in VGPRs for all K steps.  Not for one env per lane x two buildings per wave while the whole launch
+            // is resident at once (17 x 32 768: 4.5 waves per SIMD): 24 more VGPRs (67 -> 90) leave five waves per SIMD, the second 9-wave
+            // workgroup of a CU then only fits where the dispatcher happens to start it, and every launch pays ~3 us (2.77 vs 2.60 us per
+            // step at K = 24); from 65 536 envs up the launch runs in several generations anyway and the pins win (4.99 vs 5.75 us per step).
+            if constexpr (!PIN) continue;
+            CL_PIN_V(Bv[m].cpc_a0); CL_PIN_V(Bv[m].cpc_b0); CL_PIN_V(Bv[m].cpc_a1); CL_PIN_V(Bv[m].cpc_b1);
+            CL_PIN_V(Bv[m].pec_a0); CL_PIN_V(Bv[m].pec_b0); CL_PIN_V(Bv[m].pec_a1); CL_PIN_V(Bv[m].pec_b1);
+            CL_PIN_V(Bv[m].pec_a2); CL_PIN_V(Bv[m].pec_b2); CL_PIN_V(Bv[m].pec_a3); CL_PIN_V(Bv[m].pec_b3);
+        }
+    }
     float ret[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) ret[i] = 0.0f;
     float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
     cl::Out last[MB][VEC];
     float last_rw[MB][VEC];
-    cl::U4 rnd[MB][VEC];
+    PhiloxCache rnd[MB][VEC];
 
     const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * 64 * VEC) / CL_ROW0_BLOCK] : 0;   // workgroup-uniform
     for (int k = 0; k < r.k_steps; ++k) {
@@ -146,14 +171,37 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
                     rollout_action<VEC>(a_hd, r, B[m].a_hd, env0, t, k, live);
                 }
             }
+            if constexpr (!FULL) {
+                // the lean unit with its per-building uniforms outside the env loop (same expressions as cl::unit_step<false> /
+                // cl::unit_reward<false>: see cl_step_lean_kernel); the battery's curve parameters sit in VGPRs for all K steps
+                const bool first = quirk && t == 0;
+                float c_ns = first ? 3.0f * R.nsl : R.nsl, sol = R.sol;
+                const float cbk = first ? 2.0f : 1.0f;
+                if constexpr (VEC > 1) { CL_PIN_V(c_ns); CL_PIN_V(sol); }
+                const bool batt = B[m].flags & CLF_BATTERY;
+                float nets[VEC], socs[VEC], rws[VEC];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                cl::Act act = {0.0f, 0.0f, 0.0f, a_es[i], 0.0f, 0.0f};
-                if constexpr (FULL) act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
-                cl::unit_step<FULL>(B[m], R, t, quirk, act, S[m][i], last[m][i]);
-                const float rw = cl::unit_reward<FULL>(rkind, B[m], S[m][i], last[m][i].net);
-                last_rw[m][i] = rw;
-                q_net[i] += last[m][i].net; q_cost[i] += last[m][i].cost; q_em[i] += last[m][i].emission; q_rw[i] += rw;
+                for (int i = 0; i < VEC; ++i) {
+                    float eb = 0.0f;
+                    if (batt) eb = cl::battery_energy(Bv[m], a_es[i] * Bv[m].pdt, S[m][i]);
+                    nets[i] = fmaf(c_ns + cbk * eb, B[m].r, sol);
+                    socs[i] = S[m][i].soc;
+                }
+                cl::lean_rewards<VEC>(rkind, B[m], socs, nets, rws);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    last[m][i].net = nets[i]; last_rw[m][i] = rws[i];
+                    q_net[i] += nets[i]; q_cost[i] += cl::mul_rn(nets[i], R.price); q_em[i] += fmaxf(0.0f, nets[i] * R.carbon); q_rw[i] += rws[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const cl::Act act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
+                    cl::unit_step<FULL>(B[m], R, t, quirk, act, S[m][i], last[m][i]);
+                    const float rw = cl::unit_reward<FULL>(rkind, B[m], S[m][i], last[m][i].net);
+                    last_rw[m][i] = rw;
+                    q_net[i] += last[m][i].net; q_cost[i] += last[m][i].cost; q_em[i] += last[m][i].emission; q_rw[i] += rw;
+                }
             }
         }
         if (rkind == CLR_MARL) {

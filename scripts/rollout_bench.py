@@ -6,11 +6,15 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
 from golden_util import golden
+import os
+from citylearn_amd import _lib
+if os.environ.get('CL_ALT_LIB'):           # A/B experiments: a second build of the library
+    _lib.LIB_PATH = Path(os.environ['CL_ALT_LIB']).resolve()
 from citylearn_amd.engine import StepEngine
 
 g = golden('g2022_all'); spec = g.spec(); tab = spec.episode_tables(0)
 low, high = spec.action_limits()
-for E in (32768, 65536, 262144):
+for E in [int(x) for x in sys.argv[1:]] or (32768, 65536, 262144):
     for K in (24, 96):
         eng = StepEngine(tab, E); eng.set_action_limits(low, high)
         ret = torch.zeros(E, device='cuda')
