@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
         if (live && b < a.n_bldg) {               // wave-uniform in b; no `break`: it would push the arrays to scratch
             const long long off = (long long)b * a.n_env + env;
 // (non-temporal loads here: no effect between 131 072 and 1 048 576 envs, scripts/stream_floor.py -- the copy-floor pattern
-            //  gains 9 % from them at 1 048 576 envs, 120 -> 109 us, this kernel's byte-sized loads do not)
+            //  gains 9 % from them at 1 048 576 envs, 120 -> 109 us; this kernel's 4-byte-per-lane loads do not)
             s_soc[b] = a.state[CLS_B_SOC * plane + off];
             s_eff[b] = a.state[CLS_B_EFF * plane + off];
             s_deg[b] = a.state[CLS_B_DEGCAP * plane + off];

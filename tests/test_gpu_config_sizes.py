@@ -160,3 +160,41 @@ def test_c5_rollout_kernel_at_131072_envs(kind):
     torch.testing.assert_close(roll.state[:, :, E - n:], step.state, rtol=2e-6, atol=2e-6)
     torch.testing.assert_close(roll.out_bldg[:2, :, E - n:], step.out_bldg[:2], rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(ret[E - n:], ret_ref, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize('name,E,kind', [('g2022_all', 65536, 'RewardFunction'), ('g2022_all', 131072, 'MARL'), ('g2020_cz1', 16384, 'SolarPenaltyReward'),
+                                         ('g2023_p2', 65536, 'RewardFunction')])
+def test_store_policy_does_not_change_results(name, E, kind):
+    """Non-temporal plane stores / loads (`cl_tuning.nt_stores`, selected by launch size: csrc/cl_kernels.hip `pstore`) are a cache hint:
+    every plane and district sum is bit-identical with the hint forced on and forced off -- lean kernel at the headline size, env-major
+    kernel, thermal kernel (one and nine buildings per district row)."""
+    tab = golden(name).spec().episode_tables(0)
+    on, off = (StepEngine(tab, E, reward=kind, tuning=dict(nt_stores=v)) for v in (1, 2))
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    for t in range(6):
+        a = torch.rand((on.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        on.step(a, t); off.step(a, t)
+        assert torch.equal(on.state, off.state) and torch.equal(on.out_env, off.out_env), t
+        assert torch.equal(on.out_bldg[:2], off.out_bldg[:2]), t
+
+
+@pytest.mark.parametrize('kind', ['RewardFunction', 'MARL'])
+def test_lds_staged_parameters_match_scalar_parameters(kind):
+    """Building-chunked launches read their parameter blocks from LDS (`cl_step_full_kernel<.., LP = true>`); `full_variant = 3` keeps
+    them in SGPRs.  Same arithmetic, same bits -- on a 200-building thermal district (13 chunks of 16 buildings, ragged last chunk,
+    ragged env tile) and with the staging forced on a district that is not chunked."""
+    from citylearn_amd.synthetic import tile_district
+    spec = tile_district(golden('g2020_cz1').spec(), 200)
+    tab = spec.episode_tables(0)
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda()[:, None], torch.from_numpy(high).cuda()[:, None]
+    for tables, E, tun_lds in ((tab, 388, dict()), (golden('g2020_cz1').spec().episode_tables(0), 516, dict(full_variant=2))):
+        lds, sgpr = StepEngine(tables, E, reward=kind, tuning=tun_lds), StepEngine(tables, E, reward=kind, tuning=dict(full_variant=3))
+        n = lds.n_act_cols
+        gen = torch.Generator(device='cuda').manual_seed(5)
+        for t in range(8):
+            u = torch.rand((n, E), device='cuda', generator=gen)
+            a = (lo[:n] + u * (hi[:n] - lo[:n])).contiguous() if n == len(low) else u * 2 - 1
+            lds.step(a, t); sgpr.step(a, t)
+            assert torch.equal(lds.state, sgpr.state) and torch.equal(lds.out_env, sgpr.out_env), t
+            assert torch.equal(lds.out_bldg[:2], sgpr.out_bldg[:2]), t
