@@ -533,6 +533,99 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
     CL_TRACE_FLUSH();
 }
 
+// Thermal / outage districts, several env tiles per workgroup ("items" = (env tile, building) pairs dealt to the waves in order:
+// wave w takes items w, w + nw, ...).  With nine buildings a workgroup of one 128-env tile has nine units of work for four SIMDs;
+// two tiles give 18 items to 16 waves -- SIMD loads 5, 5, 4, 4, one workgroup per CU, all resident at once, and only two waves walk
+// two items.  Every item parks its four district partials in its own LDS row; the sums are then formed per (tile, quantity, env)
+// in building order (the reference's order, citylearn.py:1909-1918).
+template <int VEC, int WPE, bool NT>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_tp_kernel(const StepArgs a, const int tp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [tp * n_bldg][NQ][64*VEC], then [tp][64*VEC]
+    using F = typename Vec<VEC>::type;
+    constexpr int TILE = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    const bool first = (a.flags & CLD_REF_T0_QUIRK) && a.t == 0;
+    const int tile0 = blockIdx.x * tp * TILE;
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[tile0 / CL_ROW0_BLOCK] : 0);       // tp * TILE <= CL_ROW0_BLOCK (host)
+    const int n_items = tp * a.n_bldg;
+    const bool marl = rkind == CLR_MARL;
+    for (int j = w; j < n_items; j += a.nw) {
+        const int h = j / a.n_bldg, b = j - h * a.n_bldg;
+        const int env0 = tile0 + h * TILE + lane * VEC;
+        const bool live = env0 < a.n_env;
+        F net = (F)(0.0f), cost = (F)(0.0f), em = (F)(0.0f), rws = (F)(0.0f);
+        if (live) {
+            const uint32_t* __restrict__ f = a.params + (long long)b * CL_NP + CLP_F_FIRST;
+            FullIn<F> cur;
+            full_load_in<VEC>(cur, a, f, b, env0, plane);
+            clv::FP B;
+            clv::load_fp(B, f);
+            cl::Row R;
+            cl::load_row_scalar<true>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags, nullptr);
+            clv::St<F> S = {cur.soc, cur.eff, cur.deg, cur.cs, cur.hs, cur.ds};
+            const clv::Ac<F> act = {cur.a_cs, cur.a_hs, cur.a_ds, cur.a_es, cur.a_cd, cur.a_hd};
+            clv::Ou<F> O;
+            if (R.outage) clv::unit_step<F, true, false>(B, R, a.t, first, act, S, O);
+            else clv::unit_step<F, false, false>(B, R, a.t, first, act, S, O);
+            const F rw = clv::unit_reward<F>(rkind, B, S, O.net);
+            const long long off = (long long)b * a.n_env + env0;
+            if (B.flags & CLF_BATTERY) {
+                full_store<VEC, NT>(a.state + CLS_B_SOC * plane + off, S.soc);
+                full_store<VEC, NT>(a.state + CLS_B_EFF * plane + off, S.eff);
+                full_store<VEC, NT>(a.state + CLS_B_DEGCAP * plane + off, S.degcap);
+            }
+            if (B.flags & CLF_COOL_STO) full_store<VEC, NT>(a.state + CLS_CS_SOC * plane + off, S.cs);
+            if (B.flags & CLF_HEAT_STO) full_store<VEC, NT>(a.state + CLS_HS_SOC * plane + off, S.hs);
+            if (B.flags & CLF_DHW_STO) full_store<VEC, NT>(a.state + CLS_DS_SOC * plane + off, S.ds);
+            full_store<VEC, NT>(a.out_bldg + CLO_NET * plane + off, O.net);
+            if (!marl) full_store<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, rw);
+            net = O.net; cost = O.cost; em = O.emission; rws = rw;
+        }
+        float* row = lds + (size_t)j * NQ * TILE + lane * VEC;
+        full_store<VEC, false>(row + CLQ_NET * TILE, net); full_store<VEC, false>(row + CLQ_COST * TILE, cost);
+        full_store<VEC, false>(row + CLQ_EMISSION * TILE, em); full_store<VEC, false>(row + CLQ_REWARD * TILE, rws);
+    }
+    __syncthreads();
+    float* dnet = lds + (size_t)n_items * NQ * TILE;                  // [tp][TILE]: district net (MARL)
+    auto sum_rows = [&](int q_lo, int q_hi) {
+        const int nq = q_hi - q_lo;
+        for (int o = threadIdx.x; o < tp * nq * TILE; o += blockDim.x) {
+            const int h = o / (nq * TILE), r = o - h * nq * TILE, q = q_lo + r / TILE, e = r % TILE;
+            float s = 0.0f;
+            for (int b = 0; b < a.n_bldg; ++b) s += lds[((size_t)(h * a.n_bldg + b) * NQ + q) * TILE + e];
+            const int env = tile0 + h * TILE + e;
+            if (env < a.n_env) a.out_env[(long long)q * a.n_env + env] = s;
+            if (marl && q == CLQ_NET) dnet[h * TILE + e] = s;
+        }
+    };
+    static_assert(CLQ_NET == 0 && CLQ_REWARD == NQ - 1, "the MARL pass sums the reward rows separately");
+    sum_rows(0, marl ? NQ - 1 : NQ);
+    if (marl) {
+        // MARL couples every building to the district net (reward_function.py:132-143): each wave revisits its items with the
+        // finished net of their env tile, then the reward rows are summed
+        __syncthreads();
+        for (int j = w; j < n_items; j += a.nw) {
+            const int h = j / a.n_bldg, b = j - h * a.n_bldg;
+            const int env0 = tile0 + h * TILE + lane * VEC;
+            float* row = lds + (size_t)j * NQ * TILE + lane * VEC;
+            F rw;
+            if constexpr (VEC == 1) rw = cl::marl_reward(row[CLQ_NET * TILE], dnet[h * TILE + lane]);
+            else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) rw[i] = cl::marl_reward(row[CLQ_NET * TILE + i], dnet[h * TILE + lane * VEC + i]);
+            }
+            if (env0 < a.n_env) full_store<VEC, NT>(a.out_bldg + CLO_REWARD * plane + (long long)b * a.n_env + env0, rw);
+            else rw = (F)(0.0f);
+            full_store<VEC, false>(row + CLQ_REWARD * TILE, rw);
+        }
+        __syncthreads();
+        sum_rows(NQ - 1, NQ);
+    }
+}
+
 }  // namespace
 
 #pragma clang fp contract(fast)

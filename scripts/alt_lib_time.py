@@ -12,7 +12,7 @@ from golden_util import golden
 from citylearn_amd.engine import StepEngine
 from c4_bench import measure
 SHAPES = {'thermal': ('g2020_cz1', 65536), 'c3': ('g2023_p2', 65536), 'lean': ('g2022_all', 65536), 'lean1m': ('g2022_all', 1048576),
-          'c4': ('g2020_cz1', 1024, 1024), 'c4lean': ('g2022_all', 1024, 1024), 'thermal256k': ('g2020_cz1', 262144)}
+          'c4': ('g2020_cz1', 1024, 1024), 'c4lean': ('g2022_all', 1024, 1024), 'thermal256k': ('g2020_cz1', 262144), 'p3': ('s_2023_p3', 65536)}
 for name in (sys.argv[1:] or ['thermal', 'c3', 'lean']):
     fx, E, *tile = SHAPES[name]
     spec = golden(fx).spec()

@@ -356,3 +356,43 @@ def test_full_size_batches_through_size_independent_properties(E):
     torch.testing.assert_close(big.out_env[abi.CLQ_REWARD].double(), big.out_bldg[abi.CLO_REWARD].double().sum(dim=0), rtol=1e-6, atol=1e-4)
     total_small = small.out_bldg[abi.CLO_NET].double().sum().item()
     assert abs(big.out_bldg[abi.CLO_NET].double().sum().item() - reps * total_small) <= 1e-9 * abs(reps * total_small) + 1e-6
+
+
+@pytest.mark.parametrize('kind', REWARDS)
+@pytest.mark.parametrize('name,E,vec', [('g2020_cz1', 4996, 2), ('g2020_cz1', 772, 1), ('s_2023_p3', 516, 2), ('g2023_p2', 260, 2)])
+def test_multi_tile_thermal_kernel(name, E, vec, kind):
+    """`cl_step_full_tp_kernel` (several env tiles per workgroup, the (tile, building) items dealt to 16 waves; selected for 6 .. 16
+    buildings at one workgroup per CU, forced here with `full_variant = 5`) against the one-tile kernel: every per-building plane is
+    bit-identical; the district sums are formed in building order instead of per-wave partials first, so they -- and MARL's rewards,
+    which scale with the district net -- agree to summation-order rounding.  Ragged env tiles, outage rows (2023 schemas), waves with
+    one, two and three items."""
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    ref = StepEngine(tab, E, reward=kind, tuning=dict(full_variant=3, vec=1))
+    tp = StepEngine(tab, E, reward=kind, tuning=dict(full_variant=5, vec=vec))
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda()[:, None], torch.from_numpy(high).cuda()[:, None]
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    steps = list(range(40)) + (list(range(380, 410)) if tab.ts.shape[0] > 410 else [])
+    for t in steps:
+        a = (lo + torch.rand((ref.n_act_cols, E), device='cuda', generator=gen) * (hi - lo)).contiguous()
+        a[:, 0] = 0.0
+        ref.step(a, t); tp.step(a, t)
+        assert torch.equal(ref.state, tp.state) and torch.equal(ref.out_bldg[abi.CLO_NET], tp.out_bldg[abi.CLO_NET]), t
+        rw_ref, rw_tp = ref.out_bldg[abi.CLO_REWARD], tp.out_bldg[abi.CLO_REWARD]
+        if kind != 'MARL':
+            assert torch.equal(rw_ref, rw_tp), t
+        else:
+            # reward_b = sign(-net_b) 0.01 net_b^2 max(0, district net): it inherits the district net's summation-order rounding,
+            # a few ulp of sum |net_b| -- which is a large RELATIVE error wherever the building nets nearly cancel
+            d_dnet = 4e-6 * ref.out_bldg[abi.CLO_NET].abs().sum(dim=0, keepdim=True)
+            bound = 0.01 * ref.out_bldg[abi.CLO_NET] ** 2 * d_dnet + 1e-6 + 1e-6 * rw_ref.abs()
+            assert ((rw_tp - rw_ref).abs() <= bound).all(), t
+        # a sum of B terms in two orders differs by a few ulp of the largest partial sum
+        terms = {abi.CLQ_NET: ref.out_bldg[abi.CLO_NET], abi.CLQ_REWARD: rw_ref}
+        for q in range(abi.CL_NQ):
+            scale = terms[q].abs().sum(dim=0) if q in terms else ref.out_env[q].abs() + ref.out_bldg[abi.CLO_NET].abs().sum(dim=0)
+            slack = (rw_tp - rw_ref).abs().sum(dim=0) if (q == abi.CLQ_REWARD and kind == 'MARL') else 0.0
+            assert ((tp.out_env[q] - ref.out_env[q]).abs() <= 4e-6 * scale + 1e-6 + slack).all(), (t, q)
+        tp.state.copy_(ref.state)
