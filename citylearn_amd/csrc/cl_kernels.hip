@@ -1017,19 +1017,26 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float) + (lp ? (size_t)a.b_chunk * CL_LP_WORDS * sizeof(uint32_t) : 0);
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
-    // Thermal districts of 6 .. 16 buildings whose batch is exactly one two-tile workgroup per CU (49 152 < E <= 65 536 at two envs per
-    // lane): the (tile, building) items of cl_step_full_tp_kernel divide over the four SIMDs where nine buildings of one tile do not
-    // (scripts/tp_sweep.py, profiles/r02_tp_sweep.log: 9 x 65 536 8.5 -> 7.7 us, 12 x 65 536 11.8 -> 9.2, 16 x 65 536 13.4 -> 11.7,
-    // 6 x 65 536 7.0 -> 6.6; with fewer or more workgroups than CUs the one-tile kernel wins).  full_variant: 5 forces it, 3 forbids it.
-    const int tp_vec = tun.full_variant == 5 && tun.vec == 1 ? 1 : 2;
-    const int tp_tiles = tun.full_variant == 5 && tun.b_chunk > 0 ? tun.b_chunk : CL_ROW0_BLOCK / (64 * tp_vec);
-    const int tp_nw = tun.full_variant == 5 && tun.nw ? tun.nw : 16;
+    // Thermal districts whose batch can be cut into ONE 16-wave workgroup per CU: a workgroup takes `tiles` 128-env tiles (two envs per
+    // lane) and deals its tiles x B (tile, building) items to the 16 waves in order (cl_step_full_tp_kernel) -- the items divide over
+    // the four SIMDs where the B buildings of one tile do not, and the whole launch is resident at once.  scripts/tp_sweep.py,
+    // scripts/tp_sweep2.py (profiles/r02_tp_sweep*.log), one-tile kernel -> this one: 9 x 65 536 8.5 -> 7.7 us, 9 x 131 072 17.3 -> 14.3,
+    // 9 x 262 144 29.4 -> 28.0, 12 x 65 536 11.8 -> 9.2, 16 x 65 536 13.4 -> 11.7, 6 x 65 536 7.0 -> 6.6, 3 x 262 144 11.9 -> 10.7; with
+    // fewer than ~12 items per workgroup (3 x 65 536) or with more / fewer workgroups than CUs the one-tile kernel wins and stays.
+    // full_variant: 5 forces it (tun.vec = envs per lane, tun.nw = waves, tun.b_chunk = tiles), 3 forbids it.
+    const bool tp_forced = tun.full_variant == 5;
+    const int tp_vec = tp_forced && tun.vec == 1 ? 1 : 2;
+    const int tp_auto_tiles = (int)((dims->n_env + 256 * 64 * tp_vec - 1) / (256 * 64 * tp_vec));      // one workgroup per CU
+    const int tp_tiles = tp_forced ? (tun.b_chunk > 0 ? tun.b_chunk : CL_ROW0_BLOCK / (64 * tp_vec)) : tp_auto_tiles;
+    const int tp_nw = tp_forced && tun.nw ? tun.nw : 16;
     const unsigned tp_grid = (unsigned)((dims->n_env + tp_tiles * 64 * tp_vec - 1) / (tp_tiles * 64 * tp_vec));
-    bool tp_kernel = full && !flex && !(dims->flags & CLD_WRITE_DETAIL) && a.n_chunks == 1 && dims->n_bldg <= 32;
-    if (tun.full_variant == 5) {
-        if (!tp_kernel || tp_tiles * 64 * tp_vec > CL_ROW0_BLOCK || tp_nw > 16)
+    const size_t tp_lds = ((size_t)tp_tiles * dims->n_bldg * NQ + tp_tiles) * 64 * tp_vec * sizeof(float);
+    bool tp_kernel = full && !flex && !(dims->flags & CLD_WRITE_DETAIL) && a.n_chunks == 1 && dims->n_bldg <= 32 && tp_lds <= 150 * 1024 &&
+                     (!dims->env_row0 || tp_tiles * 64 * tp_vec <= CL_ROW0_BLOCK);          // one episode offset per workgroup
+    if (tp_forced) {
+        if (!tp_kernel || tp_nw > 16)
             return fail(CL_EINVAL, "full_variant = 5: %d tiles x %d envs per lane x %d waves is not a launch of cl_step_full_tp_kernel for this district", tp_tiles, tp_vec, tp_nw);
-    } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && dims->n_bldg >= 6 && dims->n_bldg <= 16 && tp_grid > 192 && tp_grid <= 256;
+    } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && tp_tiles * dims->n_bldg >= 12 && tp_grid > 192 && tp_grid <= 256;
     const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (tun.lean_variant & 2)) && !(tun.lean_variant & 1);
     if (flex && !full && lean_shape) {
         switch (vec) {
@@ -1057,7 +1064,7 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         // several env tiles per workgroup (cl_step_full_tp_kernel, cl_full.h); forced: tun.vec = envs per lane, tun.nw = waves, tun.b_chunk = tiles
         a.nw = tp_nw;
         const dim3 g2(tp_grid), b2(64 * a.nw);
-        const size_t l2 = ((size_t)tp_tiles * dims->n_bldg * NQ + tp_tiles) * 64 * tp_vec * sizeof(float);
+        const size_t l2 = tp_lds;
         if (tp_vec == 2) {
             if (a.nt) hipLaunchKernelGGL((cl_step_full_tp_kernel<2, 4, true>), g2, b2, l2, s, a, tp_tiles);
             else hipLaunchKernelGGL((cl_step_full_tp_kernel<2, 4, false>), g2, b2, l2, s, a, tp_tiles);

@@ -10,7 +10,7 @@ from citylearn_amd import abi
 from citylearn_amd.engine import StepEngine
 from citylearn_amd.synthetic import tile_district
 from c4_bench import measure
-what = sys.argv[1:] or ['compare', 'sweep']
+what = (sys.argv[1:] or ["compare", "sweep"]) if __name__ == "__main__" else []
 
 
 def district(B):
