@@ -251,7 +251,9 @@ typedef struct cl_tuning {
     int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent, 4 plane-transpose kernel (all columns env-dependent) */
     int32_t obs_rows;       /* LDS-tile observation kernel: envs per block */
     int32_t lstm_variant;   /* LSTM stage timing experiments (csrc/cl_lstm.h) */
-    int32_t full_variant;   /* thermal / outage districts: 1 = the round-1 general kernel instead of cl_step_full_kernel (tests) */
+    int32_t full_variant;   /* thermal / outage districts (tests, A/B): 1 = the round-1 general kernel; 2 = parameter blocks staged in LDS even when
+                               the launch is not building-chunked; 3 = one env tile per workgroup, parameters in SGPRs (neither LDS staging nor
+                               the multi-tile kernel); 5 = the multi-tile kernel (vec = envs per lane, nw = waves, b_chunk = tiles per workgroup) */
     int32_t b_chunk;        /* building-chunked launches: buildings per workgroup row (with `nw` waves per workgroup) */
     int32_t nt_stores;      /* non-temporal hint on the step kernels' plane stores: 0 = by launch footprint, 1 = always, 2 = never */
     int32_t reserved[4];

@@ -28,7 +28,7 @@ for cfg in "g2023_p2 65536 0" "g2020_cz1 65536 0" "g2020_cz1 1024 1024"; do
   done
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES \
     --output-format csv -d $OUT/pmc_${name}_SQ -o run -- python scripts/run_cfg.py $1 $2 $3 60 > /dev/null 2>$OUT/pmc_${name}_SQ.log
-  python scripts/pmc_summary.py $OUT/thermal_${name}_pmc_summary.json "cl_step_full_kernel" $OUT/pmc_${name}_FETCH_SIZE/*counter_collection.csv \
+  python scripts/pmc_summary.py $OUT/thermal_${name}_pmc_summary.json "cl_step_full" $OUT/pmc_${name}_FETCH_SIZE/*counter_collection.csv \
     $OUT/pmc_${name}_WRITE_SIZE/*counter_collection.csv $OUT/pmc_${name}_SQ/*counter_collection.csv > /dev/null
 done
 # mode B (fused rollout): VALU instruction counts and vector-ALU busy time
