@@ -390,7 +390,13 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 // through `float` lvalues instead of float4 ones, so that the parameter block of wave 0's SECOND building -- read after the first
 // one's stores, and therefore a uniform *vector* load behind them -- stays a scalar load: 73 instead of 88 VGPRs, and 8.14 vs
 // 7.99 us, three alternations on one box: slower.  The same trick is what made the thermal kernel's two-env pack viable
-// (cl_full.h); here the vector loads of the 17th building's parameters are issued early enough and the scalar ones are not.)
+// (cl_full.h); here the vector loads of the 17th building's parameters are issued early enough and the scalar ones are not.
+//  Tried again at the end of round 2, with the nt stores and the hoisted unit in place: the 17th building shared out to four waves on
+//  four SIMDs as 64-env strips at one env per lane (SIMD loads 4.25 each instead of 5, 4, 4, 4; the strips' district partials in
+//  their own LDS row, processed before the wave's main building so that its parameter block stays a scalar load): 7.36 - 7.49 vs
+//  7.37 - 7.63 us, alternating on one box -- nothing.  scripts/lean_balance_probe.py: 16 buildings x 65 536 take 6.58 us, 17 take
+//  7.39 us, 20 (four waves with two buildings: 5, 5, 5, 5) take 8.22 us = 6.98 us per 17: the cost of the 17th building is that
+//  SOME wave walks a second dependent chain behind its first, not the imbalance between the SIMDs.)
 template <int VEC, bool FLEX, bool NT>
 __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
