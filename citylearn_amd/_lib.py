@@ -117,6 +117,9 @@ def load() -> ctypes.CDLL:
     lib.cl_step_flex_f32.restype = ctypes.c_int
     lib.cl_step_flex_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, f32p, f32p, f32p, f32p,
                                      ctypes.POINTER(Flex), i32, vp]
+    lib.cl_step_observe_f32.restype = ctypes.c_int
+    lib.cl_step_observe_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, f32p, f32p, f32p, f32p, i32,
+                                        f32p, vp, f32p, vp, i32, f32p, i32, i32, i32, i32, vp]
     lib.cl_lstm_generic_step_f32.restype = ctypes.c_int
     lib.cl_rollout_f32.restype = ctypes.c_int
     lib.cl_rollout_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, i64, f32p, f32p, u64,

@@ -55,6 +55,9 @@ struct StepArgs {
     int nt;        // plane stores carry the non-temporal hint (see pstore)
 };
 
+constexpr int CL_OBS_FUSED_BLDG = 32;          // buildings a fused observation list can address (= the lean kernel's 2 x 16)
+constexpr int CL_OBS_FUSED_PER_BLDG = 4;      // observation columns per building the step launch writes itself
+
 // largest launch (env x building units) whose plane stores carry the non-temporal hint (see pstore)
 constexpr long long CL_NT_MAX_UNITS = 3ll << 20;
 
@@ -397,9 +400,18 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 //  7.37 - 7.63 us, alternating on one box -- nothing.  scripts/lean_balance_probe.py: 16 buildings x 65 536 take 6.58 us, 17 take
 //  7.39 us, 20 (four waves with two buildings: 5, 5, 5, 5) take 8.22 us = 6.98 us per 17: the cost of the 17th building is that
 //  SOME wave walks a second dependent chain behind its first, not the imbalance between the SIMDs.)
-template <int VEC, bool FLEX, bool NT>
-__global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
+// The compact observation of the NEXT row written by the step launch itself (cl_step_observe_f32): every column is an affine map
+// of a plane value the wave that stepped the building still holds in registers.
+struct ObsFusedArgs {
+    float* __restrict__ obs;            // [n_env][pitch]
+    const float* __restrict__ table;    // obs_table [n_rows][n_cols]: the offsets of the affine maps
+    int n_cols, pitch, row;
+    short start[CL_OBS_FUSED_BLDG + 1]; // deps[start[b] .. start[b + 1]) belong to building b
+    cl_obs_dep deps[CLOB_MAX_DEPS];     // grouped by building
+};
+
+template <int VEC, bool FLEX, bool NT, bool OBS>
+CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of) {     // lds: [nw][NQ][64*VEC] (, then [64*VEC][pitch])
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -439,6 +451,21 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
         cl::load_bp<false>(B, a.params + (long long)b * CL_NP);
         cl::Row R;
         cl::load_row<false>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags);
+        // (OBS) the building's column descriptors and the offsets of their affine maps, fetched with the parameters: nothing is left to
+        // wait for between the arithmetic and the tile writes
+        [[maybe_unused]] int od_n = 0, od_col[CL_OBS_FUSED_PER_BLDG], od_src[CL_OBS_FUSED_PER_BLDG];
+        [[maybe_unused]] float od_scale[CL_OBS_FUSED_PER_BLDG], od_base[CL_OBS_FUSED_PER_BLDG];
+        if constexpr (OBS) {
+            const float* __restrict__ trow = of->table + (size_t)(of->row + (ts_row - a.t)) * of->n_cols;
+            const int d0 = of->start[b];
+            od_n = of->start[b + 1] - d0;
+#pragma unroll
+            for (int k = 0; k < CL_OBS_FUSED_PER_BLDG; ++k) {
+                const int d = d0 + min(k, max(od_n - 1, 0));
+                od_col[k] = of->deps[d].col; od_src[k] = of->deps[d].src; od_scale[k] = of->deps[d].scale;
+                od_base[k] = trow[od_col[k]];
+            }
+        }
         if (!live) continue;
         const long long off = (long long)b * a.n_env + env0;
         const bool batt = B.flags & CLF_BATTERY;
@@ -513,11 +540,64 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
         }
         pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
         if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+        if constexpr (OBS) {
+            // this building's observation columns, into the workgroup's [64 * VEC envs][pitch] tile (streamed out below)
+            float* tile = lds + (size_t)a.nw * NQ * TILE;
+#pragma unroll
+            for (int k = 0; k < CL_OBS_FUSED_PER_BLDG; ++k) {
+                if (k >= od_n) break;                                                // wave-uniform
+                const int col = od_col[k], src = od_src[k];
+                const float scale = od_scale[k], base = od_base[k];
+                const bool is_out = (src >> 28) == CLOB_KIND_OUT;
+                const int pl = (src >> 20) & 0xFF;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float v = is_out ? (pl == CLO_NET ? o_net[i] : o_rw[i])
+                                           : (pl == CLS_B_SOC ? s_soc[m][i] : pl == CLS_B_EFF ? s_eff[m][i] : s_deg[m][i]);
+                    tile[(size_t)(lane * VEC + i) * of->pitch + col] = fmaf(v, scale, base);
+                }
+            }
+        }
         CL_TRACE_AFTER(3 + 4 * m, q_rw[0]);
+    }
+    if constexpr (OBS) {
+        if (w == 0) {                                                              // pad columns: zeros (like cl_observe_f32)
+            float* tile = lds + (size_t)a.nw * NQ * TILE;
+            for (int c = of->n_cols; c < of->pitch; ++c) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) tile[(size_t)(lane * VEC + i) * of->pitch + c] = 0.0f;
+            }
+        }
     }
     CL_TRACE_AFTER(13, q_net[0]);
     district_reduce<VEC, FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    if constexpr (OBS) {
+        // (district_reduce's first barrier came after every wave's tile writes.)  The tile's rows are consecutive envs: one contiguous
+        // block of the observation matrix, streamed out in 16-byte stores.
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int tile_env0 = blockIdx.x * TILE;
+        const int rows = min(TILE, a.n_env - tile_env0);
+        const f4* src4 = reinterpret_cast<const f4*>(lds + (size_t)a.nw * NQ * TILE);
+        f4* dst4 = reinterpret_cast<f4*>(of->obs + (size_t)tile_env0 * of->pitch);
+        const int total4 = rows * of->pitch / 4;
+        for (int q = threadIdx.x; q < total4; q += blockDim.x) {
+            if constexpr (NT) __builtin_nontemporal_store(src4[q], dst4 + q);
+            else dst4[q] = src4[q];
+        }
+    }
     CL_TRACE_FLUSH();
+}
+
+template <int VEC, bool FLEX, bool NT>
+__global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lean_step_body<VEC, FLEX, NT, false>(a, lds, nullptr);
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(1024) cl_step_lean_obs_kernel(const StepArgs a, const ObsFusedArgs of) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lean_step_body<4, false, NT, true>(a, lds, &of);
 }
 
 // Lean districts, one wave = 64 envs x ALL buildings ("env-major").  The wave issues every state / action load of its
@@ -923,9 +1003,11 @@ int cl_flex_reset_f32(const cl_dims* dims, const cl_flex* flex, void* stream) {
     return CL_OK;
 }
 
-int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+// `of` / `fused`: the compact observation to write from inside the step launch (cl_step_observe_f32); *fused tells the caller
+// whether the launch that ran could take it (lean district, four envs per lane, one workgroup row) or the observation is still to do.
+static int step_impl(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
                      int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg,
-                     float* kpi_env, const cl_flex* flex, int32_t t, void* stream) {
+                     float* kpi_env, const cl_flex* flex, int32_t t, void* stream, const ObsFusedArgs* of, bool* fused) {
     if (int rc = check_dims(dims)) return rc;
     const cl_tuning& tun = tuning_of(dims);
     if (int rc = check_ptr(params, "params")) return rc;
@@ -1125,7 +1207,14 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
         switch (vec) {                                   // latency-ordered lean kernel (two buildings per wave at most)
         case 1: CL_LAUNCH_NT(cl_step_lean_kernel, 1, false); break;
         case 2: CL_LAUNCH_NT(cl_step_lean_kernel, 2, false); break;
-        case 4: CL_LAUNCH_NT(cl_step_lean_kernel, 4, false); break;
+        case 4:
+            if (of && rkind_host != CLR_MARL) {                   // (MARL's reward plane is finished after the sweep the tile is filled in)
+                const size_t lds_o = lds + (size_t)tile * of->pitch * sizeof(float);
+                if (a.nt) hipLaunchKernelGGL((cl_step_lean_obs_kernel<true>), grid, block, lds_o, s, a, *of);
+                else hipLaunchKernelGGL((cl_step_lean_obs_kernel<false>), grid, block, lds_o, s, a, *of);
+                *fused = true;
+            } else CL_LAUNCH_NT(cl_step_lean_kernel, 4, false);
+            break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else {
@@ -1150,6 +1239,52 @@ int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* t
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");
     return CL_OK;
+}
+
+int cl_step_flex_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+                     int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg,
+                     float* kpi_env, const cl_flex* flex, int32_t t, void* stream) {
+    return step_impl(dims, params, ts, state, actions, act_stride_col, act_stride_env, out_bldg, out_env, kpi_bldg, kpi_env, flex, t, stream,
+                     nullptr, nullptr);
+}
+
+int cl_step_observe_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+                        int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg, float* kpi_env,
+                        int32_t t, const float* obs_table, const int32_t* col_src, const float* col_scale, const cl_obs_dep* deps,
+                        int32_t n_deps, float* obs, int32_t n_cols, int32_t obs_pitch, int32_t n_rows, int32_t obs_row, void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(obs_table, "obs_table")) return rc;
+    if (int rc = check_ptr(obs, "obs")) return rc;
+    if (!deps || n_deps != n_cols || n_cols <= 0 || n_cols > CLOB_MAX_DEPS)
+        return fail(CL_EINVAL, "cl_step_observe_f32 takes the compact form: every one of the n_cols <= %d columns env-dependent and listed (n_cols=%d, n_deps=%d)",
+                    CLOB_MAX_DEPS, n_cols, n_deps);
+    if (obs_pitch < n_cols) return fail(CL_EINVAL, "obs_pitch=%d < n_cols=%d", obs_pitch, n_cols);
+    if (obs_row < 0 || obs_row >= n_rows) return fail(CL_ERANGE, "obs_row=%d outside [0, %d)", obs_row, n_rows);
+    // what the step launch itself can write: columns fed by the planes a lean wave holds in registers, rows padded to 16 bytes
+    ObsFusedArgs of;
+    bool can = obs_pitch == ((n_cols + 3) & ~3) && dims->n_bldg <= CL_OBS_FUSED_BLDG && tuning_of(dims).obs_variant == 0;
+    int n = 0;
+    for (int b = 0; b < dims->n_bldg && can; ++b) {
+        of.start[b] = (short)n;
+        for (int d = 0; d < n_deps; ++d) {
+            const int src = deps[d].src, kind = src >> 28, pl = (src >> 20) & 0xFF;
+            if (deps[d].col < 0 || deps[d].col >= n_cols || src < 0) return fail(CL_EINVAL, "deps[%d]: col=%d src=%d", d, deps[d].col, src);
+            if ((src & 0xFFFFF) != b) continue;
+            can = can && ((kind == CLOB_KIND_STATE && (pl == CLS_B_SOC || pl == CLS_B_EFF || pl == CLS_B_DEGCAP)) ||
+                          (kind == CLOB_KIND_OUT && (pl == CLO_NET || pl == CLO_REWARD)));
+            of.deps[n++] = deps[d];
+        }
+    }
+    can = can && n == n_deps;                       // (a building index beyond n_bldg would have been skipped)
+    for (int b = 0; b < dims->n_bldg && can; ++b) can = (b + 1 < dims->n_bldg ? of.start[b + 1] : n) - of.start[b] <= CL_OBS_FUSED_PER_BLDG;
+    for (int b = dims->n_bldg; b <= CL_OBS_FUSED_BLDG; ++b) of.start[b] = (short)n;
+    of.obs = obs; of.table = obs_table; of.n_cols = n_cols; of.pitch = obs_pitch; of.row = obs_row;
+    bool fused = false;
+    if (int rc = step_impl(dims, params, ts, state, actions, act_stride_col, act_stride_env, out_bldg, out_env, kpi_bldg, kpi_env, nullptr, t,
+                           stream, can ? &of : nullptr, &fused)) return rc;
+    if (fused) return CL_OK;
+    return cl_observe_f32(dims, obs_table, col_src, col_scale, deps, n_deps, state, out_bldg, nullptr, nullptr, 0, obs, n_cols, obs_pitch,
+                          n_rows, obs_row, 0u, stream);
 }
 
 int cl_rollout_seq_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,

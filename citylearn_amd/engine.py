@@ -214,6 +214,29 @@ class StepEngine:
             _lib.check(rc)
         self.t = t + 1
 
+    def step_observe(self, actions: torch.Tensor, writer, t: Optional[int] = None) -> torch.Tensor:
+        """`step` followed by ``writer.write(t + 1)`` for an `ObservationWriter` over the COMPACT tables (every column env-dependent):
+        one C call, `cl_step_observe_f32` -- and one launch where the step runs as a single lean launch at four envs per lane."""
+        t = self.t if t is None else t
+        if self._flex_ref is not None or writer.stage is not None or writer.n_deps != writer.n_cols or writer.n_cols == 0:
+            self.step(actions, t)
+            return writer.write(min(t + 1, self.n_steps - 1))
+        if actions.dtype != torch.float32 or actions.device != self.device:
+            raise TypeError('actions must be a float32 tensor on the engine device')
+        if tuple(actions.shape) != (self.n_act_cols, self.n_env):
+            raise ValueError(f'actions shape {tuple(actions.shape)} != {(self.n_act_cols, self.n_env)}')
+        sc, se = actions.stride()
+        row = min(t + 1, self.n_steps - 1)
+        with self._on_device():
+            rc = self.lib.cl_step_observe_f32(*self._step_head, actions.data_ptr(), sc, se, *self._step_tail, int(t),
+                                              writer.table.data_ptr(), writer.col_src.data_ptr(), writer.col_scale.data_ptr(),
+                                              ctypes.cast(writer._deps, ctypes.c_void_p), writer.n_deps, writer._buffer.data_ptr(), writer.n_cols,
+                                              writer.pitch, writer.n_rows, int(row), self._stream())
+        if rc:
+            _lib.check(rc)
+        self.t = t + 1
+        return writer.obs
+
     def set_action_limits(self, low, high):
         """Bounds of the on-device uniform random policy of :meth:`rollout` (``[n_act_cols]`` each)."""
         self.act_low = torch.as_tensor(np.asarray(low, dtype=np.float32)).to(self.device).contiguous()

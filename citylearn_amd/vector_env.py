@@ -267,13 +267,14 @@ class VectorCityLearnEnv:
         from .spaces import Box
         return [Box(low=lo, high=hi, dtype=np.float32) for lo, hi in self.layout.space()]
 
-    def _obs(self):
+    def _obs(self, dep=None):
         e = self.engine
         if self._compact and self.layout is not None:
             row = min(self._t, e.n_steps - 1)
             table = self._shared_reset if (row == 0 and self._shared_reset is not None) else self._shared_rows
             shared = table[row] if e.env_row0 is None else table[e.env_row0.long() + row]          # [n_obs] or [n_blocks, n_obs]
-            dep = self.writer.write(row) if self.writer is not None else torch.zeros((e.n_env, 0), device=self.device)
+            if dep is None:                                  # (step() hands over what cl_step_observe_f32 already wrote)
+                dep = self.writer.write(row) if self.writer is not None else torch.zeros((e.n_env, 0), device=self.device)
             return {'shared': shared, 'dependent': dep, 'columns': self._dep_cols}
         if self.writer is not None:
             return self.writer.write(min(self._t, e.n_steps - 1))
@@ -293,7 +294,11 @@ class VectorCityLearnEnv:
         e = self.engine
         if actions.shape == (e.n_env, e.n_act_cols) and e.n_env != e.n_act_cols:
             actions = actions.t()                       # strided view, no copy
-        e.step(actions, self._t)
+        dep = None
+        if self._compact and self.writer is not None and self.stage is None:
+            dep = e.step_observe(actions, self.writer, self._t)      # the dependent columns of the next observation, same launch where possible
+        else:
+            e.step(actions, self._t)
         if self.stage is not None:
             self.stage.step(self._t)                    # indoor temperature (+ ComfortReward) of this step
         self._t += 1
@@ -313,7 +318,7 @@ class VectorCityLearnEnv:
             reward = self.stage.comfort.sum(dim=0) if self.central_agent else self.stage.comfort
         else:
             reward = e.district_reward if self.central_agent else e.reward_bldg
-        return self._obs(), reward, self.terminated, False, {}
+        return self._obs(dep), reward, self.terminated, False, {}
 
     def rollout(self, k_steps: int, actions: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
         """Advance ``k_steps`` steps without returning to Python in between (`StepEngine.rollout`: one fused launch, or a launch

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 2
+#define CL_ABI_VERSION 3
 
 /* ---- error codes ---- */
 #define CL_OK            0
@@ -395,6 +395,18 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
                    const float* state, const float* out_bldg, const float* indoor_temp,
                    const float* extra /* nullable: CLOB_KIND_EXTRA planes */, int32_t n_extra_rows, float* obs, int32_t n_cols,
                    int32_t obs_pitch, int32_t n_rows, int32_t row, uint32_t flags, void* stream);
+
+/* cl_step_f32 followed by cl_observe_f32 of the COMPACT observation form -- every one of the n_cols <= CLOB_MAX_DEPS columns
+ * env-dependent and listed in `deps` (host memory), e.g. the [n_env][n_dep] matrix VectorCityLearnEnv(observations='compact') hands
+ * out next to the shared row -- for observation row `obs_row` (normally t + 1: Building.observations after next_time_step,
+ * citylearn.py:1029-1042).  Same results as the two calls.  Where the step runs as one lean launch at four envs per lane (battery
+ * + PV districts of up to 32 buildings from ~50 000 envs up) and the columns are fed by the battery state planes, the net or the
+ * reward plane, the wave that stepped a building writes its columns from registers into an LDS tile and the step launch itself
+ * streams the tile out: one launch instead of two (17 x 65 536: step + observe 16.8 -> 9.1 us).  Otherwise it IS the two calls. */
+int cl_step_observe_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
+                        int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg, float* kpi_env,
+                        int32_t t, const float* obs_table, const int32_t* col_src, const float* col_scale, const cl_obs_dep* deps,
+                        int32_t n_deps, float* obs, int32_t n_cols, int32_t obs_pitch, int32_t n_rows, int32_t obs_row, void* stream);
 
 /* ---- flexible loads: EV chargers and washing machines ----
  * Replaces, for a whole env batch, Charger.update_connected_electric_vehicle_soc (electric_vehicle_charger.py:297-334),

@@ -202,3 +202,43 @@ def test_compact_observations_expand_to_the_observation_tensor(name, normalize):
         o_full = full.step(a)[0]
         o_comp = comp.step(a)[0]
         assert torch.equal(comp.materialize(o_comp), o_full), t
+
+
+@pytest.mark.parametrize('E,tuning,offsets', [(65536, None, False), (772, dict(vec=4, lean_variant=2), False), (516, None, False),
+                                               (1024, dict(vec=4, lean_variant=2), True)])
+@pytest.mark.parametrize('kind', ['RewardFunction', 'MARL'])
+@pytest.mark.parametrize('normalize', [False, True])
+def test_step_observe_matches_step_then_observe(E, tuning, offsets, kind, normalize):
+    """`cl_step_observe_f32` (`StepEngine.step_observe`): the compact observation of row t + 1 written by the step launch itself where
+    the step is one lean launch at four envs per lane (65 536 envs; forced at 772 -- ragged last tile -- and with per-env-block episode
+    offsets), by the two launches otherwise (516 envs; MARL, whose reward plane is finished after the tile is filled).  State, outputs
+    and the observation matrix are bit-identical to `step` followed by `ObservationWriter.write` either way."""
+    from citylearn_amd.engine import StepEngine
+    from citylearn_amd.observations import ObservationLayout
+    from citylearn_amd.observe import ObservationWriter
+    g = golden('g2022_all')
+    spec = g.spec()
+    if offsets:
+        tab = spec.episode_tables(0, window=(0, 400))
+        row0 = np.array([0, 37, 5, 111], dtype=np.int32)
+    else:
+        tab, row0 = spec.episode_tables(0), None
+    ot = ObservationLayout(spec, 'current', normalize).episode(tab, reset_table=offsets)
+    dep_tables, _ = ot.compact()
+    kw = dict(reward=kind, tuning=tuning)
+    if offsets:
+        kw.update(env_row0=row0, n_steps=200)
+    a_eng, b_eng = StepEngine(tab, E, **kw), StepEngine(tab, E, **kw)
+    wa, wb = ObservationWriter(a_eng, dep_tables, None), ObservationWriter(b_eng, dep_tables, None)
+    assert wa.n_deps == wa.n_cols > 0
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    for t in range(12):
+        act = torch.rand((a_eng.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        a_eng.step(act, t)
+        ref = wa.write(t + 1).clone()
+        got = b_eng.step_observe(act, wb, t)
+        assert torch.equal(a_eng.state, b_eng.state) and torch.equal(a_eng.out_bldg[:2], b_eng.out_bldg[:2]), t
+        assert torch.equal(a_eng.out_env, b_eng.out_env), t
+        assert torch.equal(got, ref), t
+        assert torch.equal(wb._buffer[:, wb.n_cols:], torch.zeros_like(wb._buffer[:, wb.n_cols:]))        # pad columns stay zero
+    assert got.abs().sum().item() > 0
