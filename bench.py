@@ -226,8 +226,8 @@ def main():
     units_per_step = eng.n_bldg * E
     bytes_per_unit = eng.algorithmic_bytes_per_unit()
     achieved = units_per_step * bytes_per_unit / launch_s / 1e9
-    # <.., true> = plane stores / loads with the non-temporal hint (launches of up to 3 Mi units, csrc/cl_kernels.hip)
-    kernel_name = (lambda e: f'cl_step_envmajor_kernel<20, {"true" if e * 17 <= 3 << 20 else "false"}>' if e >= 131072 else 'cl_step_lean_kernel<4, false, true>')
+    # <.., true> = plane stores / loads with the non-temporal hint (launches of up to 3 Mi units or from 16 Mi units, csrc/cl_kernels.hip)
+    kernel_name = (lambda e: f'cl_step_envmajor_kernel<20, {"true" if (e * 17 <= 3 << 20 or e * 17 >= 16 << 20) else "false"}>' if e >= 131072 else 'cl_step_lean_kernel<4, false, true>')
 
     traffic, traffic_source = None, None
     pmcs = sorted((ROOT / 'profiles').glob('r*_bench_pmc_summary.json'))        # the newest round's counters of this same workload

@@ -14,6 +14,8 @@ what = sys.argv[1:] or ['lean', 'thermal', 'c4']
 SHAPES = []
 if 'lean' in what:
     SHAPES += [('lean 2022', 'g2022_all', None, e) for e in (16384, 65536, 131072, 196608, 262144, 524288, 1048576)]
+if 'big' in what:
+    SHAPES += [('lean 2022', 'g2022_all', None, e) for e in (524288, 655360, 786432, 1048576, 1572864)] + [('2020 thermal', 'g2020_cz1', None, e) for e in (524288, 1048576)]
 if 'thermal' in what:
     SHAPES += [('2020 thermal', 'g2020_cz1', None, e) for e in (65536, 131072, 262144, 524288)] + [('C3 2023', 'g2023_p2', None, e) for e in (65536, 262144, 1048576)]
 if 'c4' in what:
