@@ -109,8 +109,8 @@ CL_DEV void vstore(float* __restrict__ p, const float (&src)[VEC]) {
 // XCD's L2 instead of staying dirty in it until the end-of-kernel release writes them back.  scripts/launch_gap.py: for the
 // headline shape's access pattern (17.8 MB in, 22.3 MB out) the waves are alive 2.9 us either way, but the gap to the next launch's
 // first wave is 3.2 us with plain stores and 2.7 us with nt ones (1.1 us for a read-only kernel, 1.8 us period for an empty one);
-// cl_step_lean_kernel 17 x 65 536: 7.91 -> 7.20 us.  Once the launch's footprint is past the 256 MB Infinity Cache the hint costs
-// bandwidth instead (17 x 1 048 576: 125.9 -> 132.9 us), so the host sets StepArgs::nt by size.
+// cl_step_lean_kernel 17 x 65 536: 7.91 -> 7.20 us.  With a footprint of the order of the 256 MB Infinity Cache the hint costs bandwidth
+// instead (17 x 262 144: +10 %), several times past it it wins again (17 x 1 048 576: 125 -> 115 us): the host sets StepArgs::nt by size.
 template <int VEC, bool NT>
 CL_DEV void pstore(float* __restrict__ p, const float (&src)[VEC]) {
     using V = typename Vec<VEC>::type;
