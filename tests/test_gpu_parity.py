@@ -396,3 +396,27 @@ def test_multi_tile_thermal_kernel(name, E, vec, kind):
             slack = (rw_tp - rw_ref).abs().sum(dim=0) if (q == abi.CLQ_REWARD and kind == 'MARL') else 0.0
             assert ((tp.out_env[q] - ref.out_env[q]).abs() <= 4e-6 * scale + 1e-6 + slack).all(), (t, q)
         tp.state.copy_(ref.state)
+
+
+def test_multi_tile_thermal_kernel_with_episode_offsets():
+    """`cl_step_full_tp_kernel` under per-env-block episode windows (`cl_dims.env_row0`): a workgroup's tiles never straddle an offset
+    block (two 128-env tiles = one 256-env block), so every workgroup reads one table row -- per-building planes bit-identical to the
+    one-tile kernel, district sums to summation-order rounding."""
+    g = golden('g2020_cz1')
+    spec = g.spec()
+    tab = spec.episode_tables(0, window=(0, 300))
+    E = 1280
+    row0 = np.array([0, 91, 17, 160, 5], dtype=np.int32)
+    kw = dict(env_row0=row0, n_steps=120)
+    ref = StepEngine(tab, E, tuning=dict(full_variant=3, vec=1), **kw)
+    tp = StepEngine(tab, E, tuning=dict(full_variant=5, vec=2), **kw)
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda()[:, None], torch.from_numpy(high).cuda()[:, None]
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    for t in range(40):
+        a = (lo + torch.rand((ref.n_act_cols, E), device='cuda', generator=gen) * (hi - lo)).contiguous()
+        ref.step(a, t); tp.step(a, t)
+        assert torch.equal(ref.state, tp.state) and torch.equal(ref.out_bldg[:2], tp.out_bldg[:2]), t
+        torch.testing.assert_close(tp.out_env, ref.out_env, rtol=1e-5, atol=1e-3)
+    # the blocks really ran different windows
+    assert not torch.equal(ref.out_bldg[abi.CLO_NET][:, :256], ref.out_bldg[abi.CLO_NET][:, 256:512])
