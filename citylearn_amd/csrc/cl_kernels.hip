@@ -595,10 +595,10 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     lean_step_body<VEC, FLEX, NT, false>(a, lds, nullptr);
 }
 
-template <bool NT>
+template <int VEC, bool NT>
 __global__ void __launch_bounds__(1024) cl_step_lean_obs_kernel(const StepArgs a, const ObsFusedArgs of) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    lean_step_body<4, false, NT, true>(a, lds, &of);
+    lean_step_body<VEC, false, NT, true>(a, lds, &of);
 }
 
 // Lean districts, one wave = 64 envs x ALL buildings ("env-major").  The wave issues every state / action load of its
@@ -890,8 +890,10 @@ int pick_nw(int n_bldg, int /*vec*/) {
 // envs per lane: wide (16 B) accesses once the batch is large enough to still give every CU a workgroup
 int pick_vec(int n_env, int n_bldg, bool unit_stride) {
     if (!unit_stride) return 1;
-    if (n_env >= 256 * 256) return 4;
-    if (n_env >= 256 * 128) return 2;
+    // the narrowest pack that still gives at most one workgroup per CU (the lean kernels' launch shape): 49 152 envs at two envs per
+    // lane were 384 workgroups -- the general kernel, 9.8 us -- and are 192 latency-ordered ones at four (scripts/step_observe_bench.py)
+    if (n_env > 256 * 128) return 4;
+    if (n_env > 256 * 64) return 2;
     (void)n_bldg;
     return 1;
 }
@@ -1210,16 +1212,16 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // one workgroup per CU at most: with more rounds the generic kernel's smaller register file (52 vs 88 VGPRs, two
         // workgroups per CU) wins again -- 17 x 262 144: 30.8 us vs 33.0 us
         switch (vec) {                                   // latency-ordered lean kernel (two buildings per wave at most)
-        case 1: CL_LAUNCH_NT(cl_step_lean_kernel, 1, false); break;
-        case 2: CL_LAUNCH_NT(cl_step_lean_kernel, 2, false); break;
-        case 4:
-            if (of && rkind_host != CLR_MARL) {                   // (MARL's reward plane is finished after the sweep the tile is filled in)
-                const size_t lds_o = lds + (size_t)tile * of->pitch * sizeof(float);
-                if (a.nt) hipLaunchKernelGGL((cl_step_lean_obs_kernel<true>), grid, block, lds_o, s, a, *of);
-                else hipLaunchKernelGGL((cl_step_lean_obs_kernel<false>), grid, block, lds_o, s, a, *of);
-                *fused = true;
-            } else CL_LAUNCH_NT(cl_step_lean_kernel, 4, false);
+#define CL_LEAN_CASE(V) case V: \
+            if (of && rkind_host != CLR_MARL) {       /* (MARL's reward plane is finished after the sweep the tile is filled in) */ \
+                const size_t lds_o = lds + (size_t)tile * of->pitch * sizeof(float); \
+                if (a.nt) hipLaunchKernelGGL((cl_step_lean_obs_kernel<V, true>), grid, block, lds_o, s, a, *of); \
+                else hipLaunchKernelGGL((cl_step_lean_obs_kernel<V, false>), grid, block, lds_o, s, a, *of); \
+                *fused = true; \
+            } else CL_LAUNCH_NT(cl_step_lean_kernel, V, false); \
             break;
+        CL_LEAN_CASE(1) CL_LEAN_CASE(2) CL_LEAN_CASE(4)
+#undef CL_LEAN_CASE
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else {
