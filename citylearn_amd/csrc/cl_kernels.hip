@@ -1132,7 +1132,9 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (!tp_kernel || tp_nw > 16)
             return fail(CL_EINVAL, "full_variant = 5: %d tiles x %d envs per lane x %d waves is not a launch of cl_step_full_tp_kernel for this district", tp_tiles, tp_vec, tp_nw);
     } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && tp_tiles * dims->n_bldg >= 12 && tp_grid > 192 && tp_grid <= 256;
-    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 256 || (tun.lean_variant & 2)) && !(tun.lean_variant & 1);
+    // (up to 352 workgroups: between 65 536 and 90 112 envs the latency-ordered kernel still beats the general and the env-major one,
+    //  17 x 81 920: 11.4 vs 12.7 / 12.9 us, scripts/lean_gap_sizes.py; from 106 496 envs the env-major kernel wins, 17 x 114 688: 13.5 vs 14.7 us)
+    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 352 || (tun.lean_variant & 2)) && !(tun.lean_variant & 1);
     if (flex && !full && lean_shape) {
         switch (vec) {
         case 1: CL_LAUNCH_NT(cl_step_lean_kernel, 1, true); break;
@@ -1201,7 +1203,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         case 4: hipLaunchKernelGGL((cl_step_kernel<4, true, false>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
-    } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 131072))) {
+    } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 106496))) {
         // two or more waves per SIMD: the env-major kernel (bench.py --envs-per-gpu: 17 x 131 072 17.0 vs 18.5 us,
         // 17 x 262 144 28.2 vs 32.5 us, 17 x 1 048 576 136 vs 157 us; at 17 x 65 536 -- one wave per SIMD, nothing to hide the
         // per-building dependency chain behind -- 13.1 vs 8.0 us)
