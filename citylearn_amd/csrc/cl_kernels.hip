@@ -1369,7 +1369,12 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     if (full && dims->n_bldg > 16) return fail(CL_EINVAL, "the fused rollout (thermal districts) supports n_bldg <= 16 (got %d): use cl_rollout_seq_f32", dims->n_bldg);
     a.nw = tun.nw ? tun.nw : (dims->n_bldg + mb - 1) / mb;
     if (a.nw * mb < dims->n_bldg || a.nw > 16) return fail(CL_EINVAL, "bad nw %d", a.nw);
-    const int vec = tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && dims->n_env >= 131072) ? 2 : 1);
+    // two envs per lane where its 128-env workgroups come in (nearly) full rounds of one per CU: 17 x 32 768 (the C5 per-GPU shard) 2.60 ->
+    // 2.31 us per step, 65 536 4.99 -> 4.19, 98 304 7.24 -> 6.19, 131 072 9.54 -> 8.21; 49 152 = 1.5 rounds: 4.20 vs 3.89 at one env per lane
+    // (scripts/rollout_vec_probe.py)
+    const long long wg2 = (dims->n_env + 127) / 128, rounds2 = (wg2 + 255) / 256;
+    const bool full_rounds = dims->n_env >= 32768 && wg2 * 100 >= rounds2 * 256 * 85;
+    const int vec = tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && full_rounds) ? 2 : 1);
     const int tile = 64 * vec;
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
