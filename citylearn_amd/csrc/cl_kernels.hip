@@ -1120,10 +1120,14 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // fewer than ~12 items per workgroup (3 x 65 536) or with more / fewer workgroups than CUs the one-tile kernel wins and stays.
     // full_variant: 5 forces it (tun.vec = envs per lane, tun.nw = waves, tun.b_chunk = tiles), 3 forbids it.
     const bool tp_forced = tun.full_variant == 5;
-    const int tp_vec = tp_forced && tun.vec == 1 ? 1 : 2;
-    const int tp_auto_tiles = (int)((dims->n_env + 256 * 64 * tp_vec - 1) / (256 * 64 * tp_vec));      // one workgroup per CU
+    // small batches (193 .. 256 one-env-per-lane tiles, i.e. up to 16 384 envs): one tile per workgroup, one WAVE per building --
+    // 9 x 16 384 5.62 -> 5.01 us, 6 x 16 384 5.50 -> 4.41, 12 x 16 384 6.15 -> 5.25, 16 x 16 384 6.26 -> 5.84 (scripts/tp_small_probe.py)
+    const unsigned tiles1 = (unsigned)((dims->n_env + 63) / 64);
+    const bool tp_small = !tp_forced && tiles1 > 192 && tiles1 <= 256 && dims->n_bldg >= 6 && dims->n_bldg <= 16;
+    const int tp_vec = (tp_forced && tun.vec == 1) || tp_small ? 1 : 2;
+    const int tp_auto_tiles = tp_small ? 1 : (int)((dims->n_env + 256 * 64 * tp_vec - 1) / (256 * 64 * tp_vec));      // one workgroup per CU
     const int tp_tiles = tp_forced ? (tun.b_chunk > 0 ? tun.b_chunk : CL_ROW0_BLOCK / (64 * tp_vec)) : tp_auto_tiles;
-    const int tp_nw = tp_forced && tun.nw ? tun.nw : 16;
+    const int tp_nw = tp_forced && tun.nw ? tun.nw : (tp_small ? dims->n_bldg : 16);
     const unsigned tp_grid = (unsigned)((dims->n_env + tp_tiles * 64 * tp_vec - 1) / (tp_tiles * 64 * tp_vec));
     const size_t tp_lds = ((size_t)tp_tiles * dims->n_bldg * NQ + tp_tiles) * 64 * tp_vec * sizeof(float);
     bool tp_kernel = full && !flex && !(dims->flags & CLD_WRITE_DETAIL) && a.n_chunks == 1 && dims->n_bldg <= 32 && tp_lds <= 150 * 1024 &&
@@ -1131,7 +1135,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (tp_forced) {
         if (!tp_kernel || tp_nw > 16)
             return fail(CL_EINVAL, "full_variant = 5: %d tiles x %d envs per lane x %d waves is not a launch of cl_step_full_tp_kernel for this district", tp_tiles, tp_vec, tp_nw);
-    } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && tp_tiles * dims->n_bldg >= 12 && tp_grid > 192 && tp_grid <= 256;
+    } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && (tp_small || tp_tiles * dims->n_bldg >= 12) && tp_grid > 192 && tp_grid <= 256;
     // (up to 352 workgroups: between 65 536 and 90 112 envs the latency-ordered kernel still beats the general and the env-major one,
     //  17 x 81 920: 11.4 vs 12.7 / 12.9 us, scripts/lean_gap_sizes.py; from 106 496 envs the env-major kernel wins, 17 x 114 688: 13.5 vs 14.7 us)
     const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 352 || (tun.lean_variant & 2)) && !(tun.lean_variant & 1);
