@@ -462,7 +462,7 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             od_n = of->start[b + 1] - d0;
 #pragma unroll
             for (int k = 0; k < CL_OBS_FUSED_PER_BLDG; ++k) {
-                const int d = d0 + min(k, max(od_n - 1, 0));
+                const int d = min(d0 + min(k, max(od_n - 1, 0)), CLOB_MAX_DEPS - 1);      // (a building without columns reads a valid, unused entry)
                 od_col[k] = of->deps[d].col; od_src[k] = of->deps[d].src; od_scale[k] = of->deps[d].scale;
                 od_base[k] = trow[od_col[k]];
             }
