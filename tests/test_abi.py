@@ -100,6 +100,13 @@ def test_argument_validation_without_gpu(lib):
     assert lib.cl_step_f32(ctypes.byref(d), p, p, p, p, 8, 1, p, p, None, None, 0, None) == abi.CL_EINVAL    # unknown reward kind
     d = _lib.Dims(0, 1, 10, 1, 0)
     assert lib.cl_reset_f32(ctypes.byref(d), p, p, None, None, None) == abi.CL_EINVAL
+    # cl_step_observe_f32 takes the compact observation form only: every column listed
+    lib.cl_step_observe_f32.argtypes = [ctypes.POINTER(_lib.Dims), vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp, vp, vp, vp, ctypes.c_int32,
+                                        vp, vp, vp, vp, ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    d = _lib.Dims(8, 1, 10, 1, 0)
+    assert lib.cl_step_observe_f32(ctypes.byref(d), p, p, p, p, 8, 1, p, p, None, None, 0, p, p, p, None, 2, p, 2, 4, 10, 1, None) == abi.CL_EINVAL
+    assert b'compact form' in lib.cl_last_error()
+    assert lib.cl_step_observe_f32(ctypes.byref(d), p, p, p, p, 8, 1, p, p, None, None, 0, None, p, p, p, 2, p, 2, 4, 10, 1, None) == abi.CL_ENULL
 
 
 def test_engine_refuses_to_run_without_gpu():
