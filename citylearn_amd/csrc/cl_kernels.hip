@@ -411,7 +411,7 @@ struct ObsFusedArgs {
     cl_obs_dep deps[CLOB_MAX_DEPS];     // grouped by building
 };
 
-template <int VEC, bool FLEX, bool NT, bool OBS>
+template <int VEC, bool FLEX, bool NT, bool OBS, bool KPI = false>
 CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of) {     // lds: [nw][NQ][64*VEC] (, then [64*VEC][pitch])
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
@@ -473,6 +473,7 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
         if (!act_by_bldg) load_action<VEC>(a_es[m], a, B.a_es, env0);
         CL_TRACE_WAITV(1 + 4 * m, s_deg[m][0]);
         float o_net[VEC], o_rw[VEC];
+        [[maybe_unused]] float o_cb[VEC];
         // chargers / washing machines of this building (cl_flex_kernel ran just before this launch)
         const int fbi = (FLEX && (B.flags & CLF_FLEX)) ? (int)B.p[CLP_FLEX_INDEX] : -1;
         float x_load[VEC];
@@ -520,11 +521,12 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
                     const float eb = cl::battery_energy(Bv, a_es[m][i] * Bv.pdt, S);
                     s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap;
                     soc_rw[i] = S.soc;
-                    o_net[i] = fmaf(c_ns + cbk * eb, B.r, sol);
+                    o_cb[i] = cbk * eb;                           // the battery's booked consumption (doubled at t = 0)
+                    o_net[i] = fmaf(c_ns + o_cb[i], B.r, sol);
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) { o_net[i] = fmaf(c_ns + 0.0f, B.r, sol); soc_rw[i] = 0.0f; }
+                for (int i = 0; i < VEC; ++i) { o_net[i] = fmaf(c_ns + 0.0f, B.r, sol); soc_rw[i] = 0.0f; o_cb[i] = 0.0f; }
             }
             cl::lean_rewards<VEC>(rkind, B, soc_rw, o_net, o_rw);
 #pragma unroll
@@ -541,6 +543,47 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
         }
         pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
         if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+        if constexpr (KPI && !FLEX) {
+            // The streaming KPI accumulators of this building, updated by the wave that holds its step in registers (cl_kpi_bldg_kernel's
+            // arithmetic, citylearn.py:1136-1323): a lean district has no outage and serves its whole load, so the unserved-energy sums
+            // do not move and `expected` is the load.  Baseline = the net without the battery (building.py:345-366); its plane is
+            // written for cl_kpi_env_kernel's district sums.
+            float base[VEC], v[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) base[i] = o_net[i] - o_cb[i] * B.r;
+            pstore<VEC, NT>(a.out_bldg + CLO_BASE_NET * plane + off, base);
+            auto add = [&](int kp, const float (&x)[VEC]) {
+                float k[VEC];
+                float* p = a.kpi_bldg + (long long)kp * plane + off;
+                vload<VEC>(k, p);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) k[i] += x[i];
+                pstore<VEC, false>(p, k);
+            };
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(o_net[i], 0.0f);
+            add(CLK_C_POS, v);
+            add(CLK_C_NET, o_net);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(o_net[i] * R.carbon, 0.0f);
+            add(CLK_C_EMISSION, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(o_net[i] * R.price, 0.0f);
+            add(CLK_C_COST, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(base[i], 0.0f);
+            add(CLK_B_POS, v);
+            add(CLK_B_NET, base);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(base[i] * R.carbon, 0.0f);
+            add(CLK_B_EMISSION, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(base[i] * R.price, 0.0f);
+            add(CLK_B_COST, v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[i] = R.nsl;
+            add(CLK_EXPECTED_ALL, v);
+        }
         if constexpr (OBS) {
             // this building's observation columns, into the workgroup's [64 * VEC envs][pitch] tile (streamed out below)
             float* tile = lds + (size_t)a.nw * NQ * TILE;
@@ -593,6 +636,12 @@ template <int VEC, bool FLEX, bool NT>
 __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     lean_step_body<VEC, FLEX, NT, false>(a, lds, nullptr);
+}
+
+template <int VEC, bool NT>
+__global__ void __launch_bounds__(1024) cl_step_lean_kpi_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lean_step_body<VEC, false, NT, false, true>(a, lds, nullptr);
 }
 
 template <int VEC, bool NT>
@@ -1020,7 +1069,10 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (int rc = check_ptr(out_bldg, "out_bldg")) return rc;
     if (int rc = check_ptr(out_env, "out_env")) return rc;
     if (dims->flags & CLD_KPI) {
-        if (!(dims->flags & CLD_WRITE_DETAIL)) return fail(CL_EINVAL, "CLD_KPI requires CLD_WRITE_DETAIL");
+        // the per-building accumulators read the detail planes -- except for battery + PV districts of up to 32 buildings, whose step
+        // kernel updates them itself (cl_step_lean_kpi_kernel)
+        if (!(dims->flags & CLD_WRITE_DETAIL) && (!(dims->flags & CLD_LEAN) || dims->n_bldg > 32 || flex))
+            return fail(CL_EINVAL, "CLD_KPI requires CLD_WRITE_DETAIL (except for CLD_LEAN districts of up to 32 buildings without flexible loads)");
         if (int rc = check_ptr(kpi_bldg, "kpi_bldg")) return rc;
         if (int rc = check_ptr(kpi_env, "kpi_env")) return rc;
     }
@@ -1138,7 +1190,9 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && (tp_small || tp_tiles * dims->n_bldg >= 12) && tp_grid > 192 && tp_grid <= 256;
     // (up to 352 workgroups: between 65 536 and 90 112 envs the latency-ordered kernel still beats the general and the env-major one,
     //  17 x 81 920: 11.4 vs 12.7 / 12.9 us, scripts/lean_gap_sizes.py; from 106 496 envs the env-major kernel wins, 17 x 114 688: 13.5 vs 14.7 us)
-    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 352 || (tun.lean_variant & 2)) && !(tun.lean_variant & 1);
+    // streaming KPIs without the detail planes: the lean kernel updates the per-building accumulators itself, at any grid size
+    const bool kpi_lean = (dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL);
+    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 352 || (tun.lean_variant & 2) || kpi_lean) && !((tun.lean_variant & 1) && !kpi_lean);
     if (flex && !full && lean_shape) {
         switch (vec) {
         case 1: CL_LAUNCH_NT(cl_step_lean_kernel, 1, true); break;
@@ -1207,7 +1261,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         case 4: hipLaunchKernelGGL((cl_step_kernel<4, true, false>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
-    } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 106496))) {
+    } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 106496))) {
         // two or more waves per SIMD: the env-major kernel (bench.py --envs-per-gpu: 17 x 131 072 17.0 vs 18.5 us,
         // 17 x 262 144 28.2 vs 32.5 us, 17 x 1 048 576 136 vs 157 us; at 17 x 65 536 -- one wave per SIMD, nothing to hide the
         // per-building dependency chain behind -- 13.1 vs 8.0 us)
@@ -1219,7 +1273,10 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // workgroups per CU) wins again -- 17 x 262 144: 30.8 us vs 33.0 us
         switch (vec) {                                   // latency-ordered lean kernel (two buildings per wave at most)
 #define CL_LEAN_CASE(V) case V: \
-            if (of && rkind_host != CLR_MARL) {       /* (MARL's reward plane is finished after the sweep the tile is filled in) */ \
+            if (kpi_lean) { \
+                if (a.nt) hipLaunchKernelGGL((cl_step_lean_kpi_kernel<V, true>), grid, block, lds, s, a); \
+                else hipLaunchKernelGGL((cl_step_lean_kpi_kernel<V, false>), grid, block, lds, s, a); \
+            } else if (of && rkind_host != CLR_MARL) {       /* (MARL's reward plane is finished after the sweep the tile is filled in) */ \
                 const size_t lds_o = lds + (size_t)tile * of->pitch * sizeof(float); \
                 if (a.nt) hipLaunchKernelGGL((cl_step_lean_obs_kernel<V, true>), grid, block, lds_o, s, a, *of); \
                 else hipLaunchKernelGGL((cl_step_lean_obs_kernel<V, false>), grid, block, lds_o, s, a, *of); \
@@ -1247,7 +1304,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     }
     if (dims->flags & CLD_KPI) {
         const long long n = (long long)dims->n_env * dims->n_bldg;
-        hipLaunchKernelGGL(cl_kpi_bldg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        if (dims->flags & CLD_WRITE_DETAIL) hipLaunchKernelGGL(cl_kpi_bldg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
         hipLaunchKernelGGL(cl_kpi_env_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");

@@ -92,7 +92,6 @@ class StepEngine:
         self.reward = reward
         flags = (REWARD_KINDS[reward] << abi.CLD_REWARD_SHIFT)
         flags |= abi.CLD_REF_T0_QUIRK if t0_quirk else 0
-        flags |= abi.CLD_WRITE_DETAIL if (detail or kpi) else 0
         flags |= abi.CLD_KPI if kpi else 0
         flags |= abi.CLD_CENTRAL_AGENT if central_agent else 0      # only read by the CLR_EV reward
         self.kpi = kpi
@@ -100,6 +99,10 @@ class StepEngine:
         heavy = abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS
         self.lean = not bool(np.any(bflags & heavy)) and not bool(np.any(tables.ts[:, :, [abi.CLT_COOL_DEM, abi.CLT_HEAT_DEM, abi.CLT_DHW_DEM]]))
         flags |= abi.CLD_LEAN if self.lean else 0
+        # the streaming KPI passes read the detail planes -- except for battery + PV districts of up to 32 buildings, whose step kernel
+        # updates the per-building accumulators itself (cl_step_lean_kpi_kernel): no detail planes, no second pass
+        kpi_in_step = kpi and self.lean and self.n_bldg <= 32 and self.flex_tables is None
+        flags |= abi.CLD_WRITE_DETAIL if (detail or (kpi and not kpi_in_step)) else 0
         es_cols = tables.params.view(np.int32)[:, abi.CLP_ACT_ELEC_STO]
         if np.array_equal(es_cols, np.arange(self.n_bldg)):          # one battery action per building, building order
             flags |= abi.CLD_ES_COL_IS_BLDG

@@ -220,7 +220,9 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 
 #define CLD_REF_T0_QUIRK   (1u << 0)  /* replicate the reference's repeated t=0 update_variables (SURVEY App.B1) */
 #define CLD_WRITE_DETAIL   (1u << 1)  /* also write CLO_B_EB .. CLO_C_NSL planes (parity / KPI baselines) */
-#define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators (requires CLD_WRITE_DETAIL) */
+#define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators (requires CLD_WRITE_DETAIL, except for CLD_LEAN districts of up to 32
+                                         buildings stepped without flexible loads: their step kernel updates the accumulators itself and writes
+                                         CLO_BASE_NET as the only extra plane) */
 #define CLD_ES_COL_IS_BLDG   (1u << 4)  /* hint: the electrical_storage action column of building b is column b (one action per
                                           building, building order) -- lets the step issue its action loads before the parameters */
 #define CLD_CENTRAL_AGENT  (1u << 5)  /* CLR_EV only: central_agent districts scale every building's charger terms by the DISTRICT

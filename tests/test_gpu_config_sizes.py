@@ -202,3 +202,23 @@ def test_lds_staged_parameters_match_scalar_parameters(kind):
             lds.step(a, t); sgpr.step(a, t)
             assert torch.equal(lds.state, sgpr.state) and torch.equal(lds.out_env, sgpr.out_env), t
             assert torch.equal(lds.out_bldg[:2], sgpr.out_bldg[:2]), t
+
+
+@pytest.mark.parametrize('E,tuning', [(65536, None), (516, None), (132, dict(vec=4, lean_variant=2))])
+def test_kpi_accumulators_updated_by_the_lean_step_kernel(E, tuning):
+    """`CLD_KPI` without the detail planes (battery + PV districts of up to 32 buildings): `cl_step_lean_kpi_kernel` updates the twelve
+    per-building accumulators from registers and writes only the baseline plane `cl_kpi_env_kernel` needs -- same accumulators as the
+    two passes over the detail planes (`cl_kpi_bldg_kernel`), which the reference-pinned KPI tests of tests/test_env_gpu.py cover."""
+    tab = golden('g2022_all').spec().episode_tables(0)
+    fused = StepEngine(tab, E, kpi=True, tuning=tuning)
+    two_pass = StepEngine(tab, E, kpi=True, detail=True)
+    assert not (fused.dims.flags & abi.CLD_WRITE_DETAIL) and (two_pass.dims.flags & abi.CLD_WRITE_DETAIL)
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    for t in range(30):
+        a = torch.rand((fused.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        fused.step(a, t); two_pass.step(a, t)
+    assert torch.equal(fused.state, two_pass.state) and torch.equal(fused.out_bldg[:2], two_pass.out_bldg[:2])
+    torch.testing.assert_close(fused.out_bldg[abi.CLO_BASE_NET], two_pass.out_bldg[abi.CLO_BASE_NET], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(fused.kpi_bldg, two_pass.kpi_bldg, rtol=2e-6, atol=1e-5)
+    torch.testing.assert_close(fused.kpi_env, two_pass.kpi_env, rtol=2e-5, atol=1e-4)
+    assert fused.kpi_bldg.abs().sum().item() > 0
