@@ -1,3 +1,5 @@
+"""Chunk geometry of the building-chunked launches (b_chunk x waves per workgroup x envs per lane) on the C4 shards, and waves per
+workgroup on the non-chunked thermal shapes (GPU box)."""
 import sys, os
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
