@@ -5,6 +5,10 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests')); sys.path.insert(0, str(ROOT / 'scripts'))
 from golden_util import golden
+import os
+from citylearn_amd import _lib
+if os.environ.get('CL_ALT_LIB'):
+    _lib.LIB_PATH = Path(os.environ['CL_ALT_LIB']).resolve()
 from citylearn_amd.engine import StepEngine
 from c4_bench import measure
 for name, E in (('g2022_all', 65536), ('g2020_cz1', 65536)):
