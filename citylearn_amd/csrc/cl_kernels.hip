@@ -11,6 +11,7 @@
 #include "cl_unit.h"
 #include "cl_philox.h"
 
+#include <type_traits>
 #include <stdarg.h>
 #include <string.h>
 #include <stdio.h>
@@ -1493,17 +1494,23 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
     const dim3 grid((dims->n_env + 127) / 128, dims->n_bldg);          // 4 waves x 32 envs per workgroup
     a.lstm_wb = lstm_wb;
     if (int rc = check_ptr(lstm_wb, "lstm_wb", false)) return rc;
+    const bool f16 = dims->flags & CLD_LSTM_F16;
+#define CL_LSTM_LAUNCH(DBG, SPLIT) hipLaunchKernelGGL((cl_lstm_kernel<DBG, SPLIT>), grid, dim3(256), 0, (hipStream_t)stream, a)
+#define CL_LSTM_LAUNCH_WB(DBG) do { if (f16) CL_LSTM_LAUNCH(DBG, 2); else CL_LSTM_LAUNCH(DBG, 1); } while (0)
     switch (tun.lstm_variant) {            // timing experiments (scripts/lstm_check.py); 0 in production
-    case 1: hipLaunchKernelGGL((cl_lstm_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL((cl_lstm_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 3: hipLaunchKernelGGL((cl_lstm_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a); break;   // f32 MFMA path
-    case 5: hipLaunchKernelGGL((cl_lstm_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 6: hipLaunchKernelGGL((cl_lstm_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;
-    case 8: hipLaunchKernelGGL((cl_lstm_kernel<8, true>), grid, dim3(256), 0, (hipStream_t)stream, a); break;   // two-term split
+    case 1: CL_LSTM_LAUNCH(1, 0); break;
+    case 2: CL_LSTM_LAUNCH(2, 0); break;
+    case 3: CL_LSTM_LAUNCH(0, 0); break;                                   // f32 MFMA path
+    case 5: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 5 needs lstm_wb"); CL_LSTM_LAUNCH_WB(1); break;
+    case 6: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 6 needs lstm_wb"); CL_LSTM_LAUNCH_WB(2); break;
+    case 16: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 16 needs lstm_wb"); CL_LSTM_LAUNCH_WB(16); break;   // pre-gates as the C operand
+    case 8: if (!lstm_wb || f16) return fail(CL_EINVAL, "lstm_variant 8 needs bf16 lstm_wb"); CL_LSTM_LAUNCH(8, 1); break;   // two-term bf16 split
     default:
-        if (lstm_wb) hipLaunchKernelGGL((cl_lstm_kernel<0, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((cl_lstm_kernel<0, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        if (lstm_wb) CL_LSTM_LAUNCH_WB(0);
+        else CL_LSTM_LAUNCH(0, 0);
     }
+#undef CL_LSTM_LAUNCH_WB
+#undef CL_LSTM_LAUNCH
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_kernel launch");
     return CL_OK;
 }

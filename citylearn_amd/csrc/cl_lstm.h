@@ -59,7 +59,9 @@
 namespace {
 
 CL_DEV float sigmoidf_(float x) { return cl::rcp(1.0f + __expf(-x)); }
-CL_DEV float tanhf_(float x) { return 2.0f * cl::rcp(1.0f + __expf(-2.0f * x)) - 1.0f; }
+// exp(-2 x) = exp2(x * (-2 log2 e)): one multiply instead of two, and bit-identical to __expf(-2.0f * x) = exp2((-2 x) * log2 e)
+// because the factor 2 is exact
+CL_DEV float tanhf_(float x) { return 2.0f * cl::rcp(1.0f + __builtin_amdgcn_exp2f(x * -2.885390043258667f)) - 1.0f; }
 
 // ComfortReward.calculate for one building (reward_function.py:269-334).
 CL_DEV float comfort_reward(float temp, float cool_dem, float heat_dem, float mode, float csp, float hsp, float band,
@@ -98,13 +100,14 @@ struct LstmArgs {
 
 // What every variant of the stage leaves per (building, env): the indoor temperature, ComfortReward and the streaming
 // discomfort KPIs.
+// (`heat`: the delivered heating of this step, 0 without a heating plane -- loaded by the caller, early)
 CL_DEV void lstm_outputs(const LstmArgs& a, const float* __restrict__ W, const float* __restrict__ pre_t, long long off, long long plane,
-                         float temp, float cool) {
+                         float temp, float cool, float heat) {
     a.indoor_temp[off] = temp;
     if (a.comfort) {
         const float band_p = W[CLW_RW_BAND];
         const float band = band_p == band_p ? band_p : pre_t[CLPRE_BAND];
-        a.comfort[off] = comfort_reward(temp, cool, a.heat_dem ? a.heat_dem[off] : 0.0f, pre_t[CLPRE_HVAC], pre_t[CLPRE_CSP],
+        a.comfort[off] = comfort_reward(temp, cool, heat, pre_t[CLPRE_HVAC], pre_t[CLPRE_CSP],
                                         pre_t[CLPRE_HSP], band, W[CLW_RW_LOEXP], W[CLW_RW_HIEXP]);
     }
     if (a.kpi_comfort) {
@@ -170,11 +173,19 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
 // resident workgroup so that one wave's MFMA chains meet the other's activations: 165 us without, 166 - 218 us with offsets of
 // 0.5 - 4 us -- the two phases of co-resident waves do not overlap either way.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-/* lstm_wb layout (CL_LSTM_NWB = 18 * 64 * 8 bf16 per building): fragment f = 6 * matrix{hh0, ih1, hh1} + 3 * row_block + term,
-   then [lane][8]: W[32 row_block + (lane & 31)][unit u(j, lane >> 5)], j = 0..7 */
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+/* lstm_wb layout (stride CL_LSTM_NWB 16-bit words per building): fragment f = (2 * matrix{hh0, ih1, hh1} + row_block) * T + term,
+   T = 3 bf16 terms or (CLD_LSTM_F16) 2 f16 terms, then [lane][8]: W[32 row_block + (lane & 31)][unit u(j, lane >> 5)], j = 0..7 */
 
-template <int TERMS = 3>
-CL_DEV void lstm_split3(const float (&h)[8], bf16x8 (&t)[3]) {
+// SPLIT = 1: three bf16 terms per operand, the six partial products with i + j <= 2 (dropped terms <= 2^-24 |W||h|).
+// SPLIT = 2: two f16 terms per operand (x = x0 + x1 + r, |r| <= 2^-22 |x|, or 2^-25 absolute where x1 is subnormal), the three
+//            partial products with i + j <= 1: half the matrix-pipe time and 20 fewer VALU operations per cell for an error of
+//            <= 3 * 2^-22 |W||h| -- a few fp32 roundings of the gate sums, which the reference's own fp32 accumulation also has.
+template <int SPLIT> struct LstmSplit { typedef bf16x8 v8; typedef __bf16 elem; static constexpr int T = 3; };
+template <> struct LstmSplit<2> { typedef f16x8 v8; typedef _Float16 elem; static constexpr int T = 2; };
+
+template <int N, int TERMS, typename V8, typename E>
+CL_DEV void lstm_split(const float (&h)[8], V8 (&t)[N]) {
     float r[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = h[j];
@@ -182,69 +193,110 @@ CL_DEV void lstm_split3(const float (&h)[8], bf16x8 (&t)[3]) {
     for (int k = 0; k < TERMS; ++k) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const __bf16 q = (__bf16)r[j];                 // round to nearest even (v_cvt_pk_bf16_f32)
+            const E q = (E)r[j];                            // round to nearest even (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
             t[k][j] = q;
-            r[j] -= (float)q;                              // exact
+            if (k + 1 < TERMS) r[j] -= (float)q;           // exact
         }
     }
 }
 
-// acc_r += sum_{i + j <= 2} A_r,i B_j for the two row blocks r, smallest terms first; the two accumulators alternate so
-// that consecutive MFMAs are independent
-// DBG & 8 (experiment, cl_debug_set_lstm(8)): two terms per operand, the three partial products with i + j <= 1 (dropped terms
+CL_DEV f32x16 lstm_mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+CL_DEV f32x16 lstm_mfma16(const f16x8& a, const f16x8& b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// acc_r = c_r + sum_{i + j < T} A_r,i B_j for the two row blocks r, smallest terms first; the two accumulators alternate so that
+// consecutive MFMAs are independent.  `c0` / `c1` may be the accumulators themselves (continue a sum) or other registers (the
+// first product of a chain reads its bias from there: no instruction spent on initialising the accumulators).
+// DBG & 8 (experiment): two bf16 terms per operand, the three partial products with i + j <= 1 (dropped terms
 // <= 2^-16 |W||h|): 134 us instead of 160 us at 3 x 65 536, but |dT| grows from 5.7e-6 to 1.1e-4 C over the 24 cells and
 // ComfortReward (cubic in the temperature error) misses the 1e-4 tolerance by 1.3x -- not used.
-template <int DBG = 0>
-CL_DEV void lstm_mma6(const bf16x8 (&A0)[3], const bf16x8 (&A1)[3], const bf16x8 (&B)[3], f32x16& acc0, f32x16& acc1) {
-    if constexpr (DBG & 2) { acc0[0] += (float)B[0][0]; acc1[0] += (float)B[1][0] + (float)B[2][0]; return; }   // timing experiment
-#define CL_MMA2(I, J)                                                                   \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[I], B[J], acc0, 0, 0, 0);          \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[I], B[J], acc1, 0, 0, 0);
-    if constexpr (DBG & 8) { CL_MMA2(1, 0) CL_MMA2(0, 1) CL_MMA2(0, 0) }
-    else { CL_MMA2(2, 0) CL_MMA2(1, 1) CL_MMA2(0, 2) CL_MMA2(1, 0) CL_MMA2(0, 1) CL_MMA2(0, 0) }
+template <int DBG, int T, typename V8>
+CL_DEV void lstm_mma(const V8 (&A0)[T], const V8 (&A1)[T], const V8 (&B)[T], const f32x16& c0, const f32x16& c1, f32x16& acc0, f32x16& acc1) {
+    if constexpr (DBG & 2) {                                     // timing experiment: no MFMA
+        acc0 = c0; acc1 = c1; acc0[0] += (float)B[0][0]; acc1[0] += (float)B[1][0] + (float)B[T - 1][0]; return;
+    }
+#define CL_MMA2(I, J, C0, C1) acc0 = lstm_mfma16(A0[I], B[J], C0); acc1 = lstm_mfma16(A1[I], B[J], C1);
+    if constexpr (T == 2 || (DBG & 8)) { CL_MMA2(1, 0, c0, c1) CL_MMA2(0, 1, acc0, acc1) CL_MMA2(0, 0, acc0, acc1) }
+    else { CL_MMA2(2, 0, c0, c1) CL_MMA2(1, 1, acc0, acc1) CL_MMA2(0, 2, acc0, acc1) CL_MMA2(1, 0, acc0, acc1) CL_MMA2(0, 1, acc0, acc1) CL_MMA2(0, 0, acc0, acc1) }
 #undef CL_MMA2
 }
 
-template <int DBG, bool SPLIT>
+// Wave-timeline stamps of the diagnostic build (-DCL_TRACE, scripts/lstm_timeline.py): REFCLK (100 MHz) values parked in the lanes of
+// one VGPR (a compare and a select: no memory access, no exec change, no new basic block) and written out once at the end.  `v` is a value the
+// stamp must follow; the v_mov makes the wave really wait for it (an MFMA result is not there when the MFMA has issued).
+#ifdef CL_TRACE
+#define CL_LT_PUT(val, k) lt_stamp = (lane == (k)) ? (unsigned)(val) : lt_stamp
+#define CL_LT(k, v) do { unsigned long long t_; float q_ = (v); \
+    asm("v_mov_b32 %1, %1\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(q_)); (v) = q_; \
+    CL_LT_PUT((unsigned)t_, (k)); } while (0)
+#else
+#define CL_LT(k, v)
+#endif
+
+template <int DBG, int SPLIT>
 __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
+    typedef typename LstmSplit<SPLIT>::v8 v8;
+    typedef typename LstmSplit<SPLIT>::elem elem;
+    constexpr int NT = LstmSplit<SPLIT>::T;
     const int lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
     const int wv = threadIdx.x >> 6;
     const int b = blockIdx.y;
     const int e = (blockIdx.x * 4 + wv) * 32 + col;
     const bool live = e < a.n_env;
+#ifdef CL_TRACE
+    unsigned lt_stamp = 0u;
+    { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); CL_LT_PUT((unsigned)t_, 0); }
+#endif
     const int ec = live ? e : a.n_env - 1;
     const long long plane = (long long)a.n_bldg * a.n_env;
     const long long off = (long long)b * a.n_env + ec;
     const float* __restrict__ W = a.lstm_w + (long long)b * CL_LSTM_NW;
     const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * 128) / CL_ROW0_BLOCK] : 0;      // workgroup = 128 envs: uniform
     const float* __restrict__ pre_t = a.dyn_pre + ((long long)(a.t + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
-    if (W[CLW_ACTIVE] >= 2.0f) return;                           // another LSTM shape: cl_lstm_generic_kernel owns this building
+    const float act = W[CLW_ACTIVE];
+    if (act >= 2.0f) return;                                     // another LSTM shape: cl_lstm_generic_kernel owns this building
+    const float tmin = W[CLW_TMIN], tmax = W[CLW_TMAX], cmin = W[CLW_CMIN], cmax = W[CLW_CMAX];
+    // the demand the model was trained on: delivered cooling, or delivered heating for a heating-driven model
+    const float* __restrict__ dem_src = (W[CLW_DEM_HEAT] != 0.0f && a.heat_dem) ? a.heat_dem : a.cool_dem;
+    const int slot = a.t % CL_LSTM_LOOKBACK;
+    if (act == 0.0f || a.t < CL_LSTM_LOOKBACK) {                 // block-uniform: no dynamics model, or the window is still filling
+        const float cool = a.cool_dem[off];                      // (lookback + 1 samples must exist, building.py:2996-2999)
+        if (act != 0.0f && live && hh == 0) {
+            a.hist[(long long)slot * plane + off] = (dem_src[off] - cmin) / (cmax - cmin);               // building.py:3068-3078
+            a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = pre_t[CLPRE_TNORM];            // building.py:3027-3028
+        }
+        if (live && hh == 0) lstm_outputs(a, W, pre_t, off, plane, pre_t[CLPRE_TRAW], cool, a.heat_dem ? a.heat_dem[off] : 0.0f);   // the data-file temperature
+        return;
+    }
+    // From here on: one straight line up to the window loop.  Everything the wave needs from memory is requested first, in one
+    // batch (weights, carried state, biases, this step's demand, the inputs of window steps 0 and 1), and only then used: with the
+    // loads left where their values are first needed the compiler requests the recurrent weights of layer 1 after the first
+    // layer-0 products have waited for theirs -- two or three memory round trips in a row at the start of every wave
+    // (entry -> first gates 3.8 us, window step 0 6.6 us instead of 1.9 us at 3 x 65 536, scripts/lstm_timeline.py).
     const float cool = a.cool_dem[off];
-    float temp = pre_t[CLPRE_TRAW];
-    if (W[CLW_ACTIVE] != 0.0f) {                                  // block-uniform
-        const float tmin = W[CLW_TMIN], tmax = W[CLW_TMAX], cmin = W[CLW_CMIN], cmax = W[CLW_CMAX];
-        // the demand the model was trained on: delivered cooling, or delivered heating for a heating-driven model
-        const float dem = (W[CLW_DEM_HEAT] != 0.0f && a.heat_dem) ? a.heat_dem[off] : cool;
-        const float cool_n = (dem - cmin) / (cmax - cmin);
-        const int slot = a.t % CL_LSTM_LOOKBACK;
-        if (live && hh == 0) a.hist[(long long)slot * plane + off] = cool_n;         // building.py:3068-3078
-        float y = pre_t[CLPRE_TNORM];
-        if (a.t >= CL_LSTM_LOOKBACK) {                            // lookback + 1 samples exist (building.py:2996-2999)
+    const float dem = dem_src[off];
+    const float heat = a.heat_dem ? a.heat_dem[off] : 0.0f;      // (ComfortReward, at the very end)
+    float wlin[8];                                               // Linear(16 -> 1) weights of this lane's eight units
+#pragma unroll
+    for (int m = 0; m < 8; ++m) wlin[m] = W[CLW_WLIN + lstm_unit(m, hh)];
+    const float blin = W[CLW_BLIN];
+    float temp, y;
+    {
+        {
             // A operands: row = 32 rb + col of the torch gate matrix, k-slot 2 kk + hh -> hidden unit u(kk)
             float a_hh0[2][8], a_x0[2], a_ih1[2][8], a_hh1[2][8];
-            bf16x8 A_hh0[2][3], A_ih1[2][3], A_hh1[2][3];
+            v8 A_hh0[2][NT], A_ih1[2][NT], A_hh1[2][NT];
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int row = 32 * rb + col;
                 a_x0[rb] = hh ? W[CLW_WT + row] : W[CLW_WC + row];
                 if constexpr (SPLIT) {
-                    const bf16x8* __restrict__ F = reinterpret_cast<const bf16x8*>(a.lstm_wb + (long long)b * CL_LSTM_NWB);
+                    const v8* __restrict__ F = reinterpret_cast<const v8*>(a.lstm_wb + (long long)b * CL_LSTM_NWB);
 #pragma unroll
-                    for (int k = 0; k < ((DBG & 8) ? 2 : 3); ++k) {
-                        A_hh0[rb][k] = F[(0 * 6 + rb * 3 + k) * 64 + lane];
-                        A_ih1[rb][k] = F[(1 * 6 + rb * 3 + k) * 64 + lane];
-                        A_hh1[rb][k] = F[(2 * 6 + rb * 3 + k) * 64 + lane];
+                    for (int k = 0; k < ((DBG & 8) ? 2 : NT); ++k) {
+                        A_hh0[rb][k] = F[((0 * 2 + rb) * NT + k) * 64 + lane];
+                        A_ih1[rb][k] = F[((1 * 2 + rb) * NT + k) * 64 + lane];
+                        A_hh1[rb][k] = F[((2 * 2 + rb) * NT + k) * 64 + lane];
                     }
                 } else {
 #pragma unroll
@@ -277,21 +329,56 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const float one_b = hh ? 0.0f : 1.0f;
             const float a_b1[2] = {W[CLW_B1 + col], W[CLW_B1 + 32 + col]};
+            // ring rows without a division or a branch in the loop: time % 12 = (m + s) mod 12, (time - 1) % 12 = that - 1 mod 12
+            const int ring_m = (a.t - (CL_LSTM_LOOKBACK - 1)) % CL_LSTM_LOOKBACK;           // a.t >= 12 here
+            const float* __restrict__ hist_lane = a.hist + off + (hh ? (long long)CL_LSTM_LOOKBACK * plane : 0ll);
+            // The env-independent layer-0 pre-gates of a step are two values per lane and one extra K = 2 MFMA per row block.
+            // PRE_C (experiment, DBG & 16): loaded straight in the C/D layout instead (16 values per row block and lane, four 16-byte
+            // loads each, the same addresses across a half-wave) as the C operand of the chain's first MFMA -- two MFMAs fewer per
+            // step but eight loads and 32 registers more: 119.2 vs 117.5 us with the f16 split, 168 vs 142 us with bf16 (256 registers).
+            constexpr bool PRE_C = SPLIT != 0 && (DBG & 16);
+            typedef float lstm_f4 __attribute__((ext_vector_type(4)));
+            auto fetch_pre_c = [&](int s, f32x16& p0, f32x16& p1) {
+                const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
+                const lstm_f4* __restrict__ q = reinterpret_cast<const lstm_f4*>(a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                  // rows 8 j + 4 hh + (0..3) of block 0 / block 1
+                    const lstm_f4 v0 = q[hh + 2 * j], v1 = q[8 + hh + 2 * j];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { p0[4 * j + i] = v0[i]; p1[4 * j + i] = v1[i]; }
+                }
+            };
             auto fetch = [&](int s, float (&ap)[2], float& xin) {
                 const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
                 const float* __restrict__ pre = a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
-                ap[0] = pre[col]; ap[1] = pre[32 + col];
+                if constexpr (!PRE_C) { ap[0] = pre[col]; ap[1] = pre[32 + col]; }
                 // extra k-pair of layer 0: slot 0 = cooling demand at `time`, slot 1 = temperature at `time - 1`
-                const long long hrow = hh ? (long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) : (long long)(time % CL_LSTM_LOOKBACK);
-                xin = a.hist[hrow * plane + off];                          // (step 11, slot 0 is overridden at the point of use)
+                int r0 = ring_m + s; r0 -= r0 >= CL_LSTM_LOOKBACK ? CL_LSTM_LOOKBACK : 0;
+                const int r1 = r0 == 0 ? CL_LSTM_LOOKBACK - 1 : r0 - 1;
+                xin = hist_lane[(long long)(hh ? r1 : r0) * plane];        // (step 11, slot 0 is overridden at the point of use)
             };
-            bf16x8 H0[3], H1[3];                                          // split hidden states (B operands)
+            v8 H0[NT], H1[NT];                                            // split hidden states (B operands)
+            auto split = [&](const float (&h)[8], v8 (&t)[NT]) { lstm_split<NT, (DBG & 8) ? 2 : NT, v8, elem>(h, t); };
+            // layer-1 bias in the C/D layout of the two row blocks: the first product of every layer-1 chain reads it as its C operand
+            f32x16 bias1[2];
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bias1[rb][r] = W[CLW_B1 + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh];
+            }
+            f32x16 pg0, pg1;                                              // PRE_C: pre-gates of the next layer-0 cell (one step ahead)
             auto layer0 = [&](const float (&ap)[2], float xin, f32x16& d0, f32x16& d1) {
-                d0 = CL_MFMA(ap[0], one_b, zero16);
-                d1 = CL_MFMA(ap[1], one_b, zero16);
-                d0 = CL_MFMA(a_x0[0], xin, d0);
-                d1 = CL_MFMA(a_x0[1], xin, d1);
-                if constexpr (SPLIT) lstm_mma6<DBG>(A_hh0[0], A_hh0[1], H0, d0, d1);
+                if constexpr (PRE_C) {
+                    d0 = CL_MFMA(a_x0[0], xin, pg0);
+                    d1 = CL_MFMA(a_x0[1], xin, pg1);
+                } else {
+                    d0 = CL_MFMA(ap[0], one_b, zero16);
+                    d1 = CL_MFMA(ap[1], one_b, zero16);
+                    d0 = CL_MFMA(a_x0[0], xin, d0);
+                    d1 = CL_MFMA(a_x0[1], xin, d1);
+                }
+                if constexpr (SPLIT) lstm_mma<DBG>(A_hh0[0], A_hh0[1], H0, d0, d1, d0, d1);
                 else {
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
@@ -301,16 +388,30 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
                 }
             };
             f32x16 d0, d1, e0, e1;
-            float ap[2], xin, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f;
-            if constexpr (SPLIT) { lstm_split3<(DBG & 8) ? 2 : 3>(h0, H0); lstm_split3<(DBG & 8) ? 2 : 3>(h1, H1); }
+            float ap[2], xin, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f, ap_nn[2] = {0.0f, 0.0f}, xin_nn = 0.0f;
+            if constexpr (PRE_C) fetch_pre_c(0, pg0, pg1);
             fetch(0, ap, xin);
+            fetch(1, ap_n, xin_n);
+            __builtin_amdgcn_sched_barrier(0);                             // every load above is issued before anything below
+            const float cool_n = (dem - cmin) / (cmax - cmin);
+            if (live && hh == 0) a.hist[(long long)slot * plane + off] = cool_n;         // building.py:3068-3078
+            if constexpr (SPLIT) { split(h0, H0); split(h1, H1); }
             layer0(ap, xin, d0, d1);
-            for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
-                fetch(min(s + 1, CL_LSTM_LOOKBACK - 1), ap_n, xin_n);    // unconditional: no wait is forced at a join
-                e0 = CL_MFMA(a_b1[0], one_b, zero16);
-                e1 = CL_MFMA(a_b1[1], one_b, zero16);
-                if constexpr (SPLIT) lstm_mma6<DBG>(A_hh1[0], A_hh1[1], H1, e0, e1);
+            CL_LT(1, d0[15]);                                             // weights, carried state and the first inputs arrived; first layer-0 gates done
+            // One window step.  The last one is peeled off the loop (`last`): with the `if (s + 1 < 12)` of a plain loop around
+            // layer0 the compiler sinks the history load into that conditional block, right in front of its use (a full
+            // memory latency on every step of every wave), and the block's 16 MFMAs are scheduled apart from the activations
+            // that follow; as straight-line code the load stays at the top and the MFMAs interleave with the VALU work.
+            auto window_step = [&](int s, auto last) {
+                constexpr bool LAST = decltype(last)::value;
+                // the three per-lane inputs of layer 0 are fetched two steps before their use (rotated at the end of the step)
+                if constexpr (!LAST) fetch(min(s + 2, CL_LSTM_LOOKBACK - 1), ap_nn, xin_nn);
+                if constexpr (!LAST && PRE_C) fetch_pre_c(s + 1, pg0, pg1);      // (one step ahead: 32 registers; the rows are cache-resident)
+                if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);                  // the loads stay first ...
+                if constexpr (SPLIT) lstm_mma<DBG>(A_hh1[0], A_hh1[1], H1, bias1[0], bias1[1], e0, e1);
                 else {
+                    e0 = CL_MFMA(a_b1[0], one_b, zero16);
+                    e1 = CL_MFMA(a_b1[1], one_b, zero16);
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         e0 = CL_MFMA(a_hh1[0][kk], h1[kk], e0);
@@ -318,9 +419,14 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                CL_LT(2 + 4 * s, e1[15]);                                   // W_hh1 h1 done (issued first, beside the previous activations)
                 lstm_act<DBG>(d0, d1, c0, h0);
-                if constexpr (SPLIT) { lstm_split3<(DBG & 8) ? 2 : 3>(h0, H0); lstm_mma6<DBG>(A_ih1[0], A_ih1[1], H0, e0, e1); }
-                else {
+                if constexpr (SPLIT) {
+                    split(h0, H0);
+                    CL_LT(3 + 4 * s, h0[7]);                                  // layer-0 cell update done
+                    __builtin_amdgcn_sched_barrier(0);          // ... and their consumers (layer0 below) a cell's worth of work later
+                    lstm_mma<DBG>(A_ih1[0], A_ih1[1], H0, e0, e1, e0, e1);
+                } else {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
@@ -329,12 +435,21 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
                     }
                 }
                 // the newest cooling sample (step 11, k-slot 0) was produced by this launch, not read from the ring
-                if (s + 1 < CL_LSTM_LOOKBACK) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
+                if constexpr (!LAST) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
                 if constexpr (!SPLIT) __builtin_amdgcn_sched_barrier(0);
+                CL_LT(4 + 4 * s, e1[15]);                                   // W_ih1 h0 done: layer-1 gates complete
                 lstm_act<DBG>(e0, e1, c1, h1);
-                if constexpr (SPLIT) lstm_split3<(DBG & 8) ? 2 : 3>(h1, H1);
+                CL_LT(5 + 4 * s, h1[7]);                                    // layer-1 cell update done
+                if constexpr (SPLIT) { if constexpr (!LAST) split(h1, H1); }
                 else __builtin_amdgcn_sched_barrier(0);
-            }
+                if constexpr (!LAST) {                              // rotate at the very end: the copies wait for this step's loads
+                    __builtin_amdgcn_sched_barrier(0);
+                    ap_n[0] = ap_nn[0]; ap_n[1] = ap_nn[1]; xin_n = xin_nn;
+                    CL_LT(50 + s, xin_n);                                     // the inputs fetched at the top of this step have arrived
+                }
+            };
+            for (int s = 0; s < CL_LSTM_LOOKBACK - 1; ++s) window_step(s, std::false_type{});
+            window_step(CL_LSTM_LOOKBACK - 1, std::true_type{});
 #undef CL_MFMA
             if (live) {
 #pragma unroll
@@ -347,14 +462,23 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             // Linear(16 -> 1): this lane's eight units, then the other half of the env (lane ^ 32)
             float part = 0.0f;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) part = fmaf(W[CLW_WLIN + lstm_unit(m, hh)], h1[m], part);
+            for (int m = 0; m < 8; ++m) part = fmaf(wlin[m], h1[m], part);
             const float other = __shfl_xor(part, 32);
-            y = W[CLW_BLIN] + (hh ? other + part : part + other);
+            y = blin + (hh ? other + part : part + other);
             temp = fmaf(y, tmax - tmin, tmin);                           // building.py:3031-3037
         }
         if (live && hh == 0) a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;   // building.py:3027-3028
     }
-    if (live && hh == 0) lstm_outputs(a, W, pre_t, off, plane, temp, cool);
+    if (live && hh == 0) lstm_outputs(a, W, pre_t, off, plane, temp, cool, heat);
+#ifdef CL_TRACE
+    {
+        unsigned long long t_;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+        CL_LT_PUT((unsigned)t_, 62);
+        CL_LT_PUT(__builtin_amdgcn_s_getreg(63492) | (__builtin_amdgcn_s_getreg(63508) << 16), 63);   // HW_ID | XCC_ID << 16
+        if (g_cl_trace) reinterpret_cast<unsigned*>(g_cl_trace)[(((long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wv) * 64 + lane] = lt_stamp;
+    }
+#endif
 }
 
 // ---- any other LSTM shape (hidden size <= 64, one or two layers): plain fp32 FMAs -------------------------------------
@@ -462,7 +586,7 @@ __global__ void __launch_bounds__(64) cl_lstm_generic_kernel(const LstmGenArgs g
     }
     if (live) {
         a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;              // building.py:3027-3028
-        lstm_outputs(a, W, pre_t, off, plane, temp, cool);
+        lstm_outputs(a, W, pre_t, off, plane, temp, cool, a.heat_dem ? a.heat_dem[off] : 0.0f);
     }
 }
 

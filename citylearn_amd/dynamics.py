@@ -192,23 +192,36 @@ def _bf16_split3(x: np.ndarray) -> np.ndarray:
     return np.stack(out)
 
 
-def pack_lstm_bf16(lstm_w: np.ndarray) -> np.ndarray:
-    """The three recurrent matrices of `lstm_w` ([B, CL_LSTM_NW], padded 64 x 16 layout) as split-bf16 MFMA A-operand
-    fragments: ``[B, 18, 64, 8]`` uint16, fragment ``6 * matrix{hh0, ih1, hh1} + 3 * row_block + term``, element
+def _f16_split2(x: np.ndarray) -> np.ndarray:
+    """x -> [2, ...] uint16: two round-to-nearest-even f16 terms with x ~= t0 + t1 (|x - t0 - t1| <= 2^-22 |x|, or 2^-25 absolute
+    where t1 is subnormal)."""
+    r = np.asarray(x, dtype=np.float32)
+    if np.abs(r).max(initial=0.0) >= 65504.0:
+        raise ValueError('LSTM weight outside the f16 range: use the bf16 split')
+    t0 = r.astype(np.float16)
+    t1 = (r - t0.astype(np.float32)).astype(np.float16)          # the residual is exact in fp32
+    return np.stack([t0.view(np.uint16), t1.view(np.uint16)])
+
+
+def pack_lstm_split(lstm_w: np.ndarray, fmt: str = 'bf16') -> np.ndarray:
+    """The three recurrent matrices of `lstm_w` ([B, CL_LSTM_NW], padded 64 x 16 layout) as split 16-bit MFMA A-operand
+    fragments: ``[B, 18, 64, 8]`` uint16 (the CL_LSTM_NWB stride of the C-ABI), fragment ``(2 * matrix{hh0, ih1, hh1} + row_block) * T
+    + term`` with T = 3 bf16 terms (`fmt` 'bf16') or 2 f16 terms ('f16': the first 12 fragments, CLD_LSTM_F16), element
     ``[lane][j] = W[32 row_block + (lane & 31)][unit (j & 3) + 8 (j >> 2) + 4 (lane >> 5)]`` (csrc/cl_lstm.h)."""
     B = lstm_w.shape[0]
     out = np.zeros((B, 18, 64, 8), dtype=np.uint16)
     lane = np.arange(64)
     j = np.arange(8)
     unit = (j[None, :] & 3) + 8 * (j[None, :] >> 2) + 4 * (lane[:, None] >> 5)      # [64, 8]
+    T, split_fn = {'bf16': (3, _bf16_split3), 'f16': (2, _f16_split2)}[fmt]
     for m, base in enumerate((WHH0, WIH1, WHH1)):
         Wm = lstm_w[:, base:base + 1024].reshape(B, 64, 16)
         for rb in range(2):
             rows = 32 * rb + (lane & 31)                                             # [64]
             frag = Wm[:, rows[:, None], unit]                                        # [B, 64, 8]
-            split = _bf16_split3(frag)                                               # [3, B, 64, 8]
-            for k in range(3):
-                out[:, m * 6 + rb * 3 + k] = split[k]
+            split = split_fn(frag)                                                   # [T, B, 64, 8]
+            for k in range(T):
+                out[:, (m * 2 + rb) * T + k] = split[k]
     return out
 
 
@@ -216,9 +229,12 @@ class LSTMStage:
     """Device state + driver of the LSTM stage for one env shard (pairs with a `StepEngine` built with detail=True)."""
 
     def __init__(self, spec: DistrictSpec, tables: EpisodeTables, engine, band=None, lower_exponent: float = 2.0,
-                 higher_exponent: float = 2.0, kpi: bool = False, kpi_band: float = 2.0, split_bf16: bool = True):
+                 higher_exponent: float = 2.0, kpi: bool = False, kpi_band: float = 2.0, split: Optional[str] = 'f16'):
         """`kpi`: accumulate the discomfort KPIs on the device (`kpi_comfort`, finalised by `kpi.finalize_comfort`) with the
-        scalar comfort band `kpi_band` (`CityLearnEnv.evaluate`'s ``comfort_band``, default 2.0 C -- data.py:399)."""
+        scalar comfort band `kpi_band` (`CityLearnEnv.evaluate`'s ``comfort_band``, default 2.0 C -- data.py:399).
+        `split`: operand format of the recurrent products on the matrix cores -- 'f16' (two terms per operand, three partial
+        products: the default), 'bf16' (three terms, six partial products: twice the matrix-pipe time for dropped terms of
+        2^-24 instead of 3 * 2^-22 relative) or None (exact f32 MFMA)."""
         self.lib = _lib.load()
         self.engine = engine
         self._args = None
@@ -227,8 +243,11 @@ class LSTMStage:
         dev = engine.device
         self.any_active = bool(lstm_w[:, ACTIVE].any())
         self.lstm_w = torch.from_numpy(lstm_w).to(dev)
-        # split-bf16 fragments of the recurrent matrices (bf16 matrix-core path); int16 storage of the raw bf16 bits
-        self.lstm_wb = torch.from_numpy(pack_lstm_bf16(lstm_w).view(np.int16)).to(dev) if split_bf16 else None
+        # split 16-bit fragments of the recurrent matrices (matrix-core path); int16 storage of the raw bits
+        self.lstm_wb = torch.from_numpy(pack_lstm_split(lstm_w, split).view(np.int16)).to(dev) if split else None
+        self.dims = _lib.Dims.from_buffer_copy(engine.dims)          # the engine's dims (never mutated) + the operand-format flag
+        if split == 'f16':
+            self.dims.flags |= abi.CLD_LSTM_F16
         self.dyn_pre = torch.from_numpy(dyn_pre).to(dev)
         B, E = engine.n_bldg, engine.n_env
         self.hist = torch.zeros((abi.CL_LSTM_NHIST, B, E), dtype=torch.float32, device=dev)
@@ -264,7 +283,7 @@ class LSTMStage:
         ``cool_dem`` / ``heat_dem``: delivered cooling / heating planes to use instead of the engine's own (tests)."""
         e = self.engine
         if self._args is None:          # per-step arguments that never change, converted once
-            self._args = ((ctypes.byref(e.dims), self.lstm_w.data_ptr(), None if self.lstm_wb is None else self.lstm_wb.data_ptr(),
+            self._args = ((ctypes.byref(self.dims), self.lstm_w.data_ptr(), None if self.lstm_wb is None else self.lstm_wb.data_ptr(),
                            self.dyn_pre.data_ptr()),
                           (self.hist.data_ptr(), self.hidden.data_ptr(), self.indoor_temp.data_ptr(), self.comfort.data_ptr(),
                            None if self.kpi_comfort is None else self.kpi_comfort.data_ptr()),

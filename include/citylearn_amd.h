@@ -230,6 +230,8 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 #define CLD_LEAN           (1u << 3)  /* caller asserts: no building has a thermal device / tank, outage or dynamics
                                          flag (battery + PV + non-shiftable load only, e.g. the 2022 schemas) ->
                                          the specialised lean kernel may be used */
+#define CLD_LSTM_F16       (1u << 6)  /* cl_lstm_step_f32 only: `lstm_wb` holds two f16 terms per weight (dynamics.pack_lstm_split(.., 'f16'))
+                                         instead of three bf16 terms */
 #define CLD_REWARD_SHIFT   8          /* reward kind in bits 8..11 */
 #define CLD_REWARD_MASK    (0xFu << CLD_REWARD_SHIFT)
 enum cl_reward_kind {
@@ -348,9 +350,11 @@ int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, float* kp
  * `comfort` (optional) receives ComfortReward.calculate per building (reward_function.py:269-334) evaluated on that
  * temperature; `heat_dem` (optional) is the delivered heating plane it compares the cooling demand with;
  * `kpi_comfort` (optional) accumulates the discomfort KPIs.
- * `lstm_wb` (optional, [n_bldg][CL_LSTM_NWB] bf16): the recurrent weight matrices split into three bf16 terms and laid
- * out as MFMA A-operand fragments (dynamics.pack_lstm_bf16).  When given, the recurrent products run on the bf16 matrix
- * cores with split operands (fp32-level accuracy, csrc/cl_lstm.h); NULL selects the exact f32-MFMA kernel. */
+ * `lstm_wb` (optional, [n_bldg][CL_LSTM_NWB] 16-bit words): the recurrent weight matrices split into three bf16 terms -- or, with
+ * CLD_LSTM_F16 in dims->flags, two f16 terms (the first 6144 words of each building's block) -- and laid out as MFMA A-operand
+ * fragments (dynamics.pack_lstm_split).  When given, the recurrent products run on the 16-bit matrix cores with split operands
+ * (bf16 x 3: dropped terms <= 2^-24 |W||h|; f16 x 2: <= 3 * 2^-22 |W||h| at half the matrix-pipe time; csrc/cl_lstm.h); NULL selects
+ * the exact f32-MFMA kernel. */
 #define CL_LSTM_NWB 9216
 int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* lstm_wb, const float* dyn_pre, const float* cool_dem,
                      const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,

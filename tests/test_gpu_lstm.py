@@ -12,11 +12,13 @@ from citylearn_amd.dynamics import LSTMStage
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name', ['g2023_p2', 's_baeda', 's_2023_p1', 's_2023_p3', 'g2023_heat'])
-def test_lstm_stage_fed_with_reference_cooling(name):
+@pytest.mark.parametrize('name,split', [('g2023_p2', 'f16'), ('s_baeda', 'f16'), ('s_2023_p1', 'f16'), ('s_2023_p3', 'f16'), ('g2023_heat', 'f16'),
+                                        ('g2023_p2', 'bf16'), ('s_baeda', 'bf16'), ('g2023_heat', 'bf16'), ('g2023_p2', None), ('s_2023_p3', None)])
+def test_lstm_stage_fed_with_reference_cooling(name, split):
     """Isolates the stage: the delivered cooling of every step comes from the reference; temperatures within 1e-4 C
     relative and ComfortReward within 1e-4 (+1e-4) of the reference for every step and building (2023: LSTM(13 -> 16),
-    3 and 6 buildings; baeda_3dem: three LSTM(11 -> 8, 2 layers) embedded in the 16-wide kernel + one LSTM(11 -> 50, 1 layer))."""
+    3 and 6 buildings; baeda_3dem: three LSTM(11 -> 8, 2 layers) embedded in the 16-wide kernel + one LSTM(11 -> 50, 1 layer)).
+    `split`: the operand format of the recurrent products -- two f16 terms (default), three bf16 terms, or the exact f32 MFMA."""
     g = golden(name)
     spec = g.spec()
     cols = list(range(len(spec.buildings)))
@@ -31,7 +33,7 @@ def test_lstm_stage_fed_with_reference_cooling(name):
     attrs = spec.reward_function.get('attributes') or {}
     E = 64
     eng = StepEngine(tab, E, detail=True)
-    stage = LSTMStage(spec, tab, eng, attrs.get('band'), attrs.get('lower_exponent') or 2.0, attrs.get('higher_exponent') or 2.0)
+    stage = LSTMStage(spec, tab, eng, attrs.get('band'), attrs.get('lower_exponent') or 2.0, attrs.get('higher_exponent') or 2.0, split=split)
     cool = torch.from_numpy(g.ref['cool_dem'][:, cols]).cuda()
     # g2023_heat (synthetic: heating device actions, hvac_mode 0-3, one heating-driven model): the delivered heating plane too
     heat = torch.from_numpy(g.ref['heat_dem'][:, cols]).cuda() if 'heat_dem' in g.ref.files else None
