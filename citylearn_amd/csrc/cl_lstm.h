@@ -152,9 +152,12 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
     }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const float cn = sigmoidf_(d0[8 + m]) * c[m] + sigmoidf_(d0[m]) * tanhf_(d1[m]);     // f c + i g
+        // the gate rows arrive pre-multiplied by -log2 e (i, f, o) / -2 log2 e (g) (dynamics.pack_lstm): 2^z = exp(-x) / exp(-2 x)
+        const float gi = cl::rcp(1.0f + __builtin_amdgcn_exp2f(d0[m])), gf = cl::rcp(1.0f + __builtin_amdgcn_exp2f(d0[8 + m]));
+        const float gg = 2.0f * cl::rcp(1.0f + __builtin_amdgcn_exp2f(d1[m])) - 1.0f, go = cl::rcp(1.0f + __builtin_amdgcn_exp2f(d1[8 + m]));
+        const float cn = gf * c[m] + gi * gg;                                                 // f c + i g
         c[m] = cn;
-        h[m] = sigmoidf_(d1[8 + m]) * tanhf_(cn);                                            // o tanh(c)
+        h[m] = go * tanhf_(cn);                                                               // o tanh(c)
     }
 }
 
@@ -398,36 +401,49 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             if constexpr (SPLIT) { split(h0, H0); split(h1, H1); }
             layer0(ap, xin, d0, d1);
             CL_LT(1, d0[15]);                                             // weights, carried state and the first inputs arrived; first layer-0 gates done
-            // One window step.  The last one is peeled off the loop (`last`): with the `if (s + 1 < 12)` of a plain loop around
-            // layer0 the compiler sinks the history load into that conditional block, right in front of its use (a full
-            // memory latency on every step of every wave), and the block's 16 MFMAs are scheduled apart from the activations
-            // that follow; as straight-line code the load stays at the top and the MFMAs interleave with the VALU work.
-            auto window_step = [&](int s, auto last) {
-                constexpr bool LAST = decltype(last)::value;
+            // The window loop, software-pipelined across the two layers.  Each layer is a strict chain matrix product -> cell update ->
+            // matrix product, so inside one wave matrix-core work can only run beside the OTHER layer's cell update (and the second
+            // wave of the SIMD does not fill the gaps: the older wave wins every arbitration, the younger one advances at a fifth of
+            // the speed until the older one ends -- scripts/lstm_timeline.py).  Layer 1 therefore runs one step behind layer 0:
+            //   phase A(s): cell update of layer 0, step s          beside   e(s-1) += W_hh1 h1(s-2)
+            //   phase B(s): cell update of layer 1, step s-1        beside   e(s) = b1 + W_ih1 h0(s),  d(s+1) = layer-0 gates of step s+1
+            // and every matrix product is issued next to a cell update that does not depend on it.  The window is 12 steps, so the
+            // first and the last step are written out (no branch inside the loop: with an `if` around a stage the compiler sinks that
+            // stage's loads into the conditional block, right in front of their use).
+            auto fetch_ahead = [&](int s) {
                 // the three per-lane inputs of layer 0 are fetched two steps before their use (rotated at the end of the step)
-                if constexpr (!LAST) fetch(min(s + 2, CL_LSTM_LOOKBACK - 1), ap_nn, xin_nn);
-                if constexpr (!LAST && PRE_C) fetch_pre_c(s + 1, pg0, pg1);      // (one step ahead: 32 registers; the rows are cache-resident)
-                if constexpr (SPLIT) __builtin_amdgcn_sched_barrier(0);                  // the loads stay first ...
-                if constexpr (SPLIT) lstm_mma<DBG>(A_hh1[0], A_hh1[1], H1, bias1[0], bias1[1], e0, e1);
+                fetch(min(s + 2, CL_LSTM_LOOKBACK - 1), ap_nn, xin_nn);
+                if constexpr (PRE_C) fetch_pre_c(s + 1, pg0, pg1);          // (one step ahead: 32 registers; the rows are cache-resident)
+                __builtin_amdgcn_sched_barrier(0);                          // the loads stay first
+            };
+            auto rotate = [&](int s) {                                      // at the very end: the copies wait for this step's loads
+                __builtin_amdgcn_sched_barrier(0);
+                ap_n[0] = ap_nn[0]; ap_n[1] = ap_nn[1]; xin_n = xin_nn;
+                CL_LT(50 + s, xin_n);                                       // the inputs fetched at the top of this step have arrived
+            };
+            auto hh1_product = [&]() {                                      // e += W_hh1 h1
+                if constexpr (SPLIT) lstm_mma<DBG>(A_hh1[0], A_hh1[1], H1, e0, e1, e0, e1);
                 else {
-                    e0 = CL_MFMA(a_b1[0], one_b, zero16);
-                    e1 = CL_MFMA(a_b1[1], one_b, zero16);
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         e0 = CL_MFMA(a_hh1[0][kk], h1[kk], e0);
                         e1 = CL_MFMA(a_hh1[1][kk], h1[kk], e1);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-                CL_LT(2 + 4 * s, e1[15]);                                   // W_hh1 h1 done (issued first, beside the previous activations)
+            };
+            auto phase_a = [&](int s, auto has_h) {
+                if constexpr (decltype(has_h)::value) hh1_product();
                 lstm_act<DBG>(d0, d1, c0, h0);
-                if constexpr (SPLIT) {
-                    split(h0, H0);
-                    CL_LT(3 + 4 * s, h0[7]);                                  // layer-0 cell update done
-                    __builtin_amdgcn_sched_barrier(0);          // ... and their consumers (layer0 below) a cell's worth of work later
-                    lstm_mma<DBG>(A_ih1[0], A_ih1[1], H0, e0, e1, e0, e1);
-                } else {
-                    __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SPLIT) split(h0, H0);
+                CL_LT(3 + 4 * s, h0[7]);                                    // layer-0 cell update of step s done
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto phase_b = [&](int s, auto has_e, auto has_l0) {
+                const f32x16 g0 = e0, g1 = e1;                              // the complete layer-1 gates of step s - 1
+                if constexpr (SPLIT) lstm_mma<DBG>(A_ih1[0], A_ih1[1], H0, bias1[0], bias1[1], e0, e1);
+                else {
+                    e0 = CL_MFMA(a_b1[0], one_b, zero16);
+                    e1 = CL_MFMA(a_b1[1], one_b, zero16);
 #pragma unroll
                     for (int kk = 0; kk < 8; ++kk) {
                         e0 = CL_MFMA(a_ih1[0][kk], h0[kk], e0);
@@ -435,21 +451,21 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
                     }
                 }
                 // the newest cooling sample (step 11, k-slot 0) was produced by this launch, not read from the ring
-                if constexpr (!LAST) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
-                if constexpr (!SPLIT) __builtin_amdgcn_sched_barrier(0);
-                CL_LT(4 + 4 * s, e1[15]);                                   // W_ih1 h0 done: layer-1 gates complete
-                lstm_act<DBG>(e0, e1, c1, h1);
-                CL_LT(5 + 4 * s, h1[7]);                                    // layer-1 cell update done
-                if constexpr (SPLIT) { if constexpr (!LAST) split(h1, H1); }
-                else __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!LAST) {                              // rotate at the very end: the copies wait for this step's loads
-                    __builtin_amdgcn_sched_barrier(0);
-                    ap_n[0] = ap_nn[0]; ap_n[1] = ap_nn[1]; xin_n = xin_nn;
-                    CL_LT(50 + s, xin_n);                                     // the inputs fetched at the top of this step have arrived
+                if constexpr (decltype(has_l0)::value) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
+                if constexpr (decltype(has_e)::value) {
+                    lstm_act<DBG>(g0, g1, c1, h1);
+                    if constexpr (SPLIT) split(h1, H1);
+                    CL_LT(5 + 4 * (s - 1), h1[7]);                          // layer-1 cell update of step s - 1 done
                 }
             };
-            for (int s = 0; s < CL_LSTM_LOOKBACK - 1; ++s) window_step(s, std::false_type{});
-            window_step(CL_LSTM_LOOKBACK - 1, std::true_type{});
+            constexpr std::true_type yes{};
+            constexpr std::false_type no{};
+            fetch_ahead(0); phase_a(0, no); phase_b(0, no, yes); rotate(0);
+            for (int s = 1; s < CL_LSTM_LOOKBACK - 1; ++s) { fetch_ahead(s); phase_a(s, yes); phase_b(s, yes, yes); rotate(s); }
+            phase_a(CL_LSTM_LOOKBACK - 1, yes); phase_b(CL_LSTM_LOOKBACK - 1, yes, no);
+            hh1_product();                                                  // drain: layer 1 of the last step
+            lstm_act<DBG>(e0, e1, c1, h1);
+            CL_LT(5 + 4 * (CL_LSTM_LOOKBACK - 1), h1[7]);
 #undef CL_MFMA
             if (live) {
 #pragma unroll

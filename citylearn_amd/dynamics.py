@@ -35,6 +35,10 @@ def _exo_feature(b, name: str, w: slice) -> np.ndarray:
     return np.asarray(b.series[name][w], dtype=np.float64)
 
 
+# -log2(e) for the sigmoid gates i, f, o and -2 log2(e) for the tanh gate g, rows [i; f; g; o] x 16 (cl_lstm.h: lstm_act)
+GATE_SCALE = -np.log2(np.e) * np.repeat([1.0, 1.0, 2.0, 1.0], 16)
+
+
 def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_exponent: float = 2.0, higher_exponent: float = 2.0,
               kpi_band: float = 2.0):
     """Returns ``(lstm_w [B, CL_LSTM_NW] f32, dyn_pre [T, B, CL_LSTM_NPRE] f32)``; `band` / exponents are the
@@ -79,11 +83,13 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
 
         # A hidden size below 16 is embedded exactly: the padded units have zero weights and biases, so their cell and
         # hidden state stay 0 (c = 0.5 c + 0.5 tanh(0) = 0, h = 0.5 tanh(0) = 0) and nothing reads them.
-        def gates(m):                                   # torch rows [i; f; g; o] x H  ->  [i; f; g; o] x 16
+        # The gate rows are pre-multiplied (in float64, one rounding to fp32) by -log2(e) (i, f, o) / -2 log2(e) (g): the kernel's
+        # sigmoid / tanh are 1 / (1 + 2^z) and 2 / (1 + 2^z) - 1 of the accumulated z (one multiply per activation less).
+        def gates(m):                                   # torch rows [i; f; g; o] x H  ->  scaled [i; f; g; o] x 16
             m = np.asarray(m, dtype=np.float64)
             out = np.zeros((4, 16) + m.shape[1:])
             out[:, :H] = m.reshape((4, H) + m.shape[1:])
-            return out.reshape((64,) + m.shape[1:])
+            return out.reshape((64,) + m.shape[1:]) * GATE_SCALE.reshape((64,) + (1,) * (m.ndim - 1))
 
         def cols(m):                                    # [rows, H] -> [rows, 16]
             out = np.zeros((m.shape[0], 16))

@@ -321,6 +321,8 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
  * dyn_pre [n_steps][n_bldg][CL_LSTM_NPRE]  host-precomputed env-independent part of the layer-0 gates per (t, building)
  * hist    [24][n_bldg][n_env]              rings of the last 12 normalised cooling demands and indoor temperatures
  * hidden  [n_bldg][n_env][64]              h0[16], c0[16], h1[16], c1[16] carried across env steps
+ * The 64 gate rows of every weight matrix, of the layer-1 bias and of `dyn_pre` are stored pre-multiplied by -log2(e) (gates i, f, o)
+ * and -2 log2(e) (gate g): sigmoid(x) = 1 / (1 + 2^z) and tanh(x) = 2 / (1 + 2^z) - 1 then take the accumulated z as it is.
  * (layouts: citylearn_amd/csrc/cl_lstm.h, packer: citylearn_amd/dynamics.py) */
 #define CL_LSTM_NW   3296
 #define CL_LSTM_NPRE 80
