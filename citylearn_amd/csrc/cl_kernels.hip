@@ -1503,7 +1503,6 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
     case 3: CL_LSTM_LAUNCH(0, 0); break;                                   // f32 MFMA path
     case 5: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 5 needs lstm_wb"); CL_LSTM_LAUNCH_WB(1); break;
     case 6: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 6 needs lstm_wb"); CL_LSTM_LAUNCH_WB(2); break;
-    case 16: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 16 needs lstm_wb"); CL_LSTM_LAUNCH_WB(16); break;   // pre-gates as the C operand
     case 8: if (!lstm_wb || f16) return fail(CL_EINVAL, "lstm_variant 8 needs bf16 lstm_wb"); CL_LSTM_LAUNCH(8, 1); break;   // two-term bf16 split
     default:
         if (lstm_wb) CL_LSTM_LAUNCH_WB(0);

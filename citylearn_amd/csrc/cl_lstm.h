@@ -336,25 +336,13 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             const int ring_m = (a.t - (CL_LSTM_LOOKBACK - 1)) % CL_LSTM_LOOKBACK;           // a.t >= 12 here
             const float* __restrict__ hist_lane = a.hist + off + (hh ? (long long)CL_LSTM_LOOKBACK * plane : 0ll);
             // The env-independent layer-0 pre-gates of a step are two values per lane and one extra K = 2 MFMA per row block.
-            // PRE_C (experiment, DBG & 16): loaded straight in the C/D layout instead (16 values per row block and lane, four 16-byte
-            // loads each, the same addresses across a half-wave) as the C operand of the chain's first MFMA -- two MFMAs fewer per
-            // step but eight loads and 32 registers more: 119.2 vs 117.5 us with the f16 split, 168 vs 142 us with bf16 (256 registers).
-            constexpr bool PRE_C = SPLIT != 0 && (DBG & 16);
-            typedef float lstm_f4 __attribute__((ext_vector_type(4)));
-            auto fetch_pre_c = [&](int s, f32x16& p0, f32x16& p1) {
-                const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
-                const lstm_f4* __restrict__ q = reinterpret_cast<const lstm_f4*>(a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {                  // rows 8 j + 4 hh + (0..3) of block 0 / block 1
-                    const lstm_f4 v0 = q[hh + 2 * j], v1 = q[8 + hh + 2 * j];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { p0[4 * j + i] = v0[i]; p1[4 * j + i] = v1[i]; }
-                }
-            };
+            // (Tried: loading them straight in the C/D layout -- 16 values per row block and lane, four 16-byte loads each -- as the C
+            // operand of the chain's first MFMA, the way the layer-1 bias enters: two MFMAs fewer per step but eight loads and 32
+            // registers more: 119.2 vs 117.5 us with the f16 split, 168 vs 142 us with bf16 at 256 registers.)
             auto fetch = [&](int s, float (&ap)[2], float& xin) {
                 const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
                 const float* __restrict__ pre = a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
-                if constexpr (!PRE_C) { ap[0] = pre[col]; ap[1] = pre[32 + col]; }
+                ap[0] = pre[col]; ap[1] = pre[32 + col];
                 // extra k-pair of layer 0: slot 0 = cooling demand at `time`, slot 1 = temperature at `time - 1`
                 int r0 = ring_m + s; r0 -= r0 >= CL_LSTM_LOOKBACK ? CL_LSTM_LOOKBACK : 0;
                 const int r1 = r0 == 0 ? CL_LSTM_LOOKBACK - 1 : r0 - 1;
@@ -370,17 +358,11 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) bias1[rb][r] = W[CLW_B1 + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh];
             }
-            f32x16 pg0, pg1;                                              // PRE_C: pre-gates of the next layer-0 cell (one step ahead)
             auto layer0 = [&](const float (&ap)[2], float xin, f32x16& d0, f32x16& d1) {
-                if constexpr (PRE_C) {
-                    d0 = CL_MFMA(a_x0[0], xin, pg0);
-                    d1 = CL_MFMA(a_x0[1], xin, pg1);
-                } else {
-                    d0 = CL_MFMA(ap[0], one_b, zero16);
-                    d1 = CL_MFMA(ap[1], one_b, zero16);
-                    d0 = CL_MFMA(a_x0[0], xin, d0);
-                    d1 = CL_MFMA(a_x0[1], xin, d1);
-                }
+                d0 = CL_MFMA(ap[0], one_b, zero16);
+                d1 = CL_MFMA(ap[1], one_b, zero16);
+                d0 = CL_MFMA(a_x0[0], xin, d0);
+                d1 = CL_MFMA(a_x0[1], xin, d1);
                 if constexpr (SPLIT) lstm_mma<DBG>(A_hh0[0], A_hh0[1], H0, d0, d1, d0, d1);
                 else {
 #pragma unroll
@@ -392,7 +374,6 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             };
             f32x16 d0, d1, e0, e1;
             float ap[2], xin, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f, ap_nn[2] = {0.0f, 0.0f}, xin_nn = 0.0f;
-            if constexpr (PRE_C) fetch_pre_c(0, pg0, pg1);
             fetch(0, ap, xin);
             fetch(1, ap_n, xin_n);
             __builtin_amdgcn_sched_barrier(0);                             // every load above is issued before anything below
@@ -413,7 +394,6 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             auto fetch_ahead = [&](int s) {
                 // the three per-lane inputs of layer 0 are fetched two steps before their use (rotated at the end of the step)
                 fetch(min(s + 2, CL_LSTM_LOOKBACK - 1), ap_nn, xin_nn);
-                if constexpr (PRE_C) fetch_pre_c(s + 1, pg0, pg1);          // (one step ahead: 32 registers; the rows are cache-resident)
                 __builtin_amdgcn_sched_barrier(0);                          // the loads stay first
             };
             auto rotate = [&](int s) {                                      // at the very end: the copies wait for this step's loads
