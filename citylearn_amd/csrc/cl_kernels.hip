@@ -745,6 +745,7 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
     a.out_env[(long long)CLQ_REWARD * a.n_env + env] = q_rw;
 }
 
+#ifndef CL_TU_ROLLOUT      /* (cl_rollout_tu.hip compiles only what the fused rollout kernel needs) */
 // Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x ONE district
 // quantity x 16 waves; wave w adds chunks w, w+16, ... (independent loads issued four at a time: one memory round trip for up
 // to 64 chunks), then the 16 wave partials are summed in a fixed order through LDS -- deterministic.  (The first version let one
@@ -897,11 +898,44 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
             kpi_env[(long long)k * n_env + i] = is_max ? -INFINITY : 0.0f;
         }
 }
+#endif  // CL_TU_ROLLOUT
 
 }  // namespace
 
+#ifndef CL_TU_ROLLOUT
 #include "cl_full.h"
+#endif
 #include "cl_rollout.h"
+
+// The fused rollout kernel lives in a translation unit of its own (cl_rollout_tu.hip = this file with CL_TU_ROLLOUT, built with
+// -fno-slp-vectorize): with two envs per lane the SLP vectoriser packs the two envs' identical fp32 operations into v_pk_*_f32, which
+// cost more than the two plain operations they replace -- 17 x 32 768: 2.34 -> 2.14 us per step, 65 536: 4.26 -> 3.88 (same box,
+// profiles/r02e_noslp_ab2.log).  The same switch is a loss for the LSTM kernel (109.8 -> 115.5 us) and the chunked thermal launches
+// (14.75 -> 15.08 us) and within the noise for the step kernels, hence per translation unit and not for the whole library.
+extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int key, int pin, unsigned grid, unsigned block, size_t lds,
+                                                                          void* stream, const void* rollout_args);
+
+#ifdef CL_TU_ROLLOUT
+extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int key, int pin, unsigned grid, unsigned block_threads, size_t lds,
+                                                                          void* stream, const void* rollout_args) {
+    const RolloutArgs& r = *static_cast<const RolloutArgs*>(rollout_args);       // the struct of the including translation unit: same source
+    const dim3 block(block_threads);
+    hipStream_t s = (hipStream_t)stream;
+    switch (key) {        // (full ? 100 : 0) + 10 * envs per lane + buildings per wave
+    case 11: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 1>), dim3(grid), block, lds, s, r); break;
+    case 12:
+        if (pin) hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2>), dim3(grid), block, lds, s, r);
+        else hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, false>), dim3(grid), block, lds, s, r);      // whole launch resident at once: see PIN
+        break;
+    case 21: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 1>), dim3(grid), block, lds, s, r); break;
+    case 22: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2>), dim3(grid), block, lds, s, r); break;
+    case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), dim3(grid), block, lds, s, r); break;
+    default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+#else
+
 #include "cl_lstm.h"
 #include "cl_observe.h"
 
@@ -1441,20 +1475,11 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
-    hipStream_t s = (hipStream_t)stream;
     const int key = (full ? 100 : 0) + vec * 10 + mb;
-    switch (key) {
-    case 11: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 1>), dim3(grid), block, lds, s, r); break;
-    case 12:
-        if ((long long)grid * a.nw > 5 * 1024) hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2>), dim3(grid), block, lds, s, r);
-        else hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, false>), dim3(grid), block, lds, s, r);      // whole launch resident at once: see PIN
-        break;
-    case 21: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 1>), dim3(grid), block, lds, s, r); break;
-    case 22: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2>), dim3(grid), block, lds, s, r); break;
-    case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), dim3(grid), block, lds, s, r); break;
-    default: return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
-    }
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_kernel launch");
+    if (key != 11 && key != 12 && key != 21 && key != 22 && key != 111)
+        return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
+    const int rc = cl_tu_launch_rollout(key, (long long)grid * a.nw > 5 * 1024, grid, block.x, lds, stream, &r);
+    if (rc) return hip_fail((hipError_t)rc, "cl_rollout_kernel launch");
     return CL_OK;
 }
 
@@ -1631,3 +1656,4 @@ float cl_philox_uniform(uint64_t seed, uint32_t env, uint32_t col, uint32_t t) {
 }
 
 }  // extern "C"
+#endif  // CL_TU_ROLLOUT

@@ -9,15 +9,21 @@
 //       the hidden / cell state is carried from one env step's call to the next, building.py:3023-3024)
 //
 // Mapping: see cl_lstm_kernel below -- the 64 x K gate pre-activations of a cell are a small GEMM over the env batch and
-// run on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, bit-for-bit an fmaf chain).  Eleven of the thirteen
-// input features do not depend on the env (weather, calendar, set point, occupancy); their contribution to the
-// layer-0 gates, W_ih0[:, exo] . x_exo(t) + b0, is precomputed on the host per (t, building) (`dyn_pre`) and seeds the
-// accumulators, leaving 2 per-env inputs (delivered cooling, previous indoor temperature) for layer 0.
-// Per unit and env step: 12 window steps x (64 x 18 + 64 x 32) fused multiply-adds ~ 77 kFLOP -> MFMA-bound.
-// Two VALU variants were measured first on MI355X at 3 buildings x 65 536 envs: lane = env with the weights streamed
-// through SGPRs (555 us per step, scalar-load latency bound) and lane = (env, hidden unit) with the weights resident in
-// 200 VGPRs and ds_swizzle broadcasts (467 us, dependent-FMA latency bound at 1-2 waves per SIMD); the MFMA form
-// below runs the same step in 220 us at better accuracy (the K order is the only numerical difference).
+// run on the matrix cores: the recurrent products W h with split 16-bit operands (two f16 or three bf16 terms, fp32-level
+// results), the K = 2 remainder of layer 0 on v_mfma_f32_32x32x2_f32 (exact fp32).  Eleven of the thirteen input features do
+// not depend on the env (weather, calendar, set point, occupancy); their contribution to the layer-0 gates,
+// W_ih0[:, exo] . x_exo(t) + b0, is precomputed on the host per (t, building) (`dyn_pre`) and seeds the accumulators,
+// leaving 2 per-env inputs (delivered cooling, previous indoor temperature) for layer 0.
+// Per unit and env step: 12 window steps x (64 x 18 + 64 x 32) fused multiply-adds ~ 77 kFLOP and 12 x 2 x 16 x 10 = 3 840
+// transcendentals.  What bounds the kernel is the second number: a v_exp_f32 / v_rcp_f32 holds the SIMD's vector ALU for
+// about 12 cycles against 4 for a plain operation (scripts/lstm_timeline.py: a lone wave needs 0.68 us for the 80
+// transcendental + 165 plain operations of one cell pair), and co-resident waves share that ALU serially -- the older wave
+// wins every arbitration, the younger one advances exactly as much as the older one loses.  The matrix products now hide
+// behind the cell updates; per window step a wave issues ~350 vector operations, 160 of them transcendental.
+// History: two VALU variants were measured first on MI355X at 3 buildings x 65 536 envs: lane = env with the weights
+// streamed through SGPRs (555 us per step, scalar-load latency bound) and lane = (env, hidden unit) with the weights
+// resident in 200 VGPRs and ds_swizzle broadcasts (467 us, dependent-FMA latency bound at 1-2 waves per SIMD); the
+// f32-MFMA form 220 us; split bf16 176 us; this file 113 us.
 #pragma once
 
 #define CL_LSTM_H 16            /* hidden size */
@@ -132,13 +138,13 @@ CL_DEV void lstm_outputs(const LstmArgs& a, const float* __restrict__ W, const f
     }
 }
 
-// ---- the gate pre-activations on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) ---------------------------
+// ---- the gate pre-activations on the matrix cores ----------------------------------------------------------------
 // G[64 gates x 32 envs] = W[64 x K] . X[K x 32 envs] per cell, two 32-row blocks {i, f} and {g, o}.  A wavefront owns 32
 // envs of one building.  In the C/D layout (col = lane & 31 = env, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) a lane
 // ends up with gates i, f, g, o of the SAME eight hidden units u(m) = (m & 3) + 8 (m >> 2) + 4 (lane >> 5), so the
 // cell update is lane-local; and because the K order of a dot product is free, k-slot (2 kk + (lane >> 5)) is DEFINED
 // to be hidden unit u(kk): the B operand of MFMA kk is then simply the lane's own h[kk] -- no cross-lane traffic at
-// all.  The A operands (the weights, K-permuted the same way) are 18 + 32 VGPRs loaded once per wave.
+// all.  The A operands (the weights, K-permuted the same way) are loaded once per wave (f16 split: 48 VGPRs).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 CL_DEV int lstm_unit(int m, int hh) { return (m & 3) + 8 * (m >> 2) + 4 * hh; }
@@ -162,19 +168,18 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
 }
 
 
-// ---- split-bf16 path ---------------------------------------------------------------------------------------------
+// ---- split 16-bit operands ---------------------------------------------------------------------------------------
 // The f32-input MFMA runs at the f32 VECTOR rate and -- measured -- does not overlap with VALU work: with it the kernel
-// costs MFMA time + activation time (153 us + 74 us at 3 x 65 536).  The bf16 matrix cores are 16x faster and run
-// beside the VALU, so the recurrent products W h go through v_mfma_f32_32x32x16_bf16 with both operands split into
-// three bf16 terms (x = x0 + x1 + x2, |x_i| <= 2^-8 |x_{i-1}|, round-to-nearest) and the six partial products with
-// i + j <= 2 accumulated in fp32: the dropped terms are <= 2^-24 |W||h|, i.e. fp32-level.  The weights are split on
-// the host (dynamics.pack_lstm_bf16), h is split in registers after every cell.  The two env-dependent layer-0 inputs,
-// the pre-gates and the bias keep the exact f32 MFMA (K = 2).
+// costs MFMA time + activation time (153 us + 74 us at 3 x 65 536).  The 16-bit matrix cores are 16x faster and run
+// beside the VALU, so the recurrent products W h go through v_mfma_f32_32x32x16_{bf16,f16} with both operands split into
+// a few 16-bit terms whose partial products are accumulated in fp32 (LstmSplit below).  The weights are split on the host
+// (dynamics.pack_lstm_split), h is split in registers after every cell.  The two env-dependent layer-0 inputs and the
+// pre-gates keep the exact f32 MFMA (K = 2); the layer-1 bias is the C operand of the first product of its chain.
 // (Tried: weight fragments in LDS with a 3-waves-per-SIMD register budget -- with the pipelined loop 33 spilled VGPRs,
 // 191 us vs 176 us; with one accumulator pair live at a time 7 spills, 177 us vs 166 us on the same box: more resident
-// waves do not help, the SIMD's VALU issue slots are the shared resource.  Tried: a start offset (s_sleep) for every other
+// waves do not help, the SIMD's vector ALU is the shared resource.  Tried: a start offset (s_sleep) for every other
 // resident workgroup so that one wave's MFMA chains meet the other's activations: 165 us without, 166 - 218 us with offsets of
-// 0.5 - 4 us -- the two phases of co-resident waves do not overlap either way.)
+// 0.5 - 4 us.  Both measured on the three-term bf16 kernel of round 1.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 /* lstm_wb layout (stride CL_LSTM_NWB 16-bit words per building): fragment f = (2 * matrix{hh0, ih1, hh1} + row_block) * T + term,
@@ -320,14 +325,10 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
                 h0[m] = hid[0 * CL_LSTM_H + u]; c0[m] = hid[1 * CL_LSTM_H + u];
                 h1[m] = hid[2 * CL_LSTM_H + u]; c1[m] = hid[3 * CL_LSTM_H + u];
             }
-            // The window loop issues no memory instruction on its critical path:
-            //  * the env-independent layer-0 pre-gates and the layer-1 bias enter the accumulators through one extra MFMA
-            //    (A = the 64 values, B = 1 in k-slot 0) instead of 32 loads + accumulator writes per cell;
-            //  * the three per-lane inputs of step s+1 (two pre-gate values, one history sample) are fetched at the top of
-            //    step s, a whole step ahead of their use.
-            // Layer 1's recurrent half W_hh1 h1 does not need this step's layer-0 output and is issued first.  MFMA chains
-            // are kept free of interleaved VALU (an extra issue slot between MFMAs costs far more than the instruction,
-            // MI355X_MICROARCH.md); the second wave of the SIMD fills the matrix pipe during this wave's activations.
+            // The window loop issues no memory instruction on its critical path: the env-independent layer-0 pre-gates enter the
+            // accumulators through one extra MFMA (A = the 64 values, B = 1 in k-slot 0) instead of 32 loads + accumulator
+            // writes per cell, and the three per-lane inputs of a step (two pre-gate values, one history sample) are fetched two
+            // steps ahead of their use.
 #define CL_MFMA(A, B, C) ((DBG & 2) ? (C) + (A) * (B) : __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0))
             const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const float one_b = hh ? 0.0f : 1.0f;

@@ -19,8 +19,7 @@ TRACE_LIB = ROOT / 'citylearn_amd' / 'libcitylearn_amd_trace.so'
 
 
 def build():
-    cmd = ['/opt/rocm/bin/hipcc', *_lib.HIPCC_FLAGS, '-DCL_TRACE', str(_lib.CSRC / 'cl_kernels.hip'), '-o', str(TRACE_LIB)]
-    subprocess.run(cmd, check=True)
+    _lib.build_variant(TRACE_LIB, ['-DCL_TRACE'])
     print('built', TRACE_LIB)
 
 
