@@ -88,8 +88,9 @@ def _compile(sources, out: Path, deps, force: bool, verbose: bool) -> Path:
     return out
 
 
-# cl_rollout_tu.hip: the fused rollout kernel without SLP vectorisation (packed fp32 operations cost it 9 %; csrc/cl_kernels.hip)
-LIB_SOURCES = [CSRC / 'cl_kernels.hip', (CSRC / 'cl_rollout_tu.hip', ['-fno-slp-vectorize'])]
+# cl_noslp_tu.hip: the fused rollout kernel and the plain lean step kernel without SLP vectorisation (packed fp32 operations cost them
+# 9 % / 4 %; csrc/cl_kernels.hip)
+LIB_SOURCES = [CSRC / 'cl_kernels.hip', (CSRC / 'cl_noslp_tu.hip', ['-fno-slp-vectorize'])]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:

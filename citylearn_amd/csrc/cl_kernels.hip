@@ -745,7 +745,7 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
     a.out_env[(long long)CLQ_REWARD * a.n_env + env] = q_rw;
 }
 
-#ifndef CL_TU_ROLLOUT      /* (cl_rollout_tu.hip compiles only what the fused rollout kernel needs) */
+#ifndef CL_TU_NOSLP      /* (cl_noslp_tu.hip compiles only what its two kernels need) */
 // Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x ONE district
 // quantity x 16 waves; wave w adds chunks w, w+16, ... (independent loads issued four at a time: one memory round trip for up
 // to 64 chunks), then the 16 wave partials are summed in a fixed order through LDS -- deterministic.  (The first version let one
@@ -898,24 +898,30 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
             kpi_env[(long long)k * n_env + i] = is_max ? -INFINITY : 0.0f;
         }
 }
-#endif  // CL_TU_ROLLOUT
+#endif  // CL_TU_NOSLP
 
 }  // namespace
 
-#ifndef CL_TU_ROLLOUT
+#ifndef CL_TU_NOSLP
 #include "cl_full.h"
 #endif
 #include "cl_rollout.h"
 
-// The fused rollout kernel lives in a translation unit of its own (cl_rollout_tu.hip = this file with CL_TU_ROLLOUT, built with
-// -fno-slp-vectorize): with two envs per lane the SLP vectoriser packs the two envs' identical fp32 operations into v_pk_*_f32, which
-// cost more than the two plain operations they replace -- 17 x 32 768: 2.34 -> 2.14 us per step, 65 536: 4.26 -> 3.88 (same box,
-// profiles/r02e_noslp_ab2.log).  The same switch is a loss for the LSTM kernel (109.8 -> 115.5 us) and the chunked thermal launches
-// (14.75 -> 15.08 us) and within the noise for the step kernels, hence per translation unit and not for the whole library.
+// Two kernels live in a translation unit of their own (cl_noslp_tu.hip = this file with CL_TU_NOSLP, built with -fno-slp-vectorize):
+// with several envs per lane the SLP vectoriser packs the envs' identical fp32 operations into v_pk_*_f32, which cost more than the
+// plain operations they replace.  Measured with both builds alternating on one box (profiles/r02e_noslp_ab2.log, r02f_noslp_lean_ab.log):
+//   fused rollout   17 x 32 768: 2.34 -> 2.14 us per step, 65 536: 4.26 -> 3.88
+//   lean step       17 x 65 536 (the headline launch, four envs per lane, 292 packed operations): 7.24 / 6.92 / 7.24 / 7.28 us with,
+//                   7.02 / 6.84 / 6.88 / 6.70 us without
+// The same switch is a loss for the LSTM kernel (109.8 -> 115.5 us) and the chunked thermal launches (14.75 -> 15.08 us) and within
+// the noise for the env-major kernel, hence per translation unit and not for the whole library.  The lean launches with a fused
+// epilogue (flexible loads, KPI accumulators, observation tile) were not measured and stay in the main unit.
 extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int key, int pin, unsigned grid, unsigned block, size_t lds,
                                                                           void* stream, const void* rollout_args);
+extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_lean(int vec, int nt, unsigned grid_x, unsigned grid_y, unsigned block, size_t lds,
+                                                                       void* stream, const void* step_args);
 
-#ifdef CL_TU_ROLLOUT
+#ifdef CL_TU_NOSLP
 extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int key, int pin, unsigned grid, unsigned block_threads, size_t lds,
                                                                           void* stream, const void* rollout_args) {
     const RolloutArgs& r = *static_cast<const RolloutArgs*>(rollout_args);       // the struct of the including translation unit: same source
@@ -932,6 +938,23 @@ extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int ke
     case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), dim3(grid), block, lds, s, r); break;
     default: return -1;
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_lean(int vec, int nt, unsigned grid_x, unsigned grid_y, unsigned block_threads,
+                                                                       size_t lds, void* stream, const void* step_args) {
+    const StepArgs& a = *static_cast<const StepArgs*>(step_args);
+    const dim3 grid(grid_x, grid_y), block(block_threads);
+    hipStream_t s = (hipStream_t)stream;
+#define CL_TU_LEAN(V) case V: \
+        if (nt) hipLaunchKernelGGL((cl_step_lean_kernel<V, false, true>), grid, block, lds, s, a); \
+        else hipLaunchKernelGGL((cl_step_lean_kernel<V, false, false>), grid, block, lds, s, a); \
+        break;
+    switch (vec) {
+        CL_TU_LEAN(1) CL_TU_LEAN(2) CL_TU_LEAN(4)
+    default: return -1;
+    }
+#undef CL_TU_LEAN
     return (int)hipGetLastError();
 }
 #else
@@ -1316,7 +1339,8 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
                 if (a.nt) hipLaunchKernelGGL((cl_step_lean_obs_kernel<V, true>), grid, block, lds_o, s, a, *of); \
                 else hipLaunchKernelGGL((cl_step_lean_obs_kernel<V, false>), grid, block, lds_o, s, a, *of); \
                 *fused = true; \
-            } else CL_LAUNCH_NT(cl_step_lean_kernel, V, false); \
+            } else if (const int rc = cl_tu_launch_lean(V, a.nt, grid.x, grid.y, block.x, lds, stream, &a)) \
+                return hip_fail((hipError_t)rc, "cl_step_lean_kernel launch"); \
             break;
         CL_LEAN_CASE(1) CL_LEAN_CASE(2) CL_LEAN_CASE(4)
 #undef CL_LEAN_CASE
@@ -1656,4 +1680,4 @@ float cl_philox_uniform(uint64_t seed, uint32_t env, uint32_t col, uint32_t t) {
 }
 
 }  // extern "C"
-#endif  // CL_TU_ROLLOUT
+#endif  // CL_TU_NOSLP
