@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 3
+#define CL_ABI_VERSION 4   /* 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
 
 /* ---- error codes ---- */
 #define CL_OK            0
