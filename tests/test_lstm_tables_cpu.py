@@ -1,0 +1,76 @@
+"""The packed LSTM tables (`dynamics.pack_lstm` + `pack_lstm_split`) run through a numpy restatement of cl_lstm_kernel's window loop
+(no GPU): what the device reads -- pre-scaled gate rows, host pre-gates, split 16-bit weight fragments -- must reproduce the
+reference's predicted temperatures.  Catches packing mistakes (gate scaling, fragment order, ring semantics) without a GPU box."""
+import numpy as np
+import pytest
+
+from citylearn_amd import dynamics as dyn
+from golden_util import golden
+
+
+def _weights_from_fragments(lstm_wb, fmt):
+    """[18, 64, 8] uint16 fragments of one building -> the three 64 x 16 matrices the matrix cores see (sum of the split terms)."""
+    T = 3 if fmt == 'bf16' else 2
+    lane, j = np.arange(64), np.arange(8)
+    unit = (j[None, :] & 3) + 8 * (j[None, :] >> 2) + 4 * (lane[:, None] >> 5)
+    mats = []
+    for m in range(3):
+        W = np.zeros((64, 16))
+        for rb in range(2):
+            frag = np.zeros((64, 8))
+            for k in range(T):
+                bits = lstm_wb[(m * 2 + rb) * T + k]
+                frag += ((bits.astype(np.uint32) << 16).view(np.float32) if fmt == 'bf16' else bits.view(np.float16)).astype(np.float64)
+            W[(32 * rb + (lane & 31))[:, None], unit] = frag
+        mats.append(W)
+    return mats
+
+
+def _cell(z, c):
+    """cl_lstm.h lstm_act: the gate rows arrive pre-multiplied by -log2 e (i, f, o) / -2 log2 e (g)."""
+    i, f = 1.0 / (1.0 + np.exp2(z[0:16])), 1.0 / (1.0 + np.exp2(z[16:32]))
+    g, o = 2.0 / (1.0 + np.exp2(z[32:48])) - 1.0, 1.0 / (1.0 + np.exp2(z[48:64]))
+    c = f * c + i * g
+    return c, o * np.tanh(c)
+
+
+@pytest.mark.parametrize('name,fmt,steps', [('g2023_p2', 'f16', 120), ('g2023_p2', 'bf16', 60), ('g2023_heat', 'f16', 120)])
+def test_packed_tables_reproduce_the_reference_temperatures(name, fmt, steps):
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    lstm_w, dyn_pre = dyn.pack_lstm(spec, tab)
+    wb = dyn.pack_lstm_split(lstm_w, fmt)
+    B = lstm_w.shape[0]
+    cool = g.ref['cool_dem']
+    heat = g.ref['heat_dem'] if 'heat_dem' in g.ref.files else np.zeros_like(cool)
+    steps = min(steps, g.facts['steps'])
+    worst = 0.0
+    for b in range(B):
+        w = lstm_w[b].astype(np.float64)
+        assert w[dyn.ACTIVE] == 1.0
+        whh0, wih1, whh1 = _weights_from_fragments(wb[b], fmt)
+        # the fragments are the (scaled) fp32 matrices of lstm_w, split
+        np.testing.assert_allclose(whh0, w[dyn.WHH0:dyn.WHH0 + 1024].reshape(64, 16), rtol=2.0 ** -21, atol=2.0 ** -24)
+        wc, wt, b1 = w[dyn.WC:dyn.WC + 64], w[dyn.WT:dyn.WT + 64], w[dyn.B1:dyn.B1 + 64]
+        wlin, blin = w[dyn.WLIN:dyn.WLIN + 16], w[dyn.BLIN]
+        tmin, tmax, cmin, cmax = w[dyn.TMIN], w[dyn.TMAX], w[dyn.CMIN], w[dyn.CMAX]
+        dem = heat[:, b] if w[dyn.DEM_HEAT] != 0.0 else cool[:, b]
+        ring_c, ring_t = np.zeros(12), np.zeros(12)
+        h0 = np.zeros(16); c0 = np.zeros(16); h1 = np.zeros(16); c1 = np.zeros(16)
+        for t in range(steps):
+            ring_c[t % 12] = (dem[t] - cmin) / (cmax - cmin)                    # building.py:3068-3078
+            y = dyn_pre[t, b, dyn.PRE_TNORM]
+            temp = dyn_pre[t, b, dyn.PRE_TRAW]
+            if t >= 12:                                                          # lookback + 1 samples exist (building.py:2996-2999)
+                for s in range(12):
+                    time = t - 11 + s
+                    z0 = dyn_pre[time, b, :64].astype(np.float64) + wc * ring_c[time % 12] + wt * ring_t[(time - 1) % 12] + whh0 @ h0
+                    c0, h0 = _cell(z0, c0)
+                    z1 = b1 + wih1 @ h0 + whh1 @ h1
+                    c1, h1 = _cell(z1, c1)
+                y = blin + wlin @ h1
+                temp = y * (tmax - tmin) + tmin                                 # building.py:3031-3037
+            ring_t[t % 12] = y                                                  # building.py:3027-3028
+            worst = max(worst, abs(temp - g.ref['indoor_temp'][t][b]))
+    assert worst < 2e-4, worst          # deg C; the device test's bound is 2e-3 (fp32 kernel), this restatement runs in float64
