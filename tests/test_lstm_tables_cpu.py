@@ -73,4 +73,4 @@ def test_packed_tables_reproduce_the_reference_temperatures(name, fmt, steps):
                 temp = y * (tmax - tmin) + tmin                                 # building.py:3031-3037
             ring_t[t % 12] = y                                                  # building.py:3027-3028
             worst = max(worst, abs(temp - g.ref['indoor_temp'][t][b]))
-    assert worst < 2e-4, worst          # deg C; the device test's bound is 2e-3 (fp32 kernel), this restatement runs in float64
+    assert worst < 5e-5, worst          # deg C (measured 5e-6); the device test's bound is 2e-3 (fp32 kernel), this restatement runs in float64
