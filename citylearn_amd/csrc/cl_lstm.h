@@ -277,10 +277,10 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
         return;
     }
     // From here on: one straight line up to the window loop.  Everything the wave needs from memory is requested first, in one
-    // batch (weights, carried state, biases, this step's demand, the inputs of window steps 0 and 1), and only then used: with the
-    // loads left where their values are first needed the compiler requests the recurrent weights of layer 1 after the first
-    // layer-0 products have waited for theirs -- two or three memory round trips in a row at the start of every wave
-    // (entry -> first gates 3.8 us, window step 0 6.6 us instead of 1.9 us at 3 x 65 536, scripts/lstm_timeline.py).
+    // batch (weights, carried state, biases, this step's demand, the inputs of window steps 0 and 1), and only then used; left
+    // where their values are first needed, the compiler requests the recurrent weights of layer 1 only after the first layer-0
+    // products have waited for theirs.  (Measured: no gain by itself, 121 vs 119 us -- a wave's slow first window steps, 7 us
+    // instead of 1.9 us, are the arbitration against the older wave of its SIMD, not its loads: scripts/lstm_timeline.py.)
     const float cool = a.cool_dem[off];
     const float dem = dem_src[off];
     const float heat = a.heat_dem ? a.heat_dem[off] : 0.0f;      // (ComfortReward, at the very end)
@@ -289,183 +289,179 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     for (int m = 0; m < 8; ++m) wlin[m] = W[CLW_WLIN + lstm_unit(m, hh)];
     const float blin = W[CLW_BLIN];
     float temp, y;
-    {
-        {
-            // A operands: row = 32 rb + col of the torch gate matrix, k-slot 2 kk + hh -> hidden unit u(kk)
-            float a_hh0[2][8], a_x0[2], a_ih1[2][8], a_hh1[2][8];
-            v8 A_hh0[2][NT], A_ih1[2][NT], A_hh1[2][NT];
+    // A operands: row = 32 rb + col of the torch gate matrix, k-slot 2 kk + hh -> hidden unit u(kk)
+    float a_hh0[2][8], a_x0[2], a_ih1[2][8], a_hh1[2][8];
+    v8 A_hh0[2][NT], A_ih1[2][NT], A_hh1[2][NT];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const int row = 32 * rb + col;
-                a_x0[rb] = hh ? W[CLW_WT + row] : W[CLW_WC + row];
-                if constexpr (SPLIT) {
-                    const v8* __restrict__ F = reinterpret_cast<const v8*>(a.lstm_wb + (long long)b * CL_LSTM_NWB);
+    for (int rb = 0; rb < 2; ++rb) {
+        const int row = 32 * rb + col;
+        a_x0[rb] = hh ? W[CLW_WT + row] : W[CLW_WC + row];
+        if constexpr (SPLIT) {
+            const v8* __restrict__ F = reinterpret_cast<const v8*>(a.lstm_wb + (long long)b * CL_LSTM_NWB);
 #pragma unroll
-                    for (int k = 0; k < ((DBG & 8) ? 2 : NT); ++k) {
-                        A_hh0[rb][k] = F[((0 * 2 + rb) * NT + k) * 64 + lane];
-                        A_ih1[rb][k] = F[((1 * 2 + rb) * NT + k) * 64 + lane];
-                        A_hh1[rb][k] = F[((2 * 2 + rb) * NT + k) * 64 + lane];
-                    }
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const int u = lstm_unit(kk, hh);
-                        a_hh0[rb][kk] = W[CLW_WHH0 + row * CL_LSTM_H + u];
-                        a_ih1[rb][kk] = W[CLW_WIH1 + row * CL_LSTM_H + u];
-                        a_hh1[rb][kk] = W[CLW_WHH1 + row * CL_LSTM_H + u];
-                    }
-                }
+            for (int k = 0; k < ((DBG & 8) ? 2 : NT); ++k) {
+                A_hh0[rb][k] = F[((0 * 2 + rb) * NT + k) * 64 + lane];
+                A_ih1[rb][k] = F[((1 * 2 + rb) * NT + k) * 64 + lane];
+                A_hh1[rb][k] = F[((2 * 2 + rb) * NT + k) * 64 + lane];
             }
-            // carried state of this lane's eight units
-            float* hid = a.hidden + ((long long)b * a.n_env + ec) * CL_LSTM_NHIDDEN_;
-            float h0[8], c0[8], h1[8], c1[8];
+        } else {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int u = lstm_unit(m, hh);
-                h0[m] = hid[0 * CL_LSTM_H + u]; c0[m] = hid[1 * CL_LSTM_H + u];
-                h1[m] = hid[2 * CL_LSTM_H + u]; c1[m] = hid[3 * CL_LSTM_H + u];
+            for (int kk = 0; kk < 8; ++kk) {
+                const int u = lstm_unit(kk, hh);
+                a_hh0[rb][kk] = W[CLW_WHH0 + row * CL_LSTM_H + u];
+                a_ih1[rb][kk] = W[CLW_WIH1 + row * CL_LSTM_H + u];
+                a_hh1[rb][kk] = W[CLW_WHH1 + row * CL_LSTM_H + u];
             }
-            // The window loop issues no memory instruction on its critical path: the env-independent layer-0 pre-gates enter the
-            // accumulators through one extra MFMA (A = the 64 values, B = 1 in k-slot 0) instead of 32 loads + accumulator
-            // writes per cell, and the three per-lane inputs of a step (two pre-gate values, one history sample) are fetched two
-            // steps ahead of their use.
-#define CL_MFMA(A, B, C) ((DBG & 2) ? (C) + (A) * (B) : __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0))
-            const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            const float one_b = hh ? 0.0f : 1.0f;
-            const float a_b1[2] = {W[CLW_B1 + col], W[CLW_B1 + 32 + col]};
-            // ring rows without a division or a branch in the loop: time % 12 = (m + s) mod 12, (time - 1) % 12 = that - 1 mod 12
-            const int ring_m = (a.t - (CL_LSTM_LOOKBACK - 1)) % CL_LSTM_LOOKBACK;           // a.t >= 12 here
-            const float* __restrict__ hist_lane = a.hist + off + (hh ? (long long)CL_LSTM_LOOKBACK * plane : 0ll);
-            // The env-independent layer-0 pre-gates of a step are two values per lane and one extra K = 2 MFMA per row block.
-            // (Tried: loading them straight in the C/D layout -- 16 values per row block and lane, four 16-byte loads each -- as the C
-            // operand of the chain's first MFMA, the way the layer-1 bias enters: two MFMAs fewer per step but eight loads and 32
-            // registers more: 119.2 vs 117.5 us with the f16 split, 168 vs 142 us with bf16 at 256 registers.)
-            auto fetch = [&](int s, float (&ap)[2], float& xin) {
-                const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
-                const float* __restrict__ pre = a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
-                ap[0] = pre[col]; ap[1] = pre[32 + col];
-                // extra k-pair of layer 0: slot 0 = cooling demand at `time`, slot 1 = temperature at `time - 1`
-                int r0 = ring_m + s; r0 -= r0 >= CL_LSTM_LOOKBACK ? CL_LSTM_LOOKBACK : 0;
-                const int r1 = r0 == 0 ? CL_LSTM_LOOKBACK - 1 : r0 - 1;
-                xin = hist_lane[(long long)(hh ? r1 : r0) * plane];        // (step 11, slot 0 is overridden at the point of use)
-            };
-            v8 H0[NT], H1[NT];                                            // split hidden states (B operands)
-            auto split = [&](const float (&h)[8], v8 (&t)[NT]) { lstm_split<NT, (DBG & 8) ? 2 : NT, v8, elem>(h, t); };
-            // layer-1 bias in the C/D layout of the two row blocks: the first product of every layer-1 chain reads it as its C operand
-            f32x16 bias1[2];
-            if constexpr (SPLIT) {
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) bias1[rb][r] = W[CLW_B1 + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh];
-            }
-            auto layer0 = [&](const float (&ap)[2], float xin, f32x16& d0, f32x16& d1) {
-                d0 = CL_MFMA(ap[0], one_b, zero16);
-                d1 = CL_MFMA(ap[1], one_b, zero16);
-                d0 = CL_MFMA(a_x0[0], xin, d0);
-                d1 = CL_MFMA(a_x0[1], xin, d1);
-                if constexpr (SPLIT) lstm_mma<DBG>(A_hh0[0], A_hh0[1], H0, d0, d1, d0, d1);
-                else {
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        d0 = CL_MFMA(a_hh0[0][kk], h0[kk], d0);
-                        d1 = CL_MFMA(a_hh0[1][kk], h0[kk], d1);
-                    }
-                }
-            };
-            f32x16 d0, d1, e0, e1;
-            float ap[2], xin, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f, ap_nn[2] = {0.0f, 0.0f}, xin_nn = 0.0f;
-            fetch(0, ap, xin);
-            fetch(1, ap_n, xin_n);
-            __builtin_amdgcn_sched_barrier(0);                             // every load above is issued before anything below
-            const float cool_n = (dem - cmin) / (cmax - cmin);
-            if (live && hh == 0) a.hist[(long long)slot * plane + off] = cool_n;         // building.py:3068-3078
-            if constexpr (SPLIT) { split(h0, H0); split(h1, H1); }
-            layer0(ap, xin, d0, d1);
-            CL_LT(1, d0[15]);                                             // weights, carried state and the first inputs arrived; first layer-0 gates done
-            // The window loop, software-pipelined across the two layers.  Each layer is a strict chain matrix product -> cell update ->
-            // matrix product, so inside one wave matrix-core work can only run beside the OTHER layer's cell update (and the second
-            // wave of the SIMD does not fill the gaps: the older wave wins every arbitration, the younger one advances at a fifth of
-            // the speed until the older one ends -- scripts/lstm_timeline.py).  Layer 1 therefore runs one step behind layer 0:
-            //   phase A(s): cell update of layer 0, step s          beside   e(s-1) += W_hh1 h1(s-2)
-            //   phase B(s): cell update of layer 1, step s-1        beside   e(s) = b1 + W_ih1 h0(s),  d(s+1) = layer-0 gates of step s+1
-            // and every matrix product is issued next to a cell update that does not depend on it.  The window is 12 steps, so the
-            // first and the last step are written out (no branch inside the loop: with an `if` around a stage the compiler sinks that
-            // stage's loads into the conditional block, right in front of their use).
-            auto fetch_ahead = [&](int s) {
-                // the three per-lane inputs of layer 0 are fetched two steps before their use (rotated at the end of the step)
-                fetch(min(s + 2, CL_LSTM_LOOKBACK - 1), ap_nn, xin_nn);
-                __builtin_amdgcn_sched_barrier(0);                          // the loads stay first
-            };
-            auto rotate = [&](int s) {                                      // at the very end: the copies wait for this step's loads
-                __builtin_amdgcn_sched_barrier(0);
-                ap_n[0] = ap_nn[0]; ap_n[1] = ap_nn[1]; xin_n = xin_nn;
-                CL_LT(50 + s, xin_n);                                       // the inputs fetched at the top of this step have arrived
-            };
-            auto hh1_product = [&]() {                                      // e += W_hh1 h1
-                if constexpr (SPLIT) lstm_mma<DBG>(A_hh1[0], A_hh1[1], H1, e0, e1, e0, e1);
-                else {
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        e0 = CL_MFMA(a_hh1[0][kk], h1[kk], e0);
-                        e1 = CL_MFMA(a_hh1[1][kk], h1[kk], e1);
-                    }
-                }
-            };
-            auto phase_a = [&](int s, auto has_h) {
-                if constexpr (decltype(has_h)::value) hh1_product();
-                lstm_act<DBG>(d0, d1, c0, h0);
-                if constexpr (SPLIT) split(h0, H0);
-                CL_LT(3 + 4 * s, h0[7]);                                    // layer-0 cell update of step s done
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            auto phase_b = [&](int s, auto has_e, auto has_l0) {
-                const f32x16 g0 = e0, g1 = e1;                              // the complete layer-1 gates of step s - 1
-                if constexpr (SPLIT) lstm_mma<DBG>(A_ih1[0], A_ih1[1], H0, bias1[0], bias1[1], e0, e1);
-                else {
-                    e0 = CL_MFMA(a_b1[0], one_b, zero16);
-                    e1 = CL_MFMA(a_b1[1], one_b, zero16);
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        e0 = CL_MFMA(a_ih1[0][kk], h0[kk], e0);
-                        e1 = CL_MFMA(a_ih1[1][kk], h0[kk], e1);
-                    }
-                }
-                // the newest cooling sample (step 11, k-slot 0) was produced by this launch, not read from the ring
-                if constexpr (decltype(has_l0)::value) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
-                if constexpr (decltype(has_e)::value) {
-                    lstm_act<DBG>(g0, g1, c1, h1);
-                    if constexpr (SPLIT) split(h1, H1);
-                    CL_LT(5 + 4 * (s - 1), h1[7]);                          // layer-1 cell update of step s - 1 done
-                }
-            };
-            constexpr std::true_type yes{};
-            constexpr std::false_type no{};
-            fetch_ahead(0); phase_a(0, no); phase_b(0, no, yes); rotate(0);
-            for (int s = 1; s < CL_LSTM_LOOKBACK - 1; ++s) { fetch_ahead(s); phase_a(s, yes); phase_b(s, yes, yes); rotate(s); }
-            phase_a(CL_LSTM_LOOKBACK - 1, yes); phase_b(CL_LSTM_LOOKBACK - 1, yes, no);
-            hh1_product();                                                  // drain: layer 1 of the last step
-            lstm_act<DBG>(e0, e1, c1, h1);
-            CL_LT(5 + 4 * (CL_LSTM_LOOKBACK - 1), h1[7]);
-#undef CL_MFMA
-            if (live) {
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int u = lstm_unit(m, hh);
-                    hid[0 * CL_LSTM_H + u] = h0[m]; hid[1 * CL_LSTM_H + u] = c0[m];
-                    hid[2 * CL_LSTM_H + u] = h1[m]; hid[3 * CL_LSTM_H + u] = c1[m];
-                }
-            }
-            // Linear(16 -> 1): this lane's eight units, then the other half of the env (lane ^ 32)
-            float part = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) part = fmaf(wlin[m], h1[m], part);
-            const float other = __shfl_xor(part, 32);
-            y = blin + (hh ? other + part : part + other);
-            temp = fmaf(y, tmax - tmin, tmin);                           // building.py:3031-3037
         }
-        if (live && hh == 0) a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;   // building.py:3027-3028
     }
+    // carried state of this lane's eight units
+    float* hid = a.hidden + ((long long)b * a.n_env + ec) * CL_LSTM_NHIDDEN_;
+    float h0[8], c0[8], h1[8], c1[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int u = lstm_unit(m, hh);
+        h0[m] = hid[0 * CL_LSTM_H + u]; c0[m] = hid[1 * CL_LSTM_H + u];
+        h1[m] = hid[2 * CL_LSTM_H + u]; c1[m] = hid[3 * CL_LSTM_H + u];
+    }
+    // The window loop issues no memory instruction on its critical path: the env-independent layer-0 pre-gates enter the
+    // accumulators through one extra MFMA (A = the 64 values, B = 1 in k-slot 0) instead of 32 loads + accumulator
+    // writes per cell, and the three per-lane inputs of a step (two pre-gate values, one history sample) are fetched two
+    // steps ahead of their use.
+#define CL_MFMA(A, B, C) ((DBG & 2) ? (C) + (A) * (B) : __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0))
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float one_b = hh ? 0.0f : 1.0f;
+    const float a_b1[2] = {W[CLW_B1 + col], W[CLW_B1 + 32 + col]};
+    // ring rows without a division or a branch in the loop: time % 12 = (m + s) mod 12, (time - 1) % 12 = that - 1 mod 12
+    const int ring_m = (a.t - (CL_LSTM_LOOKBACK - 1)) % CL_LSTM_LOOKBACK;           // a.t >= 12 here
+    const float* __restrict__ hist_lane = a.hist + off + (hh ? (long long)CL_LSTM_LOOKBACK * plane : 0ll);
+    // The env-independent layer-0 pre-gates of a step are two values per lane and one extra K = 2 MFMA per row block.
+    // (Tried: loading them straight in the C/D layout -- 16 values per row block and lane, four 16-byte loads each -- as the C
+    // operand of the chain's first MFMA, the way the layer-1 bias enters: two MFMAs fewer per step but eight loads and 32
+    // registers more: 119.2 vs 117.5 us with the f16 split, 168 vs 142 us with bf16 at 256 registers.)
+    auto fetch = [&](int s, float (&ap)[2], float& xin) {
+        const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
+        const float* __restrict__ pre = a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
+        ap[0] = pre[col]; ap[1] = pre[32 + col];
+        // extra k-pair of layer 0: slot 0 = cooling demand at `time`, slot 1 = temperature at `time - 1`
+        int r0 = ring_m + s; r0 -= r0 >= CL_LSTM_LOOKBACK ? CL_LSTM_LOOKBACK : 0;
+        const int r1 = r0 == 0 ? CL_LSTM_LOOKBACK - 1 : r0 - 1;
+        xin = hist_lane[(long long)(hh ? r1 : r0) * plane];        // (step 11, slot 0 is overridden at the point of use)
+    };
+    v8 H0[NT], H1[NT];                                            // split hidden states (B operands)
+    auto split = [&](const float (&h)[8], v8 (&t)[NT]) { lstm_split<NT, (DBG & 8) ? 2 : NT, v8, elem>(h, t); };
+    // layer-1 bias in the C/D layout of the two row blocks: the first product of every layer-1 chain reads it as its C operand
+    f32x16 bias1[2];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bias1[rb][r] = W[CLW_B1 + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh];
+    }
+    auto layer0 = [&](const float (&ap)[2], float xin, f32x16& d0, f32x16& d1) {
+        d0 = CL_MFMA(ap[0], one_b, zero16);
+        d1 = CL_MFMA(ap[1], one_b, zero16);
+        d0 = CL_MFMA(a_x0[0], xin, d0);
+        d1 = CL_MFMA(a_x0[1], xin, d1);
+        if constexpr (SPLIT) lstm_mma<DBG>(A_hh0[0], A_hh0[1], H0, d0, d1, d0, d1);
+        else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                d0 = CL_MFMA(a_hh0[0][kk], h0[kk], d0);
+                d1 = CL_MFMA(a_hh0[1][kk], h0[kk], d1);
+            }
+        }
+    };
+    f32x16 d0, d1, e0, e1;
+    float ap[2], xin, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f, ap_nn[2] = {0.0f, 0.0f}, xin_nn = 0.0f;
+    fetch(0, ap, xin);
+    fetch(1, ap_n, xin_n);
+    __builtin_amdgcn_sched_barrier(0);                             // every load above is issued before anything below
+    const float cool_n = (dem - cmin) / (cmax - cmin);
+    if (live && hh == 0) a.hist[(long long)slot * plane + off] = cool_n;         // building.py:3068-3078
+    if constexpr (SPLIT) { split(h0, H0); split(h1, H1); }
+    layer0(ap, xin, d0, d1);
+    CL_LT(1, d0[15]);                                             // weights, carried state and the first inputs arrived; first layer-0 gates done
+    // The window loop, software-pipelined across the two layers.  Each layer is a strict chain matrix product -> cell update ->
+    // matrix product, so inside one wave matrix-core work can only run beside the OTHER layer's cell update (and the second
+    // wave of the SIMD does not fill the gaps: the older wave wins every arbitration, the younger one advances at a fifth of
+    // the speed until the older one ends -- scripts/lstm_timeline.py).  Layer 1 therefore runs one step behind layer 0:
+    //   phase A(s): cell update of layer 0, step s          beside   e(s-1) += W_hh1 h1(s-2)
+    //   phase B(s): cell update of layer 1, step s-1        beside   e(s) = b1 + W_ih1 h0(s),  d(s+1) = layer-0 gates of step s+1
+    // and every matrix product is issued next to a cell update that does not depend on it.  The window is 12 steps, so the
+    // first and the last step are written out (no branch inside the loop: with an `if` around a stage the compiler sinks that
+    // stage's loads into the conditional block, right in front of their use).
+    auto fetch_ahead = [&](int s) {
+        // the three per-lane inputs of layer 0 are fetched two steps before their use (rotated at the end of the step)
+        fetch(min(s + 2, CL_LSTM_LOOKBACK - 1), ap_nn, xin_nn);
+        __builtin_amdgcn_sched_barrier(0);                          // the loads stay first
+    };
+    auto rotate = [&](int s) {                                      // at the very end: the copies wait for this step's loads
+        __builtin_amdgcn_sched_barrier(0);
+        ap_n[0] = ap_nn[0]; ap_n[1] = ap_nn[1]; xin_n = xin_nn;
+        CL_LT(50 + s, xin_n);                                       // the inputs fetched at the top of this step have arrived
+    };
+    auto hh1_product = [&]() {                                      // e += W_hh1 h1
+        if constexpr (SPLIT) lstm_mma<DBG>(A_hh1[0], A_hh1[1], H1, e0, e1, e0, e1);
+        else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                e0 = CL_MFMA(a_hh1[0][kk], h1[kk], e0);
+                e1 = CL_MFMA(a_hh1[1][kk], h1[kk], e1);
+            }
+        }
+    };
+    auto phase_a = [&](int s, auto has_h) {
+        if constexpr (decltype(has_h)::value) hh1_product();
+        lstm_act<DBG>(d0, d1, c0, h0);
+        if constexpr (SPLIT) split(h0, H0);
+        CL_LT(3 + 4 * s, h0[7]);                                    // layer-0 cell update of step s done
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto phase_b = [&](int s, auto has_e, auto has_l0) {
+        const f32x16 g0 = e0, g1 = e1;                              // the complete layer-1 gates of step s - 1
+        if constexpr (SPLIT) lstm_mma<DBG>(A_ih1[0], A_ih1[1], H0, bias1[0], bias1[1], e0, e1);
+        else {
+            e0 = CL_MFMA(a_b1[0], one_b, zero16);
+            e1 = CL_MFMA(a_b1[1], one_b, zero16);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                e0 = CL_MFMA(a_ih1[0][kk], h0[kk], e0);
+                e1 = CL_MFMA(a_ih1[1][kk], h0[kk], e1);
+            }
+        }
+        // the newest cooling sample (step 11, k-slot 0) was produced by this launch, not read from the ring
+        if constexpr (decltype(has_l0)::value) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
+        if constexpr (decltype(has_e)::value) {
+            lstm_act<DBG>(g0, g1, c1, h1);
+            if constexpr (SPLIT) split(h1, H1);
+            CL_LT(5 + 4 * (s - 1), h1[7]);                          // layer-1 cell update of step s - 1 done
+        }
+    };
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
+    fetch_ahead(0); phase_a(0, no); phase_b(0, no, yes); rotate(0);
+    for (int s = 1; s < CL_LSTM_LOOKBACK - 1; ++s) { fetch_ahead(s); phase_a(s, yes); phase_b(s, yes, yes); rotate(s); }
+    phase_a(CL_LSTM_LOOKBACK - 1, yes); phase_b(CL_LSTM_LOOKBACK - 1, yes, no);
+    hh1_product();                                                  // drain: layer 1 of the last step
+    lstm_act<DBG>(e0, e1, c1, h1);
+    CL_LT(5 + 4 * (CL_LSTM_LOOKBACK - 1), h1[7]);
+#undef CL_MFMA
+    if (live) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int u = lstm_unit(m, hh);
+            hid[0 * CL_LSTM_H + u] = h0[m]; hid[1 * CL_LSTM_H + u] = c0[m];
+            hid[2 * CL_LSTM_H + u] = h1[m]; hid[3 * CL_LSTM_H + u] = c1[m];
+        }
+    }
+    // Linear(16 -> 1): this lane's eight units, then the other half of the env (lane ^ 32)
+    float part = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) part = fmaf(wlin[m], h1[m], part);
+    const float other = __shfl_xor(part, 32);
+    y = blin + (hh ? other + part : part + other);
+    temp = fmaf(y, tmax - tmin, tmin);                           // building.py:3031-3037
+    if (live && hh == 0) a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;   // building.py:3027-3028
     if (live && hh == 0) lstm_outputs(a, W, pre_t, off, plane, temp, cool, heat);
 #ifdef CL_TRACE
     {
