@@ -5,7 +5,11 @@
 # then on the GPU box:  bash scripts/noslp_ab.sh [reps=2] > gpurun_out/noslp_ab.log
 # (round 2: rollout and the plain lean step kernel win 9 % / 4 % without packing and live in the no-SLP unit; LSTM and the chunked
 #  thermal launches lose 5 % / 2 %; env-major and C3 unchanged.  Not yet measured per kernel: the lean launches with a fused epilogue.)
-A=citylearn_amd/libcl_alt_noslp.so
+# A second alternative worth the same A/B: no packed fp32 instructions at all, including the explicit two-envs-per-lane vector
+# arithmetic of the thermal kernels (319 v_pk_*_f32 in cl_step_full_kernel<2, ...>), which -fno-slp-vectorize leaves alone:
+#   _lib.build_variant('citylearn_amd/libcl_alt_nopk.so', ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops'])
+#   A=citylearn_amd/libcl_alt_nopk.so bash scripts/noslp_ab.sh
+A=${A:-citylearn_amd/libcl_alt_noslp.so}
 REPS=${1:-2}
 for rep in $(seq $REPS); do
   for lib in "" $A; do
