@@ -1,6 +1,7 @@
 """The C-ABI shared library loads without a GPU and exports every symbol `include/citylearn_amd.h` declares;
 argument validation happens before any HIP call, so error codes are testable on CPU."""
 import ctypes
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -30,6 +31,23 @@ def test_library_exports_nothing_else():
     out = subprocess.run(['nm', '-D', '--defined-only', str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
     names = sorted(line.split()[-1] for line in out.splitlines() if ' T ' in line)
     assert names == abi.EXPORTED_SYMBOLS, names
+
+
+def test_translation_units_and_their_internal_launchers():
+    """The library is two translation units: the main one and csrc/cl_noslp_tu.hip (the kernels compiled without SLP vectorisation,
+    `-fno-slp-vectorize`); the launchers that connect them are linked in but have hidden visibility -- not part of the C-ABI."""
+    import subprocess
+    units = [(u, []) if not isinstance(u, tuple) else u for u in _lib.LIB_SOURCES]
+    assert [Path(u).name for u, _ in units] == ['cl_kernels.hip', 'cl_noslp_tu.hip']
+    assert units[0][1] == [] and units[1][1] == ['-fno-slp-vectorize']
+    assert all(Path(u).exists() for u, _ in units)
+    _lib.build()
+    dyn = subprocess.run(['nm', '-D', '--defined-only', str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert 'cl_tu_launch' not in dyn
+    full = subprocess.run(['nm', '--defined-only', str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    if full.strip():                 # (an unstripped build: the launchers are there as local symbols)
+        local = {line.split()[-1]: line.split()[-2] for line in full.splitlines() if 'cl_tu_launch' in line}
+        assert set(local) == {'cl_tu_launch_rollout', 'cl_tu_launch_lean'} and set(local.values()) == {'t'}, local
 
 
 def _header_struct_fields(name: str):
