@@ -1,0 +1,109 @@
+"""Static guards on the generated gfx950 code (no GPU: hipcc cross-compiles to assembly).  Each assertion pins a property that cost
+a measured factor when the compiler silently lost it: wave-uniform parameter reads as SCALAR loads, no scratch
+memory in the rollout / lean / LSTM kernels, the LSTM window loop free of a load in front of its use, no packed fp32 in the
+kernels that were moved to the no-SLP translation unit."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from citylearn_amd import _lib
+
+
+def _asm(src, extra, tmp_path_factory):
+    out = tmp_path_factory.mktemp('isa') / (src.stem + '.s')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    flags = [f for f in _lib.HIPCC_FLAGS if f not in ('-shared', '-fPIC')]
+    subprocess.run([hipcc, *flags, *extra, '-S', '--cuda-device-only', str(src), '-o', str(out)], check=True, capture_output=True)
+    kernels, meta, cur = {}, {}, None
+    for line in out.read_text().splitlines():
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            cur = m.group(1); kernels[cur] = []
+            continue
+        m = re.match(r'\s*\.set (_Z\w+)\.(num_vgpr|private_seg_size), (\d+)', line)
+        if m:
+            meta.setdefault(m.group(1), {})[m.group(2)] = int(m.group(3))
+            continue
+        t = line.split()
+        if cur is not None and re.match(r'^\.LBB\d+_\d+:', line):
+            kernels[cur].append('LABEL ' + line.split(':')[0])
+        elif cur is not None and t and not t[0].startswith(('.', ';')):
+            kernels[cur].append(line.strip())
+    return kernels, meta
+
+
+@pytest.fixture(scope='module')
+def units(tmp_path_factory):
+    (main, _), (noslp, noslp_flags) = [(u, []) if not isinstance(u, tuple) else u for u in _lib.LIB_SOURCES]
+    return _asm(main, [], tmp_path_factory), _asm(noslp, noslp_flags, tmp_path_factory)
+
+
+def _one(kernels, pattern):
+    names = [k for k in kernels if re.search(pattern, k)]
+    assert len(names) == 1, (pattern, names)
+    return names[0]
+
+
+def _count(ins, prefix):
+    return sum(1 for i in ins if i.split()[0].startswith(prefix))       # ('LABEL' pseudo-entries never match an opcode prefix)
+
+
+def test_headline_lean_kernel(units):
+    """cl_step_lean_kernel<4, false, true> (17 x 65 536): parameters and time-series rows through scalar loads (the traced build that
+    lost them ran 3.5 x slower), no scratch, no packed fp32 (same-box A/B: 7.17 -> 6.86 us without)."""
+    _, (kernels, meta) = units
+    k = _one(kernels, r'cl_step_lean_kernelILi4ELb0ELb1EE')
+    ins = kernels[k]
+    assert meta[k]['private_seg_size'] == 0
+    assert _count(ins, 'global_load') <= 32 and _count(ins, 's_load') >= 15, (_count(ins, 'global_load'), _count(ins, 's_load'))
+    assert not [i for i in ins if re.match(r'v_pk_\w+_f32', i)]
+    assert meta[k]['num_vgpr'] <= 96                       # five waves per SIMD and one 9-wave workgroup per CU
+
+
+def test_rollout_kernels_have_no_scratch_and_no_packed_fp32(units):
+    """The Philox block cache once went through scratch memory (a dynamically indexed struct): 16-byte scratch store + load per env,
+    building and step; packed fp32 costs the two-envs-per-lane kernel 9 %."""
+    _, (kernels, meta) = units
+    names = [k for k in kernels if 'cl_rollout_kernel' in k]
+    assert len(names) >= 5
+    for k in names:
+        assert meta[k]['private_seg_size'] == 0, k
+        assert not [i for i in kernels[k] if i.startswith('scratch_') or re.match(r'v_pk_\w+_f32', i)], k
+
+
+def test_main_unit_no_longer_holds_the_moved_kernels(units):
+    (kernels, _), _ = units
+    assert not [k for k in kernels if 'cl_rollout_kernel' in k or re.search(r'cl_step_lean_kernelILi\dELb0E', k)]
+
+
+def test_thermal_kernel_parameters_are_scalar_loads(units):
+    """cl_step_full_tp_kernel<1, 4, *> (2020 schema 9 x 65 536): the parameter block of a (tile, building) item is read with s_load."""
+    (kernels, meta), _ = units
+    k = _one(kernels, r'cl_step_full_tp_kernelILi1ELi4ELb1EE')
+    assert _count(kernels[k], 's_load') >= 30 and _count(kernels[k], 'global_load') <= 16
+    assert meta[k]['private_seg_size'] == 0
+
+
+def test_lstm_window_loop(units):
+    """cl_lstm_kernel<0, 2> (f16 split): two waves per SIMD (<= 256 registers, no scratch); the window loop issues its three input
+    loads at the top and waits for them only at its end -- the compiler once sank the history load right in front of its use (one
+    exposed memory latency per window step: 176 vs 150 us)."""
+    (kernels, meta), _ = units
+    k = _one(kernels, r'cl_lstm_kernelILi0ELi2EE')
+    assert meta[k]['num_vgpr'] <= 256 and meta[k]['private_seg_size'] == 0
+    ins = kernels[k]
+    # the loop: a backward conditional branch to a label, with the 18 f16 MFMAs of a window step in between
+    labels = {x.split()[1]: i for i, x in enumerate(ins) if x.startswith('LABEL ')}
+    loops = [(labels[x.split()[-1]], i) for i, x in enumerate(ins)
+             if x.startswith('s_cbranch') and x.split()[-1] in labels and labels[x.split()[-1]] < i]
+    loops = [(a, b) for a, b in loops if sum('v_mfma_f32_32x32x16_f16' in x for x in ins[a:b]) == 18]
+    assert len(loops) == 1, loops
+    a, b = loops[0]
+    body = [x for x in ins[a + 1:b] if not x.startswith('LABEL ')]
+    loads = [i for i, x in enumerate(body) if x.startswith('global_load')]
+    assert len(loads) == 3 and loads[-1] < 60, loads                         # all three at the top
+    waits0 = [i for i, x in enumerate(body) if x.startswith('s_waitcnt') and 'vmcnt(0)' in x]
+    assert waits0 and waits0[0] > len(body) - 40, (waits0, len(body))         # the only full wait: the rotation at the very end
+    assert sum('v_exp_f32' in x for x in body) == 80 and sum('v_rcp_f32' in x for x in body) == 80      # 10 per hidden unit and cell
