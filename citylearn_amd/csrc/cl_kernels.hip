@@ -1552,6 +1552,7 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
     case 3: CL_LSTM_LAUNCH(0, 0); break;                                   // f32 MFMA path
     case 5: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 5 needs lstm_wb"); CL_LSTM_LAUNCH_WB(1); break;
     case 6: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 6 needs lstm_wb"); CL_LSTM_LAUNCH_WB(2); break;
+    case 32: if (!lstm_wb) return fail(CL_EINVAL, "lstm_variant 32 needs lstm_wb"); CL_LSTM_LAUNCH_WB(32); break;   // common-denominator cell update (experiment)
     case 8: if (!lstm_wb || f16) return fail(CL_EINVAL, "lstm_variant 8 needs bf16 lstm_wb"); CL_LSTM_LAUNCH(8, 1); break;   // two-term bf16 split
     default:
         if (lstm_wb) CL_LSTM_LAUNCH_WB(0);

@@ -156,6 +156,24 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
         for (int m = 0; m < 8; ++m) { c[m] = d0[8 + m] + d1[m]; h[m] = d1[8 + m] * 0.001f + d0[m] * 0.001f; }
         return;
     }
+    if constexpr (DBG & 32) {
+        // Experiment (lstm_variant 32, not measured yet): 7 instead of 10 transcendentals per unit and cell through common denominators,
+        //   c' = [c (1 + e_i)(1 + e_g) + (1 - e_g)(1 + e_f)] / [(1 + e_f)(1 + e_i)(1 + e_g)],   h = (1 - e_c) / [(1 + e_o)(1 + e_c)],
+        // e_x = 2^z_x.  The products must stay finite: z_i + z_f + z_g < 126 and z_o < 62 are properties of the weights (a bound the
+        // host can compute when it packs the tables: |b| + sum |W_ih| x_max + sum |W_hh|; every 2023 model passes, one baeda model
+        // does not), the cell-state path is clamped here (tanh(c) is -1 to fp32 precision long before 2^64).
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float ei = __builtin_amdgcn_exp2f(d0[m]), ef = __builtin_amdgcn_exp2f(d0[8 + m]);
+            const float eg = __builtin_amdgcn_exp2f(d1[m]), eo = __builtin_amdgcn_exp2f(d1[8 + m]);
+            const float pf = 1.0f + ef, t = (1.0f + ei) * (1.0f + eg);
+            const float cn = fmaf(c[m], t, (1.0f - eg) * pf) * cl::rcp(pf * t);
+            c[m] = cn;
+            const float ec = __builtin_amdgcn_exp2f(fminf(cn * -2.885390043258667f, 64.0f));
+            h[m] = (1.0f - ec) * cl::rcp((1.0f + eo) * (1.0f + ec));
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         // the gate rows arrive pre-multiplied by -log2 e (i, f, o) / -2 log2 e (g) (dynamics.pack_lstm): 2^z = exp(-x) / exp(-2 x)

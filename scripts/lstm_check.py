@@ -18,9 +18,9 @@ SPLITS = [a.split('=')[1] for a in sys.argv[1:] if a.startswith('split=')] or ['
 cool = torch.from_numpy(g.ref['cool_dem']).cuda()
 LABEL = {0: ' split matrix-core path', 1: ' [f32 MFMA, experiment: no activations]', 2: ' [f32 MFMA, experiment: no MFMA]',
          3: ' f32-MFMA path', 8: ' two-term split-bf16 (3 partial products)', 5: ' [split, experiment: no activations]',
-         6: ' [split, experiment: no MFMA]'}
+         6: ' [split, experiment: no MFMA]', 32: ' [split, experiment: common-denominator cell update, 7 transcendentals per unit and cell]'}
 for split in SPLITS:
-    for dbg in ((0,) if QUICK else ((0, 8, 3) if split == 'bf16' else (0,))):
+    for dbg in ((0, 32) if QUICK else ((0, 32, 8, 3) if split == 'bf16' else (0, 32))):
         eng = StepEngine(tab, E, detail=True, tuning=dict(lstm_variant=dbg))
         stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'], split=split)
         wt = wr = 0.0
@@ -32,9 +32,9 @@ for split in SPLITS:
             wr = max(wr, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
         print(f'{split} variant {dbg}: teacher-fed worst |dT| =', wt, 'C ; worst comfort reward err / (1e-4 + 1e-4|ref|) =', wr, flush=True)
     if QUICK:
-        cases = ((4096, 0), (16384, 0), (65536, 0), (262144, 0), (65536, 5), (65536, 6))
+        cases = ((4096, 0), (16384, 0), (65536, 0), (262144, 0), (65536, 32), (4096, 32), (65536, 5), (65536, 6))
     else:
-        cases = ((4096, 0), (65536, 0), (65536, 5), (65536, 6)) + (((4096, 8), (65536, 8), (4096, 3), (65536, 3), (65536, 1), (65536, 2)) if split == 'bf16' else ())
+        cases = ((4096, 0), (65536, 0), (65536, 32), (65536, 5), (65536, 6)) + (((4096, 8), (65536, 8), (4096, 3), (65536, 3), (65536, 1), (65536, 2)) if split == 'bf16' else ())
     for E_, dbg in cases:
         eng = StepEngine(tab, E_, detail=True, tuning=dict(lstm_variant=dbg))
         stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0, split=split)

@@ -41,3 +41,31 @@ def test_device_side_split_of_the_hidden_state_is_exact_enough():
     assert (r <= np.maximum(2.0 ** -22 * np.abs(h), 2.0 ** -25)).all()
     t = _terms(h, 'bf16')
     assert np.array_equal((t[0] + t[1] + t[2]).astype(np.float32), h)
+
+
+def test_common_denominator_cell_update_matches_the_plain_one():
+    """The experimental cell update of cl_lstm.h (lstm_variant 32: 7 instead of 10 transcendentals per unit and cell) restated in
+    float32 numpy against the plain formulation, on pre-scaled gate values z (2^z = exp(-x)) up to the admitted bound
+    z_i + z_f + z_g < 126, z_o < 62, with cell states of both signs and sizes: same values to a few fp32 roundings, always finite."""
+    rng = np.random.RandomState(2)
+    f32 = np.float32
+    n = 200000
+    z = (rng.uniform(-40.0, 40.0, size=(4, n))).astype(f32)
+    z[:, : n // 4] = rng.uniform(-3.0, 3.0, size=(4, n // 4)).astype(f32)              # the typical range
+    c = (rng.randn(n) * 10.0 ** rng.uniform(-3, 1.5, size=n)).astype(f32)
+    one, two = f32(1.0), f32(2.0)
+    with np.errstate(over='ignore'):
+        ei, ef, eg, eo = (np.exp2(z[k]) for k in range(4))
+        # plain: lstm_act
+        gi, gf, gg, go = one / (one + ei), one / (one + ef), two / (one + eg) - one, one / (one + eo)
+        c_ref = gf * c + gi * gg
+        h_ref = go * (two / (one + np.exp2(c_ref * f32(-2.885390043258667))) - one)
+        # common denominators
+        pf, t = one + ef, (one + ei) * (one + eg)
+        c_new = (c * t + (one - eg) * pf) * (one / (pf * t))
+        ec = np.exp2(np.minimum(c_new * f32(-2.885390043258667), f32(64.0)))
+        h_new = (one - ec) * (one / ((one + eo) * (one + ec)))
+    assert np.isfinite(c_new).all() and np.isfinite(h_new).all()
+    assert np.abs(c_new - c_ref).max() <= 1e-6 * (1.0 + np.abs(c_ref).max())
+    assert (np.abs(c_new - c_ref) <= 4e-7 * (1.0 + np.abs(c_ref))).all()
+    assert np.abs(h_new - h_ref).max() <= 1e-6
