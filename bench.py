@@ -1,28 +1,38 @@
-"""bench.py -- headline benchmark of the MI355X CityLearn step engine.
+"""bench.py -- benchmark of the MI355X CityLearn step engine (BASELINE.json's metric and configs).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config headline|C2|C3|C4|C4-lean|C5]
 
-Workload (BASELINE.json `metric`): the 17-building `citylearn_challenge_2022_phase_all` district tables x
-65 536 environments per GPU, fp32, one environment step per kernel launch (`cl_step_f32`, mode A: state lives in
-HBM, fresh actions every step).  A "step" advances every (env, building) unit by one time step.  The env batch
-is sharded across GPUs with no collective on the data path (weak scaling: per-GPU work is fixed).
+`--gpus N` with N > 1 needs no launcher: when RANK / WORLD_SIZE are not in the environment this process starts the N ranks
+itself (one process per GPU, `citylearn_amd.parallel.launch_ranks`), forwards rank 0's JSON line and exits with the ranks'
+exit code.  Under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (RANK etc. set) it
+is one of the ranks.  Ranks use RCCL (`nccl`) for the barrier and the MAX-over-ranks of the timing only: the env batch is
+sharded across GPUs and no collective sits on the data path (weak scaling: per-GPU work is fixed).
 
-Timing protocol: W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over
-ranks -- repeated `--reps` times on the same pre-captured, pre-replayed hipGraphs; the line reports the MEDIAN
-repetition (all repetitions are listed in `rep_ms_per_step`).  The kernel duration for the roofline comes from HIP events
+Configs (`--config`, default `headline`):
+  headline  BASELINE.json `metric`: 2022_phase_all tables (17 buildings) x 65 536 envs per GPU, one env step per launch (mode A)
+  C2        the same tables x 4 096 envs per GPU
+  C3        2023 phase-2 schema (3 buildings: outage path, partial-load cooling, DHW tank, battery) x 65 536 envs per GPU; a step =
+            the energy step AND the LSTM indoor-temperature stage with its ComfortReward epilogue (what CityLearnEnv.step runs there)
+  C4        synthetic 1024-building district (2020 climate-zone-1 device set: heat pump, heater, two tanks, battery; parameters
+            jittered) x 1024 envs per GPU -- the per-GPU shard of the 8192-env config; C4-lean: battery + PV device set
+  C5        fused 24-step day rollout per launch with the on-device Philox random policy, 17 buildings x 32 768 envs per GPU (the
+            per-GPU shard of 262 144 envs on 8 GPUs); a "step" of the line is one 24-step launch
+
+Timing protocol: W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks --
+repeated `--reps` times on the same pre-captured, pre-replayed hipGraphs; the line reports the MEDIAN repetition (all repetitions
+in `rep_ms_per_step`, every rank's median in `rank_ms_per_step`).  The kernel duration behind `roofline` comes from HIP events
 recorded on the launch stream around max(K, 2000) consecutive steps of the same loop enqueued behind a lead-in chunk (no host
-submission gap inside the bracket); the events around each timed repetition are listed too (`timed_region_event_us_per_step`).
+submission gap inside the bracket); `roofline.kernel` is what the library reports having launched (`cl_tuning.kernel_name`).
 
-Prints ONE JSON line (rank 0).  `value` = building-timesteps/s over all GPUs with inputs resident in HBM.
-`roofline` prices the step kernel against HBM (algorithmic bytes per launch / measured launch duration) at the headline
-shape -- whose 58 MB working set sits in the 256 MB Infinity Cache across replays -- and `roofline.hbm_streaming` repeats
-the measurement at 17 x 1 048 576 envs (0.66 GB of step traffic per launch, far beyond the cache): the figure that is
-bounded by HBM proper.  `cpu_baseline` is the C restatement of the reference arithmetic (oracle/cl_oracle.c, the "port")
-timed on this box's host cores on a bounded sample (rank 0, N = 1 only); `cpu_baseline.reference` is the reference's own
-`CityLearnEnv.step` as timed by oracle/ref_harness/time_reference.py on the host named there (the reference cannot run
-on the GPU box: /root/reference does not travel).
+Prints ONE JSON line (rank 0).  `value` = building-timesteps/s over all GPUs with inputs resident in HBM.  `cpu_baseline`
+(headline, N = 1) is the C restatement of the reference arithmetic (oracle/cl_oracle.c, the "port") timed on this box's host
+cores -- all cores, and one core as `cpu_baseline.one_core`; `cpu_baseline.reference` is the reference's own `CityLearnEnv.step`
+as timed by oracle/ref_harness/time_reference.py on the host named there (/root/reference does not travel to the GPU box).
+
+Test hooks (environment): CL_BENCH_OVERSUBSCRIBE=1 maps rank r to device r mod (visible devices) so that `--gpus 2` can be
+exercised on a 1-GPU box (the ranks then share a GPU: control plane over gloo because RCCL refuses two ranks per device, and the
+line says `"oversubscribed": true` -- not a scaling measurement); CL_BENCH_DRY_RUN=1 skips all GPU work (launcher, rendezvous and
+aggregation on CPU: tests/test_distributed.py); CL_BENCH_FORCE_DIST=1 brings up the process group even for one rank.
 """
 from __future__ import annotations
 
@@ -34,39 +44,50 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_MEASURED_COPY_GBS = 6290.0  # float4 device copy measured on MI355X, same guide
+VALU_LANES = 256 * 4 * 16       # 256 CUs x 4 SIMDs x 16 lanes
+VALU_CLOCK_GHZ = 2.4            # MI355X peak engine clock
 ENVS_PER_GPU = 65536
-STREAMING_ENVS = 1048576        # second roofline entry: working set >> 256 MB Infinity Cache
+STREAMING_ENVS = 1048576        # second roofline entry of the headline: working set >> 256 MB Infinity Cache
 GRAPH_CHUNK = 100
+METRIC = 'building-timesteps/sec at 17 bldgs x 65536 envs; HBM GB/s vs roofline'
+CONFIGS = ('headline', 'C2', 'C3', 'C4', 'C4-lean', 'C5')
 
 
-def cpu_baseline(spec, tables, seconds: float = 12.0) -> dict:
-    """Time oracle/cl_oracle.c (double-precision port of the reference arithmetic, OpenMP over envs) on a bounded
-    sample of the same workload."""
+# --------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(spec, tables, seconds: float = 10.0) -> dict:
+    """Time oracle/cl_oracle.c (double-precision port of the reference arithmetic, OpenMP over envs) on a bounded sample of the
+    headline workload: all host cores, then ONE core (the "fair CPU" line of SURVEY 8d)."""
+    import ctypes
+    import numpy as np
     from oracle.c_oracle import COracle
     cores = os.cpu_count() or 1
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))
-    E = 4096
-    ora = COracle(spec, tables, E)
-    rng = np.random.RandomState(0)
-    acts = [rng.uniform(-1, 1, size=(ora.n_act_cols, E)).astype(np.float32) for _ in range(4)]
-    for t in range(3):
-        ora.step(acts[t % 4], t)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(10):
-            ora.step(acts[n % 4], 1 + n % (ora.T - 2))
-            n += 1
-    dt = time.perf_counter() - t0
-    out = {'value': E * ora.B * n / dt, 'unit': 'building-timesteps/s', 'cores': cores, 'kind': 'port',
-           'sample': f'oracle/cl_oracle.c (OpenMP, {cores} threads): 17 buildings x {E} envs x {n} steps in {dt:.1f} s'}
+    omp = ctypes.CDLL('libgomp.so.1')
+
+    def run(threads: int, E: int, budget: float):
+        omp.omp_set_num_threads(threads)
+        ora = COracle(spec, tables, E)
+        rng = np.random.RandomState(0)
+        acts = [rng.uniform(-1, 1, size=(ora.n_act_cols, E)).astype(np.float32) for _ in range(4)]
+        for t in range(3):
+            ora.step(acts[t % 4], t)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            for _ in range(10):
+                ora.step(acts[n % 4], 1 + n % (ora.T - 2))
+                n += 1
+        dt = time.perf_counter() - t0
+        return E * ora.B * n / dt, f'oracle/cl_oracle.c (OpenMP, {threads} thread{"s" if threads > 1 else ""}): 17 buildings x {E} envs x {n} steps in {dt:.1f} s'
+
+    v, sample = run(cores, 4096, seconds)
+    v1, sample1 = run(1, 256, seconds / 2)
+    out = {'value': v, 'unit': 'building-timesteps/s', 'cores': cores, 'kind': 'port', 'sample': sample,
+           'one_core': {'value': v1, 'unit': 'building-timesteps/s', 'cores': 1, 'kind': 'port', 'sample': sample1}}
     ref = ROOT / 'profiles' / 'reference_cpu_timing.json'
     if ref.exists():
         # the reference's own CityLearnEnv.step (citylearn.py:978-1056), timed where /root/reference exists
@@ -74,17 +95,18 @@ def cpu_baseline(spec, tables, seconds: float = 12.0) -> dict:
     return out
 
 
+# --------------------------------------------------------------------------------------------------- step loop as hipGraphs
 class Runner:
-    """The step loop of one engine as pre-captured hipGraphs: chunk (i0, n) = steps i0 .. i0+n-1 of the action ring / episode."""
+    """The step loop of one workload as pre-captured hipGraphs: chunk (i0, n) = steps i0 .. i0+n-1; `step_fn(i)` enqueues step i
+    on the current stream and depends on i only through i mod `period`."""
 
-    def __init__(self, eng, acts, stream, use_graph: bool):
-        self.eng, self.acts, self.stream, self.use_graph = eng, acts, stream, use_graph
-        self.T = eng.n_steps - 1                 # an episode of T+1 rows has T transitions
+    def __init__(self, step_fn, period: int, stream, use_graph: bool):
+        self.step_fn, self.period, self.stream, self.use_graph = step_fn, period, stream, use_graph
         self.graphs = {}
 
     def run(self, i0: int, n: int):
         for i in range(i0, i0 + n):
-            self.eng.step(self.acts[i % len(self.acts)], i % self.T)
+            self.step_fn(i)
 
     def chunks(self, i0: int, n: int):
         i = i0
@@ -96,10 +118,11 @@ class Runner:
     def prepare(self, i0: int, n: int):
         """Capture every graph steps [i0, i0+n) need and replay each once, untimed: the first launch of a graph pays its
         upload, which must not land in the timed region."""
+        import torch
         if not self.use_graph:
             return
         for i, c in self.chunks(i0, n):
-            key = (i % (len(self.acts) * self.T), c)
+            key = (i % self.period, c)
             if key not in self.graphs:
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr, stream=self.stream):
@@ -111,13 +134,15 @@ class Runner:
     def advance(self, i0: int, n: int):
         for i, c in self.chunks(i0, n):
             if self.use_graph:
-                self.graphs[(i % (len(self.acts) * self.T), c)].replay()
+                self.graphs[(i % self.period, c)].replay()
             else:
                 self.run(i, c)
 
 
-def timed_reps(runner: Runner, warmup: int, steps: int, reps: int, dist, device):
-    """`reps` x (exactly `steps` steps between barrier + synchronize): per-repetition (wall seconds, HIP-event seconds)."""
+def timed_reps(runner: Runner, reset_fn, warmup: int, steps: int, reps: int, dist, kernel_steps: int):
+    """`reps` x (exactly `steps` steps between barrier + synchronize): per-repetition (wall seconds, HIP-event seconds), and the
+    kernel time per step from HIP events around `kernel_steps` consecutive steps behind a lead-in chunk."""
+    import torch
     stream = runner.stream
     out = []
     with torch.cuda.stream(stream):
@@ -125,7 +150,7 @@ def timed_reps(runner: Runner, warmup: int, steps: int, reps: int, dist, device)
         stream.synchronize()
         runner.prepare(0, warmup)
         runner.prepare(warmup, steps)
-        runner.eng.reset()
+        reset_fn()
         runner.advance(0, warmup)
         stream.synchronize()
         for _ in range(reps):
@@ -143,12 +168,12 @@ def timed_reps(runner: Runner, warmup: int, steps: int, reps: int, dist, device)
                 dist.barrier()
             wall = time.perf_counter() - t0
             out.append((wall, ev0.elapsed_time(ev1) / 1e3))
-        # Kernel duration for the roofline: HIP events on the launch stream around >= 2000 consecutive steps of the same loop
+        # Kernel duration for the roofline: HIP events on the launch stream around `kernel_steps` consecutive steps of the same loop
         # (graphs of GRAPH_CHUNK steps, captured and replayed once beforehand) enqueued behind a lead-in chunk, so that the bracket
         # [ev0, ev1] holds kernel time only.  (Events around a timed repetition also hold the host's graph-submission gap between
         # `ev0` and the first kernel -- ~20 us, i.e. 1 us per step at K = 20 -- and a K-step graph replayed back to back still pays
         # ~5 us per graph boundary: both are launch behaviour of short graphs, not kernel duration.)
-        n_k = max(steps, 2000)
+        n_k = kernel_steps
         runner.prepare(warmup, n_k)
         runner.advance(warmup, min(GRAPH_CHUNK, n_k))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -160,141 +185,336 @@ def timed_reps(runner: Runner, warmup: int, steps: int, reps: int, dist, device)
     return out, kernel_s
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5000)
-    ap.add_argument('--warmup', type=int, default=300)
-    ap.add_argument('--reps', type=int, default=5, help='timed repetitions of the K steps; the median is reported')
-    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
-    ap.add_argument('--no-graph', action='store_true', help='launch every step from Python instead of hipGraph replay')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-streaming', action='store_true', help='skip the 17 x 1 048 576 HBM-streaming roofline entry')
-    args = ap.parse_args()
+# --------------------------------------------------------------------------------------------------- workloads
+def _pmc_traffic(pattern: str, kernels: str):
+    """HBM bytes per launch from the newest rocprofv3 --pmc summary under profiles/ matching `pattern` (separate FETCH_SIZE /
+    WRITE_SIZE passes, KiB units; FETCH_SIZE doubled per the gfx950 wide-load correction of MI355X_MICROARCH.md) -- only if
+    the summary was collected on the kernel this run launched (`_kernel.kernel` must contain its name)."""
+    files = sorted((ROOT / 'profiles').glob(pattern))
+    for f in reversed(files):
+        c = json.loads(f.read_text())
+        seen = c.get('_kernel', {}).get('kernel', '')
+        if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c and any(k and k in seen for k in kernels.split('+')):
+            return (2.0 * c['FETCH_SIZE']['mean'] + c['WRITE_SIZE']['mean']) * 1024.0, f.name
+    return None, None
 
+
+class StepWorkload:
+    """Mode A: one env step per launch on a district's tables (`cl_step_f32`), fresh actions from an 8-tensor ring."""
+
+    dtype = 'f32'
+
+    def __init__(self, name: str, spec, E: int, device: str, rank: int, tuning: dict, what: str, lstm: bool = False):
+        import torch
+        from citylearn_amd.engine import StepEngine
+        self.name, self.what, self.E, self.device = name, what, E, device
+        self.spec = spec
+        self.tables = spec.episode_tables(0)
+        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, detail=lstm)
+        self.eng.trace_kernels()
+        self.stage = None
+        if lstm:
+            from citylearn_amd.dynamics import LSTMStage
+            a = dict(spec.reward_function.get('attributes') or {})
+            self.stage = LSTMStage(spec, self.tables, self.eng, a.get('band'), a.get('lower_exponent') or 2.0, a.get('higher_exponent') or 2.0)
+        low, high = spec.action_limits()
+        lo, hi = torch.from_numpy(low).to(device), torch.from_numpy(high).to(device)
+        gen = torch.Generator(device=device).manual_seed(1234 + rank)
+        self.acts = [lo[:, None] + torch.rand((self.eng.n_act_cols, E), device=device, generator=gen) * (hi - lo)[:, None] for _ in range(8)]
+        self.T = self.eng.n_steps - 1                 # an episode of T+1 rows has T transitions
+        self.period = len(self.acts) * self.T
+        self.units_per_step = self.eng.n_bldg * E
+        self.kernels = None
+        self.lstm_kernels = None
+
+    def step_fn(self, i: int):
+        t = i % self.T
+        self.eng.step(self.acts[i % len(self.acts)], t)
+        if self.kernels is None:
+            self.kernels = self.eng.last_kernels
+        if self.stage is not None:
+            self.stage.step(t)
+            if t >= 13 and self.lstm_kernels is None:
+                self.lstm_kernels = self.eng.last_kernels
+
+    def reset(self):
+        self.eng.reset()
+        if self.stage is not None:
+            self.stage.reset()
+
+    def bytes_per_unit(self) -> float:
+        return self.eng.algorithmic_bytes_per_unit()
+
+    def roofline(self, launch_s: float) -> dict:
+        bpu = self.bytes_per_unit()
+        achieved = self.units_per_step * bpu / launch_s / 1e9
+        r = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+             'frac_vs_measured_copy': achieved / HBM_MEASURED_COPY_GBS, 'kernel': self.kernels, 'launch_us': launch_s * 1e6,
+             'algorithmic_bytes_per_unit': bpu, 'units_per_launch': self.units_per_step}
+        if self.stage is not None:
+            # C3: the step is two launches and the LSTM stage dominates it; it is bound by vector-ALU issue, its transcendentals first
+            # (12 window steps x 2 layers x 16 units x 10 exp / rcp per unit-step; quarter-rate instructions: 4 lanes per SIMD and cycle)
+            trans = 12 * 2 * 16 * (7 if '<32,' in (self.lstm_kernels or '') else 10)
+            peak = VALU_LANES / 4 * VALU_CLOCK_GHZ             # G transcendentals / s
+            ach = self.units_per_step * trans / launch_s / 1e9
+            r = {'bound': 'valu', 'achieved': ach, 'peak': peak, 'unit': 'G transcendental op/s', 'frac': ach / peak,
+                 'kernel': f'{self.kernels}+{self.lstm_kernels}', 'launch_us': launch_s * 1e6, 'units_per_launch': self.units_per_step,
+                 'transcendentals_per_unit': trans, 'traffic': None,
+                 'note': 'launch_us = energy step + LSTM stage of one env step; the LSTM kernel re-runs the 12-step lookback window of a 2 x 16-unit '
+                         'LSTM per (env, building) and step (building.py:3000-3078), ~77 kFLOP on the matrix cores beside the activations that bound it; '
+                         'peak = 256 CUs x 4 SIMDs x 4 quarter-rate lanes x 2.4 GHz',
+                 'energy_step_hbm': {'algorithmic_bytes_per_unit': bpu, 'note': 'see profiles/ kernel stats for the split of launch_us'}}
+        return r
+
+
+class RolloutWorkload:
+    """Mode B (config C5): K fused steps per launch, state in registers, on-device Philox policy (`cl_rollout_f32`)."""
+
+    dtype = 'f32'
+
+    def __init__(self, name: str, spec, E: int, K: int, device: str, rank: int, world: int, tuning: dict, what: str):
+        import torch
+        from citylearn_amd.engine import StepEngine
+        self.name, self.what, self.E, self.K, self.device = name, what, E, K, device
+        self.spec = spec
+        self.tables = spec.episode_tables(0)
+        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, env_offset=rank * E)     # disjoint Philox streams per shard
+        self.eng.trace_kernels()
+        low, high = spec.action_limits()
+        self.eng.set_action_limits(low, high)
+        self.ret = torch.zeros(E, device=device)
+        self.n_windows = (self.eng.n_steps - 1) // K            # whole K-step windows of the episode
+        self.period = self.n_windows
+        self.units_per_step = self.eng.n_bldg * E * K
+        self.kernels = None
+
+    def step_fn(self, i: int):
+        w = i % self.n_windows
+        self.eng.rollout(self.K, seed=5 + i % self.period, ret_env=self.ret, t0=w * self.K)
+        if self.kernels is None:
+            self.kernels = self.eng.last_kernels
+
+    def reset(self):
+        self.eng.reset()
+        self.ret.zero_()
+
+    def bytes_per_unit(self) -> float:
+        return self.eng.algorithmic_bytes_per_unit() / self.K
+
+    def roofline(self, launch_s: float) -> dict:
+        # VALU-issue bound: lane-instructions per (env, building, step) from the SQ counters of this kernel
+        # (profiles/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step at two envs per lane, 101 at one)
+        inst = 100.0
+        peak = VALU_LANES * VALU_CLOCK_GHZ                      # G lane-instructions / s
+        ach = self.units_per_step * inst / launch_s / 1e9
+        return {'bound': 'valu', 'achieved': ach, 'peak': peak, 'unit': 'G lane-instructions/s', 'frac': ach / peak, 'kernel': self.kernels,
+                'launch_us': launch_s * 1e6, 'units_per_launch': self.units_per_step, 'valu_instructions_per_unit_step': inst,
+                'traffic': None, 'hbm_bytes_per_unit_step': self.bytes_per_unit(),
+                'note': f'one launch = {self.K} env steps with state in registers; HBM sees state once per launch, so the bound is vector-ALU issue '
+                        '(SURVEY 8d): achieved = units x VALU instructions per unit-step (SQ_INSTS_VALU, profiles/) / launch time, '
+                        'peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz'}
+
+
+def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning: dict):
+    from citylearn_amd import load_district
+    from citylearn_amd.data import sample_schema
+    if cfg in ('headline', 'C2', 'C5'):
+        spec = load_district(sample_schema('citylearn_challenge_2022_phase_all_720h'))   # 17 buildings, first 720 hours
+        if cfg == 'C5':
+            return RolloutWorkload(cfg, spec, E, 24, device, rank, world, tuning,
+                                   f'citylearn_challenge_2022_phase_all tables (17 buildings, first 720 h) x {E} envs per GPU, cl_rollout_f32 mode B: '
+                                   '24 fused env steps per launch, state in registers, on-device Philox4x32-10 uniform random policy; env batch sharded '
+                                   'over GPUs (8 x 32 768 = the 262 144 envs of BASELINE config 5), no collective')
+        return StepWorkload(cfg, spec, E, device, rank, tuning,
+                            f'citylearn_challenge_2022_phase_all tables (17 buildings, first 720 h) x {E} envs per GPU, '
+                            'cl_step_f32 mode A (one env step per launch, state in HBM, fresh uniform random actions '
+                            'from an 8-tensor ring), env batch sharded over GPUs, no collective')
+    if cfg == 'C3':
+        spec = load_district(sample_schema('citylearn_challenge_2023_phase_2_local_evaluation_720h'))
+        return StepWorkload(cfg, spec, E, device, rank, tuning,
+                            f'citylearn_challenge_2023_phase_2_local_evaluation (3 buildings: power outages, partial-load cooling, DHW tank, battery; '
+                            f'first 720 h) x {E} envs per GPU; one step = cl_step_f32 (energy step, detail planes) + cl_lstm_step_f32 (LSTM indoor '
+                            'temperature + ComfortReward): the whole CityLearnEnv.step of this schema', lstm=True)
+    if cfg in ('C4', 'C4-lean'):
+        from citylearn_amd.synthetic import tile_district
+        base = 'citylearn_challenge_2020_climate_zone_1_744h' if cfg == 'C4' else 'citylearn_challenge_2022_phase_all_720h'
+        spec = tile_district(load_district(sample_schema(base)), 1024)
+        return StepWorkload(cfg, spec, E, device, rank, tuning,
+                            f'synthetic 1024-building district ({"2020 climate-zone-1 device set: heat pump, heater, 2 tanks, battery" if cfg == "C4" else "battery + PV"}'
+                            f'; sizes jittered +-10 %) x {E} envs per GPU (8 GPUs x 1024 = the 8192 envs of BASELINE config 4), cl_step_f32 mode A, '
+                            'building-chunked launch, no collective')
+    raise SystemExit(f'unknown --config {cfg}')
+
+
+DEFAULT_ENVS = {'headline': ENVS_PER_GPU, 'C2': 4096, 'C3': 65536, 'C4': 1024, 'C4-lean': 1024, 'C5': 32768}
+
+
+# --------------------------------------------------------------------------------------------------- one rank
+def dry_run_rank(args, rank: int, world: int):
+    """CL_BENCH_DRY_RUN: everything but the GPU -- rendezvous (gloo), barrier, MAX-over-ranks, per-rank gather, one JSON line."""
+    from citylearn_amd.parallel import gather_seconds, init_control_plane, reduce_max_seconds
+    dist = init_control_plane(rank, world, None, 'gloo') if world > 1 else None
+    mine = 1e-3 * (rank + 1) * args.steps                       # a different "wall time" per rank: the line must carry the MAX
+    wall = reduce_max_seconds(mine, dist, 'cpu')
+    per_rank = gather_seconds(mine, dist, 'cpu')
+    if rank == 0:
+        print(json.dumps({'metric': METRIC, 'value': world * 17 * DEFAULT_ENVS[args.config] * args.steps / wall, 'unit': 'building-timesteps/s',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': wall / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'DRY RUN (CL_BENCH_DRY_RUN): no GPU work, synthetic timings'}, 'dry_run': True,
+                          'world_size_seen': world if dist is None else dist.get_world_size(), 'control_backend': 'gloo' if dist is not None else None,
+                          'rank_ms_per_step': [s / args.steps * 1e3 for s in per_rank]}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('for --gpus N > 1 launch with torch.distributed.run (one process per GPU)')
-    torch.cuda.set_device(local_rank)
-    device = f'cuda:{local_rank}'
-    dist = None
-    if world > 1 or os.environ.get('CL_BENCH_FORCE_DIST'):       # the env hook exercises the RCCL path on a 1-GPU box (torchrun, 1 rank)
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # RCCL prints a version banner on STDOUT when the communicator comes up; stdout must carry the one JSON line only
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group('nccl', device_id=torch.device(device))
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+    if os.environ.get('CL_BENCH_DRY_RUN'):
+        return dry_run_rank(args, rank, world)
 
-    from citylearn_amd import load_district
-    from citylearn_amd.data import sample_schema
-    from citylearn_amd.engine import StepEngine
-    from citylearn_amd.parallel import reduce_max_seconds
+    import torch
+    from citylearn_amd.parallel import gather_seconds, init_control_plane, reduce_max_seconds
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        raise SystemExit('bench.py needs a GPU (no HIP device visible); there is no CPU path')
+    oversubscribed = world > n_dev
+    if oversubscribed and not os.environ.get('CL_BENCH_OVERSUBSCRIBE'):
+        raise SystemExit(f'--gpus {world} but only {n_dev} device(s) visible (set CL_BENCH_OVERSUBSCRIBE=1 to let ranks share a GPU: a plumbing test, '
+                         'not a scaling measurement)')
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    device = f'cuda:{dev_index}'
+    dist, backend = None, None
+    if world > 1 or os.environ.get('CL_BENCH_FORCE_DIST'):
+        backend = 'gloo' if oversubscribed else 'nccl'        # RCCL refuses two ranks on one device
+        dist = init_control_plane(rank, world, device, backend)
+    ctl_device = device if backend == 'nccl' else 'cpu'
 
-    spec = load_district(sample_schema('citylearn_challenge_2022_phase_all_720h'))   # 17 buildings, first 720 hours
-    tables = spec.episode_tables(0)
     tuning = {k[len('CL_TUNE_'):].lower(): int(v) for k, v in os.environ.items() if k.startswith('CL_TUNE_')}   # e.g. CL_TUNE_ENVMAJOR=2
     use_graph = not args.no_graph
+    cfg = args.config
+    E = args.envs_per_gpu or DEFAULT_ENVS[cfg]
 
-    def measure(E: int, warmup: int, steps: int, reps: int):
-        eng = StepEngine(tables, E, device=device, tuning=tuning)
-        assert eng.lean
-        gen = torch.Generator(device=device).manual_seed(1234 + rank)
-        acts = [torch.rand((eng.n_act_cols, E), device=device, generator=gen) * 2 - 1 for _ in range(8)]
-        runner = Runner(eng, acts, torch.cuda.Stream(device=device), use_graph)
-        rep, kernel_s = timed_reps(runner, warmup, steps, reps, dist, device)
-        # MAX over ranks per repetition, then the median repetition
-        walls = [reduce_max_seconds(w, dist, device) for w, _ in rep]
-        evs = [reduce_max_seconds(e, dist, device) for _, e in rep]
-        return eng, walls, evs, reduce_max_seconds(kernel_s, dist, device)
+    def measure(wl, warmup: int, steps: int, reps: int, kernel_steps: int):
+        runner = Runner(wl.step_fn, wl.period, torch.cuda.Stream(device=device), use_graph)
+        rep, kernel_s = timed_reps(runner, wl.reset, warmup, steps, reps, dist, kernel_steps)
+        walls = [reduce_max_seconds(w, dist, ctl_device) for w, _ in rep]         # MAX over ranks per repetition
+        evs = [reduce_max_seconds(e, dist, ctl_device) for _, e in rep]
+        mine = statistics.median(w for w, _ in rep)
+        return walls, evs, reduce_max_seconds(kernel_s, dist, ctl_device), gather_seconds(mine, dist, ctl_device)
 
-    E = args.envs_per_gpu
-    eng, walls, evs, launch_s = measure(E, args.warmup, args.steps, args.reps)
+    wl = build_workload(cfg, E, device, rank, world, tuning)
+    heavy = cfg in ('C3', 'C5')                          # ~100 us .. 1 ms per step: fewer steps in the kernel-time bracket
+    walls, evs, launch_s, per_rank = measure(wl, args.warmup, args.steps, args.reps, max(args.steps, 200 if heavy else 2000))
     wall_med = statistics.median(walls)
-    units_per_step = eng.n_bldg * E
-    bytes_per_unit = eng.algorithmic_bytes_per_unit()
-    achieved = units_per_step * bytes_per_unit / launch_s / 1e9
-    # <.., true> = plane stores / loads with the non-temporal hint (launches of up to 3 Mi units or from 16 Mi units, csrc/cl_kernels.hip)
-    kernel_name = (lambda e: f'cl_step_envmajor_kernel<20, {"true" if (e * 17 <= 3 << 20 or e * 17 >= 16 << 20) else "false"}>' if e >= 131072 else 'cl_step_lean_kernel<4, false, true>')
+    roof = wl.roofline(launch_s)
+    roof['launch_us_how'] = ('HIP events on the launch stream around max(K, 2000) consecutive steps (pre-replayed 100-step hipGraphs) enqueued behind a '
+                             'lead-in chunk: kernel time only') if not heavy else 'HIP events on the launch stream around max(K, 200) consecutive steps behind a lead-in chunk'
+    roof['timed_region_event_us_per_step'] = [e / args.steps * 1e6 for e in evs]
+    if roof['bound'] == 'hbm':
+        pattern = {'headline': 'r*_bench_pmc_summary.json', 'C2': 'r*_c2_pmc_summary.json', 'C4': 'r*_c4_pmc_summary.json',
+                   'C4-lean': 'r*_c4lean_pmc_summary.json'}.get(cfg, 'none')
+        roof['traffic'], roof['traffic_source'] = _pmc_traffic(pattern, wl.kernels or '') if E == DEFAULT_ENVS[cfg] else (None, None)
+    if cfg == 'headline':
+        roof['note'] = ('working set (state 13 MB + outputs 9 MB + action ring 36 MB) fits the 256 MB Infinity Cache: see hbm_streaming '
+                        'for the HBM-resident figure')
+    units_per_step, n_bldg, spec, tables, what = wl.units_per_step, wl.eng.n_bldg, wl.spec, wl.tables, wl.what
 
-    traffic, traffic_source = None, None
-    pmcs = sorted((ROOT / 'profiles').glob('r*_bench_pmc_summary.json'))        # the newest round's counters of this same workload
-    pmc = pmcs[-1] if pmcs else ROOT / 'profiles' / 'none'
-    if pmc.exists() and E == ENVS_PER_GPU:
-        # HBM bytes per launch from the rocprofv3 --pmc passes of this same workload (separate FETCH_SIZE / WRITE_SIZE
-        # runs, KiB units; FETCH_SIZE doubled per the gfx950 wide-load correction of MI355X_MICROARCH.md)
-        c = json.loads(pmc.read_text())
-        traffic = (2.0 * c['FETCH_SIZE']['mean'] + c['WRITE_SIZE']['mean']) * 1024.0
-        traffic_source = pmc.name
-
-    streaming = None
-    if not args.no_streaming and E == ENVS_PER_GPU:
-        del eng
+    if cfg == 'headline' and not args.no_streaming and E == ENVS_PER_GPU:
+        del wl
         torch.cuda.empty_cache()
         s_steps = 20
-        eng_s, _, _, launch = measure(STREAMING_ENVS, 5, s_steps, 3)
-        s_traffic, s_traffic_source = None, None
-        spmc = sorted((ROOT / 'profiles').glob('r*_streaming_pmc_summary.json'))
-        if spmc:
-            c = json.loads(spmc[-1].read_text())
-            s_traffic, s_traffic_source = (2.0 * c['FETCH_SIZE']['mean'] + c['WRITE_SIZE']['mean']) * 1024.0, spmc[-1].name
-        a = eng_s.n_bldg * STREAMING_ENVS * eng_s.algorithmic_bytes_per_unit() / launch / 1e9
-        streaming = {'workload': f'same tables x {STREAMING_ENVS} envs per GPU ({eng_s.n_bldg * STREAMING_ENVS * eng_s.algorithmic_bytes_per_unit() / 1e6:.0f} MB '
-                                 f'of algorithmic traffic per launch, beyond the 256 MB Infinity Cache)',
-                     'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
-                     'frac_vs_measured_copy': a / HBM_MEASURED_COPY_GBS, 'kernel': kernel_name(STREAMING_ENVS), 'launch_us': launch * 1e6,
-                     'units_per_launch': eng_s.n_bldg * STREAMING_ENVS, 'steps': s_steps, 'traffic': s_traffic, 'traffic_source': s_traffic_source,
-                     'value': world * eng_s.n_bldg * STREAMING_ENVS / launch}
-        n_bldg = eng_s.n_bldg
-        del eng_s
+        wl_s = build_workload(cfg, STREAMING_ENVS, device, rank, world, tuning)
+        _, _, launch, _ = measure(wl_s, 5, s_steps, 3, 2000)
+        a = wl_s.units_per_step * wl_s.bytes_per_unit() / launch / 1e9
+        s_traffic, s_source = _pmc_traffic('r*_streaming_pmc_summary.json', wl_s.kernels or '')
+        roof['hbm_streaming'] = {
+            'workload': f'same tables x {STREAMING_ENVS} envs per GPU ({wl_s.units_per_step * wl_s.bytes_per_unit() / 1e6:.0f} MB '
+                        f'of algorithmic traffic per launch, beyond the 256 MB Infinity Cache)',
+            'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
+            'frac_vs_measured_copy': a / HBM_MEASURED_COPY_GBS, 'kernel': wl_s.kernels, 'launch_us': launch * 1e6,
+            'units_per_launch': wl_s.units_per_step, 'steps': s_steps, 'traffic': s_traffic, 'traffic_source': s_source,
+            'value': world * wl_s.units_per_step / launch}
+        del wl_s
         torch.cuda.empty_cache()
-    else:
-        n_bldg = eng.n_bldg
 
     if rank == 0:
+        n_distinct = min(world, n_dev)
         out = {
-            'metric': 'building-timesteps/sec at 17 bldgs x 65536 envs; HBM GB/s vs roofline',
+            'metric': METRIC,
             'value': world * units_per_step * args.steps / wall_med,
             'unit': 'building-timesteps/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world if not oversubscribed else n_distinct, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall_med / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'citylearn_challenge_2022_phase_all tables (17 buildings, first 720 h) x {E} envs per GPU, '
-                                   'cl_step_f32 mode A (one env step per launch, state in HBM, fresh uniform random actions '
-                                   'from an 8-tensor ring), env batch sharded over GPUs, no collective',
-                       'envs_per_gpu': E, 'buildings': n_bldg, 'launch': 'hipGraph replay' if use_graph else 'eager',
-                       'reward': 'RewardFunction', 'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)'},
+            'config': {'workload': what, 'name': cfg, 'envs_per_gpu': E, 'buildings': n_bldg,
+                       'launch': 'hipGraph replay' if use_graph else 'eager', 'reward': 'ComfortReward' if cfg == 'C3' else 'RewardFunction',
+                       'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)',
+                       **({'k_steps_per_launch': 24, 'step': 'one fused 24-step launch'} if cfg == 'C5' else {})},
+            'ranks': world, 'world_size_seen': world if dist is None else dist.get_world_size(), 'control_backend': backend,
+            'rank_ms_per_step': [s / args.steps * 1e3 for s in per_rank],
             'rep_ms_per_step': [w / args.steps * 1e3 for w in walls],
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
-                         'frac_vs_measured_copy': achieved / HBM_MEASURED_COPY_GBS,
-                         'kernel': kernel_name(E), 'launch_us': launch_s * 1e6,
-                         'launch_us_how': 'HIP events on the launch stream around max(K, 2000) consecutive steps (pre-replayed 100-step hipGraphs) '
-                                          'enqueued behind a lead-in chunk: kernel time only',
-                         'timed_region_event_us_per_step': [e / args.steps * 1e6 for e in evs],
-                         'algorithmic_bytes_per_unit': bytes_per_unit, 'units_per_launch': units_per_step,
-                         'note': 'working set (state 13 MB + outputs 9 MB + action ring 36 MB) fits the 256 MB Infinity Cache: see hbm_streaming '
-                                 'for the HBM-resident figure',
-                         'hbm_streaming': streaming},
+            'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if oversubscribed:
+            out['oversubscribed'] = True
+            out['config']['note'] = (f'{world} ranks share {n_dev} GPU(s) (CL_BENCH_OVERSUBSCRIBE): exercises the multi-rank plumbing, NOT a scaling measurement; '
+                                     'n_gpus = distinct devices')
+        if cfg == 'headline' and world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(spec, tables)
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------- entry
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps K (default: 5000; 300 for C3, 200 for C5)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warmup steps W (default: 300; 30 for C3 / C5)')
+    ap.add_argument('--reps', type=int, default=5, help='timed repetitions of the K steps; the median is reported')
+    ap.add_argument('--config', choices=CONFIGS, default='headline')
+    ap.add_argument('--envs-per-gpu', type=int, default=None)
+    ap.add_argument('--no-graph', action='store_true', help='launch every step from Python instead of hipGraph replay')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-streaming', action='store_true', help='skip the 17 x 1 048 576 HBM-streaming roofline entry of the headline')
+    ap.add_argument('--launch-timeout', type=float, default=None, help='seconds after which self-spawned ranks are terminated')
+    args = ap.parse_args(argv)
+    heavy = args.config in ('C3', 'C5')
+    if args.steps is None:
+        args.steps = {'C3': 300, 'C5': 200}.get(args.config, 5000)
+    if args.warmup is None:
+        args.warmup = 30 if heavy else 300
+    return args
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU
+        from citylearn_amd.parallel import launch_ranks
+        rc, out0 = launch_ranks([sys.executable, str(Path(__file__).resolve())] + list(sys.argv[1:] if argv is None else argv), args.gpus,
+                                timeout=args.launch_timeout)
+        lines = [ln for ln in out0.splitlines() if ln.startswith('{')]
+        for ln in out0.splitlines():
+            if not ln.startswith('{'):
+                print(ln, file=sys.stderr)              # anything else rank 0 wrote to stdout: keep stdout to the one JSON line
+        if lines:
+            print(lines[-1])
+        elif rc == 0:
+            rc = 1
+            print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
+        raise SystemExit(rc)
+    run_rank(args)
 
 
 if __name__ == '__main__':

@@ -37,7 +37,8 @@ class Tuning(ctypes.Structure):
     _fields_ = [('vec', ctypes.c_int32), ('nw', ctypes.c_int32), ('no_chunks', ctypes.c_int32), ('lean_variant', ctypes.c_int32),
                 ('envmajor', ctypes.c_int32), ('flex_vec', ctypes.c_int32), ('obs_variant', ctypes.c_int32),
                 ('obs_rows', ctypes.c_int32), ('lstm_variant', ctypes.c_int32), ('full_variant', ctypes.c_int32),
-                ('b_chunk', ctypes.c_int32), ('nt_stores', ctypes.c_int32), ('reserved', ctypes.c_int32 * 4)]
+                ('b_chunk', ctypes.c_int32), ('nt_stores', ctypes.c_int32), ('kernel_name', ctypes.c_void_p),
+                ('reserved', ctypes.c_int32 * 2)]
 
 
 class Dims(ctypes.Structure):

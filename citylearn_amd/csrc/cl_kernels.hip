@@ -975,6 +975,9 @@ int check_dims(const cl_dims* d) {
     if (reinterpret_cast<uintptr_t>(d->env_row0) & 3) return fail(CL_EALIGN, "env_row0 is not 4-byte aligned");
     const uint32_t rk = (d->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     if (rk > CLR_EV) return fail(CL_EINVAL, "unknown reward kind %u", rk);
+    // the Philox counter word of the random streams is env_offset + env (32 bits): shards must not alias
+    if (d->env_offset < 0 || d->env_offset + (int64_t)d->n_env > (int64_t)1 << 32)
+        return fail(CL_ERANGE, "env_offset=%lld with n_env=%d leaves the 32-bit env index of the random streams", (long long)d->env_offset, d->n_env);
     return CL_OK;
 }
 
@@ -1010,10 +1013,23 @@ int pick_vec(int n_env, int n_bldg, bool unit_stride) {
 const cl_tuning k_default_tuning = {};
 // launch K<..., NT> with NT = a.nt (expects grid, block, lds, s, a in scope)
 #define CL_LAUNCH_NT(K, ...) do { \
+    name_add(tun, #K "<" #__VA_ARGS__ ", %s>", a.nt ? "true" : "false"); \
     if (a.nt) hipLaunchKernelGGL((K<__VA_ARGS__, true>), grid, block, lds, s, a); \
     else hipLaunchKernelGGL((K<__VA_ARGS__, false>), grid, block, lds, s, a); } while (0)
 
 const cl_tuning& tuning_of(const cl_dims* d) { return d->tuning ? *d->tuning : k_default_tuning; }
+
+// cl_tuning.kernel_name (diagnostics): the instantiations a call launched, '+'-separated, spelled as rocprofv3 prints them
+void name_reset(const cl_tuning& tun) { if (tun.kernel_name) tun.kernel_name[0] = 0; }
+void name_add(const cl_tuning& tun, const char* fmt, ...) {
+    if (!tun.kernel_name) return;
+    size_t n = strnlen(tun.kernel_name, CL_KERNEL_NAME_LEN - 1);
+    if (n && n + 2 < CL_KERNEL_NAME_LEN) { tun.kernel_name[n++] = '+'; tun.kernel_name[n] = 0; }
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tun.kernel_name + n, CL_KERNEL_NAME_LEN - n, fmt, ap);
+    va_end(ap);
+}
 
 }  // namespace
 
@@ -1120,6 +1136,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
                      float* kpi_env, const cl_flex* flex, int32_t t, void* stream, const ObsFusedArgs* of, bool* fused) {
     if (int rc = check_dims(dims)) return rc;
     const cl_tuning& tun = tuning_of(dims);
+    name_reset(tun);
     if (int rc = check_ptr(params, "params")) return rc;
     if (int rc = check_ptr(ts, "ts")) return rc;
     if (int rc = check_ptr(state, "state")) return rc;
@@ -1168,6 +1185,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (tun.flex_vec) fvec = tun.flex_vec;
         const dim3 fgrid((unsigned)((dims->n_env + 64 * fvec - 1) / (64 * fvec)), gy);
 #define CL_FLEX_LAUNCH(V) do { \
+            name_add(tun, "cl_flex_kernel<" #V ", %s>", a.nt ? "true" : "false"); \
             if (a.nt) hipLaunchKernelGGL((cl_flex_kernel<V, true>), fgrid, dim3(256), 0, (hipStream_t)stream, fa); \
             else hipLaunchKernelGGL((cl_flex_kernel<V, false>), fgrid, dim3(256), 0, (hipStream_t)stream, fa); } while (0)
         switch (fvec) {
@@ -1241,7 +1259,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     const unsigned tp_grid = (unsigned)((dims->n_env + tp_tiles * 64 * tp_vec - 1) / (tp_tiles * 64 * tp_vec));
     const size_t tp_lds = ((size_t)tp_tiles * dims->n_bldg * NQ + tp_tiles) * 64 * tp_vec * sizeof(float);
     bool tp_kernel = full && !flex && !(dims->flags & CLD_WRITE_DETAIL) && a.n_chunks == 1 && dims->n_bldg <= 32 && tp_lds <= 150 * 1024 &&
-                     (!dims->env_row0 || tp_tiles * 64 * tp_vec <= CL_ROW0_BLOCK);          // one episode offset per workgroup
+                     (!dims->env_row0 || CL_ROW0_BLOCK % (tp_tiles * 64 * tp_vec) == 0);    // one episode offset per workgroup: no workgroup straddles two blocks
     if (tp_forced) {
         if (!tp_kernel || tp_nw > 16)
             return fail(CL_EINVAL, "full_variant = 5: %d tiles x %d envs per lane x %d waves is not a launch of cl_step_full_tp_kernel for this district", tp_tiles, tp_vec, tp_nw);
@@ -1251,6 +1269,11 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // streaming KPIs without the detail planes: the lean kernel updates the per-building accumulators itself, at any grid size
     const bool kpi_lean = (dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL);
     const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 352 || (tun.lean_variant & 2) || kpi_lean) && !((tun.lean_variant & 1) && !kpi_lean);
+    // without the detail planes only cl_step_lean_kpi_kernel updates the per-building accumulators (and writes the baseline plane
+    // cl_kpi_env_kernel sums): a launch shape that cannot take it must not silently leave them stale
+    if (kpi_lean && (full || flex || !lean_shape))
+        return fail(CL_EINVAL, "CLD_KPI without CLD_WRITE_DETAIL needs the lean step launch (n_bldg=%d <= 2 x nw=%d waves, no chunks): "
+                               "drop the cl_tuning override or set CLD_WRITE_DETAIL", dims->n_bldg, a.nw);
     if (flex && !full && lean_shape) {
         switch (vec) {
         case 1: CL_LAUNCH_NT(cl_step_lean_kernel, 1, true); break;
@@ -1263,6 +1286,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (vec > 2) return fail(CL_EINVAL, "bad vec %d for the flexible-load step", vec);
         const dim3& grid_f = grid;
         const size_t lds_f = lds;
+        name_add(tun, "cl_step_kernel<%d, %s, %s, true>", vec, full ? "true" : "false", full && det ? "true" : "false");
         if (full && det) {
             if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, true, true, true>), grid_f, block, lds_f, s, a);
             else hipLaunchKernelGGL((cl_step_kernel<2, true, true, true>), grid_f, block, lds_f, s, a);
@@ -1278,6 +1302,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         a.nw = tp_nw;
         const dim3 g2(tp_grid), b2(64 * a.nw);
         const size_t l2 = tp_lds;
+        name_add(tun, "cl_step_full_tp_kernel<%d, 4, %s>", tp_vec, a.nt ? "true" : "false");
         if (tp_vec == 2) {
             if (a.nt) hipLaunchKernelGGL((cl_step_full_tp_kernel<2, 4, true>), g2, b2, l2, s, a, tp_tiles);
             else hipLaunchKernelGGL((cl_step_full_tp_kernel<2, 4, false>), g2, b2, l2, s, a, tp_tiles);
@@ -1307,12 +1332,14 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 5, false);
         }
     } else if (full && det) {
+        name_add(tun, "cl_step_kernel<%d, true, true, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, true>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, true>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else if (full) {
+        name_add(tun, "cl_step_kernel<%d, true, false, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, false>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, false>), grid, block, lds, s, a); break;
@@ -1324,6 +1351,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // 17 x 262 144 28.2 vs 32.5 us, 17 x 1 048 576 136 vs 157 us; at 17 x 65 536 -- one wave per SIMD, nothing to hide the
         // per-building dependency chain behind -- 13.1 vs 8.0 us)
         const dim3 egrid((unsigned)((dims->n_env + 255) / 256));
+        name_add(tun, "cl_step_envmajor_kernel<20, %s>", a.nt ? "true" : "false");
         if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<20, true>), egrid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((cl_step_envmajor_kernel<20, false>), egrid, dim3(256), 0, s, a);
     } else if (lean_shape) {
@@ -1331,6 +1359,8 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // workgroups per CU) wins again -- 17 x 262 144: 30.8 us vs 33.0 us
         switch (vec) {                                   // latency-ordered lean kernel (two buildings per wave at most)
 #define CL_LEAN_CASE(V) case V: \
+            name_add(tun, "%s<" #V ", %s%s>", kpi_lean ? "cl_step_lean_kpi_kernel" : (of && rkind_host != CLR_MARL) ? "cl_step_lean_obs_kernel" : "cl_step_lean_kernel", \
+                     kpi_lean || (of && rkind_host != CLR_MARL) ? "" : "false, ", a.nt ? "true" : "false"); \
             if (kpi_lean) { \
                 if (a.nt) hipLaunchKernelGGL((cl_step_lean_kpi_kernel<V, true>), grid, block, lds, s, a); \
                 else hipLaunchKernelGGL((cl_step_lean_kpi_kernel<V, false>), grid, block, lds, s, a); \
@@ -1347,6 +1377,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else {
+        name_add(tun, "cl_step_kernel<%d, false, false, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, false, false>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, false, false>), grid, block, lds, s, a); break;
@@ -1355,14 +1386,17 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         }
     }
     if (a.n_chunks > 1) {
+        name_add(tun, "cl_finish_kernel");
         hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, s, a);
         if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL) {
             const long long n = (long long)dims->n_env * dims->n_bldg;
+            name_add(tun, "cl_marl_reward_kernel");
             hipLaunchKernelGGL(cl_marl_reward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
         }
     }
     if (dims->flags & CLD_KPI) {
         const long long n = (long long)dims->n_env * dims->n_bldg;
+        name_add(tun, (dims->flags & CLD_WRITE_DETAIL) ? "cl_kpi_bldg_kernel+cl_kpi_env_kernel" : "cl_kpi_env_kernel");
         if (dims->flags & CLD_WRITE_DETAIL) hipLaunchKernelGGL(cl_kpi_bldg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
         hipLaunchKernelGGL(cl_kpi_env_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
     }
@@ -1502,7 +1536,10 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     const int key = (full ? 100 : 0) + vec * 10 + mb;
     if (key != 11 && key != 12 && key != 21 && key != 22 && key != 111)
         return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
-    const int rc = cl_tu_launch_rollout(key, (long long)grid * a.nw > 5 * 1024, grid, block.x, lds, stream, &r);
+    const bool pin = (long long)grid * a.nw > 5 * 1024;
+    name_reset(tun);
+    name_add(tun, "cl_rollout_kernel<%d, %s, %d, %s>", vec, full ? "true" : "false", mb, (key == 12 && !pin) ? "false" : "true");
+    const int rc = cl_tu_launch_rollout(key, pin, grid, block.x, lds, stream, &r);
     if (rc) return hip_fail((hipError_t)rc, "cl_rollout_kernel launch");
     return CL_OK;
 }
@@ -1544,7 +1581,9 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
     a.lstm_wb = lstm_wb;
     if (int rc = check_ptr(lstm_wb, "lstm_wb", false)) return rc;
     const bool f16 = dims->flags & CLD_LSTM_F16;
-#define CL_LSTM_LAUNCH(DBG, SPLIT) hipLaunchKernelGGL((cl_lstm_kernel<DBG, SPLIT>), grid, dim3(256), 0, (hipStream_t)stream, a)
+    name_reset(tun);
+#define CL_LSTM_LAUNCH(DBG, SPLIT) do { name_add(tun, "cl_lstm_kernel<" #DBG ", " #SPLIT ">"); \
+    hipLaunchKernelGGL((cl_lstm_kernel<DBG, SPLIT>), grid, dim3(256), 0, (hipStream_t)stream, a); } while (0)
 #define CL_LSTM_LAUNCH_WB(DBG) do { if (f16) CL_LSTM_LAUNCH(DBG, 2); else CL_LSTM_LAUNCH(DBG, 1); } while (0)
     switch (tun.lstm_variant) {            // timing experiments (scripts/lstm_check.py); 0 in production
     case 1: CL_LSTM_LAUNCH(1, 0); break;

@@ -283,6 +283,8 @@ class LSTMStage:
                                                   None if self.kpi_comfort is None else self.kpi_comfort.data_ptr(), self._stream()))
             if self.generic is not None:
                 self.generic['hidden'].zero_()
+            self.indoor_temp.zero_()            # handed out by the 'planes' observation of reset()
+            self.comfort.zero_()
 
     def step(self, t: int, cool_dem: Optional[torch.Tensor] = None, heat_dem: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t.

@@ -66,6 +66,8 @@ class StepEngine:
             raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
         if n_env % 4:
             raise ValueError('n_env must be a multiple of 4 (pad the batch)')
+        if env_offset < 0 or env_offset + n_env > 2 ** 32:
+            raise ValueError(f'env_offset={env_offset} with n_env={n_env} leaves the 32-bit env index of the random streams')
         self.device = torch.device(device)
         self.n_env = int(n_env)
         self.n_bldg = int(tables.params.shape[0])
@@ -112,7 +114,7 @@ class StepEngine:
         # launch-geometry overrides of tests / tuning scripts travel with every call (`cl_dims.tuning`); all zero = defaults
         self.tuning = _lib.Tuning()
         for key, value in (tuning or {}).items():
-            if key not in dict(_lib.Tuning._fields_) or key == 'reserved':
+            if key not in dict(_lib.Tuning._fields_) or key in ('reserved', 'kernel_name'):
                 raise ValueError(f'unknown tuning field {key!r}')
             setattr(self.tuning, key, int(value))
         self.dims = _lib.Dims(self.n_env, self.n_bldg, self.n_steps, self.n_act_cols, flags, self.n_ts_rows,
@@ -181,6 +183,19 @@ class StepEngine:
         return raw[:, self._charger_slot]
 
     # ---------------------------------------------------------------------------------------------------
+    def trace_kernels(self, on: bool = True):
+        """Diagnostics (`cl_tuning.kernel_name`): have every step / rollout / LSTM call of this engine report which kernel
+        instantiation(s) it launched; read them back with :attr:`last_kernels`.  What `bench.py` prints as `roofline.kernel`."""
+        self._kernel_name = ctypes.create_string_buffer(abi.CL_KERNEL_NAME_LEN) if on else None
+        self.tuning.kernel_name = ctypes.cast(self._kernel_name, ctypes.c_void_p) if on else None
+
+    @property
+    def last_kernels(self) -> str:
+        """'+'-separated kernel instantiations of the last call, in rocprofv3's spelling (after `trace_kernels()`)."""
+        if getattr(self, '_kernel_name', None) is None:
+            raise RuntimeError('call trace_kernels() first')
+        return self._kernel_name.value.decode()
+
     def _stream(self) -> int:
         # raw handle of torch's current stream on this device (what torch.cuda.current_stream(...).cuda_stream returns, without
         # building the Stream object: this runs once per env step)
@@ -196,6 +211,10 @@ class StepEngine:
                                              self._stream()))
             if self.flex is not None:
                 _lib.check(self.lib.cl_flex_reset_f32(ctypes.byref(self.dims), ctypes.byref(self.flex), self._stream()))
+                self.flex_out.zero_()
+            # the output planes are what a 'planes' observation hands out: an episode must not start on the previous one's last step
+            self.out_bldg.zero_()
+            self.out_env.zero_()
         self.t = 0
 
     def step(self, actions: torch.Tensor, t: Optional[int] = None):

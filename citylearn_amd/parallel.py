@@ -1,9 +1,20 @@
 """Multi-GPU decomposition: the env batch is sharded contiguously across ranks (one process per GPU); buildings of
 an env never leave their GPU, so every district reduction is intra-workgroup and the step path needs no collective
-(SURVEY.md 8e).  The only cross-rank traffic is benchmark / logging scalars."""
+(SURVEY.md 8e).  The only cross-rank traffic is benchmark / logging scalars.
+
+Besides the shard arithmetic this module holds the plumbing `bench.py` uses to be started by a plain
+``python bench.py --gpus N`` (no ``torch.distributed.run``): `launch_ranks` starts one process per rank with the
+usual RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment, `init_control_plane` brings up the process group those
+ranks use for the barrier and the MAX-over-ranks of the timing -- RCCL (``nccl``) with one rank per GPU, ``gloo``
+when ranks share a device (RCCL refuses two ranks on one GPU; only the 1-GPU test hook does that) or on CPU."""
 from __future__ import annotations
 
-from typing import Tuple
+import os
+import socket
+import subprocess
+import sys
+import time
+from typing import List, Mapping, Optional, Sequence, Tuple
 
 
 def shard_envs(total_envs: int, rank: int, world: int, align: int = 4) -> Tuple[int, int]:
@@ -23,3 +34,116 @@ def reduce_max_seconds(seconds: float, dist=None, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def gather_seconds(seconds: float, dist=None, device=None) -> List[float]:
+    """The same measurement of every rank, in rank order (bench.py's per-rank `ms_per_step`)."""
+    if dist is None or not dist.is_initialized():
+        return [float(seconds)]
+    import torch
+    mine = torch.tensor([seconds], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t[0]) for t in out]
+
+
+def free_port() -> int:
+    """A TCP port nobody listens on right now (127.0.0.1), for the rendezvous of self-spawned ranks."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return int(s.getsockname()[1])
+
+
+def rank_environment(rank: int, world: int, port: int, base: Optional[Mapping[str, str]] = None) -> dict:
+    """Environment of rank `rank` of a one-node job: what ``torch.distributed.run --nnodes=1`` would set."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this driver
+    return env
+
+
+def launch_ranks(argv: Sequence[str], world: int, timeout: Optional[float] = None,
+                 extra_env: Optional[Mapping[str, str]] = None) -> Tuple[int, str]:
+    """Start `world` processes ``argv`` (one per rank; rank r gets RANK = LOCAL_RANK = r) and wait for them.
+
+    Rank 0's stdout is captured and returned; the other ranks' stdout goes to this process's stderr, every rank's stderr is
+    inherited.  Returns ``(exit code, rank 0's stdout)``: the first non-zero exit code of any rank (the remaining ranks are
+    then terminated -- by the PIDs started here, never by pattern), 124 after `timeout` seconds, else 0."""
+    if world < 1:
+        raise ValueError('world must be >= 1')
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = rank_environment(r, world, port)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None, text=True))
+    t0, rc = time.monotonic(), 0
+    out0 = ''
+    try:
+        # rank 0's pipe is drained by communicate(); a failing peer would leave rank 0 hanging in a collective, so the
+        # peers are polled while we wait
+        drained = False
+        while True:
+            if not drained:
+                try:
+                    out0, _ = procs[0].communicate(timeout=0.5)
+                    drained = True
+                except subprocess.TimeoutExpired:
+                    pass
+            else:
+                time.sleep(0.1)
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                rc = 124
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        if not drained:
+            try:
+                out0, _ = procs[0].communicate(timeout=10)      # (keeps what the timed-out calls above had already read)
+            except Exception:
+                pass
+    return rc, out0
+
+
+def init_control_plane(rank: int, world: int, device=None, backend: Optional[str] = None):
+    """Process group for the benchmark's barrier + timing reductions.  ``backend``: 'nccl' (RCCL over xGMI, one rank per GPU),
+    'gloo' (ranks sharing a device, or CPU); default: nccl when `device` is a GPU.  Returns ``torch.distributed``.
+
+    RCCL prints a version banner on STDOUT when the communicator comes up; stdout is parked on stderr meanwhile so that it
+    carries nothing but the caller's own output."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if backend is None:
+        backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.barrier()
+        if backend == 'nccl':
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    return dist

@@ -63,6 +63,8 @@ class VectorCityLearnEnv:
         self.env_episode_offsets = env_episode_offsets
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
         self.env_offset = int(env_offset)      # first env of this shard in the whole batch (multi-GPU: parallel.shard_envs(...)[0])
+        if self.env_offset < 0 or self.env_offset + self.n_envs > 2 ** 32:
+            raise ValueError(f'env_offset={env_offset} with n_envs={n_envs} leaves the 32-bit env index of the random streams')
         if env_episode_offsets is not None:
             if not isinstance(self.spec.episode_time_steps, int):
                 raise ValueError('env_episode_offsets needs an integer episode_time_steps (schema or kwarg)')
@@ -209,7 +211,9 @@ class VectorCityLearnEnv:
         obs_tables = self.layout.episode(self.tables, reset_table=row0 is not None) if self.layout is not None else None
         self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
                                  t0_quirk=self.reference_quirks, kpi=self.kpi, n_steps=n_steps, env_row0=row0,
-                                 detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail),
+                                 # (a batched reward plugin sees the reference's full reward-observation key set: detail planes on)
+                                 detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail)
+                                 or self._plugin is not None,
                                  ev_reward_weights=self._rf_attrs.get('weights'), ev_drift=self._ev_drift, central_agent=self.central_agent,
                                  ev_penalty_coefficient=self._rf_attrs.get('charging_constraint_penalty_coefficient') or 1.0,
                                  ev_seed=(self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode, env_offset=self.env_offset)

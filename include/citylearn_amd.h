@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 4   /* 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
+#define CL_ABI_VERSION 5   /* 5: cl_tuning.kernel_name, CLD_F64_MAPS; 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
 
 /* ---- error codes ---- */
 #define CL_OK            0
@@ -260,8 +260,13 @@ typedef struct cl_tuning {
                                the multi-tile kernel); 5 = the multi-tile kernel (vec = envs per lane, nw = waves, b_chunk = tiles per workgroup) */
     int32_t b_chunk;        /* building-chunked launches: buildings per workgroup row (with `nw` waves per workgroup) */
     int32_t nt_stores;      /* non-temporal hint on the step kernels' plane stores: 0 = by launch footprint, 1 = always, 2 = never */
-    int32_t reserved[4];
+    char* kernel_name;      /* nullable HOST buffer of CL_KERNEL_NAME_LEN bytes: cl_step_f32 / cl_step_flex_f32 / cl_step_observe_f32 /
+                               cl_rollout_f32 / cl_lstm_step_f32 write the instantiation(s) they launched into it, '+'-separated, in the
+                               spelling rocprofv3 prints (bench.py's `roofline.kernel`, scripts/profile_round.sh's name check).  Output only:
+                               nothing the library computes depends on it. */
+    int32_t reserved[2];
 } cl_tuning;
+#define CL_KERNEL_NAME_LEN 256
 
 typedef struct cl_dims {
     int32_t n_env;        /* envs in this shard (multiple of 4) */

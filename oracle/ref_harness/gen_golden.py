@@ -174,8 +174,11 @@ def _action_drawer(seed: int, low, high, action_names):
     return draw
 
 
-# the 2022_phase_all sample is shipped with the package (bench.py, smoke()); every other mini dataset stays next to its fixture
-PACKAGE_DATASETS = {'g2022_all': GOLDEN.parent.parent / 'citylearn_amd' / 'data' / 'citylearn_challenge_2022_phase_all_720h'}
+# three samples are shipped with the package (bench.py's configs, smoke()); every other mini dataset stays next to its fixture
+_PACKAGE_DATA = GOLDEN.parent.parent / 'citylearn_amd' / 'data'
+PACKAGE_DATASETS = {'g2022_all': _PACKAGE_DATA / 'citylearn_challenge_2022_phase_all_720h',
+                    'g2023_p2': _PACKAGE_DATA / 'citylearn_challenge_2023_phase_2_local_evaluation_720h',
+                    'g2020_cz1': _PACKAGE_DATA / 'citylearn_challenge_2020_climate_zone_1_744h'}
 
 
 def dataset_dir(name: str) -> Path:

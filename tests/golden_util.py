@@ -6,7 +6,10 @@ from pathlib import Path
 import numpy as np
 
 GOLDEN = Path(__file__).resolve().parent / 'golden'
-PACKAGE_DATA = {'g2022_all': GOLDEN.parent.parent / 'citylearn_amd' / 'data' / 'citylearn_challenge_2022_phase_all_720h'}
+_DATA = GOLDEN.parent.parent / 'citylearn_amd' / 'data'
+PACKAGE_DATA = {'g2022_all': _DATA / 'citylearn_challenge_2022_phase_all_720h',                  # bench.py's headline / C2 / C5 tables
+                'g2023_p2': _DATA / 'citylearn_challenge_2023_phase_2_local_evaluation_720h',    # bench.py --config C3
+                'g2020_cz1': _DATA / 'citylearn_challenge_2020_climate_zone_1_744h'}             # bench.py --config C4 (device set)
 FIXTURES = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2022_p1_year', 'g2020_15min')
 # dataset sweep: 95-step runs of the other dataset families (oracle/ref_harness/gen_golden.py)
 SWEEP = ('s_baeda', 's_2021', 's_2020_cz3', 's_2023_p1', 's_2023_p3', 's_autosize')
@@ -16,7 +19,7 @@ class Golden:
     def __init__(self, name: str):
         self.name = name
         self.dir = GOLDEN / name
-        # the 2022_phase_all sample ships with the package (bench.py / smoke() load it too); every other fixture keeps its own
+        # three samples ship with the package (bench.py / smoke() load them too); every other fixture keeps its own
         self.dataset_dir = self.dir / 'dataset' if (self.dir / 'dataset').exists() else PACKAGE_DATA[name]
         self.schema_path = str(self.dataset_dir / 'schema.json')
         self.ref = np.load(self.dir / 'reference.npz', allow_pickle=False)

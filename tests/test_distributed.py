@@ -109,3 +109,50 @@ def test_two_real_shards_tile_the_unsharded_district():
         out, _ = ora.step(acts[t], t)
     assert np.array_equal(tiled[0], ora.state[:, :, OS['SOC']].T)
     assert np.array_equal(tiled[1], out[:, :, OO['NET']].T) and np.array_equal(tiled[2], out[:, :, OO['REWARD']].T)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` without torch.distributed.run: the launcher, the rendezvous and the aggregation, on CPU
+# (CL_BENCH_DRY_RUN skips the GPU work only; tests/test_gpu_bench.py runs the real thing with two ranks on one GPU)
+def _bench(*argv, env=None, timeout=300):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / 'bench.py'), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_spawns_its_own_ranks():
+    """The driver's plain command: two ranks come up (gloo here), every rank is timed, the line carries the MAX over ranks, and
+    stdout holds nothing but the one JSON line."""
+    import json
+    p = _bench('--gpus', '2', '--steps', '20', '--warmup', '5', env={'CL_BENCH_DRY_RUN': '1'})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['world_size_seen'] == 2 and out['steps'] == 20 and out['warmup'] == 5
+    assert out['rank_ms_per_step'] == [1.0, 2.0] and out['ms_per_step'] == 2.0            # MAX over ranks
+    assert out['scaling'] == 'weak' and out['unit'] == 'building-timesteps/s'
+    one = json.loads(_bench('--steps', '20', '--warmup', '5', env={'CL_BENCH_DRY_RUN': '1'}).stdout)
+    assert out['value'] == one['value']          # twice the units in twice the (synthetic) time
+
+
+def test_bench_under_an_external_launcher_is_one_rank():
+    """With RANK / WORLD_SIZE in the environment (torch.distributed.run) bench.py must not spawn anything: WORLD_SIZE has to match --gpus."""
+    p = _bench('--gpus', '2', '--steps', '20', '--warmup', '5', env={'CL_BENCH_DRY_RUN': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '4',
+                                                                      'MASTER_PORT': '1'})
+    assert p.returncode != 0 and 'WORLD_SIZE=4' in p.stderr
+
+
+def test_launcher_propagates_a_failing_rank_and_stops_the_others():
+    import time
+    from citylearn_amd.parallel import launch_ranks
+    code = "import os, sys, time\nprint('hello from', os.environ['RANK'], flush=True)\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(120)"
+    t0 = time.monotonic()
+    rc, out0 = launch_ranks([sys.executable, '-c', code], 2)
+    assert rc == 3 and time.monotonic() - t0 < 60 and 'hello from 0' in out0
+    code = "import os\nassert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['MASTER_ADDR'] == '127.0.0.1'\nprint(os.environ['RANK'])"
+    rc, out0 = launch_ranks([sys.executable, '-c', code], 3)
+    assert rc == 0 and out0.strip() == '0'
+    rc, _ = launch_ranks([sys.executable, '-c', 'import time; time.sleep(120)'], 2, timeout=2)
+    assert rc == 124

@@ -1,0 +1,54 @@
+"""bench.py on the GPU box: the multi-rank path as far as one GPU allows (two ranks sharing device 0 through the
+CL_BENCH_OVERSUBSCRIBE hook), and one short line per BASELINE config."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*argv, env=None, timeout=900):
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_gpu_without_a_launcher():
+    """`python bench.py --gpus 2` (no torchrun) starts its own ranks; with the hook both land on device 0.  The N = 1 kernel time
+    must be what one rank of the pair sees when it has the GPU to itself (the launches of two processes interleave on one GPU, so
+    only the plumbing is asserted on the pair: ranks, world size, per-rank timings, one line)."""
+    two = _bench('--gpus', '2', '--steps', '20', '--warmup', '5', '--reps', '3', '--no-streaming', env={'CL_BENCH_OVERSUBSCRIBE': '1'})
+    assert two['ranks'] == 2 and two['world_size_seen'] == 2 and two['oversubscribed'] is True and two['n_gpus'] == 1
+    assert len(two['rank_ms_per_step']) == 2 and two['control_backend'] == 'gloo'
+    assert two['ms_per_step'] >= max(two['rank_ms_per_step']) * 0.5 and two['value'] > 1e9
+    assert 'cl_step_lean_kernel<4, false, true>' in two['roofline']['kernel']
+    one = _bench('--steps', '20', '--warmup', '5', '--reps', '3', '--no-streaming', '--no-cpu-baseline')
+    assert one['ranks'] == 1 and one['n_gpus'] == 1 and 'oversubscribed' not in one
+    assert one['roofline']['kernel'] == 'cl_step_lean_kernel<4, false, true>' and 0.3 < one['roofline']['frac'] < 1.0
+    assert one['value'] == pytest.approx(17 * 65536 / (one['ms_per_step'] * 1e-3))
+
+
+def test_more_ranks_than_gpus_is_refused_without_the_hook():
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'CL_BENCH_OVERSUBSCRIBE')}
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--gpus', str(n), '--steps', '5', '--warmup', '2'], env=e, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode != 0 and 'CL_BENCH_OVERSUBSCRIBE' in p.stderr and not p.stdout.strip()
+
+
+@pytest.mark.parametrize('cfg,kernel,bound', [('C2', 'cl_step_lean_kernel<1, false, true>', 'hbm'), ('C3', 'cl_lstm_kernel<', 'valu'),
+                                              ('C4', 'cl_step_full_kernel<2, false, 1024, 4, true, true>', 'hbm'), ('C5', 'cl_rollout_kernel<2, false, 2, true>', 'valu')])
+def test_config_lines(cfg, kernel, bound):
+    out = _bench('--config', cfg, '--steps', '20', '--warmup', '5', '--reps', '2')
+    assert out['config']['name'] == cfg and out['roofline']['bound'] == bound and kernel in out['roofline']['kernel'], out['roofline']['kernel']
+    assert 0.0 < out['roofline']['frac'] < 1.0 and out['value'] > 1e8
