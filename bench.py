@@ -59,13 +59,33 @@ CONFIGS = ('headline', 'C2', 'C3', 'C4', 'C4-lean', 'C5')
 
 
 # --------------------------------------------------------------------------------------------------- CPU baseline
+def usable_cores() -> int:
+    """Host cores this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one (a box that shows 256
+    logical CPUs but grants a few through cpu.max throttles 256 spinning OpenMP threads to a crawl: 116 ms per oracle step)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = Path('/sys/fs/cgroup/cpu.max').read_text().split()[:2]                     # cgroup v2
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(Path('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read_text())                  # cgroup v1
+            period = int(Path('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read_text())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(spec, tables, seconds: float = 10.0) -> dict:
     """Time oracle/cl_oracle.c (double-precision port of the reference arithmetic, OpenMP over envs) on a bounded sample of the
-    headline workload: all host cores, then ONE core (the "fair CPU" line of SURVEY 8d)."""
+    headline workload: the host's usable cores (thread count picked by a short probe among usable, 64, 16: the one that is
+    fastest on this box), then ONE core (the "fair CPU" line of SURVEY 8d)."""
     import ctypes
     import numpy as np
     from oracle.c_oracle import COracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))
     omp = ctypes.CDLL('libgomp.so.1')
 
@@ -74,19 +94,23 @@ def cpu_baseline(spec, tables, seconds: float = 10.0) -> dict:
         ora = COracle(spec, tables, E)
         rng = np.random.RandomState(0)
         acts = [rng.uniform(-1, 1, size=(ora.n_act_cols, E)).astype(np.float32) for _ in range(4)]
-        for t in range(3):
+        for t in range(8):                                  # thread pool start-up, first touch
             ora.step(acts[t % 4], t)
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < budget:
-            for _ in range(10):
+            for _ in range(5):
                 ora.step(acts[n % 4], 1 + n % (ora.T - 2))
                 n += 1
         dt = time.perf_counter() - t0
         return E * ora.B * n / dt, f'oracle/cl_oracle.c (OpenMP, {threads} thread{"s" if threads > 1 else ""}): 17 buildings x {E} envs x {n} steps in {dt:.1f} s'
 
-    v, sample = run(cores, 4096, seconds)
+    E = 16384
+    probe = {th: run(th, E, 1.0)[0] for th in sorted({cores, *(c for c in (64, 16) if c < cores)})}
+    threads = max(probe, key=probe.get)
+    v, sample = run(threads, E, seconds)
     v1, sample1 = run(1, 256, seconds / 2)
-    out = {'value': v, 'unit': 'building-timesteps/s', 'cores': cores, 'kind': 'port', 'sample': sample,
+    out = {'value': v, 'unit': 'building-timesteps/s', 'cores': threads, 'kind': 'port', 'sample': sample,
+           'host': {'logical_cpus': os.cpu_count(), 'usable_cores': cores, 'thread_probe': {str(k): p for k, p in probe.items()}},
            'one_core': {'value': v1, 'unit': 'building-timesteps/s', 'cores': 1, 'kind': 'port', 'sample': sample1}}
     ref = ROOT / 'profiles' / 'reference_cpu_timing.json'
     if ref.exists():
