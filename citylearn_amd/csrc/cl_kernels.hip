@@ -248,7 +248,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
 
 // FLEX: the district has EV chargers / washing machines (cl_flex.h ran just before); a separate instantiation so that
 // districts without them keep their register budget.
-template <int VEC, bool FULL, bool DETAIL, bool FLEX = false>
+template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, bool F64 = false>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
@@ -279,12 +279,17 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
         if (live) {
             const long long off = (long long)b * a.n_env + env0;
             float s_soc[VEC], s_eff[VEC], s_deg[VEC], s_cs[VEC], s_hs[VEC], s_ds[VEC];
+            [[maybe_unused]] float s_efl[VEC], s_dgl[VEC];                 // CLD_F64_MAPS: low words of efficiency / degraded capacity
             float a_cs[VEC], a_hs[VEC], a_ds[VEC], a_es[VEC], a_cd[VEC], a_hd[VEC];
             const bool batt = B.flags & CLF_BATTERY;
             if (batt) {
                 vload<VEC>(s_soc, a.state + CLS_B_SOC * plane + off);
                 vload<VEC>(s_eff, a.state + CLS_B_EFF * plane + off);
                 vload<VEC>(s_deg, a.state + CLS_B_DEGCAP * plane + off);
+                if constexpr (F64) {
+                    vload<VEC>(s_efl, a.state + CLS_B_EFF_LO * plane + off);
+                    vload<VEC>(s_dgl, a.state + CLS_B_DEGCAP_LO * plane + off);
+                }
             }
             load_action<VEC>(a_es, a, B.a_es, env0);
             if constexpr (FULL) {
@@ -322,6 +327,8 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 cl::State S;
                 S.soc = batt ? s_soc[i] : 0.0f; S.eff = batt ? s_eff[i] : 1.0f; S.degcap = batt ? s_deg[i] : 0.0f;
                 S.cs = S.hs = S.ds = 0.0f;
+                S.eff_lo = S.deg_lo = 0.0f;
+                if constexpr (F64) { S.eff_lo = batt ? s_efl[i] : 0.0f; S.deg_lo = batt ? s_dgl[i] : 0.0f; }
                 cl::Act act = {0.0f, 0.0f, 0.0f, a_es[i], 0.0f, 0.0f};
                 if constexpr (FULL) {
                     S.cs = (B.flags & CLF_COOL_STO) ? s_cs[i] : 0.0f;
@@ -330,10 +337,11 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                     act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
                 }
                 cl::Out O;
-                cl::unit_step<FULL>(B, R, a.t, quirk, act, S, O);
+                cl::unit_step<FULL, F64>(B, R, a.t, quirk, act, S, O);
                 if (FLEX && fbi >= 0) cl::apply_flex(R.outage, R.price, R.carbon, x_load[i], x_chg[i], O);
                 const float rw = cl::unit_reward<FULL>(rkind, B, S, O.net);
                 s_soc[i] = S.soc; s_eff[i] = S.eff; s_deg[i] = S.degcap; s_cs[i] = S.cs; s_hs[i] = S.hs; s_ds[i] = S.ds;
+                if constexpr (F64) { s_efl[i] = S.eff_lo; s_dgl[i] = S.deg_lo; }
                 o_net[i] = O.net; o_rw[i] = rw; o_eb[i] = O.eb; o_cd[i] = O.cool_dem; o_hd[i] = O.heat_dem; o_dd[i] = O.dhw_dem;
                 o_cc[i] = O.c_cool; o_ch[i] = O.c_heat; o_cw[i] = O.c_dhw; o_cn[i] = O.c_ns;
                 o_bn[i] = O.base_net; o_ex[i] = O.expected; o_sv[i] = O.served; o_ws[i] = O.net_ws;
@@ -348,6 +356,10 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                     pstore<VEC, NT>(a.state + CLS_B_SOC * plane + off, s_soc);
                     pstore<VEC, NT>(a.state + CLS_B_EFF * plane + off, s_eff);
                     pstore<VEC, NT>(a.state + CLS_B_DEGCAP * plane + off, s_deg);
+                    if constexpr (F64) {
+                        pstore<VEC, NT>(a.state + CLS_B_EFF_LO * plane + off, s_efl);
+                        pstore<VEC, NT>(a.state + CLS_B_DEGCAP_LO * plane + off, s_dgl);
+                    }
                 }
                 if constexpr (FULL) {
                     if (B.flags & CLF_COOL_STO) pstore<VEC, NT>(a.state + CLS_CS_SOC * plane + off, s_cs);
@@ -412,7 +424,7 @@ struct ObsFusedArgs {
     cl_obs_dep deps[CLOB_MAX_DEPS];     // grouped by building
 };
 
-template <int VEC, bool FLEX, bool NT, bool OBS, bool KPI = false>
+template <int VEC, bool FLEX, bool NT, bool OBS, bool KPI = false, bool F64 = false>
 CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of) {     // lds: [nw][NQ][64*VEC] (, then [64*VEC][pitch])
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
@@ -431,6 +443,7 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
 #pragma unroll
     for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
     float s_soc[2][VEC], s_eff[2][VEC], s_deg[2][VEC], a_es[2][VEC];
+    [[maybe_unused]] float s_efl[2][VEC], s_dgl[2][VEC];             // CLD_F64_MAPS: low words of efficiency / degraded capacity
     CL_TRACE_DECL;
     CL_TRACE_ENTRY(0);
     CL_TRACE_CYCLES_ENTRY(4);
@@ -442,6 +455,10 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             pload<VEC, NT>(s_soc[m], a.state + CLS_B_SOC * plane + off);
             pload<VEC, NT>(s_eff[m], a.state + CLS_B_EFF * plane + off);
             pload<VEC, NT>(s_deg[m], a.state + CLS_B_DEGCAP * plane + off);
+            if constexpr (F64) {
+                pload<VEC, NT>(s_efl[m], a.state + CLS_B_EFF_LO * plane + off);
+                pload<VEC, NT>(s_dgl[m], a.state + CLS_B_DEGCAP_LO * plane + off);
+            }
             if (act_by_bldg) pload<VEC, NT>(a_es[m], a.actions + (long long)bb[m] * a.act_stride_col + env0);
         }
     }
@@ -506,7 +523,26 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             const float cbk = first ? 2.0f : 1.0f;               // c_b = first ? 2 eb : eb
             CL_PIN_V(c_ns); CL_PIN_V(sol);
             float soc_rw[VEC];
-            if (batt) {
+            if (F64 && batt) {
+                // the battery map in float64 on the unrounded parameters (CLD_F64_MAPS, cl_unit.h)
+                if constexpr (F64) {
+                    cl::BattP64 B64;
+                    cl::load_batt64(B64, B.p);
+                    if (B.a_es < 0) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) a_es[m][i] = 0.0f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        cl::State S = {s_soc[m][i], s_eff[m][i], s_deg[m][i], 0.0f, 0.0f, 0.0f, s_efl[m][i], s_dgl[m][i]};
+                        const float eb = cl::battery_charge_ref(B64, (double)a_es[m][i] * B64.pow * B64.dt / B64.r, a.t == 0, S);     // (flexibility = +inf)
+                        s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap; s_efl[m][i] = S.eff_lo; s_dgl[m][i] = S.deg_lo;
+                        soc_rw[i] = S.soc;
+                        o_cb[i] = cbk * eb;
+                        o_net[i] = fmaf(c_ns + o_cb[i], B.r, sol);
+                    }
+                }
+            } else if (batt) {
                 cl::BattP Bv = B.batt;
                 CL_PIN_V(Bv.cpc_a0); CL_PIN_V(Bv.cpc_b0); CL_PIN_V(Bv.cpc_a1); CL_PIN_V(Bv.cpc_b1);
                 CL_PIN_V(Bv.pec_a0); CL_PIN_V(Bv.pec_b0); CL_PIN_V(Bv.pec_a1); CL_PIN_V(Bv.pec_b1);
@@ -541,6 +577,10 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             pstore<VEC, NT>(a.state + CLS_B_SOC * plane + off, s_soc[m]);
             pstore<VEC, NT>(a.state + CLS_B_EFF * plane + off, s_eff[m]);
             pstore<VEC, NT>(a.state + CLS_B_DEGCAP * plane + off, s_deg[m]);
+            if constexpr (F64) {
+                pstore<VEC, NT>(a.state + CLS_B_EFF_LO * plane + off, s_efl[m]);
+                pstore<VEC, NT>(a.state + CLS_B_DEGCAP_LO * plane + off, s_dgl[m]);
+            }
         }
         pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
         if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
@@ -637,6 +677,13 @@ template <int VEC, bool FLEX, bool NT>
 __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     lean_step_body<VEC, FLEX, NT, false>(a, lds, nullptr);
+}
+
+// CLD_F64_MAPS: the lean step with the battery map in the reference's precision model (cl::battery_charge_ref) -- same launch shape, two more state planes
+template <int VEC, bool NT>
+__global__ void __launch_bounds__(1024) cl_step_lean_f64_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lean_step_body<VEC, false, NT, false, false, true>(a, lds, nullptr);
 }
 
 template <int VEC, bool NT>
@@ -887,6 +934,10 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
             state[CLS_CS_SOC * plane + i] = __uint_as_float(p[CLP_CS_SOC0]);
             state[CLS_HS_SOC * plane + i] = __uint_as_float(p[CLP_HS_SOC0]);
             state[CLS_DS_SOC * plane + i] = __uint_as_float(p[CLP_DS_SOC0]);
+            // CLD_F64_MAPS: what the float32 planes above lose of the two float64 start values (Battery.reset, energy_model.py:1237-1242)
+            const double eff0 = cl::pd(p, CLPD_EFF0), cap0 = cl::pd(p, CLPD_CAP);
+            state[CLS_B_EFF_LO * plane + i] = (float)(eff0 - (double)__uint_as_float(p[CLP_L_EFF0]));
+            state[CLS_B_DEGCAP_LO * plane + i] = (float)(cap0 - (double)__uint_as_float(p[CLP_L_CAP]));
         }
         if (kpi_bldg)
             for (int k = 0; k < CL_NKB; ++k) kpi_bldg[k * plane + i] = 0.0f;
@@ -1208,6 +1259,13 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         vec = full ? (units >= (1ll << 19) && dims->n_env >= 256 ? 2 : 1) : (units >= (1ll << 19) && dims->n_env >= 512 ? 4 : 1);
     }
     if (tun.vec) vec = tun.vec;
+    // CLD_F64_MAPS: the battery map in float64 -- general and lean step kernels at one or two envs per lane (a double is two VGPRs)
+    const bool f64 = dims->flags & CLD_F64_MAPS;
+    if (f64) {
+        if (flex) return fail(CL_EINVAL, "CLD_F64_MAPS is not implemented for districts with flexible loads (the EV batteries of cl_flex_kernel are fp32)");
+        if ((dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL)) return fail(CL_EINVAL, "CLD_F64_MAPS with CLD_KPI needs CLD_WRITE_DETAIL");
+        vec = full ? 1 : (vec > 2 ? 2 : vec);          // (the thermal unit with a float64 battery spills at two envs per lane)
+    }
     if (flex && vec > 2 && !(!full && dims->n_bldg <= 2 * a.nw && !will_chunk && (dims->n_env + 64 * vec - 1) / (64 * vec) <= 256 && !(tun.lean_variant & 1)))
         vec = 2;                             // general-kernel FLEX instantiations exist for 1 and 2 envs per lane
     const int tile = 64 * vec;
@@ -1236,7 +1294,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // thermal kernel with the parameter blocks of the workgroup's buildings staged in LDS
     // (for the building-chunked launches only -- a workgroup of the 9 x 65 536 launch would wait for the staging round trip before it
     //  can issue its plane loads, while its scalar reads hit the constant cache: 10.7 vs 8.7 us; full_variant = 2 forces it, 3 forbids it)
-    const bool lp = full && !flex && !det && tun.full_variant != 1 && tun.full_variant != 3 && vec <= 2 && (a.n_chunks > 1 || tun.full_variant == 2);
+    const bool lp = full && !flex && !det && !f64 && tun.full_variant != 1 && tun.full_variant != 3 && vec <= 2 && (a.n_chunks > 1 || tun.full_variant == 2);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float) + (lp ? (size_t)a.b_chunk * CL_LP_WORDS * sizeof(uint32_t) : 0);
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
@@ -1274,7 +1332,17 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (kpi_lean && (full || flex || !lean_shape))
         return fail(CL_EINVAL, "CLD_KPI without CLD_WRITE_DETAIL needs the lean step launch (n_bldg=%d <= 2 x nw=%d waves, no chunks): "
                                "drop the cl_tuning override or set CLD_WRITE_DETAIL", dims->n_bldg, a.nw);
-    if (flex && !full && lean_shape) {
+    if (f64) {
+        if (!full && lean_shape) {
+            if (vec == 1) CL_LAUNCH_NT(cl_step_lean_f64_kernel, 1); else CL_LAUNCH_NT(cl_step_lean_f64_kernel, 2);
+        } else {
+            name_add(tun, "cl_step_kernel<%d, %s, %s, false, true>", vec, full ? "true" : "false", full && det ? "true" : "false");
+            if (full && det) hipLaunchKernelGGL((cl_step_kernel<1, true, true, false, true>), grid, block, lds, s, a);
+            else if (full) hipLaunchKernelGGL((cl_step_kernel<1, true, false, false, true>), grid, block, lds, s, a);
+            else if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((cl_step_kernel<2, false, false, false, true>), grid, block, lds, s, a);
+        }
+    } else if (flex && !full && lean_shape) {
         switch (vec) {
         case 1: CL_LAUNCH_NT(cl_step_lean_kernel, 1, true); break;
         case 2: CL_LAUNCH_NT(cl_step_lean_kernel, 2, true); break;
@@ -1502,6 +1570,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_EV)
         return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_rollout_seq_f32)");
     if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "the fused rollout keeps no streaming KPIs: use cl_rollout_seq_f32 with CLD_KPI");
+    if (dims->flags & CLD_F64_MAPS) return fail(CL_EINVAL, "the fused rollout evaluates the battery map in fp32: use cl_rollout_seq_f32 with CLD_F64_MAPS");
     if (k_steps < 0 || t0 < 0 || t0 + k_steps > dims->n_steps)
         return fail(CL_ERANGE, "steps [%d, %d) outside [0, %d)", t0, t0 + k_steps, dims->n_steps);
     if (dims->n_bldg > 32) return fail(CL_EINVAL, "the fused rollout supports n_bldg <= 32 (got %d): use cl_rollout_seq_f32", dims->n_bldg);

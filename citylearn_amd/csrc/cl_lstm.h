@@ -157,7 +157,8 @@ CL_DEV void lstm_act(const f32x16& d0, const f32x16& d1, float (&c)[8], float (&
         return;
     }
     if constexpr (DBG & 32) {
-        // Experiment (lstm_variant 32, not measured yet): 7 instead of 10 transcendentals per unit and cell through common denominators,
+        // lstm_variant 32 (what LSTMStage selects where dynamics.cell_update_bounds proves the bound; 117.9 -> 108.3 us at 3 x 65 536,
+        // profiles/r03a_lstm_check_variant32.log): 7 instead of 10 transcendentals per unit and cell through common denominators,
         //   c' = [c (1 + e_i)(1 + e_g) + (1 - e_g)(1 + e_f)] / [(1 + e_f)(1 + e_i)(1 + e_g)],   h = (1 - e_c) / [(1 + e_o)(1 + e_c)],
         // e_x = 2^z_x.  The products must stay finite: z_i + z_f + z_g < 126 and z_o < 62 are properties of the weights (a bound the
         // host can compute when it packs the tables: |b| + sum |W_ih| x_max + sum |W_hh|; every 2023 model passes, one baeda model

@@ -165,8 +165,9 @@ CL_DEV void load_row_scalar(Row& R, const float* __restrict__ qf, uint32_t flags
     }
 }
 
-// Carried per-unit state (one lane).
-struct State { float soc, eff, degcap, cs, hs, ds; };
+// Carried per-unit state (one lane).  eff_lo / deg_lo: CLD_F64_MAPS only -- the low words of Battery.efficiency and
+// Battery.degraded_capacity, which the reference carries as float64 (value = (double)hi + (double)lo).
+struct State { float soc, eff, degcap, cs, hs, ds, eff_lo, deg_lo; };
 // Actions of one unit (inactive -> 0 for storages / ignored for devices, building.py:1557-1564).
 struct Act { float cs, hs, ds, es, cd, hd; };
 // Per-unit results of the step.
@@ -230,6 +231,100 @@ CL_DEV float battery_energy(const BattP& B, float E, State& S) {
     return eb;
 }
 
+// ---- CLD_F64_MAPS: the battery map in the reference's own precision model ---------------------------------------------------
+// The reference evaluates Battery.charge with Python floats and numpy scalars and stores soc[t] / energy_balance[t] in float32
+// series (energy_model.py:1027-1141).  Under numpy's promotion rules (NEP 50: a Python float is "weak", so float32 op python-float
+// stays float32, while float32 op np.float64 -- curve tables, time_step_ratio -- becomes float64) that is MOSTLY float64 with a few
+// float32 operations in fixed places: `prev_soc * capacity`, the discharge limit `(prev_soc - soc_limit) * capacity`, and
+// `capacity_loss_coefficient * capacity * |energy_balance|`.  The map soc_t = f(soc_t-1, a_t) is locally expansive on the steep
+// part of the capacity-power curve, so the ~1 ulp by which an all-fp32 evaluation differs can grow to ~2e-4 relative over a few
+// steps of a free-running episode.  This variant removes the seed instead of bounding the growth: it follows
+// oracle/oracle.py (bit-exact against the reference) operation by operation and type by type -- the same divisions, the same
+// roundings, on the packer's unrounded float64 parameters (CLP_D_* block) -- with efficiency and degraded capacity, which the
+// reference carries as float64 attributes, held as hi + lo float32 planes (48 bits).  On the first charge() of an episode the two
+// attributes are still Python floats in the reference, which moves two more operations to float32 (`first`).
+struct BattP64 {
+    double r, dt, pow, cap, oml /* 1 - loss_coefficient r */, soc_limit /* 1 - depth_of_discharge */, clccap /* capacity_loss_coefficient * capacity */;
+    double cx[3], cy[3], px[5], py[5];      // capacity_power_curve, power_efficiency_curve (x, y)
+};
+
+CL_DEV double pd(const uint32_t* __restrict__ p, int k) {           // k-th double of the CLP_D_* block (8-byte aligned: CL_NP and CLP_D_FIRST are even)
+    const uint64_t bits = (uint64_t)p[CLP_D_FIRST + 2 * k] | ((uint64_t)p[CLP_D_FIRST + 2 * k + 1] << 32);
+    double d;
+    __builtin_memcpy(&d, &bits, 8);
+    return d;
+}
+
+CL_DEV void load_batt64(BattP64& B, const uint32_t* __restrict__ p) {
+    B.r = pd(p, CLPD_TSR); B.dt = pd(p, CLPD_DT); B.pow = pd(p, CLPD_POW); B.cap = pd(p, CLPD_CAP); B.oml = pd(p, CLPD_OML);
+    B.soc_limit = pd(p, CLPD_SOC_LIMIT); B.clccap = pd(p, CLPD_CLCCAP);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { B.cx[k] = pd(p, CLPD_CPC_X0 + k); B.cy[k] = pd(p, CLPD_CPC_Y0 + k); }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { B.px[k] = pd(p, CLPD_PEC_X0 + k); B.py[k] = pd(p, CLPD_PEC_Y0 + k); }
+}
+
+// Battery.charge(energy): `energy` [kWh] is what Building.update_electrical_storage hands over (building.py:1801-1812), float64.
+// Returns energy_balance[t] as the float32 the reference stores.  `first`: the first charge() since reset (step 0).
+CL_DEV float battery_charge_ref(const BattP64& B, double energy, bool first, State& S) {
+#pragma clang fp contract(off)                                                            // the reference rounds every product before it adds
+    const double ZDP = 1e-6;                                                              // data.py:19
+    const float prev = S.soc;                                                             // soc[t-1]: a float32 series value
+    const double eff_prev = (double)S.eff + (double)S.eff_lo;
+    const double degcap = (double)S.degcap + (double)S.deg_lo;
+    // (fields copied to locals first: a select between struct members through a reference becomes a select between their
+    //  addresses and parks the whole struct in scratch memory)
+    const double cx1 = B.cx[1], cx2 = B.cx[2], cx0 = B.cx[0], cy0 = B.cy[0], cy1 = B.cy[1], cy2 = B.cy[2];
+    const double px0 = B.px[0], px1 = B.px[1], px2 = B.px[2], px3 = B.px[3], px4 = B.px[4];
+    const double py0 = B.py[0], py1 = B.py[1], py2 = B.py[2], py3 = B.py[3], py4 = B.py[4];
+    energy = energy * B.r;                                                                // energy_model.py:1036
+    const double action_energy = energy;
+    // energy_init (661-666): float32 product `prev_soc * capacity`, then float64 `* (1 - loss_coefficient)`
+    const double e_init = fmax(0.0, (double)(prev * (float)B.cap) * B.oml);
+    // get_max_input_power (1070-1090): idx = max(0, argmax(soc <= xs) - 1) -- 0 again when no breakpoint is >= soc
+    const double socn = e_init / fmax(B.cap, ZDP);
+    const bool seg1 = !(socn <= cx1) && (socn <= cx2);
+    const double xa = seg1 ? cx1 : cx0, xb = seg1 ? cx2 : cx1, ya = seg1 ? cy1 : cy0, yb = seg1 ? cy2 : cy1;
+    const double pmax = B.pow * (ya + (yb - ya) * (socn - xa) / (xb - xa));
+    double e_eff;                                                                         // argument of get_current_efficiency
+    if (energy >= 0.0) {
+        const double wrt_degrade = degcap - e_init;
+        energy = fmin(fmin(pmax, B.pow), fmin(wrt_degrade, energy));                      // (the battery's own consumption[t] is still 0: one charge() per step)
+        e_eff = fmin(action_energy, pmax);
+    } else {
+        // limit = max((prev_soc - soc_limit) * capacity * rte, 0) * -1: float32 up to `* rte`, which is float32 too while the
+        // efficiency is still the Python float of reset() and float64 afterwards (rte = efficiency ** 0.5 of the PREVIOUS call)
+        const float l32 = (prev - (float)B.soc_limit) * (float)B.cap;
+        const double rte_prev = sqrt(eff_prev);
+        const double lim = first ? (double)(l32 * (float)rte_prev) : (double)l32 * rte_prev;
+        const double limit = -fmax(lim, 0.0);
+        energy = fmax(fmax(-pmax, limit), energy);
+        e_eff = fmin(fabs(action_energy), pmax);
+    }
+    // get_current_efficiency (1092-1109)
+    const double x = fabs(e_eff) / fmax(B.pow, ZDP);
+    const int seg = (x <= px1) ? 0 : (x <= px2) ? 1 : (x <= px3) ? 2 : (x <= px4) ? 3 : 0;
+    const double qa = seg == 0 ? px0 : seg == 1 ? px1 : seg == 2 ? px2 : px3, qb = seg == 0 ? px1 : seg == 1 ? px2 : seg == 2 ? px3 : px4;
+    const double ra = seg == 0 ? py0 : seg == 1 ? py1 : seg == 2 ? py2 : py3, rb = seg == 0 ? py1 : seg == 1 ? py2 : seg == 2 ? py3 : py4;
+    const double eff = ra + (x - qa) * (rb - ra) / (qb - qa);
+    const double rte = sqrt(eff);
+    // StorageDevice.charge (719-768)
+    energy = energy * B.r;
+    const double e_fin = energy >= 0.0 ? fmin(e_init + energy * rte, B.cap) : fmax(0.0, e_init + energy / rte);
+    const float soc = (float)(e_fin / fmax(B.cap, ZDP));                                  // soc[t]: float32 series
+    const double d = e_fin - e_init;
+    const float eb = (float)(d >= 0.0 ? d / rte : d * rte);                               // energy_balance[t]: float32 series
+    // degrade (1130-1141): float32 `clc * capacity * |eb|`; the division is float32 too while degraded_capacity is still a Python float
+    const float g32 = (float)B.clccap * fabsf(eb);
+    const double den = 2.0 * fmax(degcap, ZDP);
+    const double deg = (first ? (double)(g32 / (float)den) : (double)g32 / den) * B.r;
+    const double deg_new = fmax(degcap - deg, 0.0);
+    S.soc = soc;
+    S.eff = (float)eff; S.eff_lo = (float)(eff - (double)S.eff);
+    S.degcap = (float)deg_new; S.deg_lo = (float)(deg_new - (double)S.degcap);
+    return eb;
+}
+
 // StorageDevice.charge under StorageTank.charge's power clamps (energy_model.py:719-768, 850-870).
 // `e` is the energy handed to tank.charge() after `_convert_energy_for_storage` (building.py:1814-1823),
 // i.e. it is multiplied by time_step_ratio twice on its way in.
@@ -270,15 +365,27 @@ CL_DEV void end_use(const Bp& B, const Row& R, Acc& A, float& c, float demand, f
     c += fmaxf(eb, 0.0f) * icop;
 }
 
-// The whole unit step.  `t` and `t0_quirk` are wave-uniform.
-template <bool FULL>
+// update_electrical_storage (building.py:1801-1812) + Battery.charge in the reference's precision model (CLD_F64_MAPS):
+// power = action * nominal_power; energy = power * dt; energy = min(energy, flexibility); charge(energy / time_step_ratio).
+CL_DEV float battery_step_f64(const uint32_t* __restrict__ p, float a_es, float flex, bool first, State& S) {
+#pragma clang fp contract(off)
+    BattP64 bp;
+    load_batt64(bp, p);
+    const double energy = fmin((double)a_es * bp.pow * bp.dt, (double)flex);
+    return battery_charge_ref(bp, energy / bp.r, first, S);
+}
+
+// The whole unit step.  `t` and `t0_quirk` are wave-uniform.  F64: the battery map in float64 (CLD_F64_MAPS).
+template <bool FULL, bool F64 = false>
 CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act& a, State& S, Out& O) {
     const bool first = t0_quirk && t == 0;
     const bool has_batt = B.flags & CLF_BATTERY;
     if constexpr (!FULL) {
         // battery + PV + non-shiftable load only: no outage, no thermal end uses.
         float eb = 0.0f;
-        if (has_batt) eb = battery_step(B.batt, a.es, INFINITY, S);
+        if constexpr (F64) {
+            if (has_batt) eb = battery_step_f64(B.p, a.es, INFINITY, t == 0, S);
+        } else if (has_batt) eb = battery_step(B.batt, a.es, INFINITY, S);
         // t = 0: the load is booked at reset, by the step, and again by update_variables
         const float c_ns = first ? 3.0f * R.nsl : R.nsl;
         const float c_b = first ? 2.0f * eb : eb;
@@ -313,8 +420,9 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         const bool es_first = a.es < 0.0f;                         // building.py:1606-1609
         if (has_batt && R.outage) {                                // the order only matters through `flexibility`
             if (es_first) {
-                BattP bp; load_batt(bp, B.p);
-                eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); A.c_b += eb_b;
+                if constexpr (F64) eb_b = battery_step_f64(B.p, a.es, flexibility(B, R, A), t == 0, S);
+                else { BattP bp; load_batt(bp, B.p); eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); }
+                A.c_b += eb_b;
             }
         }
         float eb_cs = 0.0f, eb_hs = 0.0f, eb_ds = 0.0f, e_cool = cool_dem, e_heat = heat_dem, e_dhw = R.dhw;
@@ -339,8 +447,9 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         const float e_ns = fminf(R.nsl, flexibility(B, R, A));
         A.c_ns += e_ns;
         if (has_batt && !(R.outage && es_first)) {
-            BattP bp; load_batt(bp, B.p);
-            eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); A.c_b += eb_b;
+            if constexpr (F64) eb_b = battery_step_f64(B.p, a.es, flexibility(B, R, A), t == 0, S);
+            else { BattP bp; load_batt(bp, B.p); eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); }
+            A.c_b += eb_b;
         }
         if (first) {
             // the first step's update_variables runs the t == 0 block again (building.py:2618-2652)

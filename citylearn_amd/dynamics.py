@@ -120,6 +120,40 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
     return lstm_w, dyn_pre
 
 
+def cell_update_bounds(spec: DistrictSpec, tables: EpisodeTables, lstm_w: np.ndarray, dyn_pre: np.ndarray):
+    """Rigorous upper bounds of the (pre-scaled) gate values z of every matrix-core LSTM of the district: ``(worst z_i + z_f + z_g over the
+    hidden units of both layers, worst z_o)``.  The common-denominator cell update of csrc/cl_lstm.h (7 instead of 10 transcendentals per
+    unit and cell) multiplies (1 + 2^z_i)(1 + 2^z_g)(1 + 2^z_f) and (1 + 2^z_o)(1 + 2^z_c), z_c <= 64: finite in fp32 while
+    z_i + z_f + z_g < 126 and z_o < 62.  What the gates can see is bounded by construction: the exogenous part is the table `dyn_pre`, a
+    hidden state lies in (-1, 1), the temperature input is a data-file value (warm-up) or a model output b + sum |W_lin| at most, and the
+    demand input is what the building's device and tank can deliver."""
+    worst_sum, worst_o = -np.inf, -np.inf
+    w = slice(tables.start, tables.end + 1)
+    for i, b in enumerate(spec.buildings):
+        W = lstm_w[i].astype(np.float64)
+        if W[ACTIVE] != 1.0:
+            continue
+        heat = W[DEM_HEAT] != 0.0
+        dev, tank, series = (b.heating_device, b.heating_storage, 'heating_demand') if heat else (b.cooling_device, b.cooling_storage, 'cooling_demand')
+        t_out = np.asarray(b.series['outdoor_dry_bulb_temperature'][w], dtype=np.float64)
+        cop = np.max(dev.cop(t_out, heating=heat)) if getattr(dev, 'is_heat_pump', True) else float(dev.efficiency)
+        dem_hi = max(float(np.max(b.series[series][w])), float(dev.nominal_power) * float(cop)) + float(tank.capacity)
+        span_c = W[CMAX] - W[CMIN]
+        xc = np.array([(0.0 - W[CMIN]) / span_c, (dem_hi - W[CMIN]) / span_c])
+        t_model = W[BLIN] + np.array([-1.0, 1.0]) * np.abs(W[WLIN:WLIN + 16]).sum()
+        t_file = dyn_pre[:, i, PRE_TNORM].astype(np.float64)
+        xt = np.array([min(t_model[0], t_file.min()), max(t_model[1], t_file.max())])
+        pre = dyn_pre[:, i, :64].astype(np.float64).max(axis=0)
+        z0 = pre + np.max(np.outer(W[WC:WC + 64], xc), axis=1) + np.max(np.outer(W[WT:WT + 64], xt), axis=1) \
+            + np.abs(W[WHH0:WHH0 + 1024].reshape(64, 16)).sum(axis=1)
+        z1 = W[B1:B1 + 64] + np.abs(W[WIH1:WIH1 + 1024].reshape(64, 16)).sum(axis=1) + np.abs(W[WHH1:WHH1 + 1024].reshape(64, 16)).sum(axis=1)
+        for z in (z0, z1):
+            zi, zf, zg, zo = z.reshape(4, 16)
+            worst_sum = max(worst_sum, float(np.max(np.maximum(zi, 0.0) + np.maximum(zf, 0.0) + np.maximum(zg, 0.0))))
+            worst_o = max(worst_o, float(zo.max()))
+    return worst_sum, worst_o
+
+
 def _demand_input(names) -> int:
     """Index of the model's one env-dependent demand input: `cooling_demand`, or `heating_demand` for a heating-driven model
     ("LSTM model only uses either cooling/heating demand not both as input variable", building.py:3013-3017)."""
@@ -235,12 +269,17 @@ class LSTMStage:
     """Device state + driver of the LSTM stage for one env shard (pairs with a `StepEngine` built with detail=True)."""
 
     def __init__(self, spec: DistrictSpec, tables: EpisodeTables, engine, band=None, lower_exponent: float = 2.0,
-                 higher_exponent: float = 2.0, kpi: bool = False, kpi_band: float = 2.0, split: Optional[str] = 'f16'):
+                 higher_exponent: float = 2.0, kpi: bool = False, kpi_band: float = 2.0, split: Optional[str] = 'f16',
+                 cell_update: str = 'auto'):
         """`kpi`: accumulate the discomfort KPIs on the device (`kpi_comfort`, finalised by `kpi.finalize_comfort`) with the
         scalar comfort band `kpi_band` (`CityLearnEnv.evaluate`'s ``comfort_band``, default 2.0 C -- data.py:399).
         `split`: operand format of the recurrent products on the matrix cores -- 'f16' (two terms per operand, three partial
         products: the default), 'bf16' (three terms, six partial products: twice the matrix-pipe time for dropped terms of
-        2^-24 instead of 3 * 2^-22 relative) or None (exact f32 MFMA)."""
+        2^-24 instead of 3 * 2^-22 relative) or None (exact f32 MFMA).
+        `cell_update`: 'plain' (sigmoid / tanh per gate: 10 transcendentals per hidden unit and cell), 'common_denominator' (7, csrc/cl_lstm.h:
+        same values to a few fp32 roundings; needs bounded gate values) or 'auto' -- the second form where `cell_update_bounds` proves the
+        bound for every model of the district (all 2023 models; not baeda_3dem's), else the first.  An explicit
+        ``tuning={'lstm_variant': ...}`` of the engine wins."""
         self.lib = _lib.load()
         self.engine = engine
         self._args = None
@@ -254,6 +293,19 @@ class LSTMStage:
         self.dims = _lib.Dims.from_buffer_copy(engine.dims)          # the engine's dims (never mutated) + the operand-format flag
         if split == 'f16':
             self.dims.flags |= abi.CLD_LSTM_F16
+        # the stage's own copy of the launch overrides: the cell-update form is chosen here
+        self.tuning = _lib.Tuning.from_buffer_copy(engine.tuning)
+        self.dims.tuning = ctypes.pointer(self.tuning)
+        self.cell_bounds = cell_update_bounds(spec, tables, lstm_w, dyn_pre) if self.any_active else (-np.inf, -np.inf)
+        admitted = self.cell_bounds[0] < 126.0 and self.cell_bounds[1] < 62.0
+        if cell_update not in ('auto', 'plain', 'common_denominator'):
+            raise ValueError("cell_update must be 'auto', 'plain' or 'common_denominator'")
+        if cell_update == 'common_denominator' and not admitted:
+            raise ValueError(f'the common-denominator cell update needs z_i + z_f + z_g < 126 and z_o < 62; this district reaches {self.cell_bounds}')
+        self.cell_update = 'plain'
+        if self.tuning.lstm_variant == 0 and split is not None and cell_update != 'plain' and admitted:
+            self.tuning.lstm_variant = 32
+            self.cell_update = 'common_denominator'
         self.dyn_pre = torch.from_numpy(dyn_pre).to(dev)
         B, E = engine.n_bldg, engine.n_env
         self.hist = torch.zeros((abi.CL_LSTM_NHIST, B, E), dtype=torch.float32, device=dev)
@@ -301,6 +353,7 @@ class LSTMStage:
         # plane and no heating plane the heating side is zero (cooling-only tests)
         hd = heat_dem.data_ptr() if heat_dem is not None else (own_hd if cool_dem is None else None)
         tail = (hd,) + tail
+        self.tuning.kernel_name = e.tuning.kernel_name               # (diagnostics: StepEngine.trace_kernels)
         with e._on_device():
             rc = self.lib.cl_lstm_step_f32(*head, own_cd if cool_dem is None else cool_dem.data_ptr(), *tail, int(t), e._stream())
             if not rc and self.generic is not None:

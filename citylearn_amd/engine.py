@@ -51,7 +51,7 @@ class StepEngine:
                  t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False,
                  n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0,
                  charger_detail: bool = False, ev_penalty_coefficient: float = 1.0, central_agent: bool = False, tuning: Optional[dict] = None,
-                 env_offset: int = 0):
+                 env_offset: int = 0, f64_maps: bool = False):
         """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
         simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
         at table row ``env_row0[g]`` -- different blocks replay different windows at once.
@@ -60,7 +60,11 @@ class StepEngine:
         Electric_Vehicles_Reward_Function, ``ev_seed`` keys the on-device N(1, 0.2) stream of the unconnected-EV SoC
         drift (citylearn.py:1468-1472) and ``ev_drift`` ([table rows, n_ev], optional) replays given multipliers instead
         (what the parity tests do: the reference draws them from the unseeded global ``np.random``); ``charger_detail``
-        also keeps every charger's electricity consumption and requested energy of the step (``charger_out``)."""
+        also keeps every charger's electricity consumption and requested energy of the step (``charger_out``).
+
+        ``f64_maps`` (`CLD_F64_MAPS`): evaluate the battery map in float64 with float32 rounding where the reference's float32 series
+        round -- the reference's own precision model (energy_model.py:1027-1141), for free-running parity at 1e-4; slower launches,
+        no fused rollout kernel, no flexible loads."""
         self.lib = _lib.load()                      # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
@@ -96,6 +100,10 @@ class StepEngine:
         flags |= abi.CLD_REF_T0_QUIRK if t0_quirk else 0
         flags |= abi.CLD_KPI if kpi else 0
         flags |= abi.CLD_CENTRAL_AGENT if central_agent else 0      # only read by the CLR_EV reward
+        flags |= abi.CLD_F64_MAPS if f64_maps else 0
+        self.f64_maps = bool(f64_maps)
+        if f64_maps and tables.flex is not None:
+            raise NotImplementedError('f64_maps is not implemented for districts with EV chargers / washing machines')
         self.kpi = kpi
         bflags = tables.params[:, abi.CLP_FLAGS]
         heavy = abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS
@@ -103,7 +111,7 @@ class StepEngine:
         flags |= abi.CLD_LEAN if self.lean else 0
         # the streaming KPI passes read the detail planes -- except for battery + PV districts of up to 32 buildings, whose step kernel
         # updates the per-building accumulators itself (cl_step_lean_kpi_kernel): no detail planes, no second pass
-        kpi_in_step = kpi and self.lean and self.n_bldg <= 32 and self.flex_tables is None
+        kpi_in_step = kpi and self.lean and self.n_bldg <= 32 and self.flex_tables is None and not f64_maps
         flags |= abi.CLD_WRITE_DETAIL if (detail or (kpi and not kpi_in_step)) else 0
         es_cols = tables.params.view(np.int32)[:, abi.CLP_ACT_ELEC_STO]
         if np.array_equal(es_cols, np.arange(self.n_bldg)):          # one battery action per building, building order
@@ -285,7 +293,7 @@ class StepEngine:
         elif self.act_low is None:
             raise ValueError('call set_action_limits(low, high) before using the on-device policy')
         full = not self.lean or bool(self.dims.flags & abi.CLD_WRITE_DETAIL)
-        if self.flex is not None or self.kpi or self.n_bldg > (16 if full else 32):
+        if self.flex is not None or self.kpi or self.f64_maps or self.n_bldg > (16 if full else 32):
             if actions is None and self._policy_actions is None:
                 self._policy_actions = torch.empty((4, self.n_act_cols, self.n_env), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
@@ -330,6 +338,6 @@ class StepEngine:
         flags = self.params[:, abi.CLP_FLAGS].cpu().numpy().view(np.uint32)
         planes = 0.0
         for f in flags:
-            planes += 3 * bool(f & abi.CLF_BATTERY) + bool(f & abi.CLF_COOL_STO) + bool(f & abi.CLF_HEAT_STO) + bool(f & abi.CLF_DHW_STO)
+            planes += (5 if self.f64_maps else 3) * bool(f & abi.CLF_BATTERY) + bool(f & abi.CLF_COOL_STO) + bool(f & abi.CLF_HEAT_STO) + bool(f & abi.CLF_DHW_STO)
         planes /= self.n_bldg
         return 8.0 * planes + 4.0 * self.n_act_cols / self.n_bldg + 8.0 + 4.0 * abi.CL_NQ / self.n_bldg

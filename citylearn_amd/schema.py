@@ -607,6 +607,16 @@ class DistrictSpec:
             pf[i, abi.CLP_L_RW_EXPONENT] = reward_exponent
             pf[i, abi.CLP_L_SOC0] = e.initial_soc
             pf[i, abi.CLP_L_EFF0] = e.efficiency
+            # CLD_F64_MAPS: the battery's parameters unrounded (the reference evaluates Battery.charge mostly in float64;
+            # csrc/cl_unit.h battery_charge_ref follows its operations one by one)
+            d64 = params[i, abi.CLP_D_FIRST:abi.CLP_D_LAST + 1].view(np.float64)
+            d64[abi.CLPD_TSR], d64[abi.CLPD_DT], d64[abi.CLPD_POW], d64[abi.CLPD_CAP] = r, dt, powr, cap
+            d64[abi.CLPD_OML] = 1.0 - e.loss_coefficient * r
+            d64[abi.CLPD_SOC_LIMIT] = 1.0 - e.depth_of_discharge
+            d64[abi.CLPD_CLCCAP] = e.capacity_loss_coefficient * cap
+            d64[abi.CLPD_EFF0] = e.efficiency
+            d64[abi.CLPD_CPC_X0:abi.CLPD_CPC_X0 + 3], d64[abi.CLPD_CPC_Y0:abi.CLPD_CPC_Y0 + 3] = cx, cy
+            d64[abi.CLPD_PEC_X0:abi.CLPD_PEC_X0 + 5], d64[abi.CLPD_PEC_Y0:abi.CLPD_PEC_Y0 + 5] = ex, ey
             for tank, base in ((b.cooling_storage, abi.CLP_CS_IRTE), (b.heating_storage, abi.CLP_HS_IRTE),
                                (b.dhw_storage, abi.CLP_DS_IRTE)):
                 pf[i, base + 0] = 1.0 / math.sqrt(tank.efficiency)

@@ -50,9 +50,9 @@ extern "C" {
 #define CL_ERANGE       -5   /* t / k_steps outside [0, n_steps) */
 
 /* ---- table widths ---- */
-#define CL_NP  192   /* words per building in `params` */
+#define CL_NP  256   /* words per building in `params` (1 KiB rows) */
 #define CL_NF   16   /* floats per (t, building) row in `ts` */
-#define CL_NS    6   /* state planes */
+#define CL_NS    8   /* state planes (the last two are only touched under CLD_F64_MAPS) */
 #define CL_NO   18   /* per-building output planes */
 #define CL_NQ    4   /* per-env (district) output planes */
 #define CL_NKB  12   /* per-building KPI accumulator planes */
@@ -127,7 +127,24 @@ enum cl_param {
     CLP_F_TANK = CLP_F_FIRST + 16,                   /* 3 x 8 (cooling, heating, dhw): capacity, capacity*(1-loss r), sqrt(eff), 1/sqrt(eff), 1/capacity,
                                                         max input, max output, action scale [kWh per unit action] (sic: building.py:1676, 1720, 1765) */
     CLP_F_BATT = CLP_F_FIRST + 40,                   /* the 24 words CLP_L_PDT .. CLP_L_PEC_B3 */
-    CLP_F_LAST = CLP_F_FIRST + 63
+    CLP_F_LAST = CLP_F_FIRST + 63,
+    /* ---- CLD_F64_MAPS: the battery's parameters as float64 (two words each, little endian; cl_param_f64 indexes them), unrounded:
+     *      the reference computes Battery.charge mostly in float64 (energy_model.py:1027-1141; csrc/cl_unit.h battery_charge_ref). ---- */
+    CLP_D_FIRST = 192,
+    CLP_D_LAST = CLP_D_FIRST + 63
+};
+enum cl_param_f64 {       /* k-th double of the CLP_D_* block */
+    CLPD_TSR = 0,         /* time_step_ratio r */
+    CLPD_DT,              /* seconds_per_time_step / 3600 */
+    CLPD_POW, CLPD_CAP,   /* nominal_power, capacity */
+    CLPD_OML,             /* 1 - loss_coefficient * r */
+    CLPD_SOC_LIMIT,       /* 1 - depth_of_discharge */
+    CLPD_CLCCAP,          /* capacity_loss_coefficient * capacity */
+    CLPD_EFF0,            /* Battery.efficiency at reset */
+    CLPD_CPC_X0, CLPD_CPC_X1, CLPD_CPC_X2, CLPD_CPC_Y0, CLPD_CPC_Y1, CLPD_CPC_Y2,          /* capacity_power_curve (x: soc, y: power fraction) */
+    CLPD_PEC_X0, CLPD_PEC_X1, CLPD_PEC_X2, CLPD_PEC_X3, CLPD_PEC_X4,                       /* power_efficiency_curve */
+    CLPD_PEC_Y0, CLPD_PEC_Y1, CLPD_PEC_Y2, CLPD_PEC_Y3, CLPD_PEC_Y4,
+    CLPD_USED             /* <= 32 */
 };
 
 /* ---- building flag bits (CLP_FLAGS) ---- */
@@ -163,7 +180,10 @@ enum cl_state {
     CLS_B_SOC = 0,    /* electrical_storage.soc[t] */
     CLS_B_EFF,        /* Battery.efficiency left by the previous charge() call (energy_model.py:1039-1052) */
     CLS_B_DEGCAP,     /* Battery.degraded_capacity [kWh] */
-    CLS_CS_SOC, CLS_HS_SOC, CLS_DS_SOC                 /* cooling / heating / dhw tank soc[t] */
+    CLS_CS_SOC, CLS_HS_SOC, CLS_DS_SOC,                /* cooling / heating / dhw tank soc[t] */
+    CLS_B_EFF_LO, CLS_B_DEGCAP_LO                      /* CLD_F64_MAPS: low words of the two float64 values the reference carries between steps --
+                                                          Battery.efficiency = (double)CLS_B_EFF + (double)CLS_B_EFF_LO, likewise the degraded
+                                                          capacity; written by cl_reset_f32, left alone by the fp32 kernels */
 };
 
 /* ---- per-building outputs (`out_bldg[plane][b][env]`) ---- */
@@ -232,6 +252,12 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
                                          the specialised lean kernel may be used */
 #define CLD_LSTM_F16       (1u << 6)  /* cl_lstm_step_f32 only: `lstm_wb` holds two f16 terms per weight (dynamics.pack_lstm_split(.., 'f16'))
                                          instead of three bf16 terms */
+#define CLD_F64_MAPS       (1u << 7)  /* cl_step_f32 / cl_step_flex_f32: evaluate the battery map in float64 on the CLP_D_* parameters, round soc[t] and
+                                         energy_balance[t] to float32 where the reference's float32 series do, carry efficiency / degraded capacity
+                                         as hi + lo planes -- the reference's own precision model, for free-running parity at 1e-4 (the default
+                                         fp32 map is locally expansive on the steep part of the capacity-power curve: DESIGN.md section 3).
+                                         Slower launches (general / lean step kernels only; not the fused rollout, the env-major or the
+                                         thermal-specialised kernels). */
 #define CLD_REWARD_SHIFT   8          /* reward kind in bits 8..11 */
 #define CLD_REWARD_MASK    (0xFu << CLD_REWARD_SHIFT)
 enum cl_reward_kind {

@@ -22,7 +22,7 @@ LABEL = {0: ' split matrix-core path', 1: ' [f32 MFMA, experiment: no activation
 for split in SPLITS:
     for dbg in ((0, 32) if QUICK else ((0, 32, 8, 3) if split == 'bf16' else (0, 32))):
         eng = StepEngine(tab, E, detail=True, tuning=dict(lstm_variant=dbg))
-        stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'], split=split)
+        stage = LSTMStage(spec, tab, eng, attrs['band'], attrs['lower_exponent'], attrs['higher_exponent'], split=split, cell_update='plain')
         wt = wr = 0.0
         for t in range(g.facts['steps']):
             temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous())
@@ -37,7 +37,7 @@ for split in SPLITS:
         cases = ((4096, 0), (65536, 0), (65536, 32), (65536, 5), (65536, 6)) + (((4096, 8), (65536, 8), (4096, 3), (65536, 3), (65536, 1), (65536, 2)) if split == 'bf16' else ())
     for E_, dbg in cases:
         eng = StepEngine(tab, E_, detail=True, tuning=dict(lstm_variant=dbg))
-        stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0, split=split)
+        stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0, split=split, cell_update='plain')
         cd = torch.rand((3, E_), device='cuda') * 5
         for t in range(12, 16): stage.step(t, cd)
         torch.cuda.synchronize()

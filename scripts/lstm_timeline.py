@@ -31,7 +31,7 @@ def capture(E, split):
 
     g = golden('g2023_p2'); spec = g.spec(); tab = spec.episode_tables(0)
     eng = StepEngine(tab, E, detail=True)
-    stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0, split=split)
+    stage = LSTMStage(spec, tab, eng, 1.0, 2.0, 3.0, split=split, cell_update='plain')
     lib = _lib.load()
     lib.cl_trace_set.argtypes = [ctypes.c_void_p]
     B = eng.n_bldg

@@ -4,23 +4,27 @@
 #define CL_HOST_SHIM 1
 #include "../../citylearn_amd/csrc/cl_unit.h"
 
-template <bool FULL>
+// state8: the six state planes of one unit + the low words of efficiency / degraded capacity (CLD_F64_MAPS)
+template <bool FULL, bool F64>
 static void run(const uint32_t* params, const float* ts_row, int t, int quirk, int rkind, const float* act6,
-                float* state6, float* out10, float* reward) {
+                float* state8, float* out10, float* reward) {
     cl::Bp B; cl::load_bp<FULL>(B, params);
     cl::Row R; cl::load_row<FULL>(R, ts_row, B.flags);
-    cl::State S = {state6[0], state6[1], state6[2], state6[3], state6[4], state6[5]};
+    cl::State S = {state8[0], state8[1], state8[2], state8[3], state8[4], state8[5], state8[6], state8[7]};
     cl::Act a = {act6[0], act6[1], act6[2], act6[3], act6[4], act6[5]};
     cl::Out O;
-    cl::unit_step<FULL>(B, R, t, quirk != 0, a, S, O);
+    cl::unit_step<FULL, F64>(B, R, t, quirk != 0, a, S, O);
     *reward = cl::unit_reward<FULL>(rkind, B, S, O.net);
-    state6[0] = S.soc; state6[1] = S.eff; state6[2] = S.degcap; state6[3] = S.cs; state6[4] = S.hs; state6[5] = S.ds;
+    state8[0] = S.soc; state8[1] = S.eff; state8[2] = S.degcap; state8[3] = S.cs; state8[4] = S.hs; state8[5] = S.ds;
+    state8[6] = S.eff_lo; state8[7] = S.deg_lo;
     out10[0] = O.net; out10[1] = O.cost; out10[2] = O.emission; out10[3] = O.eb; out10[4] = O.cool_dem;
     out10[5] = O.c_cool; out10[6] = O.c_heat; out10[7] = O.c_dhw; out10[8] = O.c_ns; out10[9] = O.base_net;
 }
 
-extern "C" void host_unit_step(const uint32_t* params, const float* ts_row, int t, int quirk, int rkind, int full,
-                               const float* act6, float* state6, float* out10, float* reward) {
-    if (full) run<true>(params, ts_row, t, quirk, rkind, act6, state6, out10, reward);
-    else run<false>(params, ts_row, t, quirk, rkind, act6, state6, out10, reward);
+extern "C" void host_unit_step(const uint32_t* params, const float* ts_row, int t, int quirk, int rkind, int full, int f64,
+                               const float* act6, float* state8, float* out10, float* reward) {
+    if (full && f64) run<true, true>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    else if (full) run<true, false>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    else if (f64) run<false, true>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    else run<false, false>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
 }

@@ -1,0 +1,83 @@
+"""CLD_F64_MAPS on the CPU: `cl::unit_step<FULL, F64>` of csrc/cl_unit.h compiled with g++ (tests/host_shim, a test harness -- the product
+has no CPU path) and run FREE-RUNNING over whole reference fixtures.  `battery_charge_ref` follows the reference's Battery.charge
+operation by operation in the reference's own mixed precision (float64 with the float32 operations numpy's promotion rules put in it,
+float32 rounding where the float32 series round, efficiency / degraded capacity carried as hi + lo pairs), so the battery state the
+unit feeds back to itself is BIT-IDENTICAL to the reference's for every step of every fixture, outage rows included, and everything
+else stays inside 0.07 x (1e-4 + 1e-4 |ref|).  (The fp32 map drifts to ~2e-4 relative on the 2020 fixture: DESIGN.md section 3.)
+The GPU kernels run the same header (tests/test_gpu_parity.py::test_free_running_whole_fixture_f64)."""
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from golden_util import golden
+from citylearn_amd import abi
+
+HERE = Path(__file__).resolve().parent / 'host_shim'
+
+
+@pytest.fixture(scope='module')
+def shim(tmp_path_factory):
+    out = tmp_path_factory.mktemp('shim') / 'libcl_unit_host.so'
+    subprocess.run(['g++', '-O2', '-shared', '-fPIC', '-DCL_HOST_SHIM', '-ffp-contract=off', str(HERE / 'cl_unit_host.cpp'), '-o', str(out)], check=True)
+    lib = ctypes.CDLL(str(out))
+    vp = ctypes.c_void_p
+    lib.host_unit_step.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+    return lib
+
+
+def free_run(lib, name: str, f64: bool):
+    """Worst error / (1e-4 + 1e-4 |ref|) of soc, efficiency, degraded capacity, tank SoCs and net over the fixture, free-running."""
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    B = tab.params.shape[0]
+    P = np.ascontiguousarray(tab.params)
+    pi, pf = P.view(np.int32), P.view(np.float32)
+    full = int(bool(np.any(P[:, abi.CLP_FLAGS] & (abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS))))
+    state = np.zeros((B, 8), dtype=np.float32)
+    d64 = P[:, abi.CLP_D_FIRST:abi.CLP_D_LAST + 1].copy().view(np.float64)
+    state[:, 0], state[:, 1], state[:, 2] = pf[:, abi.CLP_L_SOC0], pf[:, abi.CLP_L_EFF0], pf[:, abi.CLP_L_CAP]
+    state[:, 3], state[:, 4], state[:, 5] = pf[:, abi.CLP_CS_SOC0], pf[:, abi.CLP_HS_SOC0], pf[:, abi.CLP_DS_SOC0]
+    state[:, 6] = d64[:, abi.CLPD_EFF0] - state[:, 1].astype(np.float64)              # what cl_reset_kernel writes
+    state[:, 7] = d64[:, abi.CLPD_CAP] - state[:, 2].astype(np.float64)
+    has_batt = (P[:, abi.CLP_FLAGS] & abi.CLF_BATTERY) != 0
+    acts = g.ref['actions']
+    worst = {}
+    out, rw = np.zeros(10, dtype=np.float32), np.zeros(1, dtype=np.float32)
+    vp = ctypes.c_void_p
+    for t in range(g.facts['steps']):
+        for b in range(B):
+            col = lambda slot: float(acts[t][pi[b, slot]]) if pi[b, slot] >= 0 else 0.0
+            a = [col(abi.CLP_ACT_COOL_STO), col(abi.CLP_ACT_HEAT_STO), col(abi.CLP_ACT_DHW_STO), col(abi.CLP_ACT_ELEC_STO),
+                 col(abi.CLP_ACT_COOL_DEV), col(abi.CLP_ACT_HEAT_DEV)]
+            if pi[b, abi.CLP_ACT_COH_DEV] >= 0:
+                c = col(abi.CLP_ACT_COH_DEV)
+                a[4], a[5] = abs(min(c, 0.0)), abs(max(c, 0.0))
+            a6 = np.asarray(a, dtype=np.float32)
+            row = np.ascontiguousarray(tab.ts[t, b])
+            st = state[b]
+            lib.host_unit_step(P[b].ctypes.data_as(vp), row.ctypes.data_as(vp), t, 1, 0, full, int(f64), a6.ctypes.data_as(vp),
+                               st.ctypes.data_as(vp), out.ctypes.data_as(vp), rw.ctypes.data_as(vp))
+            for key, got in (('soc', st[0]), ('eff', st[1]), ('degcap', st[2]), ('cs_soc', st[3]), ('hs_soc', st[4]), ('ds_soc', st[5]), ('net', out[0])):
+                if key in ('soc', 'eff', 'degcap') and not has_batt[b]:
+                    continue
+                ref = float(g.ref[key][t][b])
+                worst[key] = max(worst.get(key, 0.0), abs(float(got) - ref) / (1e-4 + 1e-4 * abs(ref)))
+    return worst
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 'g2023_heat'])
+def test_free_running_f64_unit_stays_on_the_reference_trajectory(shim, name):
+    worst = free_run(shim, name, True)
+    assert max(worst.values()) < 0.1, worst
+    # the battery state: the reference's own float32 values, bit for bit, after a whole free-running episode
+    assert worst['soc'] == 0.0 and worst['eff'] == 0.0 and worst['degcap'] == 0.0, worst
+
+
+def test_fp32_unit_drifts_on_the_expansive_part_of_the_battery_map(shim):
+    """What CLD_F64_MAPS is for: the same free run with the fp32 map leaves the 1e-4 bar on the 2020 fixture (and stays inside 1e-3)."""
+    worst = free_run(shim, 'g2020_cz1', False)
+    assert 1.0 < max(worst.values()) < 10.0, worst

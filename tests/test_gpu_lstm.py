@@ -12,13 +12,17 @@ from citylearn_amd.dynamics import LSTMStage
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name,split', [('g2023_p2', 'f16'), ('s_baeda', 'f16'), ('s_2023_p1', 'f16'), ('s_2023_p3', 'f16'), ('g2023_heat', 'f16'),
-                                        ('g2023_p2', 'bf16'), ('s_baeda', 'bf16'), ('g2023_heat', 'bf16'), ('g2023_p2', None), ('s_2023_p3', None)])
-def test_lstm_stage_fed_with_reference_cooling(name, split):
+@pytest.mark.parametrize('name,split,cell', [
+    ('g2023_p2', 'f16', 'auto'), ('s_baeda', 'f16', 'auto'), ('s_2023_p1', 'f16', 'auto'), ('s_2023_p3', 'f16', 'auto'), ('g2023_heat', 'f16', 'auto'),
+    ('g2023_p2', 'f16', 'plain'), ('s_2023_p3', 'f16', 'plain'), ('g2023_heat', 'f16', 'plain'),
+    ('g2023_p2', 'bf16', 'auto'), ('s_baeda', 'bf16', 'auto'), ('g2023_heat', 'bf16', 'plain'), ('g2023_p2', None, 'auto'), ('s_2023_p3', None, 'auto')])
+def test_lstm_stage_fed_with_reference_cooling(name, split, cell):
     """Isolates the stage: the delivered cooling of every step comes from the reference; temperatures within 1e-4 C
     relative and ComfortReward within 1e-4 (+1e-4) of the reference for every step and building (2023: LSTM(13 -> 16),
     3 and 6 buildings; baeda_3dem: three LSTM(11 -> 8, 2 layers) embedded in the 16-wide kernel + one LSTM(11 -> 50, 1 layer)).
-    `split`: the operand format of the recurrent products -- two f16 terms (default), three bf16 terms, or the exact f32 MFMA."""
+    `split`: the operand format of the recurrent products -- two f16 terms (default), three bf16 terms, or the exact f32 MFMA.
+    `cell`: the cell update -- 'auto' picks the common-denominator form (7 transcendentals per unit and cell) for every 2023 district and the
+    plain one (10) for baeda_3dem, whose gate bound exceeds what the products admit (`dynamics.cell_update_bounds`)."""
     g = golden(name)
     spec = g.spec()
     cols = list(range(len(spec.buildings)))
@@ -33,7 +37,10 @@ def test_lstm_stage_fed_with_reference_cooling(name, split):
     attrs = spec.reward_function.get('attributes') or {}
     E = 64
     eng = StepEngine(tab, E, detail=True)
-    stage = LSTMStage(spec, tab, eng, attrs.get('band'), attrs.get('lower_exponent') or 2.0, attrs.get('higher_exponent') or 2.0, split=split)
+    stage = LSTMStage(spec, tab, eng, attrs.get('band'), attrs.get('lower_exponent') or 2.0, attrs.get('higher_exponent') or 2.0, split=split,
+                      cell_update=cell)
+    assert stage.cell_update == ('common_denominator' if (cell == 'auto' and split is not None and name != 's_baeda') else 'plain')
+    eng.trace_kernels()
     cool = torch.from_numpy(g.ref['cool_dem'][:, cols]).cuda()
     # g2023_heat (synthetic: heating device actions, hvac_mode 0-3, one heating-driven model): the delivered heating plane too
     heat = torch.from_numpy(g.ref['heat_dem'][:, cols]).cuda() if 'heat_dem' in g.ref.files else None
@@ -45,6 +52,7 @@ def test_lstm_stage_fed_with_reference_cooling(name, split):
         worst_t = max(worst_t, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t][cols]))))
         ref = g.ref['reward_ComfortReward'][t][cols]
         worst_r = max(worst_r, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
+    assert ('cl_lstm_kernel<32,' in eng.last_kernels) == (stage.cell_update == 'common_denominator'), eng.last_kernels
     assert worst_t < 2e-3, worst_t          # deg C on ~25 C: < 1e-4 relative
     assert worst_r < 1.0, worst_r           # BASELINE.json: reward parity within 1e-4 relative (measured: 0.09)
 

@@ -74,3 +74,16 @@ def test_packed_tables_reproduce_the_reference_temperatures(name, fmt, steps):
             ring_t[t % 12] = y                                                  # building.py:3027-3028
             worst = max(worst, abs(temp - g.ref['indoor_temp'][t][b]))
     assert worst < 5e-5, worst          # deg C (measured 5e-6); the device test's bound is 2e-3 (fp32 kernel), this restatement runs in float64
+
+
+def test_cell_update_bounds_admit_the_2023_models_and_refuse_baeda():
+    """`dynamics.cell_update_bounds`: the rigorous bound on the gate values that lets a district use the common-denominator cell update
+    (z_i + z_f + z_g < 126, z_o < 62 keep its products finite in fp32)."""
+    from citylearn_amd.dynamics import cell_update_bounds, pack_lstm
+    for name, ok in (('g2023_p2', True), ('s_2023_p3', True), ('g2023_heat', True), ('s_baeda', False)):
+        spec = golden(name).spec()
+        tab = spec.episode_tables(0)
+        w, pre = pack_lstm(spec, tab)
+        zs, zo = cell_update_bounds(spec, tab, w, pre)
+        assert 20.0 < zs < 200.0 and 5.0 < zo < 62.0
+        assert (zs < 126.0) == ok, (name, zs, zo)
