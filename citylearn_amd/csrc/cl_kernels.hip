@@ -54,6 +54,7 @@ struct StepArgs {
     int b_chunk;   // buildings per workgroup row (gridDim.y = n_chunks rows); == n_bldg when the grid is 1-D
     int n_chunks;
     int nt;        // plane stores carry the non-temporal hint (see pstore)
+    int fused_finish;   // building-chunked launches: the last chunk of an env tile folds the chunk partial sums itself (district_reduce)
 };
 
 constexpr int CL_OBS_FUSED_BLDG = 32;          // buildings a fused observation list can address (= the lean kernel's 2 x 16)
@@ -163,18 +164,60 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
     const int tile_env0 = blockIdx.x * TILE;
     const bool coupled = rkind == CLR_MARL || (FLEX && rkind == CLR_EV);   // rewards that need the district net
     if (a.n_chunks > 1) {
-        // large districts: this workgroup only saw buildings [y*b_chunk, (y+1)*b_chunk).  Its partial sums go to the
-        // scratch rows of out_bldg's reserved plane; cl_finish_kernel adds the chunks in order (deterministic).
-        // (Tried: letting the last workgroup of an env tile do that sum in-kernel -- agent-scope release / counter /
-        // acquire.  The per-workgroup device-scope fences write back and invalidate the XCD L2s: 177 us vs 21 us at
-        // 1024 buildings x 1024 envs.  The extra 4 us launch stays.)
+        // Large districts: this workgroup only saw buildings [y*b_chunk, (y+1)*b_chunk).  Its partial sums go to the scratch rows of
+        // out_bldg's reserved plane, and the LAST chunk of the env tile to arrive adds the chunks in chunk order (deterministic, whoever
+        // is last) -- no second launch.
+        // Round 1 tried this with an agent-scope release / acquire pair around a counter: those fences write back and invalidate the
+        // whole XCD L2 (177 us vs 21 us at 1024 buildings x 1024 envs), and round 2 kept a second launch (cl_finish_kernel, 4.8 us of
+        // pure latency).  Neither is needed: only the partial sums and the ticket cross XCDs, so only THEY are accessed at agent scope
+        // (relaxed atomic stores / loads = write-through / L2-bypassing `sc1` accesses, no cache maintenance), and the order "partials
+        // complete -> ticket" is a wait for this thread's own stores (the workgroup-scope release fence is an s_waitcnt) plus the
+        // workgroup barrier in front of the one thread that takes the ticket.
         float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
         for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
             const int q = i / TILE, e = i - q * TILE;
             float s = 0.0f;
             for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
-            if (tile_env0 + e < a.n_env) scratch[((long long)blockIdx.y * NQ + q) * a.n_env + tile_env0 + e] = s;
+            if (tile_env0 + e < a.n_env) {
+                float* dst = scratch + ((long long)blockIdx.y * NQ + q) * a.n_env + tile_env0 + e;
+                if (a.fused_finish) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = s;
+            }
         }
+        if (!a.fused_finish) return;                             // cl_tuning.finish = 1: cl_finish_kernel folds them (second launch)
+        unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (long long)a.n_chunks * NQ * a.n_env) + blockIdx.x;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial sums have left the CU
+        __syncthreads();                                         // ... and so have everybody else's (and nobody reads the wave rows of `lds` any more)
+        unsigned* flag = reinterpret_cast<unsigned*>(lds);
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != (unsigned)a.n_chunks - 1u) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool marl = rkind == CLR_MARL;
+        for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
+            const int q = i / TILE, e = i - q * TILE;
+            if (tile_env0 + e >= a.n_env) continue;
+            const float* src = scratch + (long long)q * a.n_env + tile_env0 + e;
+            const float* srcn = scratch + (long long)CLQ_NET * a.n_env + tile_env0 + e;
+            const bool scale = marl && q == CLQ_REWARD;          // the partials carried sign(-net) * 0.01 * net^2: times max(0, district net)
+            float s = 0.0f, sn = 0.0f;
+            for (int c0 = 0; c0 < a.n_chunks; c0 += 8) {         // eight independent loads in flight, added in chunk order
+                float v[8], vn[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = c0 + j < a.n_chunks;
+                    const long long o = (long long)(in ? c0 + j : 0) * NQ * a.n_env;
+                    v[j] = __hip_atomic_load(src + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vn[j] = scale ? __hip_atomic_load(srcn + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                    if (!in) { v[j] = 0.0f; vn[j] = 0.0f; }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s += v[j]; sn += vn[j]; }
+            }
+            if (scale) s *= fmaxf(0.0f, sn);
+            a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
         return;
     }
     for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
@@ -1214,6 +1257,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
     a.flex_out = nullptr; a.n_flex_bldg = 0; a.ev_penalty_coef = 0.0f;
+    a.fused_finish = tun.finish != 1;
     // non-temporal plane stores while the launch's footprint (~40 - 60 B per (env, building) unit) stays inside the Infinity Cache
     // ... and again once it is several times that cache (17 x 1 048 576: 125 -> 115 us, 17 x 1 572 864: 196 -> 170 us): nothing of a step
     // survives in the cache until the next one anyway, and the hint keeps the stores from displacing what the step still reads.  In
@@ -1285,7 +1329,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
         if (a.n_chunks == 1) a.b_chunk = dims->n_bldg;
         else a.nw = (tun.b_chunk > 0 && tun.nw > 0) ? tun.nw : 16;
-        if (a.n_chunks * NQ > dims->n_bldg) return fail(CL_EINVAL, "b_chunk=%d leaves no room for the %d chunk partial sums", a.b_chunk, a.n_chunks);
+        if (a.n_chunks * NQ + 1 > dims->n_bldg) return fail(CL_EINVAL, "b_chunk=%d leaves no room for the %d chunk partial sums and their tickets", a.b_chunk, a.n_chunks);
     }
     if (a.n_chunks > 1 && rkind_host == CLR_EV)
         return fail(CL_EINVAL, "reward kind CLR_EV is not implemented for building-chunked launches (n_bldg=%d)", dims->n_bldg);
@@ -1454,8 +1498,10 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         }
     }
     if (a.n_chunks > 1) {
-        name_add(tun, "cl_finish_kernel");
-        hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, s, a);
+        if (!a.fused_finish) {
+            name_add(tun, "cl_finish_kernel");
+            hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, s, a);
+        }
         if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL) {
             const long long n = (long long)dims->n_env * dims->n_bldg;
             name_add(tun, "cl_marl_reward_kernel");
@@ -1584,7 +1630,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t0; a.b_chunk = dims->n_bldg; a.n_chunks = 1; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
-    a.nt = 0;
+    a.nt = 0; a.fused_finish = 0;
     r.act_stride_step = act_stride_step; r.act_low = act_low; r.act_high = act_high; r.ret_env = ret_env; r.seed = seed;
     r.t0 = t0; r.k_steps = k_steps;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);

@@ -204,7 +204,8 @@ enum cl_out {
                          EvaluationCondition variants, citylearn.py:29-50) */
     CLO_SE_COOL, CLO_SE_HEAT, CLO_SE_DHW,   /* cooling / heating / dhw _storage_electricity_consumption[t]: the tank's energy balance through the
                          device's COP or efficiency (building.py:413-457); detail planes */
-    CLO_RESERVED      /* scratch of building-chunked launches (per-chunk district partial sums); keep last */
+    CLO_RESERVED      /* scratch of building-chunked launches (per-chunk district partial sums, then one arrival counter per env tile);
+                         keep last.  The caller zero-fills `out_bldg` once before the first step: the counters return to zero by themselves */
 };
 
 /* ---- district outputs (`out_env[plane][env]`) ---- */
@@ -290,7 +291,9 @@ typedef struct cl_tuning {
                                cl_rollout_f32 / cl_lstm_step_f32 write the instantiation(s) they launched into it, '+'-separated, in the
                                spelling rocprofv3 prints (bench.py's `roofline.kernel`, scripts/profile_round.sh's name check).  Output only:
                                nothing the library computes depends on it. */
-    int32_t reserved[2];
+    int32_t finish;         /* building-chunked launches (districts of more than 32 buildings): 0 = the last chunk of an env tile folds the chunk
+                               partial sums inside the step launch, 1 = a second launch does (cl_finish_kernel; tests, A/B) */
+    int32_t reserved[1];
 } cl_tuning;
 #define CL_KERNEL_NAME_LEN 256
 

@@ -1,0 +1,38 @@
+"""Building-chunked launches: the last chunk of an env tile folds the chunk partial sums in-kernel (district_reduce) -- a stress run for
+the cross-XCD hand-off: 3000 steps at 1024 buildings x 1024 envs (and a ragged shape), every step's district sums compared bit for bit
+between two engines with the in-kernel fold, and within rounding with the two-launch path (cl_tuning.finish = 1)."""
+import sys
+from pathlib import Path
+import torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from citylearn_amd import load_district
+from citylearn_amd.data import sample_schema
+from citylearn_amd.engine import StepEngine
+from citylearn_amd.synthetic import tile_district
+
+for name, B, E, kind in (('citylearn_challenge_2020_climate_zone_1_744h', 1024, 1024, 'RewardFunction'), ('citylearn_challenge_2022_phase_all_720h', 1024, 1024, 'MARL'),
+                         ('citylearn_challenge_2020_climate_zone_1_744h', 200, 772, 'MARL')):
+    spec = tile_district(load_district(sample_schema(name)), B)
+    tab = spec.episode_tables(0)
+    a1, a2 = StepEngine(tab, E, reward=kind), StepEngine(tab, E, reward=kind)
+    ref = StepEngine(tab, E, reward=kind, tuning=dict(finish=1))
+    a1.trace_kernels(); ref.trace_kernels()
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    acts = [lo[:, None] + torch.rand((len(low), E), device='cuda', generator=gen) * (hi - lo)[:, None] for _ in range(4)]
+    bad = 0
+    worst = 0.0
+    for t in range(3000):
+        for e in (a1, a2, ref):
+            e.step(acts[t % 4], t % 700)
+        if t % 10 == 0 or t < 50:
+            if not torch.equal(a1.out_env, a2.out_env):
+                bad += 1
+            worst = max(worst, float(((a1.out_env - ref.out_env).abs() / (1e-4 + 1e-4 * ref.out_env.abs())).max()))
+            assert torch.equal(a1.out_bldg[:2], ref.out_bldg[:2])
+    torch.cuda.synchronize()
+    print(f'{B} x {E} {kind}: {a1.last_kernels} vs {ref.last_kernels}: mismatching steps between two fused engines {bad}, worst vs two-launch path {worst:.4f} x tol', flush=True)
+    assert bad == 0 and worst < 0.5
+print('finish stress ok')
