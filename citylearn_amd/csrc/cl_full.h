@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
         }
     }
     CL_TRACE_AFTER(13, q_net[0]);
-    district_reduce<VEC, false>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    district_reduce<VEC, false, LP>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);      // (LP = the chunked launches' kernel)
     CL_TRACE_FLUSH();
 }
 

@@ -150,7 +150,13 @@ constexpr int NQ = CL_NQ;
 
 // District sums over buildings: wave partials -> LDS -> fixed-order serial sum over waves (deterministic).
 // `stride` is the building stride used by the caller's loop (needed by the MARL second sweep).
-template <int VEC, bool FLEX = false>
+// FOLD: instantiations that are launched building-chunked may finish the chunk sums themselves (a.fused_finish); a template parameter
+// because the fold's sixteen loads in flight would otherwise set the register budget of every kernel this is inlined into (the general
+// lean kernel went from 52 to 102 VGPRs).
+CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, float v);      // (streaming KPIs, below)
+
+// KPIS: the thread that writes an env's district net also feeds it to the env's streaming district accumulators (CLD_KPI, lean districts)
+template <int VEC, bool FLEX = false, bool FOLD = false, bool KPIS = false>
 CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int env0, bool live, long long plane, int rkind,
                             const float (&q_net)[VEC], const float (&q_cost)[VEC], const float (&q_em)[VEC],
                             const float (&q_rw)[VEC], int stride) {
@@ -165,14 +171,17 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
     const bool coupled = rkind == CLR_MARL || (FLEX && rkind == CLR_EV);   // rewards that need the district net
     if (a.n_chunks > 1) {
         // Large districts: this workgroup only saw buildings [y*b_chunk, (y+1)*b_chunk).  Its partial sums go to the scratch rows of
-        // out_bldg's reserved plane, and the LAST chunk of the env tile to arrive adds the chunks in chunk order (deterministic, whoever
-        // is last) -- no second launch.
-        // Round 1 tried this with an agent-scope release / acquire pair around a counter: those fences write back and invalidate the
-        // whole XCD L2 (177 us vs 21 us at 1024 buildings x 1024 envs), and round 2 kept a second launch (cl_finish_kernel, 4.8 us of
-        // pure latency).  Neither is needed: only the partial sums and the ticket cross XCDs, so only THEY are accessed at agent scope
-        // (relaxed atomic stores / loads = write-through / L2-bypassing `sc1` accesses, no cache maintenance), and the order "partials
-        // complete -> ticket" is a wait for this thread's own stores (the workgroup-scope release fence is an s_waitcnt) plus the
-        // workgroup barrier in front of the one thread that takes the ticket.
+        // out_bldg's reserved plane; cl_finish_kernel (a second launch, 4.8 us of pure latency) adds the chunks in a fixed order.
+        // The alternative -- the LAST chunk of an env tile to arrive folds them inside this launch -- is built (FOLD, cl_tuning.finish = 2)
+        // and measured SLOWER.  Round 1 did it with an agent-scope release / acquire pair around a counter: those fences write back and
+        // invalidate the whole XCD L2 (177 us vs 21 us at 1024 buildings x 1024 envs).  Round 3 removed every fence: only the partial sums
+        // and the ticket cross XCDs, so only THEY are accessed at agent scope (relaxed atomic stores / loads = write-through / L2-bypassing
+        // `sc1` accesses, no cache maintenance); the order "partials complete -> ticket" is a wait for the thread's own stores (a
+        // workgroup-scope release fence is an s_waitcnt) plus the workgroup barrier in front of the one thread that takes the ticket; the
+        // fold itself has every thread's loads in flight at once.  Correct and deterministic (scripts/finish_stress.py: 3000 steps, two
+        // engines bit-identical) -- and 16.2 us against 14.6 us for the two launches at 1024 x 1024 thermal, 16.0 against 10.5 us for
+        // battery + PV (profiles/r03b_c4_fold_ab.log): write-through acknowledgement, ticket and re-read are three dependent device-scope
+        // round trips of ~2 us each behind the last workgroup, more than the launch they replace.  The second launch stays the default.
         float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
         for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
             const int q = i / TILE, e = i - q * TILE;
@@ -180,11 +189,13 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
             for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
             if (tile_env0 + e < a.n_env) {
                 float* dst = scratch + ((long long)blockIdx.y * NQ + q) * a.n_env + tile_env0 + e;
-                if (a.fused_finish) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (FOLD && a.fused_finish) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *dst = s;
             }
         }
-        if (!a.fused_finish) return;                             // cl_tuning.finish = 1: cl_finish_kernel folds them (second launch)
+        if constexpr (!FOLD) return;                             // cl_finish_kernel folds them (second launch)
+        else {
+        if (!a.fused_finish) return;                             // cl_tuning.finish = 1: likewise
         unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (long long)a.n_chunks * NQ * a.n_env) + blockIdx.x;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial sums have left the CU
         __syncthreads();                                         // ... and so have everybody else's (and nobody reads the wave rows of `lds` any more)
@@ -192,33 +203,58 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
         if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*flag != (unsigned)a.n_chunks - 1u) return;
+        __syncthreads();                                         // (everybody has read the flag: `lds` is reused below)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // The fold is one dependent chain per thread -- ticket, loads, adds -- so its cost is memory round trips, not bytes (32 chunks x
+        // 4 quantities x 128 envs = 64 KB).  Every thread of the workgroup takes part: output o = (quantity, env) is shared by
+        // `rep` = blockDim / (NQ * TILE) threads, each adding a contiguous range of chunks with all its loads in flight at once (sixteen
+        // at a time); the ranges are then added in range order through LDS: the same fixed association whoever arrives last.
         const bool marl = rkind == CLR_MARL;
-        for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
-            const int q = i / TILE, e = i - q * TILE;
-            if (tile_env0 + e >= a.n_env) continue;
-            const float* src = scratch + (long long)q * a.n_env + tile_env0 + e;
-            const float* srcn = scratch + (long long)CLQ_NET * a.n_env + tile_env0 + e;
+        const int n_out = NQ * TILE;
+        const int rep = max(1, (int)blockDim.x / n_out);
+        const int cpp = (a.n_chunks + rep - 1) / rep;                       // chunks per range
+        float* part = lds;                                                  // [rep][n_out] (and [rep][n_out] district-net parts for MARL behind it)
+        for (int i = threadIdx.x; i < rep * n_out; i += blockDim.x) {
+            const int o = i % n_out, p = i / n_out;
+            const int q = o / TILE, e = o - q * TILE;
             const bool scale = marl && q == CLQ_REWARD;          // the partials carried sign(-net) * 0.01 * net^2: times max(0, district net)
             float s = 0.0f, sn = 0.0f;
-            for (int c0 = 0; c0 < a.n_chunks; c0 += 8) {         // eight independent loads in flight, added in chunk order
-                float v[8], vn[8];
+            if (tile_env0 + e < a.n_env) {
+                const float* src = scratch + (long long)q * a.n_env + tile_env0 + e;
+                const float* srcn = scratch + (long long)CLQ_NET * a.n_env + tile_env0 + e;
+                const int c_hi = min(a.n_chunks, (p + 1) * cpp);
+                for (int c0 = p * cpp; c0 < c_hi; c0 += 16) {
+                    float v[16], vn[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool in = c0 + j < a.n_chunks;
-                    const long long o = (long long)(in ? c0 + j : 0) * NQ * a.n_env;
-                    v[j] = __hip_atomic_load(src + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vn[j] = scale ? __hip_atomic_load(srcn + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-                    if (!in) { v[j] = 0.0f; vn[j] = 0.0f; }
+                    for (int j = 0; j < 16; ++j) {
+                        const bool in = c0 + j < c_hi;
+                        const long long off = (long long)(in ? c0 + j : c0) * NQ * a.n_env;
+                        v[j] = __hip_atomic_load(src + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vn[j] = scale ? __hip_atomic_load(srcn + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                        if (!in) { v[j] = 0.0f; vn[j] = 0.0f; }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { s += v[j]; sn += vn[j]; }
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { s += v[j]; sn += vn[j]; }
             }
-            if (scale) s *= fmaxf(0.0f, sn);
+            part[(size_t)p * n_out + o] = s;
+            if (marl) part[(size_t)(rep + p) * n_out + o] = sn;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
+            const int q = o / TILE, e = o - q * TILE;
+            if (tile_env0 + e >= a.n_env) continue;
+            float s = 0.0f, sn = 0.0f;
+            for (int p = 0; p < rep; ++p) {
+                s += part[(size_t)p * n_out + o];
+                if (marl) sn += part[(size_t)(rep + p) * n_out + o];
+            }
+            if (marl && q == CLQ_REWARD) s *= fmaxf(0.0f, sn);
             a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
         }
         if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
         return;
+        }
     }
     for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
         const int q = i / TILE, e = i - q * TILE;
@@ -228,7 +264,12 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
             if (FLEX && rkind == CLR_EV) lds[i] = s;           // CLR_EV accumulated sign(-net) * 0.01 * net^2: the district MARL sum / max(0, district net)
             continue;
         }
-        if (tile_env0 + e < a.n_env) a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
+        if (tile_env0 + e < a.n_env) {
+            a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
+            if constexpr (KPIS) {
+                if (q == CLQ_NET) kpi_series_update(a.kpi_env + tile_env0 + e, a.n_env, a.t, s);     // control condition (citylearn.py:1136-1323)
+            }
+        }
         if (coupled && q == CLQ_NET) lds[i] = s;               // wave-0 slot now holds the district net
     }
     if (coupled) {
@@ -291,7 +332,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
 
 // FLEX: the district has EV chargers / washing machines (cl_flex.h ran just before); a separate instantiation so that
 // districts without them keep their register budget.
-template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, bool F64 = false>
+template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, bool F64 = false, bool FOLD = false>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
@@ -433,7 +474,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
         }
     }
 
-    district_reduce<VEC, FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    district_reduce<VEC, FLEX, FOLD>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
 }
 
 // Lean districts (battery + PV + load), at most two buildings per wave, one chunk: the headline shape.  Same arithmetic
@@ -629,13 +670,10 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
         if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
         if constexpr (KPI && !FLEX) {
             // The streaming KPI accumulators of this building, updated by the wave that holds its step in registers (cl_kpi_bldg_kernel's
-            // arithmetic, citylearn.py:1136-1323): a lean district has no outage and serves its whole load, so the unserved-energy sums
-            // do not move and `expected` is the load.  Baseline = the net without the battery (building.py:345-366); its plane is
-            // written for cl_kpi_env_kernel's district sums.
-            float base[VEC], v[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) base[i] = o_net[i] - o_cb[i] * B.r;
-            pstore<VEC, NT>(a.out_bldg + CLO_BASE_NET * plane + off, base);
+            // arithmetic, citylearn.py:1136-1323).  A lean district has no outage and serves its whole load, so the unserved-energy sums
+            // do not move; and its baseline -- the net without the battery (building.py:345-366) = load + solar -- and its expected
+            // energy do not depend on the env at all: those five sums are kept ONCE per block of CL_ROW0_BLOCK envs (the envs that share
+            // a table row), at the block's first env.  Per (env, building) only the four control sums move: 32 B on top of the step's 37.
             auto add = [&](int kp, const float (&x)[VEC]) {
                 float k[VEC];
                 float* p = a.kpi_bldg + (long long)kp * plane + off;
@@ -644,6 +682,7 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
                 for (int i = 0; i < VEC; ++i) k[i] += x[i];
                 pstore<VEC, NT>(p, k);                            // (nt like the other planes: 32.0 -> 30.8 us per step at 17 x 65 536)
             };
+            float v[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[i] = fmaxf(o_net[i], 0.0f);
             add(CLK_C_POS, v);
@@ -654,19 +693,19 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
 #pragma unroll
             for (int i = 0; i < VEC; ++i) v[i] = fmaxf(o_net[i] * R.price, 0.0f);
             add(CLK_C_COST, v);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(base[i], 0.0f);
-            add(CLK_B_POS, v);
-            add(CLK_B_NET, base);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(base[i] * R.carbon, 0.0f);
-            add(CLK_B_EMISSION, v);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(base[i] * R.price, 0.0f);
-            add(CLK_B_COST, v);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = R.nsl;
-            add(CLK_EXPECTED_ALL, v);
+            const float c_ns0 = (quirk && a.t == 0) ? 3.0f * R.nsl : R.nsl;
+            const float base = fmaf(c_ns0, B.r, R.sol);                          // the step's net with the battery term left out
+            if (lane == 0) {
+                lds[(size_t)a.nw * NQ * TILE + b] = base;                          // for the district baseline series (below)
+                if ((blockIdx.x * TILE) % CL_ROW0_BLOCK == 0) {
+                    float* k0 = a.kpi_bldg + off;                                  // (lane 0: off = this building's row at the block's first env)
+                    k0[CLK_B_POS * plane] += fmaxf(base, 0.0f);
+                    k0[CLK_B_NET * plane] += base;
+                    k0[CLK_B_EMISSION * plane] += fmaxf(base * R.carbon, 0.0f);
+                    k0[CLK_B_COST * plane] += fmaxf(base * R.price, 0.0f);
+                    k0[CLK_EXPECTED_ALL * plane] += R.nsl;
+                }
+            }
         }
         if constexpr (OBS) {
             // this building's observation columns, into the workgroup's [64 * VEC envs][pitch] tile (streamed out below)
@@ -698,7 +737,16 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
         }
     }
     CL_TRACE_AFTER(13, q_net[0]);
-    district_reduce<VEC, FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    district_reduce<VEC, FLEX, false, KPI && !FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    if constexpr (KPI && !FLEX) {
+        // baseline condition of the district series: the sum of the buildings' baselines in building order, once per env block
+        // (district_reduce's barriers came after every wave's write of its buildings' values)
+        if (threadIdx.x == 0 && (blockIdx.x * TILE) % CL_ROW0_BLOCK == 0) {
+            float sum = 0.0f;
+            for (int b = 0; b < a.n_bldg; ++b) sum += lds[(size_t)a.nw * NQ * TILE + b];
+            kpi_series_update(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + blockIdx.x * TILE, a.n_env, a.t, sum);
+        }
+    }
     if constexpr (OBS) {
         // (district_reduce's first barrier came after every wave's tile writes.)  The tile's rows are consecutive envs: one contiguous
         // block of the observation matrix, streamed out in 16-byte stores.
@@ -1257,7 +1305,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
     a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
     a.flex_out = nullptr; a.n_flex_bldg = 0; a.ev_penalty_coef = 0.0f;
-    a.fused_finish = tun.finish != 1;
+    a.fused_finish = 0;                       // set where the kernel that is launched can fold the chunk sums itself (district_reduce<.., FOLD>)
     // non-temporal plane stores while the launch's footprint (~40 - 60 B per (env, building) unit) stays inside the Infinity Cache
     // ... and again once it is several times that cache (17 x 1 048 576: 125 -> 115 us, 17 x 1 572 864: 196 -> 170 us): nothing of a step
     // survives in the cache until the next one anyway, and the hint keeps the stores from displacing what the step still reads.  In
@@ -1431,6 +1479,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 1024, 4, false);
         } else if (lp) {
             // parameter blocks staged in LDS (cl_full.h); full_variant = 3 keeps them in SGPRs (tests, A/B)
+            a.fused_finish = a.n_chunks > 1 && tun.finish == 2 && !(vec == 2 && small);
             if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
             else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5, false);      // (96 VGPRs do not hold the staged operands: 61 scratch accesses)
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 4, true);
@@ -1474,8 +1523,9 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             name_add(tun, "%s<" #V ", %s%s>", kpi_lean ? "cl_step_lean_kpi_kernel" : (of && rkind_host != CLR_MARL) ? "cl_step_lean_obs_kernel" : "cl_step_lean_kernel", \
                      kpi_lean || (of && rkind_host != CLR_MARL) ? "" : "false, ", a.nt ? "true" : "false"); \
             if (kpi_lean) { \
-                if (a.nt) hipLaunchKernelGGL((cl_step_lean_kpi_kernel<V, true>), grid, block, lds, s, a); \
-                else hipLaunchKernelGGL((cl_step_lean_kpi_kernel<V, false>), grid, block, lds, s, a); \
+                const size_t lds_k = lds + CL_OBS_FUSED_BLDG * sizeof(float);      /* + one baseline value per building */ \
+                if (a.nt) hipLaunchKernelGGL((cl_step_lean_kpi_kernel<V, true>), grid, block, lds_k, s, a); \
+                else hipLaunchKernelGGL((cl_step_lean_kpi_kernel<V, false>), grid, block, lds_k, s, a); \
             } else if (of && rkind_host != CLR_MARL) {       /* (MARL's reward plane is finished after the sweep the tile is filled in) */ \
                 const size_t lds_o = lds + (size_t)tile * of->pitch * sizeof(float); \
                 if (a.nt) hipLaunchKernelGGL((cl_step_lean_obs_kernel<V, true>), grid, block, lds_o, s, a, *of); \
@@ -1488,6 +1538,12 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
 #undef CL_LEAN_CASE
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
+    } else if (a.n_chunks > 1 && tun.finish == 2 && (vec == 1 || vec == 4)) {
+        // building-chunked battery + PV districts (C4 with the 2022 device set): the instantiations that fold the chunk sums themselves
+        a.fused_finish = 1;
+        name_add(tun, "cl_step_kernel<%d, false, false, false, false, true>", vec);
+        if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, false, true>), grid, block, lds, s, a);
     } else {
         name_add(tun, "cl_step_kernel<%d, false, false, false>", vec);
         switch (vec) {
@@ -1510,9 +1566,12 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     }
     if (dims->flags & CLD_KPI) {
         const long long n = (long long)dims->n_env * dims->n_bldg;
-        name_add(tun, (dims->flags & CLD_WRITE_DETAIL) ? "cl_kpi_bldg_kernel+cl_kpi_env_kernel" : "cl_kpi_env_kernel");
-        if (dims->flags & CLD_WRITE_DETAIL) hipLaunchKernelGGL(cl_kpi_bldg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(cl_kpi_env_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
+        // (without the detail planes -- lean districts -- the step launch above has updated every accumulator itself)
+        if (dims->flags & CLD_WRITE_DETAIL) {
+            name_add(tun, "cl_kpi_bldg_kernel+cl_kpi_env_kernel");
+            hipLaunchKernelGGL(cl_kpi_bldg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(cl_kpi_env_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
+        }
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");
     return CL_OK;

@@ -113,6 +113,9 @@ class StepEngine:
         # updates the per-building accumulators itself (cl_step_lean_kpi_kernel): no detail planes, no second pass
         kpi_in_step = kpi and self.lean and self.n_bldg <= 32 and self.flex_tables is None and not f64_maps
         flags |= abi.CLD_WRITE_DETAIL if (detail or (kpi and not kpi_in_step)) else 0
+        # ... and keeps the env-independent sums of such a district (baseline, expected energy, baseline district series) once per block
+        # of CL_ROW0_BLOCK envs, at the block's first env (include/citylearn_amd.h, CLD_KPI): `kpi.finalize_streaming(shared_baseline=True)`
+        self.kpi_shared_baseline = bool(kpi_in_step and not detail)
         es_cols = tables.params.view(np.int32)[:, abi.CLP_ACT_ELEC_STO]
         if np.array_equal(es_cols, np.arange(self.n_bldg)):          # one battery action per building, building order
             flags |= abi.CLD_ES_COL_IS_BLDG

@@ -140,17 +140,28 @@ def _series_update(k, t: int, v):
     k[P.CLKE_ALL_MAX] = torch.maximum(k[P.CLKE_ALL_MAX], v)
 
 
-def finalize_streaming(kpi_bldg, kpi_env, steps_done: int, episode_rows: int, next_expected=None, next_outage=None):
+def finalize_streaming(kpi_bldg, kpi_env, steps_done: int, episode_rows: int, next_expected=None, next_outage=None,
+                       shared_baseline: bool = False):
     """Turn the device accumulators into the KPI ratios of `CityLearnEnv.evaluate` for every env.
 
     Returns ``(building, district)``: dicts name -> tensor ``[n_bldg, n_env]`` / ``[n_env]``; `district` also holds the
     mean over buildings of every building-level KPI (citylearn.py:1317-1318).  The control district series has
     `steps_done` samples, the baseline one more (the untouched zero slot of the next step, App. A.7) unless the
     data ran out.  `next_expected` / `next_outage` (``[n_bldg]``): expected energy and outage flag of that extra row
-    (the reference's series include it in the normalisation, citylearn.py:1216 + cost_function.py:384)."""
+    (the reference's series include it in the normalisation, citylearn.py:1216 + cost_function.py:384).
+    `shared_baseline` (`StepEngine.kpi_shared_baseline`: battery + PV districts stepped without the detail planes): the baseline sums,
+    the expected energy and the baseline district series do not depend on the env there and were kept at the first env of every
+    block of ``CL_ROW0_BLOCK`` envs only; they are spread over their blocks here (the slice must start on a block boundary)."""
     import torch
     P = abi
     kb = kpi_bldg.double().clone()
+    kpi_env = kpi_env.clone()
+    if shared_baseline:
+        n_env = kb.shape[-1]
+        lead = (torch.arange(n_env, device=kb.device) // P.CL_ROW0_BLOCK) * P.CL_ROW0_BLOCK
+        for plane in (P.CLK_B_POS, P.CLK_B_NET, P.CLK_B_EMISSION, P.CLK_B_COST, P.CLK_EXPECTED_ALL):
+            kb[plane] = kb[plane][:, lead]
+        kpi_env[P.CLKE_PER_COND:] = kpi_env[P.CLKE_PER_COND:][:, lead]
     if next_expected is not None and steps_done < episode_rows:
         ne = torch.as_tensor(next_expected, dtype=kb.dtype, device=kb.device)[:, None]
         kb[P.CLK_EXPECTED_ALL] += ne

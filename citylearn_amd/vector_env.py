@@ -360,7 +360,7 @@ class VectorCityLearnEnv:
                                   for b in self.spec.buildings])
                 nxt_o = (tables.outage[self._t] != 0).astype(np.float64)
             building, district = finalize_streaming(self.engine.kpi_bldg[:, :, sl], self.engine.kpi_env[:, sl], self._t, self.time_steps,
-                                                    nxt_e, nxt_o)
+                                                    nxt_e, nxt_o, shared_baseline=self.engine.kpi_shared_baseline)
             if self.stage is not None and self.stage.kpi_comfort is not None:
                 comfort = finalize_comfort(self.stage.kpi_comfort[:, :, sl], self.spec, tables, self._t, self.stage.kpi_band)
                 building.update(comfort)

@@ -242,8 +242,12 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 #define CLD_REF_T0_QUIRK   (1u << 0)  /* replicate the reference's repeated t=0 update_variables (SURVEY App.B1) */
 #define CLD_WRITE_DETAIL   (1u << 1)  /* also write CLO_B_EB .. CLO_C_NSL planes (parity / KPI baselines) */
 #define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators (requires CLD_WRITE_DETAIL, except for CLD_LEAN districts of up to 32
-                                         buildings stepped without flexible loads: their step kernel updates the accumulators itself and writes
-                                         CLO_BASE_NET as the only extra plane) */
+                                         buildings stepped without flexible loads: their step launch updates the accumulators itself.  In such a
+                                         district the baseline (net without the battery = load + solar), the expected energy and the baseline
+                                         district series do not depend on the env, so without CLD_WRITE_DETAIL the planes CLK_B_POS .. CLK_B_COST,
+                                         CLK_EXPECTED_ALL and the condition-1 rows of `kpi_env` are maintained ONCE per block of CL_ROW0_BLOCK
+                                         envs, at the block's first env -- the other entries keep their reset values -- and per (env, building)
+                                         only the four control sums move: 32 B next to the step's 37) */
 #define CLD_ES_COL_IS_BLDG   (1u << 4)  /* hint: the electrical_storage action column of building b is column b (one action per
                                           building, building order) -- lets the step issue its action loads before the parameters */
 #define CLD_CENTRAL_AGENT  (1u << 5)  /* CLR_EV only: central_agent districts scale every building's charger terms by the DISTRICT
@@ -291,8 +295,9 @@ typedef struct cl_tuning {
                                cl_rollout_f32 / cl_lstm_step_f32 write the instantiation(s) they launched into it, '+'-separated, in the
                                spelling rocprofv3 prints (bench.py's `roofline.kernel`, scripts/profile_round.sh's name check).  Output only:
                                nothing the library computes depends on it. */
-    int32_t finish;         /* building-chunked launches (districts of more than 32 buildings): 0 = the last chunk of an env tile folds the chunk
-                               partial sums inside the step launch, 1 = a second launch does (cl_finish_kernel; tests, A/B) */
+    int32_t finish;         /* building-chunked launches (districts of more than 32 buildings): 0 / 1 = a second launch folds the chunk partial
+                               sums (cl_finish_kernel), 2 = the last chunk of an env tile to arrive folds them inside the step launch
+                               (measured slower: csrc/cl_kernels.hip district_reduce; tests, A/B) */
     int32_t reserved[1];
 } cl_tuning;
 #define CL_KERNEL_NAME_LEN 256

@@ -1,6 +1,6 @@
-"""Building-chunked launches: the last chunk of an env tile folds the chunk partial sums in-kernel (district_reduce) -- a stress run for
+"""Building-chunked launches with cl_tuning.finish = 2: the last chunk of an env tile folds the chunk partial sums in-kernel (district_reduce) -- a stress run for
 the cross-XCD hand-off: 3000 steps at 1024 buildings x 1024 envs (and a ragged shape), every step's district sums compared bit for bit
-between two engines with the in-kernel fold, and within rounding with the two-launch path (cl_tuning.finish = 1)."""
+between two engines with the in-kernel fold, and within rounding with the two-launch path (the default)."""
 import sys
 from pathlib import Path
 import torch
@@ -15,8 +15,8 @@ for name, B, E, kind in (('citylearn_challenge_2020_climate_zone_1_744h', 1024, 
                          ('citylearn_challenge_2020_climate_zone_1_744h', 200, 772, 'MARL')):
     spec = tile_district(load_district(sample_schema(name)), B)
     tab = spec.episode_tables(0)
-    a1, a2 = StepEngine(tab, E, reward=kind), StepEngine(tab, E, reward=kind)
-    ref = StepEngine(tab, E, reward=kind, tuning=dict(finish=1))
+    a1, a2 = StepEngine(tab, E, reward=kind, tuning=dict(finish=2)), StepEngine(tab, E, reward=kind, tuning=dict(finish=2))
+    ref = StepEngine(tab, E, reward=kind)
     a1.trace_kernels(); ref.trace_kernels()
     low, high = spec.action_limits()
     lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
@@ -31,7 +31,11 @@ for name, B, E, kind in (('citylearn_challenge_2020_climate_zone_1_744h', 1024, 
             if not torch.equal(a1.out_env, a2.out_env):
                 bad += 1
             worst = max(worst, float(((a1.out_env - ref.out_env).abs() / (1e-4 + 1e-4 * ref.out_env.abs())).max()))
-            assert torch.equal(a1.out_bldg[:2], ref.out_bldg[:2])
+            assert torch.equal(a1.out_bldg[0], ref.out_bldg[0]) and torch.equal(a1.out_bldg[1], a2.out_bldg[1])
+            if kind == 'MARL':       # the per-building MARL reward multiplies by the district net, whose last bit depends on the summation order
+                torch.testing.assert_close(a1.out_bldg[1], ref.out_bldg[1], rtol=1e-4, atol=1e-5)
+            else:
+                assert torch.equal(a1.out_bldg[1], ref.out_bldg[1])
     torch.cuda.synchronize()
     print(f'{B} x {E} {kind}: {a1.last_kernels} vs {ref.last_kernels}: mismatching steps between two fused engines {bad}, worst vs two-launch path {worst:.4f} x tol', flush=True)
     assert bad == 0 and worst < 0.5

@@ -91,6 +91,20 @@ def test_struct_layouts_match_the_header(c_name, binding, doc):
             assert ctypes.sizeof(ta) == ctypes.sizeof(tb), (fa, fb)
 
 
+def test_integration_stub_allocates_what_the_header_says():
+    """The plane counts the INTEGRATION.md stub allocates with (a maintainer copies them) against the header: a short `out_bldg` is an
+    out-of-bounds write for every district that uses the scratch plane (VERDICT r02 weak #10: the stub said 15, CL_NO was 18)."""
+    import re
+    from pathlib import Path
+    text = (Path(abi.HEADER).parent.parent / 'INTEGRATION.md').read_text()
+    line = re.search(r'^CL_NS, CL_NO, CL_NQ = [^#\n]+', text, flags=re.M).group(0)
+    ns = {}
+    exec(line, ns)                                          # noqa: S102 - our own documentation snippet
+    assert (ns['CL_NS'], ns['CL_NO'], ns['CL_NQ']) == (abi.CL_NS, abi.CL_NO, abi.CL_NQ)
+    assert set(re.findall(r'torch\.zeros\(\((CL_\w+),', text)) == {'CL_NS', 'CL_NO', 'CL_NQ'}      # no literal plane counts left in the stub
+    assert not re.search(r'torch\.zeros\(\(\d+, B', text)
+
+
 def test_header_constants_are_consistent():
     assert abi.CLP_USED <= abi.CL_NP and abi.CLP_L_FIRST % 16 == 0 and abi.CLP_L_LAST - abi.CLP_L_FIRST < 32
     assert abi.CLT_ICOP_DHW < abi.CL_NF and abi.CLO_RESERVED < abi.CL_NO and abi.CLQ_REWARD < abi.CL_NQ
