@@ -228,13 +228,15 @@ class StepWorkload:
 
     dtype = 'f32'
 
-    def __init__(self, name: str, spec, E: int, device: str, rank: int, tuning: dict, what: str, lstm: bool = False, f64: bool = False):
+    def __init__(self, name: str, spec, E: int, device: str, rank: int, tuning: dict, what: str, lstm: bool = False, f64: bool = False, kpi: bool = False):
         import torch
         from citylearn_amd.engine import StepEngine
         self.name, self.what, self.E, self.device = name, what, E, device
         self.spec = spec
         self.tables = spec.episode_tables(0)
-        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, detail=lstm, f64_maps=f64)
+        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, detail=lstm, f64_maps=f64, kpi=kpi)
+        if kpi:
+            self.what += '; CLD_KPI: streaming KPI accumulators of evaluate() updated every step (mode A-kpi)'
         if f64:
             self.what += '; CLD_F64_MAPS: battery map in the reference\'s mixed float64 / float32 precision'
         self.eng.trace_kernels()
@@ -341,7 +343,7 @@ class RolloutWorkload:
                         'peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz'}
 
 
-def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning: dict, f64: bool = False):
+def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning: dict, f64: bool = False, kpi: bool = False):
     from citylearn_amd import load_district
     from citylearn_amd.data import sample_schema
     if cfg in ('headline', 'C2', 'C5'):
@@ -354,13 +356,13 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
         return StepWorkload(cfg, spec, E, device, rank, tuning,
                             f'citylearn_challenge_2022_phase_all tables (17 buildings, first 720 h) x {E} envs per GPU, '
                             'cl_step_f32 mode A (one env step per launch, state in HBM, fresh uniform random actions '
-                            'from an 8-tensor ring), env batch sharded over GPUs, no collective', f64=f64)
+                            'from an 8-tensor ring), env batch sharded over GPUs, no collective', f64=f64, kpi=kpi)
     if cfg == 'C3':
         spec = load_district(sample_schema('citylearn_challenge_2023_phase_2_local_evaluation_720h'))
         return StepWorkload(cfg, spec, E, device, rank, tuning,
                             f'citylearn_challenge_2023_phase_2_local_evaluation (3 buildings: power outages, partial-load cooling, DHW tank, battery; '
                             f'first 720 h) x {E} envs per GPU; one step = cl_step_f32 (energy step, detail planes) + cl_lstm_step_f32 (LSTM indoor '
-                            'temperature + ComfortReward): the whole CityLearnEnv.step of this schema', lstm=True, f64=f64)
+                            'temperature + ComfortReward): the whole CityLearnEnv.step of this schema', lstm=True, f64=f64, kpi=kpi)
     if cfg in ('C4', 'C4-lean'):
         from citylearn_amd.synthetic import tile_district
         base = 'citylearn_challenge_2020_climate_zone_1_744h' if cfg == 'C4' else 'citylearn_challenge_2022_phase_all_720h'
@@ -368,7 +370,7 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
         return StepWorkload(cfg, spec, E, device, rank, tuning,
                             f'synthetic 1024-building district ({"2020 climate-zone-1 device set: heat pump, heater, 2 tanks, battery" if cfg == "C4" else "battery + PV"}'
                             f'; sizes jittered +-10 %) x {E} envs per GPU (8 GPUs x 1024 = the 8192 envs of BASELINE config 4), cl_step_f32 mode A, '
-                            'building-chunked launch, no collective', f64=f64)
+                            'building-chunked launch, no collective', f64=f64, kpi=kpi)
     raise SystemExit(f'unknown --config {cfg}')
 
 
@@ -435,7 +437,7 @@ def run_rank(args):
         mine = statistics.median(w for w, _ in rep)
         return walls, evs, reduce_max_seconds(kernel_s, dist, ctl_device), gather_seconds(mine, dist, ctl_device)
 
-    wl = build_workload(cfg, E, device, rank, world, tuning, args.f64_maps)
+    wl = build_workload(cfg, E, device, rank, world, tuning, args.f64_maps, args.kpi)
     heavy = cfg in ('C3', 'C5')                          # ~100 us .. 1 ms per step: fewer steps in the kernel-time bracket
     walls, evs, launch_s, per_rank = measure(wl, args.warmup, args.steps, args.reps, max(args.steps, 200 if heavy else 2000))
     wall_med = statistics.median(walls)
@@ -456,7 +458,7 @@ def run_rank(args):
         del wl
         torch.cuda.empty_cache()
         s_steps = 20
-        wl_s = build_workload(cfg, STREAMING_ENVS, device, rank, world, tuning, args.f64_maps)
+        wl_s = build_workload(cfg, STREAMING_ENVS, device, rank, world, tuning, args.f64_maps, args.kpi)
         _, _, launch, _ = measure(wl_s, 5, s_steps, 3, 2000)
         a = wl_s.units_per_step * wl_s.bytes_per_unit() / launch / 1e9
         s_traffic, s_source = _pmc_traffic('r*_streaming_pmc_summary.json', wl_s.kernels or '')
@@ -514,6 +516,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-streaming', action='store_true', help='skip the 17 x 1 048 576 HBM-streaming roofline entry of the headline')
     ap.add_argument('--f64-maps', action='store_true', help="CLD_F64_MAPS: battery map in the reference's mixed float64 / float32 precision (step configs)")
+    ap.add_argument('--kpi', action='store_true', help='CLD_KPI: update the streaming KPI accumulators every step (mode A-kpi of SURVEY 8d; step configs)')
     ap.add_argument('--launch-timeout', type=float, default=None, help='seconds after which self-spawned ranks are terminated')
     args = ap.parse_args(argv)
     heavy = args.config in ('C3', 'C5')

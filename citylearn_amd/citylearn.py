@@ -46,8 +46,8 @@ class _BuildingView:
 
     def __init__(self, env: 'CityLearnEnv', index: int):
         self._env, self._i = env, index
-        self.spec = env.spec.buildings[index]
-        self.name = self.spec.name
+        self.bspec = env.district_spec.buildings[index]
+        self.name = self.bspec.name
 
     @property
     def active_observations(self) -> List[str]:
@@ -55,19 +55,19 @@ class _BuildingView:
 
     @property
     def active_actions(self) -> List[str]:
-        return self.spec.active_actions
+        return self.bspec.active_actions
 
     @property
     def action_metadata(self) -> Dict[str, bool]:
-        return dict(self.spec.action_metadata)
+        return dict(self.bspec.action_metadata)
 
     @property
     def observation_metadata(self) -> Dict[str, bool]:
-        return dict(self.spec.observation_metadata)
+        return dict(self.bspec.observation_metadata)
 
     @property
     def action_space(self) -> Box:
-        lo, hi = self.spec.action_space_limits(self._env.spec.simulation_start_time_step, self._env.spec.simulation_end_time_step)
+        lo, hi = self.bspec.action_space_limits(self._env.district_spec.simulation_start_time_step, self._env.district_spec.simulation_end_time_step)
         return Box(low=lo, high=hi, dtype=np.float32)
 
     def _series(self, key: str) -> np.ndarray:
@@ -126,8 +126,19 @@ for _suffix in _CONDITION_SUFFIXES:
                 property(lambda self, s=_suffix, k=_kind: self._condition(s, k)))
 
 
-class CityLearnEnv:
-    """One CityLearn district stepped on the GPU.  See the module docstring for the mirrored interface."""
+try:                                       # pragma: no cover - depends on the environment
+    from gymnasium import Env as _GymEnv   # the reference's CityLearnEnv is a gymnasium.Env (citylearn.py:52): wrappers assert isinstance
+except Exception:                          # noqa: BLE001 - gymnasium is optional (not part of this image)
+    _GymEnv = object
+
+
+class CityLearnEnv(_GymEnv):
+    """One CityLearn district stepped on the GPU.  See the module docstring for the mirrored interface.  A `gymnasium.Env` subclass
+    when gymnasium is importable, like the reference's (citylearn.py:52), so that `gymnasium.Wrapper` subclasses -- the reference's
+    own wrappers among them -- accept it; the loaded district is `district_spec` (`spec` belongs to gymnasium there)."""
+    metadata = {'render_modes': []}
+    if _GymEnv is object:
+        spec = property(lambda self: self.district_spec, doc='the loaded district (`district_spec`); gymnasium owns this name when it is installed')
 
     def __init__(self, schema: Union[str, Path, Mapping[str, Any]], device: str = 'cuda:0',
                  observation_mode: str = 'reference', reference_quirks: bool = True, ev_seed: int = None,
@@ -141,33 +152,33 @@ class CityLearnEnv:
         `ev_soc_drift` ([episode steps, n_ev]) replays given multipliers instead."""
         if observation_mode not in ('reference', 'current'):
             raise ValueError("observation_mode must be 'reference' or 'current'")
-        self.spec: DistrictSpec = load_district(schema, **kwargs)
-        self.electric_vehicles = list(self.spec.electric_vehicles)
+        self.district_spec: DistrictSpec = load_district(schema, **kwargs)
+        self.electric_vehicles = list(self.district_spec.electric_vehicles)
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
         self.device = device
         self.observation_mode = observation_mode
         self.reference_quirks = reference_quirks
-        self.central_agent = self.spec.central_agent
-        self.shared_observations = list(self.spec.shared_observations)
-        self.random_seed = self.spec.random_seed
-        self.seconds_per_time_step = self.spec.seconds_per_time_step
+        self.central_agent = self.district_spec.central_agent
+        self.shared_observations = list(self.district_spec.shared_observations)
+        self.random_seed = self.district_spec.random_seed
+        self.seconds_per_time_step = self.district_spec.seconds_per_time_step
         # configuration read-backs of the reference env (citylearn.py:207-450)
-        self.schema = self.spec.schema
-        self.root_directory = self.spec.root_directory
-        self.simulation_start_time_step = self.spec.simulation_start_time_step
-        self.simulation_end_time_step = self.spec.simulation_end_time_step
-        self.episode_time_steps = self.spec.episode_time_steps
-        self.rolling_episode_split = self.spec.rolling_episode_split
-        self.random_episode_split = self.spec.random_episode_split
+        self.schema = self.district_spec.schema
+        self.root_directory = self.district_spec.root_directory
+        self.simulation_start_time_step = self.district_spec.simulation_start_time_step
+        self.simulation_end_time_step = self.district_spec.simulation_end_time_step
+        self.episode_time_steps = self.district_spec.episode_time_steps
+        self.rolling_episode_split = self.district_spec.rolling_episode_split
+        self.random_episode_split = self.district_spec.random_episode_split
         self.render_enabled = False                 # rendering / export are outside the step path
-        rf_cls = resolve_reward(self.spec.reward_function.get('type'))
-        self.reward_function: RewardFunction = rf_cls(None, **(self.spec.reward_function.get('attributes') or {}))
-        self.buildings = [_BuildingView(self, i) for i in range(len(self.spec.buildings))]
+        rf_cls = resolve_reward(self.district_spec.reward_function.get('type'))
+        self.reward_function: RewardFunction = rf_cls(None, **(self.district_spec.reward_function.get('attributes') or {}))
+        self.buildings = [_BuildingView(self, i) for i in range(len(self.district_spec.buildings))]
         self._episode = -1
         self._engine = None
         self.__rewards: List[List[float]] = [[]]
         self.__episode_rewards: List[Mapping[str, Any]] = []
-        self._layout = ObservationLayout(self.spec, observation_mode, False, reference_quirks)
+        self._layout = ObservationLayout(self.district_spec, observation_mode, False, reference_quirks)
         self._obs_names = self._layout.raw_names
         self.reward_function.env_metadata = self.get_metadata()
         self.reset()
@@ -180,8 +191,8 @@ class CityLearnEnv:
     @property
     def action_names(self) -> List[List[str]]:
         if self.central_agent:
-            return [[k for b in self.spec.buildings for k in b.active_actions]]
-        return [list(b.active_actions) for b in self.spec.buildings]
+            return [[k for b in self.district_spec.buildings for k in b.active_actions]]
+        return [list(b.active_actions) for b in self.district_spec.buildings]
 
     @property
     def action_space(self) -> List[Box]:
@@ -210,7 +221,7 @@ class CityLearnEnv:
                 'heating_device': {'nominal_power': b.heating_device.nominal_power},
                 'dhw_device': {'nominal_power': b.dhw_device.nominal_power}, 'pv': {'nominal_power': b.pv_nominal_power},
                 'action_metadata': dict(b.action_metadata), 'observation_metadata': dict(b.observation_metadata),
-            } for b in self.spec.buildings],
+            } for b in self.district_spec.buildings],
         }
 
     # ---- episode state ---------------------------------------------------------------------------------------
@@ -229,7 +240,7 @@ class CityLearnEnv:
     @property
     def time_step_ratio(self) -> float:
         """Control step over data-file step (the value the reference env hands every building, citylearn.py:2183, 939-944)."""
-        return float(self.spec.buildings[0].time_step_ratio)
+        return float(self.district_spec.buildings[0].time_step_ratio)
 
     @property
     def episode_tracker(self):
@@ -290,7 +301,7 @@ class CityLearnEnv:
 
     def _history_array(self, key: str) -> np.ndarray:
         rows = self._hist[key]
-        B = len(self.spec.buildings)
+        B = len(self.district_spec.buildings)
         return np.array(rows, dtype='float32').reshape(len(rows), B)
 
     # ---- reset / step ----------------------------------------------------------------------------------------
@@ -301,7 +312,7 @@ class CityLearnEnv:
             self.random_seed = seed
         self._episode += 1
         exponent = getattr(self.reward_function, 'exponent', 1.0)
-        self._tables = self.spec.episode_tables(self._episode, self.random_seed, reward_exponent=float(exponent))
+        self._tables = self.district_spec.episode_tables(self._episode, self.random_seed, reward_exponent=float(exponent))
         kind = getattr(type(self.reward_function), 'device_kind', None)
         stock = type(self.reward_function).calculate is _stock_calculate(type(self.reward_function))
         self._fused_comfort = stock and kind == 'comfort'
@@ -316,10 +327,10 @@ class CityLearnEnv:
         self._prev_ev_soc = None
         # adjacent LSTM indoor-temperature stage (LSTMDynamicsBuilding, building.py:3000-3078) with the fused ComfortReward
         self._stage = None
-        if any(b.is_dynamics for b in self.spec.buildings):
+        if any(b.is_dynamics for b in self.district_spec.buildings):
             from .dynamics import LSTMStage
             rf = self.reward_function
-            self._stage = LSTMStage(self.spec, self._tables, self._engine, getattr(rf, 'band', None),
+            self._stage = LSTMStage(self.district_spec, self._tables, self._engine, getattr(rf, 'band', None),
                                     getattr(rf, 'lower_exponent', 2.0), getattr(rf, 'higher_exponent', 2.0))
         self._torch = torch
         self._t = 0
@@ -334,14 +345,14 @@ class CityLearnEnv:
     def _parse_actions(self, actions: Sequence[Sequence[float]]) -> np.ndarray:
         """List-of-lists -> flat action-column vector, with the reference's count checks (citylearn.py:1063-1134)."""
         actions = list(actions)
-        sizes = [len(b.active_actions) for b in self.spec.buildings]
+        sizes = [len(b.active_actions) for b in self.district_spec.buildings]
         if self.central_agent:
             flat = list(actions[0])
             expected = sum(sizes)
             assert len(flat) == expected, f'Expected {expected} actions but {len(flat)} were parsed to env.step.'
         else:
             per_b = [list(a) for a in actions]
-            for b, a, n in zip(self.spec.buildings, per_b, sizes):
+            for b, a, n in zip(self.district_spec.buildings, per_b, sizes):
                 assert len(a) == n, f'Expected {n} for {b.name} but {len(a)} actions were provided.'
             assert len(per_b) == len(sizes), f'Expected {len(sizes)} action lists but {len(per_b)} were provided.'
             flat = [x for a in per_b for x in a]
@@ -372,7 +383,7 @@ class CityLearnEnv:
             h[key].append(ob[plane])
         # Battery.charge and Building.update_variables both book the energy balance at t = 0 (building.py:2650-2652 runs in
         # reset too), and ElectricDevice.electricity_consumption is scaled by the time-step ratio like the planes above
-        ratio = np.array([b.time_step_ratio for b in self.spec.buildings], dtype='float32')
+        ratio = np.array([b.time_step_ratio for b in self.district_spec.buildings], dtype='float32')
         h['c_b'].append(ob[abi.CLO_B_EB] * ratio * (2.0 if t == 0 and self.reference_quirks else 1.0))
         h['solar'].append(ts[:, abi.CLT_SOLAR].astype('float32'))
         net64 = ob[abi.CLO_NET].astype(np.float64)
@@ -380,7 +391,7 @@ class CityLearnEnv:
         h['emission'].append(np.maximum(0.0, net64 * ts[:, abi.CLT_CARBON]).astype('float32'))
         h['d_net'].append(float(oe[abi.CLQ_NET])); h['d_cost'].append(float(oe[abi.CLQ_COST])); h['d_emission'].append(float(oe[abi.CLQ_EMISSION]))
         w_row = self._tables.start + t
-        temps = np.array([b.series['indoor_dry_bulb_temperature'][w_row] for b in self.spec.buildings], dtype='float32')
+        temps = np.array([b.series['indoor_dry_bulb_temperature'][w_row] for b in self.district_spec.buildings], dtype='float32')
         comfort = None
         if self._stage is not None:
             temps = self._stage.step(t)[:, 0].cpu().numpy()
@@ -418,7 +429,7 @@ class CityLearnEnv:
         """`Building.observations(include_all=True)` at step t for host-side reward plugins (citylearn.py:1022)."""
         out = []
         tab = self._tables
-        for i, b in enumerate(self.spec.buildings):
+        for i, b in enumerate(self.district_spec.buildings):
             d: Dict[str, float] = {}
             for k, v in b.series.items():
                 if isinstance(v, np.ndarray):
@@ -455,7 +466,7 @@ class CityLearnEnv:
             d['washing_machine_electricity_consumption'] = 0.0
         for fb, bldg in enumerate(ft.flex_bldg):
             out[bldg]['washing_machine_electricity_consumption'] = float(flex_out[abi.CLX_LOAD, fb] - flex_out[abi.CLX_CHARGERS, fb])
-        chargers = [c for b in self.spec.buildings for c in b.chargers]
+        chargers = [c for b in self.district_spec.buildings for c in b.chargers]
         for j, ((i, cid), c) in enumerate(zip(ft.charger_ids, chargers)):
             k = int(ft.charger_row(j)[t, abi.CLCT_EV])
             info = {'connected': k >= 0, 'last_charged_kwh': float(charger_out[1, j]) if k >= 0 else 0.0, 'previous_battery_soc': None,
@@ -463,14 +474,14 @@ class CityLearnEnv:
                     'hours_until_departure': None, 'max_charging_power': c.max_charging_power,
                     'max_discharging_power': c.max_discharging_power}
             if k >= 0:
-                battery = self.spec.electric_vehicles[k].battery
+                battery = self.district_spec.electric_vehicles[k].battery
                 info.update(previous_battery_soc=battery.initial_soc if t == 0 else float(self._prev_ev_soc[k]),
                             battery_soc=float(ev_soc[k]), battery_capacity=battery.capacity,
                             min_capacity=(1 - battery.depth_of_discharge) * battery.capacity,
                             required_soc=float(ft.charger_row(j)[t, abi.CLCT_REQUIRED_SOC]),
                             hours_until_departure=int(ft.charger_row(j)[t, abi.CLCT_DEPARTURE]))
             out[i]['electric_vehicles_chargers_dict'][cid] = info
-        wms = [w for b in self.spec.buildings for w in b.washing_machines]
+        wms = [w for b in self.district_spec.buildings for w in b.washing_machines]
         for (i, name), w in zip(ft.wm_names, wms):
             out[i]['washing_machines_dict'][name] = {'wm_start_time_step': int(w.series['wm_start_time_step'][t]),
                                                      'wm_end_time_step': int(w.series['wm_end_time_step'][t]),
@@ -487,11 +498,11 @@ class CityLearnEnv:
         series = None
         if control_condition is not None or baseline_condition is not None:
             suffix = lambda c: getattr(c, 'value', c)
-            dyn = any(b.is_dynamics for b in self.spec.buildings[:1])       # the first building fixes the defaults (citylearn.py:1194-1200)
+            dyn = any(b.is_dynamics for b in self.district_spec.buildings[:1])       # the first building fixes the defaults (citylearn.py:1194-1200)
             control = '' if control_condition is None else suffix(control_condition)
             baseline = ('_without_storage_and_partial_load' if dyn else '_without_storage') if baseline_condition is None else suffix(baseline_condition)
             series = (self._condition_series(control), self._condition_series(baseline), control)
-        return evaluate_district(self.spec, self._tables, self._t, h('net'), h('base_net'), h('cost'), h('emission'),
+        return evaluate_district(self.district_spec, self._tables, self._t, h('net'), h('base_net'), h('cost'), h('emission'),
                                  h('expected'), h('served'), np.array(self._hist['d_net'], dtype=np.float64), comfort_band,
                                  indoor_temp=h('indoor_temp'), condition_series=series)
 
@@ -499,22 +510,22 @@ class CityLearnEnv:
         """``[K, n_bldg]`` series `Building.net_electricity_consumption<suffix>` (building.py:320-366, 2850-2905); ``only``: one
         building's column (the partial-load conditions exist on dynamics buildings only)."""
         if only is not None:
-            if 'partial_load' in suffix and not self.spec.buildings[only].is_dynamics:
-                raise AttributeError(f"building {self.spec.buildings[only].name} has no attribute 'net_electricity_consumption{suffix}' (not a dynamics building)")
+            if 'partial_load' in suffix and not self.district_spec.buildings[only].is_dynamics:
+                raise AttributeError(f"building {self.district_spec.buildings[only].name} has no attribute 'net_electricity_consumption{suffix}' (not a dynamics building)")
             key = {'': 'net', '_without_storage': 'net_ws', '_without_storage_and_pv': 'net_ws'}.get(suffix, 'base_net')
             out = self._history_array(key)[:, only]
             return out - self._tables.ts[:self._t, only, abi.CLT_SOLAR].astype(np.float32) if suffix.endswith('_and_pv') else out
         h = self._history_array
         K = self._t
         solar = self._tables.ts[:K, :, abi.CLT_SOLAR].astype(np.float32)          # solar_generation (<= 0)
-        dynamics = np.array([b.is_dynamics for b in self.spec.buildings])
+        dynamics = np.array([b.is_dynamics for b in self.district_spec.buildings])
         if suffix == '':
             return h('net')
         if suffix in ('_without_storage', '_without_storage_and_pv'):
             out = h('net_ws')
         elif suffix in ('_without_storage_and_partial_load', '_without_storage_and_partial_load_and_pv'):
             if not dynamics.all():
-                name = next(b.name for b in self.spec.buildings if not b.is_dynamics)
+                name = next(b.name for b in self.district_spec.buildings if not b.is_dynamics)
                 raise AttributeError(f"building {name} has no attribute 'net_electricity_consumption{suffix}' (not a dynamics building)")
             out = h('base_net')
         else:

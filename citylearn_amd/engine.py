@@ -343,4 +343,11 @@ class StepEngine:
         for f in flags:
             planes += (5 if self.f64_maps else 3) * bool(f & abi.CLF_BATTERY) + bool(f & abi.CLF_COOL_STO) + bool(f & abi.CLF_HEAT_STO) + bool(f & abi.CLF_DHW_STO)
         planes /= self.n_bldg
-        return 8.0 * planes + 4.0 * self.n_act_cols / self.n_bldg + 8.0 + 4.0 * abi.CL_NQ / self.n_bldg
+        step = 8.0 * planes + 4.0 * self.n_act_cols / self.n_bldg + 8.0 + 4.0 * abi.CL_NQ / self.n_bldg
+        if not self.kpi:
+            return step
+        # mode A-kpi: four control sums read + written per unit, twelve district accumulators per env; where the baseline
+        # depends on the env (thermal / outage districts) four more per unit and twelve more per env
+        if self.kpi_shared_baseline:
+            return step + 32.0 + 8.0 * abi.CLKE_PER_COND / self.n_bldg
+        return step + 64.0 + 16.0 * abi.CLKE_PER_COND / self.n_bldg

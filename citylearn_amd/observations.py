@@ -363,7 +363,7 @@ class ObservationLayout:
         if k not in ENV_DEPENDENT or k in ('cooling_demand', 'heating_demand', 'dhw_demand'):
             return None
         ts = tab.ts[:, i].astype(np.float64)
-        pf = tab.params_f32()[i].astype(np.float64)
+        pf = tab.params_f32()[i][:abi.CLP_USED].astype(np.float64)        # (the float32 slots; the words behind them hold flags and float64 halves)
         ones = np.ones(tab.n_steps)
         const = {'electrical_storage_soc': pf[abi.CLP_B_SOC0], 'cooling_storage_soc': pf[abi.CLP_CS_SOC0],
                  'heating_storage_soc': pf[abi.CLP_HS_SOC0], 'dhw_storage_soc': pf[abi.CLP_DS_SOC0]}

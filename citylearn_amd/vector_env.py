@@ -163,6 +163,11 @@ class VectorCityLearnEnv:
         return planes
 
     @property
+    def district_spec(self) -> DistrictSpec:
+        """The loaded district (the name `CityLearnEnv` uses: there `spec` belongs to gymnasium when it is installed)."""
+        return self.spec
+
+    @property
     def n_act_cols(self) -> int:
         return self.engine.n_act_cols
 
@@ -324,6 +329,15 @@ class VectorCityLearnEnv:
             reward = e.district_reward if self.central_agent else e.reward_bldg
         return self._obs(dep), reward, self.terminated, False, {}
 
+    def capture(self, actions: torch.Tensor) -> 'CapturedSteps':
+        """`step` as hipGraph replays.  `actions` is a persistent float32 buffer (``[n_act_cols, n_envs]`` or the transposed policy
+        layout) the caller overwrites before every `CapturedSteps.step()`; the launches of a step (energy step, flexible loads, LSTM stage,
+        observation epilogue, reward) are captured once per time step of the episode -- the step index and the table row are kernel
+        arguments -- and replayed afterwards, so a Python RL loop pays one graph launch per step instead of the ctypes calls of an
+        eager step (scripts/env_step_bench.py: eager vs captured us per step).  The returned observation / reward tensors are the
+        engine's own buffers (or graph-owned ones): valid until the next step."""
+        return CapturedSteps(self, actions)
+
     def rollout(self, k_steps: int, actions: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
         """Advance ``k_steps`` steps without returning to Python in between (`StepEngine.rollout`: one fused launch, or a launch
         sequence for districts with flexible loads) with open-loop ``actions`` ``[k_steps, n_act_cols, n_envs]`` or the uniform
@@ -397,3 +411,47 @@ class VectorCityLearnEnv:
         """Uniform random actions inside the action space (the device analogue of `Agent.predict`, agents/base.py:188-209)."""
         u = torch.rand((self.n_act_cols, self.n_envs), device=self.device, generator=generator)
         return self.action_low[:, None] + u * (self.action_high - self.action_low)[:, None]
+
+
+class CapturedSteps:
+    """`VectorCityLearnEnv.step` through hipGraph replay (see `VectorCityLearnEnv.capture`).  One graph per time step of the episode,
+    captured the first time the step is reached (the capture itself does not advance the env; the replay right after it does) and reused
+    by every later episode that replays the same window -- a `reset()` that rebuilds the engine (another episode window) drops them."""
+
+    def __init__(self, env: VectorCityLearnEnv, actions: torch.Tensor):
+        e = env.engine
+        if actions.dtype != torch.float32 or actions.device != e.device or tuple(actions.shape) not in ((e.n_act_cols, e.n_env), (e.n_env, e.n_act_cols)):
+            raise ValueError(f'actions must be a float32 [{e.n_act_cols}, {e.n_env}] (or transposed) tensor on {e.device}')
+        self.env, self.actions = env, actions
+        self._key = self._state_key()
+        self._graphs = {}
+        self._stream = torch.cuda.Stream(device=e.device)
+
+    def _state_key(self):
+        e = self.env.engine
+        return (id(e), None if e.flex is None else int(e.flex.seed))
+
+    def step(self):
+        """Advance by one step with the current content of the action buffer; returns what `VectorCityLearnEnv.step` returns."""
+        env = self.env
+        if self._state_key() != self._key:
+            # reset() built a new engine (the captured launches point at freed buffers) or moved a by-value kernel argument (the drift
+            # seed of a district with EVs advances with the episode): capture again
+            self._graphs.clear()
+            self._key = self._state_key()
+        if env.terminated:
+            raise RuntimeError('episode has terminated: call reset()')
+        t = env._t
+        hit = self._graphs.get(t)
+        if hit is None:
+            self._stream.wait_stream(torch.cuda.current_stream(env.engine.device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=self._stream):
+                out = env.step(self.actions)                     # recorded, not executed: the state on the device is untouched
+            env._t = t                                           # (env.step advanced the host-side clock)
+            hit = self._graphs[t] = (graph, out)
+        graph, out = hit
+        graph.replay()
+        env._t = t + 1
+        env.engine.t = t + 1
+        return out[0], out[1], env.terminated, False, {}

@@ -23,7 +23,7 @@ class NormalizedObservationWrapper:
     def __init__(self, env):
         self.env = env
         base = env.unwrapped
-        self._layout = ObservationLayout(base.spec, base.observation_mode, True, base.reference_quirks)
+        self._layout = ObservationLayout(base.district_spec, base.observation_mode, True, base.reference_quirks)
         self._episode = None
 
     def __getattr__(self, name):

@@ -1,23 +1,48 @@
-"""User-level throughput of `VectorCityLearnEnv.step` (Python -> ctypes -> kernels), eager and under hipGraph replay."""
+"""User-level throughput of `VectorCityLearnEnv.step` (Python -> ctypes -> kernels): eager, and as hipGraph replays through
+`VectorCityLearnEnv.capture()`; 65 536 envs, the three observation forms.  GPU box; output tracked as profiles/r03*_env_step_bench.log."""
 import sys, time
 from pathlib import Path
 import torch
 ROOT = Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / 'tests'))
-from golden_util import golden
+sys.path.insert(0, str(ROOT))
+from citylearn_amd.data import sample_schema
 from citylearn_amd.vector_env import VectorCityLearnEnv
 
-for name, kw in (('g2022_all', {}), ('g2022_all', {'observations': 'tensor'}), ('g2023_p2', {}), ('g2023_p2', {'observations': 'tensor'})):
-    E = 65536
-    env = VectorCityLearnEnv(golden(name).schema_path, E, **kw)
-    acts = [env.sample_actions() for _ in range(4)]
-    n = 200
-    for i in range(20):
-        env.step(acts[i % 4])
-    torch.cuda.synchronize(); env.reset()
-    t0 = time.perf_counter()
-    for i in range(n):
-        env.step(acts[i % 4])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print(f'{name} {kw or "planes"}: eager {dt / n * 1e6:.1f} us per env.step  ({env.n_bldg * E * n / dt:.3e} building-timesteps/s)', flush=True)
+E = 65536
+for name in ('citylearn_challenge_2022_phase_all_720h', 'citylearn_challenge_2023_phase_2_local_evaluation_720h'):
+    for kw in ({}, {'observations': 'compact', 'normalize_observations': True}, {'observations': 'tensor', 'normalize_observations': True}):
+        env = VectorCityLearnEnv(sample_schema(name), E, **kw)
+        acts = [env.sample_actions() for _ in range(4)]
+        n = 300
+        for i in range(20):
+            env.step(acts[i % 4])
+        torch.cuda.synchronize(); env.reset()
+        t0 = time.perf_counter()
+        for i in range(n):
+            env.step(acts[i % 4])
+        torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / n * 1e6
+        # captured: the policy writes into one persistent action buffer; first pass captures, second pass replays
+        env.reset()
+        buf = acts[0].clone()
+        cap = env.capture(buf)
+        for i in range(n):
+            cap.step()
+        torch.cuda.synchronize(); env.reset()
+        t0 = time.perf_counter()
+        for i in range(n):
+            buf.copy_(acts[i % 4], non_blocking=True)           # what a policy's output write costs at least
+            cap.step()
+        torch.cuda.synchronize()
+        captured = (time.perf_counter() - t0) / n * 1e6
+        env.reset()
+        t0 = time.perf_counter()
+        for i in range(n):
+            cap.step()
+        torch.cuda.synchronize()
+        bare = (time.perf_counter() - t0) / n * 1e6
+        units = env.n_bldg * E
+        print(f'{name.split("_720h")[0]} {kw.get("observations", "planes")}: eager {eager:.1f} us / step ({units / eager * 1e6:.3e} building-timesteps/s)   '
+              f'captured {captured:.1f} us incl. a 4.5 MB action copy, {bare:.1f} us without ({units / bare * 1e6:.3e})', flush=True)
+        del env, cap
+        torch.cuda.empty_cache()

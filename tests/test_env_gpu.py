@@ -178,6 +178,12 @@ def test_streaming_kpi_accumulators(name, K):
         env.step(a)
         ob = eng.out_bldg.cpu().numpy()
         hist['net'][t], hist['base'][t] = ob[abi.CLO_NET], ob[abi.CLO_BASE_NET]
+        if eng.kpi_shared_baseline:
+            # battery + PV district stepped without the detail planes: the baseline (load + solar, the load booked three times at t = 0,
+            # SURVEY App. B1) does not depend on the env and is not written as a plane
+            tab_ = env.tables
+            c_ns = tab_.ts[t, :, abi.CLT_NSL] * (3.0 if t == 0 else 1.0)
+            hist['base'][t] = (c_ns * tab_.params.view(np.float32)[:, abi.CLP_L_TSR] + tab_.ts[t, :, abi.CLT_SOLAR])[:, None]
         hist['exp'][t], hist['srv'][t] = ob[abi.CLO_EXPECTED], ob[abi.CLO_SERVED]
         if env.stage is not None:
             hist['temp'][t] = env.stage.indoor_temp.cpu().numpy()
@@ -298,3 +304,55 @@ def test_vector_env_reset_reuses_the_engine():
         env.reset()
         assert env.engine is eng and env.time_step == 0
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+@pytest.mark.parametrize('name,kw', [('g2022_all', {}), ('g2022_all', {'observations': 'compact', 'normalize_observations': True}),
+                                     ('g2023_p2', {'observations': 'tensor'}), ('g2022_evs', {})])
+def test_captured_steps_replay_the_eager_steps(name, kw):
+    """`VectorCityLearnEnv.capture()`: the step as hipGraph replays (one graph per time step, captured on first use) gives the eager
+    step's observations, rewards and state bit for bit -- over an episode boundary, where the second episode only replays."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden(name)
+    E = 256
+    eager, fast = VectorCityLearnEnv(g.schema_path, E, **kw), VectorCityLearnEnv(g.schema_path, E, **kw)
+    buf = torch.zeros((fast.n_act_cols, E), device='cuda')
+    cap = fast.capture(buf)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    K = 40
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return all(torch.equal(a[k], b[k]) for k in a)
+        return torch.equal(a, b)
+
+    for episode in range(2):
+        if episode:
+            o1, _ = eager.reset(); o2, _ = fast.reset()
+            assert same(o1, o2)
+        for t in range(K):
+            a = eager.sample_actions(gen)
+            buf.copy_(a)
+            o1, r1, d1, _, _ = eager.step(a)
+            o2, r2, d2, _, _ = cap.step()
+            assert same(o1, o2) and torch.equal(r1, r2) and d1 == d2, (episode, t)
+            assert torch.equal(eager.engine.state, fast.engine.state)
+        assert fast.time_step == eager.time_step == K
+    if fast.engine.flex is None:
+        assert len(cap._graphs) == K                              # the second episode captured nothing new (EV districts re-capture: their drift seed moves)
+
+
+def test_planes_observation_of_a_second_episode_starts_clean():
+    """`reset()` reuses the engine when the episode window is unchanged; the 'planes' observation hands out the engine's own
+    output planes, which must not carry the last step of the previous episode."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    for name in ('g2022_all', 'g2023_p2'):
+        env = VectorCityLearnEnv(golden(name).schema_path, 64)
+        first = {k: v.clone() for k, v in env.reset()[0].items()}
+        for _ in range(5):
+            env.step(env.sample_actions())
+        assert env.engine.out_bldg.abs().sum() > 0
+        engine = env.engine
+        again, _ = env.reset()
+        assert env.engine is engine                               # the fast path
+        for k, v in first.items():
+            assert torch.equal(v, again[k]), (name, k)

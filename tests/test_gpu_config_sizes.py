@@ -206,19 +206,40 @@ def test_lds_staged_parameters_match_scalar_parameters(kind):
 
 @pytest.mark.parametrize('E,tuning', [(65536, None), (516, None), (132, dict(vec=4, lean_variant=2))])
 def test_kpi_accumulators_updated_by_the_lean_step_kernel(E, tuning):
-    """`CLD_KPI` without the detail planes (battery + PV districts of up to 32 buildings): `cl_step_lean_kpi_kernel` updates the twelve
-    per-building accumulators from registers and writes only the baseline plane `cl_kpi_env_kernel` needs -- same accumulators as the
-    two passes over the detail planes (`cl_kpi_bldg_kernel`), which the reference-pinned KPI tests of tests/test_env_gpu.py cover."""
+    """`CLD_KPI` without the detail planes (battery + PV districts of up to 32 buildings): `cl_step_lean_kpi_kernel` updates every
+    accumulator inside the step launch -- the four control sums per (env, building) and the control district series per env; the
+    baseline sums, the expected energy and the baseline district series, which do not depend on the env in such a district, once per
+    block of CL_ROW0_BLOCK envs at the block's first env.  Same values as the two passes over the detail planes (`cl_kpi_bldg_kernel`,
+    `cl_kpi_env_kernel`), which the reference-pinned KPI tests of tests/test_env_gpu.py cover."""
     tab = golden('g2022_all').spec().episode_tables(0)
     fused = StepEngine(tab, E, kpi=True, tuning=tuning)
     two_pass = StepEngine(tab, E, kpi=True, detail=True)
+    fused.trace_kernels()
     assert not (fused.dims.flags & abi.CLD_WRITE_DETAIL) and (two_pass.dims.flags & abi.CLD_WRITE_DETAIL)
+    assert fused.kpi_shared_baseline and not two_pass.kpi_shared_baseline
     gen = torch.Generator(device='cuda').manual_seed(E)
     for t in range(30):
         a = torch.rand((fused.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
         fused.step(a, t); two_pass.step(a, t)
+    assert fused.last_kernels.startswith('cl_step_lean_kpi_kernel<') and '+' not in fused.last_kernels          # one launch per step
     assert torch.equal(fused.state, two_pass.state) and torch.equal(fused.out_bldg[:2], two_pass.out_bldg[:2])
-    torch.testing.assert_close(fused.out_bldg[abi.CLO_BASE_NET], two_pass.out_bldg[abi.CLO_BASE_NET], rtol=1e-6, atol=1e-6)
-    torch.testing.assert_close(fused.kpi_bldg, two_pass.kpi_bldg, rtol=2e-6, atol=1e-5)
-    torch.testing.assert_close(fused.kpi_env, two_pass.kpi_env, rtol=2e-5, atol=1e-4)
+    control = [abi.CLK_C_POS, abi.CLK_C_NET, abi.CLK_C_EMISSION, abi.CLK_C_COST]
+    shared = [abi.CLK_B_POS, abi.CLK_B_NET, abi.CLK_B_EMISSION, abi.CLK_B_COST, abi.CLK_EXPECTED_ALL]
+    lead = torch.arange(0, E, abi.CL_ROW0_BLOCK, device='cuda')
+    others = torch.ones(E, dtype=torch.bool, device='cuda')
+    others[lead] = False
+    torch.testing.assert_close(fused.kpi_bldg[control], two_pass.kpi_bldg[control], rtol=2e-6, atol=1e-5)
+    torch.testing.assert_close(fused.kpi_bldg[shared][:, :, lead], two_pass.kpi_bldg[shared][:, :, lead], rtol=2e-6, atol=1e-5)
+    assert not fused.kpi_bldg[shared][:, :, others].any()                       # kept once per block: the other entries stay at reset
+    n = abi.CLKE_PER_COND
+    torch.testing.assert_close(fused.kpi_env[:n], two_pass.kpi_env[:n], rtol=2e-5, atol=1e-4)
+    torch.testing.assert_close(fused.kpi_env[n:][:, lead], two_pass.kpi_env[n:][:, lead], rtol=2e-5, atol=1e-4)
+    # what evaluate() makes of them is the same
+    from citylearn_amd.kpi import finalize_streaming
+    b1, d1 = finalize_streaming(fused.kpi_bldg, fused.kpi_env, 30, tab.n_steps, shared_baseline=True)
+    b2, d2 = finalize_streaming(two_pass.kpi_bldg, two_pass.kpi_env, 30, tab.n_steps)
+    for k in b2:
+        torch.testing.assert_close(b1[k], b2[k], rtol=1e-5, atol=1e-6, equal_nan=True)
+    for k in d2:
+        torch.testing.assert_close(d1[k], d2[k], rtol=1e-4, atol=1e-5, equal_nan=True)
     assert fused.kpi_bldg.abs().sum().item() > 0
