@@ -46,8 +46,8 @@ class _BuildingView:
 
     def __init__(self, env: 'CityLearnEnv', index: int):
         self._env, self._i = env, index
-        self.bspec = env.district_spec.buildings[index]
-        self.name = self.bspec.name
+        self.spec = env.district_spec.buildings[index]
+        self.name = self.spec.name
 
     @property
     def active_observations(self) -> List[str]:
@@ -55,19 +55,19 @@ class _BuildingView:
 
     @property
     def active_actions(self) -> List[str]:
-        return self.bspec.active_actions
+        return self.spec.active_actions
 
     @property
     def action_metadata(self) -> Dict[str, bool]:
-        return dict(self.bspec.action_metadata)
+        return dict(self.spec.action_metadata)
 
     @property
     def observation_metadata(self) -> Dict[str, bool]:
-        return dict(self.bspec.observation_metadata)
+        return dict(self.spec.observation_metadata)
 
     @property
     def action_space(self) -> Box:
-        lo, hi = self.bspec.action_space_limits(self._env.district_spec.simulation_start_time_step, self._env.district_spec.simulation_end_time_step)
+        lo, hi = self.spec.action_space_limits(self._env.district_spec.simulation_start_time_step, self._env.district_spec.simulation_end_time_step)
         return Box(low=lo, high=hi, dtype=np.float32)
 
     def _series(self, key: str) -> np.ndarray:

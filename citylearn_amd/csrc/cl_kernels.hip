@@ -1428,7 +1428,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (!full && lean_shape) {
             if (vec == 1) CL_LAUNCH_NT(cl_step_lean_f64_kernel, 1); else CL_LAUNCH_NT(cl_step_lean_f64_kernel, 2);
         } else {
-            name_add(tun, "cl_step_kernel<%d, %s, %s, false, true>", vec, full ? "true" : "false", full && det ? "true" : "false");
+            name_add(tun, "cl_step_kernel<%d, %s, %s, false, true, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
             if (full && det) hipLaunchKernelGGL((cl_step_kernel<1, true, true, false, true>), grid, block, lds, s, a);
             else if (full) hipLaunchKernelGGL((cl_step_kernel<1, true, false, false, true>), grid, block, lds, s, a);
             else if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, true>), grid, block, lds, s, a);
@@ -1446,7 +1446,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (vec > 2) return fail(CL_EINVAL, "bad vec %d for the flexible-load step", vec);
         const dim3& grid_f = grid;
         const size_t lds_f = lds;
-        name_add(tun, "cl_step_kernel<%d, %s, %s, true>", vec, full ? "true" : "false", full && det ? "true" : "false");
+        name_add(tun, "cl_step_kernel<%d, %s, %s, true, false, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
         if (full && det) {
             if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, true, true, true>), grid_f, block, lds_f, s, a);
             else hipLaunchKernelGGL((cl_step_kernel<2, true, true, true>), grid_f, block, lds_f, s, a);
@@ -1493,14 +1493,14 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 5, false);
         }
     } else if (full && det) {
-        name_add(tun, "cl_step_kernel<%d, true, true, false>", vec);
+        name_add(tun, "cl_step_kernel<%d, true, true, false, false, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, true>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, true>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else if (full) {
-        name_add(tun, "cl_step_kernel<%d, true, false, false>", vec);
+        name_add(tun, "cl_step_kernel<%d, true, false, false, false, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, false>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, false>), grid, block, lds, s, a); break;
@@ -1545,7 +1545,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, false, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, false, true>), grid, block, lds, s, a);
     } else {
-        name_add(tun, "cl_step_kernel<%d, false, false, false>", vec);
+        name_add(tun, "cl_step_kernel<%d, false, false, false, false, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, false, false>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, false, false>), grid, block, lds, s, a); break;

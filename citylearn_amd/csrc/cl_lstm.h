@@ -50,6 +50,9 @@
 #define CLW_RW_LOEXP 3287
 #define CLW_RW_HIEXP 3288
 #define CLW_DEM_HEAT 3290        /* != 0: the model's demand input is heating_demand (delivered heating plane), not cooling_demand */
+#define CLW_DEM2 3291            /* != 0 (generic kernel only): the model takes BOTH demands -- cooling first, heating as a second env-dependent input */
+#define CLW_C2MIN 3292           /* normalisation of that second input */
+#define CLW_C2MAX 3293
 #define CLW_KPI_BAND 3289        /* comfort band of the discomfort KPIs (evaluate()'s scalar, citylearn.py:1191) */
 // dyn_pre layout: [0..63] layer-0 pre-gates, [64] data-file temperature (normalised), [65] data-file temperature [C]
 #define CLPRE_TNORM 64
@@ -496,7 +499,7 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
 // ---- any other LSTM shape (hidden size <= 64, one or two layers): plain fp32 FMAs -------------------------------------
 // baeda_3dem's Building_4 is LSTM(11 -> 50, one layer).  One wave = 64 envs of one building, lane = env.  Hidden and cell
 // states live in LDS as [unit][lane] (conflict-free), the weights arrive by scalar loads in the order they are consumed:
-//   gen_w   [B][GW]       per building: WX [H][8] (gates i, f, g, o of the cooling-demand input, then of the temperature input),
+//   gen_w   [B][GW]       per building: WX [H][12] (gates i, f, g, o of the demand input, of the temperature input, of the second demand input),
 //                         WHH0 [H][H][4], WIH1 [H][H][4], WHH1 [H][H][4], B1 [H][4], WLIN [H]   (H = the padded hidden size)
 //   gen_pre [T][B][H][4]  env-independent part of the layer-0 gates of (t, building)
 //   gen_hidden [B][4][H][E]  h0, c0, h1, c1 carried across env steps
@@ -510,16 +513,17 @@ struct LstmGenArgs {
     long long gw;   // floats per building in gen_w
 };
 
-CL_DEV void lstm_gen_cell(int H, const float* __restrict__ pre /* [H][4] or null */, const float* __restrict__ wx /* [H][8] or null */,
-                          float xc, float xt, const float* __restrict__ w_in /* [H][H][4] or null */, const float* in_h,
+CL_DEV void lstm_gen_cell(int H, const float* __restrict__ pre /* [H][4] or null */, const float* __restrict__ wx /* [H][12] or null */,
+                          float xc, float xt, float x2, const float* __restrict__ w_in /* [H][H][4] or null */, const float* in_h,
                           const float* __restrict__ w_hh, const float* old_h, float* new_h, float* c, int lane) {
     for (int u = 0; u < H; ++u) {
         float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
         if (pre) { g0 = pre[u * 4 + 0]; g1 = pre[u * 4 + 1]; g2 = pre[u * 4 + 2]; g3 = pre[u * 4 + 3]; }
         if (wx) {
-            const float* q = wx + u * 8;
+            const float* q = wx + u * 12;
             g0 = fmaf(q[0], xc, g0); g1 = fmaf(q[1], xc, g1); g2 = fmaf(q[2], xc, g2); g3 = fmaf(q[3], xc, g3);
             g0 = fmaf(q[4], xt, g0); g1 = fmaf(q[5], xt, g1); g2 = fmaf(q[6], xt, g2); g3 = fmaf(q[7], xt, g3);
+            g0 = fmaf(q[8], x2, g0); g1 = fmaf(q[9], x2, g1); g2 = fmaf(q[10], x2, g2); g3 = fmaf(q[11], x2, g3);      // (zero weights without a second input)
         }
         if (w_in) {
             const float* q = w_in + (long long)u * H * 4;
@@ -561,6 +565,10 @@ __global__ void __launch_bounds__(64) cl_lstm_generic_kernel(const LstmGenArgs g
     const float cool_n = (dem - cmin) / (cmax - cmin);
     const int slot = a.t % CL_LSTM_LOOKBACK;
     if (live) a.hist[(long long)slot * plane + off] = cool_n;                     // building.py:3068-3078
+    // a model that takes both demands: delivered heating is its second env-dependent input, with a ring of its own (rows 24 .. 35)
+    const bool two = W[CLW_DEM2] != 0.0f && a.heat_dem;
+    const float heat_n = two ? (a.heat_dem[off] - W[CLW_C2MIN]) / (W[CLW_C2MAX] - W[CLW_C2MIN]) : 0.0f;
+    if (live && two) a.hist[(long long)(2 * CL_LSTM_LOOKBACK + slot) * plane + off] = heat_n;
     float y = pre_t[CLPRE_TNORM];
     if (a.t >= CL_LSTM_LOOKBACK) {
         float* h0 = lds, * h0n = lds + H * 64, * c0 = lds + 2 * H * 64, * h1 = lds + 3 * H * 64, * h1n = lds + 4 * H * 64, * c1 = lds + 5 * H * 64;
@@ -570,17 +578,18 @@ __global__ void __launch_bounds__(64) cl_lstm_generic_kernel(const LstmGenArgs g
             h1[u * 64 + lane] = hid[(long long)(2 * H + u) * a.n_env]; c1[u * 64 + lane] = hid[(long long)(3 * H + u) * a.n_env];
         }
         const float* __restrict__ G = g.gen_w + (long long)b * g.gw;
-        const float* wx = G, * whh0 = wx + H * 8, * wih1 = whh0 + (long long)H * H * 4, * whh1 = wih1 + (long long)H * H * 4;
+        const float* wx = G, * whh0 = wx + H * 12, * wih1 = whh0 + (long long)H * H * 4, * whh1 = wih1 + (long long)H * H * 4;
         const float* b1 = whh1 + (long long)H * H * 4, * wlin = b1 + H * 4;
         for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
             const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
             const float* __restrict__ pre = g.gen_pre + ((long long)(time + row0) * a.n_bldg + b) * H * 4;
             const float xc = s == CL_LSTM_LOOKBACK - 1 ? cool_n : a.hist[(long long)(time % CL_LSTM_LOOKBACK) * plane + off];
             const float xt = a.hist[(long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) * plane + off];
-            lstm_gen_cell(H, pre, wx, xc, xt, nullptr, nullptr, whh0, h0, h0n, c0, lane);
+            const float x2 = !two ? 0.0f : (s == CL_LSTM_LOOKBACK - 1 ? heat_n : a.hist[(long long)(2 * CL_LSTM_LOOKBACK + time % CL_LSTM_LOOKBACK) * plane + off]);
+            lstm_gen_cell(H, pre, wx, xc, xt, x2, nullptr, nullptr, whh0, h0, h0n, c0, lane);
             { float* sw = h0; h0 = h0n; h0n = sw; }
             if (layers == 2) {
-                lstm_gen_cell(H, b1, nullptr, 0.0f, 0.0f, wih1, h0, whh1, h1, h1n, c1, lane);
+                lstm_gen_cell(H, b1, nullptr, 0.0f, 0.0f, 0.0f, wih1, h0, whh1, h1, h1n, c1, lane);
                 float* sw = h1; h1 = h1n; h1n = sw;
             }
         }

@@ -21,6 +21,7 @@ _PERIODIC = {'month': 12, 'hour': 24, 'day_type': 7}     # building.py:1493-1498
 # offsets inside `lstm_w` (csrc/cl_lstm.h)
 WC, WT, WHH0, WIH1, WHH1, B1, WLIN, BLIN, TMIN, TMAX, CMIN, CMAX, ACTIVE = 0, 64, 128, 1152, 2176, 3200, 3264, 3280, 3281, 3282, 3283, 3284, 3285
 DEM_HEAT = 3290          # csrc/cl_lstm.h CLW_DEM_HEAT
+DEM2, C2MIN, C2MAX = 3291, 3292, 3293      # CLW_DEM2: the model also takes heating_demand (second demand input) + its normalisation
 PRE_TNORM, PRE_TRAW, PRE_HVAC, PRE_CSP, PRE_HSP, PRE_BAND, PRE_OCC, PRE_OUTAGE = 64, 65, 66, 67, 68, 69, 70, 71
 RW_BAND, RW_LOEXP, RW_HIEXP, KPI_BAND = 3286, 3287, 3288, 3289
 
@@ -69,9 +70,11 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         sd = {k: v.double().numpy() for k, v in sd.get('model_state_dict', sd).items()}
         names = list(d.input_observation_names)
         lo, hi = np.array(d.input_normalization_minimum, dtype=np.float64), np.array(d.input_normalization_maximum, dtype=np.float64)
-        ic, it = _demand_input(names), names.index('indoor_dry_bulb_temperature')
+        (ic, i2), it = _demand_inputs(names), names.index('indoor_dry_bulb_temperature')
         lstm_w[i, DEM_HEAT] = 1.0 if names[ic] == 'heating_demand' else 0.0
-        if not (d.num_layers == 2 and H <= 16):
+        if i2 is not None:                              # both demands among the inputs: delivered heating is the second env-dependent input
+            lstm_w[i, DEM2], lstm_w[i, C2MIN], lstm_w[i, C2MAX] = 1.0, lo[i2], hi[i2]
+        if _needs_generic_kernel(d):
             # another shape: the generic kernel's tables hold the weights (pack_lstm_generic); this row carries the
             # normalisation constants, the output bias and the kernel selector
             lstm_w[i, BLIN] = sd['l_linear.bias'].reshape(-1)[0]
@@ -154,30 +157,36 @@ def cell_update_bounds(spec: DistrictSpec, tables: EpisodeTables, lstm_w: np.nda
     return worst_sum, worst_o
 
 
-def _demand_input(names) -> int:
-    """Index of the model's one env-dependent demand input: `cooling_demand`, or `heating_demand` for a heating-driven model
-    ("LSTM model only uses either cooling/heating demand not both as input variable", building.py:3013-3017)."""
-    both = [n for n in ('cooling_demand', 'heating_demand') if n in names]
-    if len(both) != 1:
-        raise NotImplementedError(f'LSTM dynamics need exactly one of cooling_demand / heating_demand among their inputs (got {both})')
-    return names.index(both[0])
+def _demand_inputs(names):
+    """``(index of the model's demand input, index of a second one or None)``: `cooling_demand`, or `heating_demand` for a heating-driven
+    model ("LSTM model only uses either cooling/heating demand not both as input variable", building.py:3013-3017) -- or both: the
+    reference builds the model input generically from `input_observation_names` (building.py:3039-3078), so a model trained on both
+    demands runs there; here it takes cooling as the first and heating as the second env-dependent input of the generic kernel."""
+    have = [n for n in ('cooling_demand', 'heating_demand') if n in names]
+    if not have:
+        raise NotImplementedError('LSTM dynamics need cooling_demand and / or heating_demand among their inputs')
+    return names.index(have[0]), (names.index(have[1]) if len(have) == 2 else None)
+
+
+def _needs_generic_kernel(d) -> bool:
+    """The matrix-core kernel covers two layers of <= 16 units with ONE demand input; everything else runs on cl_lstm_generic_kernel."""
+    return not (d.num_layers == 2 and d.hidden_size <= 16) or _demand_inputs(list(d.input_observation_names))[1] is not None
 
 
 def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):
     """Tables of `cl_lstm_generic_step_f32` for the buildings `pack_lstm` marked ACTIVE = 2 / 3 (LSTM shapes other than two
     layers of <= 16 units): ``(gen_w [B, GW] f32, gen_pre [T, B, H, 4] f32, H)`` with H the largest hidden size among them, or
     ``None`` when there is no such building.  Layouts: csrc/cl_lstm.h (gate order i, f, g, o)."""
-    todo = [(i, b) for i, b in enumerate(spec.buildings)
-            if b.dynamics is not None and not (b.dynamics.num_layers == 2 and b.dynamics.hidden_size <= 16)]
+    todo = [(i, b) for i, b in enumerate(spec.buildings) if b.dynamics is not None and _needs_generic_kernel(b.dynamics)]
     if not todo:
         return None
     B, T = len(spec.buildings), tables.n_steps
     w = slice(tables.start, tables.end + 1)
     H = max(b.dynamics.hidden_size for _, b in todo)
-    gw = H * 8 + 3 * H * H * 4 + H * 4 + H
+    gw = H * 12 + 3 * H * H * 4 + H * 4 + H
     gen_w = np.zeros((B, gw), dtype=np.float32)
     gen_pre = np.zeros((T, B, H, 4), dtype=np.float32)
-    o_wx, o_hh0 = 0, H * 8
+    o_wx, o_hh0 = 0, H * 12
     o_ih1, o_hh1 = o_hh0 + H * H * 4, o_hh0 + 2 * H * H * 4
     o_b1 = o_hh0 + 3 * H * H * 4
     o_lin = o_b1 + H * 4
@@ -188,7 +197,7 @@ def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):
         sd = {k: v.double().numpy() for k, v in sd.get('model_state_dict', sd).items()}
         names = list(d.input_observation_names)
         lo, hi = np.array(d.input_normalization_minimum, dtype=np.float64), np.array(d.input_normalization_maximum, dtype=np.float64)
-        ic, it = _demand_input(names), names.index('indoor_dry_bulb_temperature')
+        (ic, i2), it = _demand_inputs(names), names.index('indoor_dry_bulb_temperature')
 
         def ug(m):                                      # torch rows [i; f; g; o] x h (x cols)  ->  [unit, gate, (cols)], padded to H units
             m = np.asarray(m, dtype=np.float64).reshape((4, h) + np.shape(m)[1:])
@@ -203,7 +212,8 @@ def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):
             return out
 
         wih0 = ug(sd['l_lstm.weight_ih_l0'])            # [H, 4, n_in]
-        gen_w[i, o_wx:o_wx + H * 8] = np.concatenate([wih0[:, :, ic], wih0[:, :, it]], axis=1).reshape(-1)
+        w2 = wih0[:, :, i2] if i2 is not None else np.zeros_like(wih0[:, :, ic])
+        gen_w[i, o_wx:o_wx + H * 12] = np.concatenate([wih0[:, :, ic], wih0[:, :, it], w2], axis=1).reshape(-1)
         gen_w[i, o_hh0:o_hh0 + H * H * 4] = square(sd['l_lstm.weight_hh_l0']).reshape(-1)
         if d.num_layers == 2:
             gen_w[i, o_ih1:o_ih1 + H * H * 4] = square(sd['l_lstm.weight_ih_l1']).reshape(-1)
@@ -212,7 +222,7 @@ def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):
         gen_w[i, o_lin:o_lin + h] = sd['l_linear.weight'].reshape(-1)
         pre = np.tile(ug(sd['l_lstm.bias_ih_l0'] + sd['l_lstm.bias_hh_l0'])[None], (T, 1, 1))        # [T, H, 4]
         for k, name in enumerate(names):
-            if k in (ic, it):
+            if k in (ic, it, i2):
                 continue
             x = (_exo_feature(b, name, w) - lo[k]) / (hi[k] - lo[k])
             pre += x[:, None, None] * wih0[None, :, :, k]

@@ -358,14 +358,15 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
 /* ---- adjacent stage: LSTM indoor-temperature dynamics of LSTMDynamicsBuilding (building.py:3000-3078, dynamics.py) ----
  * lstm_w  [n_bldg][CL_LSTM_NW]            packed LSTM(13->16, 2 layers) + Linear(16->1) weights per building
  * dyn_pre [n_steps][n_bldg][CL_LSTM_NPRE]  host-precomputed env-independent part of the layer-0 gates per (t, building)
- * hist    [24][n_bldg][n_env]              rings of the last 12 normalised cooling demands and indoor temperatures
+ * hist    [CL_LSTM_NHIST][n_bldg][n_env]   rings of the last 12 normalised demand inputs (rows 0-11), indoor temperatures (12-23) and, for a
+ *                                          model that takes both demands (generic kernel), second demand inputs (24-35)
  * hidden  [n_bldg][n_env][64]              h0[16], c0[16], h1[16], c1[16] carried across env steps
  * The 64 gate rows of every weight matrix, of the layer-1 bias and of `dyn_pre` are stored pre-multiplied by -log2(e) (gates i, f, o)
  * and -2 log2(e) (gate g): sigmoid(x) = 1 / (1 + 2^z) and tanh(x) = 2 / (1 + 2^z) - 1 then take the accumulated z as it is.
  * (layouts: citylearn_amd/csrc/cl_lstm.h, packer: citylearn_amd/dynamics.py) */
 #define CL_LSTM_NW   3296
 #define CL_LSTM_NPRE 80
-#define CL_LSTM_NHIST 24
+#define CL_LSTM_NHIST 36
 #define CL_LSTM_NHIDDEN 64
 
 /* Streaming comfort KPI accumulators `kpi_comfort[CL_NKC][n_bldg][n_env]` (row K of SURVEY 8a for dynamics buildings):
@@ -403,8 +404,10 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
 
 /* LSTM shapes the matrix-core kernel does not cover (hidden size up to CL_LSTM_GEN_HMAX, one or two layers; e.g. baeda_3dem's
  * Building_4 = LSTM(11 -> 50, 1 layer)): buildings whose lstm_w[CLW_ACTIVE] is 2 (one layer) or 3 (two layers) are skipped by
- * cl_lstm_step_f32 and advanced by this call (same inputs / outputs, plain fp32 FMAs; call it right after cl_lstm_step_f32).
- *   gen_w      [n_bldg][gen_w_stride]   WX [H][8], WHH0 [H][H][4], WIH1 [H][H][4], WHH1 [H][H][4], B1 [H][4], WLIN [H]  (gate order i, f, g, o;
+ * cl_lstm_step_f32 and advanced by this call (same inputs / outputs, plain fp32 FMAs; call it right after cl_lstm_step_f32).  So are
+ * models of any shape whose inputs hold BOTH cooling_demand and heating_demand (the reference builds the input generically from
+ * `input_observation_names`, building.py:3039-3078): lstm_w[CLW_DEM2] != 0, delivered heating as a third env-dependent input.
+ *   gen_w      [n_bldg][gen_w_stride]   WX [H][12] (demand, temperature, second demand input), WHH0 [H][H][4], WIH1 [H][H][4], WHH1 [H][H][4], B1 [H][4], WLIN [H]  (gate order i, f, g, o;
  *                                        H = gen_h, the padded hidden size; csrc/cl_lstm.h, packer dynamics.pack_lstm_generic)
  *   gen_pre    [n_ts_rows][n_bldg][gen_h][4]  env-independent part of the layer-0 gates
  *   gen_hidden [n_bldg][4][gen_h][n_env]      h0, c0, h1, c1 carried across env steps (zero at episode start) */

@@ -68,6 +68,10 @@ FIXTURES = {
     # off / cooling / heating / auto; Building_1 is controlled through `cooling_or_heating_device`, Building_2 through `heating_device`
     # with its LSTM fed by `heating_demand` instead of `cooling_demand`, Building_3 stays on `cooling_device`
     'g2023_heat': ('citylearn_challenge_2023_phase_2_local_evaluation', 264, 263, 41, False, {'__heating_synth__': True}),
+    # a temperature model that takes BOTH demands (the reference builds its input generically from `input_observation_names`,
+    # building.py:3039-3078): the same synthetic district, Building_1 (cooling-or-heating device action) with `heating_demand` appended to
+    # the inputs of its LSTM -- one more input column of seeded weights in a rewritten Building_1.pth
+    'g2023_both': ('citylearn_challenge_2023_phase_2_local_evaluation', 216, 215, 43, False, {'__heating_synth__': 'both'}),
     's_baeda': ('baeda_3dem', 96, 95, 31, False, {}),
     's_2021': ('citylearn_challenge_2021', 96, 95, 32, False, {}),
     's_2020_cz3': ('citylearn_challenge_2020_climate_zone_3', 96, 95, 33, False, {}),
@@ -113,6 +117,14 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict
             if i % 3 == 1:         # a heating-driven temperature model: same weights, the demand input renamed
                 att = b['dynamics']['attributes']
                 att['input_observation_names'] = ['heating_demand' if n == 'cooling_demand' else n for n in att['input_observation_names']]
+            if i % 3 == 0 and heating_synth == 'both':      # both demands among the inputs (the .pth is rewritten below)
+                att = b['dynamics']['attributes']
+                ic = att['input_observation_names'].index('cooling_demand')
+                att['input_observation_names'] = list(att['input_observation_names']) + ['heating_demand']
+                att['input_normalization_minimum'] = list(att['input_normalization_minimum']) + [0.0]
+                att['input_normalization_maximum'] = list(att['input_normalization_maximum']) + [round(0.5 * att['input_normalization_maximum'][ic] + 0.5, 6)]
+                if 'input_size' in att:
+                    att['input_size'] = len(att['input_observation_names'])
     noise = overrides.pop('__noise_std__', None)
     if noise is not None:
         for b in schema['buildings'].values():
@@ -130,6 +142,15 @@ def make_mini_dataset(src: Path, dst: Path, rows: int, gz: bool, overrides: dict
         if b.get('dynamics'):
             fn = b['dynamics']['attributes']['filename']
             shutil.copyfile(src / fn, dst / fn)
+            n_in = len(b['dynamics']['attributes']['input_observation_names'])
+            if heating_synth == 'both' and n_in == 14:
+                import torch
+                sd = torch.load(src / fn, map_location='cpu')
+                inner = sd.get('model_state_dict', sd)
+                w = inner['l_lstm.weight_ih_l0']
+                extra = torch.from_numpy(np.random.RandomState(43).normal(0.0, 0.25, size=(w.shape[0], 1)).astype('float32'))
+                inner['l_lstm.weight_ih_l0'] = torch.cat([w, extra], dim=1)
+                torch.save(sd, dst / fn)
         for c in (b.get('chargers') or {}).values():                    # EV charger schedules / washing machine cycles
             files.add(c['charger_simulation'])
         for wmach in (b.get('washing_machines') or {}).values():

@@ -14,13 +14,15 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize('name,split,cell', [
     ('g2023_p2', 'f16', 'auto'), ('s_baeda', 'f16', 'auto'), ('s_2023_p1', 'f16', 'auto'), ('s_2023_p3', 'f16', 'auto'), ('g2023_heat', 'f16', 'auto'),
-    ('g2023_p2', 'f16', 'plain'), ('s_2023_p3', 'f16', 'plain'), ('g2023_heat', 'f16', 'plain'),
+    ('g2023_p2', 'f16', 'plain'), ('s_2023_p3', 'f16', 'plain'), ('g2023_heat', 'f16', 'plain'), ('g2023_both', 'f16', 'auto'), ('g2023_both', 'bf16', 'plain'),
     ('g2023_p2', 'bf16', 'auto'), ('s_baeda', 'bf16', 'auto'), ('g2023_heat', 'bf16', 'plain'), ('g2023_p2', None, 'auto'), ('s_2023_p3', None, 'auto')])
 def test_lstm_stage_fed_with_reference_cooling(name, split, cell):
     """Isolates the stage: the delivered cooling of every step comes from the reference; temperatures within 1e-4 C
     relative and ComfortReward within 1e-4 (+1e-4) of the reference for every step and building (2023: LSTM(13 -> 16),
     3 and 6 buildings; baeda_3dem: three LSTM(11 -> 8, 2 layers) embedded in the 16-wide kernel + one LSTM(11 -> 50, 1 layer)).
     `split`: the operand format of the recurrent products -- two f16 terms (default), three bf16 terms, or the exact f32 MFMA.
+    g2023_both: Building_1's model takes BOTH demands (a rewritten .pth with a fourteenth input; the reference builds the input generically,
+    building.py:3039-3078) and runs on the generic kernel with delivered heating as a third env-dependent input.
     `cell`: the cell update -- 'auto' picks the common-denominator form (7 transcendentals per unit and cell) for every 2023 district and the
     plain one (10) for baeda_3dem, whose gate bound exceeds what the products admit (`dynamics.cell_update_bounds`)."""
     g = golden(name)
@@ -57,7 +59,7 @@ def test_lstm_stage_fed_with_reference_cooling(name, split, cell):
     assert worst_r < 1.0, worst_r           # BASELINE.json: reward parity within 1e-4 relative (measured: 0.09)
 
 
-@pytest.mark.parametrize('name', ['g2023_p2', 'g2023_heat'])
+@pytest.mark.parametrize('name', ['g2023_p2', 'g2023_heat', 'g2023_both'])
 def test_energy_step_plus_lstm_free_running(name):
     """Energy step + LSTM stage chained on the GPU with the golden action sequence, free-running (g2023_heat: heating device /
     cooling-or-heating device actions, every hvac mode, a heating-driven temperature model -- building.py:3123-3158)."""

@@ -201,7 +201,7 @@ def test_free_running_whole_fixture_f64(name, vec):
     fixture at the north star's 1e-4 + 1e-4 |ref| on EVERY quantity -- district sums and district reward at the plain tolerance too --
     and the battery state (soc, efficiency, degraded capacity) bit-identical to the reference's float32 values at every step."""
     worst, eng = _run(name, 'RewardFunction', vec, detail=False, teach=False, f64=True, district_slack=(1.0, 1.0))
-    assert 'f64' in eng.last_kernels or 'false, true>' in eng.last_kernels, eng.last_kernels
+    assert 'cl_step_lean_f64_kernel' in eng.last_kernels or ', true, false>' in eng.last_kernels, eng.last_kernels      # cl_step_kernel<.., F64 = true, FOLD = false>
     assert max(worst.values()) < 1.0, worst
     assert worst['soc'] == 0.0 and worst['eff'] == 0.0 and worst['degcap'] == 0.0, worst
 

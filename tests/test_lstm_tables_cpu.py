@@ -87,3 +87,58 @@ def test_cell_update_bounds_admit_the_2023_models_and_refuse_baeda():
         zs, zo = cell_update_bounds(spec, tab, w, pre)
         assert 20.0 < zs < 200.0 and 5.0 < zo < 62.0
         assert (zs < 126.0) == ok, (name, zs, zo)
+
+
+@pytest.mark.parametrize('name,b', [('g2023_both', 0), ('s_baeda', 3)])
+def test_generic_kernel_tables_reproduce_the_reference_temperatures(name, b):
+    """`dynamics.pack_lstm_generic` (cl_lstm_generic_kernel's tables: WX [H][12] = gates of the demand, the temperature and the second demand
+    input, square matrices as [unit][input][gate], host pre-gates) through a numpy restatement of that kernel's window loop: g2023_both's
+    Building_1 takes BOTH demands (delivered heating as a third env-dependent input with its own ring), baeda's Building_4 is LSTM(11 -> 50, one layer)."""
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    lstm_w, dyn_pre = dyn.pack_lstm(spec, tab)
+    gen_w, gen_pre, H = dyn.pack_lstm_generic(spec, tab)
+    w = lstm_w[b].astype(np.float64)
+    layers = {2.0: 1, 3.0: 2}[w[dyn.ACTIVE]]
+    G = gen_w[b].astype(np.float64)
+    wx = G[:H * 12].reshape(H, 3, 4)
+    o = H * 12
+    whh0 = G[o:o + H * H * 4].reshape(H, H, 4); o += H * H * 4
+    wih1 = G[o:o + H * H * 4].reshape(H, H, 4); o += H * H * 4
+    whh1 = G[o:o + H * H * 4].reshape(H, H, 4); o += H * H * 4
+    b1 = G[o:o + H * 4].reshape(H, 4); o += H * 4
+    wlin = G[o:o + H]
+    two = w[dyn.DEM2] != 0.0
+    assert two == (name == 'g2023_both')
+    cool = g.ref['cool_dem'][:, b]
+    heat = g.ref['heat_dem'][:, b] if 'heat_dem' in g.ref.files else np.zeros_like(cool)
+    dem = heat if w[dyn.DEM_HEAT] != 0.0 else cool
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+
+    def cell(z, c):                                     # z [H, 4] = gates i, f, g, o (unscaled: the generic tables keep torch's values)
+        c = sig(z[:, 1]) * c + sig(z[:, 0]) * np.tanh(z[:, 2])
+        return c, sig(z[:, 3]) * np.tanh(c)
+
+    ring_c, ring_t, ring_2 = np.zeros(12), np.zeros(12), np.zeros(12)
+    h0 = np.zeros(H); c0 = np.zeros(H); h1 = np.zeros(H); c1 = np.zeros(H)
+    worst = 0.0
+    for t in range(min(100, g.facts['steps'])):
+        ring_c[t % 12] = (dem[t] - w[dyn.CMIN]) / (w[dyn.CMAX] - w[dyn.CMIN])
+        if two:
+            ring_2[t % 12] = (heat[t] - w[dyn.C2MIN]) / (w[dyn.C2MAX] - w[dyn.C2MIN])
+        y, temp = dyn_pre[t, b, dyn.PRE_TNORM], dyn_pre[t, b, dyn.PRE_TRAW]
+        if t >= 12:
+            for s in range(12):
+                time = t - 11 + s
+                z0 = gen_pre[time, b].astype(np.float64) + wx[:, 0] * ring_c[time % 12] + wx[:, 1] * ring_t[(time - 1) % 12] + wx[:, 2] * ring_2[time % 12] \
+                    + np.einsum('ukg,k->ug', whh0, h0)
+                c0, h0 = cell(z0, c0)
+                if layers == 2:
+                    z1 = b1 + np.einsum('ukg,k->ug', wih1, h0) + np.einsum('ukg,k->ug', whh1, h1)
+                    c1, h1 = cell(z1, c1)
+            y = w[dyn.BLIN] + wlin @ (h1 if layers == 2 else h0)
+            temp = y * (w[dyn.TMAX] - w[dyn.TMIN]) + w[dyn.TMIN]
+        ring_t[t % 12] = y
+        worst = max(worst, abs(temp - g.ref['indoor_temp'][t][b]))
+    assert worst < 5e-5, worst
