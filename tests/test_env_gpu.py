@@ -314,7 +314,8 @@ def test_captured_steps_replay_the_eager_steps(name, kw):
     from citylearn_amd.vector_env import VectorCityLearnEnv
     g = golden(name)
     E = 256
-    eager, fast = VectorCityLearnEnv(g.schema_path, E, **kw), VectorCityLearnEnv(g.schema_path, E, **kw)
+    # (g.spec(): EVs without an `initial_soc` draw one from Python's global `random` at load time, like the reference -- the fixture's values for both)
+    eager, fast = VectorCityLearnEnv(g.spec(), E, **kw), VectorCityLearnEnv(g.spec(), E, **kw)
     buf = torch.zeros((fast.n_act_cols, E), device='cuda')
     cap = fast.capture(buf)
     gen = torch.Generator(device='cuda').manual_seed(11)
