@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
         }
     }
     CL_TRACE_AFTER(13, q_net[0]);
-    district_reduce<VEC, false, LP>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);      // (LP = the chunked launches' kernel)
+    district_reduce<VEC, false, LP && VEC == 2>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
     CL_TRACE_FLUSH();
 }
 

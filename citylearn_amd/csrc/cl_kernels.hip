@@ -1479,7 +1479,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 1024, 4, false);
         } else if (lp) {
             // parameter blocks staged in LDS (cl_full.h); full_variant = 3 keeps them in SGPRs (tests, A/B)
-            a.fused_finish = a.n_chunks > 1 && tun.finish == 2 && !(vec == 2 && small);
+            a.fused_finish = a.n_chunks > 1 && tun.finish == 2 && vec == 2 && !small;
             if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
             else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5, false);      // (96 VGPRs do not hold the staged operands: 61 scratch accesses)
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 4, true);
@@ -1504,7 +1504,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, false>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, false>), grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL((cl_step_kernel<4, true, false>), grid, block, lds, s, a); break;
+        // (four envs per lane is not instantiated for the thermal unit: 92 bytes of scratch per lane, never selected by the library)
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 106496))) {

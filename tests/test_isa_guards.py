@@ -134,3 +134,17 @@ def test_in_kernel_fold_uses_scoped_accesses_not_cache_maintenance(units):
     # the instantiations that never fold keep their register budget (the fold is a template parameter, not a run-time branch)
     k = _one(kernels, r'cl_step_kernelILi1ELb0ELb0ELb0ELb0ELb0EE')
     assert not [i for i in kernels[k] if i.endswith('sc1')]
+
+
+def test_scratch_memory_is_confined_to_the_known_instantiations(units):
+    """No kernel of the library touches scratch memory except the ones listed here with their byte counts (two or three VGPRs parked once per
+    wave under a 1024-thread workgroup's 128-register cap; the FLEX thermal kernel with detail planes: 13): a new entry is a regression."""
+    known = {r'cl_step_kernelILi2ELb1ELb1ELb1ELb0ELb0EE': 52, r'cl_step_full_kernelILi2ELb1ELi1024ELi4ELb0ELb[01]EE': 8,
+             r'cl_step_full_kernelILi2ELb0ELi576ELi5ELb0ELb[01]EE': 8, r'cl_step_full_kernelILi2ELb0ELi1024ELi4ELb1ELb[01]EE': 12,
+             r'cl_step_full_kernelILi1ELb0ELi1024ELi5ELb1ELb[01]EE': 12}
+    for kernels, meta in units:
+        for k, m in meta.items():
+            if not m.get('private_seg_size'):
+                continue
+            hit = [limit for pat, limit in known.items() if re.search(pat, k)]
+            assert hit and m['private_seg_size'] <= hit[0], (k, m['private_seg_size'])
