@@ -142,19 +142,23 @@ class CityLearnEnv(_GymEnv):
 
     def __init__(self, schema: Union[str, Path, Mapping[str, Any]], device: str = 'cuda:0',
                  observation_mode: str = 'reference', reference_quirks: bool = True, ev_seed: int = None,
-                 ev_soc_drift=None, **kwargs: Any):
+                 ev_soc_drift=None, f64_maps: bool = False, **kwargs: Any):
         """`schema` and `**kwargs` exactly as the reference constructor (citylearn.py:133-205).  Extra arguments:
         `device`; `observation_mode`: ``'reference'`` returns the reference's observation semantics (values of step
         t+1 read before they are computed -- SoC / net read 0), ``'current'`` returns the SoC / net
         just computed; `reference_quirks`: replicate the repeated t = 0 bookkeeping.
         Districts with EVs: `ev_seed` keys the device's N(1, 0.2) stream of the unconnected-EV SoC drift (the reference
         draws it from the global, unseeded ``np.random``, citylearn.py:1468-1472; default: the schema's random_seed);
-        `ev_soc_drift` ([episode steps, n_ev]) replays given multipliers instead."""
+        `ev_soc_drift` ([episode steps, n_ev]) replays given multipliers instead.
+        `f64_maps` (`CLD_F64_MAPS`): the battery map in the reference's own mixed float64 / float32 precision -- the battery SoC series of a
+        free-running episode is then the reference's, bit for bit, at about three times the step time; not for
+        districts with EV chargers."""
         if observation_mode not in ('reference', 'current'):
             raise ValueError("observation_mode must be 'reference' or 'current'")
         self.district_spec: DistrictSpec = load_district(schema, **kwargs)
         self.electric_vehicles = list(self.district_spec.electric_vehicles)
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
+        self.f64_maps = bool(f64_maps)
         self.device = device
         self.observation_mode = observation_mode
         self.reference_quirks = reference_quirks
@@ -323,7 +327,7 @@ class CityLearnEnv(_GymEnv):
                                   t0_quirk=self.reference_quirks, detail=True, charger_detail=True, central_agent=self.central_agent,
                                   ev_reward_weights=getattr(self.reward_function, 'weights', None), ev_drift=self._ev_drift,
                                   ev_penalty_coefficient=getattr(self.reward_function, 'charging_constraint_penalty_coefficient', 1.0),
-                                  ev_seed=(self.random_seed if self._ev_seed is None else self._ev_seed) + self._episode)
+                                  ev_seed=(self.random_seed if self._ev_seed is None else self._ev_seed) + self._episode, f64_maps=self.f64_maps)
         self._prev_ev_soc = None
         # adjacent LSTM indoor-temperature stage (LSTMDynamicsBuilding, building.py:3000-3078) with the fused ComfortReward
         self._stage = None

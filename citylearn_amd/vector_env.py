@@ -31,7 +31,8 @@ class VectorCityLearnEnv:
     def __init__(self, schema: Union[str, Mapping[str, Any], DistrictSpec], n_envs: int, device: str = 'cuda:0',
                  reference_quirks: bool = True, kpi: bool = False, observations: str = 'planes',
                  normalize_observations: bool = False, observation_mode: str = 'current',
-                 env_episode_offsets=None, ev_seed: Optional[int] = None, ev_soc_drift=None, env_offset: int = 0, **kwargs: Any):
+                 env_episode_offsets=None, ev_seed: Optional[int] = None, ev_soc_drift=None, env_offset: int = 0, f64_maps: bool = False,
+                 **kwargs: Any):
         """`observations`: ``'planes'`` (default) returns the dict of device tensors described above without
         materialising anything; ``'tensor'`` returns the Gym observation tensor ``[n_envs, n_obs]`` written by
         `cl_observe_f32` -- columns = `observation_names` (the reference's central-agent order when
@@ -50,7 +51,9 @@ class VectorCityLearnEnv:
         `ev_seed` keys the per-(env, EV, step) N(1, 0.2) drift of unconnected EVs (default: the schema's random_seed, advanced
         per episode), `ev_soc_drift` ([table rows, n_ev]) replays given multipliers for every env instead.
         `env_offset`: index of this shard's first env in a multi-GPU batch (`parallel.shard_envs(total, rank, world)[0]`): random streams
-        (rollout policy, EV drift) are keyed by it + the local env index, so shards with one seed draw disjoint streams."""
+        (rollout policy, EV drift) are keyed by it + the local env index, so shards with one seed draw disjoint streams.
+        `f64_maps` (`CLD_F64_MAPS`): the battery map in the reference's own mixed float64 / float32 precision (battery state bit-identical to
+        the reference's over a free-running episode; about 3 x the step time; no EV districts)."""
         if observations not in ('planes', 'tensor', 'compact'):
             raise ValueError("observations must be 'planes', 'tensor' or 'compact'")
         self._compact = observations == 'compact'
@@ -62,6 +65,7 @@ class VectorCityLearnEnv:
         self.central_agent = self.spec.central_agent
         self.env_episode_offsets = env_episode_offsets
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
+        self.f64_maps = bool(f64_maps)
         self.env_offset = int(env_offset)      # first env of this shard in the whole batch (multi-GPU: parallel.shard_envs(...)[0])
         if self.env_offset < 0 or self.env_offset + self.n_envs > 2 ** 32:
             raise ValueError(f'env_offset={env_offset} with n_envs={n_envs} leaves the 32-bit env index of the random streams')
@@ -221,7 +225,8 @@ class VectorCityLearnEnv:
                                  or self._plugin is not None,
                                  ev_reward_weights=self._rf_attrs.get('weights'), ev_drift=self._ev_drift, central_agent=self.central_agent,
                                  ev_penalty_coefficient=self._rf_attrs.get('charging_constraint_penalty_coefficient') or 1.0,
-                                 ev_seed=(self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode, env_offset=self.env_offset)
+                                 ev_seed=(self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode, env_offset=self.env_offset,
+                                 f64_maps=self.f64_maps)
         self.stage = None
         if any(b.is_dynamics for b in self.spec.buildings):
             from .dynamics import LSTMStage
