@@ -1792,7 +1792,7 @@ int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const flo
     if (int rc = check_ptr(kpi_comfort, "kpi_comfort", false)) return rc;
     if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
     if (gen_h < 1 || gen_h > CL_LSTM_GEN_HMAX) return fail(CL_EINVAL, "gen_h=%d outside [1, %d]", gen_h, CL_LSTM_GEN_HMAX);
-    const long long need = (long long)gen_h * 8 + 3ll * gen_h * gen_h * 4 + gen_h * 4 + gen_h;
+    const long long need = (long long)gen_h * 12 + 3ll * gen_h * gen_h * 4 + gen_h * 4 + gen_h;
     if (gen_w_stride < need) return fail(CL_EINVAL, "gen_w_stride=%lld < %lld floats for hidden size %d", (long long)gen_w_stride, need, gen_h);
     LstmGenArgs g;
     LstmArgs& a = g.s;
@@ -1800,12 +1800,12 @@ int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const flo
     a.indoor_temp = indoor_temp; a.heat_dem = heat_dem; a.comfort = comfort; a.kpi_comfort = kpi_comfort;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t; a.env_row0 = dims->env_row0;
     g.gen_w = gen_w; g.gen_pre = gen_pre; g.gen_hidden = gen_hidden; g.H = gen_h; g.gw = gen_w_stride;
-    const size_t lds = (size_t)6 * gen_h * 64 * sizeof(float);           // <= 96 KB of the CU's 160 KB
+    const size_t lds = (size_t)4 * gen_h * 64 * sizeof(float);           // h0 / h1, double-buffered: <= 64 KB of the CU's 160 KB
     if (lds > 64 * 1024) {
         if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cl_lstm_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(cl_lstm_generic_kernel)");
     }
-    hipLaunchKernelGGL(cl_lstm_generic_kernel, dim3((dims->n_env + 63) / 64, dims->n_bldg), dim3(64), lds, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(cl_lstm_generic_kernel, dim3((dims->n_env + 63) / 64, dims->n_bldg), dim3(64 * CL_GEN_NWV), lds, (hipStream_t)stream, g);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_generic_kernel launch");
     return CL_OK;
 }

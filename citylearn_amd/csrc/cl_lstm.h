@@ -496,14 +496,20 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
 #endif
 }
 
-// ---- any other LSTM shape (hidden size <= 64, one or two layers): plain fp32 FMAs -------------------------------------
-// baeda_3dem's Building_4 is LSTM(11 -> 50, one layer).  One wave = 64 envs of one building, lane = env.  Hidden and cell
-// states live in LDS as [unit][lane] (conflict-free), the weights arrive by scalar loads in the order they are consumed:
+// ---- any other LSTM shape (hidden size <= 64, one or two layers; or a model that takes both demands): plain fp32 FMAs ----------------
+// baeda_3dem's Building_4 is LSTM(11 -> 50, one layer).  A workgroup = 64 envs of one building x CL_GEN_NWV waves; lane = env, and the
+// hidden UNITS are dealt to the waves (wave v owns units v * UPW .. : UPW = ceil(H / CL_GEN_NWV) <= 16).  A wave keeps the four gate
+// accumulators and the cell state of its units in registers, walks the input index k in the OUTER loop -- one LDS read of h[k] feeds
+// 4 * UPW FMAs whose weights arrive by scalar loads (wave-uniform addresses) -- and only the hidden state travels through LDS
+// ([2][H][64] per layer, double-buffered: one barrier per cell).
 //   gen_w   [B][GW]       per building: WX [H][12] (gates i, f, g, o of the demand input, of the temperature input, of the second demand input),
 //                         WHH0 [H][H][4], WIH1 [H][H][4], WHH1 [H][H][4], B1 [H][4], WLIN [H]   (H = the padded hidden size)
 //   gen_pre [T][B][H][4]  env-independent part of the layer-0 gates of (t, building)
 //   gen_hidden [B][4][H][E]  h0, c0, h1, c1 carried across env steps
-// Padded units have zero weights: their state stays 0.  Throughput is that of a fallback (H^2 scalar-fed FMAs per cell).
+// Padded units have zero weights: their state stays 0.
+// Round 3: the first version ran ONE wave per 64 envs with every state in LDS and the unit index in the outer loop (H^2 LDS reads per
+// cell, one wave per SIMD at 65 536 envs: nothing to hide its LDS and scalar-load latencies behind): 4.5 ms per step for baeda_3dem at
+// 4 x 65 536, 0.78 ms for a 2 x 16-unit model (profiles/r03c_lstm_generic_bench.log).
 struct LstmGenArgs {
     LstmArgs s;
     const float* __restrict__ gen_w;
@@ -513,40 +519,41 @@ struct LstmGenArgs {
     long long gw;   // floats per building in gen_w
 };
 
-CL_DEV void lstm_gen_cell(int H, const float* __restrict__ pre /* [H][4] or null */, const float* __restrict__ wx /* [H][12] or null */,
-                          float xc, float xt, float x2, const float* __restrict__ w_in /* [H][H][4] or null */, const float* in_h,
-                          const float* __restrict__ w_hh, const float* old_h, float* new_h, float* c, int lane) {
-    for (int u = 0; u < H; ++u) {
-        float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
-        if (pre) { g0 = pre[u * 4 + 0]; g1 = pre[u * 4 + 1]; g2 = pre[u * 4 + 2]; g3 = pre[u * 4 + 3]; }
-        if (wx) {
-            const float* q = wx + u * 12;
-            g0 = fmaf(q[0], xc, g0); g1 = fmaf(q[1], xc, g1); g2 = fmaf(q[2], xc, g2); g3 = fmaf(q[3], xc, g3);
-            g0 = fmaf(q[4], xt, g0); g1 = fmaf(q[5], xt, g1); g2 = fmaf(q[6], xt, g2); g3 = fmaf(q[7], xt, g3);
-            g0 = fmaf(q[8], x2, g0); g1 = fmaf(q[9], x2, g1); g2 = fmaf(q[10], x2, g2); g3 = fmaf(q[11], x2, g3);      // (zero weights without a second input)
-        }
-        if (w_in) {
-            const float* q = w_in + (long long)u * H * 4;
-            for (int k = 0; k < H; ++k) {
-                const float x = in_h[k * 64 + lane];
-                g0 = fmaf(q[k * 4 + 0], x, g0); g1 = fmaf(q[k * 4 + 1], x, g1); g2 = fmaf(q[k * 4 + 2], x, g2); g3 = fmaf(q[k * 4 + 3], x, g3);
+constexpr int CL_GEN_NWV = 4;        // waves per workgroup
+constexpr int CL_GEN_UPW = (CL_LSTM_GEN_HMAX + CL_GEN_NWV - 1) / CL_GEN_NWV;      // units per wave at most (16)
+
+// gates[j][0..3] += W[u0 + j][k][0..3] * x[k] for k < H: x from LDS ([k][64] floats), W ([unit][input][gate]) by scalar loads
+CL_DEV void lstm_gen_matvec(float (&g)[CL_GEN_UPW][4], const float* __restrict__ wmat, const float* xs, int H, int u0, int n_u, int lane) {
+    for (int k = 0; k < H; ++k) {
+        const float x = xs[k * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < CL_GEN_UPW; ++j) {
+            if (j < n_u) {                                          // wave-uniform
+                const float* __restrict__ q = wmat + ((long long)(u0 + j) * H + k) * 4;
+                g[j][0] = fmaf(q[0], x, g[j][0]); g[j][1] = fmaf(q[1], x, g[j][1]);
+                g[j][2] = fmaf(q[2], x, g[j][2]); g[j][3] = fmaf(q[3], x, g[j][3]);
             }
         }
-        const float* q = w_hh + (long long)u * H * 4;
-        for (int k = 0; k < H; ++k) {
-            const float x = old_h[k * 64 + lane];
-            g0 = fmaf(q[k * 4 + 0], x, g0); g1 = fmaf(q[k * 4 + 1], x, g1); g2 = fmaf(q[k * 4 + 2], x, g2); g3 = fmaf(q[k * 4 + 3], x, g3);
-        }
-        const float cn = sigmoidf_(g1) * c[u * 64 + lane] + sigmoidf_(g0) * tanhf_(g2);      // f c + i g
-        c[u * 64 + lane] = cn;
-        new_h[u * 64 + lane] = sigmoidf_(g3) * tanhf_(cn);                                   // o tanh(c)
     }
 }
 
-__global__ void __launch_bounds__(64) cl_lstm_generic_kernel(const LstmGenArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // h0 old / new, c0, h1 old / new, c1: 6 x [H][64]
+// the cell update of this wave's units: c in registers, new h into LDS
+CL_DEV void lstm_gen_update(const float (&g)[CL_GEN_UPW][4], float (&c)[CL_GEN_UPW], float* h_new, int u0, int n_u, int lane) {
+#pragma unroll
+    for (int j = 0; j < CL_GEN_UPW; ++j) {
+        if (j < n_u) {
+            const float cn = sigmoidf_(g[j][1]) * c[j] + sigmoidf_(g[j][0]) * tanhf_(g[j][2]);      // f c + i g
+            c[j] = cn;
+            h_new[(u0 + j) * 64 + lane] = sigmoidf_(g[j][3]) * tanhf_(cn);                          // o tanh(c)
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64 * CL_GEN_NWV) cl_lstm_generic_kernel(const LstmGenArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // h0 [2][H][64], h1 [2][H][64]
     const LstmArgs& a = g.s;
-    const int lane = threadIdx.x, b = blockIdx.y, H = g.H;
+    const int lane = threadIdx.x & 63, b = blockIdx.y, H = g.H;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int e = blockIdx.x * 64 + lane;
     const bool live = e < a.n_env;
     const int ec = live ? e : a.n_env - 1;
@@ -554,8 +561,11 @@ __global__ void __launch_bounds__(64) cl_lstm_generic_kernel(const LstmGenArgs g
     const long long off = (long long)b * a.n_env + ec;
     const float* __restrict__ W = a.lstm_w + (long long)b * CL_LSTM_NW;
     const float mode = W[CLW_ACTIVE];
-    if (mode < 2.0f) return;                                      // the matrix-core kernel (or nobody) owns this building
+    if (mode < 2.0f) return;                                      // the matrix-core kernel (or nobody) owns this building (whole workgroup)
     const int layers = mode >= 3.0f ? 2 : 1;
+    const int upw = (H + CL_GEN_NWV - 1) / CL_GEN_NWV;
+    const int u0 = wv * upw, n_u = max(0, min(upw, H - u0));      // this wave's units
+    const bool lead = wv == 0;                                    // the wave that owns the per-env side effects
     const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * 64) / CL_ROW0_BLOCK] : 0;
     const float* __restrict__ pre_t = a.dyn_pre + ((long long)(a.t + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
     const float cool = a.cool_dem[off];
@@ -564,48 +574,84 @@ __global__ void __launch_bounds__(64) cl_lstm_generic_kernel(const LstmGenArgs g
     const float dem = (W[CLW_DEM_HEAT] != 0.0f && a.heat_dem) ? a.heat_dem[off] : cool;
     const float cool_n = (dem - cmin) / (cmax - cmin);
     const int slot = a.t % CL_LSTM_LOOKBACK;
-    if (live) a.hist[(long long)slot * plane + off] = cool_n;                     // building.py:3068-3078
+    if (live && lead) a.hist[(long long)slot * plane + off] = cool_n;                     // building.py:3068-3078
     // a model that takes both demands: delivered heating is its second env-dependent input, with a ring of its own (rows 24 .. 35)
     const bool two = W[CLW_DEM2] != 0.0f && a.heat_dem;
     const float heat_n = two ? (a.heat_dem[off] - W[CLW_C2MIN]) / (W[CLW_C2MAX] - W[CLW_C2MIN]) : 0.0f;
-    if (live && two) a.hist[(long long)(2 * CL_LSTM_LOOKBACK + slot) * plane + off] = heat_n;
+    if (live && lead && two) a.hist[(long long)(2 * CL_LSTM_LOOKBACK + slot) * plane + off] = heat_n;
     float y = pre_t[CLPRE_TNORM];
     if (a.t >= CL_LSTM_LOOKBACK) {
-        float* h0 = lds, * h0n = lds + H * 64, * c0 = lds + 2 * H * 64, * h1 = lds + 3 * H * 64, * h1n = lds + 4 * H * 64, * c1 = lds + 5 * H * 64;
+        float* h0b[2] = {lds, lds + H * 64};
+        float* h1b[2] = {lds + 2 * H * 64, lds + 3 * H * 64};
         float* hid = g.gen_hidden + ((long long)b * 4 * H) * a.n_env + ec;
-        for (int u = 0; u < H; ++u) {
-            h0[u * 64 + lane] = hid[(long long)(0 * H + u) * a.n_env]; c0[u * 64 + lane] = hid[(long long)(1 * H + u) * a.n_env];
-            h1[u * 64 + lane] = hid[(long long)(2 * H + u) * a.n_env]; c1[u * 64 + lane] = hid[(long long)(3 * H + u) * a.n_env];
+        float c0[CL_GEN_UPW], c1[CL_GEN_UPW];
+#pragma unroll
+        for (int j = 0; j < CL_GEN_UPW; ++j) {
+            c0[j] = c1[j] = 0.0f;
+            if (j < n_u) {
+                const int u = u0 + j;
+                h0b[0][u * 64 + lane] = hid[(long long)(0 * H + u) * a.n_env]; c0[j] = hid[(long long)(1 * H + u) * a.n_env];
+                h1b[0][u * 64 + lane] = hid[(long long)(2 * H + u) * a.n_env]; c1[j] = hid[(long long)(3 * H + u) * a.n_env];
+            }
         }
+        __syncthreads();
         const float* __restrict__ G = g.gen_w + (long long)b * g.gw;
         const float* wx = G, * whh0 = wx + H * 12, * wih1 = whh0 + (long long)H * H * 4, * whh1 = wih1 + (long long)H * H * 4;
         const float* b1 = whh1 + (long long)H * H * 4, * wlin = b1 + H * 4;
+        int cur = 0;
         for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
             const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
             const float* __restrict__ pre = g.gen_pre + ((long long)(time + row0) * a.n_bldg + b) * H * 4;
             const float xc = s == CL_LSTM_LOOKBACK - 1 ? cool_n : a.hist[(long long)(time % CL_LSTM_LOOKBACK) * plane + off];
             const float xt = a.hist[(long long)(CL_LSTM_LOOKBACK + (time - 1) % CL_LSTM_LOOKBACK) * plane + off];
             const float x2 = !two ? 0.0f : (s == CL_LSTM_LOOKBACK - 1 ? heat_n : a.hist[(long long)(2 * CL_LSTM_LOOKBACK + time % CL_LSTM_LOOKBACK) * plane + off]);
-            lstm_gen_cell(H, pre, wx, xc, xt, x2, nullptr, nullptr, whh0, h0, h0n, c0, lane);
-            { float* sw = h0; h0 = h0n; h0n = sw; }
-            if (layers == 2) {
-                lstm_gen_cell(H, b1, nullptr, 0.0f, 0.0f, 0.0f, wih1, h0, whh1, h1, h1n, c1, lane);
-                float* sw = h1; h1 = h1n; h1n = sw;
+            float acc[CL_GEN_UPW][4];
+#pragma unroll
+            for (int j = 0; j < CL_GEN_UPW; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][q] = 0.0f;
+                if (j < n_u) {
+                    const float* __restrict__ p4 = pre + (u0 + j) * 4;
+                    const float* __restrict__ qx = wx + (u0 + j) * 12;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[j][q] = fmaf(qx[8 + q], x2, fmaf(qx[4 + q], xt, fmaf(qx[q], xc, p4[q])));      // (zero weights without a second input)
+                }
             }
+            lstm_gen_matvec(acc, whh0, h0b[cur], H, u0, n_u, lane);
+            lstm_gen_update(acc, c0, h0b[cur ^ 1], u0, n_u, lane);
+            __syncthreads();                                         // h0 of this window step complete
+            if (layers == 2) {
+#pragma unroll
+                for (int j = 0; j < CL_GEN_UPW; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[j][q] = j < n_u ? b1[(u0 + j) * 4 + q] : 0.0f;
+                }
+                lstm_gen_matvec(acc, wih1, h0b[cur ^ 1], H, u0, n_u, lane);
+                lstm_gen_matvec(acc, whh1, h1b[cur], H, u0, n_u, lane);
+                lstm_gen_update(acc, c1, h1b[cur ^ 1], u0, n_u, lane);
+                __syncthreads();
+            }
+            cur ^= 1;
         }
-        const float* top = layers == 2 ? h1 : h0;
-        float acc = W[CLW_BLIN];
-        for (int u = 0; u < H; ++u) acc = fmaf(wlin[u], top[u * 64 + lane], acc);
-        y = acc;
-        temp = fmaf(y, tmax - tmin, tmin);                                           // building.py:3031-3037
+        const float* top = layers == 2 ? h1b[cur] : h0b[cur];
+        if (lead) {
+            float out = W[CLW_BLIN];
+            for (int u = 0; u < H; ++u) out = fmaf(wlin[u], top[u * 64 + lane], out);
+            y = out;
+            temp = fmaf(y, tmax - tmin, tmin);                                           // building.py:3031-3037
+        }
         if (live) {
-            for (int u = 0; u < H; ++u) {
-                hid[(long long)(0 * H + u) * a.n_env] = h0[u * 64 + lane]; hid[(long long)(1 * H + u) * a.n_env] = c0[u * 64 + lane];
-                hid[(long long)(2 * H + u) * a.n_env] = h1[u * 64 + lane]; hid[(long long)(3 * H + u) * a.n_env] = c1[u * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < CL_GEN_UPW; ++j) {
+                if (j < n_u) {
+                    const int u = u0 + j;
+                    hid[(long long)(0 * H + u) * a.n_env] = h0b[cur][u * 64 + lane]; hid[(long long)(1 * H + u) * a.n_env] = c0[j];
+                    hid[(long long)(2 * H + u) * a.n_env] = h1b[layers == 2 ? cur : 0][u * 64 + lane]; hid[(long long)(3 * H + u) * a.n_env] = c1[j];
+                }
             }
         }
     }
-    if (live) {
+    if (live && lead) {
         a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;              // building.py:3027-3028
         lstm_outputs(a, W, pre_t, off, plane, temp, cool, a.heat_dem ? a.heat_dem[off] : 0.0f);
     }
