@@ -1778,7 +1778,7 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
 }
 
 int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* gen_w, int64_t gen_w_stride,
-                             const float* gen_pre, float* gen_hidden, int32_t gen_h, const float* cool_dem, const float* heat_dem,
+                             const float* gen_pre, float* gen_hidden, int32_t gen_h, int32_t gen_layers, const float* cool_dem, const float* heat_dem,
                              float* hist, float* indoor_temp, float* comfort, float* kpi_comfort, int32_t t, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     if (int rc = check_ptr(lstm_w, "lstm_w")) return rc;
@@ -1792,6 +1792,7 @@ int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const flo
     if (int rc = check_ptr(kpi_comfort, "kpi_comfort", false)) return rc;
     if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
     if (gen_h < 1 || gen_h > CL_LSTM_GEN_HMAX) return fail(CL_EINVAL, "gen_h=%d outside [1, %d]", gen_h, CL_LSTM_GEN_HMAX);
+    if (gen_layers != 1 && gen_layers != 2) return fail(CL_EINVAL, "gen_layers=%d (1 or 2: the deepest model among the generic-kernel buildings)", gen_layers);
     const long long need = (long long)gen_h * 12 + 3ll * gen_h * gen_h * 4 + gen_h * 4 + gen_h;
     if (gen_w_stride < need) return fail(CL_EINVAL, "gen_w_stride=%lld < %lld floats for hidden size %d", (long long)gen_w_stride, need, gen_h);
     LstmGenArgs g;
@@ -1800,12 +1801,19 @@ int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const flo
     a.indoor_temp = indoor_temp; a.heat_dem = heat_dem; a.comfort = comfort; a.kpi_comfort = kpi_comfort;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.t = t; a.env_row0 = dims->env_row0;
     g.gen_w = gen_w; g.gen_pre = gen_pre; g.gen_hidden = gen_hidden; g.H = gen_h; g.gw = gen_w_stride;
-    const size_t lds = (size_t)4 * gen_h * 64 * sizeof(float);           // h0 / h1, double-buffered: <= 64 KB of the CU's 160 KB
+    // LDS: hidden states [layers][2][H][64] and, when they fit beside them, the recurrent matrices (WHH0 (, WIH1, WHH1): [H][H][4] each),
+    // sized for the deepest model of the district (`gen_layers`)
+    const size_t lds_h = (size_t)gen_layers * 2 * gen_h * 64 * sizeof(float), lds_w = (size_t)(gen_layers == 2 ? 3 : 1) * gen_h * gen_h * 4 * sizeof(float);
+    const bool staged = lds_h + lds_w <= 150 * 1024;
+    const size_t lds = lds_h + (staged ? lds_w : 0);
+    const void* fn = staged ? reinterpret_cast<const void*>(cl_lstm_generic_kernel<true>) : reinterpret_cast<const void*>(cl_lstm_generic_kernel<false>);
     if (lds > 64 * 1024) {
-        if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cl_lstm_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(cl_lstm_generic_kernel)");
+        if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+            return hip_fail(e, "hipFuncSetAttribute(cl_lstm_generic_kernel)");
     }
-    hipLaunchKernelGGL(cl_lstm_generic_kernel, dim3((dims->n_env + 63) / 64, dims->n_bldg), dim3(64 * CL_GEN_NWV), lds, (hipStream_t)stream, g);
+    const dim3 ggrid((dims->n_env + 63) / 64, dims->n_bldg), gblock(64 * CL_GEN_NWV);
+    if (staged) hipLaunchKernelGGL(cl_lstm_generic_kernel<true>, ggrid, gblock, lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(cl_lstm_generic_kernel<false>, ggrid, gblock, lds, (hipStream_t)stream, g);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_lstm_generic_kernel launch");
     return CL_OK;
 }

@@ -522,16 +522,25 @@ struct LstmGenArgs {
 constexpr int CL_GEN_NWV = 4;        // waves per workgroup
 constexpr int CL_GEN_UPW = (CL_LSTM_GEN_HMAX + CL_GEN_NWV - 1) / CL_GEN_NWV;      // units per wave at most (16)
 
-// gates[j][0..3] += W[u0 + j][k][0..3] * x[k] for k < H: x from LDS ([k][64] floats), W ([unit][input][gate]) by scalar loads
-CL_DEV void lstm_gen_matvec(float (&g)[CL_GEN_UPW][4], const float* __restrict__ wmat, const float* xs, int H, int u0, int n_u, int lane) {
+// gates[j][0..3] += W[u0 + j][k][0..3] * x[k] for k < H: x from LDS ([k][64] floats); W ([unit][input][gate]) from the workgroup's
+// staged copy in LDS (STAGED: one broadcast ds_read_b128 per (unit, k) -- every lane reads the same address) or by scalar loads
+template <bool STAGED>
+CL_DEV void lstm_gen_matvec(float (&g)[CL_GEN_UPW][4], const float* wmat, const float* xs, int H, int u0, int n_u, int lane) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     for (int k = 0; k < H; ++k) {
         const float x = xs[k * 64 + lane];
 #pragma unroll
         for (int j = 0; j < CL_GEN_UPW; ++j) {
             if (j < n_u) {                                          // wave-uniform
-                const float* __restrict__ q = wmat + ((long long)(u0 + j) * H + k) * 4;
-                g[j][0] = fmaf(q[0], x, g[j][0]); g[j][1] = fmaf(q[1], x, g[j][1]);
-                g[j][2] = fmaf(q[2], x, g[j][2]); g[j][3] = fmaf(q[3], x, g[j][3]);
+                const float* q = wmat + ((long long)(u0 + j) * H + k) * 4;
+                if constexpr (STAGED) {
+                    const f4 w = *reinterpret_cast<const f4*>(q);
+                    g[j][0] = fmaf(w[0], x, g[j][0]); g[j][1] = fmaf(w[1], x, g[j][1]);
+                    g[j][2] = fmaf(w[2], x, g[j][2]); g[j][3] = fmaf(w[3], x, g[j][3]);
+                } else {
+                    g[j][0] = fmaf(q[0], x, g[j][0]); g[j][1] = fmaf(q[1], x, g[j][1]);
+                    g[j][2] = fmaf(q[2], x, g[j][2]); g[j][3] = fmaf(q[3], x, g[j][3]);
+                }
             }
         }
     }
@@ -549,8 +558,13 @@ CL_DEV void lstm_gen_update(const float (&g)[CL_GEN_UPW][4], float (&c)[CL_GEN_U
     }
 }
 
+// STAGED: the recurrent matrices of the building are copied into LDS once per workgroup (they are re-read by all 12 window steps): a
+// weight then costs a broadcast LDS read instead of a scalar load whose latency nothing hides -- with the weights through scalar loads a
+// 2 x 16-unit model took 750 us per step at 3 x 65 536 (16 dependent scalar round trips per matrix-vector product).  The host stages
+// whenever hidden state + matrices fit 150 KB of LDS (everything up to two layers of 45 units or one of 64).
+template <bool STAGED>
 __global__ void __launch_bounds__(64 * CL_GEN_NWV) cl_lstm_generic_kernel(const LstmGenArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // h0 [2][H][64], h1 [2][H][64]
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // h0 [2][H][64], h1 [2][H][64] (two layers), then (STAGED) the matrices
     const LstmArgs& a = g.s;
     const int lane = threadIdx.x & 63, b = blockIdx.y, H = g.H;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -582,7 +596,7 @@ __global__ void __launch_bounds__(64 * CL_GEN_NWV) cl_lstm_generic_kernel(const 
     float y = pre_t[CLPRE_TNORM];
     if (a.t >= CL_LSTM_LOOKBACK) {
         float* h0b[2] = {lds, lds + H * 64};
-        float* h1b[2] = {lds + 2 * H * 64, lds + 3 * H * 64};
+        float* h1b[2] = {lds + 2 * H * 64, lds + 3 * H * 64};              // (one layer: aliases the staging area, never touched)
         float* hid = g.gen_hidden + ((long long)b * 4 * H) * a.n_env + ec;
         float c0[CL_GEN_UPW], c1[CL_GEN_UPW];
 #pragma unroll
@@ -591,13 +605,20 @@ __global__ void __launch_bounds__(64 * CL_GEN_NWV) cl_lstm_generic_kernel(const 
             if (j < n_u) {
                 const int u = u0 + j;
                 h0b[0][u * 64 + lane] = hid[(long long)(0 * H + u) * a.n_env]; c0[j] = hid[(long long)(1 * H + u) * a.n_env];
-                h1b[0][u * 64 + lane] = hid[(long long)(2 * H + u) * a.n_env]; c1[j] = hid[(long long)(3 * H + u) * a.n_env];
+                if (layers == 2) { h1b[0][u * 64 + lane] = hid[(long long)(2 * H + u) * a.n_env]; c1[j] = hid[(long long)(3 * H + u) * a.n_env]; }
             }
         }
-        __syncthreads();
         const float* __restrict__ G = g.gen_w + (long long)b * g.gw;
         const float* wx = G, * whh0 = wx + H * 12, * wih1 = whh0 + (long long)H * H * 4, * whh1 = wih1 + (long long)H * H * 4;
         const float* b1 = whh1 + (long long)H * H * 4, * wlin = b1 + H * 4;
+        const float* m_hh0 = whh0, * m_ih1 = wih1, * m_hh1 = whh1;
+        if constexpr (STAGED) {
+            float* stage = lds + (layers == 2 ? 4 : 2) * H * 64;
+            const int n_w = (layers == 2 ? 3 : 1) * H * H * 4;                  // WHH0 (, WIH1, WHH1): contiguous in gen_w
+            for (int i = threadIdx.x; i < n_w; i += blockDim.x) stage[i] = whh0[i];
+            m_hh0 = stage; m_ih1 = stage + H * H * 4; m_hh1 = stage + 2 * H * H * 4;
+        }
+        __syncthreads();
         int cur = 0;
         for (int s = 0; s < CL_LSTM_LOOKBACK; ++s) {
             const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
@@ -617,7 +638,7 @@ __global__ void __launch_bounds__(64 * CL_GEN_NWV) cl_lstm_generic_kernel(const 
                     for (int q = 0; q < 4; ++q) acc[j][q] = fmaf(qx[8 + q], x2, fmaf(qx[4 + q], xt, fmaf(qx[q], xc, p4[q])));      // (zero weights without a second input)
                 }
             }
-            lstm_gen_matvec(acc, whh0, h0b[cur], H, u0, n_u, lane);
+            lstm_gen_matvec<STAGED>(acc, m_hh0, h0b[cur], H, u0, n_u, lane);
             lstm_gen_update(acc, c0, h0b[cur ^ 1], u0, n_u, lane);
             __syncthreads();                                         // h0 of this window step complete
             if (layers == 2) {
@@ -626,8 +647,8 @@ __global__ void __launch_bounds__(64 * CL_GEN_NWV) cl_lstm_generic_kernel(const 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[j][q] = j < n_u ? b1[(u0 + j) * 4 + q] : 0.0f;
                 }
-                lstm_gen_matvec(acc, wih1, h0b[cur ^ 1], H, u0, n_u, lane);
-                lstm_gen_matvec(acc, whh1, h1b[cur], H, u0, n_u, lane);
+                lstm_gen_matvec<STAGED>(acc, m_ih1, h0b[cur ^ 1], H, u0, n_u, lane);
+                lstm_gen_matvec<STAGED>(acc, m_hh1, h1b[cur], H, u0, n_u, lane);
                 lstm_gen_update(acc, c1, h1b[cur ^ 1], u0, n_u, lane);
                 __syncthreads();
             }
@@ -646,7 +667,7 @@ __global__ void __launch_bounds__(64 * CL_GEN_NWV) cl_lstm_generic_kernel(const 
                 if (j < n_u) {
                     const int u = u0 + j;
                     hid[(long long)(0 * H + u) * a.n_env] = h0b[cur][u * 64 + lane]; hid[(long long)(1 * H + u) * a.n_env] = c0[j];
-                    hid[(long long)(2 * H + u) * a.n_env] = h1b[layers == 2 ? cur : 0][u * 64 + lane]; hid[(long long)(3 * H + u) * a.n_env] = c1[j];
+                    if (layers == 2) { hid[(long long)(2 * H + u) * a.n_env] = h1b[cur][u * 64 + lane]; hid[(long long)(3 * H + u) * a.n_env] = c1[j]; }
                 }
             }
         }

@@ -329,9 +329,10 @@ class LSTMStage:
         if packed is not None:
             gen_w, gen_pre, gen_h = packed
             self.generic = dict(w=torch.from_numpy(gen_w).to(dev), pre=torch.from_numpy(gen_pre).to(dev), h=int(gen_h),
+                                layers=2 if bool((lstm_w[:, ACTIVE] == 3.0).any()) else 1,
                                 hidden=torch.zeros((B, 4, gen_h, E), dtype=torch.float32, device=dev))
             self.lib.cl_lstm_generic_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 3 + [ctypes.c_int64] + [
-                ctypes.c_void_p] * 2 + [ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_void_p]
+                ctypes.c_void_p] * 2 + [ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 6 + [ctypes.c_int32, ctypes.c_void_p]
         self.lib.cl_lstm_step_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 10 + [ctypes.c_int32, ctypes.c_void_p]
         self.lib.cl_lstm_reset_f32.argtypes = [ctypes.POINTER(_lib.Dims)] + [ctypes.c_void_p] * 4
         self.reset()
@@ -369,7 +370,7 @@ class LSTMStage:
             if not rc and self.generic is not None:
                 gn = self.generic
                 rc = self.lib.cl_lstm_generic_step_f32(head[0], head[1], head[3], gn['w'].data_ptr(), gn['w'].shape[1], gn['pre'].data_ptr(),
-                                                       gn['hidden'].data_ptr(), gn['h'], own_cd if cool_dem is None else cool_dem.data_ptr(),
+                                                       gn['hidden'].data_ptr(), gn['h'], gn['layers'], own_cd if cool_dem is None else cool_dem.data_ptr(),
                                                        hd, tail[1], tail[3], tail[4], tail[5], int(t), e._stream())
         if rc:
             _lib.check(rc)

@@ -410,10 +410,12 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
  *   gen_w      [n_bldg][gen_w_stride]   WX [H][12] (demand, temperature, second demand input), WHH0 [H][H][4], WIH1 [H][H][4], WHH1 [H][H][4], B1 [H][4], WLIN [H]  (gate order i, f, g, o;
  *                                        H = gen_h, the padded hidden size; csrc/cl_lstm.h, packer dynamics.pack_lstm_generic)
  *   gen_pre    [n_ts_rows][n_bldg][gen_h][4]  env-independent part of the layer-0 gates
- *   gen_hidden [n_bldg][4][gen_h][n_env]      h0, c0, h1, c1 carried across env steps (zero at episode start) */
+ *   gen_hidden [n_bldg][4][gen_h][n_env]      h0, c0, h1, c1 carried across env steps (zero at episode start)
+ *   gen_layers = 1 or 2: the deepest model among those buildings (sizes the kernel's LDS: hidden states and, when they fit beside them,
+ *                the recurrent matrices) */
 #define CL_LSTM_GEN_HMAX 64
 int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const float* dyn_pre, const float* gen_w, int64_t gen_w_stride,
-                             const float* gen_pre, float* gen_hidden, int32_t gen_h, const float* cool_dem, const float* heat_dem,
+                             const float* gen_pre, float* gen_hidden, int32_t gen_h, int32_t gen_layers, const float* cool_dem, const float* heat_dem,
                              float* hist, float* indoor_temp, float* comfort, float* kpi_comfort, int32_t t, void* stream);
 
 /* ---- observation epilogue ----
