@@ -234,7 +234,7 @@ class StepWorkload:
         self.name, self.what, self.E, self.device = name, what, E, device
         self.spec = spec
         self.tables = spec.episode_tables(0)
-        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, detail=lstm, f64_maps=f64, kpi=kpi)
+        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, detail='min' if lstm else False, f64_maps=f64, kpi=kpi)
         if kpi:
             self.what += '; CLD_KPI: streaming KPI accumulators of evaluate() updated every step (mode A-kpi)'
         if f64:
@@ -361,7 +361,7 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
         spec = load_district(sample_schema('citylearn_challenge_2023_phase_2_local_evaluation_720h'))
         return StepWorkload(cfg, spec, E, device, rank, tuning,
                             f'citylearn_challenge_2023_phase_2_local_evaluation (3 buildings: power outages, partial-load cooling, DHW tank, battery; '
-                            f'first 720 h) x {E} envs per GPU; one step = cl_step_f32 (energy step, detail planes) + cl_lstm_step_f32 (LSTM indoor '
+                            f'first 720 h) x {E} envs per GPU; one step = cl_step_f32 (energy step + the delivered-demand planes the stage reads) + cl_lstm_step_f32 (LSTM indoor '
                             'temperature + ComfortReward): the whole CityLearnEnv.step of this schema', lstm=True, f64=f64, kpi=kpi)
     if cfg in ('C4', 'C4-lean'):
         from citylearn_amd.synthetic import tile_district

@@ -38,7 +38,7 @@ class Tuning(ctypes.Structure):
                 ('envmajor', ctypes.c_int32), ('flex_vec', ctypes.c_int32), ('obs_variant', ctypes.c_int32),
                 ('obs_rows', ctypes.c_int32), ('lstm_variant', ctypes.c_int32), ('full_variant', ctypes.c_int32),
                 ('b_chunk', ctypes.c_int32), ('nt_stores', ctypes.c_int32), ('kernel_name', ctypes.c_void_p),
-                ('finish', ctypes.c_int32), ('reserved', ctypes.c_int32 * 1)]
+                ('finish', ctypes.c_int32), ('kpi_passes', ctypes.c_int32)]
 
 
 class Dims(ctypes.Structure):

@@ -503,21 +503,24 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
             full_store<VEC, NT>(a.out_bldg + CLO_NET * plane + off, O.net);
             if (rkind != CLR_MARL) full_store<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, rw);
             if constexpr (DETAIL) {
-                full_store<VEC, NT>(a.out_bldg + CLO_B_EB * plane + off, O.eb);
+                // what another kernel of the path reads: the KPI pass (baseline, expected, served) and the LSTM stage (delivered demands)
                 full_store<VEC, NT>(a.out_bldg + CLO_COOL_DEM * plane + off, O.cool_dem);
                 full_store<VEC, NT>(a.out_bldg + CLO_HEAT_DEM * plane + off, O.heat_dem);
-                full_store<VEC, NT>(a.out_bldg + CLO_DHW_DEM * plane + off, O.dhw_dem);
-                full_store<VEC, NT>(a.out_bldg + CLO_C_COOL * plane + off, O.c_cool);
-                full_store<VEC, NT>(a.out_bldg + CLO_C_HEAT * plane + off, O.c_heat);
-                full_store<VEC, NT>(a.out_bldg + CLO_C_DHW * plane + off, O.c_dhw);
-                full_store<VEC, NT>(a.out_bldg + CLO_C_NSL * plane + off, O.c_ns);
                 full_store<VEC, NT>(a.out_bldg + CLO_BASE_NET * plane + off, O.base_net);
                 full_store<VEC, NT>(a.out_bldg + CLO_EXPECTED * plane + off, O.expected);
                 full_store<VEC, NT>(a.out_bldg + CLO_SERVED * plane + off, O.served);
-                full_store<VEC, NT>(a.out_bldg + CLO_NET_WS * plane + off, O.net_ws);
-                full_store<VEC, NT>(a.out_bldg + CLO_SE_COOL * plane + off, O.se_cool);
-                full_store<VEC, NT>(a.out_bldg + CLO_SE_HEAT * plane + off, O.se_heat);
-                full_store<VEC, NT>(a.out_bldg + CLO_SE_DHW * plane + off, O.se_dhw);
+                if (!(a.flags & CLD_DETAIL_MIN)) {                           // the series of evaluate() / the observations / the parity tests
+                    full_store<VEC, NT>(a.out_bldg + CLO_B_EB * plane + off, O.eb);
+                    full_store<VEC, NT>(a.out_bldg + CLO_DHW_DEM * plane + off, O.dhw_dem);
+                    full_store<VEC, NT>(a.out_bldg + CLO_C_COOL * plane + off, O.c_cool);
+                    full_store<VEC, NT>(a.out_bldg + CLO_C_HEAT * plane + off, O.c_heat);
+                    full_store<VEC, NT>(a.out_bldg + CLO_C_DHW * plane + off, O.c_dhw);
+                    full_store<VEC, NT>(a.out_bldg + CLO_C_NSL * plane + off, O.c_ns);
+                    full_store<VEC, NT>(a.out_bldg + CLO_NET_WS * plane + off, O.net_ws);
+                    full_store<VEC, NT>(a.out_bldg + CLO_SE_COOL * plane + off, O.se_cool);
+                    full_store<VEC, NT>(a.out_bldg + CLO_SE_HEAT * plane + off, O.se_heat);
+                    full_store<VEC, NT>(a.out_bldg + CLO_SE_DHW * plane + off, O.se_dhw);
+                }
             }
             full_accumulate<VEC>(q_net, O.net); full_accumulate<VEC>(q_cost, O.cost); full_accumulate<VEC>(q_em, O.emission);
             // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)

@@ -453,21 +453,24 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
                 if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
                 if constexpr (FULL && DETAIL) {
-                    pstore<VEC, NT>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
+                    // what another kernel of the path reads: the KPI pass (baseline, expected, served) and the LSTM stage (delivered demands)
                     pstore<VEC, NT>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
                     pstore<VEC, NT>(a.out_bldg + CLO_HEAT_DEM * plane + off, o_hd);
-                    pstore<VEC, NT>(a.out_bldg + CLO_DHW_DEM * plane + off, o_dd);
-                    pstore<VEC, NT>(a.out_bldg + CLO_C_COOL * plane + off, o_cc);
-                    pstore<VEC, NT>(a.out_bldg + CLO_C_HEAT * plane + off, o_ch);
-                    pstore<VEC, NT>(a.out_bldg + CLO_C_DHW * plane + off, o_cw);
-                    pstore<VEC, NT>(a.out_bldg + CLO_C_NSL * plane + off, o_cn);
                     pstore<VEC, NT>(a.out_bldg + CLO_BASE_NET * plane + off, o_bn);
                     pstore<VEC, NT>(a.out_bldg + CLO_EXPECTED * plane + off, o_ex);
                     pstore<VEC, NT>(a.out_bldg + CLO_SERVED * plane + off, o_sv);
-                    pstore<VEC, NT>(a.out_bldg + CLO_NET_WS * plane + off, o_ws);
-                    pstore<VEC, NT>(a.out_bldg + CLO_SE_COOL * plane + off, o_sc);
-                    pstore<VEC, NT>(a.out_bldg + CLO_SE_HEAT * plane + off, o_sh);
-                    pstore<VEC, NT>(a.out_bldg + CLO_SE_DHW * plane + off, o_sd);
+                    if (!(a.flags & CLD_DETAIL_MIN)) {                       // the series of evaluate() / the observations / the parity tests
+                        pstore<VEC, NT>(a.out_bldg + CLO_B_EB * plane + off, o_eb);
+                        pstore<VEC, NT>(a.out_bldg + CLO_DHW_DEM * plane + off, o_dd);
+                        pstore<VEC, NT>(a.out_bldg + CLO_C_COOL * plane + off, o_cc);
+                        pstore<VEC, NT>(a.out_bldg + CLO_C_HEAT * plane + off, o_ch);
+                        pstore<VEC, NT>(a.out_bldg + CLO_C_DHW * plane + off, o_cw);
+                        pstore<VEC, NT>(a.out_bldg + CLO_C_NSL * plane + off, o_cn);
+                        pstore<VEC, NT>(a.out_bldg + CLO_NET_WS * plane + off, o_ws);
+                        pstore<VEC, NT>(a.out_bldg + CLO_SE_COOL * plane + off, o_sc);
+                        pstore<VEC, NT>(a.out_bldg + CLO_SE_HEAT * plane + off, o_sh);
+                        pstore<VEC, NT>(a.out_bldg + CLO_SE_DHW * plane + off, o_sd);
+                    }
                 }
             };
             if (a.nt) put(NtOn{}); else put(NtOff{});
@@ -994,6 +997,51 @@ __global__ void __launch_bounds__(1024) cl_kpi_env_kernel(const StepArgs a) {
     part[w][lane] = s;
     __syncthreads();
     if (w == 0 && e < a.n_env) {
+        float base = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) base += part[k][lane];
+        kpi_series_update(a.kpi_env + e, a.n_env, a.t, a.out_env[(long long)CLQ_NET * a.n_env + e]);
+        kpi_series_update(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + e, a.n_env, a.t, base);
+    }
+}
+
+// The two passes above in ONE launch (round 3): a workgroup = 64 envs x every building (16 waves share the building loop); a wave updates
+// the per-building accumulators of its buildings from the planes the step just wrote and keeps the baseline partial sum of its envs in a
+// register, the 16 partials are added in wave order through LDS (the order cl_kpi_env_kernel used: same bits) and wave 0 feeds the two
+// district series.  One launch and one read of the baseline plane less per step.
+__global__ void __launch_bounds__(1024) cl_kpi_kernel(const StepArgs a) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int e = blockIdx.x * 64 + lane;
+    const bool live = e < a.n_env;
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * 64) / CL_ROW0_BLOCK] : 0);      // 64 divides CL_ROW0_BLOCK: workgroup-uniform
+    float s = 0.0f;
+    for (int b = w; b < a.n_bldg; b += 16) {
+        const float* __restrict__ q = a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF;
+        const float price = q[CLT_PRICE], carbon = q[CLT_CARBON];
+        const bool outage = q[CLT_OUTAGE] != 0.0f;
+        if (!live) continue;
+        const long long i = (long long)b * a.n_env + e;
+        const float net = a.out_bldg[CLO_NET * plane + i], base = a.out_bldg[CLO_BASE_NET * plane + i];
+        const float ex = a.out_bldg[CLO_EXPECTED * plane + i], sv = a.out_bldg[CLO_SERVED * plane + i];
+        float* k = a.kpi_bldg + i;
+        k[CLK_C_POS * plane] += fmaxf(net, 0.0f);
+        k[CLK_C_NET * plane] += net;
+        k[CLK_C_EMISSION * plane] += fmaxf(net * carbon, 0.0f);
+        k[CLK_C_COST * plane] += fmaxf(net * price, 0.0f);
+        k[CLK_B_POS * plane] += fmaxf(base, 0.0f);
+        k[CLK_B_NET * plane] += base;
+        k[CLK_B_EMISSION * plane] += fmaxf(base * carbon, 0.0f);
+        k[CLK_B_COST * plane] += fmaxf(base * price, 0.0f);
+        if (outage) { k[CLK_UNSERVED_OUTAGE * plane] += ex - sv; k[CLK_EXPECTED_OUTAGE * plane] += ex; }       // (row-uniform: untouched otherwise)
+        k[CLK_UNSERVED_ALL * plane] += ex - sv;
+        k[CLK_EXPECTED_ALL * plane] += ex;
+        s += base;
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && live) {
         float base = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) base += part[k][lane];
@@ -1567,10 +1615,13 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (dims->flags & CLD_KPI) {
         const long long n = (long long)dims->n_env * dims->n_bldg;
         // (without the detail planes -- lean districts -- the step launch above has updated every accumulator itself)
-        if (dims->flags & CLD_WRITE_DETAIL) {
+        if ((dims->flags & CLD_WRITE_DETAIL) && tun.kpi_passes == 2) {            // the round-1 / round-2 form: two passes (tests, A/B)
             name_add(tun, "cl_kpi_bldg_kernel+cl_kpi_env_kernel");
             hipLaunchKernelGGL(cl_kpi_bldg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
             hipLaunchKernelGGL(cl_kpi_env_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
+        } else if (dims->flags & CLD_WRITE_DETAIL) {
+            name_add(tun, "cl_kpi_kernel");
+            hipLaunchKernelGGL(cl_kpi_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);
         }
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");

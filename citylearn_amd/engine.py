@@ -48,7 +48,7 @@ class StepEngine:
     """
 
     def __init__(self, tables: EpisodeTables, n_env: int, device: str = 'cuda:0', reward: str = 'RewardFunction',
-                 t0_quirk: bool = True, detail: bool = False, n_act_cols: Optional[int] = None, kpi: bool = False,
+                 t0_quirk: bool = True, detail=False, n_act_cols: Optional[int] = None, kpi: bool = False,
                  n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0,
                  charger_detail: bool = False, ev_penalty_coefficient: float = 1.0, central_agent: bool = False, tuning: Optional[dict] = None,
                  env_offset: int = 0, f64_maps: bool = False):
@@ -112,10 +112,19 @@ class StepEngine:
         # the streaming KPI passes read the detail planes -- except for battery + PV districts of up to 32 buildings, whose step kernel
         # updates the per-building accumulators itself (cl_step_lean_kpi_kernel): no detail planes, no second pass
         kpi_in_step = kpi and self.lean and self.n_bldg <= 32 and self.flex_tables is None and not f64_maps
-        flags |= abi.CLD_WRITE_DETAIL if (detail or (kpi and not kpi_in_step)) else 0
+        # `detail`: True = every detail plane (observations, evaluate()'s series, parity tests, reward plugins); 'min' = only the planes
+        # another kernel of the path reads (CLD_DETAIL_MIN: baseline / expected / served for the KPI pass, delivered demands for the LSTM
+        # stage) -- which is also what streaming KPIs alone ask for
+        if detail not in (True, False, 'min'):
+            raise ValueError("detail must be True, False or 'min'")
+        if detail is False and kpi and not kpi_in_step:
+            detail = 'min'
+        flags |= abi.CLD_WRITE_DETAIL if detail else 0
+        flags |= abi.CLD_DETAIL_MIN if detail == 'min' else 0
         # ... and keeps the env-independent sums of such a district (baseline, expected energy, baseline district series) once per block
         # of CL_ROW0_BLOCK envs, at the block's first env (include/citylearn_amd.h, CLD_KPI): `kpi.finalize_streaming(shared_baseline=True)`
         self.kpi_shared_baseline = bool(kpi_in_step and not detail)
+        self.detail = detail
         es_cols = tables.params.view(np.int32)[:, abi.CLP_ACT_ELEC_STO]
         if np.array_equal(es_cols, np.arange(self.n_bldg)):          # one battery action per building, building order
             flags |= abi.CLD_ES_COL_IS_BLDG
@@ -125,7 +134,7 @@ class StepEngine:
         # launch-geometry overrides of tests / tuning scripts travel with every call (`cl_dims.tuning`); all zero = defaults
         self.tuning = _lib.Tuning()
         for key, value in (tuning or {}).items():
-            if key not in dict(_lib.Tuning._fields_) or key in ('reserved', 'kernel_name'):
+            if key not in dict(_lib.Tuning._fields_) or key == 'kernel_name':
                 raise ValueError(f'unknown tuning field {key!r}')
             setattr(self.tuning, key, int(value))
         self.dims = _lib.Dims(self.n_env, self.n_bldg, self.n_steps, self.n_act_cols, flags, self.n_ts_rows,

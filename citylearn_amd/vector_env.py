@@ -150,7 +150,7 @@ class VectorCityLearnEnv:
             'non_shiftable_load': col(abi.CLT_NSL), 'solar_generation': -col(abi.CLT_SOLAR),
             'outdoor_dry_bulb_temperature': col(abi.CLT_T_OUT), 'hvac_mode': col(abi.CLT_HVAC_MODE), 'power_outage': col(abi.CLT_OUTAGE),
         }
-        if e.dims.flags & abi.CLD_WRITE_DETAIL:
+        if e.detail is True:                         # (every detail plane, not the 'min' subset of the KPI pass / the LSTM stage)
             planes.update({'cooling_demand': e.out_bldg[abi.CLO_COOL_DEM], 'heating_demand': e.out_bldg[abi.CLO_HEAT_DEM],
                            'dhw_demand': e.out_bldg[abi.CLO_DHW_DEM], 'cooling_electricity_consumption': e.out_bldg[abi.CLO_C_COOL],
                            'heating_electricity_consumption': e.out_bldg[abi.CLO_C_HEAT], 'dhw_electricity_consumption': e.out_bldg[abi.CLO_C_DHW]})
@@ -221,8 +221,9 @@ class VectorCityLearnEnv:
         self.engine = StepEngine(self.tables, self.n_envs, device=str(self.device), reward=self.reward_name,
                                  t0_quirk=self.reference_quirks, kpi=self.kpi, n_steps=n_steps, env_row0=row0,
                                  # (a batched reward plugin sees the reference's full reward-observation key set: detail planes on)
-                                 detail=any(b.is_dynamics for b in self.spec.buildings) or bool(obs_tables and obs_tables.needs_detail)
-                                 or self._plugin is not None,
+                                 # ... and the LSTM stage alone only reads the delivered-demand planes: detail 'min'
+                                 detail=True if (bool(obs_tables and obs_tables.needs_detail) or self._plugin is not None)
+                                 else ('min' if any(b.is_dynamics for b in self.spec.buildings) else False),
                                  ev_reward_weights=self._rf_attrs.get('weights'), ev_drift=self._ev_drift, central_agent=self.central_agent,
                                  ev_penalty_coefficient=self._rf_attrs.get('charging_constraint_penalty_coefficient') or 1.0,
                                  ev_seed=(self.spec.random_seed if self._ev_seed is None else self._ev_seed) + self._episode, env_offset=self.env_offset,

@@ -263,6 +263,9 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
                                          fp32 map is locally expansive on the steep part of the capacity-power curve: DESIGN.md section 3).
                                          Slower launches (general / lean step kernels only; not the fused rollout, the env-major or the
                                          thermal-specialised kernels). */
+#define CLD_DETAIL_MIN     (1u << 12) /* with CLD_WRITE_DETAIL: write only the detail planes another kernel of the path reads -- CLO_BASE_NET,
+                                         CLO_EXPECTED, CLO_SERVED (the streaming KPI pass) and CLO_COOL_DEM, CLO_HEAT_DEM (the LSTM stage) -- and
+                                         leave the other ten alone (5 instead of 15 extra planes per step) */
 #define CLD_REWARD_SHIFT   8          /* reward kind in bits 8..11 */
 #define CLD_REWARD_MASK    (0xFu << CLD_REWARD_SHIFT)
 enum cl_reward_kind {
@@ -298,7 +301,8 @@ typedef struct cl_tuning {
     int32_t finish;         /* building-chunked launches (districts of more than 32 buildings): 0 / 1 = a second launch folds the chunk partial
                                sums (cl_finish_kernel), 2 = the last chunk of an env tile to arrive folds them inside the step launch
                                (measured slower: csrc/cl_kernels.hip district_reduce; tests, A/B) */
-    int32_t reserved[1];
+    int32_t kpi_passes;     /* streaming KPIs of districts stepped with the detail planes: 0 / 1 = one launch after the step (cl_kpi_kernel),
+                               2 = the two passes of rounds 1 - 2 (cl_kpi_bldg_kernel + cl_kpi_env_kernel; tests, A/B) */
 } cl_tuning;
 #define CL_KERNEL_NAME_LEN 256
 

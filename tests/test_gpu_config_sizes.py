@@ -243,3 +243,30 @@ def test_kpi_accumulators_updated_by_the_lean_step_kernel(E, tuning):
     for k in d2:
         torch.testing.assert_close(d1[k], d2[k], rtol=1e-4, atol=1e-5, equal_nan=True)
     assert fused.kpi_bldg.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize('name,E', [('g2020_cz1', 65536), ('g2023_p2', 516), ('g2022_evs', 260)])
+def test_streaming_kpis_in_one_pass_over_the_minimal_detail_planes(name, E):
+    """Districts whose KPI baseline depends on the env (thermal, outage, EV): the step writes only the detail planes another kernel reads
+    (`CLD_DETAIL_MIN`: baseline, expected, served, delivered demands) and ONE launch (`cl_kpi_kernel`) updates every accumulator -- same
+    bits as the step with all fifteen detail planes followed by the two passes of rounds 1 - 2 (`cl_tuning.kpi_passes = 2`)."""
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    new = StepEngine(tab, E, kpi=True)                                   # detail 'min' by itself
+    old = StepEngine(tab, E, kpi=True, detail=True, tuning=dict(kpi_passes=2))
+    new.trace_kernels(); old.trace_kernels()
+    assert new.detail == 'min' and (new.dims.flags & abi.CLD_DETAIL_MIN) and not (old.dims.flags & abi.CLD_DETAIL_MIN)
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda()[:, None], torch.from_numpy(high).cuda()[:, None]
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    for t in range(40):
+        a = (lo + torch.rand((new.n_act_cols, E), device='cuda', generator=gen) * (hi - lo)).contiguous()
+        new.step(a, t); old.step(a, t)
+    assert new.last_kernels.endswith('+cl_kpi_kernel') and old.last_kernels.endswith('cl_kpi_bldg_kernel+cl_kpi_env_kernel')
+    assert torch.equal(new.state, old.state) and torch.equal(new.out_env, old.out_env)
+    for pl in (abi.CLO_NET, abi.CLO_REWARD, abi.CLO_BASE_NET, abi.CLO_EXPECTED, abi.CLO_SERVED, abi.CLO_COOL_DEM, abi.CLO_HEAT_DEM):
+        assert torch.equal(new.out_bldg[pl], old.out_bldg[pl]), pl
+    assert not new.out_bldg[abi.CLO_C_NSL].any() and old.out_bldg[abi.CLO_C_NSL].any()          # the other planes are left alone
+    assert torch.equal(new.kpi_bldg, old.kpi_bldg) and torch.equal(new.kpi_env, old.kpi_env)
+    assert float(new.kpi_bldg.abs().sum()) > 0
