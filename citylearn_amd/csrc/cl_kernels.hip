@@ -531,6 +531,7 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
     for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
     float s_soc[2][VEC], s_eff[2][VEC], s_deg[2][VEC], a_es[2][VEC];
     [[maybe_unused]] float s_efl[2][VEC], s_dgl[2][VEC];             // CLD_F64_MAPS: low words of efficiency / degraded capacity
+    [[maybe_unused]] float k_pos[2][VEC], k_net[2][VEC], k_em[2][VEC], k_cost[2][VEC];      // KPI: the four control sums, fetched with the state
     CL_TRACE_DECL;
     CL_TRACE_ENTRY(0);
     CL_TRACE_CYCLES_ENTRY(4);
@@ -547,6 +548,12 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
                 pload<VEC, NT>(s_dgl[m], a.state + CLS_B_DEGCAP_LO * plane + off);
             }
             if (act_by_bldg) pload<VEC, NT>(a_es[m], a.actions + (long long)bb[m] * a.act_stride_col + env0);
+            if constexpr (KPI && !FLEX) {
+                // the accumulators arrive with the state: behind the arithmetic they were four more exposed round trips per building
+                const float* kp = a.kpi_bldg + off;
+                vload<VEC>(k_pos[m], kp + (long long)CLK_C_POS * plane); vload<VEC>(k_net[m], kp + (long long)CLK_C_NET * plane);
+                vload<VEC>(k_em[m], kp + (long long)CLK_C_EMISSION * plane); vload<VEC>(k_cost[m], kp + (long long)CLK_C_COST * plane);
+            }
         }
     }
 #pragma unroll
@@ -677,25 +684,16 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             // do not move; and its baseline -- the net without the battery (building.py:345-366) = load + solar -- and its expected
             // energy do not depend on the env at all: those five sums are kept ONCE per block of CL_ROW0_BLOCK envs (the envs that share
             // a table row), at the block's first env.  Per (env, building) only the four control sums move: 32 B on top of the step's 37.
-            auto add = [&](int kp, const float (&x)[VEC]) {
-                float k[VEC];
-                float* p = a.kpi_bldg + (long long)kp * plane + off;
-                vload<VEC>(k, p);
+            // (loaded at the top of the kernel, with the state planes: `acc += x` plane after plane is a chain of dependent round trips -- a
+            //  store to one accumulator plane may alias the next plane's load as far as the compiler knows)
+            float* kp = a.kpi_bldg + off;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) k[i] += x[i];
-                pstore<VEC, NT>(p, k);                            // (nt like the other planes: 32.0 -> 30.8 us per step at 17 x 65 536)
-            };
-            float v[VEC];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(o_net[i], 0.0f);
-            add(CLK_C_POS, v);
-            add(CLK_C_NET, o_net);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(o_net[i] * R.carbon, 0.0f);
-            add(CLK_C_EMISSION, v);
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) v[i] = fmaxf(o_net[i] * R.price, 0.0f);
-            add(CLK_C_COST, v);
+            for (int i = 0; i < VEC; ++i) {
+                k_pos[m][i] += fmaxf(o_net[i], 0.0f); k_net[m][i] += o_net[i];
+                k_em[m][i] += fmaxf(o_net[i] * R.carbon, 0.0f); k_cost[m][i] += fmaxf(o_net[i] * R.price, 0.0f);
+            }
+            pstore<VEC, NT>(kp + (long long)CLK_C_POS * plane, k_pos[m]); pstore<VEC, NT>(kp + (long long)CLK_C_NET * plane, k_net[m]);
+            pstore<VEC, NT>(kp + (long long)CLK_C_EMISSION * plane, k_em[m]); pstore<VEC, NT>(kp + (long long)CLK_C_COST * plane, k_cost[m]);
             const float c_ns0 = (quirk && a.t == 0) ? 3.0f * R.nsl : R.nsl;
             const float base = fmaf(c_ns0, B.r, R.sol);                          // the step's net with the battery term left out
             if (lane == 0) {
@@ -1025,18 +1023,27 @@ __global__ void __launch_bounds__(1024) cl_kpi_kernel(const StepArgs a) {
         const long long i = (long long)b * a.n_env + e;
         const float net = a.out_bldg[CLO_NET * plane + i], base = a.out_bldg[CLO_BASE_NET * plane + i];
         const float ex = a.out_bldg[CLO_EXPECTED * plane + i], sv = a.out_bldg[CLO_SERVED * plane + i];
+        // every accumulator is LOADED before the first one is stored: `k[p * plane] += x` one after the other is a chain of dependent
+        // round trips (a store to k[p * plane] may alias the next load as far as the compiler knows) -- that chain, not the bytes, was
+        // the 20 us of the round-2 passes
         float* k = a.kpi_bldg + i;
-        k[CLK_C_POS * plane] += fmaxf(net, 0.0f);
-        k[CLK_C_NET * plane] += net;
-        k[CLK_C_EMISSION * plane] += fmaxf(net * carbon, 0.0f);
-        k[CLK_C_COST * plane] += fmaxf(net * price, 0.0f);
-        k[CLK_B_POS * plane] += fmaxf(base, 0.0f);
-        k[CLK_B_NET * plane] += base;
-        k[CLK_B_EMISSION * plane] += fmaxf(base * carbon, 0.0f);
-        k[CLK_B_COST * plane] += fmaxf(base * price, 0.0f);
-        if (outage) { k[CLK_UNSERVED_OUTAGE * plane] += ex - sv; k[CLK_EXPECTED_OUTAGE * plane] += ex; }       // (row-uniform: untouched otherwise)
-        k[CLK_UNSERVED_ALL * plane] += ex - sv;
-        k[CLK_EXPECTED_ALL * plane] += ex;
+        float v[CL_NKB];
+#pragma unroll
+        for (int p = 0; p < CL_NKB; ++p) v[p] = (outage || (p != CLK_UNSERVED_OUTAGE && p != CLK_EXPECTED_OUTAGE)) ? k[p * plane] : 0.0f;
+        v[CLK_C_POS] += fmaxf(net, 0.0f);
+        v[CLK_C_NET] += net;
+        v[CLK_C_EMISSION] += fmaxf(net * carbon, 0.0f);
+        v[CLK_C_COST] += fmaxf(net * price, 0.0f);
+        v[CLK_B_POS] += fmaxf(base, 0.0f);
+        v[CLK_B_NET] += base;
+        v[CLK_B_EMISSION] += fmaxf(base * carbon, 0.0f);
+        v[CLK_B_COST] += fmaxf(base * price, 0.0f);
+        v[CLK_UNSERVED_OUTAGE] += ex - sv; v[CLK_EXPECTED_OUTAGE] += ex;
+        v[CLK_UNSERVED_ALL] += ex - sv;
+        v[CLK_EXPECTED_ALL] += ex;
+#pragma unroll
+        for (int p = 0; p < CL_NKB; ++p)
+            if (outage || (p != CLK_UNSERVED_OUTAGE && p != CLK_EXPECTED_OUTAGE)) k[p * plane] = v[p];       // (row-uniform: the outage sums are untouched otherwise)
         s += base;
     }
     part[w][lane] = s;
