@@ -531,7 +531,6 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
     for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
     float s_soc[2][VEC], s_eff[2][VEC], s_deg[2][VEC], a_es[2][VEC];
     [[maybe_unused]] float s_efl[2][VEC], s_dgl[2][VEC];             // CLD_F64_MAPS: low words of efficiency / degraded capacity
-    [[maybe_unused]] float k_pos[2][VEC], k_net[2][VEC], k_em[2][VEC], k_cost[2][VEC];      // KPI: the four control sums, fetched with the state
     CL_TRACE_DECL;
     CL_TRACE_ENTRY(0);
     CL_TRACE_CYCLES_ENTRY(4);
@@ -548,12 +547,6 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
                 pload<VEC, NT>(s_dgl[m], a.state + CLS_B_DEGCAP_LO * plane + off);
             }
             if (act_by_bldg) pload<VEC, NT>(a_es[m], a.actions + (long long)bb[m] * a.act_stride_col + env0);
-            if constexpr (KPI && !FLEX) {
-                // the accumulators arrive with the state: behind the arithmetic they were four more exposed round trips per building
-                const float* kp = a.kpi_bldg + off;
-                vload<VEC>(k_pos[m], kp + (long long)CLK_C_POS * plane); vload<VEC>(k_net[m], kp + (long long)CLK_C_NET * plane);
-                vload<VEC>(k_em[m], kp + (long long)CLK_C_EMISSION * plane); vload<VEC>(k_cost[m], kp + (long long)CLK_C_COST * plane);
-            }
         }
     }
 #pragma unroll
@@ -684,16 +677,19 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             // do not move; and its baseline -- the net without the battery (building.py:345-366) = load + solar -- and its expected
             // energy do not depend on the env at all: those five sums are kept ONCE per block of CL_ROW0_BLOCK envs (the envs that share
             // a table row), at the block's first env.  Per (env, building) only the four control sums move: 32 B on top of the step's 37.
-            // (loaded at the top of the kernel, with the state planes: `acc += x` plane after plane is a chain of dependent round trips -- a
-            //  store to one accumulator plane may alias the next plane's load as far as the compiler knows)
+            // (the four loads are issued together, before the first store.  Fetching them at the top of the kernel with the state planes was
+            //  measured and is slower -- 17.8 vs 15.9 us at 17 x 65 536: 117 instead of 89 VGPRs and 32 more floats per lane in the first burst)
+            float k_pos[VEC], k_net[VEC], k_em[VEC], k_cost[VEC];
             float* kp = a.kpi_bldg + off;
+            vload<VEC>(k_pos, kp + (long long)CLK_C_POS * plane); vload<VEC>(k_net, kp + (long long)CLK_C_NET * plane);
+            vload<VEC>(k_em, kp + (long long)CLK_C_EMISSION * plane); vload<VEC>(k_cost, kp + (long long)CLK_C_COST * plane);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                k_pos[m][i] += fmaxf(o_net[i], 0.0f); k_net[m][i] += o_net[i];
-                k_em[m][i] += fmaxf(o_net[i] * R.carbon, 0.0f); k_cost[m][i] += fmaxf(o_net[i] * R.price, 0.0f);
+                k_pos[i] += fmaxf(o_net[i], 0.0f); k_net[i] += o_net[i];
+                k_em[i] += fmaxf(o_net[i] * R.carbon, 0.0f); k_cost[i] += fmaxf(o_net[i] * R.price, 0.0f);
             }
-            pstore<VEC, NT>(kp + (long long)CLK_C_POS * plane, k_pos[m]); pstore<VEC, NT>(kp + (long long)CLK_C_NET * plane, k_net[m]);
-            pstore<VEC, NT>(kp + (long long)CLK_C_EMISSION * plane, k_em[m]); pstore<VEC, NT>(kp + (long long)CLK_C_COST * plane, k_cost[m]);
+            pstore<VEC, NT>(kp + (long long)CLK_C_POS * plane, k_pos); pstore<VEC, NT>(kp + (long long)CLK_C_NET * plane, k_net);
+            pstore<VEC, NT>(kp + (long long)CLK_C_EMISSION * plane, k_em); pstore<VEC, NT>(kp + (long long)CLK_C_COST * plane, k_cost);
             const float c_ns0 = (quirk && a.t == 0) ? 3.0f * R.nsl : R.nsl;
             const float base = fmaf(c_ns0, B.r, R.sol);                          // the step's net with the battery term left out
             if (lane == 0) {
