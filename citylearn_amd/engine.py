@@ -323,6 +323,23 @@ class StepEngine:
                 _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env), int(t0), int(k_steps), self._stream()))
         self.t = t0 + k_steps
 
+    def step_many(self, actions: torch.Tensor, t0: Optional[int] = None):
+        """``actions.shape[0]`` consecutive env steps enqueued by ONE C call (`cl_rollout_seq_f32` with an open-loop action tensor
+        ``[k, n_act_cols, n_env]``, any strides): the same launches as k calls of :meth:`step`, without k trips through Python and ctypes
+        -- for callers that already hold the next k actions (replay, evaluation of a fixed schedule, `bench.py`'s short timed regions)."""
+        t0 = self.t if t0 is None else t0
+        k = int(actions.shape[0])
+        if actions.dtype != torch.float32 or actions.device != self.device or tuple(actions.shape[1:]) != (self.n_act_cols, self.n_env):
+            raise ValueError(f'actions must be float32 [k, {self.n_act_cols}, {self.n_env}] on {self.device}')
+        st = actions.stride()
+        with self._on_device():
+            rc = self.lib.cl_rollout_seq_f32(ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), actions.data_ptr(), st[0], st[1], st[2],
+                                             None, None, 0, None, _ptr(self.out_bldg), _ptr(self.out_env), None, _ptr(self.kpi_bldg), _ptr(self.kpi_env),
+                                             self._flex_ref, int(t0), k, self._stream())
+        if rc:
+            _lib.check(rc)
+        self.t = t0 + k
+
     # convenient views ------------------------------------------------------------------------------------
     @property
     def soc(self) -> torch.Tensor:

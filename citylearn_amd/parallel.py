@@ -77,7 +77,8 @@ def launch_ranks(argv: Sequence[str], world: int, timeout: Optional[float] = Non
     for r in range(world):
         env = rank_environment(r, world, port)
         env.update(extra_env or {})
-        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None, text=True))
+        # (ranks > 0: stdout onto this process's stderr -- file descriptor 2, whatever object sys.stderr currently is)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else 2, stderr=None, text=True))
     t0, rc = time.monotonic(), 0
     out0 = ''
     try:

@@ -207,3 +207,17 @@ def test_vector_env_rollout_keeps_streaming_kpis():
         torch.testing.assert_close(bld_b[k], bld_a[k], rtol=0, atol=0, equal_nan=True)
     for k in dis_a:
         torch.testing.assert_close(dis_b[k], dis_a[k], rtol=0, atol=0, equal_nan=True)
+
+
+def test_step_many_is_k_steps_from_one_call():
+    """`StepEngine.step_many` (one C call enqueuing k step launches, `cl_rollout_seq_f32` with open-loop actions) == k calls of `step`."""
+    g = golden('g2022_all')
+    tab = g.spec().episode_tables(0)
+    E, K = 260, 9
+    a, b = StepEngine(tab, E, reward='MARL'), StepEngine(tab, E, reward='MARL')
+    acts = torch.rand((K, a.n_act_cols, E), device='cuda', generator=torch.Generator(device='cuda').manual_seed(4)) * 2 - 1
+    for k in range(K):
+        a.step(acts[k], 3 + k)
+    b.step_many(acts, 3)
+    assert b.t == a.t == 3 + K
+    assert torch.equal(a.state, b.state) and torch.equal(a.out_bldg[:2], b.out_bldg[:2]) and torch.equal(a.out_env, b.out_env)
