@@ -18,7 +18,8 @@ Configs (`--config`, default `headline`):
   C5        fused 24-step day rollout per launch with the on-device Philox random policy, 17 buildings x 32 768 envs per GPU (the
             per-GPU shard of 262 144 envs on 8 GPUs); a "step" of the line is one 24-step launch
 
-Timing protocol: W untimed warmup steps, then EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks --
+Timing protocol: W untimed warmup steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides (every rank reads its
+clock between its own two synchronizes, the closing barrier follows), MAX over ranks --
 repeated `--reps` times on the same pre-captured, pre-replayed hipGraphs; the line reports the MEDIAN repetition (all repetitions
 in `rep_ms_per_step`, every rank's median in `rank_ms_per_step`).  The kernel duration behind `roofline` comes from HIP events
 recorded on the launch stream around max(K, 2000) consecutive steps of the same loop enqueued behind a lead-in chunk (no host
@@ -188,9 +189,10 @@ def timed_reps(runner: Runner, reset_fn, warmup: int, steps: int, reps: int, dis
             ev1.record(stream)
             stream.synchronize()
             torch.cuda.synchronize()
+            wall = time.perf_counter() - t0          # this rank's K steps, synchronize to synchronize; the line reports the MAX over ranks
             if dist is not None:
-                dist.barrier()
-            wall = time.perf_counter() - t0
+                dist.barrier()                       # the closing barrier of the bracket: after the clock is read -- a 30 us RCCL barrier inside
+                                                     # a 20-step region would bill every rank 1.5 us per step for the collective's own latency
             out.append((wall, ev0.elapsed_time(ev1) / 1e3))
         # Kernel duration for the roofline: HIP events on the launch stream around `kernel_steps` consecutive steps of the same loop
         # (graphs of GRAPH_CHUNK steps, captured and replayed once beforehand) enqueued behind a lead-in chunk, so that the bracket
