@@ -29,7 +29,7 @@
 #define CL_LSTM_H 16            /* hidden size */
 #define CL_LSTM_LOOKBACK 12
 #define CL_LSTM_NHIDDEN_ 64      /* h0, c0, h1, c1 per (building, env): hidden[b][e][64] */
-#define CL_LSTM_NW 3296         /* floats per building in `lstm_w` */
+#define CL_LSTM_NW 3360         /* floats per building in `lstm_w` */
 #define CL_LSTM_NPRE 80         /* floats per (t, building) in `dyn_pre` */
 // lstm_w layout
 #define CLW_WC 0                /* W_ih0[:, cooling_demand]  [64] */
@@ -50,9 +50,10 @@
 #define CLW_RW_LOEXP 3287
 #define CLW_RW_HIEXP 3288
 #define CLW_DEM_HEAT 3290        /* != 0: the model's demand input is heating_demand (delivered heating plane), not cooling_demand */
-#define CLW_DEM2 3291            /* != 0 (generic kernel only): the model takes BOTH demands -- cooling first, heating as a second env-dependent input */
+#define CLW_DEM2 3291            /* != 0: the model takes BOTH demands -- cooling first, delivered heating as a second env-dependent input */
 #define CLW_C2MIN 3292           /* normalisation of that second input */
 #define CLW_C2MAX 3293
+#define CLW_W2 3296              /* W_ih0[:, second demand input] [64] (matrix-core kernel; zeros without one) */
 #define CLW_KPI_BAND 3289        /* comfort band of the discomfort KPIs (evaluate()'s scalar, citylearn.py:1191) */
 // dyn_pre layout: [0..63] layer-0 pre-gates, [64] data-file temperature (normalised), [65] data-file temperature [C]
 #define CLPRE_TNORM 64
@@ -294,6 +295,8 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
         if (act != 0.0f && live && hh == 0) {
             a.hist[(long long)slot * plane + off] = (dem_src[off] - cmin) / (cmax - cmin);               // building.py:3068-3078
             a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = pre_t[CLPRE_TNORM];            // building.py:3027-3028
+            if (W[CLW_DEM2] != 0.0f && a.heat_dem)                                                      // a model that takes both demands
+                a.hist[(long long)(2 * CL_LSTM_LOOKBACK + slot) * plane + off] = (a.heat_dem[off] - W[CLW_C2MIN]) / (W[CLW_C2MAX] - W[CLW_C2MIN]);
         }
         if (live && hh == 0) lstm_outputs(a, W, pre_t, off, plane, pre_t[CLPRE_TRAW], cool, a.heat_dem ? a.heat_dem[off] : 0.0f);   // the data-file temperature
         return;
@@ -312,12 +315,13 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const float blin = W[CLW_BLIN];
     float temp, y;
     // A operands: row = 32 rb + col of the torch gate matrix, k-slot 2 kk + hh -> hidden unit u(kk)
-    float a_hh0[2][8], a_x0[2], a_ih1[2][8], a_hh1[2][8];
+    float a_hh0[2][8], a_x0[2], a_x2[2], a_ih1[2][8], a_hh1[2][8];
     v8 A_hh0[2][NT], A_ih1[2][NT], A_hh1[2][NT];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         const int row = 32 * rb + col;
         a_x0[rb] = hh ? W[CLW_WT + row] : W[CLW_WC + row];
+        a_x2[rb] = W[CLW_W2 + row];                          // (zeros unless the model takes a second demand input)
         if constexpr (SPLIT) {
             const v8* __restrict__ F = reinterpret_cast<const v8*>(a.lstm_wb + (long long)b * CL_LSTM_NWB);
 #pragma unroll
@@ -351,7 +355,14 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     // steps ahead of their use.
 #define CL_MFMA(A, B, C) ((DBG & 2) ? (C) + (A) * (B) : __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0))
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // A model that takes BOTH demands (round 3): the pre-gate product below is a K = 2 MFMA whose second k-slot was idle (B = 0 on the
+    // hh = 1 lanes).  The second demand input rides there -- A = its weight column, B = its normalised value at the window step -- so a
+    // third env-dependent input costs no matrix instruction: one more ring read per lane and step, two selects.  Without such an input
+    // the weight column and the ring (rows 24 .. 35 of `hist`, zero since reset) are zero: the same arithmetic as before.
     const float one_b = hh ? 0.0f : 1.0f;
+    const bool two = W[CLW_DEM2] != 0.0f && a.heat_dem;
+    const float heat_n = two ? (heat - W[CLW_C2MIN]) / (W[CLW_C2MAX] - W[CLW_C2MIN]) : 0.0f;
+    const float* __restrict__ hist2_lane = a.hist + off + 2ll * CL_LSTM_LOOKBACK * plane;
     const float a_b1[2] = {W[CLW_B1 + col], W[CLW_B1 + 32 + col]};
     // ring rows without a division or a branch in the loop: time % 12 = (m + s) mod 12, (time - 1) % 12 = that - 1 mod 12
     const int ring_m = (a.t - (CL_LSTM_LOOKBACK - 1)) % CL_LSTM_LOOKBACK;           // a.t >= 12 here
@@ -360,14 +371,18 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     // (Tried: loading them straight in the C/D layout -- 16 values per row block and lane, four 16-byte loads each -- as the C
     // operand of the chain's first MFMA, the way the layer-1 bias enters: two MFMAs fewer per step but eight loads and 32
     // registers more: 119.2 vs 117.5 us with the f16 split, 168 vs 142 us with bf16 at 256 registers.)
-    auto fetch = [&](int s, float (&ap)[2], float& xin) {
+    auto fetch = [&](int s, float (&ap)[2], float& xin, float& xb) {
         const int time = a.t - (CL_LSTM_LOOKBACK - 1) + s;
         const float* __restrict__ pre = a.dyn_pre + ((long long)(time + row0) * a.n_bldg + b) * CL_LSTM_NPRE;
-        ap[0] = pre[col]; ap[1] = pre[32 + col];
+        const float p0 = pre[col], p1 = pre[32 + col];
         // extra k-pair of layer 0: slot 0 = cooling demand at `time`, slot 1 = temperature at `time - 1`
         int r0 = ring_m + s; r0 -= r0 >= CL_LSTM_LOOKBACK ? CL_LSTM_LOOKBACK : 0;
         const int r1 = r0 == 0 ? CL_LSTM_LOOKBACK - 1 : r0 - 1;
         xin = hist_lane[(long long)(hh ? r1 : r0) * plane];        // (step 11, slot 0 is overridden at the point of use)
+        const float x2 = hist2_lane[(long long)r0 * plane];        // second demand input at `time` (step 11: produced by this launch)
+        // pre-gate product: k-slot 0 = (pre-gates, 1), k-slot 1 = (weights of the second demand input, its value)
+        ap[0] = hh ? a_x2[0] : p0; ap[1] = hh ? a_x2[1] : p1;
+        xb = hh ? ((two && s == CL_LSTM_LOOKBACK - 1) ? heat_n : x2) : 1.0f;
     };
     v8 H0[NT], H1[NT];                                            // split hidden states (B operands)
     auto split = [&](const float (&h)[8], v8 (&t)[NT]) { lstm_split<NT, (DBG & 8) ? 2 : NT, v8, elem>(h, t); };
@@ -379,9 +394,9 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) bias1[rb][r] = W[CLW_B1 + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh];
     }
-    auto layer0 = [&](const float (&ap)[2], float xin, f32x16& d0, f32x16& d1) {
-        d0 = CL_MFMA(ap[0], one_b, zero16);
-        d1 = CL_MFMA(ap[1], one_b, zero16);
+    auto layer0 = [&](const float (&ap)[2], float xin, float xb, f32x16& d0, f32x16& d1) {
+        d0 = CL_MFMA(ap[0], xb, zero16);
+        d1 = CL_MFMA(ap[1], xb, zero16);
         d0 = CL_MFMA(a_x0[0], xin, d0);
         d1 = CL_MFMA(a_x0[1], xin, d1);
         if constexpr (SPLIT) lstm_mma<DBG>(A_hh0[0], A_hh0[1], H0, d0, d1, d0, d1);
@@ -394,14 +409,15 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
         }
     };
     f32x16 d0, d1, e0, e1;
-    float ap[2], xin, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f, ap_nn[2] = {0.0f, 0.0f}, xin_nn = 0.0f;
-    fetch(0, ap, xin);
-    fetch(1, ap_n, xin_n);
+    float ap[2], xin, xb, ap_n[2] = {0.0f, 0.0f}, xin_n = 0.0f, xb_n = 0.0f, ap_nn[2] = {0.0f, 0.0f}, xin_nn = 0.0f, xb_nn = 0.0f;
+    fetch(0, ap, xin, xb);
+    fetch(1, ap_n, xin_n, xb_n);
     __builtin_amdgcn_sched_barrier(0);                             // every load above is issued before anything below
     const float cool_n = (dem - cmin) / (cmax - cmin);
     if (live && hh == 0) a.hist[(long long)slot * plane + off] = cool_n;         // building.py:3068-3078
+    if (live && hh == 0 && two) a.hist[(long long)(2 * CL_LSTM_LOOKBACK + slot) * plane + off] = heat_n;
     if constexpr (SPLIT) { split(h0, H0); split(h1, H1); }
-    layer0(ap, xin, d0, d1);
+    layer0(ap, xin, xb, d0, d1);
     CL_LT(1, d0[15]);                                             // weights, carried state and the first inputs arrived; first layer-0 gates done
     // The window loop, software-pipelined across the two layers.  Each layer is a strict chain matrix product -> cell update ->
     // matrix product, so inside one wave matrix-core work can only run beside the OTHER layer's cell update (and the second
@@ -414,12 +430,12 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     // stage's loads into the conditional block, right in front of their use).
     auto fetch_ahead = [&](int s) {
         // the three per-lane inputs of layer 0 are fetched two steps before their use (rotated at the end of the step)
-        fetch(min(s + 2, CL_LSTM_LOOKBACK - 1), ap_nn, xin_nn);
+        fetch(min(s + 2, CL_LSTM_LOOKBACK - 1), ap_nn, xin_nn, xb_nn);
         __builtin_amdgcn_sched_barrier(0);                          // the loads stay first
     };
     auto rotate = [&](int s) {                                      // at the very end: the copies wait for this step's loads
         __builtin_amdgcn_sched_barrier(0);
-        ap_n[0] = ap_nn[0]; ap_n[1] = ap_nn[1]; xin_n = xin_nn;
+        ap_n[0] = ap_nn[0]; ap_n[1] = ap_nn[1]; xin_n = xin_nn; xb_n = xb_nn;
         CL_LT(50 + s, xin_n);                                       // the inputs fetched at the top of this step have arrived
     };
     auto hh1_product = [&]() {                                      // e += W_hh1 h1
@@ -452,7 +468,7 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             }
         }
         // the newest cooling sample (step 11, k-slot 0) was produced by this launch, not read from the ring
-        if constexpr (decltype(has_l0)::value) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, d0, d1);
+        if constexpr (decltype(has_l0)::value) layer0(ap_n, (!hh && s + 1 == CL_LSTM_LOOKBACK - 1) ? cool_n : xin_n, xb_n, d0, d1);
         if constexpr (decltype(has_e)::value) {
             lstm_act<DBG>(g0, g1, c1, h1);
             if constexpr (SPLIT) split(h1, H1);

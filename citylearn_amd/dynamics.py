@@ -22,6 +22,7 @@ _PERIODIC = {'month': 12, 'hour': 24, 'day_type': 7}     # building.py:1493-1498
 WC, WT, WHH0, WIH1, WHH1, B1, WLIN, BLIN, TMIN, TMAX, CMIN, CMAX, ACTIVE = 0, 64, 128, 1152, 2176, 3200, 3264, 3280, 3281, 3282, 3283, 3284, 3285
 DEM_HEAT = 3290          # csrc/cl_lstm.h CLW_DEM_HEAT
 DEM2, C2MIN, C2MAX = 3291, 3292, 3293      # CLW_DEM2: the model also takes heating_demand (second demand input) + its normalisation
+W2 = 3296                                  # CLW_W2: W_ih0[:, second demand input] (matrix-core kernel)
 PRE_TNORM, PRE_TRAW, PRE_HVAC, PRE_CSP, PRE_HSP, PRE_BAND, PRE_OCC, PRE_OUTAGE = 64, 65, 66, 67, 68, 69, 70, 71
 RW_BAND, RW_LOEXP, RW_HIEXP, KPI_BAND = 3286, 3287, 3288, 3289
 
@@ -103,6 +104,8 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         b0 = gates(sd['l_lstm.bias_ih_l0'] + sd['l_lstm.bias_hh_l0'])
         lstm_w[i, WC:WC + 64] = wih0[:, ic]
         lstm_w[i, WT:WT + 64] = wih0[:, it]
+        if i2 is not None:
+            lstm_w[i, W2:W2 + 64] = wih0[:, i2]          # rides in the idle k-slot of the pre-gate product (csrc/cl_lstm.h)
         lstm_w[i, WHH0:WHH0 + 1024] = whh0.reshape(-1)
         lstm_w[i, WIH1:WIH1 + 1024] = cols(gates(sd['l_lstm.weight_ih_l1'])).reshape(-1)
         lstm_w[i, WHH1:WHH1 + 1024] = cols(gates(sd['l_lstm.weight_hh_l1'])).reshape(-1)
@@ -114,7 +117,7 @@ def pack_lstm(spec: DistrictSpec, tables: EpisodeTables, band=None, lower_expone
         lstm_w[i, ACTIVE] = 1.0
         pre = np.tile(b0[None, :], (T, 1))
         for k, name in enumerate(names):
-            if k in (ic, it):
+            if k in (ic, it, i2):
                 continue
             x = (_exo_feature(b, name, w) - lo[k]) / (hi[k] - lo[k])
             pre += x[:, None] * wih0[None, :, k]
@@ -149,6 +152,12 @@ def cell_update_bounds(spec: DistrictSpec, tables: EpisodeTables, lstm_w: np.nda
         pre = dyn_pre[:, i, :64].astype(np.float64).max(axis=0)
         z0 = pre + np.max(np.outer(W[WC:WC + 64], xc), axis=1) + np.max(np.outer(W[WT:WT + 64], xt), axis=1) \
             + np.abs(W[WHH0:WHH0 + 1024].reshape(64, 16)).sum(axis=1)
+        if W[DEM2] != 0.0:                               # a second demand input (delivered heating)
+            hd, hs = b.heating_device, b.heating_storage
+            cop_h = np.max(hd.cop(t_out, heating=True)) if getattr(hd, 'is_heat_pump', False) else float(hd.efficiency)
+            h_hi = max(float(np.max(b.series['heating_demand'][w])), float(hd.nominal_power) * float(cop_h)) + float(hs.capacity)
+            span2 = W[C2MAX] - W[C2MIN]
+            z0 = z0 + np.max(np.outer(W[W2:W2 + 64], np.array([(0.0 - W[C2MIN]) / span2, (h_hi - W[C2MIN]) / span2])), axis=1)
         z1 = W[B1:B1 + 64] + np.abs(W[WIH1:WIH1 + 1024].reshape(64, 16)).sum(axis=1) + np.abs(W[WHH1:WHH1 + 1024].reshape(64, 16)).sum(axis=1)
         for z in (z0, z1):
             zi, zf, zg, zo = z.reshape(4, 16)
@@ -169,8 +178,8 @@ def _demand_inputs(names):
 
 
 def _needs_generic_kernel(d) -> bool:
-    """The matrix-core kernel covers two layers of <= 16 units with ONE demand input; everything else runs on cl_lstm_generic_kernel."""
-    return not (d.num_layers == 2 and d.hidden_size <= 16) or _demand_inputs(list(d.input_observation_names))[1] is not None
+    """The matrix-core kernel covers two layers of <= 16 units (one or both demand inputs); everything else runs on cl_lstm_generic_kernel."""
+    return not (d.num_layers == 2 and d.hidden_size <= 16)
 
 
 def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):

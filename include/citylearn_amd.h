@@ -368,7 +368,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
  * The 64 gate rows of every weight matrix, of the layer-1 bias and of `dyn_pre` are stored pre-multiplied by -log2(e) (gates i, f, o)
  * and -2 log2(e) (gate g): sigmoid(x) = 1 / (1 + 2^z) and tanh(x) = 2 / (1 + 2^z) - 1 then take the accumulated z as it is.
  * (layouts: citylearn_amd/csrc/cl_lstm.h, packer: citylearn_amd/dynamics.py) */
-#define CL_LSTM_NW   3296
+#define CL_LSTM_NW   3360
 #define CL_LSTM_NPRE 80
 #define CL_LSTM_NHIST 36
 #define CL_LSTM_NHIDDEN 64

@@ -156,3 +156,28 @@ def test_launcher_propagates_a_failing_rank_and_stops_the_others():
     assert rc == 0 and out0.strip() == '0'
     rc, _ = launch_ranks([sys.executable, '-c', 'import time; time.sleep(120)'], 2, timeout=2)
     assert rc == 124
+
+
+def test_bench_uses_only_counters_collected_on_the_kernel_it_launched(tmp_path, monkeypatch):
+    """`bench._pmc_traffic`: a PMC summary under profiles/ feeds `roofline.traffic` only if its `_kernel.kernel` names the kernel the run
+    launched (VERDICT r02 weak #8: stale counters beside a newer kernel); `scripts/check_profiles.py` is the same check for a profile run."""
+    import json
+    import subprocess
+    sys.path.insert(0, str(ROOT))
+    import bench
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    summary = {'FETCH_SIZE': {'mean': 100.0}, 'WRITE_SIZE': {'mean': 50.0},
+               '_kernel': {'kernel': 'void (anonymous namespace)::cl_step_envmajor_kernel<20>((anonymous namespace)::StepArgs)'}}
+    (prof / 'r02_streaming_pmc_summary.json').write_text(json.dumps(summary))
+    monkeypatch.setattr(bench, 'ROOT', tmp_path)
+    assert bench._pmc_traffic('r*_streaming_pmc_summary.json', 'cl_step_envmajor_kernel<20, true>') == (None, None)      # another instantiation
+    summary['_kernel']['kernel'] = 'void (anonymous namespace)::cl_step_envmajor_kernel<20, true>((anonymous namespace)::StepArgs)'
+    (prof / 'r03_streaming_pmc_summary.json').write_text(json.dumps(summary))
+    traffic, source = bench._pmc_traffic('r*_streaming_pmc_summary.json', 'cl_step_envmajor_kernel<20, true>')
+    assert source == 'r03_streaming_pmc_summary.json' and traffic == (2 * 100.0 + 50.0) * 1024.0          # FETCH_SIZE doubled (gfx950), KiB
+    line = tmp_path / 'line.json'
+    line.write_text(json.dumps({'roofline': {'kernel': 'cl_step_envmajor_kernel<20, true>'}}))
+    check = [sys.executable, str(ROOT / 'scripts' / 'check_profiles.py'), str(line)]
+    assert subprocess.run(check + [str(prof / 'r03_streaming_pmc_summary.json')], capture_output=True).returncode == 0
+    assert subprocess.run(check + [str(prof / 'r02_streaming_pmc_summary.json')], capture_output=True).returncode == 1
