@@ -1809,9 +1809,12 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
     a.lstm_wb = lstm_wb;
     if (int rc = check_ptr(lstm_wb, "lstm_wb", false)) return rc;
     const bool f16 = dims->flags & CLD_LSTM_F16;
+    const bool two = dims->flags & CLD_LSTM_TWO_DEMANDS;
+    if (two && !heat_dem) return fail(CL_EINVAL, "CLD_LSTM_TWO_DEMANDS needs heat_dem");
     name_reset(tun);
-#define CL_LSTM_LAUNCH(DBG, SPLIT) do { name_add(tun, "cl_lstm_kernel<" #DBG ", " #SPLIT ">"); \
-    hipLaunchKernelGGL((cl_lstm_kernel<DBG, SPLIT>), grid, dim3(256), 0, (hipStream_t)stream, a); } while (0)
+#define CL_LSTM_LAUNCH(DBG, SPLIT) do { if (two) { name_add(tun, "cl_lstm_kernel<" #DBG ", " #SPLIT ", true>"); \
+    hipLaunchKernelGGL((cl_lstm_kernel<DBG, SPLIT, true>), grid, dim3(256), 0, (hipStream_t)stream, a); } else { name_add(tun, "cl_lstm_kernel<" #DBG ", " #SPLIT ", false>"); \
+    hipLaunchKernelGGL((cl_lstm_kernel<DBG, SPLIT, false>), grid, dim3(256), 0, (hipStream_t)stream, a); } } while (0)
 #define CL_LSTM_LAUNCH_WB(DBG) do { if (f16) CL_LSTM_LAUNCH(DBG, 2); else CL_LSTM_LAUNCH(DBG, 1); } while (0)
     switch (tun.lstm_variant) {            // timing experiments (scripts/lstm_check.py); 0 in production
     case 1: CL_LSTM_LAUNCH(1, 0); break;

@@ -263,7 +263,7 @@ CL_DEV void lstm_mma(const V8 (&A0)[T], const V8 (&A1)[T], const V8 (&B)[T], con
 #define CL_LT(k, v)
 #endif
 
-template <int DBG, int SPLIT>
+template <int DBG, int SPLIT, bool TWO>
 __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     typedef typename LstmSplit<SPLIT>::v8 v8;
     typedef typename LstmSplit<SPLIT>::elem elem;
@@ -287,6 +287,7 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const float act = W[CLW_ACTIVE];
     if (act >= 2.0f) return;                                     // another LSTM shape: cl_lstm_generic_kernel owns this building
     const float tmin = W[CLW_TMIN], tmax = W[CLW_TMAX], cmin = W[CLW_CMIN], cmax = W[CLW_CMAX];
+    const float dem2 = W[CLW_DEM2];                              // (read here, with the other parameters: at its last use the load would be an exposed latency per wave)
     // the demand the model was trained on: delivered cooling, or delivered heating for a heating-driven model
     const float* __restrict__ dem_src = (W[CLW_DEM_HEAT] != 0.0f && a.heat_dem) ? a.heat_dem : a.cool_dem;
     const int slot = a.t % CL_LSTM_LOOKBACK;
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
         if (act != 0.0f && live && hh == 0) {
             a.hist[(long long)slot * plane + off] = (dem_src[off] - cmin) / (cmax - cmin);               // building.py:3068-3078
             a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = pre_t[CLPRE_TNORM];            // building.py:3027-3028
-            if (W[CLW_DEM2] != 0.0f && a.heat_dem)                                                      // a model that takes both demands
+            if (dem2 != 0.0f && a.heat_dem)                                                             // a model that takes both demands
                 a.hist[(long long)(2 * CL_LSTM_LOOKBACK + slot) * plane + off] = (a.heat_dem[off] - W[CLW_C2MIN]) / (W[CLW_C2MAX] - W[CLW_C2MIN]);
         }
         if (live && hh == 0) lstm_outputs(a, W, pre_t, off, plane, pre_t[CLPRE_TRAW], cool, a.heat_dem ? a.heat_dem[off] : 0.0f);   // the data-file temperature
@@ -357,10 +358,11 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // A model that takes BOTH demands (round 3): the pre-gate product below is a K = 2 MFMA whose second k-slot was idle (B = 0 on the
     // hh = 1 lanes).  The second demand input rides there -- A = its weight column, B = its normalised value at the window step -- so a
-    // third env-dependent input costs no matrix instruction: one more ring read per lane and step, two selects.  Without such an input
-    // the weight column and the ring (rows 24 .. 35 of `hist`, zero since reset) are zero: the same arithmetic as before.
+    // third env-dependent input costs no matrix instruction: one more ring read per lane and step, two selects -- which still cost 8 us
+    // of 96 at 3 x 65 536 (the loads sit in the software pipeline's fetch slots), so the path is an instantiation of its own (TWO),
+    // launched for districts whose caller sets CLD_LSTM_TWO_DEMANDS; in the other instantiation a building with such a model gets NaN.
     const float one_b = hh ? 0.0f : 1.0f;
-    const bool two = W[CLW_DEM2] != 0.0f && a.heat_dem;
+    const bool two = TWO && dem2 != 0.0f && a.heat_dem;
     const float heat_n = two ? (heat - W[CLW_C2MIN]) / (W[CLW_C2MAX] - W[CLW_C2MIN]) : 0.0f;
     const float* __restrict__ hist2_lane = a.hist + off + 2ll * CL_LSTM_LOOKBACK * plane;
     const float a_b1[2] = {W[CLW_B1 + col], W[CLW_B1 + 32 + col]};
@@ -379,10 +381,12 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
         int r0 = ring_m + s; r0 -= r0 >= CL_LSTM_LOOKBACK ? CL_LSTM_LOOKBACK : 0;
         const int r1 = r0 == 0 ? CL_LSTM_LOOKBACK - 1 : r0 - 1;
         xin = hist_lane[(long long)(hh ? r1 : r0) * plane];        // (step 11, slot 0 is overridden at the point of use)
-        const float x2 = hist2_lane[(long long)r0 * plane];        // second demand input at `time` (step 11: produced by this launch)
-        // pre-gate product: k-slot 0 = (pre-gates, 1), k-slot 1 = (weights of the second demand input, its value)
-        ap[0] = hh ? a_x2[0] : p0; ap[1] = hh ? a_x2[1] : p1;
-        xb = hh ? ((two && s == CL_LSTM_LOOKBACK - 1) ? heat_n : x2) : 1.0f;
+        if constexpr (TWO) {
+            const float x2 = hist2_lane[(long long)r0 * plane];    // second demand input at `time` (step 11: produced by this launch)
+            // pre-gate product: k-slot 0 = (pre-gates, 1), k-slot 1 = (weights of the second demand input, its value)
+            ap[0] = hh ? a_x2[0] : p0; ap[1] = hh ? a_x2[1] : p1;
+            xb = hh ? ((two && s == CL_LSTM_LOOKBACK - 1) ? heat_n : x2) : 1.0f;
+        } else { ap[0] = p0; ap[1] = p1; xb = one_b; }
     };
     v8 H0[NT], H1[NT];                                            // split hidden states (B operands)
     auto split = [&](const float (&h)[8], v8 (&t)[NT]) { lstm_split<NT, (DBG & 8) ? 2 : NT, v8, elem>(h, t); };
@@ -395,8 +399,8 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
             for (int r = 0; r < 16; ++r) bias1[rb][r] = W[CLW_B1 + 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * hh];
     }
     auto layer0 = [&](const float (&ap)[2], float xin, float xb, f32x16& d0, f32x16& d1) {
-        d0 = CL_MFMA(ap[0], xb, zero16);
-        d1 = CL_MFMA(ap[1], xb, zero16);
+        d0 = CL_MFMA(ap[0], TWO ? xb : one_b, zero16);
+        d1 = CL_MFMA(ap[1], TWO ? xb : one_b, zero16);
         d0 = CL_MFMA(a_x0[0], xin, d0);
         d1 = CL_MFMA(a_x0[1], xin, d1);
         if constexpr (SPLIT) lstm_mma<DBG>(A_hh0[0], A_hh0[1], H0, d0, d1, d0, d1);
@@ -499,6 +503,7 @@ __global__ void __launch_bounds__(256) cl_lstm_kernel(const LstmArgs a) {
     const float other = __shfl_xor(part, 32);
     y = blin + (hh ? other + part : part + other);
     temp = fmaf(y, tmax - tmin, tmin);                           // building.py:3031-3037
+    if constexpr (!TWO) { if (dem2 != 0.0f) temp = __builtin_nanf(""); }     // a both-demand model in a launch without CLD_LSTM_TWO_DEMANDS: loud, not wrong
     if (live && hh == 0) a.hist[(long long)(CL_LSTM_LOOKBACK + slot) * plane + off] = y;   // building.py:3027-3028
     if (live && hh == 0) lstm_outputs(a, W, pre_t, off, plane, temp, cool, heat);
 #ifdef CL_TRACE

@@ -177,9 +177,12 @@ def _demand_inputs(names):
     return names.index(have[0]), (names.index(have[1]) if len(have) == 2 else None)
 
 
+FORCE_GENERIC_KERNEL = False          # tests: route every model to cl_lstm_generic_kernel (cross-checks the two kernels on the same fixtures)
+
+
 def _needs_generic_kernel(d) -> bool:
     """The matrix-core kernel covers two layers of <= 16 units (one or both demand inputs); everything else runs on cl_lstm_generic_kernel."""
-    return not (d.num_layers == 2 and d.hidden_size <= 16)
+    return FORCE_GENERIC_KERNEL or not (d.num_layers == 2 and d.hidden_size <= 16)
 
 
 def pack_lstm_generic(spec: DistrictSpec, tables: EpisodeTables):
@@ -312,6 +315,8 @@ class LSTMStage:
         self.dims = _lib.Dims.from_buffer_copy(engine.dims)          # the engine's dims (never mutated) + the operand-format flag
         if split == 'f16':
             self.dims.flags |= abi.CLD_LSTM_F16
+        if bool(((lstm_w[:, ACTIVE] == 1.0) & (lstm_w[:, DEM2] != 0.0)).any()):
+            self.dims.flags |= abi.CLD_LSTM_TWO_DEMANDS          # a 2 x 16-unit model that takes both demands: the instantiation with the third input ring
         # the stage's own copy of the launch overrides: the cell-update form is chosen here
         self.tuning = _lib.Tuning.from_buffer_copy(engine.tuning)
         self.dims.tuning = ctypes.pointer(self.tuning)

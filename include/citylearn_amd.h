@@ -266,6 +266,9 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 #define CLD_DETAIL_MIN     (1u << 12) /* with CLD_WRITE_DETAIL: write only the detail planes another kernel of the path reads -- CLO_BASE_NET,
                                          CLO_EXPECTED, CLO_SERVED (the streaming KPI pass) and CLO_COOL_DEM, CLO_HEAT_DEM (the LSTM stage) -- and
                                          leave the other ten alone (5 instead of 15 extra planes per step) */
+#define CLD_LSTM_TWO_DEMANDS (1u << 13) /* cl_lstm_step_f32 only: caller asserts that a building of the district has a temperature model taking BOTH
+                                          demands (lstm_w[CLW_DEM2] != 0; needs `heat_dem`): selects the instantiation that reads the third input
+                                          ring (rows 24-35 of `hist`).  Without it such a building's indoor_temp is NaN */
 #define CLD_REWARD_SHIFT   8          /* reward kind in bits 8..11 */
 #define CLD_REWARD_MASK    (0xFu << CLD_REWARD_SHIFT)
 enum cl_reward_kind {
@@ -363,7 +366,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
  * lstm_w  [n_bldg][CL_LSTM_NW]            packed LSTM(13->16, 2 layers) + Linear(16->1) weights per building
  * dyn_pre [n_steps][n_bldg][CL_LSTM_NPRE]  host-precomputed env-independent part of the layer-0 gates per (t, building)
  * hist    [CL_LSTM_NHIST][n_bldg][n_env]   rings of the last 12 normalised demand inputs (rows 0-11), indoor temperatures (12-23) and, for a
- *                                          model that takes both demands (generic kernel), second demand inputs (24-35)
+ *                                          model that takes both demands, second demand inputs (24-35)
  * hidden  [n_bldg][n_env][64]              h0[16], c0[16], h1[16], c1[16] carried across env steps
  * The 64 gate rows of every weight matrix, of the layer-1 bias and of `dyn_pre` are stored pre-multiplied by -log2(e) (gates i, f, o)
  * and -2 log2(e) (gate g): sigmoid(x) = 1 / (1 + 2^z) and tanh(x) = 2 / (1 + 2^z) - 1 then take the accumulated z as it is.
@@ -408,9 +411,10 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
 
 /* LSTM shapes the matrix-core kernel does not cover (hidden size up to CL_LSTM_GEN_HMAX, one or two layers; e.g. baeda_3dem's
  * Building_4 = LSTM(11 -> 50, 1 layer)): buildings whose lstm_w[CLW_ACTIVE] is 2 (one layer) or 3 (two layers) are skipped by
- * cl_lstm_step_f32 and advanced by this call (same inputs / outputs, plain fp32 FMAs; call it right after cl_lstm_step_f32).  So are
- * models of any shape whose inputs hold BOTH cooling_demand and heating_demand (the reference builds the input generically from
- * `input_observation_names`, building.py:3039-3078): lstm_w[CLW_DEM2] != 0, delivered heating as a third env-dependent input.
+ * cl_lstm_step_f32 and advanced by this call (same inputs / outputs, plain fp32 FMAs; call it right after cl_lstm_step_f32).  A model
+ * whose inputs hold BOTH cooling_demand and heating_demand (the reference builds the input generically from `input_observation_names`,
+ * building.py:3039-3078; lstm_w[CLW_DEM2] != 0, delivered heating as a third env-dependent input) runs on either kernel: on the
+ * matrix-core kernel when it is 2 x <= 16 units (CLD_LSTM_TWO_DEMANDS), here otherwise.
  *   gen_w      [n_bldg][gen_w_stride]   WX [H][12] (demand, temperature, second demand input), WHH0 [H][H][4], WIH1 [H][H][4], WHH1 [H][H][4], B1 [H][4], WLIN [H]  (gate order i, f, g, o;
  *                                        H = gen_h, the padded hidden size; csrc/cl_lstm.h, packer dynamics.pack_lstm_generic)
  *   gen_pre    [n_ts_rows][n_bldg][gen_h][4]  env-independent part of the layer-0 gates

@@ -205,3 +205,31 @@ def test_lstm_stage_at_full_batch_size_by_replication():
         tiled = big.reshape(3, reps, 128)
         assert torch.equal(tiled, small.unsqueeze(1).expand_as(tiled))
     assert torch.isfinite(stages[1].indoor_temp).all() and float(stages[1].indoor_temp.std()) > 0
+
+
+@pytest.mark.parametrize('name', ['g2023_p2', 'g2023_both', 'g2023_heat'])
+def test_generic_kernel_agrees_with_the_matrix_core_kernel(name, monkeypatch):
+    """Every 2 x 16-unit model forced onto `cl_lstm_generic_kernel` (`dynamics.FORCE_GENERIC_KERNEL`): the fallback kernel -- hidden units
+    dealt to four waves, matrices staged in LDS, three env-dependent inputs -- against the reference, on the fixtures the matrix-core
+    kernel is pinned on (g2023_both: a model that takes both demands, on either kernel)."""
+    from citylearn_amd import dynamics
+    monkeypatch.setattr(dynamics, 'FORCE_GENERIC_KERNEL', True)
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    attrs = spec.reward_function.get('attributes') or {}
+    E = 68
+    eng = StepEngine(tab, E, detail=True)
+    stage = LSTMStage(spec, tab, eng, attrs.get('band'), attrs.get('lower_exponent') or 2.0, attrs.get('higher_exponent') or 2.0)
+    assert stage.generic is not None and stage.generic['layers'] == 2 and not (stage.lstm_w[:, dynamics.ACTIVE] == 1.0).any()
+    cool = torch.from_numpy(g.ref['cool_dem']).cuda()
+    heat = torch.from_numpy(g.ref['heat_dem']).cuda() if 'heat_dem' in g.ref.files else None
+    worst_t = worst_r = 0.0
+    for t in range(min(150, g.facts['steps'])):
+        temp = stage.step(t, cool[t][:, None].expand(-1, E).contiguous(), None if heat is None else heat[t][:, None].expand(-1, E).contiguous())
+        tt, rr = temp.cpu().numpy(), stage.comfort.cpu().numpy()
+        assert (tt[:, :1] == tt).all()
+        worst_t = max(worst_t, float(np.max(np.abs(tt[:, 0] - g.ref['indoor_temp'][t]))))
+        ref = g.ref['reward_ComfortReward'][t]
+        worst_r = max(worst_r, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
+    assert worst_t < 2e-3 and worst_r < 1.0, (worst_t, worst_r)

@@ -91,7 +91,10 @@ def test_lstm_window_loop(units):
     loads at the top and waits for them only at its end -- the compiler once sank the history load right in front of its use (one
     exposed memory latency per window step: 176 vs 150 us)."""
     (kernels, meta), _ = units
-    k = _one(kernels, r'cl_lstm_kernelILi0ELi2EE')
+    # the both-demand instantiation (CLD_LSTM_TWO_DEMANDS): one more load per window step, the same register budget
+    k2 = _one(kernels, r'cl_lstm_kernelILi0ELi2ELb1EE')
+    assert meta[k2]['num_vgpr'] <= 256 and meta[k2]['private_seg_size'] == 0
+    k = _one(kernels, r'cl_lstm_kernelILi0ELi2ELb0EE')
     assert meta[k]['num_vgpr'] <= 256 and meta[k]['private_seg_size'] == 0
     ins = kernels[k]
     # the loop: a backward conditional branch to a label, with the 18 f16 MFMAs of a window step in between

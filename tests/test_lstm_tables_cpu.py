@@ -34,7 +34,7 @@ def _cell(z, c):
     return c, o * np.tanh(c)
 
 
-@pytest.mark.parametrize('name,fmt,steps', [('g2023_p2', 'f16', 120), ('g2023_p2', 'bf16', 60), ('g2023_heat', 'f16', 120)])
+@pytest.mark.parametrize('name,fmt,steps', [('g2023_p2', 'f16', 120), ('g2023_p2', 'bf16', 60), ('g2023_heat', 'f16', 120), ('g2023_both', 'f16', 120)])
 def test_packed_tables_reproduce_the_reference_temperatures(name, fmt, steps):
     g = golden(name)
     spec = g.spec()
@@ -53,19 +53,23 @@ def test_packed_tables_reproduce_the_reference_temperatures(name, fmt, steps):
         # the fragments are the (scaled) fp32 matrices of lstm_w, split
         np.testing.assert_allclose(whh0, w[dyn.WHH0:dyn.WHH0 + 1024].reshape(64, 16), rtol=2.0 ** -21, atol=2.0 ** -24)
         wc, wt, b1 = w[dyn.WC:dyn.WC + 64], w[dyn.WT:dyn.WT + 64], w[dyn.B1:dyn.B1 + 64]
+        w2 = w[dyn.W2:dyn.W2 + 64]                       # second demand input (g2023_both's Building_1; zeros elsewhere)
+        assert bool(np.any(w2)) == (w[dyn.DEM2] != 0.0) == (name == 'g2023_both' and b == 0)
         wlin, blin = w[dyn.WLIN:dyn.WLIN + 16], w[dyn.BLIN]
         tmin, tmax, cmin, cmax = w[dyn.TMIN], w[dyn.TMAX], w[dyn.CMIN], w[dyn.CMAX]
         dem = heat[:, b] if w[dyn.DEM_HEAT] != 0.0 else cool[:, b]
-        ring_c, ring_t = np.zeros(12), np.zeros(12)
+        ring_c, ring_t, ring_2 = np.zeros(12), np.zeros(12), np.zeros(12)
         h0 = np.zeros(16); c0 = np.zeros(16); h1 = np.zeros(16); c1 = np.zeros(16)
         for t in range(steps):
             ring_c[t % 12] = (dem[t] - cmin) / (cmax - cmin)                    # building.py:3068-3078
+            if w[dyn.DEM2] != 0.0:
+                ring_2[t % 12] = (heat[t, b] - w[dyn.C2MIN]) / (w[dyn.C2MAX] - w[dyn.C2MIN])
             y = dyn_pre[t, b, dyn.PRE_TNORM]
             temp = dyn_pre[t, b, dyn.PRE_TRAW]
             if t >= 12:                                                          # lookback + 1 samples exist (building.py:2996-2999)
                 for s in range(12):
                     time = t - 11 + s
-                    z0 = dyn_pre[time, b, :64].astype(np.float64) + wc * ring_c[time % 12] + wt * ring_t[(time - 1) % 12] + whh0 @ h0
+                    z0 = dyn_pre[time, b, :64].astype(np.float64) + wc * ring_c[time % 12] + wt * ring_t[(time - 1) % 12] + w2 * ring_2[time % 12] + whh0 @ h0
                     c0, h0 = _cell(z0, c0)
                     z1 = b1 + wih1 @ h0 + whh1 @ h1
                     c1, h1 = _cell(z1, c1)
@@ -89,11 +93,12 @@ def test_cell_update_bounds_admit_the_2023_models_and_refuse_baeda():
         assert (zs < 126.0) == ok, (name, zs, zo)
 
 
-@pytest.mark.parametrize('name,b', [('g2023_both', 0), ('s_baeda', 3)])
-def test_generic_kernel_tables_reproduce_the_reference_temperatures(name, b):
+@pytest.mark.parametrize('name,b', [('g2023_both', 0), ('s_baeda', 3), ('g2023_p2', 1)])
+def test_generic_kernel_tables_reproduce_the_reference_temperatures(name, b, monkeypatch):
     """`dynamics.pack_lstm_generic` (cl_lstm_generic_kernel's tables: WX [H][12] = gates of the demand, the temperature and the second demand
     input, square matrices as [unit][input][gate], host pre-gates) through a numpy restatement of that kernel's window loop: g2023_both's
     Building_1 takes BOTH demands (delivered heating as a third env-dependent input with its own ring), baeda's Building_4 is LSTM(11 -> 50, one layer)."""
+    monkeypatch.setattr(dyn, 'FORCE_GENERIC_KERNEL', True)        # (2 x 16-unit models normally run on the matrix-core kernel)
     g = golden(name)
     spec = g.spec()
     tab = spec.episode_tables(0)
