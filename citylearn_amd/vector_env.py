@@ -344,6 +344,16 @@ class VectorCityLearnEnv:
         engine's own buffers (or graph-owned ones): valid until the next step."""
         return CapturedSteps(self, actions)
 
+    def capture_rollout(self, policy, k_steps: int, keep_rewards: bool = True) -> 'CapturedRollout':
+        """``k_steps`` x (policy, `step`) as ONE hipGraph replay -- the closed-loop counterpart of :meth:`rollout` for a policy written in
+        torch.  ``policy(obs, i)`` is called while the graph is being captured, once per step ``i`` of the chunk, with the observation
+        `step` would hand out, and returns that step's actions (float32 ``[n_act_cols, n_envs]`` or transposed, on the env's device);
+        whatever device work it enqueues on the current stream (an MLP, sampling with torch's graph-safe generator, writes into its own
+        trajectory buffers) becomes part of the graph, between the env's kernels.  A Python RL loop then pays one graph launch per
+        ``k_steps`` env steps instead of one trip through Python, ctypes and the HIP launch path per step: what `bench.py` times, behind
+        the user-level API (scripts/env_step_bench.py).  See `CapturedRollout`."""
+        return CapturedRollout(self, policy, int(k_steps), keep_rewards)
+
     def rollout(self, k_steps: int, actions: Optional[torch.Tensor] = None, seed: int = 0) -> torch.Tensor:
         """Advance ``k_steps`` steps without returning to Python in between (`StepEngine.rollout`: one fused launch, or a launch
         sequence for districts with flexible loads) with open-loop ``actions`` ``[k_steps, n_act_cols, n_envs]`` or the uniform
@@ -461,3 +471,59 @@ class CapturedSteps:
         env._t = t + 1
         env.engine.t = t + 1
         return out[0], out[1], env.terminated, False, {}
+
+
+class CapturedRollout:
+    """`VectorCityLearnEnv.capture_rollout`: chunks of ``k_steps`` closed-loop env steps, one hipGraph per chunk start ``t0`` (the step
+    index and the table row are kernel arguments), captured the first time the env stands at ``t0`` -- the capture does not advance
+    the env, the replay right after it does -- and reused by every later episode over the same window.
+
+    `run()` returns ``(observation, rewards, terminated)``: the observation after the chunk's last step (the env's own buffers, valid
+    until the next step), and ``rewards`` ``[k_steps, ...]`` = what `step` returned at each step (a graph-owned buffer, overwritten by
+    the next `run()` from the same ``t0``; None with ``keep_rewards=False`` for policies that record what they need themselves)."""
+
+    def __init__(self, env: VectorCityLearnEnv, policy, k_steps: int, keep_rewards: bool = True):
+        if k_steps < 1:
+            raise ValueError('k_steps must be at least 1')
+        self.env, self.policy, self.k_steps, self.keep_rewards = env, policy, k_steps, keep_rewards
+        self._key = self._state_key()
+        self._graphs = {}
+        self._stream = torch.cuda.Stream(device=env.engine.device)
+
+    def _state_key(self):
+        e = self.env.engine
+        return (id(e), None if e.flex is None else int(e.flex.seed))
+
+    def run(self, observation=None):
+        """Advance the env by ``k_steps`` steps.  ``observation``: ignored after the first capture of a chunk (the graph reads the env's
+        own observation buffers); at capture time it defaults to the env's current observation."""
+        env, k = self.env, self.k_steps
+        if self._state_key() != self._key:              # another engine / EV drift seed: the recorded launches are stale
+            self._graphs.clear()
+            self._key = self._state_key()
+        if env.terminated:
+            raise RuntimeError('episode has terminated: call reset()')
+        t0 = env._t
+        if t0 + k > env.time_steps - 1:
+            raise RuntimeError(f'{k} steps from t={t0} run past the episode end ({env.time_steps - 1} steps): finish the episode with step()')
+        hit = self._graphs.get(t0)
+        if hit is None:
+            dev = env.engine.device
+            self._stream.wait_stream(torch.cuda.current_stream(dev))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=self._stream):
+                obs = env._obs() if observation is None else observation
+                rewards = None
+                for i in range(k):
+                    obs, reward, _, _, _ = env.step(self.policy(obs, i))
+                    if self.keep_rewards:
+                        if rewards is None:
+                            rewards = torch.empty((k,) + tuple(reward.shape), dtype=reward.dtype, device=dev)
+                        rewards[i].copy_(reward)
+            env._t = t0                                  # (recorded, not executed)
+            hit = self._graphs[t0] = (graph, obs, rewards)
+        graph, obs, rewards = hit
+        graph.replay()
+        env._t = t0 + k
+        env.engine.t = t0 + k
+        return obs, rewards, env.terminated

@@ -342,6 +342,60 @@ def test_captured_steps_replay_the_eager_steps(name, kw):
         assert len(cap._graphs) == K                              # the second episode captured nothing new (EV districts re-capture: their drift seed moves)
 
 
+@pytest.mark.parametrize('name,kw', [('g2022_all', {}), ('g2022_all', {'observations': 'tensor', 'normalize_observations': True}),
+                                     ('g2023_p2', {'observations': 'compact'}), ('g2022_evs', {})])
+def test_captured_rollout_replays_the_eager_closed_loop(name, kw):
+    """`VectorCityLearnEnv.capture_rollout(policy, k)`: k x (policy, step) per hipGraph replay.  The policy here reads the observation it
+    is handed (so the graph really is closed-loop: its actions depend on the state the previous step left) and a table of per-step noise;
+    the eager loop with the same policy gives the same rewards, observations and state bit for bit, over two episodes."""
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    g = golden(name)
+    E, k, chunks = 256, 8, 4
+    eager, fast = VectorCityLearnEnv(g.spec(), E, **kw), VectorCityLearnEnv(g.spec(), E, **kw)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    noise = torch.rand((k * chunks, eager.n_act_cols, E), device='cuda', generator=gen)
+    clock = {'eager': torch.zeros((), dtype=torch.long, device='cuda'), 'fast': torch.zeros((), dtype=torch.long, device='cuda')}
+
+    def make_policy(env, who):
+        lo, hi = env.action_low[:, None], env.action_high[:, None]
+
+        def policy(obs, i):
+            if isinstance(obs, dict):                                  # 'planes' / 'compact': some env-dependent plane
+                feat = obs['electrical_storage_soc'][:1] if 'electrical_storage_soc' in obs else obs['dependent'][:, :1].t()
+            else:
+                feat = obs[:, -1:].t()
+            u = noise.index_select(0, clock[who].reshape(1))[0]        # device-side step counter: the same graph serves every replay
+            clock[who] += 1
+            return lo + (hi - lo) * (0.5 * u + 0.5 * torch.sigmoid(feat))
+        return policy
+
+    pol_e, pol_f = make_policy(eager, 'eager'), make_policy(fast, 'fast')
+    roll = fast.capture_rollout(pol_f, k)
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return all(torch.equal(a[key], b[key]) for key in a)
+        return torch.equal(a, b)
+
+    for episode in range(2):
+        o1, _ = eager.reset(); fast.reset()
+        clock['eager'].zero_(); clock['fast'].zero_()
+        for c in range(chunks):
+            rs = []
+            for i in range(k):
+                o1, r1, _, _, _ = eager.step(pol_e(o1, i))
+                rs.append(r1.clone())
+            o2, r2, done = roll.run()
+            assert torch.equal(torch.stack(rs), r2) and same(o1, o2) and not done, (episode, c)
+            assert torch.equal(eager.engine.state, fast.engine.state)
+        assert fast.time_step == eager.time_step == k * chunks
+    if fast.engine.flex is None:
+        assert len(roll._graphs) == chunks
+    with pytest.raises(RuntimeError, match='past the episode end'):
+        fast._t = fast.time_steps - 3
+        roll.run()
+
+
 def test_planes_observation_of_a_second_episode_starts_clean():
     """`reset()` reuses the engine when the episode window is unchanged; the 'planes' observation hands out the engine's own
     output planes, which must not carry the last step of the previous episode."""
