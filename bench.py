@@ -56,7 +56,7 @@ ENVS_PER_GPU = 65536
 STREAMING_ENVS = 1048576        # second roofline entry of the headline: working set >> 256 MB Infinity Cache
 GRAPH_CHUNK = 100
 METRIC = 'building-timesteps/sec at 17 bldgs x 65536 envs; HBM GB/s vs roofline'
-CONFIGS = ('headline', 'C2', 'C3', 'C4', 'C4-lean', 'C5')
+CONFIGS = ('headline', 'C2', 'C3', 'C4', 'C4-lean', 'C5', 'T9')
 
 
 # --------------------------------------------------------------------------------------------------- CPU baseline
@@ -365,6 +365,12 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
                             f'citylearn_challenge_2023_phase_2_local_evaluation (3 buildings: power outages, partial-load cooling, DHW tank, battery; '
                             f'first 720 h) x {E} envs per GPU; one step = cl_step_f32 (energy step + the delivered-demand planes the stage reads) + cl_lstm_step_f32 (LSTM indoor '
                             'temperature + ComfortReward): the whole CityLearnEnv.step of this schema', lstm=True, f64=f64, kpi=kpi)
+    if cfg == 'T9':
+        spec = load_district(sample_schema('citylearn_challenge_2020_climate_zone_1_744h'))
+        return StepWorkload(cfg, spec, E, device, rank, tuning,
+                            f'citylearn_challenge_2020_climate_zone_1 (9 buildings: heat pump, electric heater, cooling + DHW tanks, battery, PV; first 744 h) '
+                            f'x {E} envs per GPU, cl_step_f32 mode A (thermal district: the reference\'s full per-building energy balance), env batch sharded '
+                            'over GPUs, no collective', f64=f64, kpi=kpi)
     if cfg in ('C4', 'C4-lean'):
         from citylearn_amd.synthetic import tile_district
         base = 'citylearn_challenge_2020_climate_zone_1_744h' if cfg == 'C4' else 'citylearn_challenge_2022_phase_all_720h'
@@ -376,7 +382,7 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
     raise SystemExit(f'unknown --config {cfg}')
 
 
-DEFAULT_ENVS = {'headline': ENVS_PER_GPU, 'C2': 4096, 'C3': 65536, 'C4': 1024, 'C4-lean': 1024, 'C5': 32768}
+DEFAULT_ENVS = {'headline': ENVS_PER_GPU, 'C2': 4096, 'C3': 65536, 'C4': 1024, 'C4-lean': 1024, 'C5': 32768, 'T9': 65536}
 
 
 # --------------------------------------------------------------------------------------------------- one rank
@@ -449,7 +455,7 @@ def run_rank(args):
     roof['timed_region_event_us_per_step'] = [e / args.steps * 1e6 for e in evs]
     if roof['bound'] == 'hbm':
         pattern = {'headline': 'r*_bench_pmc_summary.json', 'C2': 'r*_c2_pmc_summary.json', 'C4': 'r*_c4_pmc_summary.json',
-                   'C4-lean': 'r*_c4lean_pmc_summary.json'}.get(cfg, 'none')
+                   'C4-lean': 'r*_c4lean_pmc_summary.json', 'T9': 'r*_kpi_t9_pmc_summary.json' if args.kpi else 'r*_t9_pmc_summary.json'}.get(cfg, 'none')
         roof['traffic'], roof['traffic_source'] = _pmc_traffic(pattern, wl.kernels or '') if E == DEFAULT_ENVS[cfg] else (None, None)
     if cfg == 'headline':
         roof['note'] = ('working set (state 13 MB + outputs 9 MB + action ring 36 MB) fits the 256 MB Infinity Cache: see hbm_streaming '

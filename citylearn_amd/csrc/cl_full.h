@@ -435,9 +435,22 @@ CL_DEV void full_accumulate(float (&q)[VEC], typename Vec<VEC>::type v) {
 // also stop costing a v_mov per two-scalar instruction, and the SGPR file no longer spills.
 constexpr int CL_LP_WORDS = (CLP_F_LAST - CLP_F_FIRST + 1) + CL_NF;      // 64 + 16
 
-template <int VEC, bool DETAIL, int MAXT, int WPE, bool LP, bool NT>
-__global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_kernel(const StepArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC], then (LP) [buildings of the workgroup][CL_LP_WORDS]
+// KPI (round 3, cl_step_full_kpi_kernel): the wave that steps a building also updates the building's streaming KPI accumulators
+// (CLD_KPI) -- net, baseline, expected and served energy are in its registers, the ten (outage steps: twelve) accumulator loads are
+// issued next to the state loads, long before the arithmetic needs anything, and their stores leave with the plane stores -- and the
+// workgroup feeds the two district series after the district reduction.  Replaces the step launch with the CLD_DETAIL_MIN planes + the
+// cl_kpi_kernel launch that read them back (9 x 65 536: 29.1 us for the pair).  Same values in the same order as cl_kpi_kernel: bit-identical.
+// Measured at 9 x 65 536 (scripts/kpi_cost_probe.py, profiles/r03_kpi_in_step_probe.log): 18.8 us with four waves per workgroup -- 4096
+// waves, what the chip holds at once at this kernel's 119 registers; the step-only default of five waves (two generations) 23.6 us, one
+// building per wave 23.8 us.  Tried and slower: the accumulator loads at their point of use with 88 registers and five waves per SIMD
+// (19.5 us at best); wave specialisation -- two extra waves per workgroup that fetch the accumulators at entry, meet the step waves at the
+// reduction's barrier, where those have parked net / baseline / expected / served in LDS, and add and store while the step waves reduce:
+// 22.7 - 34 us (every accumulator store of a workgroup leaves after its slowest step wave, nothing overlaps them any more); plain instead of
+// non-temporal accumulator stores (they are read back by the next step): no difference at 65 536 or 262 144 envs.
+template <int VEC, bool DETAIL, bool LP, bool NT, bool KPI>
+CL_DEV void full_step_body(const StepArgs& a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC], then (LP) [buildings of the workgroup][CL_LP_WORDS] or (KPI) [n_bldg][64*VEC] baselines
+    static_assert(!KPI || (DETAIL && !LP && VEC == 1), "the KPI epilogue is written for one env per lane, with the baseline / expected / served values of the detail unit");
     using F = typename Vec<VEC>::type;
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
@@ -472,6 +485,7 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
         }
         __syncthreads();
     }
+    [[maybe_unused]] float* hand = lds + (size_t)a.nw * NQ * TILE;        // (KPI) [n_bldg][TILE]: the buildings' baselines of this step
     for (int b = b_lo + w; b < b_hi; b += a.nw) {
         if (live) {
             const uint32_t* __restrict__ f = LP ? stage + (b - b_lo) * CL_LP_WORDS : a.params + (long long)b * CL_NP + CLP_F_FIRST;
@@ -482,6 +496,15 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
             cl::Row R;
             cl::load_row_scalar<true>(R, LP ? reinterpret_cast<const float*>(f + (CL_LP_WORDS - CL_NF)) : a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags,
                                       DETAIL ? a.ts + ((long long)(ts_row - a.t + a.n_steps - 1) * a.n_bldg + b) * CL_NF : nullptr);
+            const long long off = (long long)b * a.n_env + env0;
+            // (KPI) every accumulator is loaded before anything is stored, here, with the inputs in flight (cl_kpi_kernel's note: a `+=`
+            // per accumulator is a chain of dependent round trips)
+            [[maybe_unused]] float kv[CL_NKB];
+            if constexpr (KPI) {
+                const float* __restrict__ k = a.kpi_bldg + off;
+#pragma unroll
+                for (int p = 0; p < CL_NKB; ++p) kv[p] = (R.outage || (p != CLK_UNSERVED_OUTAGE && p != CLK_EXPECTED_OUTAGE)) ? k[p * plane] : 0.0f;
+            }
             CL_TRACE_INPUTS(1 + 4 * tr_i, cur);
             clv::St<F> S = {cur.soc, cur.eff, cur.deg, cur.cs, cur.hs, cur.ds};
             const clv::Ac<F> act = {cur.a_cs, cur.a_hs, cur.a_ds, cur.a_es, cur.a_cd, cur.a_hd};
@@ -491,7 +514,6 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
             F rw = clv::unit_reward<F>(rkind, B, S, O.net);
             CL_TRACE_AFTER(2 + 4 * tr_i, rw);
             CL_TRACE_AFTER(2 + 4 * tr_i, S.soc);
-            const long long off = (long long)b * a.n_env + env0;
             if (B.flags & CLF_BATTERY) {
                 full_store<VEC, NT>(a.state + CLS_B_SOC * plane + off, S.soc);
                 full_store<VEC, NT>(a.state + CLS_B_EFF * plane + off, S.eff);
@@ -502,7 +524,26 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
             if (B.flags & CLF_DHW_STO) full_store<VEC, NT>(a.state + CLS_DS_SOC * plane + off, S.ds);
             full_store<VEC, NT>(a.out_bldg + CLO_NET * plane + off, O.net);
             if (rkind != CLR_MARL) full_store<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, rw);
-            if constexpr (DETAIL) {
+            if constexpr (KPI) {
+                const float net = O.net, base = O.base_net, ex = O.expected, sv = O.served;
+                kv[CLK_C_POS] += fmaxf(net, 0.0f);
+                kv[CLK_C_NET] += net;
+                kv[CLK_C_EMISSION] += fmaxf(net * R.carbon, 0.0f);
+                kv[CLK_C_COST] += fmaxf(net * R.price, 0.0f);
+                kv[CLK_B_POS] += fmaxf(base, 0.0f);
+                kv[CLK_B_NET] += base;
+                kv[CLK_B_EMISSION] += fmaxf(base * R.carbon, 0.0f);
+                kv[CLK_B_COST] += fmaxf(base * R.price, 0.0f);
+                kv[CLK_UNSERVED_OUTAGE] += ex - sv; kv[CLK_EXPECTED_OUTAGE] += ex;
+                kv[CLK_UNSERVED_ALL] += ex - sv;
+                kv[CLK_EXPECTED_ALL] += ex;
+                float* __restrict__ k = a.kpi_bldg + off;
+#pragma unroll
+                for (int p = 0; p < CL_NKB; ++p)
+                    if (R.outage || (p != CLK_UNSERVED_OUTAGE && p != CLK_EXPECTED_OUTAGE)) full_store<1, NT>(k + p * plane, kv[p]);
+                hand[(size_t)b * TILE + lane] = base;                                      // the district baseline series is summed below
+            }
+            if (DETAIL && (!KPI || (a.flags & CLD_WRITE_DETAIL))) {
                 // what another kernel of the path reads: the KPI pass (baseline, expected, served) and the LSTM stage (delivered demands)
                 full_store<VEC, NT>(a.out_bldg + CLO_COOL_DEM * plane + off, O.cool_dem);
                 full_store<VEC, NT>(a.out_bldg + CLO_HEAT_DEM * plane + off, O.heat_dem);
@@ -532,8 +573,32 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
         }
     }
     CL_TRACE_AFTER(13, q_net[0]);
-    district_reduce<VEC, false, LP && VEC == 2>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
+    district_reduce<VEC, false, LP && VEC == 2, KPI>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
+    if constexpr (KPI) {
+        // baseline district series: the per-building baselines in cl_kpi_kernel's association (16 strided partial sums, added in order).
+        // (district_reduce's barriers came after every wave's LDS writes; MARL's extra sweep leaves this region alone.)
+        if (w == 0 && live) {
+            const float* __restrict__ bl = hand + lane;
+            float base = 0.0f;
+            for (int k = 0; k < 16; ++k) {
+                float s = 0.0f;
+                for (int b = k; b < a.n_bldg; b += 16) s += bl[(size_t)b * TILE];
+                base += s;
+            }
+            kpi_series_update(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + env0, a.n_env, a.t, base);
+        }
+    }
     CL_TRACE_FLUSH();
+}
+
+template <int VEC, bool DETAIL, int MAXT, int WPE, bool LP, bool NT>
+__global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_kernel(const StepArgs a) {
+    full_step_body<VEC, DETAIL, LP, NT, false>(a);
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) cl_step_full_kpi_kernel(const StepArgs a) {
+    full_step_body<1, true, false, NT, true>(a);
 }
 
 // Thermal / outage districts, several env tiles per workgroup ("items" = (env tile, building) pairs dealt to the waves in order:

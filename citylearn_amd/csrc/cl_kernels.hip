@@ -1337,10 +1337,10 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (int rc = check_ptr(out_bldg, "out_bldg")) return rc;
     if (int rc = check_ptr(out_env, "out_env")) return rc;
     if (dims->flags & CLD_KPI) {
-        // the per-building accumulators read the detail planes -- except for battery + PV districts of up to 32 buildings, whose step
-        // kernel updates them itself (cl_step_lean_kpi_kernel)
-        if (!(dims->flags & CLD_WRITE_DETAIL) && (!(dims->flags & CLD_LEAN) || dims->n_bldg > 32 || flex))
-            return fail(CL_EINVAL, "CLD_KPI requires CLD_WRITE_DETAIL (except for CLD_LEAN districts of up to 32 buildings without flexible loads)");
+        // the per-building accumulators read the detail planes -- except for districts of up to 32 buildings without flexible loads, whose
+        // step kernel updates them itself (cl_step_lean_kpi_kernel / cl_step_full_kpi_kernel; the launch selection below refuses the rest)
+        if (!(dims->flags & CLD_WRITE_DETAIL) && (dims->n_bldg > 32 || flex))
+            return fail(CL_EINVAL, "CLD_KPI requires CLD_WRITE_DETAIL (except for districts of up to 32 buildings without flexible loads)");
         if (int rc = check_ptr(kpi_bldg, "kpi_bldg")) return rc;
         if (int rc = check_ptr(kpi_env, "kpi_env")) return rc;
     }
@@ -1434,6 +1434,16 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         return fail(CL_EINVAL, "reward kind CLR_EV is not implemented for building-chunked launches (n_bldg=%d)", dims->n_bldg);
     const dim3 grid(grid_x, a.n_chunks);
     const bool det = dims->flags & CLD_WRITE_DETAIL;
+    // streaming KPIs of thermal / outage districts (and of any district stepped with detail planes) inside the step launch:
+    // cl_step_full_kpi_kernel (cl_full.h); cl_tuning.kpi_passes = 1 keeps the separate cl_kpi_kernel pass (A/B), 2 the two round-1 passes
+    const bool kpi_full = (dims->flags & CLD_KPI) && full && !flex && !f64 && a.n_chunks == 1 && vec == 1 && tun.full_variant != 1 && tun.kpi_passes == 0;
+    // ... whose waves should all be resident at once (16 per CU at its 119 registers): as many waves per workgroup as that allows, at least
+    // two (9 x 65 536: four waves 18.8 us, the step-only default of five -- two generations -- 23.6 us; profiles/r03_kpi_in_step_probe.log)
+    if (kpi_full && !tun.nw) {
+        const long long fit = (16ll * 256) / grid_x;
+        a.nw = (int)(fit < 2 ? 2 : fit > 16 ? 16 : fit);
+        if (a.nw > dims->n_bldg) a.nw = dims->n_bldg;
+    }
     // thermal kernel with the parameter blocks of the workgroup's buildings staged in LDS
     // (for the building-chunked launches only -- a workgroup of the 9 x 65 536 launch would wait for the staging round trip before it
     //  can issue its plane loads, while its scalar reads hit the constant cache: 10.7 vs 8.7 us; full_variant = 2 forces it, 3 forbids it)
@@ -1459,7 +1469,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     const int tp_nw = tp_forced && tun.nw ? tun.nw : (tp_small ? dims->n_bldg : 16);
     const unsigned tp_grid = (unsigned)((dims->n_env + tp_tiles * 64 * tp_vec - 1) / (tp_tiles * 64 * tp_vec));
     const size_t tp_lds = ((size_t)tp_tiles * dims->n_bldg * NQ + tp_tiles) * 64 * tp_vec * sizeof(float);
-    bool tp_kernel = full && !flex && !(dims->flags & CLD_WRITE_DETAIL) && a.n_chunks == 1 && dims->n_bldg <= 32 && tp_lds <= 150 * 1024 &&
+    bool tp_kernel = full && !flex && !(dims->flags & CLD_WRITE_DETAIL) && !kpi_full && a.n_chunks == 1 && dims->n_bldg <= 32 && tp_lds <= 150 * 1024 &&
                      (!dims->env_row0 || CL_ROW0_BLOCK % (tp_tiles * 64 * tp_vec) == 0);    // one episode offset per workgroup: no workgroup straddles two blocks
     if (tp_forced) {
         if (!tp_kernel || tp_nw > 16)
@@ -1468,13 +1478,14 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // (up to 352 workgroups: between 65 536 and 90 112 envs the latency-ordered kernel still beats the general and the env-major one,
     //  17 x 81 920: 11.4 vs 12.7 / 12.9 us, scripts/lean_gap_sizes.py; from 106 496 envs the env-major kernel wins, 17 x 114 688: 13.5 vs 14.7 us)
     // streaming KPIs without the detail planes: the lean kernel updates the per-building accumulators itself, at any grid size
-    const bool kpi_lean = (dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL);
+    const bool kpi_lean = (dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL) && !kpi_full;
     const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 352 || (tun.lean_variant & 2) || kpi_lean) && !((tun.lean_variant & 1) && !kpi_lean);
     // without the detail planes only cl_step_lean_kpi_kernel updates the per-building accumulators (and writes the baseline plane
     // cl_kpi_env_kernel sums): a launch shape that cannot take it must not silently leave them stale
     if (kpi_lean && (full || flex || !lean_shape))
-        return fail(CL_EINVAL, "CLD_KPI without CLD_WRITE_DETAIL needs the lean step launch (n_bldg=%d <= 2 x nw=%d waves, no chunks): "
-                               "drop the cl_tuning override or set CLD_WRITE_DETAIL", dims->n_bldg, a.nw);
+        return fail(CL_EINVAL, "CLD_KPI without CLD_WRITE_DETAIL needs a step launch that updates the accumulators itself (battery + PV: n_bldg=%d <= 2 x nw=%d "
+                               "waves, no chunks; thermal: one env per lane, no chunks, no flexible loads, no CLD_F64_MAPS): drop the cl_tuning override or set CLD_WRITE_DETAIL",
+                    dims->n_bldg, a.nw);
     if (f64) {
         if (!full && lean_shape) {
             if (vec == 1) CL_LAUNCH_NT(cl_step_lean_f64_kernel, 1); else CL_LAUNCH_NT(cl_step_lean_f64_kernel, 2);
@@ -1524,7 +1535,12 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     } else if (full && tun.full_variant != 1 && vec <= 2) {
         // thermal / outage districts: the pack-generic kernel of cl_full.h
         const bool small = block.x <= 576;
-        if (det) {
+        if (kpi_full) {
+            const size_t lds_k = lds + (size_t)dims->n_bldg * tile * sizeof(float);      // + the per-building baselines of the tile
+            name_add(tun, "cl_step_full_kpi_kernel<%s>", a.nt ? "true" : "false");
+            if (a.nt) hipLaunchKernelGGL((cl_step_full_kpi_kernel<true>), grid, block, lds_k, s, a);
+            else hipLaunchKernelGGL((cl_step_full_kpi_kernel<false>), grid, block, lds_k, s, a);
+        } else if (det) {
             if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, true, 1024, 4, false);
             else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 576, 3, false);
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 1024, 4, false);
@@ -1618,7 +1634,9 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (dims->flags & CLD_KPI) {
         const long long n = (long long)dims->n_env * dims->n_bldg;
         // (without the detail planes -- lean districts -- the step launch above has updated every accumulator itself)
-        if ((dims->flags & CLD_WRITE_DETAIL) && tun.kpi_passes == 2) {            // the round-1 / round-2 form: two passes (tests, A/B)
+        if (kpi_full) {
+            // (cl_step_full_kpi_kernel has updated every accumulator)
+        } else if ((dims->flags & CLD_WRITE_DETAIL) && tun.kpi_passes == 2) {            // the round-1 / round-2 form: two passes (tests, A/B)
             name_add(tun, "cl_kpi_bldg_kernel+cl_kpi_env_kernel");
             hipLaunchKernelGGL(cl_kpi_bldg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
             hipLaunchKernelGGL(cl_kpi_env_kernel, dim3((dims->n_env + 63) / 64), dim3(1024), 0, s, a);

@@ -112,12 +112,16 @@ class StepEngine:
         # the streaming KPI passes read the detail planes -- except for battery + PV districts of up to 32 buildings, whose step kernel
         # updates the per-building accumulators itself (cl_step_lean_kpi_kernel): no detail planes, no second pass
         kpi_in_step = kpi and self.lean and self.n_bldg <= 32 and self.flex_tables is None and not f64_maps
+        # ... and for thermal / outage districts stepped by the one-env-per-lane thermal kernel (cl_step_full_kpi_kernel; any launch override
+        # that selects another kernel falls back to the detail subset + the KPI launch)
+        kpi_in_full_step = (kpi and not self.lean and self.n_bldg <= 32 and self.flex_tables is None and not f64_maps
+                            and not any((tuning or {}).get(k) for k in ('vec', 'kpi_passes', 'no_chunks')) and (tuning or {}).get('full_variant') != 1)
         # `detail`: True = every detail plane (observations, evaluate()'s series, parity tests, reward plugins); 'min' = only the planes
         # another kernel of the path reads (CLD_DETAIL_MIN: baseline / expected / served for the KPI pass, delivered demands for the LSTM
         # stage) -- which is also what streaming KPIs alone ask for
         if detail not in (True, False, 'min'):
             raise ValueError("detail must be True, False or 'min'")
-        if detail is False and kpi and not kpi_in_step:
+        if detail is False and kpi and not kpi_in_step and not kpi_in_full_step:
             detail = 'min'
         flags |= abi.CLD_WRITE_DETAIL if detail else 0
         flags |= abi.CLD_DETAIL_MIN if detail == 'min' else 0
@@ -372,8 +376,12 @@ class StepEngine:
         step = 8.0 * planes + 4.0 * self.n_act_cols / self.n_bldg + 8.0 + 4.0 * abi.CL_NQ / self.n_bldg
         if not self.kpi:
             return step
-        # mode A-kpi: four control sums read + written per unit, twelve district accumulators per env; where the baseline
-        # depends on the env (thermal / outage districts) four more per unit and twelve more per env
+        # mode A-kpi.  Per unit, read + written every step: the four control sums (positive net, net, emission, cost) and, where
+        # the baseline depends on the env (thermal / outage districts), its four sums and the unserved / expected energy sums: 4 or 10
+        # accumulators.  Per env and district series (control; + baseline where it depends on the env): the seven values that move every
+        # step -- previous value, ramping sum, open day's sum and maximum, open month's sum and maximum, all-time peak (the closed-group
+        # sums move once per 24 / 730 steps and are not counted).
+        moving = 7.0
         if self.kpi_shared_baseline:
-            return step + 32.0 + 8.0 * abi.CLKE_PER_COND / self.n_bldg
-        return step + 64.0 + 16.0 * abi.CLKE_PER_COND / self.n_bldg
+            return step + 32.0 + 8.0 * moving / self.n_bldg
+        return step + 80.0 + 16.0 * moving / self.n_bldg

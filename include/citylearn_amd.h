@@ -241,8 +241,10 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 
 #define CLD_REF_T0_QUIRK   (1u << 0)  /* replicate the reference's repeated t=0 update_variables (SURVEY App.B1) */
 #define CLD_WRITE_DETAIL   (1u << 1)  /* also write CLO_B_EB .. CLO_C_NSL planes (parity / KPI baselines) */
-#define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators (requires CLD_WRITE_DETAIL, except for CLD_LEAN districts of up to 32
-                                         buildings stepped without flexible loads: their step launch updates the accumulators itself.  In such a
+#define CLD_KPI            (1u << 2)  /* update the streaming KPI accumulators.  The step launch updates them itself -- no detail planes needed -- for
+                                         thermal / outage districts of up to 32 buildings without flexible loads and without CLD_F64_MAPS
+                                         (cl_step_full_kpi_kernel) and for CLD_LEAN districts of up to 32 buildings stepped without flexible loads;
+                                         every other district needs CLD_WRITE_DETAIL (a launch after the step reads the planes).  In such a CLD_LEAN
                                          district the baseline (net without the battery = load + solar), the expected energy and the baseline
                                          district series do not depend on the env, so without CLD_WRITE_DETAIL the planes CLK_B_POS .. CLK_B_COST,
                                          CLK_EXPECTED_ALL and the condition-1 rows of `kpi_env` are maintained ONCE per block of CL_ROW0_BLOCK
@@ -304,8 +306,10 @@ typedef struct cl_tuning {
     int32_t finish;         /* building-chunked launches (districts of more than 32 buildings): 0 / 1 = a second launch folds the chunk partial
                                sums (cl_finish_kernel), 2 = the last chunk of an env tile to arrive folds them inside the step launch
                                (measured slower: csrc/cl_kernels.hip district_reduce; tests, A/B) */
-    int32_t kpi_passes;     /* streaming KPIs of districts stepped with the detail planes: 0 / 1 = one launch after the step (cl_kpi_kernel),
-                               2 = the two passes of rounds 1 - 2 (cl_kpi_bldg_kernel + cl_kpi_env_kernel; tests, A/B) */
+    int32_t kpi_passes;     /* streaming KPIs of thermal / outage districts and of districts stepped with the detail planes: 0 = inside the step
+                               launch where the launch is the one-env-per-lane thermal kernel (cl_step_full_kpi_kernel), else one launch after
+                               the step; 1 = always the launch after the step (cl_kpi_kernel; needs CLD_WRITE_DETAIL), 2 = the two passes of
+                               rounds 1 - 2 (cl_kpi_bldg_kernel + cl_kpi_env_kernel; tests, A/B) */
 } cl_tuning;
 #define CL_KERNEL_NAME_LEN 256
 

@@ -35,13 +35,13 @@ done
 python scripts/pmc_summary.py $OUT/streaming_pmc_summary.json "$KS" $OUT/pmc_streaming_FETCH_SIZE/*counter_collection.csv $OUT/pmc_streaming_WRITE_SIZE/*counter_collection.csv > /dev/null
 python scripts/check_profiles.py $OUT/bench_streaming_line.json $OUT/streaming_pmc_summary.json >> $OUT/check.log || FAIL=1
 # ---- one line per BASELINE config (+ HBM counters for the A-mode ones, kernel stats for all) ----
-for c in C2 C3 C4 C4-lean C5; do
+for c in C2 C3 C4 C4-lean C5 T9; do
   n=$(echo $c | tr 'A-Z' 'a-z' | tr -d '-')
   python bench.py --config $c > $OUT/bench_$c.json 2>$OUT/bench_$c.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$n -o run -- python bench.py --config $c --reps 1 > /dev/null 2>$OUT/trace_$n.log
   cp $OUT/trace_$n/*kernel_stats.csv $OUT/${n}_kernel_stats.csv 2>/dev/null
   python scripts/check_profiles.py $OUT/bench_$c.json $OUT/${n}_kernel_stats.csv >> $OUT/check.log || FAIL=1
-  case $c in C2|C4|C4-lean)
+  case $c in C2|C4|C4-lean|T9)
     KC=$(kernel_of $OUT/bench_$c.json)
     for ctr in FETCH_SIZE WRITE_SIZE; do
       pmc_pass ${n}_$ctr $ctr -- python bench.py --config $c --steps 300 --warmup 50 --reps 1 --no-graph
@@ -58,6 +58,17 @@ python scripts/pmc_by_kernel.py cl_rollout_kernel $OUT/pmc_c5_SQ/*counter_collec
 # ---- streaming KPIs (mode A-kpi), CLD_F64_MAPS cost, user-level step ----
 python bench.py --kpi --no-streaming --no-cpu-baseline > $OUT/bench_kpi.json 2>$OUT/bench_kpi.err
 python bench.py --kpi --config C3 > $OUT/bench_kpi_C3.json 2>$OUT/bench_kpi_C3.err
+# thermal district with streaming KPIs inside the step launch (cl_step_full_kpi_kernel): line, kernel stats, HBM counters
+python bench.py --kpi --config T9 --no-cpu-baseline > $OUT/bench_kpi_T9.json 2>$OUT/bench_kpi_T9.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_kpi_t9 -o run -- python bench.py --kpi --config T9 --reps 1 --no-cpu-baseline > /dev/null 2>$OUT/trace_kpi_t9.log
+cp $OUT/trace_kpi_t9/*kernel_stats.csv $OUT/kpi_t9_kernel_stats.csv 2>/dev/null
+python scripts/check_profiles.py $OUT/bench_kpi_T9.json $OUT/kpi_t9_kernel_stats.csv >> $OUT/check.log || FAIL=1
+KC=$(kernel_of $OUT/bench_kpi_T9.json)
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  pmc_pass kpi_t9_$ctr $ctr -- python bench.py --kpi --config T9 --steps 300 --warmup 50 --reps 1 --no-graph --no-cpu-baseline
+done
+python scripts/pmc_summary.py $OUT/kpi_t9_pmc_summary.json "$KC" $OUT/pmc_kpi_t9_FETCH_SIZE/*counter_collection.csv $OUT/pmc_kpi_t9_WRITE_SIZE/*counter_collection.csv > /dev/null
+python scripts/check_profiles.py $OUT/bench_kpi_T9.json $OUT/kpi_t9_pmc_summary.json >> $OUT/check.log || FAIL=1
 python bench.py --f64-maps --no-streaming --no-cpu-baseline > $OUT/bench_f64_maps.json 2>$OUT/bench_f64_maps.err
 for s in env_step_bench f64_cost ev_step_bench observe_bench; do
   timeout 600 python scripts/$s.py > $OUT/${s}.log 2>$OUT/$s.err

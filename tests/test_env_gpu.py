@@ -172,11 +172,21 @@ def test_streaming_kpi_accumulators(name, K):
     B, E = eng.n_bldg, 8
     hist = {k: np.zeros((K, B, E), dtype='float32') for k in ('net', 'base', 'exp', 'srv', 'temp')}
     d_net = np.zeros((K, E))
+    # a thermal district without dynamics updates its accumulators inside the step launch and writes no detail plane (cl_step_full_kpi_kernel):
+    # the baseline / expected / served series then come from a twin engine that does write them
+    twin = None
+    if eng.detail is False and not eng.kpi_shared_baseline:
+        from citylearn_amd.engine import StepEngine
+        twin = StepEngine(env.tables, E, detail=True)
     for t in range(K):
         a = env.sample_actions(gen)
         a[:, 0] = acts_g[t]
         env.step(a)
         ob = eng.out_bldg.cpu().numpy()
+        if twin is not None:
+            twin.step(a, t)
+            assert torch.equal(twin.out_bldg[abi.CLO_NET], eng.out_bldg[abi.CLO_NET])
+            ob = twin.out_bldg.cpu().numpy()
         hist['net'][t], hist['base'][t] = ob[abi.CLO_NET], ob[abi.CLO_BASE_NET]
         if eng.kpi_shared_baseline:
             # battery + PV district stepped without the detail planes: the baseline (load + solar, the load booked three times at t = 0,

@@ -245,28 +245,75 @@ def test_kpi_accumulators_updated_by_the_lean_step_kernel(E, tuning):
     assert fused.kpi_bldg.abs().sum().item() > 0
 
 
-@pytest.mark.parametrize('name,E', [('g2020_cz1', 65536), ('g2023_p2', 516), ('g2022_evs', 260)])
+def _kpi_step_waves(n_env, n_bldg):
+    """cl_step_full_kpi_kernel's waves per workgroup (csrc/cl_kernels.hip step_impl): as many as keep every wave of the launch resident."""
+    return min(n_bldg, max(2, min(16, 4096 // -(-n_env // 64))))
+
+
+@pytest.mark.parametrize('name,E', [('g2020_cz1', 65536), ('g2023_p2', 516), ('g2022_evs', 260), ('s_2023_p3', 1028)])
 def test_streaming_kpis_in_one_pass_over_the_minimal_detail_planes(name, E):
-    """Districts whose KPI baseline depends on the env (thermal, outage, EV): the step writes only the detail planes another kernel reads
-    (`CLD_DETAIL_MIN`: baseline, expected, served, delivered demands) and ONE launch (`cl_kpi_kernel`) updates every accumulator -- same
-    bits as the step with all fifteen detail planes followed by the two passes of rounds 1 - 2 (`cl_tuning.kpi_passes = 2`)."""
+    """Districts whose KPI baseline depends on the env (thermal, outage, EV), three ways, same bits:
+    * default, thermal / outage districts: the step launch updates every accumulator itself (`cl_step_full_kpi_kernel`, no detail planes);
+    * `cl_tuning.kpi_passes = 1` (and EV districts by default): the step writes only the detail planes another kernel reads
+      (`CLD_DETAIL_MIN`: baseline, expected, served, delivered demands) and ONE launch (`cl_kpi_kernel`) updates the accumulators;
+    * `kpi_passes = 2`: the step with all fifteen detail planes followed by the two passes of rounds 1 - 2."""
     g = golden(name)
     spec = g.spec()
     tab = spec.episode_tables(0)
-    new = StepEngine(tab, E, kpi=True)                                   # detail 'min' by itself
-    old = StepEngine(tab, E, kpi=True, detail=True, tuning=dict(kpi_passes=2))
-    new.trace_kernels(); old.trace_kernels()
+    fused = StepEngine(tab, E, kpi=True)                                 # thermal: in the step launch; EV: detail 'min' by itself
+    # (the in-step launch picks its own number of waves per workgroup -- all waves resident at once -- and the district sums are added
+    #  per wave, then over waves: the same geometry for the other two, so that every sum compares bit for bit)
+    nw = {} if fused.flex is not None else dict(nw=_kpi_step_waves(E, fused.n_bldg))
+    new = StepEngine(tab, E, kpi=True, tuning=dict(kpi_passes=1, **nw))        # detail 'min' + cl_kpi_kernel
+    old = StepEngine(tab, E, kpi=True, detail=True, tuning=dict(kpi_passes=2, **nw))
+    for e in (fused, new, old):
+        e.trace_kernels()
+    in_step = fused.flex is None
+    assert fused.detail == (False if in_step else 'min')
     assert new.detail == 'min' and (new.dims.flags & abi.CLD_DETAIL_MIN) and not (old.dims.flags & abi.CLD_DETAIL_MIN)
     low, high = spec.action_limits()
     lo, hi = torch.from_numpy(low).cuda()[:, None], torch.from_numpy(high).cuda()[:, None]
     gen = torch.Generator(device='cuda').manual_seed(E)
     for t in range(40):
         a = (lo + torch.rand((new.n_act_cols, E), device='cuda', generator=gen) * (hi - lo)).contiguous()
-        new.step(a, t); old.step(a, t)
+        fused.step(a, t); new.step(a, t); old.step(a, t)
+    assert fused.last_kernels.startswith('cl_step_full_kpi_kernel<') == in_step and ('cl_kpi_kernel' in fused.last_kernels) != in_step, fused.last_kernels
     assert new.last_kernels.endswith('+cl_kpi_kernel') and old.last_kernels.endswith('cl_kpi_bldg_kernel+cl_kpi_env_kernel')
     assert torch.equal(new.state, old.state) and torch.equal(new.out_env, old.out_env)
+    assert torch.equal(fused.state, old.state) and torch.equal(fused.out_env, old.out_env)
     for pl in (abi.CLO_NET, abi.CLO_REWARD, abi.CLO_BASE_NET, abi.CLO_EXPECTED, abi.CLO_SERVED, abi.CLO_COOL_DEM, abi.CLO_HEAT_DEM):
         assert torch.equal(new.out_bldg[pl], old.out_bldg[pl]), pl
+    assert torch.equal(fused.out_bldg[:2], old.out_bldg[:2])
+    if in_step:
+        assert not fused.out_bldg[abi.CLO_BASE_NET].any()                                       # no detail plane written at all
     assert not new.out_bldg[abi.CLO_C_NSL].any() and old.out_bldg[abi.CLO_C_NSL].any()          # the other planes are left alone
     assert torch.equal(new.kpi_bldg, old.kpi_bldg) and torch.equal(new.kpi_env, old.kpi_env)
+    assert torch.equal(fused.kpi_bldg, old.kpi_bldg) and torch.equal(fused.kpi_env, old.kpi_env)
     assert float(new.kpi_bldg.abs().sum()) > 0
+
+
+def test_streaming_kpis_in_the_thermal_step_launch_with_detail_planes_and_episode_offsets():
+    """`cl_step_full_kpi_kernel` also when the caller wants detail planes (all of them: observations / plugins; the subset: the LSTM
+    stage) and with per-env-block episode offsets; MARL reward (its extra sweep runs between the reduction and the district series)."""
+    g = golden('g2023_p2')
+    spec = g.spec()
+    E = 768
+    row0 = np.array([0, 24, 100])
+    tab = spec.episode_tables(0)
+    n_steps = 120
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda()[:, None], torch.from_numpy(high).cuda()[:, None]
+    for detail in (True, 'min'):
+        kw = dict(kpi=True, detail=detail, reward='MARL', n_steps=n_steps, env_row0=row0)
+        fused = StepEngine(tab, E, **kw)
+        ref = StepEngine(tab, E, tuning=dict(kpi_passes=1, nw=_kpi_step_waves(E, 3)), **kw)
+        fused.trace_kernels(); ref.trace_kernels()
+        gen = torch.Generator(device='cuda').manual_seed(3)
+        for t in range(30):
+            a = (lo + torch.rand((fused.n_act_cols, E), device='cuda', generator=gen) * (hi - lo)).contiguous()
+            fused.step(a, t); ref.step(a, t)
+        assert fused.last_kernels.startswith('cl_step_full_kpi_kernel<') and 'cl_kpi_kernel' not in fused.last_kernels
+        assert ref.last_kernels.endswith('+cl_kpi_kernel')
+        assert torch.equal(fused.state, ref.state) and torch.equal(fused.out_env, ref.out_env) and torch.equal(fused.out_bldg[:-1], ref.out_bldg[:-1])
+        assert torch.equal(fused.kpi_bldg, ref.kpi_bldg) and torch.equal(fused.kpi_env, ref.kpi_env)
+        assert float(fused.kpi_bldg.abs().sum()) > 0
