@@ -52,3 +52,12 @@ def test_config_lines(cfg, kernel, bound):
     out = _bench('--config', cfg, '--steps', '20', '--warmup', '5', '--reps', '2')
     assert out['config']['name'] == cfg and out['roofline']['bound'] == bound and kernel in out['roofline']['kernel'], out['roofline']['kernel']
     assert 0.0 < out['roofline']['frac'] < 1.0 and out['value'] > 1e8
+
+
+def test_thermal_kpi_line_runs_the_kpis_inside_the_step_launch():
+    """`bench.py --config T9 --kpi`: one launch per step (`cl_step_full_kpi_kernel`), priced against HBM with the ten per-unit accumulators
+    and the moving district-series values in the byte count."""
+    out = _bench('--config', 'T9', '--kpi', '--steps', '20', '--warmup', '5', '--reps', '2', '--no-cpu-baseline')
+    r = out['roofline']
+    assert out['config']['name'] == 'T9' and r['bound'] == 'hbm' and r['kernel'] == 'cl_step_full_kpi_kernel<true>', r['kernel']
+    assert 140.0 < r['algorithmic_bytes_per_unit'] < 160.0 and 0.3 < r['frac'] < 1.0
