@@ -573,11 +573,16 @@ CL_DEV void full_step_body(const StepArgs& a) {
         }
     }
     CL_TRACE_AFTER(13, q_net[0]);
+    [[maybe_unused]] KpiSeries base_pre;
+    if constexpr (KPI) {
+        // (the baseline series' accumulators of this lane's env: fetched before the reduction's barriers, by the LAST wave -- wave 0 carries the control series)
+        if (w == a.nw - 1 && live) kpi_series_fetch(base_pre, a.kpi_env + (long long)CLKE_PER_COND * a.n_env + env0, a.n_env);
+    }
     district_reduce<VEC, false, LP && VEC == 2, KPI>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
     if constexpr (KPI) {
         // baseline district series: the per-building baselines in cl_kpi_kernel's association (16 strided partial sums, added in order).
         // (district_reduce's barriers came after every wave's LDS writes; MARL's extra sweep leaves this region alone.)
-        if (w == 0 && live) {
+        if (w == a.nw - 1 && live) {
             const float* __restrict__ bl = hand + lane;
             float base = 0.0f;
             for (int k = 0; k < 16; ++k) {
@@ -585,7 +590,7 @@ CL_DEV void full_step_body(const StepArgs& a) {
                 for (int b = k; b < a.n_bldg; b += 16) s += bl[(size_t)b * TILE];
                 base += s;
             }
-            kpi_series_update(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + env0, a.n_env, a.t, base);
+            kpi_series_apply(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + env0, a.n_env, a.t, base, base_pre);
         }
     }
     CL_TRACE_FLUSH();

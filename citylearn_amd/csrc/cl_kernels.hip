@@ -153,7 +153,14 @@ constexpr int NQ = CL_NQ;
 // FOLD: instantiations that are launched building-chunked may finish the chunk sums themselves (a.fused_finish); a template parameter
 // because the fold's sixteen loads in flight would otherwise set the register budget of every kernel this is inlined into (the general
 // lean kernel went from 52 to 102 VGPRs).
-CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, float v);      // (streaming KPIs, below)
+// (streaming KPIs, below)  One more sample of a district series costs ONE round trip: the seven accumulators that move every step are
+// fetched together (kpi_series_fetch -- where the caller can, before a barrier it has to wait at anyway), then updated and stored
+// (kpi_series_apply).  As `k[..] += ..` statements one after the other -- what rounds 1 - 3 had -- every load waits for the store in
+// front of it (the compiler cannot tell the planes apart): five dependent round trips at the very end of every workgroup.
+struct KpiSeries { float prev, ramp, dsum, dmax, msum, mmax, amax; };
+CL_DEV void kpi_series_fetch(KpiSeries& s, const float* __restrict__ k, long long n_env);
+CL_DEV void kpi_series_apply(float* __restrict__ k, long long n_env, int t, float v, const KpiSeries& s);
+CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, float v);
 
 // KPIS: the thread that writes an env's district net also feeds it to the env's streaming district accumulators (CLD_KPI, lean districts)
 template <int VEC, bool FLEX = false, bool FOLD = false, bool KPIS = false>
@@ -166,8 +173,13 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
     vstore<VEC>(mine + 1 * TILE, q_cost);
     vstore<VEC>(mine + 2 * TILE, q_em);
     vstore<VEC>(mine + 3 * TILE, q_rw);
-    __syncthreads();
     const int tile_env0 = blockIdx.x * TILE;
+    // (KPIS) the control series' accumulators of the env whose district net this thread is about to write: in flight across the barrier
+    [[maybe_unused]] KpiSeries pre;
+    if constexpr (KPIS) {
+        if (threadIdx.x < TILE && tile_env0 + (int)threadIdx.x < a.n_env) kpi_series_fetch(pre, a.kpi_env + tile_env0 + threadIdx.x, a.n_env);
+    }
+    __syncthreads();
     const bool coupled = rkind == CLR_MARL || (FLEX && rkind == CLR_EV);   // rewards that need the district net
     if (a.n_chunks > 1) {
         // Large districts: this workgroup only saw buildings [y*b_chunk, (y+1)*b_chunk).  Its partial sums go to the scratch rows of
@@ -267,7 +279,10 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
         if (tile_env0 + e < a.n_env) {
             a.out_env[(long long)q * a.n_env + tile_env0 + e] = s;
             if constexpr (KPIS) {
-                if (q == CLQ_NET) kpi_series_update(a.kpi_env + tile_env0 + e, a.n_env, a.t, s);     // control condition (citylearn.py:1136-1323)
+                if (q == CLQ_NET) {                                                                   // control condition (citylearn.py:1136-1323)
+                    if (i == (int)threadIdx.x) kpi_series_apply(a.kpi_env + tile_env0 + e, a.n_env, a.t, s, pre);
+                    else kpi_series_update(a.kpi_env + tile_env0 + e, a.n_env, a.t, s);               // (workgroups narrower than their env tile)
+                }
             }
         }
         if (coupled && q == CLQ_NET) lds[i] = s;               // wave-0 slot now holds the district net
@@ -734,14 +749,21 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
         }
     }
     CL_TRACE_AFTER(13, q_net[0]);
+    [[maybe_unused]] KpiSeries base_pre;
+    [[maybe_unused]] const bool base_writer = KPI && !FLEX && threadIdx.x == blockDim.x - 1 && (blockIdx.x * TILE) % CL_ROW0_BLOCK == 0;
+    if constexpr (KPI && !FLEX) {
+        // (the baseline series' accumulators: fetched before the reduction's barriers, by the workgroup's LAST thread -- the first ones
+        //  carry the control series)
+        if (base_writer) kpi_series_fetch(base_pre, a.kpi_env + (long long)CLKE_PER_COND * a.n_env + blockIdx.x * TILE, a.n_env);
+    }
     district_reduce<VEC, FLEX, false, KPI && !FLEX>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
     if constexpr (KPI && !FLEX) {
         // baseline condition of the district series: the sum of the buildings' baselines in building order, once per env block
         // (district_reduce's barriers came after every wave's write of its buildings' values)
-        if (threadIdx.x == 0 && (blockIdx.x * TILE) % CL_ROW0_BLOCK == 0) {
+        if (base_writer) {
             float sum = 0.0f;
             for (int b = 0; b < a.n_bldg; ++b) sum += lds[(size_t)a.nw * NQ * TILE + b];
-            kpi_series_update(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + blockIdx.x * TILE, a.n_env, a.t, sum);
+            kpi_series_apply(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + blockIdx.x * TILE, a.n_env, a.t, sum, base_pre);
         }
     }
     if constexpr (OBS) {
@@ -955,12 +977,18 @@ __global__ void cl_kpi_bldg_kernel(const StepArgs a) {
     k[CLK_EXPECTED_ALL * plane] += ex;
 }
 
-CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, float v) {
+CL_DEV void kpi_series_fetch(KpiSeries& s, const float* __restrict__ k, long long n_env) {
+    s.prev = k[CLKE_PREV * n_env]; s.ramp = k[CLKE_RAMP * n_env];
+    s.dsum = k[CLKE_DAY_SUM * n_env]; s.dmax = k[CLKE_DAY_MAX * n_env];
+    s.msum = k[CLKE_MON_SUM * n_env]; s.mmax = k[CLKE_MON_MAX * n_env];
+    s.amax = k[CLKE_ALL_MAX * n_env];
+}
+
+CL_DEV void kpi_series_apply(float* __restrict__ k, long long n_env, int t, float v, const KpiSeries& s) {
     // one more sample `v` (index t) of a district series: ramping, 24- and 730-step load factor / peak groups
-    float prev = k[CLKE_PREV * n_env];
-    if (t > 0) k[CLKE_RAMP * n_env] += fmaxf(v - prev, 0.0f);
+    if (t > 0) k[CLKE_RAMP * n_env] = s.ramp + fmaxf(v - s.prev, 0.0f);
     k[CLKE_PREV * n_env] = v;
-    float dsum = k[CLKE_DAY_SUM * n_env], dmax = k[CLKE_DAY_MAX * n_env];
+    float dsum = s.dsum, dmax = s.dmax;
     if (t > 0 && t % 24 == 0) {
         k[CLKE_DAY_LF_SUM * n_env] += 1.0f - (dsum * (1.0f / 24.0f)) / dmax;
         k[CLKE_DAY_PEAK_SUM * n_env] += dmax;
@@ -968,14 +996,20 @@ CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, flo
         dsum = 0.0f; dmax = -INFINITY;
     }
     k[CLKE_DAY_SUM * n_env] = dsum + v; k[CLKE_DAY_MAX * n_env] = fmaxf(dmax, v);
-    float msum = k[CLKE_MON_SUM * n_env], mmax = k[CLKE_MON_MAX * n_env];
+    float msum = s.msum, mmax = s.mmax;
     if (t > 0 && t % 730 == 0) {
         k[CLKE_MON_LF_SUM * n_env] += 1.0f - (msum * (1.0f / 730.0f)) / mmax;
         k[CLKE_MON_N * n_env] += 1.0f;
         msum = 0.0f; mmax = -INFINITY;
     }
     k[CLKE_MON_SUM * n_env] = msum + v; k[CLKE_MON_MAX * n_env] = fmaxf(mmax, v);
-    k[CLKE_ALL_MAX * n_env] = fmaxf(k[CLKE_ALL_MAX * n_env], v);
+    k[CLKE_ALL_MAX * n_env] = fmaxf(s.amax, v);
+}
+
+CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, float v) {
+    KpiSeries s;
+    kpi_series_fetch(s, k, n_env);
+    kpi_series_apply(k, n_env, t, v, s);
 }
 
 // District series: control = out_env net; baseline = sum over buildings of the baseline plane (16 waves share the
@@ -994,8 +1028,12 @@ __global__ void __launch_bounds__(1024) cl_kpi_env_kernel(const StepArgs a) {
         float base = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) base += part[k][lane];
-        kpi_series_update(a.kpi_env + e, a.n_env, a.t, a.out_env[(long long)CLQ_NET * a.n_env + e]);
-        kpi_series_update(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + e, a.n_env, a.t, base);
+        KpiSeries sc, sb;                       // both series' accumulators first, then the stores (one round trip instead of ten)
+        kpi_series_fetch(sc, a.kpi_env + e, a.n_env);
+        kpi_series_fetch(sb, a.kpi_env + (long long)CLKE_PER_COND * a.n_env + e, a.n_env);
+        const float dnet = a.out_env[(long long)CLQ_NET * a.n_env + e];
+        kpi_series_apply(a.kpi_env + e, a.n_env, a.t, dnet, sc);
+        kpi_series_apply(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + e, a.n_env, a.t, base, sb);
     }
 }
 
@@ -1048,8 +1086,12 @@ __global__ void __launch_bounds__(1024) cl_kpi_kernel(const StepArgs a) {
         float base = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) base += part[k][lane];
-        kpi_series_update(a.kpi_env + e, a.n_env, a.t, a.out_env[(long long)CLQ_NET * a.n_env + e]);
-        kpi_series_update(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + e, a.n_env, a.t, base);
+        KpiSeries sc, sb;                       // both series' accumulators first, then the stores (one round trip instead of ten)
+        kpi_series_fetch(sc, a.kpi_env + e, a.n_env);
+        kpi_series_fetch(sb, a.kpi_env + (long long)CLKE_PER_COND * a.n_env + e, a.n_env);
+        const float dnet = a.out_env[(long long)CLQ_NET * a.n_env + e];
+        kpi_series_apply(a.kpi_env + e, a.n_env, a.t, dnet, sc);
+        kpi_series_apply(a.kpi_env + (long long)CLKE_PER_COND * a.n_env + e, a.n_env, a.t, base, sb);
     }
 }
 
