@@ -113,6 +113,14 @@ struct LstmArgs {
 // (`heat`: the delivered heating of this step, 0 without a heating plane -- loaded by the caller, early)
 CL_DEV void lstm_outputs(const LstmArgs& a, const float* __restrict__ W, const float* __restrict__ pre_t, long long off, long long plane,
                          float temp, float cool, float heat) {
+    // (the ten accumulators are fetched together, before the first store of this function: as `k[..] += ..` statements one after the
+    //  other every load waits for the store in front of it -- ten dependent round trips at the end of every wave)
+    float kc[CL_NKC];
+    if (a.kpi_comfort) {
+        const float* __restrict__ k = a.kpi_comfort + off;
+#pragma unroll
+        for (int p = 0; p < CL_NKC; ++p) kc[p] = k[p * plane];
+    }
     a.indoor_temp[off] = temp;
     if (a.comfort) {
         const float band_p = W[CLW_RW_BAND];
@@ -128,17 +136,19 @@ CL_DEV void lstm_outputs(const LstmArgs& a, const float* __restrict__ W, const f
         const float cd = occupied ? temp - pre_t[CLPRE_CSP] : 0.0f, hd = occupied ? temp - pre_t[CLPRE_HSP] : 0.0f;
         const bool hot = cd > band, cold = hd < -band;
         const float cmag = fabsf(fminf(hd, 0.0f)), hmag = fabsf(fmaxf(cd, 0.0f));
-        float* k = a.kpi_comfort + off;
-        k[CLKC_UNMET * plane] += (hot || cold) ? 1.0f : 0.0f;
-        k[CLKC_COLD * plane] += cold ? 1.0f : 0.0f;
-        k[CLKC_HOT * plane] += hot ? 1.0f : 0.0f;
-        k[CLKC_COLD_MIN * plane] = fminf(k[CLKC_COLD_MIN * plane], cmag);
-        k[CLKC_COLD_MAX * plane] = fmaxf(k[CLKC_COLD_MAX * plane], cmag);
-        k[CLKC_COLD_SUM * plane] += cmag;
-        k[CLKC_HOT_MIN * plane] = fminf(k[CLKC_HOT_MIN * plane], hmag);
-        k[CLKC_HOT_MAX * plane] = fmaxf(k[CLKC_HOT_MAX * plane], hmag);
-        k[CLKC_HOT_SUM * plane] += hmag;
-        k[CLKC_UNMET_OUTAGE * plane] += ((hot || cold) && pre_t[CLPRE_OUTAGE] != 0.0f) ? 1.0f : 0.0f;
+        kc[CLKC_UNMET] += (hot || cold) ? 1.0f : 0.0f;
+        kc[CLKC_COLD] += cold ? 1.0f : 0.0f;
+        kc[CLKC_HOT] += hot ? 1.0f : 0.0f;
+        kc[CLKC_COLD_MIN] = fminf(kc[CLKC_COLD_MIN], cmag);
+        kc[CLKC_COLD_MAX] = fmaxf(kc[CLKC_COLD_MAX], cmag);
+        kc[CLKC_COLD_SUM] += cmag;
+        kc[CLKC_HOT_MIN] = fminf(kc[CLKC_HOT_MIN], hmag);
+        kc[CLKC_HOT_MAX] = fmaxf(kc[CLKC_HOT_MAX], hmag);
+        kc[CLKC_HOT_SUM] += hmag;
+        kc[CLKC_UNMET_OUTAGE] += ((hot || cold) && pre_t[CLPRE_OUTAGE] != 0.0f) ? 1.0f : 0.0f;
+        float* __restrict__ k = a.kpi_comfort + off;
+#pragma unroll
+        for (int p = 0; p < CL_NKC; ++p) k[p * plane] = kc[p];
     }
 }
 
