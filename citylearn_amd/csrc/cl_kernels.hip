@@ -698,6 +698,15 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             float* kp = a.kpi_bldg + off;
             vload<VEC>(k_pos, kp + (long long)CLK_C_POS * plane); vload<VEC>(k_net, kp + (long long)CLK_C_NET * plane);
             vload<VEC>(k_em, kp + (long long)CLK_C_EMISSION * plane); vload<VEC>(k_cost, kp + (long long)CLK_C_COST * plane);
+            // ... and, in the same burst, the block's five env-independent sums (lane 0 of the block's first workgroup; they were five
+            // `+=` statements behind the stores below: five dependent round trips on every wave's way to the reduction)
+            const bool block_sums = lane == 0 && (blockIdx.x * TILE) % CL_ROW0_BLOCK == 0;
+            float b_pos = 0.0f, b_net = 0.0f, b_em = 0.0f, b_cost = 0.0f, b_exp = 0.0f;
+            if (block_sums) {
+                b_pos = kp[(long long)CLK_B_POS * plane]; b_net = kp[(long long)CLK_B_NET * plane];
+                b_em = kp[(long long)CLK_B_EMISSION * plane]; b_cost = kp[(long long)CLK_B_COST * plane];
+                b_exp = kp[(long long)CLK_EXPECTED_ALL * plane];
+            }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 k_pos[i] += fmaxf(o_net[i], 0.0f); k_net[i] += o_net[i];
@@ -707,16 +716,13 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             pstore<VEC, NT>(kp + (long long)CLK_C_EMISSION * plane, k_em); pstore<VEC, NT>(kp + (long long)CLK_C_COST * plane, k_cost);
             const float c_ns0 = (quirk && a.t == 0) ? 3.0f * R.nsl : R.nsl;
             const float base = fmaf(c_ns0, B.r, R.sol);                          // the step's net with the battery term left out
-            if (lane == 0) {
-                lds[(size_t)a.nw * NQ * TILE + b] = base;                          // for the district baseline series (below)
-                if ((blockIdx.x * TILE) % CL_ROW0_BLOCK == 0) {
-                    float* k0 = a.kpi_bldg + off;                                  // (lane 0: off = this building's row at the block's first env)
-                    k0[CLK_B_POS * plane] += fmaxf(base, 0.0f);
-                    k0[CLK_B_NET * plane] += base;
-                    k0[CLK_B_EMISSION * plane] += fmaxf(base * R.carbon, 0.0f);
-                    k0[CLK_B_COST * plane] += fmaxf(base * R.price, 0.0f);
-                    k0[CLK_EXPECTED_ALL * plane] += R.nsl;
-                }
+            if (lane == 0) lds[(size_t)a.nw * NQ * TILE + b] = base;               // for the district baseline series (below)
+            if (block_sums) {                                                      // (lane 0: kp = this building's row at the block's first env)
+                kp[(long long)CLK_B_POS * plane] = b_pos + fmaxf(base, 0.0f);
+                kp[(long long)CLK_B_NET * plane] = b_net + base;
+                kp[(long long)CLK_B_EMISSION * plane] = b_em + fmaxf(base * R.carbon, 0.0f);
+                kp[(long long)CLK_B_COST * plane] = b_cost + fmaxf(base * R.price, 0.0f);
+                kp[(long long)CLK_EXPECTED_ALL * plane] = b_exp + R.nsl;
             }
         }
         if constexpr (OBS) {
