@@ -1484,7 +1484,9 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     const bool det = dims->flags & CLD_WRITE_DETAIL;
     // streaming KPIs of thermal / outage districts (and of any district stepped with detail planes) inside the step launch:
     // cl_step_full_kpi_kernel (cl_full.h); cl_tuning.kpi_passes = 1 keeps the separate cl_kpi_kernel pass (A/B), 2 the two round-1 passes
-    const bool kpi_full = (dims->flags & CLD_KPI) && full && !flex && !f64 && a.n_chunks == 1 && vec == 1 && tun.full_variant != 1 && tun.kpi_passes == 0;
+    // (up to 128 buildings: their baselines of one env tile sit in LDS, 256 B per building)
+    const bool kpi_full = (dims->flags & CLD_KPI) && full && !flex && !f64 && a.n_chunks == 1 && vec == 1 && tun.full_variant != 1 && tun.kpi_passes == 0 &&
+                          dims->n_bldg <= 128;
     // ... whose waves should all be resident at once (16 per CU at its 119 registers): as many waves per workgroup as that allows, at least
     // two (9 x 65 536: four waves 18.8 us, the step-only default of five -- two generations -- 23.6 us; profiles/r03_kpi_in_step_probe.log)
     if (kpi_full && !tun.nw) {

@@ -233,3 +233,26 @@ def test_generic_kernel_agrees_with_the_matrix_core_kernel(name, monkeypatch):
         ref = g.ref['reward_ComfortReward'][t]
         worst_r = max(worst_r, float(np.max(np.abs(rr[:, 0] - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
     assert worst_t < 2e-3 and worst_r < 1.0, (worst_t, worst_r)
+
+
+def test_two_demand_model_without_its_flag_is_poisoned_not_wrong():
+    """`CLD_LSTM_TWO_DEMANDS` selects the matrix-core instantiation that reads the third input ring; a caller that packs a both-demand model
+    (lstm_w[CLW_DEM2] != 0) and forgets the flag gets NaN for that building's temperature -- and the right values for the others."""
+    from citylearn_amd import abi, dynamics
+    g = golden('g2023_both')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E = 64
+    eng = StepEngine(tab, E, detail=True)
+    good, bad = LSTMStage(spec, tab, eng), LSTMStage(spec, tab, eng)
+    assert good.dims.flags & abi.CLD_LSTM_TWO_DEMANDS and good.generic is None
+    bad.dims.flags &= ~abi.CLD_LSTM_TWO_DEMANDS
+    cool = torch.from_numpy(g.ref['cool_dem']).cuda()
+    heat = torch.from_numpy(g.ref['heat_dem']).cuda()
+    for t in range(16):
+        c, h = cool[t][:, None].expand(-1, E).contiguous(), heat[t][:, None].expand(-1, E).contiguous()
+        tg, tb = good.step(t, c, h).clone(), bad.step(t, c, h).clone()
+    two = (good.lstm_w[:, dynamics.DEM2] != 0).cpu().numpy()
+    assert two.tolist() == [True, False, False]
+    assert torch.isnan(tb[0]).all() and torch.isfinite(tg).all()
+    assert torch.equal(tb[1:], tg[1:])
