@@ -446,7 +446,10 @@ constexpr int CL_LP_WORDS = (CLP_F_LAST - CLP_F_FIRST + 1) + CL_NF;      // 64 +
 // (19.5 us at best); wave specialisation -- two extra waves per workgroup that fetch the accumulators at entry, meet the step waves at the
 // reduction's barrier, where those have parked net / baseline / expected / served in LDS, and add and store while the step waves reduce:
 // 22.7 - 34 us (every accumulator store of a workgroup leaves after its slowest step wave, nothing overlaps them any more); plain instead of
-// non-temporal accumulator stores (they are read back by the next step): no difference at 65 536 or 262 144 envs.
+// non-temporal accumulator stores (they are read back by the next step): no difference at 65 536 or 262 144 envs; two envs per lane
+// (576-thread workgroups, three waves per SIMD, 168 registers with a few spills; the vector ALUs are ~40 % busy at one env per lane
+// and the pack halves their work): bit-identical and 24 - 29 us against 17.7 us at 9 x 65 536, slower at every size tried -- the
+// waves in flight, not the instruction count, carry this kernel.
 template <int VEC, bool DETAIL, bool LP, bool NT, bool KPI>
 CL_DEV void full_step_body(const StepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC], then (LP) [buildings of the workgroup][CL_LP_WORDS] or (KPI) [n_bldg][64*VEC] baselines
