@@ -33,7 +33,9 @@ as timed by oracle/ref_harness/time_reference.py on the host named there (/root/
 Test hooks (environment): CL_BENCH_OVERSUBSCRIBE=1 maps rank r to device r mod (visible devices) so that `--gpus 2` can be
 exercised on a 1-GPU box (the ranks then share a GPU: control plane over gloo because RCCL refuses two ranks per device, and the
 line says `"oversubscribed": true` -- not a scaling measurement); CL_BENCH_DRY_RUN=1 skips all GPU work (launcher, rendezvous and
-aggregation on CPU: tests/test_distributed.py); CL_BENCH_FORCE_DIST=1 brings up the process group even for one rank.
+aggregation on CPU: tests/test_distributed.py); CL_BENCH_FORCE_DIST=1 brings up the process group even for one rank; CL_BENCH_CONTROL=nccl|gloo
+picks the control plane's backend (default: RCCL with one rank per GPU; if RCCL cannot come up the barrier falls back to gloo and the line says
+so in `control_fallback` -- CL_BENCH_STRICT_RCCL=1 makes that fatal instead).
 """
 from __future__ import annotations
 
@@ -428,8 +430,9 @@ def run_rank(args):
     device = f'cuda:{dev_index}'
     dist, backend = None, None
     if world > 1 or os.environ.get('CL_BENCH_FORCE_DIST'):
-        backend = 'gloo' if oversubscribed else 'nccl'        # RCCL refuses two ranks on one device
+        backend = os.environ.get('CL_BENCH_CONTROL') or ('gloo' if oversubscribed else 'nccl')        # RCCL refuses two ranks on one device
         dist = init_control_plane(rank, world, device, backend)
+        backend = dist.control_backend                        # 'gloo' also when RCCL could not come up (the line then carries `control_fallback`)
     ctl_device = device if backend == 'nccl' else 'cpu'
 
     tuning = {k[len('CL_TUNE_'):].lower(): int(v) for k, v in os.environ.items() if k.startswith('CL_TUNE_')}   # e.g. CL_TUNE_ENVMAJOR=2
@@ -494,7 +497,7 @@ def run_rank(args):
                        'launch': 'hipGraph replay' if use_graph else 'eager', 'reward': 'ComfortReward' if cfg == 'C3' else 'RewardFunction',
                        'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)',
                        **({'k_steps_per_launch': 24, 'step': 'one fused 24-step launch'} if cfg == 'C5' else {})},
-            'ranks': world, 'world_size_seen': world if dist is None else dist.get_world_size(), 'control_backend': backend,
+            'ranks': world, 'world_size_seen': world if dist is None else dist.get_world_size(), 'control_backend': backend, **({'control_fallback': dist.control_fallback} if getattr(dist, 'control_fallback', None) else {}),
             'rank_ms_per_step': [s / args.steps * 1e3 for s in per_rank],
             'rep_ms_per_step': [w / args.steps * 1e3 for w in walls],
             'roofline': roof,

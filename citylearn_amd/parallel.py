@@ -130,6 +130,8 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
     import torch
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if world == 1:
+        os.environ.setdefault('MASTER_PORT', str(free_port()))          # (a lone rank has nobody to agree with; launchers set it for the others)
     if backend is None:
         backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
     sys.stdout.flush()
@@ -137,14 +139,39 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
     os.dup2(2, 1)
     try:
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+            try:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+                dist.barrier()
+                torch.cuda.synchronize()
+            except Exception as exc:                  # noqa: BLE001 -- whatever RCCL raises (it fails symmetrically: every rank lands here)
+                # The step path has no collective: the group only carries the benchmark's barrier and a MAX over ranks.  If RCCL cannot
+                # come up on this node (IPC mode, fabric, driver), those two travel over gloo instead and the line says so -- a scaling
+                # run must not be lost to the control plane.  CL_BENCH_STRICT_RCCL=1 keeps the failure fatal.
+                if os.environ.get('CL_BENCH_STRICT_RCCL') == '1':
+                    raise
+                print(f'[rank {rank}] RCCL control plane failed ({type(exc).__name__}: {exc}); falling back to gloo', file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:                     # noqa: BLE001
+                    pass
+                os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)      # a fresh rendezvous store
+                backend = 'gloo'
+                dist.init_process_group('gloo', rank=rank, world_size=world)
+                dist.barrier()
+                dist.control_fallback = f'{type(exc).__name__}: {exc}'[:300]
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)
-        dist.barrier()
-        if backend == 'nccl':
-            torch.cuda.synchronize()
+            dist.barrier()
     finally:
         sys.stdout.flush()
+        try:
+            # RCCL's banner goes through C stdio, which buffers when stdout is a pipe or a file: without this flush it would come out at
+            # process exit, on the restored descriptor -- after the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                             # noqa: BLE001
+            pass
         os.dup2(saved, 1)
         os.close(saved)
+    dist.control_backend = backend                    # what actually carries the barrier ('nccl' = RCCL, or 'gloo')
     return dist

@@ -158,6 +158,26 @@ def test_launcher_propagates_a_failing_rank_and_stops_the_others():
     assert rc == 124
 
 
+def test_control_plane_falls_back_to_gloo_when_rccl_cannot_come_up():
+    """`init_control_plane(.., 'nccl')` on a box where RCCL cannot build its communicator (here: no GPU at all; on a GPU node: IPC mode,
+    fabric, two ranks on one device): every rank lands in the same `except`, the barrier and the MAX over ranks travel over gloo on a fresh
+    rendezvous, and the caller can tell (`control_backend`, `control_fallback`).  CL_BENCH_STRICT_RCCL=1 keeps the failure fatal."""
+    from citylearn_amd.parallel import launch_ranks
+    code = ("import os, sys\n"
+            f"sys.path.insert(0, {str(ROOT)!r})\n"
+            "from citylearn_amd.parallel import init_control_plane, reduce_max_seconds\n"
+            "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+            "d = init_control_plane(r, w, 'cuda:0', 'nccl')\n"
+            "assert d.control_backend == 'gloo' and d.control_fallback, d.control_backend\n"
+            "m = reduce_max_seconds(1.0 + r, d, 'cpu')\n"
+            "d.barrier(); d.destroy_process_group()\n"
+            "print('max', m, flush=True)\n")
+    rc, out0 = launch_ranks([sys.executable, '-c', code], 2, timeout=240)
+    assert rc == 0 and out0.strip().endswith('max 2.0'), out0
+    rc, _ = launch_ranks([sys.executable, '-c', code], 2, timeout=240, extra_env={'CL_BENCH_STRICT_RCCL': '1'})
+    assert rc not in (0, 124)
+
+
 def test_bench_uses_only_counters_collected_on_the_kernel_it_launched(tmp_path, monkeypatch):
     """`bench._pmc_traffic`: a PMC summary under profiles/ feeds `roofline.traffic` only if its `_kernel.kernel` names the kernel the run
     launched (VERDICT r02 weak #8: stale counters beside a newer kernel); `scripts/check_profiles.py` is the same check for a profile run."""

@@ -61,3 +61,20 @@ def test_thermal_kpi_line_runs_the_kpis_inside_the_step_launch():
     r = out['roofline']
     assert out['config']['name'] == 'T9' and r['bound'] == 'hbm' and r['kernel'] == 'cl_step_full_kpi_kernel<true>', r['kernel']
     assert 140.0 < r['algorithmic_bytes_per_unit'] < 160.0 and 0.3 < r['frac'] < 1.0
+
+
+def test_rccl_control_plane_keeps_stdout_to_the_one_line():
+    """A lone rank with the process group forced up (CL_BENCH_FORCE_DIST): the control plane is RCCL -- the communicator really is
+    created on this GPU -- and RCCL's banner, which goes through buffered C stdio, does not end up on stdout behind the JSON line."""
+    out = _bench('--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-streaming', env={'CL_BENCH_FORCE_DIST': '1'})      # (_bench asserts the single line)
+    assert out['control_backend'] == 'nccl' and 'control_fallback' not in out and out['world_size_seen'] == 1
+
+
+def test_control_plane_falls_back_to_gloo_when_rccl_refuses():
+    """Two ranks on ONE device with RCCL forced (it refuses: "Duplicate GPU detected", in every rank): the barrier and the MAX over ranks
+    move to gloo, the run completes, and the line says why."""
+    out = _bench('--gpus', '2', '--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-streaming',
+                 env={'CL_BENCH_OVERSUBSCRIBE': '1', 'CL_BENCH_CONTROL': 'nccl'})
+    assert out['ranks'] == 2 and out['world_size_seen'] == 2 and out['control_backend'] == 'gloo'
+    assert 'Duplicate GPU' in out['control_fallback'] or 'NCCL' in out['control_fallback'], out['control_fallback']
+    assert len(out['rank_ms_per_step']) == 2
