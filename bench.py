@@ -413,6 +413,11 @@ def run_rank(args):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if rank != 0:
+        # stdout belongs to rank 0's one JSON line: an external launcher (torch.distributed.run) merges every rank's stdout into its own,
+        # and libraries print there (RCCL's banner).  The other ranks' descriptor 1 goes to stderr for the life of the process.
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if os.environ.get('CL_BENCH_DRY_RUN'):
         return dry_run_rank(args, rank, world)
 

@@ -137,6 +137,24 @@ def test_bench_spawns_its_own_ranks():
     assert out['value'] == one['value']          # twice the units in twice the (synthetic) time
 
 
+def test_bench_under_torchrun_leaves_one_line_on_the_merged_stdout():
+    """What the driver runs for N > 1: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`.  The launcher merges the
+    ranks' stdout; only rank 0 may write there (the other ranks park descriptor 1 on stderr) -- here with the dry-run rank body."""
+    import json
+    import subprocess
+    from citylearn_amd.parallel import free_port
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    e['CL_BENCH_DRY_RUN'] = '1'
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(free_port()), str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5'],
+                       env=e, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['world_size_seen'] == 2 and out['rank_ms_per_step'] == [1.0, 2.0]
+
+
 def test_bench_under_an_external_launcher_is_one_rank():
     """With RANK / WORLD_SIZE in the environment (torch.distributed.run) bench.py must not spawn anything: WORLD_SIZE has to match --gpus."""
     p = _bench('--gpus', '2', '--steps', '20', '--warmup', '5', env={'CL_BENCH_DRY_RUN': '1', 'RANK': '0', 'LOCAL_RANK': '0', 'WORLD_SIZE': '4',
