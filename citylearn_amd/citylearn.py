@@ -308,6 +308,27 @@ class CityLearnEnv(_GymEnv):
         B = len(self.district_spec.buildings)
         return np.array(rows, dtype='float32').reshape(len(rows), B)
 
+    def _baseline_series(self) -> np.ndarray:
+        """``[K, n_bldg]`` `net_electricity_consumption_without_storage(_and_partial_load)` as the reference computes it NOW, at the env's
+        current time step.  The device books the partial-load heating difference of every step with the heating COP of the episode's last
+        row -- what the reference's property gives once the episode is over, because it reads `outdoor_dry_bulb_temperature[self.time_step]`,
+        ONE temperature for the whole series (sic, building.py:2893-2898).  Called mid-episode the reference therefore converts every past
+        step with the COP of the step the env stands at; the difference is linear in the stored series, so it is applied here."""
+        base = self._history_array('base_net')
+        tab = self._tables
+        K, last = self._t, tab.n_steps - 1
+        t_eval = min(K, last)
+        if K == 0 or t_eval == last:
+            return base
+        flags = tab.params[:, abi.CLP_FLAGS]
+        heat_dem = self._history_array('heat_dem')
+        out = base.astype(np.float64)
+        for i, b in enumerate(self.district_spec.buildings):
+            if b.is_dynamics and (int(flags[i]) & abi.CLF_HEAT_IS_HP):
+                diff = tab.ts[:K, i, abi.CLT_HEAT_DEM].astype(np.float64) - heat_dem[:, i]
+                out[:, i] += diff * (float(tab.ts[t_eval, i, abi.CLT_ICOP_HEAT]) - float(tab.ts[last, i, abi.CLT_ICOP_HEAT]))
+        return out.astype('float32')
+
     # ---- reset / step ----------------------------------------------------------------------------------------
     def reset(self, seed: int = None, options: Mapping[str, Any] = None) -> Tuple[List[List[float]], dict]:
         import torch
@@ -506,7 +527,7 @@ class CityLearnEnv(_GymEnv):
             control = '' if control_condition is None else suffix(control_condition)
             baseline = ('_without_storage_and_partial_load' if dyn else '_without_storage') if baseline_condition is None else suffix(baseline_condition)
             series = (self._condition_series(control), self._condition_series(baseline), control)
-        return evaluate_district(self.district_spec, self._tables, self._t, h('net'), h('base_net'), h('cost'), h('emission'),
+        return evaluate_district(self.district_spec, self._tables, self._t, h('net'), self._baseline_series(), h('cost'), h('emission'),
                                  h('expected'), h('served'), np.array(self._hist['d_net'], dtype=np.float64), comfort_band,
                                  indoor_temp=h('indoor_temp'), condition_series=series)
 
@@ -517,7 +538,7 @@ class CityLearnEnv(_GymEnv):
             if 'partial_load' in suffix and not self.district_spec.buildings[only].is_dynamics:
                 raise AttributeError(f"building {self.district_spec.buildings[only].name} has no attribute 'net_electricity_consumption{suffix}' (not a dynamics building)")
             key = {'': 'net', '_without_storage': 'net_ws', '_without_storage_and_pv': 'net_ws'}.get(suffix, 'base_net')
-            out = self._history_array(key)[:, only]
+            out = (self._baseline_series() if key == 'base_net' else self._history_array(key))[:, only]
             return out - self._tables.ts[:self._t, only, abi.CLT_SOLAR].astype(np.float32) if suffix.endswith('_and_pv') else out
         h = self._history_array
         K = self._t
@@ -531,7 +552,7 @@ class CityLearnEnv(_GymEnv):
             if not dynamics.all():
                 name = next(b.name for b in self.district_spec.buildings if not b.is_dynamics)
                 raise AttributeError(f"building {name} has no attribute 'net_electricity_consumption{suffix}' (not a dynamics building)")
-            out = h('base_net')
+            out = self._baseline_series()
         else:
             raise ValueError(f'unknown evaluation condition {suffix!r}')
         return out - solar if suffix.endswith('_and_pv') else out

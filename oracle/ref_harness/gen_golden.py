@@ -508,6 +508,43 @@ def run_conditions(name: str):
     print(f'{name}: kpi_conditions.json with {len(pairs)} condition pairs')
 
 
+MID_FIXTURES = {'g2023_heat': 120, 'g2023_p2': 200}
+
+
+def run_mid_evaluate(name: str, step: int):
+    """`kpi_mid.npz`: `evaluate()` called MID-EPISODE, after `step` steps of the fixture's action sequence.  On a district with controlled
+    heat-pump heating the reference converts the partial-load heating difference of EVERY past step with the COP of the time step the env
+    stands at when evaluate() is called (`outdoor_dry_bulb_temperature[self.time_step]`, building.py:2893-2898), so the table is not a
+    prefix property of the end-of-episode one."""
+    dataset, rows, K, seed, gz, env_kwargs = FIXTURES[name]
+    out_dir = GOLDEN / name
+    ref_env.setup_reference()
+    from citylearn.citylearn import CityLearnEnv
+    import random as py_random
+    py_random.seed(seed)
+    np.random.seed(seed)
+    env = CityLearnEnv(str(dataset_dir(name) / 'schema.json'))
+    sizes = [b.action_space.shape[0] for b in env.buildings]
+    actions = np.load(out_dir / 'reference.npz')['actions']
+    env.reset()
+    for t in range(step):
+        al = [float(x) for x in actions[t]]
+        if env.central_agent:
+            acts = [al]
+        else:
+            acts, p = [], 0
+            for n in sizes:
+                acts.append(al[p:p + n]); p += n
+        env.step(acts)
+    assert env.time_step == step
+    kpis = env.evaluate()
+    kpis = kpis[kpis['value'].notnull()]
+    np.savez_compressed(out_dir / 'kpi_mid.npz', step=np.array(step),
+                        kpi_names=np.array([f'{r.level}|{r.name}|{r.cost_function}' for r in kpis.itertuples()]),
+                        kpi_values=kpis['value'].to_numpy(dtype='float64'))
+    print(f'{name}: kpi_mid.npz after {step} steps, {len(kpis)} values')
+
+
 OBS_FIXTURES = {'g2022_all': 200, 'g2020_cz1': 200, 'g2023_p2': 300, 'g2020_15min': 120, 's_baeda': 95, 's_2021': 95,
                 's_2020_cz3': 95, 's_2023_p1': 95, 's_2023_p3': 95, 'g2022_evs': 239, 'g_cc_demo': 167, 'g_evs_15min': 119, 'g_evs_central': 119,
                 'g_evs_noise': 119}
@@ -522,6 +559,8 @@ if __name__ == '__main__':
         kind, name = args[1], args[2]
         if kind == 'conditions':
             run_conditions(name)
+        elif kind == 'mid_evaluate':
+            run_mid_evaluate(name, MID_FIXTURES[name])
         elif kind == 'observations':
             run_observations(name, OBS_FIXTURES.get(name))
         else:
@@ -531,6 +570,8 @@ if __name__ == '__main__':
         jobs = [('conditions', n) for n in (args[1:] or ['g2022_all', 'g2023_p2'])]
     elif args and args[0] == 'observations':
         jobs = [('observations', n) for n in (args[1:] or list(OBS_FIXTURES))]
+    elif args and args[0] == 'mid_evaluate':
+        jobs = [('mid_evaluate', n) for n in (args[1:] or list(MID_FIXTURES))]
     else:
         names = args or list(FIXTURES)
         jobs = [('reference', n) for n in names] + [('observations', n) for n in names if n in OBS_FIXTURES]

@@ -256,3 +256,28 @@ def test_two_demand_model_without_its_flag_is_poisoned_not_wrong():
     assert two.tolist() == [True, False, False]
     assert torch.isnan(tb[0]).all() and torch.isfinite(tg).all()
     assert torch.equal(tb[1:], tg[1:])
+
+
+@pytest.mark.parametrize('name', ['g2023_heat', 'g2023_p2'])
+def test_evaluate_called_mid_episode(name):
+    """`CityLearnEnv.evaluate()` in the middle of an episode against the reference doing the same (`kpi_mid.npz`, generated by
+    `oracle/ref_harness/gen_golden.py mid_evaluate`).  With controlled heat-pump heating (g2023_heat) the reference converts the partial-load
+    heating difference of every past step with the COP of the step it stands at (building.py:2893-2898): the cost KPIs of the baseline move."""
+    from citylearn_amd.citylearn import CityLearnEnv
+    g = golden(name)
+    mid = np.load(g.dir / 'kpi_mid.npz')
+    step = int(mid['step'])
+    env = CityLearnEnv(g.schema_path)
+    for t in range(step):
+        env.step([[float(x) for x in g.ref['actions'][t]]])
+    frame = env.evaluate()
+    mine = {f'{r.level}|{r.name}|{r.cost_function}': r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
+    ref = dict(zip([str(x) for x in mid['kpi_names']], mid['kpi_values']))
+    assert len(ref) >= 40
+    for k, v in ref.items():
+        np.testing.assert_allclose(mine[k], v, rtol=5e-3, atol=2e-3, err_msg=k)
+    if name == 'g2023_heat':
+        # ... and the correction is what makes it so: with the series as the device booked it (episode-end COP) some baseline KPI is off
+        env._baseline_series = lambda: env._history_array('base_net')
+        raw = {f'{r.level}|{r.name}|{r.cost_function}': r.value for r in env.evaluate().itertuples() if r.value is not None and not np.isnan(r.value)}
+        assert max(abs(raw[k] - v) / (2e-3 + 5e-3 * abs(v)) for k, v in ref.items()) > 1.0
