@@ -614,6 +614,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
 // two tiles give 18 items to 16 waves -- SIMD loads 5, 5, 4, 4, one workgroup per CU, all resident at once, and only two waves walk
 // two items.  Every item parks its four district partials in its own LDS row; the sums are then formed per (tile, quantity, env)
 // in building order (the reference's order, citylearn.py:1909-1918).
+// (Round 3, tried: a wave that walks two items fetching the second item's planes before it stores the first one's -- the stores otherwise
+//  fence the loads behind them.  102 instead of 77 registers and SLOWER: 9 x 65 536 8.44 vs 7.86 us, 9 x 262 144 29.9 vs 29.2 us.)
 template <int VEC, int WPE, bool NT>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_tp_kernel(const StepArgs a, const int tp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [tp * n_bldg][NQ][64*VEC], then [tp][64*VEC]
