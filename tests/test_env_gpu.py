@@ -67,8 +67,16 @@ def test_env_matches_reference_api_and_rewards(name):
     dyn = env.buildings[0].spec.is_dynamics
     base_name = 'net_electricity_consumption_without_storage' + ('_and_partial_load' if dyn else '')
     base = np.stack([getattr(b, base_name) for b in env.buildings], axis=1)
-    np.testing.assert_allclose(base, g.ref['base_net'][:K], rtol=1e-4, atol=2e-4)
-    np.testing.assert_allclose(getattr(env, base_name), g.ref['base_net'][:K].sum(axis=1), rtol=1e-4, atol=2e-3)
+    # (the fixture's series was read after the reference's episode had ended.  On a district with controlled heat-pump heating the property
+    #  read MID-episode differs -- the reference converts every past step's partial-load heating difference with the COP of the step it
+    #  stands at, building.py:2893-2898; `test_evaluate_called_mid_episode` pins that -- so there the device-booked series is compared)
+    booked = env._history_array('base_net')
+    moved = not np.allclose(base, booked, rtol=1e-6, atol=1e-6)
+    assert moved == (name == 'g2023_heat')
+    np.testing.assert_allclose(booked, g.ref['base_net'][:K], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(getattr(env, base_name), base.astype(np.float64).sum(axis=1), rtol=1e-5, atol=1e-4)
+    if not moved:
+        np.testing.assert_allclose(getattr(env, base_name), g.ref['base_net'][:K].sum(axis=1), rtol=1e-4, atol=2e-3)
     b0 = env.buildings[0]
     no_pv = getattr(b0, base_name + '_and_pv')
     np.testing.assert_allclose(no_pv, base[:, 0] - b0.solar_generation, rtol=1e-6, atol=1e-5)
