@@ -502,7 +502,7 @@ def run_rank(args):
                        'launch': 'hipGraph replay' if use_graph else 'eager', 'reward': 'ComfortReward' if cfg == 'C3' else 'RewardFunction',
                        'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)',
                        **({'k_steps_per_launch': 24, 'step': 'one fused 24-step launch'} if cfg == 'C5' else {})},
-            'ranks': world, 'world_size_seen': world if dist is None else dist.get_world_size(), 'control_backend': backend, **({'control_fallback': dist.control_fallback} if getattr(dist, 'control_fallback', None) else {}),
+            'ranks': world, 'world_size_seen': world if dist is None else dist.get_world_size(), 'control_backend': backend, **({'control_fallback': dist.control_fallback} if dist is not None and dist.control_fallback else {}),
             'rank_ms_per_step': [s / args.steps * 1e3 for s in per_rank],
             'rep_ms_per_step': [w / args.steps * 1e3 for w in walls],
             'roofline': roof,

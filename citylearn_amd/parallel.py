@@ -121,9 +121,21 @@ def launch_ranks(argv: Sequence[str], world: int, timeout: Optional[float] = Non
     return rc, out0
 
 
-def init_control_plane(rank: int, world: int, device=None, backend: Optional[str] = None):
+class ControlPlane:
+    """`torch.distributed` (every attribute is forwarded) + what `init_control_plane` settled on: `control_backend` ('nccl' = RCCL, or 'gloo')
+    and `control_fallback` (why RCCL was given up, else None)."""
+
+    def __init__(self, dist, backend: str, fallback: Optional[str] = None):
+        self._dist, self.control_backend, self.control_fallback = dist, backend, fallback
+
+    def __getattr__(self, name):
+        return getattr(self._dist, name)
+
+
+def init_control_plane(rank: int, world: int, device=None, backend: Optional[str] = None) -> ControlPlane:
     """Process group for the benchmark's barrier + timing reductions.  ``backend``: 'nccl' (RCCL over xGMI, one rank per GPU),
-    'gloo' (ranks sharing a device, or CPU); default: nccl when `device` is a GPU.  Returns ``torch.distributed``.
+    'gloo' (ranks sharing a device, or CPU); default: nccl when `device` is a GPU.  Returns a `ControlPlane` (``torch.distributed`` + the
+    backend that ended up carrying the barrier).
 
     RCCL prints a version banner on STDOUT when the communicator comes up; stdout is parked on stderr meanwhile so that it
     carries nothing but the caller's own output."""
@@ -137,6 +149,7 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
+    fallback = None
     try:
         if backend == 'nccl':
             try:
@@ -158,7 +171,7 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
                 backend = 'gloo'
                 dist.init_process_group('gloo', rank=rank, world_size=world)
                 dist.barrier()
-                dist.control_fallback = f'{type(exc).__name__}: {exc}'[:300]
+                fallback = f'{type(exc).__name__}: {exc}'[:300]
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)
             dist.barrier()
@@ -173,5 +186,4 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
             pass
         os.dup2(saved, 1)
         os.close(saved)
-    dist.control_backend = backend                    # what actually carries the barrier ('nccl' = RCCL, or 'gloo')
-    return dist
+    return ControlPlane(dist, backend, fallback)
