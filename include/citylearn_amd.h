@@ -407,7 +407,10 @@ int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, float* kp
  * CLD_LSTM_F16 in dims->flags, two f16 terms (the first 6144 words of each building's block) -- and laid out as MFMA A-operand
  * fragments (dynamics.pack_lstm_split).  When given, the recurrent products run on the 16-bit matrix cores with split operands
  * (bf16 x 3: dropped terms <= 2^-24 |W||h|; f16 x 2: <= 3 * 2^-22 |W||h| at half the matrix-pipe time; csrc/cl_lstm.h); NULL selects
- * the exact f32-MFMA kernel. */
+ * the exact f32-MFMA kernel.
+ * A district in which a two-layer model of <= 16 units takes BOTH demands (lstm_w[CLW_DEM2] != 0: delivered heating as a third
+ * env-dependent input, its ring in rows 24-35 of `hist`) needs CLD_LSTM_TWO_DEMANDS in dims->flags and `heat_dem`; without the flag that
+ * building's indoor_temp is NaN (loud, not wrong), the other buildings are unaffected. */
 #define CL_LSTM_NWB 9216
 int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* lstm_wb, const float* dyn_pre, const float* cool_dem,
                      const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,
