@@ -166,6 +166,18 @@ class Runner:
                 self.run(i, c)
 
 
+def _barrier(dist):
+    """The bracket's barrier, enqueued on the DEFAULT stream -- never on the stream the graphs are captured on.  torch runs a blocking
+    collective on the caller's current stream and its watchdog thread keeps polling the collective's end event for a while after it has
+    completed; HIP refuses `hipEventQuery` on an event whose last-recorded stream is capturing (hipErrorCapturedEvent), the watchdog
+    throws and aborts the process.  Seen as 1 abort in ~10 lone-rank RCCL runs when the barrier shared the launch stream with the
+    captures that follow it (`gpurun` runs 36 / 37 of round 3); with gloo there is no such event, which is why no earlier test saw it."""
+    import torch
+    with torch.cuda.stream(torch.cuda.default_stream()):
+        dist.barrier()
+    torch.cuda.default_stream().synchronize()
+
+
 def timed_reps(runner: Runner, reset_fn, warmup: int, steps: int, reps: int, dist, kernel_steps: int):
     """`reps` x (exactly `steps` steps between barrier + synchronize): per-repetition (wall seconds, HIP-event seconds), and the
     kernel time per step from HIP events around `kernel_steps` consecutive steps behind a lead-in chunk."""
@@ -182,7 +194,7 @@ def timed_reps(runner: Runner, reset_fn, warmup: int, steps: int, reps: int, dis
         stream.synchronize()
         for _ in range(reps):
             if dist is not None:
-                dist.barrier()
+                _barrier(dist)
             torch.cuda.synchronize()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
@@ -193,7 +205,7 @@ def timed_reps(runner: Runner, reset_fn, warmup: int, steps: int, reps: int, dis
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0          # this rank's K steps, synchronize to synchronize; the line reports the MAX over ranks
             if dist is not None:
-                dist.barrier()                       # the closing barrier of the bracket: after the clock is read -- a 30 us RCCL barrier inside
+                _barrier(dist)                       # the closing barrier of the bracket: after the clock is read -- a 30 us RCCL barrier inside
                                                      # a 20-step region would bill every rank 1.5 us per step for the collective's own latency
             out.append((wall, ev0.elapsed_time(ev1) / 1e3))
         # Kernel duration for the roofline: HIP events on the launch stream around `kernel_steps` consecutive steps of the same loop
