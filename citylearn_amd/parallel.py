@@ -167,9 +167,13 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
                     dist.destroy_process_group()
                 except Exception:                     # noqa: BLE001
                     pass
-                os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)      # a fresh rendezvous store
+                # a fresh rendezvous store on the next port, hosted by rank 0 itself: under torch.distributed.run the env:// store lives in
+                # the launcher's agent (TORCHELASTIC_USE_AGENT_STORE) and nobody would serve another port
+                from datetime import timedelta
+                port = int(os.environ.get('MASTER_PORT', '29500')) + 1
+                store = dist.TCPStore(os.environ['MASTER_ADDR'], port, world, rank == 0, timeout=timedelta(seconds=180))
                 backend = 'gloo'
-                dist.init_process_group('gloo', rank=rank, world_size=world)
+                dist.init_process_group('gloo', store=store, rank=rank, world_size=world)
                 dist.barrier()
                 fallback = f'{type(exc).__name__}: {exc}'[:300]
         else:

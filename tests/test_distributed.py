@@ -194,6 +194,14 @@ def test_control_plane_falls_back_to_gloo_when_rccl_cannot_come_up():
     assert rc == 0 and out0.strip().endswith('max 2.0'), out0
     rc, _ = launch_ranks([sys.executable, '-c', code], 2, timeout=240, extra_env={'CL_BENCH_STRICT_RCCL': '1'})
     assert rc not in (0, 124)
+    # ... and under torch.distributed.run, whose env:// store lives in the launcher's agent: the fallback has to host its own store
+    import subprocess
+    from citylearn_amd.parallel import free_port
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(free_port()), '--no-python', sys.executable, '-c', code],
+                       env=e, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.count('max 2.0') == 2, (p.stdout[-500:], p.stderr[-1500:])
 
 
 def test_bench_uses_only_counters_collected_on_the_kernel_it_launched(tmp_path, monkeypatch):
