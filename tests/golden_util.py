@@ -12,7 +12,9 @@ PACKAGE_DATA = {'g2022_all': _DATA / 'citylearn_challenge_2022_phase_all_720h', 
                 'g2020_cz1': _DATA / 'citylearn_challenge_2020_climate_zone_1_744h'}             # bench.py --config C4 (device set)
 FIXTURES = ('g2022_all', 'g2020_cz1', 'g2023_p2', 'g2022_p1_year', 'g2020_15min')
 # dataset sweep: 95-step runs of the other dataset families (oracle/ref_harness/gen_golden.py)
-SWEEP = ('s_baeda', 's_2021', 's_2020_cz3', 's_2023_p1', 's_2023_p3', 's_autosize')
+SWEEP = ('s_baeda', 's_2021', 's_2020_cz3', 's_2023_p1', 's_2023_p3', 's_autosize',
+         # round 3: every other dataset of the reference checkout that the reference itself can run here
+         's_2020_cz2', 's_2022_p2', 's_2023_oe1', 's_2023_oe2', 's_2023_oe3', 's_2023_p32', 's_2023_p33')
 
 
 class Golden:

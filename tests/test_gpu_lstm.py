@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('name,split,cell', [
     ('g2023_p2', 'f16', 'auto'), ('s_baeda', 'f16', 'auto'), ('s_2023_p1', 'f16', 'auto'), ('s_2023_p3', 'f16', 'auto'), ('g2023_heat', 'f16', 'auto'),
     ('g2023_p2', 'f16', 'plain'), ('s_2023_p3', 'f16', 'plain'), ('g2023_heat', 'f16', 'plain'), ('g2023_both', 'f16', 'auto'), ('g2023_both', 'bf16', 'plain'),
-    ('g2023_p2', 'bf16', 'auto'), ('s_baeda', 'bf16', 'auto'), ('g2023_heat', 'bf16', 'plain'), ('g2023_p2', None, 'auto'), ('s_2023_p3', None, 'auto')])
+    ('g2023_p2', 'bf16', 'auto'), ('s_baeda', 'bf16', 'auto'), ('g2023_heat', 'bf16', 'plain'), ('g2023_p2', None, 'auto'), ('s_2023_p3', None, 'auto'),
+    # the other 2023 districts of the reference checkout (their own LSTM weights, outage seeds and buildings)
+    ('s_2023_oe1', 'f16', 'auto'), ('s_2023_oe2', 'f16', 'auto'), ('s_2023_oe3', 'f16', 'auto'), ('s_2023_p32', 'f16', 'auto'), ('s_2023_p33', 'f16', 'auto')])
 def test_lstm_stage_fed_with_reference_cooling(name, split, cell):
     """Isolates the stage: the delivered cooling of every step comes from the reference; temperatures within 1e-4 C
     relative and ComfortReward within 1e-4 (+1e-4) of the reference for every step and building (2023: LSTM(13 -> 16),
