@@ -383,6 +383,25 @@ class CityLearnEnv(_GymEnv):
             flat = [x for a in per_b for x in a]
         return np.asarray(flat, dtype=np.float32)
 
+    def _demand_limit_check(self, t: int, ob: np.ndarray):
+        """`Building.___demand_limit_check` (building.py:1825-1829): outside a power outage the reference REFUSES to step a building whose
+        end-use demand exceeds what its device (after the storage's discharge) can deliver -- AssertionError, e.g. at the first row of
+        citylearn_challenge_2020_climate_zone_4.  The device clamps the delivered energy instead (every env of a batch keeps running);
+        this façade, which mirrors the reference's error behaviour, raises the same error from the step's expected / served energy."""
+        tol = 1e-4                                                    # data.py:18 TOLERANCE
+        tab = self._tables
+        unmet = ob[abi.CLO_EXPECTED].astype(np.float64) - ob[abi.CLO_SERVED]
+        for i, b in enumerate(self.district_spec.buildings):
+            if tab.outage[t, i] != 0 or not unmet[i] >= tol:
+                continue
+            # which end use: the data-file demand against the delivered energy (a dynamics building's partial-load demand is its own)
+            gaps = {'cooling': float(tab.ts[t, i, abi.CLT_COOL_DEM]) - float(ob[abi.CLO_COOL_DEM, i]),
+                    'heating': float(tab.ts[t, i, abi.CLT_HEAT_DEM]) - float(ob[abi.CLO_HEAT_DEM, i]),
+                    'dhw': float(tab.ts[t, i, abi.CLT_DHW_DEM]) - float(ob[abi.CLO_DHW_DEM, i])}
+            end_use = max(gaps, key=gaps.get) if not b.is_dynamics else 'cooling / heating'
+            raise AssertionError(f'demand is greater than {end_use}_device max output | timestep: {t}, building: {b.name}, outage: False, '
+                                 f'expected: {float(ob[abi.CLO_EXPECTED, i])}, served: {float(ob[abi.CLO_SERVED, i])}, difference: {float(unmet[i])}')
+
     def step(self, actions: Sequence[Sequence[float]]):
         torch = self._torch
         eng = self._engine
@@ -398,6 +417,8 @@ class CityLearnEnv(_GymEnv):
         oe = eng.out_env[:, 0].cpu().numpy()
         st = eng.state[:, :, 0].cpu().numpy()
         self._last_state, self._last_out = st, ob
+        if self.reference_quirks:
+            self._demand_limit_check(t, ob)
         h = self._hist
         h['net'].append(ob[abi.CLO_NET]); h['base_net'].append(ob[abi.CLO_BASE_NET]); h['soc'].append(st[abi.CLS_B_SOC])
         h['net_ws'].append(ob[abi.CLO_NET_WS])

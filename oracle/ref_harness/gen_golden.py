@@ -520,6 +520,46 @@ def run_conditions(name: str):
     print(f'{name}: kpi_conditions.json with {len(pairs)} condition pairs')
 
 
+ERROR_FIXTURES = {
+    # name: (reference dataset, rows kept, action seed).  Datasets on which the REFERENCE raises one of its physics assertions
+    # (Building.___demand_limit_check, building.py:1825-1829): the fixture is the mini dataset + where and what it raised
+    'x_2020_cz4': ('citylearn_challenge_2020_climate_zone_4', 48, 52),
+}
+
+
+def run_reference_error(name: str):
+    """`reference_error.json`: the step at which the reference's `CityLearnEnv.step` raises AssertionError on this dataset, and its text."""
+    dataset, rows, seed = ERROR_FIXTURES[name]
+    out_dir = GOLDEN / name
+    if (out_dir / 'dataset').exists():
+        shutil.rmtree(out_dir / 'dataset')
+    make_mini_dataset(ref_env.REFERENCE_ROOT / 'data' / 'datasets' / dataset, out_dir / 'dataset', rows, False, {})
+    ref_env.setup_reference()
+    from citylearn.citylearn import CityLearnEnv
+    env = CityLearnEnv(str(out_dir / 'dataset' / 'schema.json'))
+    low = np.concatenate([b.action_space.low for b in env.buildings]).astype('float32')
+    high = np.concatenate([b.action_space.high for b in env.buildings]).astype('float32')
+    sizes = [b.action_space.shape[0] for b in env.buildings]
+    draw = _action_drawer(seed, low, high, [n for l in env.action_names for n in l])
+    env.reset()
+    actions, err = [], None
+    for t in range(rows - 1):
+        a = draw()
+        actions.append([float(x) for x in a])
+        acts, p = [], 0
+        for n in sizes:
+            acts.append([float(x) for x in a[p:p + n]]); p += n
+        try:
+            env.step([sum(acts, [])] if env.central_agent else acts)
+        except AssertionError as exc:
+            err = {'step': t, 'message': str(exc), 'building_names': [b.name for b in env.buildings]}
+            break
+    assert err is not None, 'the reference ran through'
+    err['actions'] = actions
+    (out_dir / 'reference_error.json').write_text(json.dumps(err))
+    print(f'{name}: the reference raises at step {err["step"]}: {err["message"][:160]}')
+
+
 MID_FIXTURES = {'g2023_heat': 120, 'g2023_p2': 200}
 
 
@@ -573,6 +613,8 @@ if __name__ == '__main__':
             run_conditions(name)
         elif kind == 'mid_evaluate':
             run_mid_evaluate(name, MID_FIXTURES[name])
+        elif kind == 'reference_error':
+            run_reference_error(name)
         elif kind == 'observations':
             run_observations(name, OBS_FIXTURES.get(name))
         else:
@@ -584,6 +626,8 @@ if __name__ == '__main__':
         jobs = [('observations', n) for n in (args[1:] or list(OBS_FIXTURES))]
     elif args and args[0] == 'mid_evaluate':
         jobs = [('mid_evaluate', n) for n in (args[1:] or list(MID_FIXTURES))]
+    elif args and args[0] == 'reference_error':
+        jobs = [('reference_error', n) for n in (args[1:] or list(ERROR_FIXTURES))]
     else:
         names = args or list(FIXTURES)
         jobs = [('reference', n) for n in names] + [('observations', n) for n in names if n in OBS_FIXTURES]

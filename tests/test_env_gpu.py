@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import golden
+from golden_util import golden, GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -412,6 +412,33 @@ def test_captured_rollout_replays_the_eager_closed_loop(name, kw):
     with pytest.raises(RuntimeError, match='past the episode end'):
         fast._t = fast.time_steps - 3
         roll.run()
+
+
+def test_demand_limit_assertion_of_the_reference():
+    """The reference refuses to step a building whose demand exceeds its device's output outside an outage (AssertionError from
+    `Building.___demand_limit_check`, building.py:1825-1829) -- the first row of citylearn_challenge_2020_climate_zone_4 does that to it
+    (`tests/golden/x_2020_cz4/reference_error.json`: where and what the reference raised, `gen_golden.py reference_error`).  `CityLearnEnv`
+    raises the same error at the same step for the same building; the batched env keeps stepping (the device clamps)."""
+    import json
+    from citylearn_amd.citylearn import CityLearnEnv
+    from citylearn_amd.vector_env import VectorCityLearnEnv
+    d = GOLDEN / 'x_2020_cz4'
+    ref = json.loads((d / 'reference_error.json').read_text())
+    schema = str(d / 'dataset' / 'schema.json')
+    env = CityLearnEnv(schema)
+    assert [b.name for b in env.buildings] == ref['building_names']
+    sizes = [len(n) for n in env.action_names]
+    with pytest.raises(AssertionError, match='demand is greater than cooling_device max output') as exc:
+        for t, a in enumerate(ref['actions']):
+            acts, p = [], 0
+            for n in sizes:
+                acts.append(a[p:p + n]); p += n
+            env.step(acts)
+    assert t == ref['step'] and 'building: Building_6' in str(exc.value) and 'Building_6' in ref['message']
+    venv = VectorCityLearnEnv(schema, 64)
+    for _ in range(5):
+        venv.step(venv.sample_actions())
+    assert venv.time_step == 5
 
 
 def test_planes_observation_of_a_second_episode_starts_clean():
