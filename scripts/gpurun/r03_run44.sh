@@ -1,0 +1,4 @@
+#!/bin/bash
+set -u
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
