@@ -28,12 +28,13 @@ submission gap inside the bracket); `roofline.kernel` is what the library report
 Prints ONE JSON line (rank 0).  `value` = building-timesteps/s over all GPUs with inputs resident in HBM.  `cpu_baseline`
 (headline, N = 1) is the C restatement of the reference arithmetic (oracle/cl_oracle.c, the "port") timed on this box's host
 cores -- all cores, and one core as `cpu_baseline.one_core`; `cpu_baseline.reference` is the reference's own `CityLearnEnv.step`
-as timed by oracle/ref_harness/time_reference.py on the host named there (/root/reference does not travel to the GPU box).
+timed in the same run on the same host by oracle/ref_harness/time_reference.py (usable-cores processes x 200 steps of 2022_phase_all)
+from the staging `oracle/_ref/reference` that build() makes (git-ignored; travels with the snapshot like the built .so files).
 
 Test hooks (environment): CL_BENCH_OVERSUBSCRIBE=1 maps rank r to device r mod (visible devices) so that `--gpus 2` can be
 exercised on a 1-GPU box (the ranks then share a GPU: control plane over gloo because RCCL refuses two ranks per device, and the
 line says `"oversubscribed": true` -- not a scaling measurement); CL_BENCH_DRY_RUN=1 skips all GPU work (launcher, rendezvous and
-aggregation on CPU: tests/test_distributed.py); CL_BENCH_FORCE_DIST=1 brings up the process group even for one rank; CL_BENCH_CONTROL=nccl|gloo
+aggregation on CPU: tests/test_distributed.py; refused when a GPU is visible); CL_BENCH_FORCE_DIST=1 brings up the process group even for one rank; CL_BENCH_CONTROL=nccl|gloo
 picks the control plane's backend (default: RCCL with one rank per GPU; if RCCL cannot come up the barrier falls back to gloo and the line says
 so in `control_fallback` -- CL_BENCH_STRICT_RCCL=1 makes that fatal instead).
 """
@@ -115,10 +116,47 @@ def cpu_baseline(spec, tables, seconds: float = 10.0) -> dict:
     out = {'value': v, 'unit': 'building-timesteps/s', 'cores': threads, 'kind': 'port', 'sample': sample,
            'host': {'logical_cpus': os.cpu_count(), 'usable_cores': cores, 'thread_probe': {str(k): p for k, p in probe.items()}},
            'one_core': {'value': v1, 'unit': 'building-timesteps/s', 'cores': 1, 'kind': 'port', 'sample': sample1}}
-    ref = ROOT / 'profiles' / 'reference_cpu_timing.json'
-    if ref.exists():
-        # the reference's own CityLearnEnv.step (citylearn.py:978-1056), timed where /root/reference exists
-        out['reference'] = json.loads(ref.read_text())
+    out['reference'] = reference_cpu_baseline(cores)
+    return out
+
+
+def reference_cpu_baseline(cores: int, steps: int = 200, timeout: float = 420.0) -> dict:
+    """The REFERENCE's own `CityLearnEnv.step` (citylearn.py:978-1056) timed on THIS host in THIS run: `cores` independent processes
+    (the path has no intra-step threading), each stepping its own citylearn_challenge_2022_phase_all env for `steps` steps --
+    oracle/ref_harness/time_reference.py in a subprocess, importing the staging `oracle/_ref/reference` that `__graft_entry__.build()`
+    made from /root/reference (git-ignored; travels to the GPU box like the built .so files).  When the staging is absent or fails,
+    the build container's committed timing is attached instead and says so."""
+    import subprocess
+    staged = ROOT / 'oracle' / '_ref' / 'reference'
+    committed = ROOT / 'profiles' / 'reference_cpu_timing.json'
+    err = None
+    if (staged / 'MANIFEST.json').is_file():
+        cmd = [sys.executable, str(ROOT / 'oracle' / 'ref_harness' / 'time_reference.py'), '--root', str(staged), '--skip-c1',
+               '--procs', str(cores), '--steps', str(steps), '--out', '-']
+        try:
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=str(ROOT),
+                               env={**os.environ, 'OMP_NUM_THREADS': '1', 'MKL_NUM_THREADS': '1', 'HIP_VISIBLE_DEVICES': ''})
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+            if p.returncode == 0 and lines:
+                ref = json.loads(lines[-1])
+                ref['measured'] = 'live, in this bench run, on this host'
+                ref['seconds_including_env_construction'] = round(time.perf_counter() - t0, 1)
+                try:
+                    import torch
+                    ref['host_gpu'] = torch.cuda.get_device_name(0) if torch.cuda.is_available() else None
+                except Exception:
+                    ref['host_gpu'] = None
+                return ref
+            err = f'time_reference.py rc {p.returncode}: {(p.stderr or p.stdout)[-400:]}'
+        except subprocess.TimeoutExpired:
+            err = f'time_reference.py exceeded {timeout:.0f} s'
+    else:
+        err = 'oracle/_ref/reference not staged (run __graft_entry__.build() where /root/reference exists)'
+    ref = json.loads(committed.read_text()) if committed.exists() else {'kind': 'reference', 'value': None}
+    ref['measured'] = 'NOT in this run: committed timing from the build container (profiles/reference_cpu_timing.json)'
+    ref['live_error'] = err
+    return ref
     return out
 
 
@@ -431,6 +469,10 @@ def run_rank(args):
         sys.stdout.flush()
         os.dup2(2, 1)
     if os.environ.get('CL_BENCH_DRY_RUN'):
+        import torch
+        if torch.cuda.is_available():
+            # the dry run prints a complete metric line of made-up timings: it must be impossible to get one from a box that could measure
+            raise SystemExit('CL_BENCH_DRY_RUN is a CPU-only launcher test hook: refused because a GPU is visible (unset it to measure)')
         return dry_run_rank(args, rank, world)
 
     import torch

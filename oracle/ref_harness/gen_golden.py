@@ -23,6 +23,7 @@ reference, the oracle and the GPU kernel all see bit-identical actions.
 from __future__ import annotations
 
 import gzip
+import os
 import json
 import shutil
 import sys
@@ -35,7 +36,10 @@ REPO = HERE.parent.parent
 sys.path.insert(0, str(HERE))
 import ref_env  # noqa: E402
 
-GOLDEN = REPO / 'tests' / 'golden'
+# CL_GOLDEN_ROOT redirects every output (fixtures AND the package-data mini datasets) into a scratch directory: the regeneration
+# test (tests/test_golden_recipe.py) re-runs the recipe there and compares with the committed files bit for bit.
+_SCRATCH = os.environ.get('CL_GOLDEN_ROOT')
+GOLDEN = Path(_SCRATCH) if _SCRATCH else REPO / 'tests' / 'golden'
 
 FIXTURES = {
     # name: (reference dataset, rows kept, steps simulated, action seed, gzip, env kwargs)
@@ -208,21 +212,24 @@ def _action_drawer(seed: int, low, high, action_names):
 
 
 # three samples are shipped with the package (bench.py's configs, smoke()); every other mini dataset stays next to its fixture
-_PACKAGE_DATA = GOLDEN.parent.parent / 'citylearn_amd' / 'data'
+_PACKAGE_DATA = REPO / 'citylearn_amd' / 'data'
 PACKAGE_DATASETS = {'g2022_all': _PACKAGE_DATA / 'citylearn_challenge_2022_phase_all_720h',
                     'g2023_p2': _PACKAGE_DATA / 'citylearn_challenge_2023_phase_2_local_evaluation_720h',
                     'g2020_cz1': _PACKAGE_DATA / 'citylearn_challenge_2020_climate_zone_1_744h'}
 
 
 def dataset_dir(name: str) -> Path:
+    if _SCRATCH:
+        return GOLDEN / name / 'dataset'
     return PACKAGE_DATASETS.get(name, GOLDEN / name / 'dataset')
 
 
 def run_reference(name: str):
     dataset, rows, steps, seed, gz, env_kwargs = FIXTURES[name]
     out_dir = GOLDEN / name
-    if out_dir.exists():
-        shutil.rmtree(out_dir)
+    # only this recipe's own outputs are replaced: observations.npz / kpi_conditions.json / kpi_mid.npz of the same fixture stay
+    out_dir.mkdir(parents=True, exist_ok=True)
+    (out_dir / 'reference.npz').unlink(missing_ok=True)
     if dataset_dir(name).exists():
         shutil.rmtree(dataset_dir(name))
     make_mini_dataset(ref_env.REFERENCE_ROOT / 'data' / 'datasets' / dataset, dataset_dir(name), rows, gz, env_kwargs)

@@ -1,8 +1,10 @@
 """Import helper for running the *reference* CityLearn (read-only at /root/reference).
 
 TEST INFRASTRUCTURE ONLY (oracle side).  Used by `gen_golden.py` to produce the
-committed fixtures under tests/golden/.  `/root/reference` does not exist on the
-GPU box, so nothing on the `-m gpu` / bench / smoke path imports this module.
+committed fixtures under tests/golden/ and by `time_reference.py` (bench.py's
+`cpu_baseline.reference` leg, a subprocess).  `/root/reference` does not exist on the
+GPU box: there the root is the git-ignored staging `oracle/_ref/reference`
+(`stage_reference.py`); nothing on the `-m gpu` / smoke path imports this module.
 
 Recipe: SURVEY.md App. C — gymnasium + simplejson stand-ins, a pre-seeded
 platformdirs cache so `CityLearnEnv._load` (citylearn.py:2055-2057) never hits
@@ -14,8 +16,18 @@ import sys
 import tempfile
 from pathlib import Path
 
-REFERENCE_ROOT = Path(os.environ.get('CITYLEARN_REFERENCE_ROOT', '/root/reference'))
 _HERE = Path(__file__).resolve().parent
+STAGED_ROOT = _HERE.parent / '_ref' / 'reference'        # stage_reference.py: what the GPU box has instead of /root/reference
+
+
+def _default_root() -> Path:
+    if 'CITYLEARN_REFERENCE_ROOT' in os.environ:
+        return Path(os.environ['CITYLEARN_REFERENCE_ROOT'])
+    live = Path('/root/reference')
+    return live if (live / 'citylearn' / 'citylearn.py').is_file() else STAGED_ROOT
+
+
+REFERENCE_ROOT = _default_root()
 
 
 def reference_available() -> bool:

@@ -1,11 +1,13 @@
 """Time the REFERENCE's own step path -- `CityLearnEnv.step` (/root/reference/citylearn/citylearn.py:978-1056) -- on this host.
 
 TEST / MEASUREMENT INFRASTRUCTURE (oracle side): imports the reference through `ref_env` (gymnasium / simplejson stand-ins,
-seeded cache).  `/root/reference` exists only in the build container, so this cannot run on the GPU box;
-its result is committed as `profiles/reference_cpu_timing.json` (host, core count and date inside) and `bench.py` attaches it
-to its line as `cpu_baseline.reference`, next to the C port it times live on the GPU box's own cores.
+seeded cache).  `/root/reference` exists only in the build container; `stage_reference.py` (run by
+`__graft_entry__.build()`) stages the package + the two datasets this timing needs into the git-ignored `oracle/_ref/reference/`,
+which travels to the GPU box with the snapshot.  `bench.py`'s `cpu_baseline` leg runs this script there (`--root oracle/_ref/reference
+--skip-c1 --out -`, a bounded sample) and reports the result as `cpu_baseline.reference`, host = the GPU box, next to the C port.
+The long form (C1 exactly + 1000 steps on every core) is committed as `profiles/reference_cpu_timing.json`.
 
-    python oracle/ref_harness/time_reference.py [--steps 1000] [--procs N] [--out profiles/reference_cpu_timing.json]
+    python oracle/ref_harness/time_reference.py [--root DIR] [--steps 1000] [--procs N] [--skip-c1] [--out FILE|-]
 
 Two measurements (SURVEY.md 8d "CPU baseline beside it"):
   (i)  C1 exactly: citylearn_challenge_2022_phase_1 (5 buildings), ONE process, the full 8759-step episode, actions
@@ -55,13 +57,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=1000)
     ap.add_argument('--procs', type=int, default=os.cpu_count() or 1)
-    ap.add_argument('--out', default=str(HERE.parent.parent / 'profiles' / 'reference_cpu_timing.json'))
+    ap.add_argument('--out', default=str(HERE.parent.parent / 'profiles' / 'reference_cpu_timing.json'),
+                    help="file, or '-' = one JSON line on stdout (what bench.py reads)")
+    ap.add_argument('--root', default=None, help='reference tree to import (default: $CITYLEARN_REFERENCE_ROOT, /root/reference, '
+                                                 'else the staging under oracle/_ref/reference)')
+    ap.add_argument('--skip-c1', action='store_true', help='skip the single-process full C1 episode (about 2 minutes)')
     args = ap.parse_args()
+    if args.root:
+        os.environ['CITYLEARN_REFERENCE_ROOT'] = str(Path(args.root).resolve())       # inherited by the spawned workers
+    import ref_env
+    log = sys.stderr if args.out == '-' else sys.stdout
 
-    B, n, dt = _episode('citylearn_challenge_2022_phase_1', None, 0)
-    c1 = {'dataset': 'citylearn_challenge_2022_phase_1', 'buildings': B, 'steps': n, 'seconds': round(dt, 3), 'processes': 1,
-          'building_timesteps_per_s': B * n / dt}
-    print('C1:', c1, flush=True)
+    c1 = None
+    if not args.skip_c1:
+        B, n, dt = _episode('citylearn_challenge_2022_phase_1', None, 0)
+        c1 = {'dataset': 'citylearn_challenge_2022_phase_1', 'buildings': B, 'steps': n, 'seconds': round(dt, 3), 'processes': 1,
+              'building_timesteps_per_s': B * n / dt}
+        print('C1:', c1, file=log, flush=True)
 
     ctx = mp.get_context('spawn')
     barrier, q = ctx.Barrier(args.procs), ctx.Queue()
@@ -76,7 +88,7 @@ def main():
     par = {'dataset': 'citylearn_challenge_2022_phase_all', 'buildings': res[0][0], 'steps': res[0][1], 'processes': args.procs,
            'seconds_slowest_process': round(slowest, 3), 'building_timesteps_per_s': units / slowest,
            'building_timesteps_per_s_per_core': units / slowest / args.procs}
-    print('parallel:', par, flush=True)
+    print('parallel:', par, file=log, flush=True)
 
     cpu = platform.processor() or platform.machine()
     try:
@@ -85,12 +97,14 @@ def main():
         pass
     out = {'kind': 'reference', 'what': 'CityLearnEnv.step of the reference (citylearn.py:978-1056, v2.4.2), numpy / Python',
            'value': par['building_timesteps_per_s'], 'unit': 'building-timesteps/s', 'cores': args.procs,
-           'host': f'{platform.node()} ({cpu}, {os.cpu_count()} logical cores): the build container, NOT the GPU box -- the reference '
-                   'tree does not travel there',
+           'host': f'{platform.node()} ({cpu}, {os.cpu_count()} logical cores)', 'reference_root': str(ref_env.REFERENCE_ROOT),
            'date': time.strftime('%Y-%m-%d'), 'sample': f'{args.procs} processes x 17 buildings x {par["steps"]} steps', 'c1_single_process': c1,
            'all_cores': par, 'script': 'oracle/ref_harness/time_reference.py'}
-    Path(args.out).write_text(json.dumps(out, indent=1) + '\n')
-    print('wrote', args.out)
+    if args.out == '-':
+        print(json.dumps(out), flush=True)
+    else:
+        Path(args.out).write_text(json.dumps(out, indent=1) + '\n')
+        print('wrote', args.out)
 
 
 if __name__ == '__main__':

@@ -4,7 +4,7 @@
 # scripts/check_profiles.py fails the run otherwise), one line + counters per BASELINE config, the A-kpi line, user-level step timings.
 # Outputs under gpurun_out/prof_$TAG/; copy what should be judged into profiles/ (scripts/collect_profiles.sh).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -25,7 +25,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc_pass bench_$c $c -- python bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-graph --no-streaming
 done
 python scripts/pmc_summary.py $OUT/bench_pmc_summary.json "$K" $OUT/pmc_bench_FETCH_SIZE/*counter_collection.csv $OUT/pmc_bench_WRITE_SIZE/*counter_collection.csv > /dev/null
-python scripts/check_profiles.py $OUT/bench_line.json $OUT/bench_pmc_summary.json $OUT/bench_kernel_stats.csv >> $OUT/check.log || FAIL=1
+python scripts/check_profiles.py --duration-tol 0.05 $OUT/bench_line.json $OUT/bench_pmc_summary.json $OUT/bench_kernel_stats.csv >> $OUT/check.log || FAIL=1
 # ---- HBM-streaming entry (17 x 1 048 576): counters on the kernel that line names ----
 python bench.py --envs-per-gpu 1048576 --steps 20 --warmup 5 --reps 3 --no-cpu-baseline > $OUT/bench_streaming_line.json 2>$OUT/bench_streaming_line.err
 KS=$(kernel_of $OUT/bench_streaming_line.json)
@@ -34,6 +34,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python scripts/pmc_summary.py $OUT/streaming_pmc_summary.json "$KS" $OUT/pmc_streaming_FETCH_SIZE/*counter_collection.csv $OUT/pmc_streaming_WRITE_SIZE/*counter_collection.csv > /dev/null
 python scripts/check_profiles.py $OUT/bench_streaming_line.json $OUT/streaming_pmc_summary.json >> $OUT/check.log || FAIL=1
+# rocprofv3 duration of the HBM-true shape (the judge's round-3 gap): same command shape as the line above; the kernel's AverageNs must
+# agree with the line's HIP-event launch_us within 5 %
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_streaming -o run -- python bench.py --envs-per-gpu 1048576 --steps 200 --warmup 20 --reps 3 --no-cpu-baseline > $OUT/bench_streaming_under_rocprof.json 2>$OUT/trace_streaming.log
+cp $OUT/trace_streaming/*kernel_stats.csv $OUT/streaming_kernel_stats.csv 2>/dev/null
+python scripts/check_profiles.py --duration-tol 0.05 $OUT/bench_streaming_line.json $OUT/streaming_kernel_stats.csv >> $OUT/check.log || FAIL=1
 # ---- one line per BASELINE config (+ HBM counters for the A-mode ones, kernel stats for all) ----
 for c in C2 C3 C4 C4-lean C5 T9; do
   n=$(echo $c | tr 'A-Z' 'a-z' | tr -d '-')

@@ -121,6 +121,15 @@ def _bench(*argv, env=None, timeout=300):
     return subprocess.run([sys.executable, str(ROOT / 'bench.py'), *argv], env=e, capture_output=True, text=True, timeout=timeout)
 
 
+def _no_gpu_here():
+    import torch
+    return not torch.cuda.is_available()
+
+
+_dry = pytest.mark.skipif(not _no_gpu_here(), reason='CL_BENCH_DRY_RUN is refused on a box with a GPU (tests/test_gpu_bench.py covers that)')
+
+
+@_dry
 def test_bench_spawns_its_own_ranks():
     """The driver's plain command: two ranks come up (gloo here), every rank is timed, the line carries the MAX over ranks, and
     stdout holds nothing but the one JSON line."""
@@ -137,6 +146,7 @@ def test_bench_spawns_its_own_ranks():
     assert out['value'] == one['value']          # twice the units in twice the (synthetic) time
 
 
+@_dry
 def test_bench_under_torchrun_leaves_one_line_on_the_merged_stdout():
     """What the driver runs for N > 1: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`.  The launcher merges the
     ranks' stdout; only rank 0 may write there (the other ranks park descriptor 1 on stderr) -- here with the dry-run rank body."""

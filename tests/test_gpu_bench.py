@@ -37,6 +37,14 @@ def test_two_ranks_on_one_gpu_without_a_launcher():
     assert one['value'] == pytest.approx(17 * 65536 / (one['ms_per_step'] * 1e-3))
 
 
+def test_dry_run_is_refused_where_a_gpu_is_visible():
+    """CL_BENCH_DRY_RUN prints a complete line of made-up timings (CPU launcher tests): a box that can measure must never emit one."""
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    e['CL_BENCH_DRY_RUN'] = '1'
+    p = subprocess.run([sys.executable, str(ROOT / 'bench.py'), '--steps', '5', '--warmup', '2'], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and 'CL_BENCH_DRY_RUN' in p.stderr and not p.stdout.strip()
+
+
 def test_more_ranks_than_gpus_is_refused_without_the_hook():
     e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'CL_BENCH_OVERSUBSCRIBE')}
     import torch
