@@ -157,7 +157,6 @@ def reference_cpu_baseline(cores: int, steps: int = 200, timeout: float = 420.0)
     ref['measured'] = 'NOT in this run: committed timing from the build container (profiles/reference_cpu_timing.json)'
     ref['live_error'] = err
     return ref
-    return out
 
 
 # --------------------------------------------------------------------------------------------------- step loop as hipGraphs
@@ -165,13 +164,16 @@ class Runner:
     """The step loop of one workload as pre-captured hipGraphs: chunk (i0, n) = steps i0 .. i0+n-1; `step_fn(i)` enqueues step i
     on the current stream and depends on i only through i mod `period`."""
 
-    def __init__(self, step_fn, period: int, stream, use_graph: bool):
+    def __init__(self, step_fn, period: int, stream, use_graph: bool, flush_fn=None):
         self.step_fn, self.period, self.stream, self.use_graph = step_fn, period, stream, use_graph
+        self.flush_fn = flush_fn           # end of a step sequence (a captured chunk): e.g. the deferred finish of the C4 shard's district sums
         self.graphs = {}
 
     def run(self, i0: int, n: int):
         for i in range(i0, i0 + n):
             self.step_fn(i)
+        if self.flush_fn is not None:
+            self.flush_fn()
 
     def chunks(self, i0: int, n: int):
         i = i0
@@ -324,6 +326,11 @@ class StepWorkload:
         if self.stage is not None:
             self.stage.reset()
 
+    def flush(self):
+        """End of a step sequence (every captured chunk of <= GRAPH_CHUNK steps ends with it, inside the timed region): brings out_env up
+        to date where the district sums are finished deferred (C4 shard, `cl_tuning.finish = 3`); nothing to enqueue otherwise."""
+        self.eng.finish()
+
     def bytes_per_unit(self) -> float:
         return self.eng.algorithmic_bytes_per_unit()
 
@@ -427,10 +434,13 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
         from citylearn_amd.synthetic import tile_district
         base = 'citylearn_challenge_2020_climate_zone_1_744h' if cfg == 'C4' else 'citylearn_challenge_2022_phase_all_720h'
         spec = tile_district(load_district(sample_schema(base)), 1024)
+        # district sums finished DEFERRED (cl_tuning.finish = 3): every launch folds its predecessor's chunk partial sums, cl_finish_f32 runs
+        # once at the end of each captured chunk of <= 100 steps (inside the timed region); CL_TUNE_FINISH=1 restores the launch per step
+        tuning = {'finish': 3, **tuning}
         return StepWorkload(cfg, spec, E, device, rank, tuning,
                             f'synthetic 1024-building district ({"2020 climate-zone-1 device set: heat pump, heater, 2 tanks, battery" if cfg == "C4" else "battery + PV"}'
                             f'; sizes jittered +-10 %) x {E} envs per GPU (8 GPUs x 1024 = the 8192 envs of BASELINE config 4), cl_step_f32 mode A, '
-                            'building-chunked launch, no collective', f64=f64, kpi=kpi)
+                            'building-chunked launch' + ('; district sums folded by the NEXT launch (deferred finish), cl_finish_f32 once per captured chunk of <= 100 steps' if tuning.get('finish') == 3 else '') + ', no collective', f64=f64, kpi=kpi)
     raise SystemExit(f'unknown --config {cfg}')
 
 
@@ -500,7 +510,7 @@ def run_rank(args):
     E = args.envs_per_gpu or DEFAULT_ENVS[cfg]
 
     def measure(wl, warmup: int, steps: int, reps: int, kernel_steps: int):
-        runner = Runner(wl.step_fn, wl.period, torch.cuda.Stream(device=device), use_graph)
+        runner = Runner(wl.step_fn, wl.period, torch.cuda.Stream(device=device), use_graph, getattr(wl, 'flush', None))
         rep, kernel_s = timed_reps(runner, wl.reset, warmup, steps, reps, dist, kernel_steps)
         walls = [reduce_max_seconds(w, dist, ctl_device) for w, _ in rep]         # MAX over ranks per repetition
         evs = [reduce_max_seconds(e, dist, ctl_device) for _, e in rep]

@@ -157,6 +157,8 @@ def load() -> ctypes.CDLL:
     lib.cl_rollout_seq_f32.restype = ctypes.c_int
     lib.cl_rollout_seq_f32.argtypes = [ctypes.POINTER(Dims), vp, f32p, f32p, f32p, i64, i64, i64, f32p, f32p, u64, f32p,
                                        f32p, f32p, f32p, f32p, f32p, ctypes.POINTER(Flex), i32, i32, vp]
+    lib.cl_finish_f32.restype = ctypes.c_int
+    lib.cl_finish_f32.argtypes = [ctypes.POINTER(Dims), f32p, f32p, i32, vp]
     lib.cl_philox_uniform.restype = ctypes.c_float
     lib.cl_philox_uniform.argtypes = [u64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     got = lib.cl_abi_version()

@@ -477,6 +477,11 @@ CL_DEV void full_step_body(const StepArgs& a) {
     CL_TRACE_CYCLES_ENTRY(4);     // shader-clock cycles at entry (slot 12: at the end) -- gives the clock the launch ran at
     [[maybe_unused]] int tr_i = 0;
     [[maybe_unused]] uint32_t* stage = reinterpret_cast<uint32_t*>(lds + (size_t)a.nw * NQ * TILE);
+    constexpr bool FOLDK = LP && VEC == 2;               // the C4 shard's kernel: district_reduce<.., FOLD>
+    [[maybe_unused]] float fold_prev = 0.0f;
+    [[maybe_unused]] bool fold_issued = false, folded = false;
+    // (deferred finish) [64 chunks][16 district sums], behind the staged parameter blocks
+    [[maybe_unused]] float* lds_fold = lds + (size_t)a.nw * NQ * TILE + (LP ? (size_t)a.b_chunk * CL_LP_WORDS : 0);
     if constexpr (LP) {
         static_assert(!DETAIL, "the evaluate()-time COP row of the detail planes is not staged");
         const int n_words = (b_hi - b_lo) * CL_LP_WORDS;
@@ -494,6 +499,11 @@ CL_DEV void full_step_body(const StepArgs& a) {
             const uint32_t* __restrict__ f = LP ? stage + (b - b_lo) * CL_LP_WORDS : a.params + (long long)b * CL_NP + CLP_F_FIRST;
             FullIn<F> cur;
             full_load_in<VEC, LP>(cur, a, f, b, env0, plane);
+            if constexpr (FOLDK) {
+                // (deferred finish: this wave's share of the previous step's chunk sums, issued behind the first building's plane loads --
+                //  fold_prefetch's note)
+                if (!fold_issued) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane); fold_issued = true; }
+            }
             clv::FP B;
             clv::load_fp<LP>(B, f);
             cl::Row R;
@@ -517,6 +527,9 @@ CL_DEV void full_step_body(const StepArgs& a) {
             F rw = clv::unit_reward<F>(rkind, B, S, O.net);
             CL_TRACE_AFTER(2 + 4 * tr_i, rw);
             CL_TRACE_AFTER(2 + 4 * tr_i, S.soc);
+            if constexpr (FOLDK) {
+                if (!folded && b + a.nw >= b_hi) { fold_stash(a, lds_fold, w, lane, fold_prev); folded = true; }      // ... and parked in LDS before the LAST building's stores
+            }
             if (B.flags & CLF_BATTERY) {
                 full_store<VEC, NT>(a.state + CLS_B_SOC * plane + off, S.soc);
                 full_store<VEC, NT>(a.state + CLS_B_EFF * plane + off, S.eff);
@@ -581,7 +594,13 @@ CL_DEV void full_step_body(const StepArgs& a) {
         // (the baseline series' accumulators of this lane's env: fetched before the reduction's barriers, by the LAST wave -- wave 0 carries the control series)
         if (w == a.nw - 1 && live) kpi_series_fetch(base_pre, a.kpi_env + (long long)CLKE_PER_COND * a.n_env + env0, a.n_env);
     }
-    district_reduce<VEC, false, LP && VEC == 2, KPI>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
+    if constexpr (FOLDK) {
+        if (!folded) {
+            if (!fold_issued) fold_prev = fold_prefetch<TILE>(a, w, lane, plane);
+            fold_stash(a, lds_fold, w, lane, fold_prev);
+        }
+    }
+    district_reduce<VEC, false, FOLDK, KPI>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
     if constexpr (KPI) {
         // baseline district series: the per-building baselines in cl_kpi_kernel's association (16 strided partial sums, added in order).
         // (district_reduce's barriers came after every wave's LDS writes; MARL's extra sweep leaves this region alone.)

@@ -162,11 +162,58 @@ CL_DEV void kpi_series_fetch(KpiSeries& s, const float* __restrict__ k, long lon
 CL_DEV void kpi_series_apply(float* __restrict__ k, long long n_env, int t, float v, const KpiSeries& s);
 CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, float v);
 
+// DEFERRED FINISH (cl_tuning.finish = 3, a.fused_finish == 2), the fold half: every workgroup of a building-chunked launch adds up
+// `opw` <= 16 district sums (quantity, env) of the PREVIOUS step out of scratch buffer (t + 1) & 1 -- n_chunks x opw partial sums -- in
+// cl_finish_kernel's association and writes them to out_env.  What was tried, on the 1024 x 1024 shards (rocprofv3 averages of the step
+// kernel, thermal / battery + PV; 11.5 / 7.8 us without any fold):
+//  1. one district sum per wave, lane = chunk (a 64-line gather), fetched inside district_reduce behind the plane stores: 13.5 us -- on
+//     gfx9 vector loads and stores share one counter and return out of order with respect to each other, so a load waited for after
+//     stores were issued waits for their acknowledgements too;
+//  2. the same gather fetched at the very top of the kernel: 13.9 / 9.7 us;  3. fetched behind the first building's plane loads and
+//     consumed before its stores: 14.1 / 9.8 us -- so not a placement problem: the sixteen waves of a workgroup each gathered 4 bytes
+//     out of the SAME 64 lines (16 consecutive envs of 64 chunk rows), 262 144 line requests per launch for 1 MB of data;
+//  4. (this one) every line is requested once: thread i of the workgroup fetches partial sum (chunk i / 16, district sum i % 16) -- a
+//     wave reads four 64-byte segments -- issued behind the first building's plane loads, parked in LDS before the wave's first store,
+//     and added up behind district_reduce's first barrier: wave w takes district sum w, lanes 0..15 form the sixteen wave-partials of
+//     cl_finish_kernel (chunks k, k + 16, k + 32, k + 48), then their sum in order: 14.4 / 8.8 us.  Piece by piece on one box
+//     (profiles/r04_c4_fold_breakdown.log; 13.0 / 7.8 us with the second launch, whose own 4 - 5 us mostly overlap the next step):
+//     double-buffered rows + marker only 13.7 / 8.1 -- step launches now run back to back, each starting into the previous one's
+//     draining stores; + load and stash 14.9 / 8.4; + add-up without the load 14.4 / 8.6; everything 15.3 / 9.0.
+template <int TILE>
+CL_DEV float fold_prefetch(const StepArgs& a, int w, int lane, long long plane) {
+    if (a.fused_finish != 2) return 0.0f;
+    const int opw = (NQ * TILE + a.n_chunks - 1) / a.n_chunks;           // district sums of an env tile per workgroup row (<= 16: host)
+    const int i = w * 64 + lane, chunk = i >> 4, o = (int)blockIdx.y * opw + (i & 15);
+    const int e = (int)blockIdx.x * TILE + o % TILE;
+    if (chunk < a.n_chunks && (i & 15) < opw && o < NQ * TILE && e < a.n_env)
+        return a.out_bldg[(long long)CLO_RESERVED * plane + ((long long)((a.t + 1) & 1) * a.n_chunks + chunk) * NQ * a.n_env + (long long)(o / TILE) * a.n_env + e];
+    return 0.0f;
+}
+CL_DEV void fold_stash(const StepArgs& a, float* lds_fold, int w, int lane, float v) {
+    if (a.fused_finish == 2 && w < 16) lds_fold[w * 64 + lane] = v;        // [64 chunks][16 district sums]
+}
+template <int TILE>
+CL_DEV void fold_finish(const StepArgs& a, const float* lds_fold, int w, int lane) {
+    const int opw = (NQ * TILE + a.n_chunks - 1) / a.n_chunks;
+    const int o = (int)blockIdx.y * opw + w;
+    if (w >= opw || w >= 16 || o >= NQ * TILE || (int)blockIdx.x * TILE + o % TILE >= a.n_env) return;       // wave-uniform
+    const int k = lane & 15;
+    float pk = 0.0f;
+    if (k < a.n_chunks) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk += k + 16 * j < a.n_chunks ? lds_fold[(k + 16 * j) * 16 + w] : 0.0f;
+    }
+    float tot = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), q));
+    if (lane == 0) a.out_env[(long long)(o / TILE) * a.n_env + (int)blockIdx.x * TILE + o % TILE] = tot;
+}
+
 // KPIS: the thread that writes an env's district net also feeds it to the env's streaming district accumulators (CLD_KPI, lean districts)
 template <int VEC, bool FLEX = false, bool FOLD = false, bool KPIS = false>
 CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int env0, bool live, long long plane, int rkind,
                             const float (&q_net)[VEC], const float (&q_cost)[VEC], const float (&q_em)[VEC],
-                            const float (&q_rw)[VEC], int stride) {
+                            const float (&q_rw)[VEC], int stride, [[maybe_unused]] const float* lds_fold = nullptr) {
     constexpr int TILE = 64 * VEC;
     float* mine = lds + (size_t)w * NQ * TILE + lane * VEC;
     vstore<VEC>(mine + 0 * TILE, q_net);
@@ -194,22 +241,47 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
         // engines bit-identical) -- and 16.2 us against 14.6 us for the two launches at 1024 x 1024 thermal, 16.0 against 10.5 us for
         // battery + PV (profiles/r03b_c4_fold_ab.log): write-through acknowledgement, ticket and re-read are three dependent device-scope
         // round trips of ~2 us each behind the last workgroup, more than the launch they replace.  The second launch stays the default.
+        // DEFERRED FINISH (FOLD, cl_tuning.finish = 3, a.fused_finish == 2; round 4): nothing in step t + 1 reads step t's district sums
+        // unless the reward couples the buildings (MARL, EV) -- so the second launch leaves the per-step critical path altogether.  The
+        // scratch rows are double-buffered by step parity: this launch writes its partial sums to buffer t & 1 and every wave folds ONE
+        // district sum of the PREVIOUS step out of buffer (t + 1) & 1 (plain loads of what the previous launch wrote -- no cross-workgroup
+        // traffic inside a launch, no fence, no ticket), in cl_finish_kernel's summation order: out_env trails the step by one launch, and
+        // cl_finish_f32 (the same cl_finish_kernel, on buffer t & 1) brings it up to date when somebody wants to read it -- the host's
+        // lazy read, or the end of a captured rollout.  A marker word per buffer (step + 1; with the chunk count, in the last 16 bytes of the
+        // reserved plane) tells cl_finish_f32 whether the buffer really holds step t's partial sums: calls that did not defer leave it
+        // alone, and cl_finish_f32 is then a no-op -- the library keeps no host-side state about pending folds.
         float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
+        const bool deferred = FOLD && a.fused_finish == 2;
+        if (deferred) scratch += (long long)(a.t & 1) * a.n_chunks * NQ * a.n_env;
         for (int i = threadIdx.x; i < NQ * TILE; i += blockDim.x) {
             const int q = i / TILE, e = i - q * TILE;
             float s = 0.0f;
             for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
             if (tile_env0 + e < a.n_env) {
                 float* dst = scratch + ((long long)blockIdx.y * NQ + q) * a.n_env + tile_env0 + e;
-                if (FOLD && a.fused_finish) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (FOLD && a.fused_finish == 1) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *dst = s;
             }
         }
         if constexpr (!FOLD) return;                             // cl_finish_kernel folds them (second launch)
         else {
         if (!a.fused_finish) return;                             // cl_tuning.finish = 1: likewise
+        if (a.fused_finish == 2) {
+            // the previous step's district sums, behind this step's partial-sum stores (the exchange tile was complete at the barrier above)
+            fold_finish<TILE>(a, lds_fold, w, lane);
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+                unsigned* marker = reinterpret_cast<unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4);   // last 16 bytes of the plane
+                marker[a.t & 1] = (unsigned)a.t + 1u;
+                marker[2] = (unsigned)a.n_chunks;
+            }
+            return;
+        }
         unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (long long)a.n_chunks * NQ * a.n_env) + blockIdx.x;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's partial sums have left the CU
+        // this thread's partial sums have left the CU: outside tgsplit mode a workgroup-scope release fence does NOT wait for outstanding
+        // vector stores (it only orders LDS), so the wait is spelled out -- s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0) -- in front of it
+        // (round-3 advisor finding: the ticket could otherwise become visible before the write-through partial sums are acknowledged)
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();                                         // ... and so have everybody else's (and nobody reads the wave rows of `lds` any more)
         unsigned* flag = reinterpret_cast<unsigned*>(lds);
         if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -369,6 +441,10 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     const bool marl_partial = rkind == CLR_MARL && a.n_chunks > 1;
     // table row of this env tile: TILE divides CL_ROW0_BLOCK, so the offset is workgroup-uniform (scalar load)
     const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
+    // (FOLD, deferred finish) this wave's share of the previous step's chunk sums: the first load of the kernel
+    [[maybe_unused]] float fold_prev = 0.0f;
+    [[maybe_unused]] bool fold_issued = false, folded = false;
+    [[maybe_unused]] float* lds_fold = lds + (size_t)a.nw * NQ * TILE;        // (deferred finish) [64][16] behind the reduction rows
     for (int b = b_lo + w; b < b_hi; b += a.nw) {
         cl::Bp B;
         cl::load_bp<FULL>(B, a.params + (long long)b * CL_NP);
@@ -407,6 +483,11 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                     load_action<VEC>(a_cd, a, B.a_cd, env0);
                     load_action<VEC>(a_hd, a, B.a_hd, env0);
                 }
+            }
+            if constexpr (FOLD) {
+                // (deferred finish) this wave's share of the previous step's chunk sums: issued BEHIND the first building's plane loads --
+                // it crosses XCDs (another workgroup's L2 wrote it) and returns later than they do, and loads return in order
+                if (!fold_issued) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane); fold_issued = true; }
             }
             float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_hd[VEC], o_dd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC], o_ws[VEC], o_sc[VEC], o_sh[VEC], o_sd[VEC];
             // chargers / washing machines of this building, advanced by cl_flex_kernel just before this launch
@@ -448,6 +529,12 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)
                 q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
                 q_rw[i] += (marl_partial || (FLEX && rkind == CLR_EV)) ? cl::marl_reward(O.net, 1.0f) : rw;
+            }
+            if constexpr (FOLD) {
+                // ... and parked in LDS after the LAST building's arithmetic, before its stores: the load crosses XCDs and takes longer than one
+                // building's arithmetic (stash before the first of two buildings' stores: + 1.1 us on the thermal shard); the stores of earlier
+                // buildings have long been acknowledged by then (a load waited for right behind stores waits for their acknowledgements too)
+                if (!folded && b + a.nw >= b_hi) { fold_stash(a, lds_fold, w, lane, fold_prev); folded = true; }
             }
             auto put = [&](auto nt_tag) {
                 constexpr bool NT = decltype(nt_tag)::value;
@@ -492,7 +579,13 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
         }
     }
 
-    district_reduce<VEC, FLEX, FOLD>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    if constexpr (FOLD) {
+        if (!folded) {                                              // (waves without a building or beyond the batch)
+            if (!fold_issued) fold_prev = fold_prefetch<TILE>(a, w, lane, plane);
+            fold_stash(a, lds_fold, w, lane, fold_prev);
+        }
+    }
+    district_reduce<VEC, FLEX, FOLD>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);
 }
 
 // Lean districts (battery + PV + load), at most two buildings per wave, one chunk: the headline shape.  Same arithmetic
@@ -913,24 +1006,32 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
 // quantity x 16 waves; wave w adds chunks w, w+16, ... (independent loads issued four at a time: one memory round trip for up
 // to 64 chunks), then the 16 wave partials are summed in a fixed order through LDS -- deterministic.  (The first version let one
 // workgroup walk all four quantities of its 64 envs: 16 workgroups and four dependent rounds at 1024 envs, 4.7 us of a 22 us step.)
-__global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a) {
+// `deferred` (cl_finish_f32): fold buffer t & 1 of the double-buffered scratch rows, and only if its marker says it holds step t's sums.
+__global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a, const int deferred) {
     __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     const int q = blockIdx.y;
     const long long plane = (long long)a.n_bldg * a.n_env;
     const float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
+    int n_chunks = a.n_chunks;
+    if (deferred) {
+        const unsigned* marker = reinterpret_cast<const unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4);
+        if (marker[a.t & 1] != (unsigned)a.t + 1u) return;                   // (uniform) step t did not defer its finish: out_env is already final
+        n_chunks = (int)marker[2];
+        scratch += (long long)(a.t & 1) * n_chunks * NQ * a.n_env;
+    }
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     const bool marl = rkind == CLR_MARL && q == CLQ_REWARD;      // partials carried sign(-net) * 0.01 * net^2: scale by max(0, district net)
     float s = 0.0f, sn = 0.0f;
     if (e < a.n_env) {
-        for (int c0 = w; c0 < a.n_chunks; c0 += 64) {
+        for (int c0 = w; c0 < n_chunks; c0 += 64) {
             float v[4], vn[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c0 + 16 * j;
-                v[j] = c < a.n_chunks ? scratch[((long long)c * NQ + q) * a.n_env + e] : 0.0f;
-                vn[j] = (marl && c < a.n_chunks) ? scratch[((long long)c * NQ + CLQ_NET) * a.n_env + e] : 0.0f;
+                v[j] = c < n_chunks ? scratch[((long long)c * NQ + q) * a.n_env + e] : 0.0f;
+                vn[j] = (marl && c < n_chunks) ? scratch[((long long)c * NQ + CLQ_NET) * a.n_env + e] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s += v[j]; sn += vn[j]; }
@@ -1480,6 +1581,15 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     }
     if (a.n_chunks > 1 && rkind_host == CLR_EV)
         return fail(CL_EINVAL, "reward kind CLR_EV is not implemented for building-chunked launches (n_bldg=%d)", dims->n_bldg);
+    // Deferred finish (cl_tuning.finish = 3): the launch folds the PREVIOUS step's chunk sums and leaves its own for the next launch or for
+    // cl_finish_f32 (district_reduce).  Only where nothing of the path reads out_env inside the step: no coupled reward (MARL's per-building
+    // rewards need the district net of the same step, reward_function.py:132-143; the EV reward likewise), no streaming KPIs, no flexible
+    // loads, and the kernels that carry the fold (the FOLD instantiations below); a 16-wave workgroup folds at most 16 district sums (<= 64 chunks),
+    // and the reserved plane has to hold both buffers and the marker words.  Anything else keeps the second launch.
+    const int fold_per_row = a.n_chunks > 1 ? (NQ * tile + a.n_chunks - 1) / a.n_chunks : 0;
+    const bool can_defer = a.n_chunks > 1 && tun.finish == 3 && rkind_host != CLR_MARL && rkind_host != CLR_EV && !flex &&
+                           !(dims->flags & (CLD_KPI | CLD_F64_MAPS | CLD_WRITE_DETAIL)) && fold_per_row <= 16 && a.nw == 16 && a.n_chunks <= 64 &&
+                           (2ll * a.n_chunks * NQ + 1) * dims->n_env <= (long long)dims->n_bldg * dims->n_env - 4;
     const dim3 grid(grid_x, a.n_chunks);
     const bool det = dims->flags & CLD_WRITE_DETAIL;
     // streaming KPIs of thermal / outage districts (and of any district stepped with detail planes) inside the step launch:
@@ -1498,7 +1608,8 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // (for the building-chunked launches only -- a workgroup of the 9 x 65 536 launch would wait for the staging round trip before it
     //  can issue its plane loads, while its scalar reads hit the constant cache: 10.7 vs 8.7 us; full_variant = 2 forces it, 3 forbids it)
     const bool lp = full && !flex && !det && !f64 && tun.full_variant != 1 && tun.full_variant != 3 && vec <= 2 && (a.n_chunks > 1 || tun.full_variant == 2);
-    const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float) + (lp ? (size_t)a.b_chunk * CL_LP_WORDS * sizeof(uint32_t) : 0);
+    const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float) + (lp ? (size_t)a.b_chunk * CL_LP_WORDS * sizeof(uint32_t) : 0) +
+                       (can_defer ? 64 * 16 * sizeof(float) : 0);          // (+ the [64 chunks][16 sums] exchange tile of the deferred fold)
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
     // Thermal districts whose batch can be cut into ONE 16-wave workgroup per CU: a workgroup takes `tiles` 128-env tiles (two envs per
@@ -1596,7 +1707,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, true, 1024, 4, false);
         } else if (lp) {
             // parameter blocks staged in LDS (cl_full.h); full_variant = 3 keeps them in SGPRs (tests, A/B)
-            a.fused_finish = a.n_chunks > 1 && tun.finish == 2 && vec == 2 && !small;
+            a.fused_finish = (a.n_chunks > 1 && vec == 2 && !small) ? (tun.finish == 2 ? 1 : can_defer ? 2 : 0) : 0;
             if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
             else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5, false);      // (96 VGPRs do not hold the staged operands: 61 scratch accesses)
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 4, true);
@@ -1655,9 +1766,10 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
 #undef CL_LEAN_CASE
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
-    } else if (a.n_chunks > 1 && tun.finish == 2 && (vec == 1 || vec == 4)) {
+    } else if (a.n_chunks > 1 && (tun.finish == 2 || can_defer) && (vec == 1 || vec == 4)) {
         // building-chunked battery + PV districts (C4 with the 2022 device set): the instantiations that fold the chunk sums themselves
-        a.fused_finish = 1;
+        // (finish = 2: their own, inside the launch; finish = 3: the previous step's, deferred)
+        a.fused_finish = tun.finish == 2 ? 1 : 2;
         name_add(tun, "cl_step_kernel<%d, false, false, false, false, true>", vec);
         if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, false, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, false, true>), grid, block, lds, s, a);
@@ -1673,7 +1785,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (a.n_chunks > 1) {
         if (!a.fused_finish) {
             name_add(tun, "cl_finish_kernel");
-            hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, s, a);
+            hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, s, a, 0);
         }
         if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL) {
             const long long n = (long long)dims->n_env * dims->n_bldg;
@@ -1696,6 +1808,20 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         }
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_step_kernel launch");
+    return CL_OK;
+}
+
+int cl_finish_f32(const cl_dims* dims, float* out_bldg, float* out_env, int32_t t, void* stream) {
+    if (int rc = check_dims(dims)) return rc;
+    if (int rc = check_ptr(out_bldg, "out_bldg")) return rc;
+    if (int rc = check_ptr(out_env, "out_env")) return rc;
+    if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
+    if (dims->n_bldg <= 32) return CL_OK;              // never building-chunked: every step launch finishes its own district sums
+    StepArgs a = {};
+    a.out_bldg = out_bldg; a.out_env = out_env; a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps;
+    a.flags = dims->flags; a.t = t; a.n_chunks = 0;    // (the kernel reads the chunk count next to the marker)
+    hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, (hipStream_t)stream, a, 1);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_finish_kernel launch");
     return CL_OK;
 }
 
@@ -1771,9 +1897,16 @@ int cl_rollout_seq_f32(const cl_dims* dims, const uint32_t* params, const float*
         if (int rc = cl_step_flex_f32(dims, params, ts, state, a, actions ? act_stride_col : (int64_t)dims->n_env,
                                       actions ? act_stride_env : (int64_t)1, out_bldg, out_env, kpi_bldg, kpi_env, flex, t, stream))
             return rc;
-        if (ret_env)
+        if (ret_env) {
+            // (a deferred finish -- cl_tuning.finish = 3 -- would leave the previous step's reward here: fold now; a no-op where the step did not defer)
+            if (tuning_of(dims).finish == 3)
+                if (int rc = cl_finish_f32(dims, out_bldg, out_env, t, stream)) return rc;
             hipLaunchKernelGGL(cl_return_kernel, dim3(gx), dim3(256), 0, s, ret_env, out_env + (long long)CLQ_REWARD * dims->n_env, dims->n_env);
+        }
     }
+    // end of the sequence: out_env holds the last step's district sums whatever the finish mode
+    if (!ret_env && k_steps > 0 && tuning_of(dims).finish == 3)
+        if (int rc = cl_finish_f32(dims, out_bldg, out_env, t0 + k_steps - 1, stream)) return rc;
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_seq_f32 launch");
     return CL_OK;
 }
@@ -2000,6 +2133,16 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
     // every column env-dependent (the compact observation form) and few of them: a plain transpose of the planes
     const bool transpose = !all_exo && n_seg == 1 && listed && vec4 && t.n_deps == n_cols && n_cols <= OBS_TCOLS && obs_pitch <= OBS_TCOLS + 4 &&
                            (tun.obs_variant == 0 || tun.obs_variant == 4);
+    // wide vectors in one segment with a host-side list: the one-round-trip row-wise kernel (obs_variant 5 forces it, 1 keeps the round-1 one)
+    int row1_slots = 0;                               // most dependent columns any lane owns (lane = 16-byte column group mod 64)
+    if (n_seg == 1 && listed) {
+        int owned[64] = {0};
+        for (int d = 0; d < t.n_deps; ++d) { const int n = ++owned[(deps[d].col >> 2) & 63]; row1_slots = n > row1_slots ? n : row1_slots; }
+    }
+    // (profiles/r04_observe_bench.log, 65 536 envs, round-1 kernel -> this one: 476 columns 27.6 -> 26.6 us, 527: 32.7 -> 31.5, 272: 26.9 -> 23.4,
+    //  245: 19.6 -> 20.6 -- kept on the round-1 kernel --, 262 144 x 476: 122 -> 110 us, where it also beats the wave-independent kernel's 113.5)
+    const bool row1 = n_seg == 1 && listed && vec4 && !transpose && row1_slots <= 4 && (tun.obs_variant == 5 || (tun.obs_variant == 0 && !narrow && padded >= 256));
+    if (row1) wide = false;
     if (transpose) {
         t.o = a;
         hipLaunchKernelGGL(cl_observe_transpose_kernel, dim3((dims->n_env + OBS_TILE - 1) / OBS_TILE), dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
@@ -2009,6 +2152,13 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
         const dim3 wgrid((n_waves + per_wg - 1) / per_wg);
         if (padded <= 512) hipLaunchKernelGGL(cl_observe_wave_kernel<2>, wgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
         else hipLaunchKernelGGL(cl_observe_wave_kernel<4>, wgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
+    } else if (row1) {
+        t.o = a;
+        const dim3 rgrid((dims->n_env + OBS_TILE - 1) / OBS_TILE);
+        if (padded <= 512) {
+            if (row1_slots <= 2) hipLaunchKernelGGL((cl_observe_row1_kernel<2, 2>), rgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
+            else hipLaunchKernelGGL((cl_observe_row1_kernel<2, 4>), rgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
+        } else hipLaunchKernelGGL((cl_observe_row1_kernel<4, 4>), rgrid, dim3(OBS_THREADS), 0, (hipStream_t)stream, t);
     } else if (n_seg == 1 && padded == obs_pitch && listed && narrow && dims->env_row0 == nullptr) {   // one template row per launch
         int r = tun.obs_rows ? tun.obs_rows : 16;          // 16 envs = one 64-byte line of every dependent plane
         while (r * obs_pitch > OBS_BUF) r >>= 1;       // pitch <= OBS_SEG + 3 -> r >= 4

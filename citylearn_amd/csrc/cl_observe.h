@@ -126,6 +126,106 @@ __global__ __launch_bounds__(OBS_THREADS) void cl_observe_kernel(ObsArgs a) {
     }
 }
 
+// ObsArgs + the host-side list of env-dependent columns (<= OBS_DEP_MAX), all in the kernel arguments: scalar loads, no round trip
+struct ObsTileArgs {
+    ObsArgs o;
+    int n_deps;
+    cl_obs_dep deps[OBS_DEP_MAX];
+};
+
+// Row-wise kernel with the dependent-column list in the kernel arguments (round 4; wide observation vectors in one segment -- every
+// shipped schema).  cl_observe_kernel above makes THREE dependent global round trips before its first store -- col_src scan -> plane
+// loads -> template-row loads, each behind a barrier -- and at 65 536 envs every workgroup of the launch is resident at once, so nobody
+// stores while everybody waits: 27.4 us with the 34 dependent columns of the 2022 district against 21.8 us without them (and 19.3 vs
+// 12.4 us at the 245 columns of the 2020 one), although the dependent planes are 7 % of the traffic.  Here every load of the workgroup --
+// the dependent planes (wave w: columns w, w + 4, ...; lane = env), the lane's 16-byte groups of the template row, the scalar reads of
+// the list's base values -- is issued before the first wait: ONE round trip, then a barrier that waits on LDS only, then stores.
+// GROUPS = 16-byte column groups per lane: 2 covers 512 columns, 4 covers OBS_SEG.
+// SLOTS = dependent columns one lane may own (host: falls back to cl_observe_kernel beyond 4).  The store loop holds no LDS access and
+// no branch: a lane's dependent values for the 16 rows of its wave are read from the staging tile in one batch behind the barrier, the
+// loop selects (v_cndmask) and stores.  (The first form read the tile inside the loop, under the lane's exec mask, column by column:
+// two dependent LDS round trips and a dozen exec-mask branches per row and column group.)
+template <int GROUPS, int SLOTS>
+__global__ __launch_bounds__(OBS_THREADS) void cl_observe_row1_kernel(ObsTileArgs t) {
+    __shared__ float dep_s[OBS_DEP_MAX][OBS_TILE + 1];      // (+ 1: lanes that read different columns of one row hit different banks)
+    const ObsArgs& a = t.o;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int env0 = blockIdx.x * OBS_TILE;
+    const int n_rows = min(OBS_TILE, a.n_env - env0);
+    const float* __restrict__ trow = a.row + (a.env_row0 ? (long long)a.env_row0[env0 / CL_ROW0_BLOCK] * a.n_cols : 0);
+    const int n_deps = a.all_exo ? 0 : t.n_deps;
+    constexpr int NWV = OBS_THREADS / 64, PER_WAVE = OBS_DEP_MAX / NWV, ROWS = OBS_TILE / NWV;
+    float pv[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int d = w + k * NWV;
+        pv[k] = 0.0f;
+        if (d < n_deps && lane < n_rows) pv[k] = obs_plane(a, t.deps[d].src)[env0 + lane];
+    }
+    float exo[GROUPS][4];
+    const bool row16 = (a.n_cols & 3) == 0;              // table rows start on 16-byte boundaries
+#pragma unroll
+    for (int k = 0; k < GROUPS; ++k) {
+        const int c = (lane + 64 * k) * 4;
+        if (row16 && c < a.n_cols) {
+            const float4 v = *reinterpret_cast<const float4*>(trow + c);
+            exo[k][0] = v.x; exo[k][1] = v.y; exo[k][2] = v.z; exo[k][3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) exo[k][j] = c + j < a.n_cols ? trow[c + j] : 0.0f;
+        }
+    }
+    // this lane's dependent columns (scalar walk over the kernel-argument list): position k * 4 + j in its groups, list entry d
+    int own_kj[SLOTS], own_d[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) { own_kj[s] = -1; own_d[s] = 0; }
+    int cnt = 0;
+    for (int d = 0; d < n_deps; ++d) {
+        const int col = t.deps[d].col;                                   // scalar load
+        const int grp = col >> 2;
+        if ((grp & 63) == lane) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (cnt == s) { own_kj[s] = (grp >> 6) * 4 + (col & 3); own_d[s] = d; }
+            ++cnt;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int d = w + k * NWV;
+        if (d < n_deps) dep_s[d][lane] = fmaf(pv[k], t.deps[d].scale, trow[t.deps[d].col]);
+    }
+    __syncthreads();
+    float val[SLOTS][ROWS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) val[s][i] = dep_s[own_d[s]][w + i * NWV];        // (unowned slots read entry 0: discarded below)
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int e = w + i * NWV;
+        if (e >= n_rows) break;                                                        // wave-uniform
+        float* out = a.obs + (long long)(env0 + e) * a.pitch;
+#pragma unroll
+        for (int k = 0; k < GROUPS; ++k) {
+            const int c = (lane + 64 * k) * 4;
+            if (c >= a.padded) continue;
+            float v[4] = {exo[k][0], exo[k][1], exo[k][2], exo[k][3]};
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = own_kj[s] == k * 4 + j ? val[s][i] : v[j];
+            *reinterpret_cast<float4*>(out + c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// (A persistent form -- about one workgroup per CU, the dependent planes of ALL its env tiles fetched before its first store -- was
+//  built on the idea that the ~7 us the dependent columns cost are reads issued under a saturated write stream.  Measured slower, and
+//  slower still with fewer waves: 65 536 x 476 34.8 us with eight waves per CU, 37.9 us with four, against 27.6 us for one tile per
+//  workgroup = sixteen waves per CU (profiles/r04_observe_persistent.log).  Not kept: what the store stream wants is waves.)
 // Fast path (single segment, <= OBS_DEP_MAX dependent columns -- every real schema): the R x pitch block of envs a
 // workgroup writes is ONE contiguous, 256-byte aligned stretch of the output.  A template of R identical rows (the
 // env-independent values) is built once in LDS; per block only the dependent columns are patched, then the buffer is
@@ -138,12 +238,6 @@ __global__ __launch_bounds__(OBS_THREADS) void cl_observe_kernel(ObsArgs a) {
 // (A persistent variant with a dedicated loader wave prefetching the planes of the next block was built and measured
 // slower: 40 us at 476 columns -- the per-block hand-off serialises on the read latency under a saturated write stream.)
 constexpr int OBS_BUF = 8192;       // floats in the LDS tile buffer
-
-struct ObsTileArgs {
-    ObsArgs o;
-    int n_deps;
-    cl_obs_dep deps[OBS_DEP_MAX];
-};
 
 CL_DEV void obs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 

@@ -148,7 +148,7 @@ class StepEngine:
             self.ts = torch.from_numpy(np.ascontiguousarray(tables.ts)).to(self.device)
             self.state = torch.zeros((abi.CL_NS, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device)
             self.out_bldg = torch.zeros((abi.CL_NO, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device)
-            self.out_env = torch.zeros((abi.CL_NQ, self.n_env), dtype=torch.float32, device=self.device)
+            self._out_env = torch.zeros((abi.CL_NQ, self.n_env), dtype=torch.float32, device=self.device)
             self.kpi_bldg = torch.zeros((abi.CL_NKB, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
             self.kpi_env = torch.zeros((abi.CL_NKE, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
             self.flex = None
@@ -158,7 +158,11 @@ class StepEngine:
         self._raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
         # per-step call arguments that never change: computed once (ctypes conversions dominate an 8 us kernel otherwise)
         self._step_head = (ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state))
-        self._step_tail = (_ptr(self.out_bldg), _ptr(self.out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env))
+        self._step_tail = (_ptr(self.out_bldg), _ptr(self._out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env))
+        # deferred finish (`tuning={'finish': 3}`, districts of more than 32 buildings): `step` leaves the district sums of its step to the
+        # next launch; reading `out_env` (or any view of it) folds the pending one first (`finish`)
+        self._deferred = int(self.tuning.finish) == 3 and self.n_bldg > 32
+        self._pending_t = None
         self._flex_ref = None if self.flex is None else ctypes.byref(self.flex)
         self.act_low = self.act_high = None         # bounds of the on-device rollout policy (set_action_limits)
         self._policy_actions = None                 # scratch planes of cl_rollout_seq_f32 (four steps of policy draws)
@@ -238,7 +242,8 @@ class StepEngine:
                 self.flex_out.zero_()
             # the output planes are what a 'planes' observation hands out: an episode must not start on the previous one's last step
             self.out_bldg.zero_()
-            self.out_env.zero_()
+            self._out_env.zero_()
+        self._pending_t = None
         self.t = 0
 
     def step(self, actions: torch.Tensor, t: Optional[int] = None):
@@ -258,7 +263,25 @@ class StepEngine:
                 rc = self.lib.cl_step_f32(*self._step_head, actions.data_ptr(), sc, se, *self._step_tail, int(t), self._stream())
         if rc:
             _lib.check(rc)
+        if self._deferred:
+            self._pending_t = int(t)
         self.t = t + 1
+
+    def finish(self):
+        """Deferred finish (`tuning={'finish': 3}`): fold the chunk partial sums the last `step` left behind into `out_env`
+        (`cl_finish_f32`; one small launch on the current stream).  Called by every read of `out_env` / `district_*`; call it yourself
+        at the end of a step sequence captured into a hipGraph (a replay runs no Python).  Nothing to do in any other mode."""
+        if self._pending_t is None:
+            return
+        with self._on_device():
+            _lib.check(self.lib.cl_finish_f32(ctypes.byref(self.dims), _ptr(self.out_bldg), _ptr(self._out_env), self._pending_t, self._stream()))
+        self._pending_t = None
+
+    @property
+    def out_env(self) -> torch.Tensor:
+        """``[CL_NQ, n_env]`` district sums of the last step (after a deferred step: folded first, see `finish`)."""
+        self.finish()
+        return self._out_env
 
     def step_observe(self, actions: torch.Tensor, writer, t: Optional[int] = None) -> torch.Tensor:
         """`step` followed by ``writer.write(t + 1)`` for an `ObservationWriter` over the COMPACT tables (every column env-dependent):
@@ -316,15 +339,16 @@ class StepEngine:
                 _lib.check(self.lib.cl_rollout_seq_f32(
                     ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
                     _ptr(self.act_low), _ptr(self.act_high), int(seed) & (2 ** 64 - 1),
-                    _ptr(None if actions is not None else self._policy_actions), _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env),
+                    _ptr(None if actions is not None else self._policy_actions), _ptr(self.out_bldg), _ptr(self._out_env), _ptr(ret_env),
                     _ptr(self.kpi_bldg), _ptr(self.kpi_env), self._flex_ref, int(t0), int(k_steps), self._stream()))
             self.t = t0 + k_steps
+            self._pending_t = None          # (cl_rollout_seq_f32 finishes its last step itself)
             return
         with torch.cuda.device(self.device):
             _lib.check(self.lib.cl_rollout_f32(
                 ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
                 _ptr(self.act_low), _ptr(self.act_high), int(seed) & (2 ** 64 - 1),
-                _ptr(self.out_bldg), _ptr(self.out_env), _ptr(ret_env), int(t0), int(k_steps), self._stream()))
+                _ptr(self.out_bldg), _ptr(self._out_env), _ptr(ret_env), int(t0), int(k_steps), self._stream()))
         self.t = t0 + k_steps
 
     def step_many(self, actions: torch.Tensor, t0: Optional[int] = None):
@@ -338,10 +362,11 @@ class StepEngine:
         st = actions.stride()
         with self._on_device():
             rc = self.lib.cl_rollout_seq_f32(ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), actions.data_ptr(), st[0], st[1], st[2],
-                                             None, None, 0, None, _ptr(self.out_bldg), _ptr(self.out_env), None, _ptr(self.kpi_bldg), _ptr(self.kpi_env),
+                                             None, None, 0, None, _ptr(self.out_bldg), _ptr(self._out_env), None, _ptr(self.kpi_bldg), _ptr(self.kpi_env),
                                              self._flex_ref, int(t0), k, self._stream())
         if rc:
             _lib.check(rc)
+        self._pending_t = None              # (cl_rollout_seq_f32 finishes its last step itself)
         self.t = t0 + k
 
     # convenient views ------------------------------------------------------------------------------------

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 5   /* 5: cl_tuning.kernel_name, CLD_F64_MAPS; 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
+#define CL_ABI_VERSION 6   /* 6: cl_finish_f32, cl_tuning.finish = 3 (deferred finish); 5: cl_tuning.kernel_name, CLD_F64_MAPS; 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
 
 /* ---- error codes ---- */
 #define CL_OK            0
@@ -204,8 +204,10 @@ enum cl_out {
                          EvaluationCondition variants, citylearn.py:29-50) */
     CLO_SE_COOL, CLO_SE_HEAT, CLO_SE_DHW,   /* cooling / heating / dhw _storage_electricity_consumption[t]: the tank's energy balance through the
                          device's COP or efficiency (building.py:413-457); detail planes */
-    CLO_RESERVED      /* scratch of building-chunked launches (per-chunk district partial sums, then one arrival counter per env tile);
-                         keep last.  The caller zero-fills `out_bldg` once before the first step: the counters return to zero by themselves */
+    CLO_RESERVED      /* scratch of building-chunked launches (per-chunk district partial sums, then one arrival counter per env tile; with
+                         cl_tuning.finish = 3 two such row sets, double-buffered by step parity, and three marker words in the plane's last
+                         16 bytes); keep last.  The caller zero-fills `out_bldg` once before the first step: the counters return to zero by
+                         themselves */
 };
 
 /* ---- district outputs (`out_env[plane][env]`) ---- */
@@ -291,7 +293,8 @@ typedef struct cl_tuning {
     int32_t lean_variant;   /* lean districts: 1 = general kernel, 2 = latency-ordered lean kernel at any grid size */
     int32_t envmajor;       /* env-major kernels (one lane = one env x all buildings): 0 = by batch size, 1 = always, 2 = never */
     int32_t flex_vec;       /* envs per lane of the flexible-load kernel: 1, 2 or 4 */
-    int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent, 4 plane-transpose kernel (all columns env-dependent) */
+    int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent, 4 plane-transpose kernel (all columns env-dependent),
+                               5 row-wise with the dependent-column list in the kernel arguments (one round trip; default for wide vectors) */
     int32_t obs_rows;       /* LDS-tile observation kernel: envs per block */
     int32_t lstm_variant;   /* LSTM stage timing experiments (csrc/cl_lstm.h) */
     int32_t full_variant;   /* thermal / outage districts (tests, A/B): 1 = the round-1 general kernel; 2 = parameter blocks staged in LDS even when
@@ -305,7 +308,11 @@ typedef struct cl_tuning {
                                nothing the library computes depends on it. */
     int32_t finish;         /* building-chunked launches (districts of more than 32 buildings): 0 / 1 = a second launch folds the chunk partial
                                sums (cl_finish_kernel), 2 = the last chunk of an env tile to arrive folds them inside the step launch
-                               (measured slower: csrc/cl_kernels.hip district_reduce; tests, A/B) */
+                               (measured slower: csrc/cl_kernels.hip district_reduce; tests, A/B); 3 = DEFERRED: the step launch folds the
+                               PREVIOUS step's chunk sums and leaves its own in the scratch rows -- `out_env` then trails the step by one
+                               launch until cl_finish_f32 (below) is called.  Only for rewards that do not couple the buildings (not
+                               MARL / EV), without CLD_KPI / CLD_F64_MAPS / CLD_WRITE_DETAIL / flexible loads; every other call keeps
+                               the second launch, and cl_finish_f32 is then a no-op.  cl_rollout_seq_f32 finishes its last step itself. */
     int32_t kpi_passes;     /* streaming KPIs of thermal / outage districts and of districts stepped with the detail planes: 0 = inside the step
                                launch where the launch is the one-env-per-lane thermal kernel (cl_step_full_kpi_kernel), else one launch after
                                the step; 1 = always the launch after the step (cl_kpi_kernel; needs CLD_WRITE_DETAIL), 2 = the two passes of
@@ -606,6 +613,13 @@ int cl_rollout_seq_f32(const cl_dims* dims, const uint32_t* params, const float*
                        const float* act_low, const float* act_high, uint64_t seed, float* policy_actions,
                        float* out_bldg, float* out_env, float* ret_env, float* kpi_bldg, float* kpi_env, const cl_flex* flex,
                        int32_t t0, int32_t k_steps, void* stream);
+
+/* Deferred finish (cl_tuning.finish = 3): bring `out_env` up to date with step `t` -- the last step enqueued on `stream` -- by folding
+ * the chunk partial sums that step left in `out_bldg`'s reserved plane (reference: the district sums of CityLearnEnv.update_variables,
+ * citylearn.py:1888-1918, which the reference forms inside every step).  Idempotent; a no-op (one tiny launch that finds no marker, or
+ * none at all for districts of up to 32 buildings) when step `t` finished its own sums.  Call it before reading `out_env` and at the end
+ * of a captured step sequence; between two deferred steps it is not needed (each launch folds its predecessor's sums). */
+int cl_finish_f32(const cl_dims* dims, float* out_bldg, float* out_env, int32_t t, void* stream);
 
 /* Philox4x32-10 reference draw used by cl_rollout_f32 (host-callable so tests can reproduce the policy):
  * returns u in [0,1) for (seed, env, col, t). */

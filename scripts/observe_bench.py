@@ -43,6 +43,7 @@ for name, E in (('g2022_all', 65536), ('g2022_all', 262144), ('g2020_cz1', 65536
         w = ObservationWriter(eng, ot, stage)
         acts = torch.rand((eng.n_act_cols, E), device='cuda') * 2 - 1
         eng.tuning.obs_variant = 1; us_row = timed(lambda: w.write(7))
+        eng.tuning.obs_variant = 5; us_row1 = timed(lambda: w.write(7))
         eng.tuning.obs_variant = 3; us_wave = timed(lambda: w.write(7))
         alt = []
         for rows in (8, 16, 64):
@@ -56,7 +57,7 @@ for name, E in (('g2022_all', 65536), ('g2022_all', 262144), ('g2020_cz1', 65536
         print(f'   (all-exogenous write(0): {us0:.1f} us; torch broadcast copy_ of the row: {us_t:.1f} us)')
         del dense
         by = w.algorithmic_bytes()
-        print(f'   (row-wise kernel: {us_row:.1f} us; wave-independent kernel: {us_wave:.1f} us; tile kernel by block rows: {", ".join(alt)} us)')
+        print(f'   (round-1 row-wise kernel: {us_row:.1f} us; one-round-trip row-wise kernel: {us_row1:.1f} us; wave-independent kernel: {us_wave:.1f} us; tile kernel by block rows: {", ".join(alt)} us)')
         dep_tables, dep_cols = ot.compact()
         wc = ObservationWriter(eng, dep_tables, stage)
         us_c = timed(lambda: wc.write(7))

@@ -16,7 +16,7 @@ def lib():
 
 
 def test_exports_every_declared_symbol(lib):
-    assert abi.EXPORTED_SYMBOLS == ['cl_abi_version', 'cl_flex_reset_f32', 'cl_last_error', 'cl_lstm_generic_step_f32', 'cl_lstm_reset_f32', 'cl_lstm_step_f32', 'cl_observe_f32',
+    assert abi.EXPORTED_SYMBOLS == ['cl_abi_version', 'cl_finish_f32', 'cl_flex_reset_f32', 'cl_last_error', 'cl_lstm_generic_step_f32', 'cl_lstm_reset_f32', 'cl_lstm_step_f32', 'cl_observe_f32',
                                     'cl_philox_uniform', 'cl_reset_f32', 'cl_rollout_f32', 'cl_rollout_seq_f32', 'cl_step_f32', 'cl_step_flex_f32', 'cl_step_observe_f32']
     for s in abi.EXPORTED_SYMBOLS:
         assert hasattr(lib, s), s

@@ -122,6 +122,54 @@ def test_c4_shard_1024_buildings_x_1024_envs(fixture, kind):
     assert max(worst.values()) < 1.0, (fixture, kind, worst)
 
 
+@pytest.mark.parametrize('kind', REWARDS)
+@pytest.mark.parametrize('fixture', ['g2020_cz1', 'g2022_all'])
+def test_c4_shard_deferred_finish(fixture, kind):
+    """`tuning={'finish': 3}` (round 4): the step launch folds the PREVIOUS step's chunk partial sums and leaves its own to the next
+    launch / to `cl_finish_f32` -- no second launch per step.  Free-running next to the default engine (second launch every step) on
+    the C4 per-GPU shard, both device sets, all four rewards (MARL couples the buildings and keeps its second launch: identical
+    trivially): every plane and -- once folded -- every district sum bit for bit; before the fold `out_env` trails by exactly one
+    step; `cl_finish_f32` is idempotent and a no-op for engines that did not defer; `step_many` finishes its last step itself."""
+    spec, tab = _c4_district(fixture)
+    E, K = 1024, 6
+    ref = StepEngine(tab, E, reward=kind)
+    dfr = StepEngine(tab, E, reward=kind, tuning=dict(finish=3))
+    ref.trace_kernels(); dfr.trace_kernels()
+    low, high = spec.action_limits()
+    rng = np.random.RandomState(3)
+    acts = torch.from_numpy(rng.uniform(low[:, None], high[:, None], size=(K, len(low), E)).astype(np.float32)).cuda()
+    prev = None
+    for t in range(K):
+        ref.step(acts[t], t)
+        dfr.step(acts[t], t)
+        if kind == 'MARL':
+            assert 'cl_finish_kernel' in dfr.last_kernels and dfr.last_kernels == ref.last_kernels
+        else:
+            assert 'cl_finish_kernel' in ref.last_kernels and 'cl_finish_kernel' not in dfr.last_kernels, dfr.last_kernels
+            if prev is not None:
+                assert torch.equal(dfr._out_env, prev)                # not folded yet: the previous step's district sums
+        assert torch.equal(dfr.state, ref.state)
+        assert torch.equal(dfr.out_bldg[:abi.CLO_RESERVED], ref.out_bldg[:abi.CLO_RESERVED])
+        if t % 2 == 0 or t == K - 1:                                  # (odd steps are folded by the next launch instead)
+            assert torch.equal(dfr.out_env, ref.out_env), (t, (dfr.out_env - ref.out_env).abs().max().item())
+            dfr._pending_t = t
+            assert torch.equal(dfr.out_env, ref.out_env)              # a second cl_finish_f32 of the same step changes nothing
+        prev = ref.out_env.clone()
+    # an engine that does not defer: cl_finish_f32 finds no marker and leaves out_env alone
+    before = ref._out_env.clone()
+    ref._pending_t = K - 1
+    ref.finish()
+    assert torch.equal(ref._out_env, before)
+    # step_many (cl_rollout_seq_f32) folds its last step itself
+    ref.reset(); dfr.reset()
+    ref.step_many(acts); dfr.step_many(acts)
+    assert dfr._pending_t is None and torch.equal(dfr._out_env, ref._out_env) and torch.equal(dfr.state, ref.state)
+    ret_r, ret_d = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
+    ref.reset(); dfr.reset()
+    ref.rollout(K, actions=acts, ret_env=ret_r); dfr.rollout(K, actions=acts, ret_env=ret_d)
+    assert torch.equal(ret_d, ret_r) and torch.equal(dfr._out_env, ref._out_env)
+
+
 @pytest.mark.parametrize('kind', ['RewardFunction', 'MARL'])
 def test_c5_rollout_kernel_at_131072_envs(kind):
     """BASELINE config 5's kernel template -- two envs per lane, two buildings per wave (`cl_rollout_kernel<2, false, 2>`,
