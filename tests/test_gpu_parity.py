@@ -194,6 +194,19 @@ def test_free_running_whole_fixture(name):
     assert max(worst.values()) < 1.0, worst
 
 
+@pytest.mark.parametrize('name', ['g2022_all', 'g2023_p2'])
+def test_free_running_at_the_north_star_bar_in_plain_fp32(name):
+    """BASELINE.json's bar -- 1e-4 relative -- FREE-RUNNING over the whole fixture with the default fp32 kernels (the ones the headline
+    speed is quoted on), on the two headline schemas: measured worst 0.69 x (2022, 17 buildings x 719 steps) and 0.22 x (2023, outage
+    path) of 1e-4 + 1e-4 |ref| in round 3; pinned here so that a regression to the looser 1e-3 gate of the test above cannot pass
+    unnoticed.  (The 2020 / 15-minute fixtures sit at 2.1 x on the per-building planes in plain fp32 -- battery map on the steep segment of
+    the capacity-power curve -- and reach the bar with CLD_F64_MAPS: next test.)  District sums keep `_run`'s stated slack: 17-term fp32
+    sums of O(100) kWh against the reference's float64 sums."""
+    worst, _ = _run(name, 'RewardFunction', 1, detail=False, teach=False, atol=1e-4, rtol=1e-4)
+    assert max(worst.values()) < 1.0, worst
+    print(name, {k: round(v, 3) for k, v in worst.items()})
+
+
 @pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 'g2023_heat'])
 @pytest.mark.parametrize('vec', [1, 2])
 def test_free_running_whole_fixture_f64(name, vec):
