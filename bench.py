@@ -36,7 +36,8 @@ exercised on a 1-GPU box (the ranks then share a GPU: control plane over gloo be
 line says `"oversubscribed": true` -- not a scaling measurement); CL_BENCH_DRY_RUN=1 skips all GPU work (launcher, rendezvous and
 aggregation on CPU: tests/test_distributed.py; refused when a GPU is visible); CL_BENCH_FORCE_DIST=1 brings up the process group even for one rank; CL_BENCH_CONTROL=nccl|gloo
 picks the control plane's backend (default: RCCL with one rank per GPU; if RCCL cannot come up the barrier falls back to gloo and the line says
-so in `control_fallback` -- CL_BENCH_STRICT_RCCL=1 makes that fatal instead).
+so in `control_fallback` -- CL_BENCH_STRICT_RCCL=1 makes that fatal instead); CL_BENCH_EXTRA_CONFIGS=1 runs the N > 1 line's `extra_configs` (C4, C4-lean, C5 in the same run)
+whatever the rank count; CL_BENCH_NO_PIN=1 leaves the ranks' CPU affinity alone.
 """
 from __future__ import annotations
 
@@ -497,6 +498,11 @@ def run_rank(args):
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = f'cuda:{dev_index}'
+    # N > 1: this rank's launch thread on cores of the NUMA node its GPU hangs off (CL_BENCH_NO_PIN=1 leaves the affinity mask alone)
+    from citylearn_amd.parallel import pin_rank_to_gpu_node
+    affinity = None
+    if world > 1 and not os.environ.get('CL_BENCH_NO_PIN'):
+        affinity = pin_rank_to_gpu_node(dev_index, local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     dist, backend = None, None
     if world > 1 or os.environ.get('CL_BENCH_FORCE_DIST'):
         backend = os.environ.get('CL_BENCH_CONTROL') or ('gloo' if oversubscribed else 'nccl')        # RCCL refuses two ranks on one device
@@ -515,11 +521,11 @@ def run_rank(args):
         walls = [reduce_max_seconds(w, dist, ctl_device) for w, _ in rep]         # MAX over ranks per repetition
         evs = [reduce_max_seconds(e, dist, ctl_device) for _, e in rep]
         mine = statistics.median(w for w, _ in rep)
-        return walls, evs, reduce_max_seconds(kernel_s, dist, ctl_device), gather_seconds(mine, dist, ctl_device)
+        return walls, evs, reduce_max_seconds(kernel_s, dist, ctl_device), gather_seconds(mine, dist, ctl_device), gather_seconds(kernel_s, dist, ctl_device)
 
     wl = build_workload(cfg, E, device, rank, world, tuning, args.f64_maps, args.kpi)
     heavy = cfg in ('C3', 'C5')                          # ~100 us .. 1 ms per step: fewer steps in the kernel-time bracket
-    walls, evs, launch_s, per_rank = measure(wl, args.warmup, args.steps, args.reps, max(args.steps, 200 if heavy else 2000))
+    walls, evs, launch_s, per_rank, per_rank_kernel = measure(wl, args.warmup, args.steps, args.reps, max(args.steps, 200 if heavy else 2000))
     wall_med = statistics.median(walls)
     roof = wl.roofline(launch_s)
     roof['launch_us_how'] = ('HIP events on the launch stream around max(K, 2000) consecutive steps (pre-replayed 100-step hipGraphs) enqueued behind a '
@@ -535,11 +541,11 @@ def run_rank(args):
     units_per_step, n_bldg, spec, tables, what = wl.units_per_step, wl.eng.n_bldg, wl.spec, wl.tables, wl.what
 
     if cfg == 'headline' and not args.no_streaming and E == ENVS_PER_GPU:
-        del wl
+        wl = None
         torch.cuda.empty_cache()
         s_steps = 20
         wl_s = build_workload(cfg, STREAMING_ENVS, device, rank, world, tuning, args.f64_maps, args.kpi)
-        _, _, launch, _ = measure(wl_s, 5, s_steps, 3, 2000)
+        _, _, launch, _, _ = measure(wl_s, 5, s_steps, 3, 2000)
         a = wl_s.units_per_step * wl_s.bytes_per_unit() / launch / 1e9
         s_traffic, s_source = _pmc_traffic('r*_streaming_pmc_summary.json', wl_s.kernels or '')
         roof['hbm_streaming'] = {
@@ -552,6 +558,30 @@ def run_rank(args):
         del wl_s
         torch.cuda.empty_cache()
 
+    # N > 1 on a real node: BASELINE configs 4 and 5 measured in the same lease (their per-GPU shards, weak scaling like the headline) -- the
+    # driver's scaling run is the only time anybody sees N > 1, so the line carries them as `extra_configs` (--no-extra-configs skips them)
+    extra = {}
+    want_extra = (world > 1 and not oversubscribed and not args.no_extra_configs) or os.environ.get('CL_BENCH_EXTRA_CONFIGS') == '1'      # (the hook: 1-GPU tests)
+    if cfg == 'headline' and want_extra:
+        wl = None
+        torch.cuda.empty_cache()
+        for xc in ('C4', 'C4-lean', 'C5'):
+            x_steps, x_warm = (200, 30) if xc == 'C5' else (2000, 200)
+            if os.environ.get('CL_BENCH_EXTRA_CONFIGS') == '1':
+                x_steps, x_warm = x_steps // 10, x_warm // 10
+            wl_x = build_workload(xc, DEFAULT_ENVS[xc], device, rank, world, tuning, False, False)
+            x_walls, _, x_launch, x_rank, x_rank_k = measure(wl_x, x_warm, x_steps, 3, 200 if xc == 'C5' else 2000)
+            x_wall = statistics.median(x_walls)
+            extra[xc] = {'workload': wl_x.what, 'value': world * wl_x.units_per_step * x_steps / x_wall, 'unit': 'building-timesteps/s',
+                         'ms_per_step': x_wall / x_steps * 1e3, 'steps': x_steps, 'warmup': x_warm, 'reps': 3, 'envs_per_gpu': DEFAULT_ENVS[xc],
+                         'rank_ms_per_step': [v / x_steps * 1e3 for v in x_rank], 'rank_launch_us': [k * 1e6 for k in x_rank_k],
+                         'roofline': wl_x.roofline(x_launch)}
+            del wl_x
+            torch.cuda.empty_cache()
+    affinities = None
+    if dist is not None and world > 1:
+        affinities = [None] * world
+        torch.distributed.all_gather_object(affinities, affinity)            # (default group = gloo: host objects)
     if rank == 0:
         n_distinct = min(world, n_dev)
         out = {
@@ -568,9 +598,16 @@ def run_rank(args):
                        **({'k_steps_per_launch': 24, 'step': 'one fused 24-step launch'} if cfg == 'C5' else {})},
             'ranks': world, 'world_size_seen': world if dist is None else dist.get_world_size(), 'control_backend': backend, **({'control_fallback': dist.control_fallback} if dist is not None and dist.control_fallback else {}),
             'rank_ms_per_step': [s / args.steps * 1e3 for s in per_rank],
+            # kernel time only, per rank (HIP events around back-to-back steps): next to rank_ms_per_step it separates what the GPU took from
+            # what the host's graph submission added -- 8 ranks share the host's usable cores
+            'rank_launch_us': [k * 1e6 for k in per_rank_kernel],
             'rep_ms_per_step': [w / args.steps * 1e3 for w in walls],
             'roofline': roof,
         }
+        if extra:
+            out['extra_configs'] = extra
+        if affinities is not None:
+            out['rank_affinity'] = affinities
         if oversubscribed:
             out['oversubscribed'] = True
             out['config']['note'] = (f'{world} ranks share {n_dev} GPU(s) (CL_BENCH_OVERSUBSCRIBE): exercises the multi-rank plumbing, NOT a scaling measurement; '
@@ -594,6 +631,7 @@ def parse_args(argv=None):
     ap.add_argument('--envs-per-gpu', type=int, default=None)
     ap.add_argument('--no-graph', action='store_true', help='launch every step from Python instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true', help='N > 1, headline: skip the C4 / C4-lean / C5 lines measured in the same run (`extra_configs`)')
     ap.add_argument('--no-streaming', action='store_true', help='skip the 17 x 1 048 576 HBM-streaming roofline entry of the headline')
     ap.add_argument('--f64-maps', action='store_true', help="CLD_F64_MAPS: battery map in the reference's mixed float64 / float32 precision (step configs)")
     ap.add_argument('--kpi', action='store_true', help='CLD_KPI: update the streaming KPI accumulators every step (mode A-kpi of SURVEY 8d; step configs)')

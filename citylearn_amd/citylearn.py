@@ -138,7 +138,12 @@ class CityLearnEnv(_GymEnv):
     own wrappers among them -- accept it; the loaded district is `district_spec` (`spec` belongs to gymnasium there)."""
     metadata = {'render_modes': []}
     if _GymEnv is object:
-        spec = property(lambda self: self.district_spec, doc='the loaded district (`district_spec`); gymnasium owns this name when it is installed')
+        def _spec_alias(self):
+            # behaviour must not fork on an optional import: with gymnasium installed `spec` is gymnasium's EnvSpec slot (None here)
+            import warnings
+            warnings.warn('CityLearnEnv.spec is deprecated: use district_spec (gymnasium owns `spec` when it is installed)', DeprecationWarning, stacklevel=2)
+            return self.district_spec
+        spec = property(_spec_alias, doc='deprecated alias of `district_spec`')
 
     def __init__(self, schema: Union[str, Path, Mapping[str, Any]], device: str = 'cuda:0',
                  observation_mode: str = 'reference', reference_quirks: bool = True, ev_seed: int = None,

@@ -121,26 +121,108 @@ def launch_ranks(argv: Sequence[str], world: int, timeout: Optional[float] = Non
     return rc, out0
 
 
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/node*/cpulist)."""
+    cpus: List[int] = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pick_cores(node_cpus: Sequence[int], allowed: Sequence[int], ranks_on_node: int, index: int, min_cores: int = 2) -> List[int]:
+    """The launch thread(s) of one rank: slice `index` of `ranks_on_node` equal slices of the cores that are both on the GPU's NUMA
+    node and in the process's affinity mask, in core order.  Falls back to the whole allowed set when the node has fewer than
+    `min_cores` usable cores per rank (a cgroup that hands out cores of another node, an unknown topology): pinning must never leave
+    a rank with less than it had."""
+    allowed_set = set(allowed)
+    usable = [c for c in node_cpus if c in allowed_set]
+    if ranks_on_node < 1 or not 0 <= index < ranks_on_node:
+        raise ValueError(f'rank slot {index} of {ranks_on_node}')
+    per = len(usable) // ranks_on_node
+    if per < min_cores:
+        return sorted(allowed_set)
+    return usable[index * per:(index + 1) * per]
+
+
+def gpu_numa_node(pci_bus_id: str, sysfs: str = '/sys') -> int:
+    """NUMA node of the PCI device `pci_bus_id` ('0000:c1:00.0'), -1 when the kernel does not say."""
+    try:
+        with open(os.path.join(sysfs, 'bus', 'pci', 'devices', pci_bus_id.lower(), 'numa_node')) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def pin_rank_to_gpu_node(dev_index: int, local_rank: int, local_world: int, sysfs: str = '/sys') -> Optional[dict]:
+    """Pin this process to cores of the NUMA node its GPU hangs off (one host thread per rank replays hipGraphs: on a two-socket node a
+    launch thread on the far socket adds fabric latency to every submission, and eight ranks on one socket's cores contend).  Ranks whose
+    GPUs share a node split its cores by local rank.  Returns what was done (bench.py prints it per rank as `rank_affinity`), None when
+    the topology cannot be read -- the affinity mask is then left alone."""
+    if not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        import torch
+        props = [torch.cuda.get_device_properties(i) for i in range(torch.cuda.device_count())]
+        bus = lambda p: f'{getattr(p, "pci_domain_id", 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0'
+        nodes = [gpu_numa_node(bus(p), sysfs) for p in props]
+        node = nodes[dev_index]
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, 'devices', 'system', 'node', f'node{node}', 'cpulist')) as f:
+            node_cpus = parse_cpulist(f.read())
+        # ranks r of this job whose device (r mod n_dev) sits on the same node, in rank order
+        n_dev = len(props)
+        same = [r for r in range(local_world) if nodes[r % n_dev] == node]
+        allowed = sorted(os.sched_getaffinity(0))
+        cores = pick_cores(node_cpus, allowed, len(same), same.index(local_rank))
+        os.sched_setaffinity(0, cores)
+        return {'numa_node': node, 'cores': f'{cores[0]}-{cores[-1]}' if cores == list(range(cores[0], cores[-1] + 1)) else cores,
+                'n_cores': len(cores), 'ranks_on_node': len(same)}
+    except Exception:                                     # noqa: BLE001 -- topology files differ between kernels / containers
+        return None
+
+
 class ControlPlane:
     """`torch.distributed` (every attribute is forwarded) + what `init_control_plane` settled on: `control_backend` ('nccl' = RCCL, or 'gloo')
-    and `control_fallback` (why RCCL was given up, else None)."""
+    and `control_fallback` (why RCCL was given up, else None).  `barrier` / `all_reduce` / `all_gather` run on the group that carries the
+    benchmark's control traffic: the RCCL subgroup when it came up, else the gloo group every rank joined first."""
 
-    def __init__(self, dist, backend: str, fallback: Optional[str] = None):
-        self._dist, self.control_backend, self.control_fallback = dist, backend, fallback
+    def __init__(self, dist, backend: str, fallback: Optional[str] = None, group=None):
+        self._dist, self.control_backend, self.control_fallback, self._group = dist, backend, fallback, group
 
     def __getattr__(self, name):
         return getattr(self._dist, name)
 
+    def barrier(self):
+        return self._dist.barrier(group=self._group)
 
-def init_control_plane(rank: int, world: int, device=None, backend: Optional[str] = None) -> ControlPlane:
+    def all_reduce(self, tensor, op=None):
+        return self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM if op is None else op, group=self._group)
+
+    def all_gather(self, out, tensor):
+        return self._dist.all_gather(out, tensor, group=self._group)
+
+
+def init_control_plane(rank: int, world: int, device=None, backend: Optional[str] = None, nccl_timeout_s: float = 90.0) -> ControlPlane:
     """Process group for the benchmark's barrier + timing reductions.  ``backend``: 'nccl' (RCCL over xGMI, one rank per GPU),
     'gloo' (ranks sharing a device, or CPU); default: nccl when `device` is a GPU.  Returns a `ControlPlane` (``torch.distributed`` + the
     backend that ended up carrying the barrier).
+
+    Every rank joins a gloo group first (one rendezvous through the launcher's env:// store -- the only one), RCCL comes up as a
+    SUBGROUP of it, and the ranks agree over gloo whether it did: if any rank could not bring RCCL up (IPC mode, fabric, driver, two
+    ranks on one device) ALL of them carry the barrier and the MAX over gloo and the line says why in `control_fallback` -- the step
+    path has no collective, a scaling run must not be lost to the control plane.  (Round 3 re-rendezvoused on MASTER_PORT + 1 after a
+    failure, a port nobody had reserved, and assumed the failure symmetric: one failing rank would have waited in a TCPStore while its
+    peers sat in the RCCL barrier.)  CL_BENCH_STRICT_RCCL=1 makes the fallback fatal.
 
     RCCL prints a version banner on STDOUT when the communicator comes up; stdout is parked on stderr meanwhile so that it
     carries nothing but the caller's own output."""
     import torch
     import torch.distributed as dist
+    from datetime import timedelta
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if world == 1:
         os.environ.setdefault('MASTER_PORT', str(free_port()))          # (a lone rank has nobody to agree with; launchers set it for the others)
@@ -149,36 +231,26 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
-    fallback = None
+    fallback, group = None, None
     try:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.barrier()
         if backend == 'nccl':
+            err = None
             try:
-                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
-                dist.barrier()
+                group = dist.new_group(backend='nccl', timeout=timedelta(seconds=nccl_timeout_s))
+                dist.barrier(group=group)
                 torch.cuda.synchronize()
-            except Exception as exc:                  # noqa: BLE001 -- whatever RCCL raises (it fails symmetrically: every rank lands here)
-                # The step path has no collective: the group only carries the benchmark's barrier and a MAX over ranks.  If RCCL cannot
-                # come up on this node (IPC mode, fabric, driver), those two travel over gloo instead and the line says so -- a scaling
-                # run must not be lost to the control plane.  CL_BENCH_STRICT_RCCL=1 keeps the failure fatal.
+            except Exception as exc:                  # noqa: BLE001 -- whatever RCCL raises
+                err = f'{type(exc).__name__}: {exc}'[:300]
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # over gloo: every rank learns whether EVERY rank has RCCL
+            if int(ok[0]) == 0:
                 if os.environ.get('CL_BENCH_STRICT_RCCL') == '1':
-                    raise
-                print(f'[rank {rank}] RCCL control plane failed ({type(exc).__name__}: {exc}); falling back to gloo', file=sys.stderr, flush=True)
-                try:
-                    dist.destroy_process_group()
-                except Exception:                     # noqa: BLE001
-                    pass
-                # a fresh rendezvous store on the next port, hosted by rank 0 itself: under torch.distributed.run the env:// store lives in
-                # the launcher's agent (TORCHELASTIC_USE_AGENT_STORE) and nobody would serve another port
-                from datetime import timedelta
-                port = int(os.environ.get('MASTER_PORT', '29500')) + 1
-                store = dist.TCPStore(os.environ['MASTER_ADDR'], port, world, rank == 0, timeout=timedelta(seconds=180))
-                backend = 'gloo'
-                dist.init_process_group('gloo', store=store, rank=rank, world_size=world)
-                dist.barrier()
-                fallback = f'{type(exc).__name__}: {exc}'[:300]
-        else:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-            dist.barrier()
+                    raise RuntimeError(f'[rank {rank}] RCCL control plane failed ({err or "on another rank"}) and CL_BENCH_STRICT_RCCL=1')
+                print(f'[rank {rank}] RCCL control plane failed ({err or "on another rank"}); barrier and MAX stay on gloo', file=sys.stderr, flush=True)
+                fallback = err or 'RCCL did not come up on another rank'
+                backend, group = 'gloo', None
     finally:
         sys.stdout.flush()
         try:
@@ -190,4 +262,4 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
             pass
         os.dup2(saved, 1)
         os.close(saved)
-    return ControlPlane(dist, backend, fallback)
+    return ControlPlane(dist, backend, fallback, group)

@@ -237,3 +237,68 @@ def test_bench_uses_only_counters_collected_on_the_kernel_it_launched(tmp_path, 
     check = [sys.executable, str(ROOT / 'scripts' / 'check_profiles.py'), str(line)]
     assert subprocess.run(check + [str(prof / 'r03_streaming_pmc_summary.json')], capture_output=True).returncode == 0
     assert subprocess.run(check + [str(prof / 'r02_streaming_pmc_summary.json')], capture_output=True).returncode == 1
+
+
+def _asymmetric_rank(rank, world, port, q):
+    """Rank 1's "RCCL" fails at once, rank 0's would sit in its barrier: a gloo subgroup with a short timeout stands in for the RCCL one."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    import torch.distributed as d
+    from citylearn_amd.parallel import init_control_plane, reduce_max_seconds
+    real_new_group = d.new_group
+
+    def fake_new_group(backend=None, timeout=None, **kw):
+        g = real_new_group(backend='gloo', timeout=timeout)
+        if rank == 1:
+            raise RuntimeError('no RCCL on this rank')
+        return g
+    d.new_group = fake_new_group
+    t0 = time.monotonic()
+    cp = init_control_plane(rank, world, None, 'nccl', nccl_timeout_s=5.0)
+    took = time.monotonic() - t0
+    worst = reduce_max_seconds(float(rank + 1), cp, 'cpu')          # the control plane still works, over gloo
+    cp.barrier()
+    q.put((rank, cp.control_backend, cp.control_fallback, took, worst))
+    d.destroy_process_group()
+
+
+def test_control_plane_converges_when_rccl_fails_on_one_rank_only():
+    """an asymmetric RCCL failure must not strand the healthy ranks.  Every rank joins gloo first and RCCL is a subgroup; the
+    ranks agree over gloo whether it came up everywhere -- the failing rank reports at once, the other one after its (short) RCCL timeout,
+    and both end on gloo with the reason in `control_fallback`."""
+    from citylearn_amd.parallel import free_port
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_asymmetric_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, backend, fallback, took, worst in res:
+        assert backend == 'gloo' and fallback and took < 60 and worst == 2.0, res
+    assert 'no RCCL on this rank' in res[1][2] and res[0][2]
+
+
+def test_rank_affinity_arithmetic(tmp_path):
+    """`pin_rank_to_gpu_node`'s pieces: cpulist parsing, the per-rank slice of a NUMA node's cores, the fallbacks."""
+    from citylearn_amd.parallel import gpu_numa_node, parse_cpulist, pick_cores
+    assert parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist('') == [] and parse_cpulist('5') == [5]
+    node0 = parse_cpulist('0-63,128-191')
+    allowed = list(range(256))
+    slices = [pick_cores(node0, allowed, 4, i) for i in range(4)]
+    assert all(len(s) == 32 for s in slices) and sorted(c for s in slices for c in s) == node0       # disjoint, cover the node
+    assert slices[0] == list(range(32)) and slices[3] == list(range(160, 192))
+    # the affinity mask (a cpuset) cuts the node: slices come from the intersection
+    assert pick_cores(node0, list(range(16)), 2, 1) == list(range(8, 16))
+    # a cpuset that has (almost) nothing on the GPU's node: the rank keeps every core it was allowed
+    assert pick_cores(node0, list(range(64, 80)), 2, 0) == list(range(64, 80))
+    assert pick_cores(node0, [0, 1, 2], 2, 1) == [0, 1, 2]
+    with pytest.raises(ValueError):
+        pick_cores(node0, allowed, 2, 2)
+    dev = tmp_path / 'bus' / 'pci' / 'devices' / '0000:c1:00.0'
+    dev.mkdir(parents=True)
+    (dev / 'numa_node').write_text('1\n')
+    assert gpu_numa_node('0000:C1:00.0', str(tmp_path)) == 1 and gpu_numa_node('0000:05:00.0', str(tmp_path)) == -1

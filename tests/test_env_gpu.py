@@ -212,7 +212,7 @@ def test_streaming_kpi_accumulators(name, K):
         net = hist['net'][:, :, e]
         cost = (net.astype(np.float64) * tab.ts[:K, :, abi.CLT_PRICE]).astype('float32')
         em = np.maximum(0, net.astype(np.float64) * tab.ts[:K, :, abi.CLT_CARBON]).astype('float32')
-        frame = evaluate_district(env.spec, tab, K, net, hist['base'][:, :, e], cost, em, hist['exp'][:, :, e], hist['srv'][:, :, e], d_net[:, e],
+        frame = evaluate_district(env.district_spec, tab, K, net, hist['base'][:, :, e], cost, em, hist['exp'][:, :, e], hist['srv'][:, :, e], d_net[:, e],
                                   indoor_temp=hist['temp'][:, :, e] if env.stage is not None else None)
         ref = {(r.level, r.name, r.cost_function): r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
         n = 0
@@ -222,7 +222,7 @@ def test_streaming_kpi_accumulators(name, K):
             if level == 'district':
                 got = float(district[fn][e])
             else:
-                got = float(building[fn][[b.name for b in env.spec.buildings].index(bname), e])
+                got = float(building[fn][[b.name for b in env.district_spec.buildings].index(bname), e])
             np.testing.assert_allclose(got, v, rtol=2e-4, atol=2e-5, err_msg=f'{fn} {bname} env {e}')
             n += 1
         assert n >= 9 + 4 * B

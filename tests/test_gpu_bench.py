@@ -45,6 +45,22 @@ def test_dry_run_is_refused_where_a_gpu_is_visible():
     assert p.returncode != 0 and 'CL_BENCH_DRY_RUN' in p.stderr and not p.stdout.strip()
 
 
+def test_scale_run_extras_on_the_one_gpu_there_is():
+    """What only the driver's N > 1 run executes otherwise: the C4 / C4-lean / C5 lines measured in the same run
+    (`extra_configs`), per-rank kernel time next to per-rank wall time, and the ranks' CPU pinning -- two ranks sharing device 0."""
+    two = _bench('--gpus', '2', '--steps', '20', '--warmup', '5', '--reps', '2', '--no-streaming', env={'CL_BENCH_OVERSUBSCRIBE': '1', 'CL_BENCH_EXTRA_CONFIGS': '1'})
+    assert len(two['rank_launch_us']) == 2 and all(3.0 < k < 60.0 for k in two['rank_launch_us']), two['rank_launch_us']
+    assert set(two['extra_configs']) == {'C4', 'C4-lean', 'C5'}
+    for name, x in two['extra_configs'].items():
+        assert x['value'] > 1e9 and len(x['rank_ms_per_step']) == 2 and len(x['rank_launch_us']) == 2 and x['roofline']['kernel'], name
+    assert 'cl_finish_kernel' not in two['extra_configs']['C4']['roofline']['kernel']        # deferred finish
+    assert 'cl_rollout_kernel' in two['extra_configs']['C5']['roofline']['kernel']
+    aff = two['rank_affinity']
+    assert len(aff) == 2
+    if aff[0] is not None:                                   # (None: the box does not expose the GPU's NUMA node)
+        assert aff[0]['ranks_on_node'] == 2 and aff[0]['n_cores'] >= 1 and aff[0]['cores'] != aff[1]['cores']
+
+
 def test_more_ranks_than_gpus_is_refused_without_the_hook():
     e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'CL_BENCH_OVERSUBSCRIBE')}
     import torch

@@ -137,7 +137,7 @@ def test_env_on_the_ev_dataset_matches_the_reference(name):
     spec = g.spec()
     drift = _drift(g, spec, spec.episode_tables(0))
     env = CityLearnEnv(g.schema_path, ev_soc_drift=drift, noise_seed=g.facts.get('noise_seed'))
-    for ev, fact in zip(env.spec.electric_vehicles, g.facts['electric_vehicles']):      # see golden_util.Golden.spec
+    for ev, fact in zip(env.district_spec.electric_vehicles, g.facts['electric_vehicles']):      # see golden_util.Golden.spec
         ev.battery.initial_soc = fact['initial_soc']
     assert type(env.reward_function).__name__ == 'Electric_Vehicles_Reward_Function' and env._fused_reward
     assert env.observation_names == g.facts['observation_names'] and env.action_names == g.facts['action_names']
@@ -194,7 +194,7 @@ def test_ev_reward_plugin_on_the_host_agrees_with_the_device():
     envs = [CityLearnEnv(g.schema_path, ev_soc_drift=drift), CityLearnEnv(g.schema_path, ev_soc_drift=drift, reward_function=Mine)]
     assert envs[0]._fused_reward and not envs[1]._fused_reward
     for env in envs:
-        for ev, fact in zip(env.spec.electric_vehicles, g.facts['electric_vehicles']):
+        for ev, fact in zip(env.district_spec.electric_vehicles, g.facts['electric_vehicles']):
             ev.battery.initial_soc = fact['initial_soc']
         env.reset()
     flips = 0
@@ -238,7 +238,7 @@ def test_vector_env_with_evs_and_episode_offsets():
     ft = off.tables.flex
     for blk, row in enumerate((0, 96)):
         rule = ft.ev_ts[row, :, abi.CLEV_RULE_RESET]
-        init = np.array([ev.battery.initial_soc for ev in off.spec.electric_vehicles], dtype=np.float32)
+        init = np.array([ev.battery.initial_soc for ev in off.district_spec.electric_vehicles], dtype=np.float32)
         expect = np.where(rule >= 0, rule, init)
         got = off.engine.ev_state[0, :, blk * 256:(blk + 1) * 256].cpu().numpy()
         assert np.allclose(got, expect[:, None], atol=1e-6), (blk, got[:, 0], expect)

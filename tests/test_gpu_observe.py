@@ -172,7 +172,7 @@ def test_vector_env_observation_tensor(name, normalize):
         for c in np.nonzero(dep)[0]:
             i, k = lay.columns[c]
             if k.endswith('_delta'):
-                sp = env.spec.buildings[i].series[k.replace('_delta', '_set_point')][t]
+                sp = env.district_spec.buildings[i].series[k.replace('_delta', '_set_point')][t]
                 want = float(o['robs_indoor_dry_bulb_temperature'][t, i]) - float(sp)
             else:
                 want = float(o[f'robs_{k}'][t, i])
