@@ -58,7 +58,6 @@ class VectorCityLearnEnv:
             raise ValueError("observations must be 'planes', 'tensor' or 'compact'")
         self._compact = observations == 'compact'
         self.spec = schema if isinstance(schema, DistrictSpec) else load_district(schema, **kwargs)
-        self.district_spec = self.spec          # the name CityLearnEnv uses (gymnasium owns `spec` on a gymnasium.Env)
         self.n_envs = int(n_envs)
         self.device = torch.device(device)
         self.reference_quirks = reference_quirks
