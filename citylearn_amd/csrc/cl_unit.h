@@ -246,7 +246,19 @@ CL_DEV float battery_energy(const BattP& B, float E, State& S) {
 struct BattP64 {
     double r, dt, pow, cap, oml /* 1 - loss_coefficient r */, soc_limit /* 1 - depth_of_discharge */, clccap /* capacity_loss_coefficient * capacity */;
     double cx[3], cy[3], px[5], py[5];      // capacity_power_curve, power_efficiency_curve (x, y)
+    double rcap, rpow, rcx[2], rpx[4];      // correctly rounded reciprocals of the constant divisors (CLPD_RCAP ..): div_rn below
 };
+
+// RN(a / b) for a divisor whose correctly rounded reciprocal rb = RN(1 / b) is at hand: q0 = RN(a rb) is within two ulps of the quotient,
+// one residual step (the residual a - b q is exact in a fused multiply-add) brings it within a fraction of an ulp, and Markstein's theorem
+// (IBM J. Res. Dev. 34, 1990) makes the second step's result the correctly rounded quotient -- the bits IEEE division returns, which is
+// what the reference computes.  Five FMA-class operations; a non-finite reciprocal (degenerate curve segment) takes the hardware division.
+CL_DEV double div_rn(double a, double b, double rb) {
+    if (!(fabs(rb) < 1.0e300)) return a / b;                   // inf / nan reciprocal (uniform: a parameter of the building)
+    const double q0 = a * rb;
+    const double q1 = __builtin_fma(__builtin_fma(-q0, b, a), rb, q0);
+    return __builtin_fma(__builtin_fma(-q1, b, a), rb, q1);
+}
 
 CL_DEV double pd(const uint32_t* __restrict__ p, int k) {           // k-th double of the CLP_D_* block (8-byte aligned: CL_NP and CLP_D_FIRST are even)
     const uint64_t bits = (uint64_t)p[CLP_D_FIRST + 2 * k] | ((uint64_t)p[CLP_D_FIRST + 2 * k + 1] << 32);
@@ -262,6 +274,10 @@ CL_DEV void load_batt64(BattP64& B, const uint32_t* __restrict__ p) {
     for (int k = 0; k < 3; ++k) { B.cx[k] = pd(p, CLPD_CPC_X0 + k); B.cy[k] = pd(p, CLPD_CPC_Y0 + k); }
 #pragma unroll
     for (int k = 0; k < 5; ++k) { B.px[k] = pd(p, CLPD_PEC_X0 + k); B.py[k] = pd(p, CLPD_PEC_Y0 + k); }
+    B.rcap = pd(p, CLPD_RCAP); B.rpow = pd(p, CLPD_RPOW);
+    B.rcx[0] = pd(p, CLPD_RCPC_01); B.rcx[1] = pd(p, CLPD_RCPC_12);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) B.rpx[k] = pd(p, CLPD_RPEC_01 + k);
 }
 
 // Battery.charge(energy): `energy` [kWh] is what Building.update_electrical_storage hands over (building.py:1801-1812), float64.
@@ -282,10 +298,12 @@ CL_DEV float battery_charge_ref(const BattP64& B, double energy, bool first, Sta
     // energy_init (661-666): float32 product `prev_soc * capacity`, then float64 `* (1 - loss_coefficient)`
     const double e_init = fmax(0.0, (double)(prev * (float)B.cap) * B.oml);
     // get_max_input_power (1070-1090): idx = max(0, argmax(soc <= xs) - 1) -- 0 again when no breakpoint is >= soc
-    const double socn = e_init / fmax(B.cap, ZDP);
+    const double capz = fmax(B.cap, ZDP), powz = fmax(B.pow, ZDP);
+    const double socn = div_rn(e_init, capz, B.rcap);
     const bool seg1 = !(socn <= cx1) && (socn <= cx2);
     const double xa = seg1 ? cx1 : cx0, xb = seg1 ? cx2 : cx1, ya = seg1 ? cy1 : cy0, yb = seg1 ? cy2 : cy1;
-    const double pmax = B.pow * (ya + (yb - ya) * (socn - xa) / (xb - xa));
+    const double rc0 = B.rcx[0], rc1 = B.rcx[1];
+    const double pmax = B.pow * (ya + div_rn((yb - ya) * (socn - xa), xb - xa, seg1 ? rc1 : rc0));
     double e_eff;                                                                         // argument of get_current_efficiency
     if (energy >= 0.0) {
         const double wrt_degrade = degcap - e_init;
@@ -302,18 +320,25 @@ CL_DEV float battery_charge_ref(const BattP64& B, double energy, bool first, Sta
         e_eff = fmin(fabs(action_energy), pmax);
     }
     // get_current_efficiency (1092-1109)
-    const double x = fabs(e_eff) / fmax(B.pow, ZDP);
+    const double x = div_rn(fabs(e_eff), powz, B.rpow);
     const int seg = (x <= px1) ? 0 : (x <= px2) ? 1 : (x <= px3) ? 2 : (x <= px4) ? 3 : 0;
     const double qa = seg == 0 ? px0 : seg == 1 ? px1 : seg == 2 ? px2 : px3, qb = seg == 0 ? px1 : seg == 1 ? px2 : seg == 2 ? px3 : px4;
     const double ra = seg == 0 ? py0 : seg == 1 ? py1 : seg == 2 ? py2 : py3, rb = seg == 0 ? py1 : seg == 1 ? py2 : seg == 2 ? py3 : py4;
-    const double eff = ra + (x - qa) * (rb - ra) / (qb - qa);
+    const double rp0 = B.rpx[0], rp1 = B.rpx[1], rp2 = B.rpx[2], rp3 = B.rpx[3];
+    const double eff = ra + div_rn((x - qa) * (rb - ra), qb - qa, seg == 0 ? rp0 : seg == 1 ? rp1 : seg == 2 ? rp2 : rp3);
     const double rte = sqrt(eff);
-    // StorageDevice.charge (719-768)
+    // StorageDevice.charge (719-768).  The reference divides by the round-trip efficiency once per call: `energy / rte` when discharging
+    // (to get e_fin), `d / rte` when charging (energy_balance from the stored difference) -- one hardware division on the numerator the
+    // call's sign selects (as two selects between a product and a quotient it was two divisions on every lane).
     energy = energy * B.r;
-    const double e_fin = energy >= 0.0 ? fmin(e_init + energy * rte, B.cap) : fmax(0.0, e_init + energy / rte);
-    const float soc = (float)(e_fin / fmax(B.cap, ZDP));                                  // soc[t]: float32 series
+    const bool charging = energy >= 0.0;
+    const double e_fin_c = fmin(e_init + energy * rte, B.cap);
+    const double quot = (charging ? e_fin_c - e_init : energy) / rte;
+    const double e_fin = charging ? e_fin_c : fmax(0.0, e_init + quot);
+    const float soc = (float)div_rn(e_fin, capz, B.rcap);                                 // soc[t]: float32 series
     const double d = e_fin - e_init;
-    const float eb = (float)(d >= 0.0 ? d / rte : d * rte);                               // energy_balance[t]: float32 series
+    // (charging: d = e_fin_c - e_init >= 0 and quot = d / rte; discharging: e_fin <= e_init, so d <= 0 -> d * rte, and d == 0 gives 0 either way)
+    const float eb = (float)(charging && d >= 0.0 ? quot : d * rte);                     // energy_balance[t]: float32 series
     // degrade (1130-1141): float32 `clc * capacity * |eb|`; the division is float32 too while degraded_capacity is still a Python float
     const float g32 = (float)B.clccap * fabsf(eb);
     const double den = 2.0 * fmax(degcap, ZDP);

@@ -617,6 +617,11 @@ class DistrictSpec:
             d64[abi.CLPD_EFF0] = e.efficiency
             d64[abi.CLPD_CPC_X0:abi.CLPD_CPC_X0 + 3], d64[abi.CLPD_CPC_Y0:abi.CLPD_CPC_Y0 + 3] = cx, cy
             d64[abi.CLPD_PEC_X0:abi.CLPD_PEC_X0 + 5], d64[abi.CLPD_PEC_Y0:abi.CLPD_PEC_Y0 + 5] = ex, ey
+            with np.errstate(divide='ignore'):                   # (a degenerate curve segment gives inf: the kernel then divides the long way)
+                d64[abi.CLPD_RCAP] = 1.0 / max(cap, ZERO_DIVISION_PLACEHOLDER)
+                d64[abi.CLPD_RPOW] = 1.0 / max(powr, ZERO_DIVISION_PLACEHOLDER)
+                d64[abi.CLPD_RCPC_01:abi.CLPD_RCPC_01 + 2] = 1.0 / (np.asarray(cx[1:3], dtype=np.float64) - np.asarray(cx[0:2], dtype=np.float64))
+                d64[abi.CLPD_RPEC_01:abi.CLPD_RPEC_01 + 4] = 1.0 / (np.asarray(ex[1:5], dtype=np.float64) - np.asarray(ex[0:4], dtype=np.float64))
             for tank, base in ((b.cooling_storage, abi.CLP_CS_IRTE), (b.heating_storage, abi.CLP_HS_IRTE),
                                (b.dhw_storage, abi.CLP_DS_IRTE)):
                 pf[i, base + 0] = 1.0 / math.sqrt(tank.efficiency)

@@ -144,6 +144,13 @@ enum cl_param_f64 {       /* k-th double of the CLP_D_* block */
     CLPD_CPC_X0, CLPD_CPC_X1, CLPD_CPC_X2, CLPD_CPC_Y0, CLPD_CPC_Y1, CLPD_CPC_Y2,          /* capacity_power_curve (x: soc, y: power fraction) */
     CLPD_PEC_X0, CLPD_PEC_X1, CLPD_PEC_X2, CLPD_PEC_X3, CLPD_PEC_X4,                       /* power_efficiency_curve */
     CLPD_PEC_Y0, CLPD_PEC_Y1, CLPD_PEC_Y2, CLPD_PEC_Y3, CLPD_PEC_Y4,
+    /* correctly rounded float64 reciprocals of the map's CONSTANT divisors (round 4): battery_charge_ref divides by them through two
+       fused-multiply-add correction steps (Markstein), which returns the correctly rounded quotient -- the same bits as the division the
+       reference executes -- in 5 FMAs instead of the ~11-instruction v_div_scale / v_rcp_f64 / v_div_fmas sequence */
+    CLPD_RCAP,            /* 1 / max(capacity, ZERO_DIVISION_PLACEHOLDER) */
+    CLPD_RPOW,            /* 1 / max(nominal_power, ZERO_DIVISION_PLACEHOLDER) */
+    CLPD_RCPC_01, CLPD_RCPC_12,                             /* 1 / (cpc_x[k + 1] - cpc_x[k]) */
+    CLPD_RPEC_01, CLPD_RPEC_12, CLPD_RPEC_23, CLPD_RPEC_34, /* 1 / (pec_x[k + 1] - pec_x[k]) */
     CLPD_USED             /* <= 32 */
 };
 

@@ -28,3 +28,13 @@ extern "C" void host_unit_step(const uint32_t* params, const float* ts_row, int 
     else if (f64) run<false, true>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
     else run<false, false>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
 }
+
+// div_rn(a, b, RN(1 / b)) against the hardware division, element by element; returns the number of mismatching quotients
+extern "C" long host_div_rn_mismatches(const double* a, const double* b, long n) {
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        const double q = cl::div_rn(a[i], b[i], 1.0 / b[i]), r = a[i] / b[i];
+        bad += !(q == r || (q != q && r != r));
+    }
+    return bad;
+}

@@ -81,3 +81,30 @@ def test_fp32_unit_drifts_on_the_expansive_part_of_the_battery_map(shim):
     """What CLD_F64_MAPS is for: the same free run with the fp32 map leaves the 1e-4 bar on the 2020 fixture (and stays inside 1e-3)."""
     worst = free_run(shim, 'g2020_cz1', False)
     assert 1.0 < max(worst.values()) < 10.0, worst
+
+
+def test_markstein_division_returns_the_ieee_quotient(shim):
+    """`cl::div_rn` (round 4: the float64 battery map divides by its constant divisors through their correctly rounded reciprocals and two
+    fused-multiply-add correction steps): the result must be the correctly rounded quotient -- what the reference's division returns --
+    for every operand pair, not just the fixtures': four million pairs over eleven decades, divisors with all-ones / near-power-of-two
+    significands (the classic hard cases of reciprocal-based division), zero and negative numerators; a non-finite reciprocal takes the
+    plain division."""
+    shim.host_div_rn_mismatches.restype = ctypes.c_long
+    shim.host_div_rn_mismatches.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+    rng = np.random.RandomState(11)
+    n = 1 << 22
+    a = rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-6, 5, n)
+    b = rng.uniform(0.5, 2, n) * 10.0 ** rng.uniform(-6, 5, n)
+    hard = np.concatenate([np.nextafter(2.0 ** rng.randint(-20, 20, 4096), 0), np.nextafter(2.0 ** rng.randint(-20, 20, 4096), np.inf),
+                           2.0 ** rng.randint(-20, 20, 4096).astype(float), np.float64(1e-6) * np.ones(16)])
+    b[:hard.size] = hard
+    a[hard.size:hard.size + 1024] = 0.0
+    assert shim.host_div_rn_mismatches(a.ctypes.data, b.ctypes.data, n) == 0
+    # ... and the curve-segment form the map uses: (y1 - y0) (x - x0) / (x1 - x0) with the shipped battery curves' breakpoints
+    xs = np.array([0.0, 0.3, 0.7, 0.8, 1.0])
+    num = rng.uniform(-1, 1, 1 << 16) * rng.uniform(0, 1, 1 << 16)
+    for d in np.diff(xs):
+        den = np.full(num.size, d)
+        assert shim.host_div_rn_mismatches(num.ctypes.data, den.ctypes.data, num.size) == 0
+    z = np.zeros(4)
+    assert shim.host_div_rn_mismatches(np.ones(4).ctypes.data, z.ctypes.data, 4) == 0          # 1 / 0: inf both ways
