@@ -55,6 +55,10 @@ for c in C2 C3 C4 C4-lean C5 T9; do
     python scripts/check_profiles.py $OUT/bench_$c.json $OUT/${n}_pmc_summary.json >> $OUT/check.log || FAIL=1;;
   esac
 done
+# C4 shards with the second launch per step (cl_tuning.finish = 1) next to the deferred finish of the lines above: same box, same session
+for c in C4 C4-lean; do
+  CL_TUNE_FINISH=1 python bench.py --config $c > $OUT/bench_${c}_second_launch.json 2>/dev/null
+done
 # C3 / C5: vector-ALU counters of the LSTM and the rollout kernel (their bound is instruction issue, not HBM)
 pmc_pass c3_SQ SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- python bench.py --config C3 --steps 60 --warmup 20 --reps 1 --no-graph
 python scripts/pmc_by_kernel.py cl_lstm_kernel $OUT/pmc_c3_SQ/*counter_collection.csv > $OUT/c3_lstm_sq_by_kernel.jsonl

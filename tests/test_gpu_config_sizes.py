@@ -73,6 +73,51 @@ def test_thermal_districts_at_65536_envs(name, kind, detail):
     assert small.state.abs().sum().item() > 0 and small.out_bldg[abi.CLO_NET].abs().sum().item() > 0
 
 
+@pytest.mark.parametrize('name,E,steps,kind', [('g2022_all', 65536, 6, 'RewardFunction'), ('g2022_all', 65536, 4, 'MARL'), ('g2023_p2', 65536, 6, 'RewardFunction'),
+                                               ('g2020_cz1', 65536, 4, 'SolarPenaltyReward'), ('g2022_all', 262144, 3, 'RewardFunction')])
+def test_config_sizes_with_distinct_actions_against_the_c_oracle(name, E, steps, kind):
+    """at the config sizes the replication tests above compare the engine with itself; here EVERY env of the headline shape
+    (17 x 65 536, the lean kernel at four envs per lane), of C3's energy step (2023 schema, 3 x 65 536), of the thermal 9 x 65 536 shape
+    (multi-tile kernel) and of the 17 x 262 144 shape (env-major kernel) has its own actions (bounds and zeros included) and is compared
+    with the C restatement of the reference arithmetic (oracle/cl_oracle.c, float64, OpenMP over envs) on every state plane, net,
+    reward and district sum -- teacher-forced from the oracle's state each step, rows inside the 2023 fixture's outage included."""
+    from oracle.c_oracle import COracle, OS, OO
+    g = golden(name)
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    eng = StepEngine(tab, E, reward=kind)
+    eng.trace_kernels()
+    ora = COracle(spec, tab, E, reward=kind)
+    low, high = spec.action_limits()
+    rng = np.random.RandomState(E % 1000 + len(name))
+    t0 = 388 if name == 'g2023_p2' else 0                    # (the fixture's power outage covers rows 389 - 403)
+    worst = {}
+    planes = ((abi.CLS_B_SOC, 'SOC'), (abi.CLS_B_EFF, 'EFF'), (abi.CLS_B_DEGCAP, 'DEGCAP'), (abi.CLS_CS_SOC, 'CS'), (abi.CLS_HS_SOC, 'HS'), (abi.CLS_DS_SOC, 'DS'))
+    if t0:                                                   # mid-episode start: some charge in every storage
+        ora.state[:, :, OS['SOC']] = rng.uniform(0.2, 0.8, size=ora.state.shape[:2])
+        ora.state[:, :, OS['DS']] = rng.uniform(0.0, 0.6, size=ora.state.shape[:2])
+    for t in range(t0, t0 + steps):
+        a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
+        a[:, 0] = 0.0
+        a[:, 1], a[:, 2] = low, high
+        for pl, key in planes:
+            eng.state[pl] = torch.from_numpy(np.ascontiguousarray(ora.state[:, :, OS[key]].T).astype(np.float32)).cuda()
+        eng.step(torch.from_numpy(a).cuda(), t)
+        out, oe = ora.step(a, t)
+        checks = [(key.lower(), eng.state[pl].cpu().numpy(), ora.state[:, :, OS[key]].T, 1e-4, 1e-4) for pl, key in planes]
+        checks += [('net', eng.net.cpu().numpy(), out[:, :, OO['NET']].T, 1e-4, 1e-4),
+                   ('reward', eng.reward_bldg.cpu().numpy(), out[:, :, OO['REWARD']].T, 1e-3 if kind in ('MARL', 'SolarPenaltyReward') else 1e-4, 2e-4),
+                   ('d_net', eng.district_net.cpu().numpy(), oe[:, 0], 4e-4, 1e-4), ('d_cost', eng.out_env[abi.CLQ_COST].cpu().numpy(), oe[:, 1], 4e-4, 1e-4),
+                   ('d_emission', eng.out_env[abi.CLQ_EMISSION].cpu().numpy(), oe[:, 2], 4e-4, 1e-4),
+                   ('d_reward', eng.district_reward.cpu().numpy(), oe[:, 3], 4e-3 if kind in ('MARL', 'SolarPenaltyReward') else 4e-4, 4e-4)]
+        for key, got, ref, atol, rtol in checks:
+            worst[key] = max(worst.get(key, 0.0), _err(got, ref, atol, rtol))
+    expect = {('g2022_all', 65536): 'cl_step_lean_kernel<4', ('g2023_p2', 65536): 'cl_step_full', ('g2020_cz1', 65536): 'cl_step_full_tp_kernel',
+              ('g2022_all', 262144): 'cl_step_envmajor_kernel'}[(name, E)]
+    assert expect in eng.last_kernels, eng.last_kernels
+    assert max(worst.values()) < 1.0, (name, E, kind, worst)
+
+
 @lru_cache(maxsize=None)
 def _c4_district(fixture: str):
     from citylearn_amd.synthetic import tile_district
