@@ -536,6 +536,8 @@ def run_rank(args):
                    'C4-lean': 'r*_c4lean_pmc_summary.json', 'T9': 'r*_kpi_t9_pmc_summary.json' if args.kpi else 'r*_t9_pmc_summary.json'}.get(cfg, 'none')
         roof['traffic'], roof['traffic_source'] = _pmc_traffic(pattern, wl.kernels or '') if E == DEFAULT_ENVS[cfg] else (None, None)
     if cfg == 'headline':
+        # (`bound` keeps the contract's vocabulary -- this path has no MFMA, so "hbm" -- but at THIS shape the bytes come out of the Infinity Cache)
+        roof['residency'] = 'infinity-cache (fabric bandwidth, not HBM): the HBM-true figure is hbm_streaming' if E * 17 * 52 < 256e6 else 'hbm'
         roof['note'] = ('working set (state 13 MB + outputs 9 MB + action ring 36 MB) fits the 256 MB Infinity Cache: see hbm_streaming '
                         'for the HBM-resident figure')
     units_per_step, n_bldg, spec, tables, what = wl.units_per_step, wl.eng.n_bldg, wl.spec, wl.tables, wl.what
