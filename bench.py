@@ -131,7 +131,11 @@ def reference_cpu_baseline(cores: int, steps: int = 200, timeout: float = 420.0)
     staged = ROOT / 'oracle' / '_ref' / 'reference'
     committed = ROOT / 'profiles' / 'reference_cpu_timing.json'
     err = None
-    if (staged / 'MANIFEST.json').is_file():
+    sys.path.insert(0, str(ROOT / 'oracle' / 'ref_harness'))
+    import stage_reference                                    # (measurement side: only this leg touches oracle/)
+    if (staged / 'MANIFEST.json').is_file() and not stage_reference.verify(staged):
+        err = 'oracle/_ref/reference does not match its manifest (re-run __graft_entry__.build() where /root/reference exists)'
+    elif (staged / 'MANIFEST.json').is_file():
         cmd = [sys.executable, str(ROOT / 'oracle' / 'ref_harness' / 'time_reference.py'), '--root', str(staged), '--skip-c1',
                '--procs', str(cores), '--steps', str(steps), '--out', '-']
         try:

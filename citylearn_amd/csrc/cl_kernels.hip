@@ -263,6 +263,10 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
                 else *dst = s;
             }
         }
+        // (a launch that does NOT defer clears this step's marker: a buffer left behind by an earlier deferred step with the same parity
+        //  must not look current to a later cl_finish_f32)
+        if (!deferred && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+            reinterpret_cast<unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4)[a.t & 1] = 0u;
         if constexpr (!FOLD) return;                             // cl_finish_kernel folds them (second launch)
         else {
         if (!a.fused_finish) return;                             // cl_tuning.finish = 1: likewise

@@ -319,7 +319,8 @@ typedef struct cl_tuning {
                                PREVIOUS step's chunk sums and leaves its own in the scratch rows -- `out_env` then trails the step by one
                                launch until cl_finish_f32 (below) is called.  Only for rewards that do not couple the buildings (not
                                MARL / EV), without CLD_KPI / CLD_F64_MAPS / CLD_WRITE_DETAIL / flexible loads; every other call keeps
-                               the second launch, and cl_finish_f32 is then a no-op.  cl_rollout_seq_f32 finishes its last step itself. */
+                               the second launch, and cl_finish_f32 is then a no-op (a launch that does not defer clears its step parity's marker, so the mode
+                               may change between steps on live buffers).  cl_rollout_seq_f32 finishes its last step itself. */
     int32_t kpi_passes;     /* streaming KPIs of thermal / outage districts and of districts stepped with the detail planes: 0 = inside the step
                                launch where the launch is the one-env-per-lane thermal kernel (cl_step_full_kpi_kernel), else one launch after
                                the step; 1 = always the launch after the step (cl_kpi_kernel; needs CLD_WRITE_DETAIL), 2 = the two passes of

@@ -55,8 +55,9 @@ def stage(source: Path = SOURCE, staged: Path = STAGED) -> dict:
     files['data/misc/battery_choices.yaml'] = hashlib.sha256((staged / 'data' / 'misc' / 'battery_choices.yaml').read_bytes()).hexdigest()
     for d in DATASETS:
         _copy_tree(source / 'data' / 'datasets' / d, staged / 'data' / 'datasets' / d, files, staged)
-    version = {}
-    exec((staged / 'citylearn' / '__init__.py').read_text().split('\n')[0], version)        # `__version__ = '2.4.2'`
+    import re
+    m = re.search(r"__version__\s*=\s*['\"]([^'\"]+)['\"]", (staged / 'citylearn' / '__init__.py').read_text())      # (parsed, not executed)
+    version = {'__version__': m.group(1) if m else None}
     manifest = {'what': 'verbatim staging of the reference package for the cpu_baseline timing (oracle/ref_harness/time_reference.py)',
                 'source': str(source), 'version': version.get('__version__'), 'staged': time.strftime('%Y-%m-%d %H:%M:%S'),
                 'n_files': len(files), 'bytes': sum((staged / f).stat().st_size for f in files), 'files': files}

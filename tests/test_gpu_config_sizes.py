@@ -205,6 +205,18 @@ def test_c4_shard_deferred_finish(fixture, kind):
     ref._pending_t = K - 1
     ref.finish()
     assert torch.equal(ref._out_env, before)
+    # a step that does NOT defer clears its parity's marker: switching the mode on live buffers cannot make a later cl_finish_f32 fold a stale buffer
+    if kind != 'MARL':
+        dfr.step(acts[1], 1)                                           # deferred: marker of parity 1 set, out_env not folded yet
+        dfr.tuning.finish = 1
+        dfr._deferred = False
+        dfr.step(acts[1], 1)                                           # the same step again with the second launch
+        after = dfr._out_env.clone()
+        dfr._pending_t = 1
+        dfr.finish()
+        assert torch.equal(dfr._out_env, after)
+        dfr.tuning.finish = 3
+        dfr._deferred = True
     # step_many (cl_rollout_seq_f32) folds its last step itself
     ref.reset(); dfr.reset()
     ref.step_many(acts); dfr.step_many(acts)
