@@ -150,6 +150,7 @@ def reference_cpu_baseline(cores: int, steps: int = 200, timeout: float = 420.0)
                 try:
                     import torch
                     ref['host_gpu'] = torch.cuda.get_device_name(0) if torch.cuda.is_available() else None
+                    ref['host_gpu_arch'] = getattr(torch.cuda.get_device_properties(0), 'gcnArchName', None) if torch.cuda.is_available() else None
                 except Exception:
                     ref['host_gpu'] = None
                 return ref
