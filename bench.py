@@ -25,7 +25,9 @@ in `rep_ms_per_step`, every rank's median in `rank_ms_per_step`).  The kernel du
 recorded on the launch stream around max(K, 2000) consecutive steps of the same loop enqueued behind a lead-in chunk (no host
 submission gap inside the bracket); `roofline.kernel` is what the library reports having launched (`cl_tuning.kernel_name`).
 
-Prints ONE JSON line (rank 0).  `value` = building-timesteps/s over all GPUs with inputs resident in HBM.  `cpu_baseline`
+Prints ONE JSON line (rank 0).  `value` = building-timesteps/s over all GPUs with inputs resident in HBM.  `roofline.traffic` of the headline
+line (N = 1) is measured by the run itself: two child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (`_live_traffic`;
+`--no-traffic-pass` skips them and falls back to the newest matching summary under profiles/); the other configs read that summary.  `cpu_baseline`
 (headline, N = 1) is the C restatement of the reference arithmetic (oracle/cl_oracle.c, the "port") timed on this box's host
 cores -- all cores, and one core as `cpu_baseline.one_core`; `cpu_baseline.reference` is the reference's own `CityLearnEnv.step`
 timed in the same run on the same host by oracle/ref_harness/time_reference.py (usable-cores processes x 200 steps of 2022_phase_all)
@@ -285,6 +287,46 @@ def _pmc_traffic(pattern: str, kernels: str):
     return None, None
 
 
+def _live_traffic(kernels: str, extra_args, timeout: float = 150.0):
+    """HBM bytes per launch of `kernels`' first kernel MEASURED IN THIS RUN: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counter collection only -- no tracing domain beside it -- as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB units, FETCH_SIZE doubled: its gfx950 wide-load correction), eager launches
+    of the same workload, the dispatches with the kernel's largest grid averaged.  Returns (bytes, source string) or (None, reason)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if Path('/opt/rocm/bin/rocprofv3').exists() else None)
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    needle = (kernels or '').split('+')[0]
+    means, n_disp = {}, 0
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out = tempfile.mkdtemp(prefix=f'cl_pmc_{counter}_', dir='/tmp')
+        cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', out, '-o', 'run', '--', sys.executable, str(Path(__file__).resolve()),
+               '--steps', '200', '--warmup', '50', '--reps', '1', '--no-cpu-baseline', '--no-graph', '--no-streaming', '--no-traffic-pass', *extra_args]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd='/tmp', env={**os.environ, 'TMPDIR': '/tmp'})
+            files = list(Path(out).rglob('*counter_collection.csv'))
+            if p.returncode != 0 or not files:
+                return None, f'rocprofv3 --pmc {counter}: rc {p.returncode} {(p.stderr or "")[-200:]}'
+            rows = []
+            for f in files:
+                with open(f, newline='') as fh:
+                    rows += [r for r in csv.DictReader(fh) if needle and needle in r['Kernel_Name'] and r['Counter_Name'] == counter]
+            if not rows:
+                return None, f'no dispatch of {needle} in the {counter} pass'
+            biggest = max(int(r['Grid_Size']) for r in rows)
+            vals = [float(r['Counter_Value']) for r in rows if int(r['Grid_Size']) == biggest]
+            means[counter], n_disp = sum(vals) / len(vals), len(vals)
+        except subprocess.TimeoutExpired:
+            return None, f'rocprofv3 --pmc {counter} exceeded {timeout:.0f} s'
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * means['FETCH_SIZE'] + means['WRITE_SIZE']) * 1024.0, \
+        f'measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes, {n_disp} dispatches of {needle} (2 x FETCH + WRITE, KiB)'
+
+
 class StepWorkload:
     """Mode A: one env step per launch on a district's tables (`cl_step_f32`), fresh actions from an 8-tensor ring."""
 
@@ -540,6 +582,13 @@ def run_rank(args):
         pattern = {'headline': 'r*_bench_pmc_summary.json', 'C2': 'r*_c2_pmc_summary.json', 'C4': 'r*_c4_pmc_summary.json',
                    'C4-lean': 'r*_c4lean_pmc_summary.json', 'T9': 'r*_kpi_t9_pmc_summary.json' if args.kpi else 'r*_t9_pmc_summary.json'}.get(cfg, 'none')
         roof['traffic'], roof['traffic_source'] = _pmc_traffic(pattern, wl.kernels or '') if E == DEFAULT_ENVS[cfg] else (None, None)
+    if cfg == 'headline' and world == 1 and rank == 0 and not args.no_traffic_pass and E == DEFAULT_ENVS[cfg] and not args.kpi and not args.f64_maps:
+        live, how = _live_traffic(wl.kernels or '', [])
+        if live is not None:
+            roof['traffic_committed_file'] = {'traffic': roof.get('traffic'), 'source': roof.get('traffic_source')}
+            roof['traffic'], roof['traffic_source'] = live, how
+        else:
+            roof['traffic_live_error'] = how
     if cfg == 'headline':
         # (`bound` keeps the contract's vocabulary -- this path has no MFMA, so "hbm" -- but at THIS shape the bytes come out of the Infinity Cache)
         roof['residency'] = 'infinity-cache (fabric bandwidth, not HBM): the HBM-true figure is hbm_streaming' if E * 17 * 52 < 256e6 else 'hbm'
@@ -639,6 +688,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-graph', action='store_true', help='launch every step from Python instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-configs', action='store_true', help='N > 1, headline: skip the C4 / C4-lean / C5 lines measured in the same run (`extra_configs`)')
+    ap.add_argument('--no-traffic-pass', action='store_true', help='headline, N = 1: skip the two rocprofv3 --pmc child runs that measure roofline.traffic live')
     ap.add_argument('--no-streaming', action='store_true', help='skip the 17 x 1 048 576 HBM-streaming roofline entry of the headline')
     ap.add_argument('--f64-maps', action='store_true', help="CLD_F64_MAPS: battery map in the reference's mixed float64 / float32 precision (step configs)")
     ap.add_argument('--kpi', action='store_true', help='CLD_KPI: update the streaming KPI accumulators every step (mode A-kpi of SURVEY 8d; step configs)')

@@ -17,12 +17,12 @@ FAIL=0
 # ---- headline ----
 python bench.py > $OUT/bench_line.json 2>$OUT/bench_line.err
 python bench.py --steps 20 --warmup 5 > $OUT/bench_line_driver_flags.json 2>$OUT/bench_line_driver_flags.err
-BENCH="python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-streaming"
+BENCH="python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-streaming --no-traffic-pass"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2>$OUT/trace.log
 cp $OUT/trace/*kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
 K=$(kernel_of $OUT/bench_line.json)
 for c in FETCH_SIZE WRITE_SIZE; do
-  pmc_pass bench_$c $c -- python bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-graph --no-streaming
+  pmc_pass bench_$c $c -- python bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-graph --no-streaming --no-traffic-pass
 done
 python scripts/pmc_summary.py $OUT/bench_pmc_summary.json "$K" $OUT/pmc_bench_FETCH_SIZE/*counter_collection.csv $OUT/pmc_bench_WRITE_SIZE/*counter_collection.csv > /dev/null
 python scripts/check_profiles.py --duration-tol 0.05 $OUT/bench_line.json $OUT/bench_pmc_summary.json $OUT/bench_kernel_stats.csv >> $OUT/check.log || FAIL=1
@@ -65,7 +65,7 @@ python scripts/pmc_by_kernel.py cl_lstm_kernel $OUT/pmc_c3_SQ/*counter_collectio
 pmc_pass c5_SQ SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- python bench.py --config C5 --steps 40 --warmup 10 --reps 1 --no-graph
 python scripts/pmc_by_kernel.py cl_rollout_kernel $OUT/pmc_c5_SQ/*counter_collection.csv > $OUT/c5_rollout_sq_by_kernel.jsonl
 # ---- streaming KPIs (mode A-kpi), CLD_F64_MAPS cost, user-level step ----
-python bench.py --kpi --no-streaming --no-cpu-baseline > $OUT/bench_kpi.json 2>$OUT/bench_kpi.err
+python bench.py --kpi --no-streaming --no-cpu-baseline --no-traffic-pass > $OUT/bench_kpi.json 2>$OUT/bench_kpi.err
 python bench.py --kpi --config C3 > $OUT/bench_kpi_C3.json 2>$OUT/bench_kpi_C3.err
 # thermal district with streaming KPIs inside the step launch (cl_step_full_kpi_kernel): line, kernel stats, HBM counters
 python bench.py --kpi --config T9 --no-cpu-baseline > $OUT/bench_kpi_T9.json 2>$OUT/bench_kpi_T9.err
@@ -78,7 +78,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
 done
 python scripts/pmc_summary.py $OUT/kpi_t9_pmc_summary.json "$KC" $OUT/pmc_kpi_t9_FETCH_SIZE/*counter_collection.csv $OUT/pmc_kpi_t9_WRITE_SIZE/*counter_collection.csv > /dev/null
 python scripts/check_profiles.py $OUT/bench_kpi_T9.json $OUT/kpi_t9_pmc_summary.json >> $OUT/check.log || FAIL=1
-python bench.py --f64-maps --no-streaming --no-cpu-baseline > $OUT/bench_f64_maps.json 2>$OUT/bench_f64_maps.err
+python bench.py --f64-maps --no-streaming --no-cpu-baseline --no-traffic-pass > $OUT/bench_f64_maps.json 2>$OUT/bench_f64_maps.err
 for s in env_step_bench f64_cost ev_step_bench observe_bench; do
   timeout 600 python scripts/$s.py > $OUT/${s}.log 2>$OUT/$s.err
 done

@@ -31,10 +31,24 @@ def test_two_ranks_on_one_gpu_without_a_launcher():
     assert len(two['rank_ms_per_step']) == 2 and two['control_backend'] == 'gloo'
     assert two['ms_per_step'] >= max(two['rank_ms_per_step']) * 0.5 and two['value'] > 1e9
     assert 'cl_step_lean_kernel<4, false, true>' in two['roofline']['kernel']
-    one = _bench('--steps', '20', '--warmup', '5', '--reps', '3', '--no-streaming', '--no-cpu-baseline')
+    one = _bench('--steps', '20', '--warmup', '5', '--reps', '3', '--no-streaming', '--no-cpu-baseline', '--no-traffic-pass')
     assert one['ranks'] == 1 and one['n_gpus'] == 1 and 'oversubscribed' not in one
     assert one['roofline']['kernel'] == 'cl_step_lean_kernel<4, false, true>' and 0.3 < one['roofline']['frac'] < 1.0
     assert one['value'] == pytest.approx(17 * 65536 / (one['ms_per_step'] * 1e-3))
+
+
+def test_headline_line_measures_its_hbm_traffic_in_the_run():
+    """`roofline.traffic` of the default line is MEASURED by the run itself (two `rocprofv3 --pmc` child passes, FETCH_SIZE / WRITE_SIZE,
+    counter collection only), not read from a committed file: it must land on the algorithmic byte count (no wasted re-reads)."""
+    import shutil
+    if shutil.which('rocprofv3') is None and not Path('/opt/rocm/bin/rocprofv3').exists():
+        pytest.skip('rocprofv3 not installed')
+    out = _bench('--steps', '20', '--warmup', '5', '--reps', '2', '--no-streaming', '--no-cpu-baseline')
+    r = out['roofline']
+    assert 'traffic_live_error' not in r, r.get('traffic_live_error')
+    assert r['traffic_source'].startswith('measured in this run') and 'cl_step_lean_kernel<4, false, true>' in r['traffic_source']
+    algorithmic = r['algorithmic_bytes_per_unit'] * r['units_per_launch']
+    assert 0.97 < r['traffic'] / algorithmic < 1.10, (r['traffic'], algorithmic)
 
 
 def test_dry_run_is_refused_where_a_gpu_is_visible():
@@ -90,7 +104,7 @@ def test_thermal_kpi_line_runs_the_kpis_inside_the_step_launch():
 def test_rccl_control_plane_keeps_stdout_to_the_one_line():
     """A lone rank with the process group forced up (CL_BENCH_FORCE_DIST): the control plane is RCCL -- the communicator really is
     created on this GPU -- and RCCL's banner, which goes through buffered C stdio, does not end up on stdout behind the JSON line."""
-    out = _bench('--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-streaming', env={'CL_BENCH_FORCE_DIST': '1'})      # (_bench asserts the single line)
+    out = _bench('--steps', '20', '--warmup', '5', '--no-cpu-baseline', '--no-streaming', '--no-traffic-pass', env={'CL_BENCH_FORCE_DIST': '1'})      # (_bench asserts the single line)
     # (RCCL came up on every box of round 3; should a box refuse it, the fallback must have taken over -- still one line)
     assert out['world_size_seen'] == 1 and (out['control_backend'] == 'nccl' or out.get('control_fallback'))
 
