@@ -299,6 +299,11 @@ def _live_traffic(kernels: str, extra_args, timeout: float = 150.0):
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if Path('/opt/rocm/bin/rocprofv3').exists() else None)
     if exe is None:
         return None, 'rocprofv3 not found'
+    # never nest: a run that is itself being profiled (rocprofv3 exports ROCPROF* / ROCP_* / ROCPROFILER_* and preloads its tool library) would
+    # hand its tracing tool to the children -- counters beside a tracing domain is the one combination the profiling guide forbids
+    profiled = [k for k in os.environ if k.startswith(('ROCPROF', 'ROCP_', 'ROCPROFILER'))] or 'rocprofiler' in os.environ.get('LD_PRELOAD', '')
+    if profiled:
+        return None, 'this run is itself under a rocprofiler tool: no nested counter pass'
     needle = (kernels or '').split('+')[0]
     means, n_disp = {}, 0
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
