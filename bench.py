@@ -26,7 +26,7 @@ recorded on the launch stream around max(K, 2000) consecutive steps of the same 
 submission gap inside the bracket); `roofline.kernel` is what the library reports having launched (`cl_tuning.kernel_name`).
 
 Prints ONE JSON line (rank 0).  `value` = building-timesteps/s over all GPUs with inputs resident in HBM.  `roofline.traffic` of the headline
-line (N = 1) is measured by the run itself: two child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (`_live_traffic`;
+line (N = 1) and of its `hbm_streaming` entry is measured by the run itself: two child runs each of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (`_live_traffic`;
 `--no-traffic-pass` skips them and falls back to the newest matching summary under profiles/); the other configs read that summary.  `cpu_baseline`
 (headline, N = 1) is the C restatement of the reference arithmetic (oracle/cl_oracle.c, the "port") timed on this box's host
 cores -- all cores, and one core as `cpu_baseline.one_core`; `cpu_baseline.reference` is the reference's own `CityLearnEnv.step`
@@ -287,7 +287,7 @@ def _pmc_traffic(pattern: str, kernels: str):
     return None, None
 
 
-def _live_traffic(kernels: str, extra_args, timeout: float = 150.0):
+def _live_traffic(kernels: str, extra_args, timeout: float = 150.0, steps: int = 200, warmup: int = 50):
     """HBM bytes per launch of `kernels`' first kernel MEASURED IN THIS RUN: two child runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counter collection only -- no tracing domain beside it -- as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB units, FETCH_SIZE doubled: its gfx950 wide-load correction), eager launches
@@ -309,7 +309,7 @@ def _live_traffic(kernels: str, extra_args, timeout: float = 150.0):
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         out = tempfile.mkdtemp(prefix=f'cl_pmc_{counter}_', dir='/tmp')
         cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', out, '-o', 'run', '--', sys.executable, str(Path(__file__).resolve()),
-               '--steps', '200', '--warmup', '50', '--reps', '1', '--no-cpu-baseline', '--no-graph', '--no-streaming', '--no-traffic-pass', *extra_args]
+               '--steps', str(steps), '--warmup', str(warmup), '--reps', '1', '--no-cpu-baseline', '--no-graph', '--no-streaming', '--no-traffic-pass', *extra_args]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd='/tmp', env={**os.environ, 'TMPDIR': '/tmp'})
             files = list(Path(out).rglob('*counter_collection.csv'))
@@ -608,15 +608,26 @@ def run_rank(args):
         wl_s = build_workload(cfg, STREAMING_ENVS, device, rank, world, tuning, args.f64_maps, args.kpi)
         _, _, launch, _, _ = measure(wl_s, 5, s_steps, 3, 2000)
         a = wl_s.units_per_step * wl_s.bytes_per_unit() / launch / 1e9
+        s_units, s_bpu, s_kernels = wl_s.units_per_step, wl_s.bytes_per_unit(), wl_s.kernels
         s_traffic, s_source = _pmc_traffic('r*_streaming_pmc_summary.json', wl_s.kernels or '')
+        s_live_error = None
+        if world == 1 and rank == 0 and not args.no_traffic_pass and not args.kpi and not args.f64_maps:
+            wl_s = None                                    # (the child runs allocate the same 17 x 1 048 576 planes)
+            torch.cuda.empty_cache()
+            live, how = _live_traffic(s_kernels or '', ['--envs-per-gpu', str(STREAMING_ENVS)], steps=30, warmup=5)
+            if live is not None:
+                s_traffic, s_source = live, how
+            else:
+                s_live_error = how
         roof['hbm_streaming'] = {
-            'workload': f'same tables x {STREAMING_ENVS} envs per GPU ({wl_s.units_per_step * wl_s.bytes_per_unit() / 1e6:.0f} MB '
+            'workload': f'same tables x {STREAMING_ENVS} envs per GPU ({s_units * s_bpu / 1e6:.0f} MB '
                         f'of algorithmic traffic per launch, beyond the 256 MB Infinity Cache)',
             'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
-            'frac_vs_measured_copy': a / HBM_MEASURED_COPY_GBS, 'kernel': wl_s.kernels, 'launch_us': launch * 1e6,
-            'units_per_launch': wl_s.units_per_step, 'steps': s_steps, 'traffic': s_traffic, 'traffic_source': s_source,
-            'value': world * wl_s.units_per_step / launch}
-        del wl_s
+            'frac_vs_measured_copy': a / HBM_MEASURED_COPY_GBS, 'kernel': s_kernels, 'launch_us': launch * 1e6,
+            'units_per_launch': s_units, 'steps': s_steps, 'traffic': s_traffic, 'traffic_source': s_source,
+            **({'traffic_live_error': s_live_error} if s_live_error else {}),
+            'value': world * s_units / launch}
+        wl_s = None
         torch.cuda.empty_cache()
 
     # N > 1 on a real node: BASELINE configs 4 and 5 measured in the same lease (their per-GPU shards, weak scaling like the headline) -- the
