@@ -287,7 +287,10 @@ def _pmc_traffic(pattern: str, kernels: str):
     return None, None
 
 
-def _live_traffic(kernels: str, extra_args, timeout: float = 150.0, steps: int = 200, warmup: int = 50):
+_LIVE_TRAFFIC_DISABLED = None          # why the counter passes were given up in this run (a failing / hanging rocprofv3 is tried ONCE: 60 s at most)
+
+
+def _live_traffic(kernels: str, extra_args, timeout: float = 60.0, steps: int = 200, warmup: int = 50):
     """HBM bytes per launch of `kernels`' first kernel MEASURED IN THIS RUN: two child runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counter collection only -- no tracing domain beside it -- as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; KiB units, FETCH_SIZE doubled: its gfx950 wide-load correction), eager launches
@@ -296,6 +299,9 @@ def _live_traffic(kernels: str, extra_args, timeout: float = 150.0, steps: int =
     import shutil
     import subprocess
     import tempfile
+    global _LIVE_TRAFFIC_DISABLED
+    if _LIVE_TRAFFIC_DISABLED:
+        return None, _LIVE_TRAFFIC_DISABLED
     exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if Path('/opt/rocm/bin/rocprofv3').exists() else None)
     if exe is None:
         return None, 'rocprofv3 not found'
@@ -314,7 +320,8 @@ def _live_traffic(kernels: str, extra_args, timeout: float = 150.0, steps: int =
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd='/tmp', env={**os.environ, 'TMPDIR': '/tmp'})
             files = list(Path(out).rglob('*counter_collection.csv'))
             if p.returncode != 0 or not files:
-                return None, f'rocprofv3 --pmc {counter}: rc {p.returncode} {(p.stderr or "")[-200:]}'
+                _LIVE_TRAFFIC_DISABLED = f'rocprofv3 --pmc {counter}: rc {p.returncode} {(p.stderr or "")[-200:]}'
+                return None, _LIVE_TRAFFIC_DISABLED
             rows = []
             for f in files:
                 with open(f, newline='') as fh:
@@ -325,7 +332,8 @@ def _live_traffic(kernels: str, extra_args, timeout: float = 150.0, steps: int =
             vals = [float(r['Counter_Value']) for r in rows if int(r['Grid_Size']) == biggest]
             means[counter], n_disp = sum(vals) / len(vals), len(vals)
         except subprocess.TimeoutExpired:
-            return None, f'rocprofv3 --pmc {counter} exceeded {timeout:.0f} s'
+            _LIVE_TRAFFIC_DISABLED = f'rocprofv3 --pmc {counter} exceeded {timeout:.0f} s'
+            return None, _LIVE_TRAFFIC_DISABLED
         finally:
             shutil.rmtree(out, ignore_errors=True)
     return (2.0 * means['FETCH_SIZE'] + means['WRITE_SIZE']) * 1024.0, \
