@@ -147,6 +147,28 @@ def test_bench_spawns_its_own_ranks():
 
 
 @_dry
+def test_bench_eight_ranks_like_the_scaling_run():
+    """The driver's N = 8 command shapes with the dry-run rank body: eight self-spawned ranks, and eight ranks under torch.distributed.run --
+    one line on stdout, every rank's timing in rank order, MAX over ranks."""
+    import json
+    import subprocess
+    from citylearn_amd.parallel import free_port
+    p = _bench('--gpus', '8', '--steps', '20', '--warmup', '5', env={'CL_BENCH_DRY_RUN': '1'}, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(p.stdout.strip().splitlines()) == 1 and out['n_gpus'] == 8 and out['world_size_seen'] == 8
+    assert out['rank_ms_per_step'] == pytest.approx([float(r + 1) for r in range(8)]) and out['ms_per_step'] == pytest.approx(8.0)
+    e = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    e['CL_BENCH_DRY_RUN'] = '1'
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                        '--master-port', str(free_port()), str(ROOT / 'bench.py'), '--gpus', '8', '--steps', '20', '--warmup', '5'],
+                       env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])['rank_ms_per_step'] == pytest.approx([float(r + 1) for r in range(8)])
+
+
+@_dry
 def test_bench_under_torchrun_leaves_one_line_on_the_merged_stdout():
     """What the driver runs for N > 1: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`.  The launcher merges the
     ranks' stdout; only rank 0 may write there (the other ranks park descriptor 1 on stderr) -- here with the dry-run rank body."""
