@@ -132,19 +132,45 @@ def parse_cpulist(text: str) -> List[int]:
     return cpus
 
 
+def format_cpulist(cpus: Sequence[int]) -> str:
+    """[64, 65, 66, 192, 193] -> '64-66,192-193' (the inverse of `parse_cpulist`)."""
+    out, run = [], []
+    for c in sorted(cpus):
+        if run and c == run[-1] + 1:
+            run.append(c)
+        else:
+            if run:
+                out.append(run)
+            run = [c]
+    if run:
+        out.append(run)
+    return ','.join(f'{r[0]}-{r[-1]}' if len(r) > 1 else str(r[0]) for r in out)
+
+
 def pick_cores(node_cpus: Sequence[int], allowed: Sequence[int], ranks_on_node: int, index: int, min_cores: int = 2) -> List[int]:
     """The launch thread(s) of one rank: slice `index` of `ranks_on_node` equal slices of the cores that are both on the GPU's NUMA
-    node and in the process's affinity mask, in core order.  Falls back to the whole allowed set when the node has fewer than
-    `min_cores` usable cores per rank (a cgroup that hands out cores of another node, an unknown topology): pinning must never leave
-    a rank with less than it had."""
+    node and in the process's affinity mask.  Every CONTIGUOUS run of the node's cpulist is cut separately ('64-127,192-255' is one
+    set of physical cores listed twice -- first hardware threads, then their SMT siblings: cutting the flat list in two would hand rank 0
+    every core's first thread and rank 1 its sibling), so a rank gets whole cores.  Falls back to the whole allowed set when the node
+    has fewer than `min_cores` usable cores per rank (a cgroup that hands out cores of another node, an unknown topology): pinning must
+    never leave a rank with less than it had."""
     allowed_set = set(allowed)
     usable = [c for c in node_cpus if c in allowed_set]
     if ranks_on_node < 1 or not 0 <= index < ranks_on_node:
         raise ValueError(f'rank slot {index} of {ranks_on_node}')
-    per = len(usable) // ranks_on_node
-    if per < min_cores:
+    if len(usable) // ranks_on_node < min_cores:
         return sorted(allowed_set)
-    return usable[index * per:(index + 1) * per]
+    runs: List[List[int]] = []
+    for c in usable:
+        if runs and c == runs[-1][-1] + 1:
+            runs[-1].append(c)
+        else:
+            runs.append([c])
+    mine: List[int] = []
+    for run in runs:
+        per = len(run) // ranks_on_node
+        mine.extend(run[index * per:(index + 1) * per] if per else [])
+    return mine if len(mine) >= min_cores else usable[index * (len(usable) // ranks_on_node):(index + 1) * (len(usable) // ranks_on_node)]
 
 
 def gpu_numa_node(pci_bus_id: str, sysfs: str = '/sys') -> int:
@@ -179,8 +205,7 @@ def pin_rank_to_gpu_node(dev_index: int, local_rank: int, local_world: int, sysf
         allowed = sorted(os.sched_getaffinity(0))
         cores = pick_cores(node_cpus, allowed, len(same), same.index(local_rank))
         os.sched_setaffinity(0, cores)
-        return {'numa_node': node, 'cores': f'{cores[0]}-{cores[-1]}' if cores == list(range(cores[0], cores[-1] + 1)) else cores,
-                'n_cores': len(cores), 'ranks_on_node': len(same)}
+        return {'numa_node': node, 'cores': format_cpulist(cores), 'n_cores': len(cores), 'ranks_on_node': len(same)}
     except Exception:                                     # noqa: BLE001 -- topology files differ between kernels / containers
         return None
 

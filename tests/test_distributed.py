@@ -306,13 +306,15 @@ def test_control_plane_converges_when_rccl_fails_on_one_rank_only():
 
 def test_rank_affinity_arithmetic(tmp_path):
     """`pin_rank_to_gpu_node`'s pieces: cpulist parsing, the per-rank slice of a NUMA node's cores, the fallbacks."""
-    from citylearn_amd.parallel import gpu_numa_node, parse_cpulist, pick_cores
+    from citylearn_amd.parallel import format_cpulist, gpu_numa_node, parse_cpulist, pick_cores
+    assert format_cpulist([64, 65, 66, 192, 193, 7]) == '7,64-66,192-193' and parse_cpulist(format_cpulist([3, 4, 9])) == [3, 4, 9]
     assert parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist('') == [] and parse_cpulist('5') == [5]
     node0 = parse_cpulist('0-63,128-191')
     allowed = list(range(256))
     slices = [pick_cores(node0, allowed, 4, i) for i in range(4)]
     assert all(len(s) == 32 for s in slices) and sorted(c for s in slices for c in s) == node0       # disjoint, cover the node
-    assert slices[0] == list(range(32)) and slices[3] == list(range(160, 192))
+    # every contiguous run is cut separately: a rank gets a core's first hardware thread AND its SMT sibling (c, c + 128)
+    assert slices[0] == list(range(16)) + list(range(128, 144)) and slices[3] == list(range(48, 64)) + list(range(176, 192))
     # the affinity mask (a cpuset) cuts the node: slices come from the intersection
     assert pick_cores(node0, list(range(16)), 2, 1) == list(range(8, 16))
     # a cpuset that has (almost) nothing on the GPU's node: the rank keeps every core it was allowed
