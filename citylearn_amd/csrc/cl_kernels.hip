@@ -263,13 +263,13 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
                 else *dst = s;
             }
         }
-        // (a launch that does NOT defer clears this step's marker: a buffer left behind by an earlier deferred step with the same parity
-        //  must not look current to a later cl_finish_f32)
-        if (!deferred && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-            reinterpret_cast<unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4)[a.t & 1] = 0u;
         if constexpr (!FOLD) return;                             // cl_finish_kernel folds them (second launch)
         else {
         if (!a.fused_finish) return;                             // cl_tuning.finish = 1: likewise
+        // (a launch that does NOT defer clears this step's marker -- here for the in-launch fold, in cl_finish_kernel for the second launch:
+        //  a buffer left behind by an earlier deferred step with the same parity must not look current to a later cl_finish_f32)
+        if (a.fused_finish == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+            reinterpret_cast<unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4)[a.t & 1] = 0u;
         if (a.fused_finish == 2) {
             // the previous step's district sums, behind this step's partial-sum stores (the exchange tile was complete at the barrier above)
             fold_finish<TILE>(a, lds_fold, w, lane);
@@ -1019,6 +1019,8 @@ __global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a, const
     const long long plane = (long long)a.n_bldg * a.n_env;
     const float* scratch = a.out_bldg + (long long)CLO_RESERVED * plane;
     int n_chunks = a.n_chunks;
+    if (!deferred && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)         // (this step did not defer: see district_reduce)
+        reinterpret_cast<unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4)[a.t & 1] = 0u;
     if (deferred) {
         const unsigned* marker = reinterpret_cast<const unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4);
         if (marker[a.t & 1] != (unsigned)a.t + 1u) return;                   // (uniform) step t did not defer its finish: out_env is already final
