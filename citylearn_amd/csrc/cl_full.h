@@ -482,6 +482,19 @@ CL_DEV void full_step_body(const StepArgs& a) {
     [[maybe_unused]] bool fold_issued = false, folded = false;
     // (deferred finish) [64 chunks][16 district sums], behind the staged parameter blocks
     [[maybe_unused]] float* lds_fold = lds + (size_t)a.nw * NQ * TILE + (LP ? (size_t)a.b_chunk * CL_LP_WORDS : 0);
+    // (LP) The wave's FIRST building does not wait for the staging round trip: its eight header words (flags + action columns) come through
+    // scalar loads from the parameter table itself and its plane / action loads are in flight before the staging loads are (round 4; as the
+    // loop's first statement they sat behind staging loads -> LDS writes -> barrier: one more dependent round trip at the head of every
+    // workgroup of a single-generation launch).
+    [[maybe_unused]] FullIn<F> early;
+    [[maybe_unused]] bool have_early = false;
+    if constexpr (LP) {
+        if (live && b_lo + w < b_hi) {
+            full_load_in<VEC, false>(early, a, a.params + (long long)(b_lo + w) * CL_NP + CLP_F_FIRST, b_lo + w, env0, plane);
+            have_early = true;
+            if constexpr (FOLDK) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane); fold_issued = true; }
+        }
+    }
     if constexpr (LP) {
         static_assert(!DETAIL, "the evaluate()-time COP row of the detail planes is not staged");
         const int n_words = (b_hi - b_lo) * CL_LP_WORDS;
@@ -494,11 +507,10 @@ CL_DEV void full_step_body(const StepArgs& a) {
         __syncthreads();
     }
     [[maybe_unused]] float* hand = lds + (size_t)a.nw * NQ * TILE;        // (KPI) [n_bldg][TILE]: the buildings' baselines of this step
-    for (int b = b_lo + w; b < b_hi; b += a.nw) {
-        if (live) {
+    // one building of the wave: `cur` = its inputs (in flight); everything else of the unit
+    auto building = [&](const int b, FullIn<F>& cur) {
+        {
             const uint32_t* __restrict__ f = LP ? stage + (b - b_lo) * CL_LP_WORDS : a.params + (long long)b * CL_NP + CLP_F_FIRST;
-            FullIn<F> cur;
-            full_load_in<VEC, LP>(cur, a, f, b, env0, plane);
             if constexpr (FOLDK) {
                 // (deferred finish: this wave's share of the previous step's chunk sums, issued behind the first building's plane loads --
                 //  fold_prefetch's note)
@@ -586,6 +598,15 @@ CL_DEV void full_step_body(const StepArgs& a) {
 #ifdef CL_TRACE
             if (tr_i < 2) ++tr_i;
 #endif
+        }
+    };
+    if (live) {
+        int b = b_lo + w;
+        if (LP && have_early) { building(b, early); b += a.nw; }              // (peeled: the loop body proper never sees `early`)
+        for (; b < b_hi; b += a.nw) {
+            FullIn<F> cur;
+            full_load_in<VEC, LP>(cur, a, LP ? stage + (b - b_lo) * CL_LP_WORDS : a.params + (long long)b * CL_NP + CLP_F_FIRST, b, env0, plane);
+            building(b, cur);
         }
     }
     CL_TRACE_AFTER(13, q_net[0]);
