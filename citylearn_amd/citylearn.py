@@ -393,7 +393,9 @@ class CityLearnEnv(_GymEnv):
         """Where `Building.___demand_limit_check` (building.py:1825-1829) fires, for every (step, building): the reference asserts, per end
         use and outside a power outage, `demand <= max_device_output or |demand - max_device_output| < TOLERANCE` with
         `max_device_output = (nominal_power - electricity_consumption[t]) * cop` (energy_model.py:121-124, 252-281, 378-401) -- the DEVICE
-        alone, whatever the storage could add, in float64.  Every operand is env-independent (file demand, weather, device size; the
+        alone, whatever the storage could add.  Precision: float32 demand against a float64 product of the float32 available power and
+        the COP (the chain is restated below; within ~1e-7 relative of the limit an all-float64 evaluation could disagree with the reference
+        about raising).  Every operand is env-independent (file demand, weather, device size; the
         device's own consumption of the step is still zero when its update runs, except at t = 0 where reset() has booked the ideal
         load once -- SURVEY App. B1), so the table is evaluated once per episode on the host in the reference's precision.  (Round 3
         derived the error from the device's float32 expected / served planes: two differently associated fp32 sums whose rounding exceeds
@@ -411,13 +413,17 @@ class CityLearnEnv(_GymEnv):
             warm = (b.dynamics.lookback + 1) if b.dynamics is not None else None
             for end_use, key, dev, heating in (('cooling', 'cooling_demand', b.cooling_device, False),
                                                ('heating', 'heating_demand', b.heating_device, True), ('dhw', 'dhw_demand', b.dhw_device, True)):
-                demand = np.asarray(b.series[key][rows], dtype=np.float64)
+                # the reference's dtype chain (NumPy >= 2 promotion): file demand and the device's electricity_consumption are float32
+                # series, `nominal_power - consumption[t]` is therefore a float32 difference (the Python float is the weak operand,
+                # energy_model.py:121-124); np.min([flexibility, available]) lifts it to float64 and the product with the COP is float64
+                demand32 = np.asarray(b.series[key][rows], dtype=np.float32)
+                demand = demand32.astype(np.float64)
                 cop = np.asarray(dev.cop(t_out, heating), dtype=np.float64) if dev.is_heat_pump else np.full(T, float(dev.efficiency))
-                booked = np.zeros(T)
+                booked = np.zeros(T, dtype=np.float32)
                 if self.reference_quirks:
                     with np.errstate(divide='ignore', invalid='ignore'):
-                        booked[0] = demand[0] / cop[0] * r if cop[0] != 0 else 0.0
-                max_out = (float(dev.nominal_power) - booked) * cop
+                        booked[0] = np.float32(demand32[0] / np.float32(cop[0])) * np.float32(r) if cop[0] != 0 else 0.0
+                max_out = (np.float32(dev.nominal_power) - booked).astype(np.float64) * cop
                 bad = live & ~(demand <= max_out) & ~(np.abs(demand - max_out) < 1e-4)          # data.py:18 TOLERANCE
                 if warm is not None and end_use != 'dhw':
                     bad[warm:] = False

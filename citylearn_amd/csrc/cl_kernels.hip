@@ -1011,7 +1011,9 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
 // to 64 chunks), then the 16 wave partials are summed in a fixed order through LDS -- deterministic.  (The first version let one
 // workgroup walk all four quantities of its 64 envs: 16 workgroups and four dependent rounds at 1024 envs, 4.7 us of a 22 us step.)
 // `deferred` (cl_finish_f32): fold buffer t & 1 of the double-buffered scratch rows, and only if its marker says it holds step t's sums.
-__global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a, const int deferred) {
+// `ret_env` (chunked fused rollout, cl_rollout_f32): workgroup row NQ adds the chunks' shares of the K-step return -- one scratch row per
+// chunk behind the n_chunks x NQ partial sums -- to ret_env, in the same association.
+__global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a, const int deferred, float* __restrict__ ret_env) {
     __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
@@ -1036,7 +1038,7 @@ __global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a, const
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c0 + 16 * j;
-                v[j] = c < n_chunks ? scratch[((long long)c * NQ + q) * a.n_env + e] : 0.0f;
+                v[j] = c < n_chunks ? scratch[(q < NQ ? (long long)c * NQ + q : (long long)n_chunks * NQ + c) * a.n_env + e] : 0.0f;
                 vn[j] = (marl && c < n_chunks) ? scratch[((long long)c * NQ + CLQ_NET) * a.n_env + e] : 0.0f;
             }
 #pragma unroll
@@ -1061,7 +1063,10 @@ __global__ void __launch_bounds__(1024) cl_finish_kernel(const StepArgs a, const
             t *= fmaxf(0.0f, n);
         }
     }
-    if (w == 0 && e < a.n_env) a.out_env[(long long)q * a.n_env + e] = t;
+    if (w == 0 && e < a.n_env) {
+        if (q < NQ) a.out_env[(long long)q * a.n_env + e] = t;
+        else ret_env[e] += t;
+    }
 }
 
 // ---- streaming KPI accumulators (CLD_KPI): two small passes over the detail planes the step kernel just wrote ----
@@ -1264,26 +1269,30 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
 // The same switch is a loss for the LSTM kernel (109.8 -> 115.5 us) and the chunked thermal launches (14.75 -> 15.08 us) and within
 // the noise for the env-major kernel, hence per translation unit and not for the whole library.  The lean launches with a fused
 // epilogue (flexible loads, KPI accumulators, observation tile) were not measured and stay in the main unit.
-extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int key, int pin, unsigned grid, unsigned block, size_t lds,
+extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int key, int pin, unsigned grid, unsigned grid_y, unsigned block, size_t lds,
                                                                           void* stream, const void* rollout_args);
 extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_lean(int vec, int nt, unsigned grid_x, unsigned grid_y, unsigned block, size_t lds,
                                                                        void* stream, const void* step_args);
 
 #ifdef CL_TU_NOSLP
-extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int key, int pin, unsigned grid, unsigned block_threads, size_t lds,
+extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int key, int pin, unsigned grid_x, unsigned grid_y, unsigned block_threads, size_t lds,
                                                                           void* stream, const void* rollout_args) {
     const RolloutArgs& r = *static_cast<const RolloutArgs*>(rollout_args);       // the struct of the including translation unit: same source
-    const dim3 block(block_threads);
+    const dim3 block(block_threads), grid(grid_x, grid_y);
     hipStream_t s = (hipStream_t)stream;
     switch (key) {        // (full ? 100 : 0) + 10 * envs per lane + buildings per wave
-    case 11: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 1>), dim3(grid), block, lds, s, r); break;
+    case 11: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 1>), grid, block, lds, s, r); break;
     case 12:
-        if (pin) hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2>), dim3(grid), block, lds, s, r);
-        else hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, false>), dim3(grid), block, lds, s, r);      // whole launch resident at once: see PIN
+        if (pin) hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2>), grid, block, lds, s, r);
+        else hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, false>), grid, block, lds, s, r);      // whole launch resident at once: see PIN
         break;
-    case 21: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 1>), dim3(grid), block, lds, s, r); break;
-    case 22: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2>), dim3(grid), block, lds, s, r); break;
-    case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), dim3(grid), block, lds, s, r); break;
+    case 21: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 1>), grid, block, lds, s, r); break;
+    case 22: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2>), grid, block, lds, s, r); break;
+    case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), grid, block, lds, s, r); break;
+    // building-chunked districts (gridDim.y workgroup rows; cl_rollout.h)
+    case 1012: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, true, true>), grid, block, lds, s, r); break;
+    case 1022: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2, true, true>), grid, block, lds, s, r); break;
+    case 1111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1, true, true>), grid, block, lds, s, r); break;
     default: return -1;
     }
     return (int)hipGetLastError();
@@ -1583,7 +1592,11 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
         if (a.n_chunks == 1) a.b_chunk = dims->n_bldg;
         else a.nw = (tun.b_chunk > 0 && tun.nw > 0) ? tun.nw : 16;
-        if (a.n_chunks * NQ + 1 > dims->n_bldg) return fail(CL_EINVAL, "b_chunk=%d leaves no room for the %d chunk partial sums and their tickets", a.b_chunk, a.n_chunks);
+        // the reserved plane holds the chunk partial sums (twice under the deferred finish), the tickets of the in-launch fold and, in its
+        // last 16 bytes, the marker words EVERY chunked launch touches (a non-deferring one clears its step's marker)
+        const long long scratch_words = (long long)a.n_chunks * NQ * dims->n_env * (tun.finish == 3 ? 2 : 1) + grid_x + 4;
+        if (scratch_words > (long long)dims->n_bldg * dims->n_env)
+            return fail(CL_EINVAL, "b_chunk=%d leaves no room for the %d chunk partial sums, their tickets and the marker words", a.b_chunk, a.n_chunks);
     }
     if (a.n_chunks > 1 && rkind_host == CLR_EV)
         return fail(CL_EINVAL, "reward kind CLR_EV is not implemented for building-chunked launches (n_bldg=%d)", dims->n_bldg);
@@ -1777,6 +1790,14 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // (finish = 2: their own, inside the launch; finish = 3: the previous step's, deferred)
         a.fused_finish = tun.finish == 2 ? 1 : 2;
         name_add(tun, "cl_step_kernel<%d, false, false, false, false, true>", vec);
+        // (four envs per lane x 16 waves: 64 KB of reduction rows + the 4 KB exchange tile of the deferred fold -- more dynamic LDS than a
+        //  kernel gets without opting in where the runtime enforces the 64 KB default; gfx950's 160 KB hold it)
+        if (lds > 64 * 1024) {
+            const void* fn = vec == 1 ? reinterpret_cast<const void*>(cl_step_kernel<1, false, false, false, false, true>)
+                                      : reinterpret_cast<const void*>(cl_step_kernel<4, false, false, false, false, true>);
+            if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+                return hip_fail(e, "hipFuncSetAttribute(cl_step_kernel<.., FOLD>)");
+        }
         if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, false, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, false, true>), grid, block, lds, s, a);
     } else {
@@ -1791,7 +1812,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (a.n_chunks > 1) {
         if (!a.fused_finish) {
             name_add(tun, "cl_finish_kernel");
-            hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, s, a, 0);
+            hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, s, a, 0, (float*)nullptr);
         }
         if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL) {
             const long long n = (long long)dims->n_env * dims->n_bldg;
@@ -1826,7 +1847,7 @@ int cl_finish_f32(const cl_dims* dims, float* out_bldg, float* out_env, int32_t 
     StepArgs a = {};
     a.out_bldg = out_bldg; a.out_env = out_env; a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps;
     a.flags = dims->flags; a.t = t; a.n_chunks = 0;    // (the kernel reads the chunk count next to the marker)
-    hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, (hipStream_t)stream, a, 1);
+    hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ), dim3(1024), 0, (hipStream_t)stream, a, 1, (float*)nullptr);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_finish_kernel launch");
     return CL_OK;
 }
@@ -1939,7 +1960,6 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     if (dims->flags & CLD_F64_MAPS) return fail(CL_EINVAL, "the fused rollout evaluates the battery map in fp32: use cl_rollout_seq_f32 with CLD_F64_MAPS");
     if (k_steps < 0 || t0 < 0 || t0 + k_steps > dims->n_steps)
         return fail(CL_ERANGE, "steps [%d, %d) outside [0, %d)", t0, t0 + k_steps, dims->n_steps);
-    if (dims->n_bldg > 32) return fail(CL_EINVAL, "the fused rollout supports n_bldg <= 32 (got %d): use cl_rollout_seq_f32", dims->n_bldg);
     if (actions && act_stride_env == 1 && ((act_stride_col % 4) != 0 || (act_stride_step % 4) != 0))
         return fail(CL_EALIGN, "action strides must be multiples of 4 floats for the coalesced layout");
 
@@ -1954,28 +1974,50 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     r.act_stride_step = act_stride_step; r.act_low = act_low; r.act_high = act_high; r.ret_env = ret_env; r.seed = seed;
     r.t0 = t0; r.k_steps = k_steps;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
-    const int mb = full ? 1 : (dims->n_bldg > 16 ? 2 : 1);
-    if (full && dims->n_bldg > 16) return fail(CL_EINVAL, "the fused rollout (thermal districts) supports n_bldg <= 16 (got %d): use cl_rollout_seq_f32", dims->n_bldg);
-    a.nw = tun.nw ? tun.nw : (dims->n_bldg + mb - 1) / mb;
-    if (a.nw * mb < dims->n_bldg || a.nw > 16) return fail(CL_EINVAL, "bad nw %d", a.nw);
+    // a wave keeps the state of MB buildings in registers: two battery + PV buildings, one thermal one.  Districts beyond 16 MB buildings are
+    // cut into chunks of `b_chunk` <= 16 MB along gridDim.y (cl_rollout_kernel's note); cl_finish_kernel folds the chunk sums once per launch
+    const int mb_max = full ? 1 : 2;
+    const bool chunked = dims->n_bldg > 16 * mb_max;
+    int mb = full ? 1 : (dims->n_bldg > 16 ? 2 : 1);
+    if (chunked) {
+        if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL)
+            return fail(CL_EINVAL, "the fused rollout of a building-chunked district (n_bldg=%d) cannot couple the buildings inside a step (MARL): use cl_rollout_seq_f32", dims->n_bldg);
+        a.b_chunk = tun.b_chunk > 0 ? tun.b_chunk : 16 * mb_max;
+        if (a.b_chunk > 16 * mb_max) return fail(CL_EINVAL, "b_chunk=%d: a fused-rollout workgroup holds at most %d buildings of this district", a.b_chunk, 16 * mb_max);
+        mb = mb_max;                      // (battery + PV: always two buildings per wave -- the one-building chunked instantiations spill)
+        a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
+        // the reserved plane holds n_chunks x NQ partial sums, one return row per chunk and the marker words
+        if (((long long)a.n_chunks * (NQ + 1)) * dims->n_env + 4 > (long long)dims->n_bldg * dims->n_env)
+            return fail(CL_EINVAL, "b_chunk=%d leaves no room for the %d chunk partial sums of the fused rollout", a.b_chunk, a.n_chunks);
+    }
+    a.nw = tun.nw ? tun.nw : ((chunked ? a.b_chunk : dims->n_bldg) + mb - 1) / mb;
+    if (a.nw * mb < (chunked ? a.b_chunk : dims->n_bldg) || a.nw > 16) return fail(CL_EINVAL, "bad nw %d", a.nw);
     // two envs per lane where its 128-env workgroups come in (nearly) full rounds of one per CU: 17 x 32 768 (the C5 per-GPU shard) 2.60 ->
     // 2.31 us per step, 65 536 4.99 -> 4.19, 98 304 7.24 -> 6.19, 131 072 9.54 -> 8.21; 49 152 = 1.5 rounds: 4.20 vs 3.89 at one env per lane
-    // (scripts/rollout_vec_probe.py)
-    const long long wg2 = (dims->n_env + 127) / 128, rounds2 = (wg2 + 255) / 256;
-    const bool full_rounds = dims->n_env >= 32768 && wg2 * 100 >= rounds2 * 256 * 85;
+    // (scripts/rollout_vec_probe.py); chunked districts: the workgroup count is env tiles x chunks
+    const long long wg2 = (long long)((dims->n_env + 127) / 128) * a.n_chunks, rounds2 = (wg2 + 255) / 256;
+    const bool full_rounds = (long long)dims->n_env * a.n_chunks >= 32768 && wg2 * 100 >= rounds2 * 256 * 85 && dims->n_env >= 128;
     const int vec = tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && full_rounds) ? 2 : 1);
     const int tile = 64 * vec;
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
     const int key = (full ? 100 : 0) + vec * 10 + mb;
-    if (key != 11 && key != 12 && key != 21 && key != 22 && key != 111)
+    if ((key != 11 && key != 12 && key != 21 && key != 22 && key != 111) || (chunked && key != 12 && key != 22 && key != 111))
         return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
-    const bool pin = (long long)grid * a.nw > 5 * 1024;
+    const bool pin = chunked || (long long)grid * a.nw > 5 * 1024;
     name_reset(tun);
-    name_add(tun, "cl_rollout_kernel<%d, %s, %d, %s>", vec, full ? "true" : "false", mb, (key == 12 && !pin) ? "false" : "true");
-    const int rc = cl_tu_launch_rollout(key, pin, grid, block.x, lds, stream, &r);
+    name_add(tun, "cl_rollout_kernel<%d, %s, %d, %s%s>", vec, full ? "true" : "false", mb, (key == 12 && !pin) ? "false" : "true", chunked ? ", true" : "");
+    const int rc = cl_tu_launch_rollout(key + (chunked ? 1000 : 0), pin, grid, (unsigned)a.n_chunks, block.x, lds, stream, &r);
     if (rc) return hip_fail((hipError_t)rc, "cl_rollout_kernel launch");
+    if (chunked && k_steps > 0) {
+        // the last step's district sums (and the K-step return): one fold per launch
+        StepArgs f = a;
+        f.t = t0 + k_steps - 1;
+        name_add(tun, "cl_finish_kernel");
+        hipLaunchKernelGGL(cl_finish_kernel, dim3((dims->n_env + 63) / 64, NQ + (ret_env ? 1 : 0)), dim3(1024), 0, (hipStream_t)stream, f, 0, ret_env);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_finish_kernel launch");
+    }
     return CL_OK;
 }
 

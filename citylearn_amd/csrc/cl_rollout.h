@@ -79,7 +79,12 @@ CL_DEV void rollout_action_cached(float (&dst)[VEC], PhiloxCache (&cache)[VEC], 
 }
 
 // MB = buildings owned by one wave (wave w owns w, w + nw, ...): their State stays in registers for all K steps.
-template <int VEC, bool FULL, int MB, bool PIN = true>
+// Districts beyond MB x 16 buildings (round 5; BASELINE config 4's 1024): the buildings are cut into chunks of `b_chunk` = MB x nw along
+// gridDim.y exactly as the one-step launches cut them -- wave w of workgroup row y owns y b_chunk + w (+ nw) -- and a workgroup ends with
+// the last step's chunk partial sums (and its chunk's share of the K-step return) in the scratch rows of out_bldg's reserved plane, which
+// cl_finish_kernel folds once per LAUNCH, i.e. once per K steps.  Per unit and step the HBM traffic drops from 36 B (mode A) to 24 / K + 12 / K;
+// what a chunked launch cannot do is a reward that couples the buildings inside a step (MARL: the host keeps cl_rollout_seq_f32 for it).
+template <int VEC, bool FULL, int MB, bool PIN = true, bool CHUNK = false>
 __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     const StepArgs& a = r.s;
@@ -93,15 +98,22 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
     const bool quirk = a.flags & CLD_REF_T0_QUIRK;
     const bool detail = a.flags & CLD_WRITE_DETAIL;
 
+    // (CHUNK is a template parameter: the scalar register file of these kernels is full -- numbered_sgpr = 100 with two dozen values parked in
+    //  vector-register lanes -- and the workgroup-row index alone moved the one-row instantiations' allocation enough to reserve scratch memory)
+    const int b_lo = CHUNK ? blockIdx.y * a.b_chunk : 0;
+    const int b_hi = CHUNK ? min(a.n_bldg, b_lo + a.b_chunk) : a.n_bldg;
+    // the table rows of this wave's first building: inside the K-step loop neither the chunk nor the wave index is needed for a row address
+    // (the scalar register file of these kernels is full: one more value alive across the loop spills)
+    const float* __restrict__ ts_w = a.ts + (long long)(b_lo + w) * CL_NF;
     cl::Bp B[MB];
     cl::State S[MB][VEC];
     bool own[MB];
     long long off[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-        const int b = w + m * a.nw;
-        own[m] = b < a.n_bldg;
-        const int bc = own[m] ? b : w;
+        const int b = b_lo + w + m * a.nw;
+        own[m] = b < b_hi;
+        const int bc = own[m] ? b : (CHUNK ? min(b_lo + w, a.n_bldg - 1) : w);
         off[m] = (long long)bc * a.n_env + env0;
         cl::load_bp<FULL>(B[m], a.params + (long long)bc * CL_NP);
 #pragma unroll
@@ -151,10 +163,9 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             if (!own[m]) continue;                                       // wave-uniform
-            const int b = w + m * a.nw;
             cl::Row R;
-            cl::load_row<FULL>(R, a.ts + ((long long)(t + row0) * a.n_bldg + b) * CL_NF, B[m].flags,
-                               FULL ? a.ts + ((long long)(a.n_steps - 1 + row0) * a.n_bldg + b) * CL_NF : nullptr);
+            cl::load_row<FULL>(R, ts_w + ((long long)(t + row0) * a.n_bldg + m * a.nw) * CL_NF, B[m].flags,
+                               FULL ? ts_w + ((long long)(a.n_steps - 1 + row0) * a.n_bldg + m * a.nw) * CL_NF : nullptr);
             float a_es[VEC], a_cs[VEC], a_hs[VEC], a_ds[VEC], a_cd[VEC], a_hd[VEC];
             rollout_action_cached<VEC>(a_es, rnd[m], r, B[m].a_es, env0, t, k, live);
             if constexpr (FULL) {
@@ -282,10 +293,14 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
         vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, ret);
         __syncthreads();
         const int tile_env0 = blockIdx.x * TILE;
+        // (chunked: this workgroup row's share of the return goes to its scratch row behind the n_chunks x NQ partial sums; cl_finish_kernel adds the rows)
         for (int e = threadIdx.x; e < TILE; e += blockDim.x) {
             float s = 0.0f;
             for (int kk = 0; kk < a.nw; ++kk) s += lds[(size_t)kk * TILE + e];
-            if (tile_env0 + e < a.n_env) r.ret_env[tile_env0 + e] += s;
+            if (tile_env0 + e < a.n_env) {
+                if constexpr (CHUNK) a.out_bldg[(long long)CLO_RESERVED * plane + ((long long)a.n_chunks * NQ + blockIdx.y) * a.n_env + tile_env0 + e] = s;
+                else r.ret_env[tile_env0 + e] += s;
+            }
         }
     }
 }

@@ -160,8 +160,8 @@ class StepEngine:
         self._step_head = (ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state))
         self._step_tail = (_ptr(self.out_bldg), _ptr(self._out_env), _ptr(self.kpi_bldg), _ptr(self.kpi_env))
         # deferred finish (`tuning={'finish': 3}`, districts of more than 32 buildings): `step` leaves the district sums of its step to the
-        # next launch; reading `out_env` (or any view of it) folds the pending one first (`finish`)
-        self._deferred = int(self.tuning.finish) == 3 and self.n_bldg > 32
+        # next launch; reading `out_env` (or any view of it) folds the pending one first (`finish`).  `_deferred` is read from the tuning
+        # block at every call: the library does the same (cl_dims.tuning travels with the call), so the two cannot disagree.
         self._pending_t = None
         self._flex_ref = None if self.flex is None else ctypes.byref(self.flex)
         self.act_low = self.act_high = None         # bounds of the on-device rollout policy (set_action_limits)
@@ -246,6 +246,10 @@ class StepEngine:
         self._pending_t = None
         self.t = 0
 
+    @property
+    def _deferred(self) -> bool:
+        return int(self.tuning.finish) == 3 and self.n_bldg > 32
+
     def step(self, actions: torch.Tensor, t: Optional[int] = None):
         """Advance every (env, building) by one step.  ``actions``: float32 ``[n_act_cols, n_env]`` on the
         engine's device (any 2-D strides; ``[n_env, n_act_cols].T`` works too)."""
@@ -303,6 +307,8 @@ class StepEngine:
                                               writer.pitch, writer.n_rows, int(row), self._stream())
         if rc:
             _lib.check(rc)
+        if self._deferred:
+            self._pending_t = int(t)        # (cl_step_observe_f32 runs the same step launch: a chunked district defers its sums here too)
         self.t = t + 1
         return writer.obs
 
@@ -313,10 +319,12 @@ class StepEngine:
         assert self.act_low.numel() == self.n_act_cols == self.act_high.numel()
 
     def rollout(self, k_steps: int, actions: Optional[torch.Tensor] = None, seed: int = 0,
-                ret_env: Optional[torch.Tensor] = None, t0: Optional[int] = None):
-        """Fused K-step rollout in one launch (`cl_rollout_f32`): state stays in registers between steps.  Districts with flexible
-        loads, streaming KPIs (``kpi=True``) or more buildings than the fused kernel holds (32 battery + PV / 16 thermal) run the
-        same K steps as K x (policy, [flex], step, [kpi]) launches (`cl_rollout_seq_f32`), same action streams.
+                ret_env: Optional[torch.Tensor] = None, t0: Optional[int] = None, fused: Optional[bool] = None):
+        """Fused K-step rollout in one launch (`cl_rollout_f32`): state stays in registers between steps.  Districts of more than
+        32 battery + PV / 16 thermal buildings run it building-chunked (one more tiny launch per K steps folds the chunks' district
+        sums and returns).  Districts with flexible loads, streaming KPIs (``kpi=True``), the float64 battery map, or a reward that
+        couples the buildings of a chunked district inside a step (MARL) run the same K steps as K x (policy, [flex], step, [kpi])
+        launches (`cl_rollout_seq_f32`), same action streams; ``fused=False`` asks for that sequence explicitly.
 
         ``actions``: open-loop float32 tensor ``[k_steps, n_act_cols, n_env]`` (any strides), or ``None`` for the
         on-device policy ``a = low + u (high - low)``, ``u = Philox4x32-10(seed; env, column, t)``.
@@ -332,7 +340,10 @@ class StepEngine:
         elif self.act_low is None:
             raise ValueError('call set_action_limits(low, high) before using the on-device policy')
         full = not self.lean or bool(self.dims.flags & abi.CLD_WRITE_DETAIL)
-        if self.flex is not None or self.kpi or self.f64_maps or self.n_bldg > (16 if full else 32):
+        chunked = self.n_bldg > (16 if full else 32)
+        if fused is None:
+            fused = not (self.flex is not None or self.kpi or self.f64_maps or (chunked and self.reward == 'MARL'))
+        if not fused:
             if actions is None and self._policy_actions is None:
                 self._policy_actions = torch.empty((4, self.n_act_cols, self.n_env), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
@@ -349,6 +360,7 @@ class StepEngine:
                 ctypes.byref(self.dims), _ptr(self.params), _ptr(self.ts), _ptr(self.state), _ptr(actions), st[0], st[1], st[2],
                 _ptr(self.act_low), _ptr(self.act_high), int(seed) & (2 ** 64 - 1),
                 _ptr(self.out_bldg), _ptr(self._out_env), _ptr(ret_env), int(t0), int(k_steps), self._stream()))
+        self._pending_t = None              # (a chunked fused rollout folds its last step's district sums itself)
         self.t = t0 + k_steps
 
     def step_many(self, actions: torch.Tensor, t0: Optional[int] = None):

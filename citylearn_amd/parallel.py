@@ -221,6 +221,11 @@ class ControlPlane:
     def __getattr__(self, name):
         return getattr(self._dist, name)
 
+    @property
+    def rccl_world_size(self) -> Optional[int]:
+        """Ranks the RCCL communicator itself holds (None when the control plane runs on gloo): the default group is always the gloo one."""
+        return self._dist.get_world_size(group=self._group) if self._group is not None else None
+
     def barrier(self):
         return self._dist.barrier(group=self._group)
 
@@ -231,7 +236,20 @@ class ControlPlane:
         return self._dist.all_gather(out, tensor, group=self._group)
 
 
-def init_control_plane(rank: int, world: int, device=None, backend: Optional[str] = None, nccl_timeout_s: float = 90.0) -> ControlPlane:
+def _rccl_preflight(rank: int, world: int, device) -> Optional[str]:
+    """Why this rank cannot take part in an RCCL communicator, judged locally (None = it can try)."""
+    import torch
+    if not torch.cuda.is_available():
+        return 'no HIP device visible'
+    if device is None or torch.device(device).type != 'cuda':
+        return f'device {device!r} is not a GPU'
+    if world > torch.cuda.device_count() and os.environ.get('CL_BENCH_OVERSUBSCRIBE'):
+        return f'{world} ranks on {torch.cuda.device_count()} device(s): RCCL refuses two ranks per device'
+    return None
+
+
+def init_control_plane(rank: int, world: int, device=None, backend: Optional[str] = None, nccl_timeout_s: float = 90.0,
+                       preflight=_rccl_preflight) -> ControlPlane:
     """Process group for the benchmark's barrier + timing reductions.  ``backend``: 'nccl' (RCCL over xGMI, one rank per GPU),
     'gloo' (ranks sharing a device, or CPU); default: nccl when `device` is a GPU.  Returns a `ControlPlane` (``torch.distributed`` + the
     backend that ended up carrying the barrier).
@@ -241,7 +259,10 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
     ranks on one device) ALL of them carry the barrier and the MAX over gloo and the line says why in `control_fallback` -- the step
     path has no collective, a scaling run must not be lost to the control plane.  (Round 3 re-rendezvoused on MASTER_PORT + 1 after a
     failure, a port nobody had reserved, and assumed the failure symmetric: one failing rank would have waited in a TCPStore while its
-    peers sat in the RCCL barrier.)  CL_BENCH_STRICT_RCCL=1 makes the fallback fatal.
+    peers sat in the RCCL barrier.)  CL_BENCH_STRICT_RCCL=1 makes the fallback fatal.  Round 5 (advisor): a local `preflight`
+    (callable (rank, world, device) -> reason or None; tests pass their own) is agreed over gloo BEFORE any rank enters an RCCL call,
+    and the communicator probe runs with blocking waits and torch's async error handling off, so that a peer's failure surfaces as an
+    exception in this thread instead of the watchdog aborting the process.
 
     RCCL prints a version banner on STDOUT when the communicator comes up; stdout is parked on stderr meanwhile so that it
     carries nothing but the caller's own output."""
@@ -261,16 +282,38 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
         dist.init_process_group('gloo', rank=rank, world_size=world)
         dist.barrier()
         if backend == 'nccl':
-            err = None
-            try:
-                group = dist.new_group(backend='nccl', timeout=timedelta(seconds=nccl_timeout_s))
-                dist.barrier(group=group)
-                torch.cuda.synchronize()
-            except Exception as exc:                  # noqa: BLE001 -- whatever RCCL raises
-                err = f'{type(exc).__name__}: {exc}'[:300]
+            # (1) A local pre-flight, agreed over gloo BEFORE anybody enters an RCCL call: a rank that cannot possibly bring RCCL up (no device,
+            # a device shared with another rank, a test hook) must not leave its peers inside a communicator rendezvous it never joins.
+            err = preflight(rank, world, device) if preflight is not None else None
             ok = torch.tensor([0 if err else 1], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # over gloo: every rank learns whether EVERY rank has RCCL
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 1:
+                # (2) The communicator itself.  torch's default async error handling lets the watchdog thread ABORT the process when a
+                # collective times out -- the healthy ranks of an asymmetric failure would die instead of reaching the agreement below.  For
+                # the probe the collective blocks and RAISES in this thread instead (both variables are read when the group is constructed).
+                saved_env = {k: os.environ.get(k) for k in ('TORCH_NCCL_ASYNC_ERROR_HANDLING', 'TORCH_NCCL_BLOCKING_WAIT')}
+                os.environ['TORCH_NCCL_ASYNC_ERROR_HANDLING'] = '0'
+                os.environ['TORCH_NCCL_BLOCKING_WAIT'] = '1'
+                try:
+                    group = dist.new_group(backend='nccl', timeout=timedelta(seconds=nccl_timeout_s))
+                    dist.barrier(group=group)
+                    torch.cuda.synchronize()
+                except Exception as exc:                  # noqa: BLE001 -- whatever RCCL raises
+                    err = f'{type(exc).__name__}: {exc}'[:300]
+                finally:
+                    for k, v in saved_env.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)                # over gloo: every rank learns whether EVERY rank has RCCL
             if int(ok[0]) == 0:
+                if group is not None:
+                    try:
+                        dist.destroy_process_group(group)               # the half-up communicator must not linger beside the gloo group
+                    except Exception:                                   # noqa: BLE001
+                        pass
                 if os.environ.get('CL_BENCH_STRICT_RCCL') == '1':
                     raise RuntimeError(f'[rank {rank}] RCCL control plane failed ({err or "on another rank"}) and CL_BENCH_STRICT_RCCL=1')
                 print(f'[rank {rank}] RCCL control plane failed ({err or "on another rank"}); barrier and MAX stay on gloo', file=sys.stderr, flush=True)

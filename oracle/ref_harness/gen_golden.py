@@ -614,6 +614,13 @@ if __name__ == '__main__':
     # `time_step_ratios=[]`, data.py:403) -- a 15-minute run leaves its ratio behind for every env built afterwards.
     import subprocess
     args = sys.argv[1:]
+    if args and args[0] == 'package_year':
+        # data only (no reference run): the whole year of citylearn_challenge_2022_phase_all, gzipped, as package data -- the table bench.py's
+        # headline steps through (T = 8 760 rows; the 720-hour cut beside it stays the parity fixture's and smoke()'s source)
+        dst = _PACKAGE_DATA / 'citylearn_challenge_2022_phase_all_8760h'
+        make_mini_dataset(ref_env.REFERENCE_ROOT / 'data' / 'datasets' / 'citylearn_challenge_2022_phase_all', dst, 8760, True)
+        print('wrote', dst)
+        sys.exit(0)
     if args and args[0] == '--one':
         kind, name = args[1], args[2]
         if kind == 'conditions':

@@ -4,7 +4,7 @@ TEST / MEASUREMENT INFRASTRUCTURE (oracle side): imports the reference through `
 seeded cache).  `/root/reference` exists only in the build container; `stage_reference.py` (run by
 `__graft_entry__.build()`) stages the package + the two datasets this timing needs into the git-ignored `oracle/_ref/reference/`,
 which travels to the GPU box with the snapshot.  `bench.py`'s `cpu_baseline` leg runs this script there (`--root oracle/_ref/reference
---skip-c1 --out -`, a bounded sample) and reports the result as `cpu_baseline.reference`, host = the GPU box, next to the C port.
+--c1-budget 60 --out -`, a bounded sample) and reports the result as `cpu_baseline` (kind "reference"), host = the GPU box, the C port beside it.
 The long form (C1 exactly + 1000 steps on every core) is committed as `profiles/reference_cpu_timing.json`.
 
     python oracle/ref_harness/time_reference.py [--root DIR] [--steps 1000] [--procs N] [--skip-c1] [--out FILE|-]
@@ -29,7 +29,9 @@ HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE))
 
 
-def _episode(dataset: str, steps, seed: int, barrier=None):
+def _episode(dataset: str, steps, seed: int, barrier=None, budget_s=None, fallback_steps=2000, probe_steps=500):
+    """`budget_s` (C1 on the bench host): after `probe_steps` steps the full episode's duration is projected from the rate so far; if it
+    exceeds the budget the episode stops at `fallback_steps` (the count actually run is what the caller reports)."""
     import numpy as np
     import ref_env
     ref_env.setup_reference()
@@ -43,10 +45,16 @@ def _episode(dataset: str, steps, seed: int, barrier=None):
     if barrier is not None:
         barrier.wait()
     t0 = time.perf_counter()
+    done = 0
     for a in acts:
         env.step(a)
+        done += 1
+        if budget_s is not None and done == probe_steps and (time.perf_counter() - t0) / done * n > budget_s:
+            n = min(n, max(int(fallback_steps), probe_steps))
+        if done >= n:
+            break
     dt = time.perf_counter() - t0
-    return B, n, dt
+    return B, done, dt
 
 
 def _worker(dataset, steps, seed, barrier, q):
@@ -62,6 +70,9 @@ def main():
     ap.add_argument('--root', default=None, help='reference tree to import (default: $CITYLEARN_REFERENCE_ROOT, /root/reference, '
                                                  'else the staging under oracle/_ref/reference)')
     ap.add_argument('--skip-c1', action='store_true', help='skip the single-process full C1 episode (about 2 minutes)')
+    ap.add_argument('--c1-budget', type=float, default=None, help='seconds the C1 episode may take: if the first 500 steps project the full 8759 '
+                                                                  'beyond it, only the first --c1-fallback-steps are run (and the count is stated)')
+    ap.add_argument('--c1-fallback-steps', type=int, default=2000)
     args = ap.parse_args()
     if args.root:
         os.environ['CITYLEARN_REFERENCE_ROOT'] = str(Path(args.root).resolve())       # inherited by the spawned workers
@@ -70,9 +81,10 @@ def main():
 
     c1 = None
     if not args.skip_c1:
-        B, n, dt = _episode('citylearn_challenge_2022_phase_1', None, 0)
+        B, n, dt = _episode('citylearn_challenge_2022_phase_1', None, 0, budget_s=args.c1_budget, fallback_steps=args.c1_fallback_steps)
         c1 = {'dataset': 'citylearn_challenge_2022_phase_1', 'buildings': B, 'steps': n, 'seconds': round(dt, 3), 'processes': 1,
-              'building_timesteps_per_s': B * n / dt}
+              'building_timesteps_per_s': B * n / dt,
+              'episode': 'full (8759 transitions)' if n >= 8759 else f'first {n} steps (the full episode projected beyond the {args.c1_budget:.0f} s budget)'}
         print('C1:', c1, file=log, flush=True)
 
     ctx = mp.get_context('spawn')

@@ -4,6 +4,8 @@ next to it names (`roofline.kernel` is what the library reports having launched,
     python scripts/check_profiles.py [--duration-tol 0.05] <bench_line.json> <pmc_summary.json | kernel_stats.csv> [...]
 
 Exit code 1 (and a message per mismatch) when a summary belongs to another kernel: stale counters must not sit beside a newer kernel.
+A line whose `roofline.traffic_source` names a summary file must also carry THAT file's traffic ((2 x FETCH_SIZE + WRITE_SIZE) KiB): a
+summary re-collected after the line was written (round 4: 73.29 MB in the line, 68.84 MB in the summary it cited) fails here.
 With --duration-tol F a kernel_stats.csv must also AGREE IN TIME: the rocprofv3 `AverageNs` of the kernel a single-kernel line names
 has to lie within F (relative) of that line's `roofline.launch_us` (HIP events inside bench.py) -- the two clocks behind `roofline.frac`."""
 import csv
@@ -25,12 +27,19 @@ def main():
         tol, argv = float(argv[1]), argv[2:]
     line, files = argv[0], argv[1:]
     want = kernels_of(line)
-    launch_us = json.load(open(line))['roofline'].get('launch_us')
+    roof = json.load(open(line))['roofline']
+    launch_us = roof.get('launch_us')
     bad = 0
     for f in files:
         if f.endswith('.json'):
-            seen = json.load(open(f)).get('_kernel', {}).get('kernel', '')
+            summary = json.load(open(f))
+            seen = summary.get('_kernel', {}).get('kernel', '')
             ok = any(k in seen for k in want)
+            import os
+            if ok and roof.get('traffic') is not None and roof.get('traffic_source') == os.path.basename(f) and 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
+                in_file = (2.0 * summary['FETCH_SIZE']['mean'] + summary['WRITE_SIZE']['mean']) * 1024.0
+                ok = abs(in_file - roof['traffic']) <= 1e-3 * in_file
+                seen += f"; line traffic {roof['traffic'] / 1e6:.2f} MB vs {in_file / 1e6:.2f} MB in the summary it names"
         else:
             with open(f, newline='') as fh:
                 rows = list(csv.DictReader(fh))

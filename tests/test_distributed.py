@@ -259,6 +259,10 @@ def test_bench_uses_only_counters_collected_on_the_kernel_it_launched(tmp_path, 
     check = [sys.executable, str(ROOT / 'scripts' / 'check_profiles.py'), str(line)]
     assert subprocess.run(check + [str(prof / 'r03_streaming_pmc_summary.json')], capture_output=True).returncode == 0
     assert subprocess.run(check + [str(prof / 'r02_streaming_pmc_summary.json')], capture_output=True).returncode == 1
+    # a line that cites a summary must carry that summary's traffic -- a summary re-collected after the line was written fails
+    for traffic, rc in ((traffic, 0), (traffic * 1.06, 1)):
+        line.write_text(json.dumps({'roofline': {'kernel': 'cl_step_envmajor_kernel<20, true>', 'traffic': traffic, 'traffic_source': 'r03_streaming_pmc_summary.json'}}))
+        assert subprocess.run(check + [str(prof / 'r03_streaming_pmc_summary.json')], capture_output=True).returncode == rc
 
 
 def _asymmetric_rank(rank, world, port, q):
@@ -276,11 +280,27 @@ def _asymmetric_rank(rank, world, port, q):
         return g
     d.new_group = fake_new_group
     t0 = time.monotonic()
-    cp = init_control_plane(rank, world, None, 'nccl', nccl_timeout_s=5.0)
+    cp = init_control_plane(rank, world, None, 'nccl', nccl_timeout_s=5.0, preflight=None)
     took = time.monotonic() - t0
     worst = reduce_max_seconds(float(rank + 1), cp, 'cpu')          # the control plane still works, over gloo
     cp.barrier()
+    assert cp.rccl_world_size is None                               # (nothing but gloo carries the control plane now)
     q.put((rank, cp.control_backend, cp.control_fallback, took, worst))
+    d.destroy_process_group()
+
+
+def _preflight_rank(rank, world, port, q):
+    """Rank 1 knows locally that it cannot bring RCCL up: nobody may enter an RCCL call (new_group would hang / abort the healthy rank)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as d
+    from citylearn_amd.parallel import init_control_plane
+
+    def no_new_group(*a, **kw):
+        raise AssertionError('an RCCL communicator was attempted although a rank had failed its pre-flight')
+    d.new_group = no_new_group
+    cp = init_control_plane(rank, world, None, 'nccl', nccl_timeout_s=5.0, preflight=lambda r, w, dev: 'no xGMI on this rank' if r == 1 else None)
+    cp.barrier()
+    q.put((rank, cp.control_backend, cp.control_fallback, cp.rccl_world_size))
     d.destroy_process_group()
 
 
@@ -302,6 +322,24 @@ def test_control_plane_converges_when_rccl_fails_on_one_rank_only():
     for rank, backend, fallback, took, worst in res:
         assert backend == 'gloo' and fallback and took < 60 and worst == 2.0, res
     assert 'no RCCL on this rank' in res[1][2] and res[0][2]
+
+
+def test_control_plane_preflight_keeps_every_rank_out_of_rccl():
+    """with torch's default async error handling a rank stuck in an RCCL rendezvous is killed by the watchdog, not handed an
+    exception -- so a rank that knows locally that RCCL cannot work says so over gloo BEFORE anybody enters an RCCL call."""
+    from citylearn_amd.parallel import free_port
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_preflight_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ['gloo', 'gloo'] and all(r[3] is None for r in res), res
+    assert 'no xGMI' in res[1][2] and 'another rank' in res[0][2], res
 
 
 def test_rank_affinity_arithmetic(tmp_path):

@@ -208,15 +208,13 @@ def test_c4_shard_deferred_finish(fixture, kind):
     # a step that does NOT defer clears its parity's marker: switching the mode on live buffers cannot make a later cl_finish_f32 fold a stale buffer
     if kind != 'MARL':
         dfr.step(acts[1], 1)                                           # deferred: marker of parity 1 set, out_env not folded yet
-        dfr.tuning.finish = 1
-        dfr._deferred = False
+        dfr.tuning.finish = 1                                          # (the engine reads the mode from the tuning block at every call)
         dfr.step(acts[1], 1)                                           # the same step again with the second launch
         after = dfr._out_env.clone()
         dfr._pending_t = 1
         dfr.finish()
         assert torch.equal(dfr._out_env, after)
         dfr.tuning.finish = 3
-        dfr._deferred = True
     # step_many (cl_rollout_seq_f32) folds its last step itself
     ref.reset(); dfr.reset()
     ref.step_many(acts); dfr.step_many(acts)
@@ -225,6 +223,46 @@ def test_c4_shard_deferred_finish(fixture, kind):
     ref.reset(); dfr.reset()
     ref.rollout(K, actions=acts, ret_env=ret_r); dfr.rollout(K, actions=acts, ret_env=ret_d)
     assert torch.equal(ret_d, ret_r) and torch.equal(dfr._out_env, ref._out_env)
+
+
+def test_deferred_finish_through_step_observe():
+    """`StepEngine.step_observe`'s one-call path (`cl_step_observe_f32`) runs the same step launch as `step` -- on a chunked
+    district under `finish = 3` it defers the district sums too, so a later read of `out_env` must fold them (it used to return the
+    previous step's).  A 256-building battery + PV district of which only the first eight buildings expose env-dependent observations
+    (the compact form holds at most 64 columns), 1024 envs: 16 chunks, deferred fold."""
+    import copy
+    from dataclasses import replace
+    from citylearn_amd.observations import ObservationLayout
+    from citylearn_amd.observe import ObservationWriter
+    from citylearn_amd.synthetic import tile_district
+    spec = tile_district(golden('g2022_all').spec(), 256)
+    blds = []
+    for i, b in enumerate(spec.buildings):
+        b = copy.copy(b)
+        if i >= 8:
+            b.observation_metadata = {k: (k == 'hour') for k in b.observation_metadata}
+        blds.append(b)
+    spec = replace(spec, buildings=blds)
+    tab = spec.episode_tables(0)
+    dep_tables, _ = ObservationLayout(spec, 'current', False).episode(tab).compact()
+    E = 1024
+    ref, dfr = StepEngine(tab, E), StepEngine(tab, E, tuning=dict(finish=3))
+    wa, wb = ObservationWriter(ref, dep_tables, None), ObservationWriter(dfr, dep_tables, None)
+    assert 0 < wa.n_deps == wa.n_cols <= 64
+    dfr.trace_kernels()
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    for t in range(5):
+        act = torch.rand((ref.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        ref.step(act, t)
+        want = wa.write(t + 1).clone()
+        got = dfr.step_observe(act, wb, t)
+        assert 'cl_finish_kernel' not in dfr.last_kernels and 'true>' in dfr.last_kernels, dfr.last_kernels      # the FOLD instantiation, deferred
+        assert dfr._pending_t == t
+        assert torch.equal(got, want) and torch.equal(dfr.state, ref.state), t
+        if t % 2 == 0:                                                  # (odd steps are folded by the next launch instead)
+            assert torch.equal(dfr.out_env, ref.out_env), t
+            assert dfr._pending_t is None
+    assert torch.equal(dfr.out_env, ref.out_env)
 
 
 @pytest.mark.parametrize('kind', ['RewardFunction', 'MARL'])

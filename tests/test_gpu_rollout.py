@@ -133,8 +133,8 @@ def test_rollout_with_streaming_kpis_and_large_districts(name, kind, B):
     gen = torch.Generator(device='cuda').manual_seed(seed)
     lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
     acts = lo[None, :, None] + torch.rand((K, cols, E), device='cuda', generator=gen) * (hi - lo)[None, :, None]
-    b.rollout(K, actions=acts, ret_env=ret)
-    ret_ref = torch.zeros(E, device='cuda')
+    b.rollout(K, actions=acts, ret_env=ret, fused=False if B else None)      # (large districts: the launch sequence asked for explicitly --
+    ret_ref = torch.zeros(E, device='cuda')                                  #  by default they run the chunked fused kernel, tested below)
     for k in range(K):
         a.step(acts[k])
         ret_ref += a.district_reward
@@ -157,6 +157,76 @@ def test_rollout_with_streaming_kpis_and_large_districts(name, kind, B):
             c.step(host[k])
         torch.testing.assert_close(d.state, c.state, rtol=2e-5, atol=2e-5)
         torch.testing.assert_close(d.kpi_bldg, c.kpi_bldg, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('name,kind,B,E,tuning', [('g2022_all', 'RewardFunction', 1024, 256, None), ('g2020_cz1', 'RewardFunction', 1024, 128, None),
+                                                  ('g2022_all', 'SolarPenaltyReward', 100, 260, None), ('g2020_cz1', 'IndependentSACReward', 48, 68, None),
+                                                  ('g2022_all', 'RewardFunction', 70, 4096, dict(vec=2)), ('g2022_all', 'IndependentSACReward', 33, 64, dict(b_chunk=24))])
+def test_chunked_fused_rollout_equals_single_steps(name, kind, B, E, tuning):
+    """Mode B for building-chunked districts (round 5; BASELINE config 4's 1024 buildings): `cl_rollout_f32` cuts the district into workgroup
+    rows of 32 battery + PV / 16 thermal buildings, keeps every unit's state in registers for the K steps and leaves the last step's chunk
+    partial sums + each chunk's share of the K-step return to one `cl_finish_kernel` launch.  Against K calls of `cl_step_f32`
+    (citylearn.py:978-1056 K times, district sums citylearn.py:1888-1918) within the fused kernel's tolerance (the tolerances of
+    test_open_loop_rollout_equals_single_steps; district sums scaled with the district size); ragged last chunks (100 = 3 x 32 + 4, 48 = 3 x 16,
+    33 = 24 + 9), ragged last env tiles (260, 68 envs), both pack widths; a second rollout continues from the state the first one left."""
+    from citylearn_amd.synthetic import tile_district
+    spec = tile_district(golden(name).spec(), B)
+    tab = spec.episode_tables(0)
+    K = 24
+    low, high = spec.action_limits()
+    gen = torch.Generator(device='cuda').manual_seed(B + E)
+    lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+    acts = lo[None, :, None] + torch.rand((K, len(low), E), device='cuda', generator=gen) * (hi - lo)[None, :, None]
+    a, b = StepEngine(tab, E, reward=kind), StepEngine(tab, E, reward=kind, tuning=tuning)
+    b.trace_kernels()
+    ret_ref = torch.zeros(E, device='cuda', dtype=torch.float64)
+    for k in range(K):
+        a.step(acts[k])
+        ret_ref += a.district_reward.double()
+    ret = torch.full((E,), 3.0, device='cuda')                       # (the return is ADDED to what the caller passes in)
+    b.rollout(K, actions=acts, ret_env=ret)
+    assert 'cl_rollout_kernel' in b.last_kernels and b.last_kernels.endswith(', true>+cl_finish_kernel'), b.last_kernels
+    _close(b.state, a.state)
+    _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
+    # district sums over B buildings: the per-building tolerance times the district size (DESIGN section 3)
+    torch.testing.assert_close(b.out_env, a.out_env, rtol=1e-5, atol=1e-6 * B)
+    torch.testing.assert_close(ret.double() - 3.0, ret_ref, rtol=1e-5, atol=2e-5 * B)
+    assert b.t == a.t == K and b._pending_t is None
+    more = acts[:6].contiguous()
+    for k in range(6):
+        a.step(more[k])
+    b.rollout(6, actions=more)
+    _close(b.state, a.state)
+    torch.testing.assert_close(b.out_env, a.out_env, rtol=1e-5, atol=1e-6 * B)
+
+
+def test_chunked_fused_rollout_policy_and_fallbacks():
+    """The on-device Philox policy through the chunked kernel (same stream as the launch sequence draws: env, column, step), MARL on a
+    chunked district (falls back to the launch sequence: the reward couples the buildings inside a step), and the room check."""
+    from citylearn_amd.synthetic import tile_district
+    spec = tile_district(golden('g2022_all').spec(), 256)
+    tab = spec.episode_tables(0)
+    E, K, seed = 512, 12, 31
+    low, high = spec.action_limits()
+    f, q = StepEngine(tab, E), StepEngine(tab, E)
+    for e in (f, q):
+        e.set_action_limits(low, high)
+        e.trace_kernels()
+    rf, rq = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
+    f.rollout(K, seed=seed, ret_env=rf)
+    q.rollout(K, seed=seed, ret_env=rq, fused=False)
+    assert 'cl_rollout_kernel' in f.last_kernels and 'cl_rollout_kernel' not in q.last_kernels
+    _close(f.state, q.state)
+    torch.testing.assert_close(f.out_env, q.out_env, rtol=1e-5, atol=3e-4)
+    torch.testing.assert_close(rf, rq, rtol=1e-5, atol=5e-3)
+    m = StepEngine(tab, E, reward='MARL')
+    m.set_action_limits(low, high)
+    m.trace_kernels()
+    m.rollout(4, seed=seed)
+    assert 'cl_rollout_kernel' not in m.last_kernels and 'cl_marl_reward_kernel' in m.last_kernels
+    with pytest.raises(_lib.EngineError) as err:
+        m.rollout(4, seed=seed, fused=True)
+    assert err.value.code == abi.CL_EINVAL and 'MARL' in str(err.value)
 
 
 def test_sharded_rollouts_reproduce_the_unsharded_policy_stream():
