@@ -15,6 +15,7 @@ Configs (`--config`, default `headline`):
             the energy step AND the LSTM indoor-temperature stage with its ComfortReward epilogue (what CityLearnEnv.step runs there)
   C4        synthetic 1024-building district (2020 climate-zone-1 device set: heat pump, heater, two tanks, battery; parameters
             jittered) x 1024 envs per GPU -- the per-GPU shard of the 8192-env config; C4-lean: battery + PV device set
+  C4-B / C4-lean-B  the same districts in mode B: 24 fused env steps per launch through the building-chunked cl_rollout_f32 (round 5)
   C5        fused 24-step day rollout per launch with the on-device Philox random policy, 17 buildings x 32 768 envs per GPU (the
             per-GPU shard of 262 144 envs on 8 GPUs); a "step" of the line is one 24-step launch
 
@@ -62,7 +63,7 @@ ENVS_PER_GPU = 65536
 STREAMING_ENVS = 1048576        # second roofline entry of the headline: working set >> 256 MB Infinity Cache
 GRAPH_CHUNK = 100
 METRIC = 'building-timesteps/sec at 17 bldgs x 65536 envs; HBM GB/s vs roofline'
-CONFIGS = ('headline', 'C2', 'C3', 'C4', 'C4-lean', 'C5', 'T9')
+CONFIGS = ('headline', 'C2', 'C3', 'C4', 'C4-lean', 'C5', 'T9', 'C4-B', 'C4-lean-B')
 
 
 # --------------------------------------------------------------------------------------------------- CPU baseline
@@ -429,7 +430,8 @@ class RolloutWorkload:
 
     dtype = 'f32'
 
-    def __init__(self, name: str, spec, E: int, K: int, device: str, rank: int, world: int, tuning: dict, what: str):
+    def __init__(self, name: str, spec, E: int, K: int, device: str, rank: int, world: int, tuning: dict, what: str, valu_per_unit_step: float = 100.0,
+                 valu_source: str = 'profiles/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step at two envs per lane, 101 at one'):
         import torch
         from citylearn_amd.engine import StepEngine
         self.name, self.what, self.E, self.K, self.device = name, what, E, K, device
@@ -444,6 +446,7 @@ class RolloutWorkload:
         self.period = self.n_windows
         self.units_per_step = self.eng.n_bldg * E * K
         self.kernels = None
+        self.inst, self.inst_source = valu_per_unit_step, valu_source
 
     def step_fn(self, i: int):
         w = i % self.n_windows
@@ -459,14 +462,13 @@ class RolloutWorkload:
         return self.eng.algorithmic_bytes_per_unit() / self.K
 
     def roofline(self, launch_s: float) -> dict:
-        # VALU-issue bound: lane-instructions per (env, building, step) from the SQ counters of this kernel
-        # (profiles/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step at two envs per lane, 101 at one)
-        inst = 100.0
+        # VALU-issue bound: lane-instructions per (env, building, step) from the SQ counters of this kernel (`inst_source`)
+        inst = self.inst
         peak = VALU_LANES * VALU_CLOCK_GHZ                      # G lane-instructions / s
         ach = self.units_per_step * inst / launch_s / 1e9
         return {'bound': 'valu', 'achieved': ach, 'peak': peak, 'unit': 'G lane-instructions/s', 'frac': ach / peak, 'kernel': self.kernels,
                 'launch_us': launch_s * 1e6, 'units_per_launch': self.units_per_step, 'valu_instructions_per_unit_step': inst,
-                'traffic': None, 'hbm_bytes_per_unit_step': self.bytes_per_unit(),
+                'valu_instructions_source': self.inst_source, 'traffic': None, 'hbm_bytes_per_unit_step': self.bytes_per_unit(),
                 'note': f'one launch = {self.K} env steps with state in registers; HBM sees state once per launch, so the bound is vector-ALU issue '
                         '(SURVEY 8d): achieved = units x VALU instructions per unit-step (SQ_INSTS_VALU, profiles/) / launch time, '
                         'peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz'}
@@ -500,6 +502,20 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
                             f'citylearn_challenge_2020_climate_zone_1 (9 buildings: heat pump, electric heater, cooling + DHW tanks, battery, PV; first 744 h) '
                             f'x {E} envs per GPU, cl_step_f32 mode A (thermal district: the reference\'s full per-building energy balance), env batch sharded '
                             'over GPUs, no collective', f64=f64, kpi=kpi)
+    if cfg in ('C4-B', 'C4-lean-B'):
+        # BASELINE config 4 in mode B (round 5): the 1024-building district through the building-chunked fused rollout -- 24 env steps per launch,
+        # unit state in registers, one cl_finish_kernel per launch for the chunks' district sums and returns
+        from citylearn_amd.synthetic import tile_district
+        thermal = cfg == 'C4-B'
+        spec = tile_district(load_district(sample_schema('citylearn_challenge_2020_climate_zone_1_744h' if thermal else 'citylearn_challenge_2022_phase_all_720h')), 1024)
+        return RolloutWorkload(cfg, spec, E, 24, device, rank, world, tuning,
+                               f'synthetic 1024-building district ({"2020 climate-zone-1 device set: heat pump, heater, 2 tanks, battery" if thermal else "battery + PV"}; sizes '
+                               f'jittered +-10 %) x {E} envs per GPU, cl_rollout_f32 mode B on the building-chunked district: 24 fused env steps per launch, unit state in '
+                               'registers, on-device Philox4x32-10 uniform random policy, one cl_finish_kernel per launch (district sums of the last step + K-step returns); '
+                               'env batch sharded over GPUs (8 x 1024 = the 8192 envs of BASELINE config 4), no collective',
+                               valu_per_unit_step=384.0 if thermal else 100.0,
+                               valu_source=('profiles/r02_thermal_*: 384 VALU instructions per unit of cl::unit_step<true>, the arithmetic the thermal fused kernel runs'
+                                            if thermal else 'profiles/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step (battery + PV fused kernel)'))
     if cfg in ('C4', 'C4-lean'):
         from citylearn_amd.synthetic import tile_district
         base = 'citylearn_challenge_2020_climate_zone_1_744h' if cfg == 'C4' else 'citylearn_challenge_2022_phase_all_720h'
@@ -514,7 +530,7 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
     raise SystemExit(f'unknown --config {cfg}')
 
 
-DEFAULT_ENVS = {'headline': ENVS_PER_GPU, 'C2': 4096, 'C3': 65536, 'C4': 1024, 'C4-lean': 1024, 'C5': 32768, 'T9': 65536}
+DEFAULT_ENVS = {'headline': ENVS_PER_GPU, 'C2': 4096, 'C3': 65536, 'C4': 1024, 'C4-lean': 1024, 'C5': 32768, 'T9': 65536, 'C4-B': 1024, 'C4-lean-B': 1024}
 
 
 # --------------------------------------------------------------------------------------------------- one rank
@@ -593,7 +609,7 @@ def run_rank(args):
         return walls, evs, reduce_max_seconds(kernel_s, dist, ctl_device), gather_seconds(mine, dist, ctl_device), gather_seconds(kernel_s, dist, ctl_device)
 
     wl = build_workload(cfg, E, device, rank, world, tuning, args.f64_maps, args.kpi, args.table_hours)
-    heavy = cfg in ('C3', 'C5')                          # ~100 us .. 1 ms per step: fewer steps in the kernel-time bracket
+    heavy = cfg in ('C3', 'C5', 'C4-B', 'C4-lean-B')     # ~100 us .. 1 ms per step: fewer steps in the kernel-time bracket
     walls, evs, launch_s, per_rank, per_rank_kernel = measure(wl, args.warmup, args.steps, args.reps, max(args.steps, 200 if heavy else 2000))
     wall_med = statistics.median(walls)
     roof = wl.roofline(launch_s)
@@ -689,7 +705,7 @@ def run_rank(args):
             'config': {'workload': what, 'name': cfg, 'envs_per_gpu': E, 'buildings': n_bldg,
                        'launch': 'hipGraph replay' if use_graph else 'eager', 'reward': 'ComfortReward' if cfg == 'C3' else 'RewardFunction',
                        'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)',
-                       **({'k_steps_per_launch': 24, 'step': 'one fused 24-step launch'} if cfg == 'C5' else {})},
+                       **({'k_steps_per_launch': 24, 'step': 'one fused 24-step launch'} if cfg in ('C5', 'C4-B', 'C4-lean-B') else {})},
             'ranks': world, 'world_size_seen': world if dist is None else dist.get_world_size(),
             # ranks inside the RCCL communicator itself (`world_size_seen` is the gloo group every rank joins first); null when the control plane is gloo
             'rccl_world_size': None if dist is None else dist.rccl_world_size, 'control_backend': backend, **({'control_fallback': dist.control_fallback} if dist is not None and dist.control_fallback else {}),
@@ -738,9 +754,9 @@ def parse_args(argv=None):
     ap.add_argument('--kpi', action='store_true', help='CLD_KPI: update the streaming KPI accumulators every step (mode A-kpi of SURVEY 8d; step configs)')
     ap.add_argument('--launch-timeout', type=float, default=None, help='seconds after which self-spawned ranks are terminated')
     args = ap.parse_args(argv)
-    heavy = args.config in ('C3', 'C5')
+    heavy = args.config in ('C3', 'C5', 'C4-B', 'C4-lean-B')
     if args.steps is None:
-        args.steps = {'C3': 300, 'C5': 200}.get(args.config, 5000)
+        args.steps = {'C3': 300, 'C5': 200, 'C4-B': 100, 'C4-lean-B': 200}.get(args.config, 5000)
     if args.warmup is None:
         args.warmup = 30 if heavy else 300
     return args

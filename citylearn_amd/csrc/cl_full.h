@@ -478,6 +478,16 @@ CL_DEV void full_step_body(const StepArgs& a) {
     [[maybe_unused]] int tr_i = 0;
     [[maybe_unused]] uint32_t* stage = reinterpret_cast<uint32_t*>(lds + (size_t)a.nw * NQ * TILE);
     constexpr bool FOLDK = LP && VEC == 2;               // the C4 shard's kernel: district_reduce<.., FOLD>
+    // ... whose 128 registers (16 waves per workgroup) do not hold two envs' unit, the next building's inputs, the fold's value AND the eight
+    // district accumulators: the accumulators live in the wave's own LDS row instead (zeroed here, read - add - written after every building:
+    // the same additions in the same order as in registers -- (0 + O1) + O2 -- and nobody else touches the row before district_reduce's barrier)
+    constexpr bool QLDS = LP;
+    [[maybe_unused]] float* qrow = lds + (size_t)w * NQ * TILE + lane * VEC;
+    if constexpr (QLDS) {
+        const F zero = (F)(0.0f);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) full_store<VEC, false>(qrow + q * TILE, zero);
+    }
     [[maybe_unused]] float fold_prev = 0.0f;
     [[maybe_unused]] bool fold_issued = false, folded = false;
     // (deferred finish) [64 chunks][16 district sums], behind the staged parameter blocks
@@ -591,9 +601,16 @@ CL_DEV void full_step_body(const StepArgs& a) {
                     full_store<VEC, NT>(a.out_bldg + CLO_SE_DHW * plane + off, O.se_dhw);
                 }
             }
-            full_accumulate<VEC>(q_net, O.net); full_accumulate<VEC>(q_cost, O.cost); full_accumulate<VEC>(q_em, O.emission);
             // multi-chunk MARL: accumulate sign(-net) * 0.01 * net^2; cl_finish_kernel scales by max(0, district net)
-            full_accumulate<VEC>(q_rw, marl_partial ? clv::marl_partial<F>(O.net) : rw);
+            if constexpr (QLDS) {
+                static_assert(CLQ_NET == 0 && CLQ_COST == 1 && CLQ_EMISSION == 2 && CLQ_REWARD == 3, "row order of the LDS accumulators");
+                const F add[NQ] = {O.net, O.cost, O.emission, marl_partial ? clv::marl_partial<F>(O.net) : rw};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) full_store<VEC, false>(qrow + q * TILE, full_load<VEC>(qrow + q * TILE) + add[q]);
+            } else {
+                full_accumulate<VEC>(q_net, O.net); full_accumulate<VEC>(q_cost, O.cost); full_accumulate<VEC>(q_em, O.emission);
+                full_accumulate<VEC>(q_rw, marl_partial ? clv::marl_partial<F>(O.net) : rw);
+            }
             CL_TRACE_AFTER(3 + 4 * tr_i, q_rw[0]);          // stores issued
 #ifdef CL_TRACE
             if (tr_i < 2) ++tr_i;
@@ -621,7 +638,7 @@ CL_DEV void full_step_body(const StepArgs& a) {
             fold_stash(a, lds_fold, w, lane, fold_prev);
         }
     }
-    district_reduce<VEC, false, FOLDK, KPI>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
+    district_reduce<VEC, false, FOLDK, KPI, QLDS>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
     if constexpr (KPI) {
         // baseline district series: the per-building baselines in cl_kpi_kernel's association (16 strided partial sums, added in order).
         // (district_reduce's barriers came after every wave's LDS writes; MARL's extra sweep leaves this region alone.)

@@ -210,16 +210,20 @@ CL_DEV void fold_finish(const StepArgs& a, const float* lds_fold, int w, int lan
 }
 
 // KPIS: the thread that writes an env's district net also feeds it to the env's streaming district accumulators (CLD_KPI, lean districts)
-template <int VEC, bool FLEX = false, bool FOLD = false, bool KPIS = false>
+// PRESTORED: the caller has kept the wave's partial sums in its LDS row all along (cl_full.h, the C4 shard's kernel: four accumulators fewer in
+// registers across the buildings of a wave) -- q_* are not read.
+template <int VEC, bool FLEX = false, bool FOLD = false, bool KPIS = false, bool PRESTORED = false>
 CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int env0, bool live, long long plane, int rkind,
                             const float (&q_net)[VEC], const float (&q_cost)[VEC], const float (&q_em)[VEC],
                             const float (&q_rw)[VEC], int stride, [[maybe_unused]] const float* lds_fold = nullptr) {
     constexpr int TILE = 64 * VEC;
-    float* mine = lds + (size_t)w * NQ * TILE + lane * VEC;
-    vstore<VEC>(mine + 0 * TILE, q_net);
-    vstore<VEC>(mine + 1 * TILE, q_cost);
-    vstore<VEC>(mine + 2 * TILE, q_em);
-    vstore<VEC>(mine + 3 * TILE, q_rw);
+    if constexpr (!PRESTORED) {
+        float* mine = lds + (size_t)w * NQ * TILE + lane * VEC;
+        vstore<VEC>(mine + 0 * TILE, q_net);
+        vstore<VEC>(mine + 1 * TILE, q_cost);
+        vstore<VEC>(mine + 2 * TILE, q_em);
+        vstore<VEC>(mine + 3 * TILE, q_rw);
+    }
     const int tile_env0 = blockIdx.x * TILE;
     // (KPIS) the control series' accumulators of the env whose district net this thread is about to write: in flight across the barrier
     [[maybe_unused]] KpiSeries pre;
@@ -917,20 +921,25 @@ __global__ void __launch_bounds__(1024) cl_step_lean_obs_kernel(const StepArgs a
 // order -- the reference's own summation order, citylearn.py:1909-1918).  With one such wave per SIMD the read stream, the
 // arithmetic and the write stream of a CU overlap, which the building-major kernels (one generation of waves in lockstep:
 // load, then compute, then store) cannot do.  NB = compile-time bound on the buildings held in flight.
-template <int NB, bool NT>
-__global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a) {
-    const int env = blockIdx.x * 256 + threadIdx.x;
-    const bool live = env < a.n_env;
+// VEC (round 5): envs per lane.  At one env per lane every plane access is a dword per lane -- 256 B per wave instruction; two envs per
+// lane (8-byte accesses, 128-thread workgroups so that the env tile still divides CL_ROW0_BLOCK) halve the number of memory instructions
+// and of wave-uniform operations per unit, at twice the registers per wave (two waves per SIMD instead of four, the same bytes in flight).
+// The district net of building b is parked in the register that held its state of charge (dead by then): no second array for MARL.
+template <int NB, bool NT, int VEC = 1>
+__global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepArgs a) {
+    constexpr int THREADS = 256 / VEC, TILE = 256;
+    const int env = blockIdx.x * TILE + threadIdx.x * VEC;
+    const bool live = env < a.n_env;                  // n_env % 4 == 0 (host): a lane's envs are all live or all dead
     const long long plane = (long long)a.n_bldg * a.n_env;
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     const bool quirk = a.flags & CLD_REF_T0_QUIRK;
     const bool act_by_bldg = (a.flags & CLD_ES_COL_IS_BLDG) && a.act_stride_env == 1;
-    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * 256) / CL_ROW0_BLOCK] : 0);
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
     // the buildings' parameter blocks and time-series rows, staged once per workgroup: a wave walking 17 buildings cannot
     // afford a scalar-load round trip per building (16 us at any batch size), and 17 x 36 SGPRs do not exist
     constexpr int PW = CLP_L_LAST - CLP_L_FIRST + 1;          // 32 parameter words
     __shared__ uint32_t sp[NB][PW + 4];
-    for (int i = threadIdx.x; i < a.n_bldg * (PW + 4); i += 256) {
+    for (int i = threadIdx.x; i < a.n_bldg * (PW + 4); i += THREADS) {
         const int b = i / (PW + 4), k = i - b * (PW + 4);
         uint32_t v;
         if (k < PW) v = a.params[(long long)b * CL_NP + CLP_L_FIRST + k];
@@ -940,27 +949,28 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
         }
         sp[b][k] = v;
     }
-    float s_soc[NB], s_eff[NB], s_deg[NB], a_es[NB];
+    float s_soc[NB][VEC], s_eff[NB][VEC], s_deg[NB][VEC], a_es[NB][VEC];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        s_soc[b] = s_eff[b] = s_deg[b] = a_es[b] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s_soc[b][i] = s_eff[b][i] = s_deg[b][i] = a_es[b][i] = 0.0f;
         if (live && b < a.n_bldg) {               // wave-uniform in b; no `break`: it would push the arrays to scratch
             const long long off = (long long)b * a.n_env + env;
-// (non-temporal loads here: no effect between 131 072 and 1 048 576 envs, scripts/stream_floor.py -- the copy-floor pattern
+            // (non-temporal loads here: no effect between 131 072 and 1 048 576 envs, scripts/stream_floor.py -- the copy-floor pattern
             //  gains 9 % from them at 1 048 576 envs, 120 -> 109 us; this kernel's 4-byte-per-lane loads do not)
-            s_soc[b] = a.state[CLS_B_SOC * plane + off];
-            s_eff[b] = a.state[CLS_B_EFF * plane + off];
-            s_deg[b] = a.state[CLS_B_DEGCAP * plane + off];
-            if (act_by_bldg) a_es[b] = a.actions[(long long)b * a.act_stride_col + env];
+            vload<VEC>(s_soc[b], a.state + CLS_B_SOC * plane + off);
+            vload<VEC>(s_eff[b], a.state + CLS_B_EFF * plane + off);
+            vload<VEC>(s_deg[b], a.state + CLS_B_DEGCAP * plane + off);
+            if (act_by_bldg) vload<VEC>(a_es[b], a.actions + (long long)b * a.act_stride_col + env);
         }
     }
     __syncthreads();
     if (!live) return;
-    float q_net = 0.0f, q_cost = 0.0f, q_em = 0.0f, q_rw = 0.0f;
-    float nets[NB];
+    float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        nets[b] = 0.0f;
         if (b >= a.n_bldg) continue;
         cl::Bp B;
         cl::load_bp<false>(B, &sp[b][0] - CLP_L_FIRST);           // the CLP_L_* block, from LDS (uniform address: a broadcast read)
@@ -970,39 +980,46 @@ __global__ void __launch_bounds__(256) cl_step_envmajor_kernel(const StepArgs a)
         R.outage = false;
         const long long off = (long long)b * a.n_env + env;
         const bool batt = B.flags & CLF_BATTERY;
-        float act_v = 0.0f;
-        if (B.a_es >= 0) act_v = act_by_bldg ? a_es[b] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)env * a.act_stride_env];
-        cl::State S;
-        S.soc = batt ? s_soc[b] : 0.0f; S.eff = batt ? s_eff[b] : 1.0f; S.degcap = batt ? s_deg[b] : 0.0f;
-        S.cs = S.hs = S.ds = 0.0f;
-        const cl::Act act = {0.0f, 0.0f, 0.0f, act_v, 0.0f, 0.0f};
-        cl::Out O;
-        cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
-        const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
-        if (batt) {
-            pstore<1, NT>(a.state + CLS_B_SOC * plane + off, {S.soc});
-            pstore<1, NT>(a.state + CLS_B_EFF * plane + off, {S.eff});
-            pstore<1, NT>(a.state + CLS_B_DEGCAP * plane + off, {S.degcap});
+        float o_soc[VEC], o_eff[VEC], o_deg[VEC], o_net[VEC], o_rw[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float act_v = 0.0f;
+            if (B.a_es >= 0) act_v = act_by_bldg ? a_es[b][i] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)(env + i) * a.act_stride_env];
+            cl::State S;
+            S.soc = batt ? s_soc[b][i] : 0.0f; S.eff = batt ? s_eff[b][i] : 1.0f; S.degcap = batt ? s_deg[b][i] : 0.0f;
+            S.cs = S.hs = S.ds = 0.0f;
+            const cl::Act act = {0.0f, 0.0f, 0.0f, act_v, 0.0f, 0.0f};
+            cl::Out O;
+            cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
+            o_soc[i] = S.soc; o_eff[i] = S.eff; o_deg[i] = S.degcap; o_net[i] = O.net;
+            o_rw[i] = cl::unit_reward<false>(rkind, B, S, O.net);
+            s_soc[b][i] = O.net;                                  // (MARL's second sweep reads the nets from here)
+            q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission; q_rw[i] += o_rw[i];
         }
-        pstore<1, NT>(a.out_bldg + CLO_NET * plane + off, {O.net});
-        if (rkind != CLR_MARL) pstore<1, NT>(a.out_bldg + CLO_REWARD * plane + off, {rw});
-        nets[b] = O.net;
-        q_net += O.net; q_cost += O.cost; q_em += O.emission; q_rw += rw;
+        if (batt) {
+            pstore<VEC, NT>(a.state + CLS_B_SOC * plane + off, o_soc);
+            pstore<VEC, NT>(a.state + CLS_B_EFF * plane + off, o_eff);
+            pstore<VEC, NT>(a.state + CLS_B_DEGCAP * plane + off, o_deg);
+        }
+        pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
+        if (rkind != CLR_MARL) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
     }
     if (rkind == CLR_MARL) {                      // reward_function.py:132-143: every building against the district net
-        q_rw = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) q_rw[i] = 0.0f;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             if (b >= a.n_bldg) continue;
-            const float rw = cl::marl_reward(nets[b], q_net);
-            a.out_bldg[CLO_REWARD * plane + (long long)b * a.n_env + env] = rw;
-            q_rw += rw;
+            float rw[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { rw[i] = cl::marl_reward(s_soc[b][i], q_net[i]); q_rw[i] += rw[i]; }
+            vstore<VEC>(a.out_bldg + CLO_REWARD * plane + (long long)b * a.n_env + env, rw);
         }
     }
-    a.out_env[(long long)CLQ_NET * a.n_env + env] = q_net;
-    a.out_env[(long long)CLQ_COST * a.n_env + env] = q_cost;
-    a.out_env[(long long)CLQ_EMISSION * a.n_env + env] = q_em;
-    a.out_env[(long long)CLQ_REWARD * a.n_env + env] = q_rw;
+    vstore<VEC>(a.out_env + (long long)CLQ_NET * a.n_env + env, q_net);
+    vstore<VEC>(a.out_env + (long long)CLQ_COST * a.n_env + env, q_cost);
+    vstore<VEC>(a.out_env + (long long)CLQ_EMISSION * a.n_env + env, q_em);
+    vstore<VEC>(a.out_env + (long long)CLQ_REWARD * a.n_env + env, q_rw);
 }
 
 #ifndef CL_TU_NOSLP      /* (cl_noslp_tu.hip compiles only what its two kernels need) */
@@ -1759,9 +1776,16 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // 17 x 262 144 28.2 vs 32.5 us, 17 x 1 048 576 136 vs 157 us; at 17 x 65 536 -- one wave per SIMD, nothing to hide the
         // per-building dependency chain behind -- 13.1 vs 8.0 us)
         const dim3 egrid((unsigned)((dims->n_env + 255) / 256));
-        name_add(tun, "cl_step_envmajor_kernel<20, %s>", a.nt ? "true" : "false");
-        if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<20, true>), egrid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((cl_step_envmajor_kernel<20, false>), egrid, dim3(256), 0, s, a);
+        // envs per lane (cl_tuning.vec: 1 or 2) and the compile-time bound on the buildings held in flight (17 = the 2022 challenge's
+        // district: three fewer register quadruples than the general 20)
+        const int evec = tun.vec == 2 && act_stride_env == 1 ? 2 : 1;
+        const int enb = dims->n_bldg <= 17 && tun.lean_variant != 8 ? 17 : 20;
+        name_add(tun, "cl_step_envmajor_kernel<%d, %s, %d>", enb, a.nt ? "true" : "false", evec);
+#define CL_EM(NB_, V_) do { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<NB_, true, V_>), egrid, dim3(256 / V_), 0, s, a); \
+                            else hipLaunchKernelGGL((cl_step_envmajor_kernel<NB_, false, V_>), egrid, dim3(256 / V_), 0, s, a); } while (0)
+        if (enb == 17) { if (evec == 2) CL_EM(17, 2); else CL_EM(17, 1); }
+        else { if (evec == 2) CL_EM(20, 2); else CL_EM(20, 1); }
+#undef CL_EM
     } else if (lean_shape) {
         // one workgroup per CU at most: with more rounds the generic kernel's smaller register file (52 vs 88 VGPRs, two
         // workgroups per CU) wins again -- 17 x 262 144: 30.8 us vs 33.0 us

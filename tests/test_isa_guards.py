@@ -144,14 +144,15 @@ def test_scratch_memory_is_confined_to_the_known_instantiations(units):
     wave under a 1024-thread workgroup's 128-register cap; the FLEX thermal kernel with detail planes: 13): a new entry is a regression."""
     known = {r'cl_step_kernelILi2ELb1ELb1ELb1ELb0ELb0EE': 52, r'cl_step_full_kernelILi2ELb1ELi1024ELi4ELb0ELb[01]EE': 8,
              r'cl_step_full_kernelILi2ELb0ELi576ELi5ELb0ELb[01]EE': 8, r'cl_step_full_kernelILi2ELb0ELi1024ELi5ELb0ELb[01]EE': 8,     # (the second: forced launches only)
-             # (the C4 shard's kernel: 12 bytes until round 4; the deferred fold keeps one more value alive across both buildings: 28 bytes = four
-             #  spills and five reloads per wave, measured together with the fold: profiles/r04_c4_fold_breakdown.log; 16 bytes since the first building's
-             #  loads left the loop)
-             r'cl_step_full_kernelILi2ELb0ELi1024ELi4ELb1ELb[01]EE': 16,
-             r'cl_step_full_kernelILi1ELb0ELi1024ELi5ELb1ELb[01]EE': 12,
              # the thermal step with the streaming KPI epilogue: 36 bytes RESERVED (slots of scalar registers that ended up parked in
              # vector-register lanes instead) and never accessed -- checked below
              r'cl_step_full_kpi_kernelILb[01]E': 36}
+    # the building-chunked thermal launches (BASELINE config 4; parameter blocks staged in LDS): 16 / 12 bytes per lane until round 4 -- the C4
+    # shard's 1.145 x HBM traffic (VERDICT r04) -- none since their district accumulators live in the wave's LDS row (cl_full.h, QLDS)
+    main_meta = units[0][1]
+    for pat in (r'cl_step_full_kernelILi2ELb0ELi1024ELi4ELb1ELb[01]EE', r'cl_step_full_kernelILi1ELb0ELi1024ELi5ELb1ELb[01]EE'):
+        hits = [k for k in main_meta if re.search(pat, k)]
+        assert len(hits) == 2 and all(main_meta[k]['private_seg_size'] == 0 for k in hits), (pat, [(k, main_meta[k]) for k in hits])
     for kernels, meta in units:
         for k, m in meta.items():
             if not m.get('private_seg_size'):
