@@ -362,7 +362,9 @@ class StepWorkload:
         self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, detail='min' if lstm else False, f64_maps=f64, kpi=kpi)
         if kpi:
             self.what += '; CLD_KPI: streaming KPI accumulators of evaluate() updated every step (mode A-kpi)'
-        if f64:
+        if f64 == 'chain':
+            self.what += '; CLD_F64_CHAIN: battery soc chain in float64, degraded capacity carried as the capacity loss'
+        elif f64:
             self.what += '; CLD_F64_MAPS: battery map in the reference\'s mixed float64 / float32 precision'
         self.eng.trace_kernels()
         self.stage = None
@@ -430,14 +432,14 @@ class RolloutWorkload:
 
     dtype = 'f32'
 
-    def __init__(self, name: str, spec, E: int, K: int, device: str, rank: int, world: int, tuning: dict, what: str, valu_per_unit_step: float = 100.0,
+    def __init__(self, name: str, spec, E: int, K: int, device: str, rank: int, world: int, tuning: dict, what: str, f64=False, valu_per_unit_step: float = 100.0,
                  valu_source: str = 'profiles/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step at two envs per lane, 101 at one'):
         import torch
         from citylearn_amd.engine import StepEngine
         self.name, self.what, self.E, self.K, self.device = name, what, E, K, device
         self.spec = spec
         self.tables = spec.episode_tables(0)
-        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, env_offset=rank * E)     # disjoint Philox streams per shard
+        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, env_offset=rank * E, f64_maps=f64)     # disjoint Philox streams per shard
         self.eng.trace_kernels()
         low, high = spec.action_limits()
         self.eng.set_action_limits(low, high)
@@ -485,7 +487,7 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
             return RolloutWorkload(cfg, spec, E, 24, device, rank, world, tuning,
                                    f'citylearn_challenge_2022_phase_all tables (17 buildings, {span}) x {E} envs per GPU, cl_rollout_f32 mode B: '
                                    '24 fused env steps per launch, state in registers, on-device Philox4x32-10 uniform random policy; env batch sharded '
-                                   'over GPUs (8 x 32 768 = the 262 144 envs of BASELINE config 5), no collective')
+                                   'over GPUs (8 x 32 768 = the 262 144 envs of BASELINE config 5), no collective', f64=f64)
         return StepWorkload(cfg, spec, E, device, rank, tuning,
                             f'citylearn_challenge_2022_phase_all tables (17 buildings, {span}) x {E} envs per GPU, '
                             'cl_step_f32 mode A (one env step per launch, state in HBM, fresh uniform random actions '
@@ -701,7 +703,7 @@ def run_rank(args):
             'n_gpus': world if not oversubscribed else n_distinct, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': wall_med / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if not args.f64_maps else 'f64 battery map / f32', 'data': 'synthetic',
+            'dtype': 'f32' if not args.f64_maps else 'f64 battery soc chain / f32' if args.f64_maps == 'chain' else 'f64 battery map / f32', 'data': 'synthetic',
             'config': {'workload': what, 'name': cfg, 'envs_per_gpu': E, 'buildings': n_bldg,
                        'launch': 'hipGraph replay' if use_graph else 'eager', 'reward': 'ComfortReward' if cfg == 'C3' else 'RewardFunction',
                        'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)',
@@ -751,9 +753,12 @@ def parse_args(argv=None):
     ap.add_argument('--no-traffic-pass', action='store_true', help='headline, N = 1: skip the two rocprofv3 --pmc child runs that measure roofline.traffic live')
     ap.add_argument('--no-streaming', action='store_true', help='skip the 17 x 1 048 576 HBM-streaming roofline entry of the headline')
     ap.add_argument('--f64-maps', action='store_true', help="CLD_F64_MAPS: battery map in the reference's mixed float64 / float32 precision (step configs)")
+    ap.add_argument('--f64-chain', action='store_true', help='CLD_F64_CHAIN: the battery soc chain in float64, degraded capacity as the capacity loss -- free-running 1e-4 on the default planes')
     ap.add_argument('--kpi', action='store_true', help='CLD_KPI: update the streaming KPI accumulators every step (mode A-kpi of SURVEY 8d; step configs)')
     ap.add_argument('--launch-timeout', type=float, default=None, help='seconds after which self-spawned ranks are terminated')
     args = ap.parse_args(argv)
+    if args.f64_chain:
+        args.f64_maps = 'chain'
     heavy = args.config in ('C3', 'C5', 'C4-B', 'C4-lean-B')
     if args.steps is None:
         args.steps = {'C3': 300, 'C5': 200, 'C4-B': 100, 'C4-lean-B': 200}.get(args.config, 5000)

@@ -52,3 +52,4 @@ EXPORTED_SYMBOLS = sorted(set(re.findall(r'\b(cl_\w+)\s*\(', _strip_comments(HEA
 
 assert _C['CLP_USED'] <= _C['CLP_F_FIRST'] and _C['CLP_F_LAST'] < _C['CLP_D_FIRST'] and _C['CLP_D_LAST'] < _C['CL_NP'], 'cl_param overflows CL_NP'
 assert _C['CLPD_USED'] * 2 <= _C['CLP_D_LAST'] - _C['CLP_D_FIRST'] + 1 and _C['CLP_D_FIRST'] % 2 == 0 and _C['CL_NP'] % 2 == 0
+assert _C['CLP_D_LAST'] < _C['CLP_C_FIRST'] and _C['CLP_C_LAST'] < _C['CL_NP'] and _C['CLP_C_FIRST'] % 2 == 0 and _C['CLPC_USED'] * 2 <= _C['CLP_C_LAST'] - _C['CLP_C_FIRST'] + 1

@@ -163,7 +163,7 @@ class CityLearnEnv(_GymEnv):
         self.district_spec: DistrictSpec = load_district(schema, **kwargs)
         self.electric_vehicles = list(self.district_spec.electric_vehicles)
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
-        self.f64_maps = bool(f64_maps)
+        self.f64_maps = f64_maps if f64_maps in ('chain', 'ref') else bool(f64_maps)      # ('chain': CLD_F64_CHAIN, the cheap 1e-4 mode)
         self.device = device
         self.observation_mode = observation_mode
         self.reference_quirks = reference_quirks

@@ -140,6 +140,36 @@ CL_DEV F battery_energy(const cl::BattP& B, F E, F& soc, F& eff_s, F& degcap) {
     return eb;
 }
 
+// update_electrical_storage (building.py:1801-1812) in either precision model: PREC 0 the fp32 map above, PREC 2 CLD_F64_CHAIN
+// (cl::battery_charge_chain per env of the pack; `deg` is then the capacity loss).  `flex`: the downward flexibility where OUT, else unused.
+// `g`: the building's whole parameter row in global memory (PREC 2 reads its CLP_C_* block from there; unused otherwise).
+template <typename F, int PREC, bool OUT>
+CL_DEV F battery_any(const FP& B, [[maybe_unused]] const uint32_t* __restrict__ g, F a_es, F flex, F& soc, F& eff, F& deg) {
+    if constexpr (PREC == 2) {
+        cl::BattC bc;
+        cl::load_battc(bc, g);
+        F eb;
+        if constexpr (Tr<F>::N == 1) {
+            cl::State S = {soc, eff, deg, 0.0f, 0.0f, 0.0f};
+            eb = cl::battery_charge_chain(bc, a_es, OUT ? flex : INFINITY, S);
+            soc = S.soc; eff = S.eff; deg = S.degcap;
+        } else {
+#pragma unroll
+            for (int i = 0; i < Tr<F>::N; ++i) {
+                cl::State S = {soc[i], eff[i], deg[i], 0.0f, 0.0f, 0.0f};
+                eb[i] = cl::battery_charge_chain(bc, a_es[i], OUT ? flex[i] : INFINITY, S);
+                soc[i] = S.soc; eff[i] = S.eff; deg[i] = S.degcap;
+            }
+        }
+        return eb;
+    } else {
+        cl::BattP bp; load_batt_f(bp, B.f + (CLP_F_BATT - CLP_F_FIRST), B.r);
+        F E = a_es * bp.pdt;
+        if constexpr (OUT) E = vmin(E, flex);
+        return battery_energy<F>(bp, E, soc, eff, deg);
+    }
+}
+
 // StorageDevice.charge under StorageTank.charge's power clamps (energy_model.py:719-768, 850-870)
 template <typename F>
 CL_DEV void tank_charge(F e, F prev_soc, const cl::TankP& T, float r, F& soc, F& eb) {
@@ -184,8 +214,8 @@ CL_DEV void end_use(const FP& B, const cl::Row& R, Ax<F>& A, F& c, F demand, F a
 }
 
 // The whole unit step; `t`, `first` (t == 0 under CLD_REF_T0_QUIRK) and OUT are wave-uniform.
-template <typename F, bool OUT, bool DETAIL>
-CL_DEV void unit_step(const FP& B, const cl::Row& R, int t, bool first, const Ac<F>& a, St<F>& S, Ou<F>& O) {
+template <typename F, bool OUT, bool DETAIL, int PREC = 0>
+CL_DEV void unit_step(const FP& B, const cl::Row& R, int t, bool first, const Ac<F>& a, St<F>& S, Ou<F>& O, [[maybe_unused]] const uint32_t* __restrict__ g = nullptr) {
     const F zero = splat<F>(0.0f);
     const bool has_batt = B.flags & CLF_BATTERY;
     Ax<F> A = {zero, zero, zero, zero, zero};
@@ -215,8 +245,11 @@ CL_DEV void unit_step(const FP& B, const cl::Row& R, int t, bool first, const Ac
     const auto es_first = a.es < 0.0f;
     if constexpr (OUT) {
         if (has_batt) {
-            cl::BattP bp; load_batt_f(bp, B.f + (CLP_F_BATT - CLP_F_FIRST), B.r);
-            eb_first = battery_energy<F>(bp, vmin(a.es * bp.pdt, flexibility<F>(B, R, A)), S_first.soc, S_first.eff, S_first.degcap);
+            if constexpr (PREC == 2) eb_first = battery_any<F, PREC, true>(B, g, a.es, flexibility<F>(B, R, A), S_first.soc, S_first.eff, S_first.degcap);
+            else {
+                cl::BattP bp; load_batt_f(bp, B.f + (CLP_F_BATT - CLP_F_FIRST), B.r);
+                eb_first = battery_energy<F>(bp, vmin(a.es * bp.pdt, flexibility<F>(B, R, A)), S_first.soc, S_first.eff, S_first.degcap);
+            }
             A.c_b = A.c_b + vsel(es_first, eb_first, zero);
         }
     }
@@ -241,11 +274,19 @@ CL_DEV void unit_step(const FP& B, const cl::Row& R, int t, bool first, const Ac
     A.c_ns = A.c_ns + e_ns;
     F eb_b = zero;
     if (has_batt) {
-        cl::BattP bp; load_batt_f(bp, B.f + (CLP_F_BATT - CLP_F_FIRST), B.r);
-        F E = a.es * bp.pdt;
-        if constexpr (OUT) E = vmin(E, flexibility<F>(B, R, A));
-        F soc = S.soc, eff = S.eff, deg = S.degcap;
-        const F eb_last = battery_energy<F>(bp, E, soc, eff, deg);
+        F soc, eff, deg, eb_last;
+        if constexpr (PREC == 2) {
+            soc = S.soc; eff = S.eff; deg = S.degcap;
+            F fl = zero;
+            if constexpr (OUT) fl = flexibility<F>(B, R, A);
+            eb_last = battery_any<F, PREC, OUT>(B, g, a.es, fl, soc, eff, deg);
+        } else {
+            cl::BattP bp; load_batt_f(bp, B.f + (CLP_F_BATT - CLP_F_FIRST), B.r);
+            F E = a.es * bp.pdt;
+            if constexpr (OUT) E = vmin(E, flexibility<F>(B, R, A));
+            soc = S.soc; eff = S.eff; deg = S.degcap;
+            eb_last = battery_energy<F>(bp, E, soc, eff, deg);
+        }
         if constexpr (OUT) {
             eb_b = vsel(es_first, eb_first, eb_last);
             S.soc = vsel(es_first, S_first.soc, soc); S.eff = vsel(es_first, S_first.eff, eff); S.degcap = vsel(es_first, S_first.degcap, deg);
@@ -450,7 +491,7 @@ constexpr int CL_LP_WORDS = (CLP_F_LAST - CLP_F_FIRST + 1) + CL_NF;      // 64 +
 // (576-thread workgroups, three waves per SIMD, 168 registers with a few spills; the vector ALUs are ~40 % busy at one env per lane
 // and the pack halves their work): bit-identical and 24 - 29 us against 17.7 us at 9 x 65 536, slower at every size tried -- the
 // waves in flight, not the instruction count, carry this kernel.
-template <int VEC, bool DETAIL, bool LP, bool NT, bool KPI>
+template <int VEC, bool DETAIL, bool LP, bool NT, bool KPI, int PREC = 0>
 CL_DEV void full_step_body(const StepArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC], then (LP) [buildings of the workgroup][CL_LP_WORDS] or (KPI) [n_bldg][64*VEC] baselines
     static_assert(!KPI || (DETAIL && !LP && VEC == 1), "the KPI epilogue is written for one env per lane, with the baseline / expected / served values of the detail unit");
@@ -528,6 +569,7 @@ CL_DEV void full_step_body(const StepArgs& a) {
             }
             clv::FP B;
             clv::load_fp<LP>(B, f);
+            [[maybe_unused]] const uint32_t* __restrict__ grow = PREC == 2 ? a.params + (long long)b * CL_NP : nullptr;
             cl::Row R;
             cl::load_row_scalar<true>(R, LP ? reinterpret_cast<const float*>(f + (CL_LP_WORDS - CL_NF)) : a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags,
                                       DETAIL ? a.ts + ((long long)(ts_row - a.t + a.n_steps - 1) * a.n_bldg + b) * CL_NF : nullptr);
@@ -544,8 +586,8 @@ CL_DEV void full_step_body(const StepArgs& a) {
             clv::St<F> S = {cur.soc, cur.eff, cur.deg, cur.cs, cur.hs, cur.ds};
             const clv::Ac<F> act = {cur.a_cs, cur.a_hs, cur.a_ds, cur.a_es, cur.a_cd, cur.a_hd};
             clv::Ou<F> O;
-            if (R.outage) clv::unit_step<F, true, DETAIL>(B, R, a.t, first, act, S, O);
-            else clv::unit_step<F, false, DETAIL>(B, R, a.t, first, act, S, O);
+            if (R.outage) clv::unit_step<F, true, DETAIL, PREC>(B, R, a.t, first, act, S, O, grow);
+            else clv::unit_step<F, false, DETAIL, PREC>(B, R, a.t, first, act, S, O, grow);
             F rw = clv::unit_reward<F>(rkind, B, S, O.net);
             CL_TRACE_AFTER(2 + 4 * tr_i, rw);
             CL_TRACE_AFTER(2 + 4 * tr_i, S.soc);
@@ -661,6 +703,12 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
     full_step_body<VEC, DETAIL, LP, NT, false>(a);
 }
 
+// CLD_F64_CHAIN: the same kernel around cl::battery_charge_chain (the float64 soc chain; csrc/cl_unit.h)
+template <int VEC, bool DETAIL, int MAXT, int WPE, bool LP, bool NT>
+__global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_chain_kernel(const StepArgs a) {
+    full_step_body<VEC, DETAIL, LP, NT, false, 2>(a);
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) cl_step_full_kpi_kernel(const StepArgs a) {
     full_step_body<1, true, false, NT, true>(a);
@@ -673,8 +721,8 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
 // in building order (the reference's order, citylearn.py:1909-1918).
 // (Round 3, tried: a wave that walks two items fetching the second item's planes before it stores the first one's -- the stores otherwise
 //  fence the loads behind them.  102 instead of 77 registers and SLOWER: 9 x 65 536 8.44 vs 7.86 us, 9 x 262 144 29.9 vs 29.2 us.)
-template <int VEC, int WPE, bool NT>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_tp_kernel(const StepArgs a, const int tp) {
+template <int VEC, bool NT, int PREC>
+CL_DEV void full_tp_body(const StepArgs& a, const int tp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [tp * n_bldg][NQ][64*VEC], then [tp][64*VEC]
     using F = typename Vec<VEC>::type;
     constexpr int TILE = 64 * VEC;
@@ -698,13 +746,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))
             full_load_in<VEC>(cur, a, f, b, env0, plane);
             clv::FP B;
             clv::load_fp(B, f);
+            [[maybe_unused]] const uint32_t* __restrict__ grow = PREC == 2 ? a.params + (long long)b * CL_NP : nullptr;
             cl::Row R;
             cl::load_row_scalar<true>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags, nullptr);
             clv::St<F> S = {cur.soc, cur.eff, cur.deg, cur.cs, cur.hs, cur.ds};
             const clv::Ac<F> act = {cur.a_cs, cur.a_hs, cur.a_ds, cur.a_es, cur.a_cd, cur.a_hd};
             clv::Ou<F> O;
-            if (R.outage) clv::unit_step<F, true, false>(B, R, a.t, first, act, S, O);
-            else clv::unit_step<F, false, false>(B, R, a.t, first, act, S, O);
+            if (R.outage) clv::unit_step<F, true, false, PREC>(B, R, a.t, first, act, S, O, grow);
+            else clv::unit_step<F, false, false, PREC>(B, R, a.t, first, act, S, O, grow);
             const F rw = clv::unit_reward<F>(rkind, B, S, O.net);
             const long long off = (long long)b * a.n_env + env0;
             if (B.flags & CLF_BATTERY) {
@@ -759,6 +808,17 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))
         __syncthreads();
         sum_rows(NQ - 1, NQ);
     }
+}
+
+template <int VEC, int WPE, bool NT>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_tp_kernel(const StepArgs a, const int tp) {
+    full_tp_body<VEC, NT, 0>(a, tp);
+}
+
+// CLD_F64_CHAIN
+template <int VEC, int WPE, bool NT>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_tp_chain_kernel(const StepArgs a, const int tp) {
+    full_tp_body<VEC, NT, 2>(a, tp);
 }
 
 }  // namespace

@@ -427,8 +427,10 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
 
 // FLEX: the district has EV chargers / washing machines (cl_flex.h ran just before); a separate instantiation so that
 // districts without them keep their register budget.
-template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, bool F64 = false, bool FOLD = false>
+// PREC: the battery map -- 0 fp32, 1 CLD_F64_MAPS (two more state planes), 2 CLD_F64_CHAIN (cl_unit.h)
+template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, int PREC = 0, bool FOLD = false>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
+    constexpr bool F64 = PREC == 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
@@ -525,7 +527,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                     act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
                 }
                 cl::Out O;
-                cl::unit_step<FULL, F64>(B, R, a.t, quirk, act, S, O);
+                cl::unit_step<FULL, PREC>(B, R, a.t, quirk, act, S, O);
                 if (FLEX && fbi >= 0) cl::apply_flex(R.outage, R.price, R.carbon, x_load[i], x_chg[i], O);
                 const float rw = cl::unit_reward<FULL>(rkind, B, S, O.net);
                 s_soc[i] = S.soc; s_eff[i] = S.eff; s_deg[i] = S.degcap; s_cs[i] = S.cs; s_hs[i] = S.hs; s_ds[i] = S.ds;
@@ -627,8 +629,9 @@ struct ObsFusedArgs {
     cl_obs_dep deps[CLOB_MAX_DEPS];     // grouped by building
 };
 
-template <int VEC, bool FLEX, bool NT, bool OBS, bool KPI = false, bool F64 = false>
+template <int VEC, bool FLEX, bool NT, bool OBS, bool KPI = false, int PREC = 0>
 CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of) {     // lds: [nw][NQ][64*VEC] (, then [64*VEC][pitch])
+    constexpr bool F64 = PREC == 1;
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -740,6 +743,25 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
                         cl::State S = {s_soc[m][i], s_eff[m][i], s_deg[m][i], 0.0f, 0.0f, 0.0f, s_efl[m][i], s_dgl[m][i]};
                         const float eb = cl::battery_charge_ref(B64, (double)a_es[m][i] * B64.pow * B64.dt / B64.r, a.t == 0, S);     // (flexibility = +inf)
                         s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap; s_efl[m][i] = S.eff_lo; s_dgl[m][i] = S.deg_lo;
+                        soc_rw[i] = S.soc;
+                        o_cb[i] = cbk * eb;
+                        o_net[i] = fmaf(c_ns + o_cb[i], B.r, sol);
+                    }
+                }
+            } else if (PREC == 2 && batt) {
+                // the soc chain in float64, the degraded capacity as the capacity loss (CLD_F64_CHAIN, cl_unit.h)
+                if constexpr (PREC == 2) {
+                    cl::BattC bc;
+                    cl::load_battc(bc, B.p);
+                    if (B.a_es < 0) {
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) a_es[m][i] = 0.0f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        cl::State S = {s_soc[m][i], s_eff[m][i], s_deg[m][i], 0.0f, 0.0f, 0.0f};
+                        const float eb = cl::battery_charge_chain(bc, a_es[m][i], INFINITY, S);
+                        s_soc[m][i] = S.soc; s_eff[m][i] = S.eff; s_deg[m][i] = S.degcap;
                         soc_rw[i] = S.soc;
                         o_cb[i] = cbk * eb;
                         o_net[i] = fmaf(c_ns + o_cb[i], B.r, sol);
@@ -900,7 +922,14 @@ __global__ void __launch_bounds__(1024) cl_step_lean_kernel(const StepArgs a) {
 template <int VEC, bool NT>
 __global__ void __launch_bounds__(1024) cl_step_lean_f64_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    lean_step_body<VEC, false, NT, false, false, true>(a, lds, nullptr);
+    lean_step_body<VEC, false, NT, false, false, 1>(a, lds, nullptr);
+}
+
+// CLD_F64_CHAIN: the lean step with the soc chain in float64 (cl::battery_charge_chain) -- same launch shape, same three state planes
+template <int VEC, bool NT>
+__global__ void __launch_bounds__(1024) cl_step_lean_chain_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lean_step_body<VEC, false, NT, false, false, 2>(a, lds, nullptr);
 }
 
 template <int VEC, bool NT>
@@ -925,7 +954,7 @@ __global__ void __launch_bounds__(1024) cl_step_lean_obs_kernel(const StepArgs a
 // lane (8-byte accesses, 128-thread workgroups so that the env tile still divides CL_ROW0_BLOCK) halve the number of memory instructions
 // and of wave-uniform operations per unit, at twice the registers per wave (two waves per SIMD instead of four, the same bytes in flight).
 // The district net of building b is parked in the register that held its state of charge (dead by then): no second array for MARL.
-template <int NB, bool NT, int VEC = 1>
+template <int NB, bool NT, int VEC = 1, int PREC = 0>
 __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepArgs a) {
     constexpr int THREADS = 256 / VEC, TILE = 256;
     const int env = blockIdx.x * TILE + threadIdx.x * VEC;
@@ -937,12 +966,15 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
     const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
     // the buildings' parameter blocks and time-series rows, staged once per workgroup: a wave walking 17 buildings cannot
     // afford a scalar-load round trip per building (16 us at any batch size), and 17 x 36 SGPRs do not exist
+    // (PREC == 2, CLD_F64_CHAIN: the chain's float64 constants -- 2 x CLPC_USED words of the CLP_C_* block -- ride behind them)
     constexpr int PW = CLP_L_LAST - CLP_L_FIRST + 1;          // 32 parameter words
-    __shared__ uint32_t sp[NB][PW + 4];
-    for (int i = threadIdx.x; i < a.n_bldg * (PW + 4); i += THREADS) {
-        const int b = i / (PW + 4), k = i - b * (PW + 4);
+    constexpr int CW = PREC == 2 ? 2 * CLPC_USED : 0;
+    __shared__ __attribute__((aligned(8))) uint32_t sp[NB][PW + 4 + CW];
+    for (int i = threadIdx.x; i < a.n_bldg * (PW + 4 + CW); i += THREADS) {
+        const int b = i / (PW + 4 + CW), k = i - b * (PW + 4 + CW);
         uint32_t v;
         if (k < PW) v = a.params[(long long)b * CL_NP + CLP_L_FIRST + k];
+        else if (k >= PW + 4) v = a.params[(long long)b * CL_NP + CLP_C_FIRST + (k - (PW + 4))];
         else {
             const float* q = a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF;
             v = __float_as_uint(k == PW ? q[CLT_NSL] : k == PW + 1 ? q[CLT_SOLAR] : k == PW + 2 ? q[CLT_PRICE] : q[CLT_CARBON]);
@@ -990,7 +1022,19 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
             S.cs = S.hs = S.ds = 0.0f;
             const cl::Act act = {0.0f, 0.0f, 0.0f, act_v, 0.0f, 0.0f};
             cl::Out O;
-            cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
+            if constexpr (PREC == 2) {
+                // the lean unit around cl::battery_charge_chain (same lines as cl::unit_step<false, 2>), its constants read from the LDS copy
+                float eb = 0.0f;
+                if (batt) {
+                    cl::BattC bc;
+                    cl::load_battc64(bc, &sp[b][0] + (PW + 4) - CLP_C_FIRST);
+                    bc.cap32 = B.batt.cap; bc.omd32 = B.batt.omd; bc.degk = B.batt.degk;       // (the CLP_L_* words: already here)
+                    eb = cl::battery_charge_chain(bc, act_v, INFINITY, S);
+                }
+                const bool first = quirk && a.t == 0;
+                const float c_ns = first ? 3.0f * R.nsl : R.nsl, c_b = first ? 2.0f * eb : eb;
+                O.net = fmaf(c_ns + c_b, B.r, R.sol); O.cost = cl::mul_rn(O.net, R.price); O.emission = fmaxf(0.0f, O.net * R.carbon);
+            } else cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
             o_soc[i] = S.soc; o_eff[i] = S.eff; o_deg[i] = S.degcap; o_net[i] = O.net;
             o_rw[i] = cl::unit_reward<false>(rkind, B, S, O.net);
             s_soc[b][i] = O.net;                                  // (MARL's second sweep reads the nets from here)
@@ -1240,7 +1284,7 @@ __global__ void cl_marl_reward_kernel(const StepArgs a) {
 }
 
 __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __restrict__ state,
-                                float* __restrict__ kpi_bldg, float* __restrict__ kpi_env, int n_env, int n_bldg) {
+                                float* __restrict__ kpi_bldg, float* __restrict__ kpi_env, int n_env, int n_bldg, uint32_t flags) {
     const long long plane = (long long)n_bldg * n_env;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < plane) {
@@ -1249,7 +1293,8 @@ __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __re
         if (state) {
             state[CLS_B_SOC * plane + i] = __uint_as_float(p[CLP_L_SOC0]);
             state[CLS_B_EFF * plane + i] = __uint_as_float(p[CLP_L_EFF0]);
-            state[CLS_B_DEGCAP * plane + i] = __uint_as_float(p[CLP_L_CAP]);
+            // (CLD_F64_CHAIN: the plane carries the capacity LOSS, capacity - degraded_capacity: nothing lost yet)
+            state[CLS_B_DEGCAP * plane + i] = (flags & CLD_F64_CHAIN) ? 0.0f : __uint_as_float(p[CLP_L_CAP]);
             state[CLS_CS_SOC * plane + i] = __uint_as_float(p[CLP_CS_SOC0]);
             state[CLS_HS_SOC * plane + i] = __uint_as_float(p[CLP_HS_SOC0]);
             state[CLS_DS_SOC * plane + i] = __uint_as_float(p[CLP_DS_SOC0]);
@@ -1306,6 +1351,11 @@ extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int ke
     case 21: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 1>), grid, block, lds, s, r); break;
     case 22: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2>), grid, block, lds, s, r); break;
     case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), grid, block, lds, s, r); break;
+    // CLD_F64_CHAIN (one env per lane: 2000 + key)
+    case 2012: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, true, false, 2>), grid, block, lds, s, r); break;
+    case 2111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1, true, false, 2>), grid, block, lds, s, r); break;
+    case 3012: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, true, true, 2>), grid, block, lds, s, r); break;
+    case 3111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1, true, true, 2>), grid, block, lds, s, r); break;
     // building-chunked districts (gridDim.y workgroup rows; cl_rollout.h)
     case 1012: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, true, true>), grid, block, lds, s, r); break;
     case 1022: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2, true, true>), grid, block, lds, s, r); break;
@@ -1460,7 +1510,7 @@ int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, floa
     const int block = 256;
     const unsigned grid = (unsigned)((n + block - 1) / block);
     hipLaunchKernelGGL(cl_reset_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, params, state, kpi_bldg,
-                       kpi_env, dims->n_env, dims->n_bldg);
+                       kpi_env, dims->n_env, dims->n_bldg, dims->flags);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_reset_kernel launch");
     return CL_OK;
 }
@@ -1585,6 +1635,15 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (tun.vec) vec = tun.vec;
     // CLD_F64_MAPS: the battery map in float64 -- general and lean step kernels at one or two envs per lane (a double is two VGPRs)
     const bool f64 = dims->flags & CLD_F64_MAPS;
+    // CLD_F64_CHAIN: the soc chain in float64 on the default three state planes (cl_unit.h battery_charge_chain) -- lean, env-major, general and
+    // thermal-specialised step kernels
+    const bool chain = dims->flags & CLD_F64_CHAIN;
+    if (chain) {
+        if (f64) return fail(CL_EINVAL, "CLD_F64_CHAIN and CLD_F64_MAPS are two precision models of the same map: pick one");
+        if (flex) return fail(CL_EINVAL, "CLD_F64_CHAIN is not implemented for districts with flexible loads (the EV batteries of cl_flex_kernel are fp32)");
+        if ((dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL)) return fail(CL_EINVAL, "CLD_F64_CHAIN with CLD_KPI needs CLD_WRITE_DETAIL");
+        if (full) vec = 1;                     // (the thermal unit around the float64 chain spills at two envs per lane)
+    }
     if (f64) {
         if (flex) return fail(CL_EINVAL, "CLD_F64_MAPS is not implemented for districts with flexible loads (the EV batteries of cl_flex_kernel are fp32)");
         if ((dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL)) return fail(CL_EINVAL, "CLD_F64_MAPS with CLD_KPI needs CLD_WRITE_DETAIL");
@@ -1624,14 +1683,14 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // and the reserved plane has to hold both buffers and the marker words.  Anything else keeps the second launch.
     const int fold_per_row = a.n_chunks > 1 ? (NQ * tile + a.n_chunks - 1) / a.n_chunks : 0;
     const bool can_defer = a.n_chunks > 1 && tun.finish == 3 && rkind_host != CLR_MARL && rkind_host != CLR_EV && !flex &&
-                           !(dims->flags & (CLD_KPI | CLD_F64_MAPS | CLD_WRITE_DETAIL)) && fold_per_row <= 16 && a.nw == 16 && a.n_chunks <= 64 &&
+                           !(dims->flags & (CLD_KPI | CLD_F64_MAPS | CLD_F64_CHAIN | CLD_WRITE_DETAIL)) && fold_per_row <= 16 && a.nw == 16 && a.n_chunks <= 64 &&
                            (2ll * a.n_chunks * NQ + 1) * dims->n_env <= (long long)dims->n_bldg * dims->n_env - 4;
     const dim3 grid(grid_x, a.n_chunks);
     const bool det = dims->flags & CLD_WRITE_DETAIL;
     // streaming KPIs of thermal / outage districts (and of any district stepped with detail planes) inside the step launch:
     // cl_step_full_kpi_kernel (cl_full.h); cl_tuning.kpi_passes = 1 keeps the separate cl_kpi_kernel pass (A/B), 2 the two round-1 passes
     // (up to 128 buildings: their baselines of one env tile sit in LDS, 256 B per building)
-    const bool kpi_full = (dims->flags & CLD_KPI) && full && !flex && !f64 && a.n_chunks == 1 && vec == 1 && tun.full_variant != 1 && tun.kpi_passes == 0 &&
+    const bool kpi_full = (dims->flags & CLD_KPI) && full && !flex && !f64 && !chain && a.n_chunks == 1 && vec == 1 && tun.full_variant != 1 && tun.kpi_passes == 0 &&
                           dims->n_bldg <= 128;
     // ... whose waves should all be resident at once (16 per CU at its 119 registers): as many waves per workgroup as that allows, at least
     // two (9 x 65 536: four waves 18.8 us, the step-only default of five -- two generations -- 23.6 us; profiles/r03_kpi_in_step_probe.log)
@@ -1660,7 +1719,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // 9 x 16 384 5.62 -> 5.01 us, 6 x 16 384 5.50 -> 4.41, 12 x 16 384 6.15 -> 5.25, 16 x 16 384 6.26 -> 5.84 (scripts/tp_small_probe.py)
     const unsigned tiles1 = (unsigned)((dims->n_env + 63) / 64);
     const bool tp_small = !tp_forced && tiles1 > 192 && tiles1 <= 256 && dims->n_bldg >= 6 && dims->n_bldg <= 16;
-    const int tp_vec = (tp_forced && tun.vec == 1) || tp_small ? 1 : 2;
+    const int tp_vec = (tp_forced && tun.vec == 1) || tp_small || chain ? 1 : 2;       // (the float64 chain spills at two envs per lane)
     const int tp_auto_tiles = tp_small ? 1 : (int)((dims->n_env + 256 * 64 * tp_vec - 1) / (256 * 64 * tp_vec));      // one workgroup per CU
     const int tp_tiles = tp_forced ? (tun.b_chunk > 0 ? tun.b_chunk : CL_ROW0_BLOCK / (64 * tp_vec)) : tp_auto_tiles;
     const int tp_nw = tp_forced && tun.nw ? tun.nw : (tp_small ? dims->n_bldg : 16);
@@ -1683,15 +1742,52 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         return fail(CL_EINVAL, "CLD_KPI without CLD_WRITE_DETAIL needs a step launch that updates the accumulators itself (battery + PV: n_bldg=%d <= 2 x nw=%d "
                                "waves, no chunks; thermal: one env per lane, no chunks, no flexible loads, no CLD_F64_MAPS): drop the cl_tuning override or set CLD_WRITE_DETAIL",
                     dims->n_bldg, a.nw);
-    if (f64) {
+    const bool envmajor_shape = !full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 106496));
+    if (chain) {
+        if (envmajor_shape) {
+            const dim3 egrid((unsigned)((dims->n_env + 255) / 256));
+            const int enb = dims->n_bldg <= 17 ? 17 : 20;
+            name_add(tun, "cl_step_envmajor_kernel<%d, %s, 1, 2>", enb, a.nt ? "true" : "false");
+            if (enb == 17) { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<17, true, 1, 2>), egrid, dim3(256), 0, s, a);
+                             else hipLaunchKernelGGL((cl_step_envmajor_kernel<17, false, 1, 2>), egrid, dim3(256), 0, s, a); }
+            else { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<20, true, 1, 2>), egrid, dim3(256), 0, s, a);
+                   else hipLaunchKernelGGL((cl_step_envmajor_kernel<20, false, 1, 2>), egrid, dim3(256), 0, s, a); }
+        } else if (!full && lean_shape) {
+            switch (vec) {
+            case 1: CL_LAUNCH_NT(cl_step_lean_chain_kernel, 1); break;
+            case 2: CL_LAUNCH_NT(cl_step_lean_chain_kernel, 2); break;
+            case 4: CL_LAUNCH_NT(cl_step_lean_chain_kernel, 4); break;
+            default: return fail(CL_EINVAL, "bad vec %d", vec);
+            }
+        } else if (tp_kernel) {
+            // thermal districts, several env tiles per workgroup (cl_step_full_tp_kernel's launch shape)
+            a.nw = tp_nw;
+            const dim3 g2(tp_grid), b2(64 * a.nw);
+            name_add(tun, "cl_step_full_tp_chain_kernel<1, 4, %s>", a.nt ? "true" : "false");
+            if (a.nt) hipLaunchKernelGGL((cl_step_full_tp_chain_kernel<1, 4, true>), g2, b2, tp_lds, s, a, tp_tiles);
+            else hipLaunchKernelGGL((cl_step_full_tp_chain_kernel<1, 4, false>), g2, b2, tp_lds, s, a, tp_tiles);
+        } else if (full && tun.full_variant != 1) {
+            // thermal / outage districts: the pack-generic kernel of cl_full.h at one env per lane (parameter blocks staged in LDS where chunked)
+            if (det) CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, true, 1024, 4, false);
+            else if (lp) CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, true);
+            else CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, false);
+        } else {
+            name_add(tun, "cl_step_kernel<%d, %s, %s, false, 2, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
+            if (full && det) hipLaunchKernelGGL((cl_step_kernel<1, true, true, false, 2>), grid, block, lds, s, a);
+            else if (full) hipLaunchKernelGGL((cl_step_kernel<1, true, false, false, 2>), grid, block, lds, s, a);
+            else if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, 2>), grid, block, lds, s, a);
+            else if (vec == 2) hipLaunchKernelGGL((cl_step_kernel<2, false, false, false, 2>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, 2>), grid, block, lds, s, a);
+        }
+    } else if (f64) {
         if (!full && lean_shape) {
             if (vec == 1) CL_LAUNCH_NT(cl_step_lean_f64_kernel, 1); else CL_LAUNCH_NT(cl_step_lean_f64_kernel, 2);
         } else {
-            name_add(tun, "cl_step_kernel<%d, %s, %s, false, true, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
-            if (full && det) hipLaunchKernelGGL((cl_step_kernel<1, true, true, false, true>), grid, block, lds, s, a);
-            else if (full) hipLaunchKernelGGL((cl_step_kernel<1, true, false, false, true>), grid, block, lds, s, a);
-            else if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, true>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((cl_step_kernel<2, false, false, false, true>), grid, block, lds, s, a);
+            name_add(tun, "cl_step_kernel<%d, %s, %s, false, 1, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
+            if (full && det) hipLaunchKernelGGL((cl_step_kernel<1, true, true, false, 1>), grid, block, lds, s, a);
+            else if (full) hipLaunchKernelGGL((cl_step_kernel<1, true, false, false, 1>), grid, block, lds, s, a);
+            else if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, 1>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((cl_step_kernel<2, false, false, false, 1>), grid, block, lds, s, a);
         }
     } else if (flex && !full && lean_shape) {
         switch (vec) {
@@ -1705,7 +1801,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (vec > 2) return fail(CL_EINVAL, "bad vec %d for the flexible-load step", vec);
         const dim3& grid_f = grid;
         const size_t lds_f = lds;
-        name_add(tun, "cl_step_kernel<%d, %s, %s, true, false, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
+        name_add(tun, "cl_step_kernel<%d, %s, %s, true, 0, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
         if (full && det) {
             if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, true, true, true>), grid_f, block, lds_f, s, a);
             else hipLaunchKernelGGL((cl_step_kernel<2, true, true, true>), grid_f, block, lds_f, s, a);
@@ -1757,21 +1853,21 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 5, false);
         }
     } else if (full && det) {
-        name_add(tun, "cl_step_kernel<%d, true, true, false, false, false>", vec);
+        name_add(tun, "cl_step_kernel<%d, true, true, false, 0, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, true>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, true>), grid, block, lds, s, a); break;
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
     } else if (full) {
-        name_add(tun, "cl_step_kernel<%d, true, false, false, false, false>", vec);
+        name_add(tun, "cl_step_kernel<%d, true, false, false, 0, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, true, false>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, true, false>), grid, block, lds, s, a); break;
         // (four envs per lane is not instantiated for the thermal unit: 92 bytes of scratch per lane, never selected by the library)
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
-    } else if (!full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 106496))) {
+    } else if (envmajor_shape) {
         // two or more waves per SIMD: the env-major kernel (bench.py --envs-per-gpu: 17 x 131 072 17.0 vs 18.5 us,
         // 17 x 262 144 28.2 vs 32.5 us, 17 x 1 048 576 136 vs 157 us; at 17 x 65 536 -- one wave per SIMD, nothing to hide the
         // per-building dependency chain behind -- 13.1 vs 8.0 us)
@@ -1780,7 +1876,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // district: three fewer register quadruples than the general 20)
         const int evec = tun.vec == 2 && act_stride_env == 1 ? 2 : 1;
         const int enb = dims->n_bldg <= 17 && tun.lean_variant != 8 ? 17 : 20;
-        name_add(tun, "cl_step_envmajor_kernel<%d, %s, %d>", enb, a.nt ? "true" : "false", evec);
+        name_add(tun, "cl_step_envmajor_kernel<%d, %s, %d, 0>", enb, a.nt ? "true" : "false", evec);
 #define CL_EM(NB_, V_) do { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<NB_, true, V_>), egrid, dim3(256 / V_), 0, s, a); \
                             else hipLaunchKernelGGL((cl_step_envmajor_kernel<NB_, false, V_>), egrid, dim3(256 / V_), 0, s, a); } while (0)
         if (enb == 17) { if (evec == 2) CL_EM(17, 2); else CL_EM(17, 1); }
@@ -1813,19 +1909,19 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // building-chunked battery + PV districts (C4 with the 2022 device set): the instantiations that fold the chunk sums themselves
         // (finish = 2: their own, inside the launch; finish = 3: the previous step's, deferred)
         a.fused_finish = tun.finish == 2 ? 1 : 2;
-        name_add(tun, "cl_step_kernel<%d, false, false, false, false, true>", vec);
+        name_add(tun, "cl_step_kernel<%d, false, false, false, 0, true>", vec);
         // (four envs per lane x 16 waves: 64 KB of reduction rows + the 4 KB exchange tile of the deferred fold -- more dynamic LDS than a
         //  kernel gets without opting in where the runtime enforces the 64 KB default; gfx950's 160 KB hold it)
         if (lds > 64 * 1024) {
-            const void* fn = vec == 1 ? reinterpret_cast<const void*>(cl_step_kernel<1, false, false, false, false, true>)
-                                      : reinterpret_cast<const void*>(cl_step_kernel<4, false, false, false, false, true>);
+            const void* fn = vec == 1 ? reinterpret_cast<const void*>(cl_step_kernel<1, false, false, false, 0, true>)
+                                      : reinterpret_cast<const void*>(cl_step_kernel<4, false, false, false, 0, true>);
             if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
                 return hip_fail(e, "hipFuncSetAttribute(cl_step_kernel<.., FOLD>)");
         }
-        if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, false, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, false, true>), grid, block, lds, s, a);
+        if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, 0, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, 0, true>), grid, block, lds, s, a);
     } else {
-        name_add(tun, "cl_step_kernel<%d, false, false, false, false, false>", vec);
+        name_add(tun, "cl_step_kernel<%d, false, false, false, 0, false>", vec);
         switch (vec) {
         case 1: hipLaunchKernelGGL((cl_step_kernel<1, false, false>), grid, block, lds, s, a); break;
         case 2: hipLaunchKernelGGL((cl_step_kernel<2, false, false>), grid, block, lds, s, a); break;
@@ -1981,7 +2077,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_EV)
         return fail(CL_EINVAL, "reward kind CLR_EV needs the flexible-load tables (cl_rollout_seq_f32)");
     if (dims->flags & CLD_KPI) return fail(CL_EINVAL, "the fused rollout keeps no streaming KPIs: use cl_rollout_seq_f32 with CLD_KPI");
-    if (dims->flags & CLD_F64_MAPS) return fail(CL_EINVAL, "the fused rollout evaluates the battery map in fp32: use cl_rollout_seq_f32 with CLD_F64_MAPS");
+    if (dims->flags & CLD_F64_MAPS) return fail(CL_EINVAL, "the fused rollout evaluates the battery map in fp32 or as the float64 chain (CLD_F64_CHAIN): use cl_rollout_seq_f32 with CLD_F64_MAPS");
     if (k_steps < 0 || t0 < 0 || t0 + k_steps > dims->n_steps)
         return fail(CL_ERANGE, "steps [%d, %d) outside [0, %d)", t0, t0 + k_steps, dims->n_steps);
     if (actions && act_stride_env == 1 && ((act_stride_col % 4) != 0 || (act_stride_step % 4) != 0))
@@ -2002,7 +2098,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     // cut into chunks of `b_chunk` <= 16 MB along gridDim.y (cl_rollout_kernel's note); cl_finish_kernel folds the chunk sums once per launch
     const int mb_max = full ? 1 : 2;
     const bool chunked = dims->n_bldg > 16 * mb_max;
-    int mb = full ? 1 : (dims->n_bldg > 16 ? 2 : 1);
+    int mb = full ? 1 : (dims->n_bldg > 16 || (dims->flags & CLD_F64_CHAIN) ? 2 : 1);      // (the one-building chain instantiation reserves scratch memory)
     if (chunked) {
         if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL)
             return fail(CL_EINVAL, "the fused rollout of a building-chunked district (n_bldg=%d) cannot couple the buildings inside a step (MARL): use cl_rollout_seq_f32", dims->n_bldg);
@@ -2021,18 +2117,20 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     // (scripts/rollout_vec_probe.py); chunked districts: the workgroup count is env tiles x chunks
     const long long wg2 = (long long)((dims->n_env + 127) / 128) * a.n_chunks, rounds2 = (wg2 + 255) / 256;
     const bool full_rounds = (long long)dims->n_env * a.n_chunks >= 32768 && wg2 * 100 >= rounds2 * 256 * 85 && dims->n_env >= 128;
-    const int vec = tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && full_rounds) ? 2 : 1);
+    const bool chain = dims->flags & CLD_F64_CHAIN;          // (the float64 soc chain: instantiated at one env per lane)
+    const int vec = chain ? 1 : tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && full_rounds) ? 2 : 1);
     const int tile = 64 * vec;
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
     const int key = (full ? 100 : 0) + vec * 10 + mb;
-    if ((key != 11 && key != 12 && key != 21 && key != 22 && key != 111) || (chunked && key != 12 && key != 22 && key != 111))
+    if ((key != 11 && key != 12 && key != 21 && key != 22 && key != 111) || ((chunked || chain) && key != 12 && key != 22 && key != 111) || (chain && key == 22))
         return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
-    const bool pin = chunked || (long long)grid * a.nw > 5 * 1024;
+    const bool pin = chunked || chain || (long long)grid * a.nw > 5 * 1024;
     name_reset(tun);
-    name_add(tun, "cl_rollout_kernel<%d, %s, %d, %s%s>", vec, full ? "true" : "false", mb, (key == 12 && !pin) ? "false" : "true", chunked ? ", true" : "");
-    const int rc = cl_tu_launch_rollout(key + (chunked ? 1000 : 0), pin, grid, (unsigned)a.n_chunks, block.x, lds, stream, &r);
+    // (spelled as rocprofv3 prints them: every template argument, defaults included)
+    name_add(tun, "cl_rollout_kernel<%d, %s, %d, %s, %s, %d>", vec, full ? "true" : "false", mb, (key == 12 && !pin) ? "false" : "true", chunked ? "true" : "false", chain ? 2 : 0);
+    const int rc = cl_tu_launch_rollout(key + (chunked ? 1000 : 0) + (chain ? 2000 : 0), pin, grid, (unsigned)a.n_chunks, block.x, lds, stream, &r);
     if (rc) return hip_fail((hipError_t)rc, "cl_rollout_kernel launch");
     if (chunked && k_steps > 0) {
         // the last step's district sums (and the K-step return): one fold per launch

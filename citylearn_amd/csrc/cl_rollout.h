@@ -84,7 +84,8 @@ CL_DEV void rollout_action_cached(float (&dst)[VEC], PhiloxCache (&cache)[VEC], 
 // the last step's chunk partial sums (and its chunk's share of the K-step return) in the scratch rows of out_bldg's reserved plane, which
 // cl_finish_kernel folds once per LAUNCH, i.e. once per K steps.  Per unit and step the HBM traffic drops from 36 B (mode A) to 24 / K + 12 / K;
 // what a chunked launch cannot do is a reward that couples the buildings inside a step (MARL: the host keeps cl_rollout_seq_f32 for it).
-template <int VEC, bool FULL, int MB, bool PIN = true, bool CHUNK = false>
+// PREC = 2: CLD_F64_CHAIN (cl::battery_charge_chain; the degraded-capacity plane carries the capacity loss)
+template <int VEC, bool FULL, int MB, bool PIN = true, bool CHUNK = false, int PREC = 0>
 __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     const StepArgs& a = r.s;
@@ -191,10 +192,16 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
                 if constexpr (VEC > 1) { CL_PIN_V(c_ns); CL_PIN_V(sol); }
                 const bool batt = B[m].flags & CLF_BATTERY;
                 float nets[VEC], socs[VEC], rws[VEC];
+                [[maybe_unused]] cl::BattC bc;
+                if constexpr (PREC == 2) {
+                    if (batt) cl::load_battc(bc, B[m].p);          // (scalar loads every step: 19 doubles per building do not fit beside the fp32 block)
+                }
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     float eb = 0.0f;
-                    if (batt) eb = cl::battery_energy(Bv[m], a_es[i] * Bv[m].pdt, S[m][i]);
+                    if constexpr (PREC == 2) {
+                        if (batt) eb = cl::battery_charge_chain(bc, a_es[i], INFINITY, S[m][i]);
+                    } else if (batt) eb = cl::battery_energy(Bv[m], a_es[i] * Bv[m].pdt, S[m][i]);
                     nets[i] = fmaf(c_ns + cbk * eb, B[m].r, sol);
                     socs[i] = S[m][i].soc;
                 }
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const cl::Act act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
-                    cl::unit_step<FULL>(B[m], R, t, quirk, act, S[m][i], last[m][i]);
+                    cl::unit_step<FULL, PREC>(B[m], R, t, quirk, act, S[m][i], last[m][i]);
                     const float rw = cl::unit_reward<FULL>(rkind, B[m], S[m][i], last[m][i].net);
                     last_rw[m][i] = rw;
                     q_net[i] += last[m][i].net; q_cost[i] += last[m][i].cost; q_em[i] += last[m][i].emission; q_rw[i] += rw;

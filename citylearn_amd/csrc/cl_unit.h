@@ -350,6 +350,90 @@ CL_DEV float battery_charge_ref(const BattP64& B, double energy, bool first, Sta
     return eb;
 }
 
+// ---- CLD_F64_CHAIN: the soc chain in float64, everything else as in the fp32 map ---------------------------------------------------
+// What makes the all-fp32 map drift on free-running episodes is not its arithmetic but ONE rounding: the degraded capacity, a float64
+// attribute of the reference's Battery, kept as a float32 plane.  Whenever the charge clamp `degraded_capacity - energy_init` binds, that
+// half-ulp lands in soc[t] (d soc / d degraded_capacity = round-trip efficiency / capacity), and the steep segment of the capacity-power
+// curve -- where the battery then sits -- multiplies a soc error by 1 - |slope| rte / capacity when charging and 1 + |slope| / (rte
+// capacity) when discharging (2022 batteries: -1.6 and +3.9 per step).  tests/test_f64_maps_host.py measures it: fp32 arithmetic with the
+// degraded capacity exact -- 11 x (2022) / 2.2 x (2020) less soc drift; float64 arithmetic with a float32 degraded capacity -- no gain at
+// all; float64 chain + exact degraded capacity -- 70 - 170 x less, soc[t] equal to the reference's float32 value at ~90 % of all steps.
+// So this variant (a) carries the LOSS D = capacity - degraded_capacity in the float32 plane (D << capacity: its half-ulp is ~2^-40 of
+// the capacity; the degradation increments, ~1e-5 kWh, are added in fp32) and (b) evaluates energy_init -> capacity-power limit ->
+// selected energy -> efficiency -> round-trip efficiency -> final energy -> soc[t] / energy_balance[t] in float64 -- rounded to
+// float32 exactly where the reference's float32 series round -- on host-prepared constants (CLP_C_*): both curves as a first segment
+// plus one ramp per breakpoint (no segment selection: a float64 select is two v_cndmask), reciprocals instead of divisions, 1 / sqrt
+// from the fp32 seed and one Newton step (2^-45).  The efficiency of the previous call stays a float32 plane: it only enters the
+// discharge limit, which ends the step at (nearly) zero energy whatever came before.
+struct BattC {
+    double cap, oml, rcap, pdt, pow, rpow, r, ca0, cb0, cx1, cdb1, ea0, eb0, ex1, edb1, ex2, edb2, ex3, edb3;
+    float cap32, omd32, degk;
+};
+
+CL_DEV double pc(const uint32_t* __restrict__ p, int k) {           // k-th double of the CLP_C_* block (8-byte aligned)
+    const uint64_t bits = (uint64_t)p[CLP_C_FIRST + 2 * k] | ((uint64_t)p[CLP_C_FIRST + 2 * k + 1] << 32);
+    double d;
+    __builtin_memcpy(&d, &bits, 8);
+    return d;
+}
+
+// the float64 part, from the CLP_C_* block at p + CLP_C_FIRST
+CL_DEV void load_battc64(BattC& C, const uint32_t* __restrict__ p) {
+    C.cap = pc(p, CLPC_CAP); C.oml = pc(p, CLPC_OML); C.rcap = pc(p, CLPC_RCAP); C.pdt = pc(p, CLPC_PDT); C.pow = pc(p, CLPC_POW);
+    C.rpow = pc(p, CLPC_RPOW); C.r = pc(p, CLPC_TSR);
+    C.ca0 = pc(p, CLPC_CPC_A0); C.cb0 = pc(p, CLPC_CPC_B0); C.cx1 = pc(p, CLPC_CPC_X1); C.cdb1 = pc(p, CLPC_CPC_DB1);
+    C.ea0 = pc(p, CLPC_PEC_A0); C.eb0 = pc(p, CLPC_PEC_B0); C.ex1 = pc(p, CLPC_PEC_X1); C.edb1 = pc(p, CLPC_PEC_DB1);
+    C.ex2 = pc(p, CLPC_PEC_X2); C.edb2 = pc(p, CLPC_PEC_DB2); C.ex3 = pc(p, CLPC_PEC_X3); C.edb3 = pc(p, CLPC_PEC_DB3);
+}
+
+CL_DEV void load_battc(BattC& C, const uint32_t* __restrict__ p) {
+    load_battc64(C, p);
+    C.cap32 = pw(p, CLP_L_CAP); C.omd32 = pw(p, CLP_L_OMD); C.degk = pw(p, CLP_L_DEGK);
+}
+
+// 1 / sqrt(x) to ~2^-45: the fp32 seed (v_rsq_f32, 1 ulp) and one Newton step whose residual is a single fused multiply-add
+CL_DEV double rsq64(double x) {
+    const double y = (double)rsq((float)x);
+    const double e = __builtin_fma(-(0.5 * x) * y, y, 0.5);
+    return __builtin_fma(y, e, y);
+}
+
+// update_electrical_storage + Battery.charge (building.py:1801-1812, energy_model.py:1027-1141) for one unit: `a_es` the action, `flex` the
+// downward electrical flexibility [kWh] at the moment of the call.  S.degcap holds the capacity LOSS.  Returns energy_balance[t].
+CL_DEV float battery_charge_chain(const BattC& C, float a_es, float flex, State& S) {
+    const float prev = S.soc;
+    // energy_init (661-666): the reference's float32 product `prev_soc * capacity`, then float64
+    const double e_init = fmax(0.0, (double)(prev * C.cap32) * C.oml);
+    const double socn = e_init * C.rcap;
+    const double pmax = __builtin_fma(C.cdb1, fmax(socn - C.cx1, 0.0), __builtin_fma(C.cb0, socn, C.ca0));                // (1070-1090)
+    const double E = fmin((double)a_es * C.pdt, (double)flex);                          // energy handed to charge(): `/ r` there, `* r` inside (1036)
+    const double degcap = C.cap - (double)S.degcap;
+    // charge: min(pmax, P, degraded - e_init, E); discharge: max(-pmax, -DoD limit, E) (1036-1050); the limit from float32 operands, like the reference
+    const double e_chg = fmin(fmin(pmax, C.pow), fmin(degcap - e_init, E));
+    const double lim = fmax((double)((prev - C.omd32) * C.cap32 * fsqrt(S.eff)), 0.0);
+    const double e_dis = fmax(fmax(-pmax, -lim), E);
+    const bool chg = E >= 0.0;
+    double e = chg ? e_chg : e_dis;
+    // power_efficiency_curve at min(|E|, pmax) / P (1039, 1052, 1092-1109)
+    const double x = fmin(fabs(E), pmax) * C.rpow;
+    double eff = __builtin_fma(C.eb0, x, C.ea0);
+    eff = __builtin_fma(C.edb1, fmax(x - C.ex1, 0.0), eff);
+    eff = __builtin_fma(C.edb2, fmax(x - C.ex2, 0.0), eff);
+    eff = __builtin_fma(C.edb3, fmax(x - C.ex3, 0.0), eff);
+    const double irte = rsq64(eff), rte = eff * irte;
+    // StorageDevice.charge (719-768): one clamp of one fma, as in the fp32 map (0 <= e_init <= capacity)
+    e *= C.r;
+    const double e_fin = fmin(fmax(__builtin_fma(e, chg ? rte : irte, e_init), 0.0), C.cap);
+    const double d = e_fin - e_init;
+    const float eb = (float)(d * (chg ? irte : rte));                                    // energy_balance[t]: float32 series
+    // degrade (1130-1141) on the pre-step degraded capacity: the increment (~1e-5 kWh) in fp32, accumulated into the loss
+    const float degcap32 = C.cap32 - S.degcap;
+    S.degcap = fminf(fmaf(C.degk * fabsf(eb), rcp(fmaxf(degcap32, CL_ZDP)), S.degcap), C.cap32);
+    S.eff = (float)eff;
+    S.soc = (float)(e_fin * C.rcap);                                                     // soc[t]: float32 series
+    return eb;
+}
+
 // StorageDevice.charge under StorageTank.charge's power clamps (energy_model.py:719-768, 850-870).
 // `e` is the energy handed to tank.charge() after `_convert_energy_for_storage` (building.py:1814-1823),
 // i.e. it is multiplied by time_step_ratio twice on its way in.
@@ -401,8 +485,10 @@ CL_DEV float battery_step_f64(const uint32_t* __restrict__ p, float a_es, float 
 }
 
 // The whole unit step.  `t` and `t0_quirk` are wave-uniform.  F64: the battery map in float64 (CLD_F64_MAPS).
-template <bool FULL, bool F64 = false>
+// PREC: 0 = fp32 battery map, 1 = CLD_F64_MAPS (battery_charge_ref), 2 = CLD_F64_CHAIN (battery_charge_chain; S.degcap is the capacity loss)
+template <bool FULL, int PREC = 0>
 CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act& a, State& S, Out& O) {
+    constexpr bool F64 = PREC == 1;
     const bool first = t0_quirk && t == 0;
     const bool has_batt = B.flags & CLF_BATTERY;
     if constexpr (!FULL) {
@@ -410,6 +496,8 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         float eb = 0.0f;
         if constexpr (F64) {
             if (has_batt) eb = battery_step_f64(B.p, a.es, INFINITY, t == 0, S);
+        } else if constexpr (PREC == 2) {
+            if (has_batt) { BattC bc; load_battc(bc, B.p); eb = battery_charge_chain(bc, a.es, INFINITY, S); }
         } else if (has_batt) eb = battery_step(B.batt, a.es, INFINITY, S);
         // t = 0: the load is booked at reset, by the step, and again by update_variables
         const float c_ns = first ? 3.0f * R.nsl : R.nsl;
@@ -446,6 +534,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         if (has_batt && R.outage) {                                // the order only matters through `flexibility`
             if (es_first) {
                 if constexpr (F64) eb_b = battery_step_f64(B.p, a.es, flexibility(B, R, A), t == 0, S);
+                else if constexpr (PREC == 2) { BattC bc; load_battc(bc, B.p); eb_b = battery_charge_chain(bc, a.es, flexibility(B, R, A), S); }
                 else { BattP bp; load_batt(bp, B.p); eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); }
                 A.c_b += eb_b;
             }
@@ -473,6 +562,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         A.c_ns += e_ns;
         if (has_batt && !(R.outage && es_first)) {
             if constexpr (F64) eb_b = battery_step_f64(B.p, a.es, flexibility(B, R, A), t == 0, S);
+            else if constexpr (PREC == 2) { BattC bc; load_battc(bc, B.p); eb_b = battery_charge_chain(bc, a.es, flexibility(B, R, A), S); }
             else { BattP bp; load_batt(bp, B.p); eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); }
             A.c_b += eb_b;
         }

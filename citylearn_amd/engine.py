@@ -64,7 +64,9 @@ class StepEngine:
 
         ``f64_maps`` (`CLD_F64_MAPS`): evaluate the battery map in float64 with float32 rounding where the reference's float32 series
         round -- the reference's own precision model (energy_model.py:1027-1141), for free-running parity at 1e-4; slower launches,
-        no fused rollout kernel, no flexible loads."""
+        no fused rollout kernel, no flexible loads.  ``f64_maps='chain'`` (`CLD_F64_CHAIN`): only the battery's soc chain in float64
+        and the degraded capacity carried as the capacity LOSS in its float32 plane (`degraded_capacity` converts) -- not bit-identical
+        but inside 1e-4 free-running on every fixture, the default three state planes, every step kernel and the fused rollout."""
         self.lib = _lib.load()                      # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
@@ -100,10 +102,20 @@ class StepEngine:
         flags |= abi.CLD_REF_T0_QUIRK if t0_quirk else 0
         flags |= abi.CLD_KPI if kpi else 0
         flags |= abi.CLD_CENTRAL_AGENT if central_agent else 0      # only read by the CLR_EV reward
-        flags |= abi.CLD_F64_MAPS if f64_maps else 0
-        self.f64_maps = bool(f64_maps)
+        if f64_maps not in (False, True, 'ref', 'chain'):
+            raise ValueError("f64_maps must be False, True / 'ref' (CLD_F64_MAPS) or 'chain' (CLD_F64_CHAIN)")
+        self.f64_chain = f64_maps == 'chain'
+        self.f64_maps = bool(f64_maps) and not self.f64_chain
+        flags |= abi.CLD_F64_MAPS if self.f64_maps else 0
+        flags |= abi.CLD_F64_CHAIN if self.f64_chain else 0
         if f64_maps and tables.flex is not None:
             raise NotImplementedError('f64_maps is not implemented for districts with EV chargers / washing machines')
+        if self.f64_chain:
+            has_batt = (tables.params[:, abi.CLP_FLAGS] & abi.CLF_BATTERY) != 0
+            valid = tables.params[:, abi.CLP_C_FIRST:abi.CLP_C_LAST + 1].copy().view(np.float64)[:, abi.CLPC_VALID]
+            if np.any(has_batt & (valid != 1.0)):
+                raise NotImplementedError("f64_maps='chain' needs battery curves with ascending breakpoints that end at 1 and power fractions <= 1 "
+                                          "(the ramp form of the float64 chain); use f64_maps=True for this district")
         self.kpi = kpi
         bflags = tables.params[:, abi.CLP_FLAGS]
         heavy = abi.CLF_THERMAL | abi.CLF_OUTAGE | abi.CLF_DYNAMICS
@@ -385,6 +397,16 @@ class StepEngine:
     @property
     def soc(self) -> torch.Tensor:
         return self.state[abi.CLS_B_SOC]
+
+    @property
+    def degraded_capacity(self) -> torch.Tensor:
+        """``[n_bldg, n_env]`` Battery.degraded_capacity [kWh].  Under `f64_maps='chain'` the state plane carries the capacity LOSS
+        (capacity - degraded capacity: what lets a float32 plane hold the reference's float64 attribute): converted here."""
+        plane = self.state[abi.CLS_B_DEGCAP]
+        if not self.f64_chain:
+            return plane
+        cap = self.params[:, abi.CLP_L_CAP].view(torch.float32)
+        return cap[:, None] - plane
 
     @property
     def net(self) -> torch.Tensor:

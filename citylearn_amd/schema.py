@@ -622,6 +622,23 @@ class DistrictSpec:
                 d64[abi.CLPD_RPOW] = 1.0 / max(powr, ZERO_DIVISION_PLACEHOLDER)
                 d64[abi.CLPD_RCPC_01:abi.CLPD_RCPC_01 + 2] = 1.0 / (np.asarray(cx[1:3], dtype=np.float64) - np.asarray(cx[0:2], dtype=np.float64))
                 d64[abi.CLPD_RPEC_01:abi.CLPD_RPEC_01 + 4] = 1.0 / (np.asarray(ex[1:5], dtype=np.float64) - np.asarray(ex[0:4], dtype=np.float64))
+            # CLD_F64_CHAIN: the same map's constants in the form the fast float64 chain consumes (csrc/cl_unit.h battery_charge_chain): each
+            # curve as its first segment plus one ramp per further breakpoint -- no segment selection on the device
+            c64 = params[i, abi.CLP_C_FIRST:abi.CLP_C_LAST + 1].view(np.float64)
+            c64[abi.CLPC_CAP], c64[abi.CLPC_OML] = cap, 1.0 - e.loss_coefficient * r
+            c64[abi.CLPC_RCAP], c64[abi.CLPC_RPOW] = 1.0 / max(cap, ZERO_DIVISION_PLACEHOLDER), 1.0 / max(powr, ZERO_DIVISION_PLACEHOLDER)
+            c64[abi.CLPC_PDT], c64[abi.CLPC_POW], c64[abi.CLPC_TSR] = powr * dt, powr, r
+            with np.errstate(divide='ignore', invalid='ignore'):
+                cslope = [(cy[k + 1] - cy[k]) / (cx[k + 1] - cx[k]) for k in range(2)]
+                eslope = [(ey[k + 1] - ey[k]) / (ex[k + 1] - ex[k]) for k in range(4)]
+            c64[abi.CLPC_CPC_A0], c64[abi.CLPC_CPC_B0] = powr * (cy[0] - cslope[0] * cx[0]), powr * cslope[0]
+            c64[abi.CLPC_CPC_X1], c64[abi.CLPC_CPC_DB1] = cx[1], powr * (cslope[1] - cslope[0])
+            c64[abi.CLPC_PEC_A0], c64[abi.CLPC_PEC_B0] = ey[0] - eslope[0] * ex[0], eslope[0]
+            for k in range(1, 4):
+                c64[abi.CLPC_PEC_X1 + 2 * (k - 1)], c64[abi.CLPC_PEC_DB1 + 2 * (k - 1)] = ex[k], eslope[k] - eslope[k - 1]
+            chain_ok = (np.all(np.diff(cx) > 0) and np.all(np.diff(ex) > 0) and cx[2] >= 1.0 and ex[4] >= 1.0 and np.max(cy) <= 1.0
+                        and np.all(np.isfinite(c64[:abi.CLPC_VALID])))
+            c64[abi.CLPC_VALID] = 1.0 if chain_ok else 0.0
             for tank, base in ((b.cooling_storage, abi.CLP_CS_IRTE), (b.heating_storage, abi.CLP_HS_IRTE),
                                (b.dhw_storage, abi.CLP_DS_IRTE)):
                 pf[i, base + 0] = 1.0 / math.sqrt(tank.efficiency)

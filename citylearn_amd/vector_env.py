@@ -65,7 +65,7 @@ class VectorCityLearnEnv:
         self.central_agent = self.spec.central_agent
         self.env_episode_offsets = env_episode_offsets
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
-        self.f64_maps = bool(f64_maps)
+        self.f64_maps = f64_maps if f64_maps in ('chain', 'ref') else bool(f64_maps)      # ('chain': CLD_F64_CHAIN, the cheap 1e-4 mode)
         self.env_offset = int(env_offset)      # first env of this shard in the whole batch (multi-GPU: parallel.shard_envs(...)[0])
         if self.env_offset < 0 or self.env_offset + self.n_envs > 2 ** 32:
             raise ValueError(f'env_offset={env_offset} with n_envs={n_envs} leaves the 32-bit env index of the random streams')

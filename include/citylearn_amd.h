@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 6   /* 6: cl_finish_f32, cl_tuning.finish = 3 (deferred finish); 5: cl_tuning.kernel_name, CLD_F64_MAPS; 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
+#define CL_ABI_VERSION 7   /* 7: CLD_F64_CHAIN (params rows of 320 words: CLP_C_* block); 6: cl_finish_f32, cl_tuning.finish = 3 (deferred finish); 5: cl_tuning.kernel_name, CLD_F64_MAPS; 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
 
 /* ---- error codes ---- */
 #define CL_OK            0
@@ -50,7 +50,7 @@ extern "C" {
 #define CL_ERANGE       -5   /* t / k_steps outside [0, n_steps) */
 
 /* ---- table widths ---- */
-#define CL_NP  256   /* words per building in `params` (1 KiB rows) */
+#define CL_NP  320   /* words per building in `params` (1.25 KiB rows) */
 #define CL_NF   16   /* floats per (t, building) row in `ts` */
 #define CL_NS    8   /* state planes (the last two are only touched under CLD_F64_MAPS) */
 #define CL_NO   18   /* per-building output planes */
@@ -131,7 +131,26 @@ enum cl_param {
     /* ---- CLD_F64_MAPS: the battery's parameters as float64 (two words each, little endian; cl_param_f64 indexes them), unrounded:
      *      the reference computes Battery.charge mostly in float64 (energy_model.py:1027-1141; csrc/cl_unit.h battery_charge_ref). ---- */
     CLP_D_FIRST = 192,
-    CLP_D_LAST = CLP_D_FIRST + 63
+    CLP_D_LAST = CLP_D_FIRST + 63,
+    /* ---- CLD_F64_CHAIN: the battery map's constants as float64 in the form the fast float64 chain consumes them (cl_param_chain indexes
+     *      them; csrc/cl_unit.h battery_charge_chain): both curves as a first segment plus one ramp per further breakpoint. ---- */
+    CLP_C_FIRST = 256,
+    CLP_C_LAST = CLP_C_FIRST + 63
+};
+enum cl_param_chain {     /* k-th double of the CLP_C_* block */
+    CLPC_CAP = 0,         /* capacity */
+    CLPC_OML,             /* 1 - loss_coefficient * r */
+    CLPC_RCAP,            /* 1 / max(capacity, ZERO_DIVISION_PLACEHOLDER) */
+    CLPC_PDT,             /* nominal_power * seconds_per_time_step / 3600  [kWh per unit action] */
+    CLPC_POW, CLPC_RPOW,  /* nominal_power, 1 / max(nominal_power, ZERO_DIVISION_PLACEHOLDER) */
+    CLPC_TSR,             /* time_step_ratio r */
+    /* capacity_power_curve (energy_model.py:1070-1090), times nominal_power: pmax = A0 + B0 soc + DB1 max(soc - X1, 0) */
+    CLPC_CPC_A0, CLPC_CPC_B0, CLPC_CPC_X1, CLPC_CPC_DB1,
+    /* power_efficiency_curve (energy_model.py:1092-1109): eff = A0 + B0 x + sum_k DBk max(x - Xk, 0) */
+    CLPC_PEC_A0, CLPC_PEC_B0, CLPC_PEC_X1, CLPC_PEC_DB1, CLPC_PEC_X2, CLPC_PEC_DB2, CLPC_PEC_X3, CLPC_PEC_DB3,
+    CLPC_VALID,           /* 1.0 when the curves have the shape the ramp form assumes (breakpoints ascending, the last one >= 1, power fractions
+                             <= 1: the reference's out-of-range rule -- segment 0 again beyond the last breakpoint -- is then unreachable), else 0.0 */
+    CLPC_USED             /* <= 32 */
 };
 enum cl_param_f64 {       /* k-th double of the CLP_D_* block */
     CLPD_TSR = 0,         /* time_step_ratio r */
@@ -186,7 +205,7 @@ enum cl_feat {
 enum cl_state {
     CLS_B_SOC = 0,    /* electrical_storage.soc[t] */
     CLS_B_EFF,        /* Battery.efficiency left by the previous charge() call (energy_model.py:1039-1052) */
-    CLS_B_DEGCAP,     /* Battery.degraded_capacity [kWh] */
+    CLS_B_DEGCAP,     /* Battery.degraded_capacity [kWh] (under CLD_F64_CHAIN: capacity - degraded_capacity, the accumulated loss) */
     CLS_CS_SOC, CLS_HS_SOC, CLS_DS_SOC,                /* cooling / heating / dhw tank soc[t] */
     CLS_B_EFF_LO, CLS_B_DEGCAP_LO                      /* CLD_F64_MAPS: low words of the two float64 values the reference carries between steps --
                                                           Battery.efficiency = (double)CLS_B_EFF + (double)CLS_B_EFF_LO, likewise the degraded
@@ -274,6 +293,15 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
                                          fp32 map is locally expansive on the steep part of the capacity-power curve: DESIGN.md section 3).
                                          Slower launches (general / lean step kernels only; not the fused rollout, the env-major or the
                                          thermal-specialised kernels). */
+#define CLD_F64_CHAIN      (1u << 14) /* cl_step_f32 / cl_rollout_f32: the battery's soc chain -- energy_init, capacity-power limit, efficiency, final energy, soc[t],
+                                         energy_balance[t] (energy_model.py:1027-1109, 719-768) -- in float64 on the CLP_C_* constants, and the degraded
+                                         capacity carried as the LOSS `capacity - degraded_capacity` in the CLS_B_DEGCAP plane (float32 holds it to
+                                         ~2^-40 of the capacity; cl_reset_f32 writes 0 there under this flag).  Not bit-identical to the reference
+                                         like CLD_F64_MAPS, but free-running inside 1e-4 on every fixture at a fraction of its cost and with the
+                                         default three state planes: what seeds the fp32 map's drift on the steep part of the capacity-power
+                                         curve is the float32 rounding of the degraded capacity, not the arithmetic.
+                                         Available in every step kernel and in the fused rollout; mutually exclusive with CLD_F64_MAPS;
+                                         districts with flexible loads keep the fp32 map (their EV batteries are fp32). */
 #define CLD_DETAIL_MIN     (1u << 12) /* with CLD_WRITE_DETAIL: write only the detail planes another kernel of the path reads -- CLO_BASE_NET,
                                          CLO_EXPECTED, CLO_SERVED (the streaming KPI pass) and CLO_COOL_DEM, CLO_HEAT_DEM (the LSTM stage) -- and
                                          leave the other ten alone (5 instead of 15 extra planes per step) */

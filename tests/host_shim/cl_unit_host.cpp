@@ -5,7 +5,7 @@
 #include "../../citylearn_amd/csrc/cl_unit.h"
 
 // state8: the six state planes of one unit + the low words of efficiency / degraded capacity (CLD_F64_MAPS)
-template <bool FULL, bool F64>
+template <bool FULL, int PREC>
 static void run(const uint32_t* params, const float* ts_row, int t, int quirk, int rkind, const float* act6,
                 float* state8, float* out10, float* reward) {
     cl::Bp B; cl::load_bp<FULL>(B, params);
@@ -13,7 +13,7 @@ static void run(const uint32_t* params, const float* ts_row, int t, int quirk, i
     cl::State S = {state8[0], state8[1], state8[2], state8[3], state8[4], state8[5], state8[6], state8[7]};
     cl::Act a = {act6[0], act6[1], act6[2], act6[3], act6[4], act6[5]};
     cl::Out O;
-    cl::unit_step<FULL, F64>(B, R, t, quirk != 0, a, S, O);
+    cl::unit_step<FULL, PREC>(B, R, t, quirk != 0, a, S, O);
     *reward = cl::unit_reward<FULL>(rkind, B, S, O.net);
     state8[0] = S.soc; state8[1] = S.eff; state8[2] = S.degcap; state8[3] = S.cs; state8[4] = S.hs; state8[5] = S.ds;
     state8[6] = S.eff_lo; state8[7] = S.deg_lo;
@@ -23,10 +23,13 @@ static void run(const uint32_t* params, const float* ts_row, int t, int quirk, i
 
 extern "C" void host_unit_step(const uint32_t* params, const float* ts_row, int t, int quirk, int rkind, int full, int f64,
                                const float* act6, float* state8, float* out10, float* reward) {
-    if (full && f64) run<true, true>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
-    else if (full) run<true, false>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
-    else if (f64) run<false, true>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
-    else run<false, false>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    // f64: 0 = fp32 battery map, 1 = CLD_F64_MAPS, 2 = CLD_F64_CHAIN (state8[2] then holds the capacity loss)
+    if (full && f64 == 2) run<true, 2>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    else if (full && f64) run<true, 1>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    else if (full) run<true, 0>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    else if (f64 == 2) run<false, 2>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    else if (f64) run<false, 1>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
+    else run<false, 0>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
 }
 
 // div_rn(a, b, RN(1 / b)) against the hardware division, element by element; returns the number of mismatching quotients

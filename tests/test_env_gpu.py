@@ -476,3 +476,24 @@ def test_env_with_f64_maps_reproduces_the_reference_battery_series(name):
     assert np.array_equal(soc[:, has_battery].astype(np.float32), g.ref['soc'][:K][:, has_battery])
     net = np.stack([b.net_electricity_consumption for b in env.buildings], axis=1)[:K]
     assert float(np.max(np.abs(net - g.ref['net'][:K]) / (1e-4 + 1e-4 * np.abs(g.ref['net'][:K])))) < 1.0
+
+
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1'])
+def test_env_with_the_f64_chain_stays_on_the_reference(name):
+    """`CityLearnEnv(f64_maps='chain')` (CLD_F64_CHAIN through the Gym surface): a free-running episode holds soc, net and rewards at the
+    north star's 1e-4 + 1e-4 |ref| -- the mode that costs a fraction of CLD_F64_MAPS and keeps every kernel."""
+    from citylearn_amd.citylearn import CityLearnEnv
+    g = golden(name)
+    env = CityLearnEnv(g.schema_path, f64_maps='chain')
+    env.reset()
+    K = g.facts['steps']
+    for t in range(K):
+        _, reward, _, _, _ = env.step(_actions(g, env, t))
+        ref = g.ref['reward_' + g.facts['reward_type']][t]
+        np.testing.assert_allclose(reward, [ref.sum()] if env.central_agent else ref, rtol=1e-4, atol=1e-4)
+    has_battery = [b.electrical_storage.present for b in env.district_spec.buildings]
+    soc = np.stack([b.electrical_storage_soc for b in env.buildings], axis=1)[:K]
+    ref = g.ref['soc'][:K][:, has_battery]
+    assert float(np.max(np.abs(soc[:, has_battery] - ref) / (1e-4 + 1e-4 * np.abs(ref)))) < 0.2
+    net = np.stack([b.net_electricity_consumption for b in env.buildings], axis=1)[:K]
+    assert float(np.max(np.abs(net - g.ref['net'][:K]) / (1e-4 + 1e-4 * np.abs(g.ref['net'][:K])))) < 1.0

@@ -85,7 +85,7 @@ def test_more_ranks_than_gpus_is_refused_without_the_hook():
 
 
 @pytest.mark.parametrize('cfg,kernel,bound', [('C2', 'cl_step_lean_kernel<1, false, true>', 'hbm'), ('C3', 'cl_lstm_kernel<', 'valu'),
-                                              ('C4', 'cl_step_full_kernel<2, false, 1024, 4, true, true>', 'hbm'), ('C5', 'cl_rollout_kernel<2, false, 2, true>', 'valu')])
+                                              ('C4', 'cl_step_full_kernel<2, false, 1024, 4, true, true>', 'hbm'), ('C5', 'cl_rollout_kernel<2, false, 2, true, false, 0>', 'valu')])
 def test_config_lines(cfg, kernel, bound):
     out = _bench('--config', cfg, '--steps', '20', '--warmup', '5', '--reps', '2')
     assert out['config']['name'] == cfg and out['roofline']['bound'] == bound and kernel in out['roofline']['kernel'], out['roofline']['kernel']

@@ -256,7 +256,7 @@ def test_deferred_finish_through_step_observe():
         ref.step(act, t)
         want = wa.write(t + 1).clone()
         got = dfr.step_observe(act, wb, t)
-        assert 'cl_finish_kernel' not in dfr.last_kernels and 'true>' in dfr.last_kernels, dfr.last_kernels      # the FOLD instantiation, deferred
+        assert 'cl_finish_kernel' not in dfr.last_kernels and ', 0, true>' in dfr.last_kernels, dfr.last_kernels      # the FOLD instantiation, deferred
         assert dfr._pending_t == t
         assert torch.equal(got, want) and torch.equal(dfr.state, ref.state), t
         if t % 2 == 0:                                                  # (odd steps are folded by the next launch instead)

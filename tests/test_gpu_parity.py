@@ -47,10 +47,14 @@ def _run(name, kind, vec, detail, teach, steps=None, E=64, atol=1e-4, rtol=1e-4,
         if teach and t > 0:
             for k, pl in STATE_KEYS:
                 eng.state[pl] = ref_state[k][t - 1][:, None]
+            if f64 == 'chain':
+                eng.state[abi.CLS_B_DEGCAP] = (eng.params[:, abi.CLP_L_CAP].view(torch.float32) - ref_state['degcap'][t - 1])[:, None]
         eng.step(acts[t][:, None].expand(-1, E).contiguous())
         st, ob, oe = eng.state.cpu().numpy(), eng.out_bldg.cpu().numpy(), eng.out_env.cpu().numpy()
         assert (st[:, :, :1] == st).all() and (ob[:2, :, :1] == ob[:2]).all(), 'envs with equal actions diverged'
         pairs = {k: st[pl, :, 0] for k, pl in STATE_KEYS}
+        if f64 == 'chain':                       # (CLD_F64_CHAIN: the plane carries the capacity loss)
+            pairs['degcap'] = eng.degraded_capacity.cpu().numpy()[:, 0]
         pairs['net'] = ob[abi.CLO_NET, :, 0]
         if detail:
             pairs.update({k: ob[pl, :, 0] for k, pl in DETAIL_KEYS})
@@ -214,9 +218,62 @@ def test_free_running_whole_fixture_f64(name, vec):
     fixture at the north star's 1e-4 + 1e-4 |ref| on EVERY quantity -- district sums and district reward at the plain tolerance too --
     and the battery state (soc, efficiency, degraded capacity) bit-identical to the reference's float32 values at every step."""
     worst, eng = _run(name, 'RewardFunction', vec, detail=False, teach=False, f64=True, district_slack=(1.0, 1.0))
-    assert 'cl_step_lean_f64_kernel' in eng.last_kernels or ', true, false>' in eng.last_kernels, eng.last_kernels      # cl_step_kernel<.., F64 = true, FOLD = false>
+    assert 'cl_step_lean_f64_kernel' in eng.last_kernels or ', 1, false>' in eng.last_kernels, eng.last_kernels      # cl_step_kernel<.., PREC = 1, FOLD = false>
     assert max(worst.values()) < 1.0, worst
     assert worst['soc'] == 0.0 and worst['eff'] == 0.0 and worst['degcap'] == 0.0, worst
+
+
+CHAIN_CASES = [('g2022_all', 1, None, False, 'cl_step_lean_chain_kernel<1'), ('g2022_all', 2, None, False, 'cl_step_lean_chain_kernel<2'),
+               ('g2022_all', 4, None, False, 'cl_step_lean_chain_kernel<4'), ('g2022_all', 0, dict(envmajor=1), False, 'cl_step_envmajor_kernel<17, true, 1, 2>'),
+               ('g2022_all', 2, dict(lean_variant=1), False, 'cl_step_kernel<2, false, false, false, 2, false>'),
+               ('g2020_cz1', 0, None, False, 'cl_step_full_chain_kernel<1, false, 1024, 4, false'), ('g2020_cz1', 0, dict(full_variant=5), False, 'cl_step_full_tp_chain_kernel<1, 4'),
+               ('g2020_cz1', 1, dict(full_variant=1), False, 'cl_step_kernel<1, true, false, false, 2, false>'), ('g2020_cz1', 0, None, True, 'cl_step_full_chain_kernel<1, true'),
+               ('g2023_p2', 0, None, False, 'cl_step_full_chain_kernel'), ('g2020_15min', 0, None, False, 'chain'), ('g2023_heat', 0, None, True, 'chain')]
+
+
+@pytest.mark.parametrize('name,vec,tuning,detail,kernel', CHAIN_CASES)
+def test_free_running_whole_fixture_f64_chain(name, vec, tuning, detail, kernel):
+    """CLD_F64_CHAIN (`StepEngine(f64_maps='chain')`): the battery's soc chain in float64 and the degraded capacity carried
+    as the capacity loss in its float32 plane -- the default three state planes, every step kernel.  FREE-RUNNING over whole fixtures at the
+    north star's 1e-4 + 1e-4 |ref| on every per-building quantity (the fp32 map needs 1e-3 on the 2020 / 15-minute / heating fixtures:
+    `test_free_running_whole_fixture`), in the lean kernel at every pack width, the env-major kernel, the general kernel, the
+    thermal-specialised kernels (one tile and several tiles per workgroup) with and without the detail planes, outage rows included.
+    Measured worst (tests/test_f64_maps_host.py runs the same header on the CPU): 0.07 x the bound."""
+    worst, eng = _run(name, 'RewardFunction', vec, detail=detail, teach=False, f64='chain', tuning=tuning)
+    assert kernel in eng.last_kernels, eng.last_kernels
+    assert max(worst.values()) < 1.0, worst
+    print(name, eng.last_kernels, {k: round(v, 3) for k, v in worst.items()})
+
+
+@pytest.mark.parametrize('name', SWEEP)
+def test_dataset_sweep_free_running_f64_chain(name):
+    """... and free-running over the short fixtures of every other dataset family, at 1e-4."""
+    worst, _ = _run(name, 'RewardFunction', 0, detail=True, teach=False, f64='chain')
+    assert max(worst.values()) < 1.0, worst
+
+
+@pytest.mark.parametrize('kind', ['MARL', 'SolarPenaltyReward'])
+def test_f64_chain_teacher_forced_other_rewards(kind):
+    worst, _ = _run('g2020_cz1', kind, 0, detail=False, teach=True, f64='chain', steps=200)
+    assert max(worst.values()) < 1.0, worst
+
+
+def test_f64_chain_refusals_and_views():
+    g = golden('g2022_all')
+    tab = g.spec().episode_tables(0)
+    eng = StepEngine(tab, 64, f64_maps='chain')
+    assert float(eng.state[abi.CLS_B_DEGCAP].abs().max()) == 0.0                       # nothing lost at reset
+    cap = eng.params[:, abi.CLP_L_CAP].view(torch.float32)
+    assert torch.equal(eng.degraded_capacity, cap[:, None].expand(-1, 64))
+    eng.dims.flags |= abi.CLD_F64_MAPS
+    with pytest.raises(_lib.EngineError) as e:
+        eng.step(torch.zeros((eng.n_act_cols, 64), device='cuda'))
+    assert e.value.code == abi.CL_EINVAL and 'pick one' in str(e.value)
+    with pytest.raises(ValueError):
+        StepEngine(tab, 64, f64_maps='double')
+    ev = golden('g2022_evs').spec().episode_tables(0)
+    with pytest.raises(NotImplementedError):
+        StepEngine(ev, 64, f64_maps='chain')
 
 
 @pytest.mark.parametrize('name,kind', [('g2020_cz1', 'SolarPenaltyReward'), ('g2022_all', 'MARL'), ('g2023_p2', 'IndependentSACReward')])

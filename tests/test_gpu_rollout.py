@@ -185,7 +185,7 @@ def test_chunked_fused_rollout_equals_single_steps(name, kind, B, E, tuning):
         ret_ref += a.district_reward.double()
     ret = torch.full((E,), 3.0, device='cuda')                       # (the return is ADDED to what the caller passes in)
     b.rollout(K, actions=acts, ret_env=ret)
-    assert 'cl_rollout_kernel' in b.last_kernels and b.last_kernels.endswith(', true>+cl_finish_kernel'), b.last_kernels
+    assert 'cl_rollout_kernel' in b.last_kernels and b.last_kernels.endswith(', true, 0>+cl_finish_kernel'), b.last_kernels
     _close(b.state, a.state)
     _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
     # district sums over B buildings: the per-building tolerance times the district size
@@ -227,6 +227,38 @@ def test_chunked_fused_rollout_policy_and_fallbacks():
     with pytest.raises(_lib.EngineError) as err:
         m.rollout(4, seed=seed, fused=True)
     assert err.value.code == abi.CL_EINVAL and 'MARL' in str(err.value)
+
+
+@pytest.mark.parametrize('name,B,E', [('g2022_all', 0, 192), ('g2020_cz1', 0, 128), ('g2022_all', 100, 68), ('g2020_cz1', 40, 64), ('g2023_p2', 0, 64)])
+def test_fused_rollout_with_the_f64_chain(name, B, E):
+    """CLD_F64_CHAIN in mode B (`cl_rollout_kernel<.., PREC = 2>`: battery + PV and thermal districts, one workgroup row and building-chunked):
+    K fused steps against K single steps of the same precision model -- the soc chain is float64 in both, so the battery state agrees to
+    the last bits a differently contracted fp32 epilogue can move -- and a fixture's own actions keep the rolled-out soc on the reference."""
+    from citylearn_amd.synthetic import tile_district
+    g = golden(name)
+    spec = tile_district(g.spec(), B) if B else g.spec()
+    tab = spec.episode_tables(0)
+    K = 24
+    low, high = spec.action_limits()
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+    acts = lo[None, :, None] + torch.rand((K, len(low), E), device='cuda', generator=gen) * (hi - lo)[None, :, None]
+    if not B:
+        acts[:, :, 0] = torch.from_numpy(g.ref['actions'][:K]).cuda()                 # env 0 replays the fixture
+    a, b = StepEngine(tab, E, f64_maps='chain'), StepEngine(tab, E, f64_maps='chain')
+    b.trace_kernels()
+    for k in range(K):
+        a.step(acts[k])
+    ret = torch.zeros(E, device='cuda')
+    b.rollout(K, actions=acts, ret_env=ret)
+    assert 'cl_rollout_kernel<1, ' in b.last_kernels and ', 2>' in b.last_kernels, b.last_kernels
+    _close(b.state, a.state)
+    _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
+    torch.testing.assert_close(b.out_env, a.out_env, rtol=1e-5, atol=1e-6 * max(B, 17))
+    if not B:
+        has = torch.tensor([bl.electrical_storage.present for bl in spec.buildings], device='cuda')
+        soc, ref = b.soc[:, 0][has].cpu().numpy(), g.ref['soc'][K - 1][has.cpu().numpy()]
+        assert float(np.max(np.abs(soc - ref) / (1e-4 + 1e-4 * np.abs(ref)))) < 0.1
 
 
 def test_sharded_rollouts_reproduce_the_unsharded_policy_stream():
