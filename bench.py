@@ -359,7 +359,9 @@ class StepWorkload:
         self.name, self.what, self.E, self.device = name, what, E, device
         self.spec = spec
         self.tables = spec.episode_tables(0)
-        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, detail='min' if lstm else False, f64_maps=f64, kpi=kpi)
+        # (CL_BENCH_NO_PITCH=1: rows exactly n_env floats apart even where the engine would pad them -- the A/B of cl_dims.env_pitch)
+        self.eng = StepEngine(self.tables, E, device=device, tuning=tuning, detail='min' if lstm else False, f64_maps=f64, kpi=kpi,
+                              env_pitch=E if os.environ.get('CL_BENCH_NO_PITCH') == '1' else None)
         if kpi:
             self.what += '; CLD_KPI: streaming KPI accumulators of evaluate() updated every step (mode A-kpi)'
         if f64 == 'chain':
@@ -639,7 +641,7 @@ def run_rank(args):
         roof['residency'] = 'infinity-cache (fabric bandwidth, not HBM): the HBM-true figure is hbm_streaming' if E * 17 * 52 < 256e6 else 'hbm'
         roof['note'] = ('working set (state 13 MB + outputs 9 MB + action ring 36 MB) fits the 256 MB Infinity Cache: see hbm_streaming '
                         'for the HBM-resident figure')
-    units_per_step, n_bldg, spec, tables, what = wl.units_per_step, wl.eng.n_bldg, wl.spec, wl.tables, wl.what
+    units_per_step, n_bldg, spec, tables, what, env_pitch = wl.units_per_step, wl.eng.n_bldg, wl.spec, wl.tables, wl.what, wl.eng.env_pitch
 
     if cfg == 'headline' and not args.no_streaming and E == ENVS_PER_GPU:
         wl = None
@@ -648,7 +650,7 @@ def run_rank(args):
         wl_s = build_workload(cfg, STREAMING_ENVS, device, rank, world, tuning, args.f64_maps, args.kpi, args.table_hours)
         _, _, launch, _, _ = measure(wl_s, 5, s_steps, 3, 2000)
         a = wl_s.units_per_step * wl_s.bytes_per_unit() / launch / 1e9
-        s_units, s_bpu, s_kernels = wl_s.units_per_step, wl_s.bytes_per_unit(), wl_s.kernels
+        s_units, s_bpu, s_kernels, s_pitch = wl_s.units_per_step, wl_s.bytes_per_unit(), wl_s.kernels, wl_s.eng.env_pitch
         s_traffic, s_source = _pmc_traffic('r*_streaming_pmc_summary.json', wl_s.kernels or '')
         s_live_error = None
         if world == 1 and rank == 0 and not args.no_traffic_pass and not args.kpi and not args.f64_maps:
@@ -664,7 +666,7 @@ def run_rank(args):
                         f'of algorithmic traffic per launch, beyond the 256 MB Infinity Cache)',
             'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': a / HBM_PEAK_GBS,
             'frac_vs_measured_copy': a / HBM_MEASURED_COPY_GBS, 'kernel': s_kernels, 'launch_us': launch * 1e6,
-            'units_per_launch': s_units, 'steps': s_steps, 'traffic': s_traffic, 'traffic_source': s_source,
+            'units_per_launch': s_units, 'steps': s_steps, 'env_pitch': s_pitch, 'traffic': s_traffic, 'traffic_source': s_source,
             **({'traffic_live_error': s_live_error} if s_live_error else {}),
             'value': world * s_units / launch}
         wl_s = None
@@ -704,7 +706,7 @@ def run_rank(args):
             'ms_per_step': wall_med / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if not args.f64_maps else 'f64 battery soc chain / f32' if args.f64_maps == 'chain' else 'f64 battery map / f32', 'data': 'synthetic',
-            'config': {'workload': what, 'name': cfg, 'envs_per_gpu': E, 'buildings': n_bldg,
+            'config': {'workload': what, 'name': cfg, 'envs_per_gpu': E, 'buildings': n_bldg, 'env_pitch': env_pitch,
                        'launch': 'hipGraph replay' if use_graph else 'eager', 'reward': 'ComfortReward' if cfg == 'C3' else 'RewardFunction',
                        'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)',
                        **({'k_steps_per_launch': 24, 'step': 'one fused 24-step launch'} if cfg in ('C5', 'C4-B', 'C4-lean-B') else {})},

@@ -45,7 +45,8 @@ class Dims(ctypes.Structure):
     """``cl_dims`` (include/citylearn_amd.h)."""
     _fields_ = [('n_env', ctypes.c_int32), ('n_bldg', ctypes.c_int32), ('n_steps', ctypes.c_int32),
                 ('n_act_cols', ctypes.c_int32), ('flags', ctypes.c_uint32), ('n_ts_rows', ctypes.c_int32),
-                ('env_row0', ctypes.c_void_p), ('tuning', ctypes.POINTER(Tuning)), ('env_offset', ctypes.c_int64)]
+                ('env_row0', ctypes.c_void_p), ('tuning', ctypes.POINTER(Tuning)), ('env_offset', ctypes.c_int64),
+                ('env_pitch', ctypes.c_int32), ('reserved0', ctypes.c_int32)]
 
 
 class Flex(ctypes.Structure):

@@ -47,7 +47,9 @@ struct StepArgs {
     int n_flex_bldg;
     unsigned env_offset;                    // cl_dims.env_offset (low 32 bits: the Philox counter word)
     float ev_penalty_coef;                  // > 0: some building has charging constraints; CLR_EV subtracts coef * violation
-    int n_env, n_bldg, n_steps, n_act_cols;
+    int n_env, n_bldg, n_steps;
+    int ld;        // floats between consecutive building rows of the state / out_bldg planes (cl_dims.env_pitch; = n_env unless padded).  (In the slot of
+                   // the action-column count, which no kernel reads: one more word in this struct cost every detail kernel a scratch reservation)
     uint32_t flags;
     int t;
     int nw;        // waves per workgroup == building lanes
@@ -385,7 +387,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
         for (int i = 0; i < VEC; ++i) r_sum[i] = 0.0f;
         if (live) {
             for (int b = w; b < a.n_bldg; b += stride) {
-                const long long off = (long long)b * a.n_env + env0;
+                const long long off = (long long)b * (FLEX ? a.n_env : a.ld) + env0;
                 float n[VEC], rw[VEC];
                 vload<VEC>(n, a.out_bldg + CLO_NET * plane + off);
 #pragma unroll
@@ -437,7 +439,10 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int env0 = blockIdx.x * TILE + lane * VEC;
     const bool live = env0 < a.n_env;                     // n_env % VEC == 0 is enforced on the host
-    const long long plane = (long long)a.n_bldg * a.n_env;
+    // (a row pitch exists for battery + PV districts only: the thermal / flexible-load instantiations never read it -- their scalar
+    //  register file is full, one more live word costs them a scratch reservation)
+    const int ld = (FULL || FLEX) ? a.n_env : a.ld;
+    const long long plane = (long long)a.n_bldg * ld;
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     const bool quirk = a.flags & CLD_REF_T0_QUIRK;
     constexpr bool detail = DETAIL;
@@ -462,7 +467,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
         cl::load_row<FULL>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags,
                            (FULL && DETAIL) ? a.ts + ((long long)(ts_row - a.t + a.n_steps - 1) * a.n_bldg + b) * CL_NF : nullptr);
         if (live) {
-            const long long off = (long long)b * a.n_env + env0;
+            const long long off = (long long)b * ld + env0;
             float s_soc[VEC], s_eff[VEC], s_deg[VEC], s_cs[VEC], s_hs[VEC], s_ds[VEC];
             [[maybe_unused]] float s_efl[VEC], s_dgl[VEC];                 // CLD_F64_MAPS: low words of efficiency / degraded capacity
             float a_cs[VEC], a_hs[VEC], a_ds[VEC], a_es[VEC], a_cd[VEC], a_hd[VEC];
@@ -637,7 +642,7 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int env0 = blockIdx.x * TILE + lane * VEC;
     const bool live = env0 < a.n_env;
-    const long long plane = (long long)a.n_bldg * a.n_env;
+    const long long plane = (long long)a.n_bldg * a.ld;
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     const bool quirk = a.flags & CLD_REF_T0_QUIRK;
     const bool act_by_bldg = (a.flags & CLD_ES_COL_IS_BLDG) && a.act_stride_env == 1;
@@ -657,7 +662,7 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             if (!own[m]) continue;
-            const long long off = (long long)bb[m] * a.n_env + env0;       // every building has its state rows: no flag test
+            const long long off = (long long)bb[m] * a.ld + env0;          // every building has its state rows: no flag test
             pload<VEC, NT>(s_soc[m], a.state + CLS_B_SOC * plane + off);
             pload<VEC, NT>(s_eff[m], a.state + CLS_B_EFF * plane + off);
             pload<VEC, NT>(s_deg[m], a.state + CLS_B_DEGCAP * plane + off);
@@ -692,7 +697,7 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
             }
         }
         if (!live) continue;
-        const long long off = (long long)b * a.n_env + env0;
+        const long long off = (long long)b * a.ld + env0;
         const bool batt = B.flags & CLF_BATTERY;
         if (!act_by_bldg) load_action<VEC>(a_es[m], a, B.a_es, env0);
         CL_TRACE_WAITV(1 + 4 * m, s_deg[m][0]);
@@ -959,7 +964,7 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
     constexpr int THREADS = 256 / VEC, TILE = 256;
     const int env = blockIdx.x * TILE + threadIdx.x * VEC;
     const bool live = env < a.n_env;                  // n_env % 4 == 0 (host): a lane's envs are all live or all dead
-    const long long plane = (long long)a.n_bldg * a.n_env;
+    const long long plane = (long long)a.n_bldg * a.ld;
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     const bool quirk = a.flags & CLD_REF_T0_QUIRK;
     const bool act_by_bldg = (a.flags & CLD_ES_COL_IS_BLDG) && a.act_stride_env == 1;
@@ -987,7 +992,7 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s_soc[b][i] = s_eff[b][i] = s_deg[b][i] = a_es[b][i] = 0.0f;
         if (live && b < a.n_bldg) {               // wave-uniform in b; no `break`: it would push the arrays to scratch
-            const long long off = (long long)b * a.n_env + env;
+            const long long off = (long long)b * a.ld + env;
             // (non-temporal loads here: no effect between 131 072 and 1 048 576 envs, scripts/stream_floor.py -- the copy-floor pattern
             //  gains 9 % from them at 1 048 576 envs, 120 -> 109 us; this kernel's 4-byte-per-lane loads do not)
             vload<VEC>(s_soc[b], a.state + CLS_B_SOC * plane + off);
@@ -1010,7 +1015,7 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
         R.nsl = __uint_as_float(sp[b][PW]); R.sol = __uint_as_float(sp[b][PW + 1]);
         R.price = __uint_as_float(sp[b][PW + 2]); R.carbon = __uint_as_float(sp[b][PW + 3]);
         R.outage = false;
-        const long long off = (long long)b * a.n_env + env;
+        const long long off = (long long)b * a.ld + env;
         const bool batt = B.flags & CLF_BATTERY;
         float o_soc[VEC], o_eff[VEC], o_deg[VEC], o_net[VEC], o_rw[VEC];
 #pragma unroll
@@ -1057,7 +1062,7 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
             float rw[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) { rw[i] = cl::marl_reward(s_soc[b][i], q_net[i]); q_rw[i] += rw[i]; }
-            vstore<VEC>(a.out_bldg + CLO_REWARD * plane + (long long)b * a.n_env + env, rw);
+            vstore<VEC>(a.out_bldg + CLO_REWARD * plane + (long long)b * a.ld + env, rw);
         }
     }
     vstore<VEC>(a.out_env + (long long)CLQ_NET * a.n_env + env, q_net);
@@ -1284,11 +1289,12 @@ __global__ void cl_marl_reward_kernel(const StepArgs a) {
 }
 
 __global__ void cl_reset_kernel(const uint32_t* __restrict__ params, float* __restrict__ state,
-                                float* __restrict__ kpi_bldg, float* __restrict__ kpi_env, int n_env, int n_bldg, uint32_t flags) {
-    const long long plane = (long long)n_bldg * n_env;
+                                float* __restrict__ kpi_bldg, float* __restrict__ kpi_env, int n_env, int n_bldg, uint32_t flags, int ld) {
+    // (`ld`: cl_dims.env_pitch -- the pad entries of a row are initialised like its envs; the KPI planes are never pitched: host)
+    const long long plane = (long long)n_bldg * ld;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < plane) {
-        const int b = (int)(i / n_env);
+        const int b = (int)(i / ld);
         const uint32_t* p = params + (long long)b * CL_NP;
         if (state) {
             state[CLS_B_SOC * plane + i] = __uint_as_float(p[CLP_L_SOC0]);
@@ -1397,11 +1403,20 @@ int check_dims(const cl_dims* d) {
     if (d->n_ts_rows != 0 && d->n_ts_rows < d->n_steps)
         return fail(CL_EINVAL, "n_ts_rows=%d < n_steps=%d", d->n_ts_rows, d->n_steps);
     if (reinterpret_cast<uintptr_t>(d->env_row0) & 3) return fail(CL_EALIGN, "env_row0 is not 4-byte aligned");
+    if (d->env_pitch != 0 && (d->env_pitch < d->n_env || d->env_pitch % 4 != 0))
+        return fail(CL_EINVAL, "env_pitch=%d must be 0 or a multiple of 4 >= n_env=%d", d->env_pitch, d->n_env);
     const uint32_t rk = (d->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     if (rk > CLR_EV) return fail(CL_EINVAL, "unknown reward kind %u", rk);
     // the Philox counter word of the random streams is env_offset + env (32 bits): shards must not alias
     if (d->env_offset < 0 || d->env_offset + (int64_t)d->n_env > (int64_t)1 << 32)
         return fail(CL_ERANGE, "env_offset=%lld with n_env=%d leaves the 32-bit env index of the random streams", (long long)d->env_offset, d->n_env);
+    return CL_OK;
+}
+
+// cl_dims.env_pitch (0 = n_env); entry points that do not implement a pitch refuse one
+int pitch_of(const cl_dims* d) { return d->env_pitch ? d->env_pitch : d->n_env; }
+int no_pitch(const cl_dims* d, const char* who) {
+    if (pitch_of(d) != d->n_env) return fail(CL_EINVAL, "%s: env_pitch=%d != n_env=%d is not implemented for this call", who, d->env_pitch, d->n_env);
     return CL_OK;
 }
 
@@ -1506,11 +1521,13 @@ int cl_reset_f32(const cl_dims* dims, const uint32_t* params, float* state, floa
     if (int rc = check_ptr(state, "state", false)) return rc;
     if (int rc = check_ptr(kpi_bldg, "kpi_bldg", false)) return rc;
     if (int rc = check_ptr(kpi_env, "kpi_env", false)) return rc;
-    const long long n = (long long)dims->n_env * dims->n_bldg;
+    const int ld = pitch_of(dims);
+    if (ld != dims->n_env && (kpi_bldg || kpi_env)) return fail(CL_EINVAL, "env_pitch=%d: the streaming KPI planes are not pitched", ld);
+    const long long n = (long long)ld * dims->n_bldg;
     const int block = 256;
     const unsigned grid = (unsigned)((n + block - 1) / block);
     hipLaunchKernelGGL(cl_reset_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, params, state, kpi_bldg,
-                       kpi_env, dims->n_env, dims->n_bldg, dims->flags);
+                       kpi_env, dims->n_env, dims->n_bldg, dims->flags, ld);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_reset_kernel launch");
     return CL_OK;
 }
@@ -1542,6 +1559,7 @@ static int check_flex(const cl_dims* dims, const cl_flex* f) {
 int cl_flex_reset_f32(const cl_dims* dims, const cl_flex* flex, void* stream) {
     if (int rc = check_dims(dims)) return rc;
     if (!flex) return fail(CL_ENULL, "flex is NULL");
+    if (int rc = no_pitch(dims, "cl_flex_reset_f32")) return rc;
     if (int rc = check_flex(dims, flex)) return rc;
     const int wm_slots = flex->n_flex_bldg * CL_MAXW;
     const long long n = (long long)dims->n_env * (flex->n_ev > wm_slots ? flex->n_ev : wm_slots);
@@ -1584,8 +1602,13 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     a.params = params; a.ts = ts; a.state = state; a.actions = actions; a.out_bldg = out_bldg; a.out_env = out_env;
     a.kpi_bldg = kpi_bldg; a.kpi_env = kpi_env;
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
-    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
+    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps;
     a.flags = dims->flags; a.t = t; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
+    a.ld = pitch_of(dims);
+    // a pitch is implemented where 2^20-env batches exist: battery + PV districts stepped by the lean / env-major / general lean kernels
+    if (a.ld != a.n_env && (!(dims->flags & CLD_LEAN) || (dims->flags & (CLD_WRITE_DETAIL | CLD_KPI | CLD_F64_MAPS)) || flex || dims->n_bldg > 32))
+        return fail(CL_EINVAL, "env_pitch=%d != n_env=%d is implemented for CLD_LEAN districts of up to 32 buildings without detail planes, streaming KPIs, "
+                               "flexible loads or CLD_F64_MAPS", a.ld, a.n_env);
     a.flex_out = nullptr; a.n_flex_bldg = 0; a.ev_penalty_coef = 0.0f;
     a.fused_finish = 0;                       // set where the kernel that is launched can fold the chunk sums itself (district_reduce<.., FOLD>)
     // non-temporal plane stores while the launch's footprint (~40 - 60 B per (env, building) unit) stays inside the Infinity Cache
@@ -1964,6 +1987,7 @@ int cl_finish_f32(const cl_dims* dims, float* out_bldg, float* out_env, int32_t 
     if (int rc = check_ptr(out_env, "out_env")) return rc;
     if (t < 0 || t >= dims->n_steps) return fail(CL_ERANGE, "t=%d outside [0, %d)", t, dims->n_steps);
     if (dims->n_bldg <= 32) return CL_OK;              // never building-chunked: every step launch finishes its own district sums
+    if (int rc = no_pitch(dims, "cl_finish_f32")) return rc;
     StepArgs a = {};
     a.out_bldg = out_bldg; a.out_env = out_env; a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps;
     a.flags = dims->flags; a.t = t; a.n_chunks = 0;    // (the kernel reads the chunk count next to the marker)
@@ -2088,9 +2112,12 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     a.params = params; a.ts = ts; a.state = state; a.actions = actions; a.out_bldg = out_bldg; a.out_env = out_env;
     a.kpi_bldg = nullptr; a.kpi_env = nullptr;
     a.act_stride_col = act_stride_col; a.act_stride_env = act_stride_env;
-    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps; a.n_act_cols = dims->n_act_cols;
+    a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_steps = dims->n_steps;
     a.flags = dims->flags; a.t = t0; a.b_chunk = dims->n_bldg; a.n_chunks = 1; a.env_row0 = dims->env_row0; a.env_offset = (unsigned)dims->env_offset;
     a.nt = 0; a.fused_finish = 0;
+    a.ld = pitch_of(dims);
+    if (a.ld != a.n_env && (!(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL) || dims->n_bldg > 32))
+        return fail(CL_EINVAL, "env_pitch=%d != n_env=%d: the fused rollout implements a pitch for CLD_LEAN districts of up to 32 buildings", a.ld, a.n_env);
     r.act_stride_step = act_stride_step; r.act_low = act_low; r.act_high = act_high; r.ret_env = ret_env; r.seed = seed;
     r.t0 = t0; r.k_steps = k_steps;
     const bool full = !(dims->flags & CLD_LEAN) || (dims->flags & CLD_WRITE_DETAIL);
@@ -2145,6 +2172,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
 
 int cl_lstm_reset_f32(const cl_dims* dims, float* hist, float* hidden, float* kpi_comfort, void* stream) {
     if (int rc = check_dims(dims)) return rc;
+    if (int rc = no_pitch(dims, "cl_lstm_reset_f32")) return rc;
     if (int rc = check_ptr(hist, "hist")) return rc;
     if (int rc = check_ptr(hidden, "hidden")) return rc;
     const size_t plane = (size_t)dims->n_env * dims->n_bldg * sizeof(float);
@@ -2163,6 +2191,7 @@ int cl_lstm_step_f32(const cl_dims* dims, const float* lstm_w, const uint16_t* l
                      const float* heat_dem, float* hist, float* hidden, float* indoor_temp, float* comfort,
                      float* kpi_comfort, int32_t t, void* stream) {
     if (int rc = check_dims(dims)) return rc;
+    if (int rc = no_pitch(dims, "cl_lstm_step_f32")) return rc;
     const cl_tuning& tun = tuning_of(dims);
     if (int rc = check_ptr(lstm_w, "lstm_w")) return rc;
     if (int rc = check_ptr(dyn_pre, "dyn_pre")) return rc;
@@ -2209,6 +2238,7 @@ int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const flo
                              const float* gen_pre, float* gen_hidden, int32_t gen_h, int32_t gen_layers, const float* cool_dem, const float* heat_dem,
                              float* hist, float* indoor_temp, float* comfort, float* kpi_comfort, int32_t t, void* stream) {
     if (int rc = check_dims(dims)) return rc;
+    if (int rc = no_pitch(dims, "cl_lstm_generic_step_f32")) return rc;
     if (int rc = check_ptr(lstm_w, "lstm_w")) return rc;
     if (int rc = check_ptr(dyn_pre, "dyn_pre")) return rc;
     if (int rc = check_ptr(gen_w, "gen_w")) return rc;
@@ -2269,6 +2299,8 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
     a.row = obs_table + (size_t)row * n_cols; a.col_src = col_src; a.col_scale = col_scale; a.state = state;
     a.out_bldg = out_bldg; a.indoor_temp = indoor_temp; a.obs = obs; a.extra = extra; a.n_extra_rows = n_extra_rows;
     a.n_env = dims->n_env; a.n_bldg = dims->n_bldg; a.n_cols = n_cols; a.all_exo = all_exo ? 1 : 0;
+    a.ld = pitch_of(dims);
+    if (a.ld != a.n_env && (indoor_temp || extra)) return fail(CL_EINVAL, "cl_observe_f32: env_pitch=%d != n_env=%d is not implemented with LSTM / flexible-load planes", a.ld, a.n_env);
     a.env_row0 = dims->env_row0;
     const bool vec4 = obs_pitch % 4 == 0;            // 16-byte stores need 16-byte aligned rows
     a.pitch = obs_pitch;

@@ -31,6 +31,7 @@ struct ObsArgs {
     int n_extra_rows;
     float* __restrict__ obs;                // [E][pitch]
     int n_env, n_bldg, n_cols, pitch;
+    int ld;                                 // row stride of the state / out_bldg planes (cl_dims.env_pitch; = n_env unless padded)
     int padded;                             // columns written per row: n_cols rounded up to 4, at most pitch
     int sub_rows;                           // tile kernel: rows per LDS sub-tile (power of two, 4..64)
     int all_exo;                            // reset observation: every column comes from the table
@@ -38,10 +39,11 @@ struct ObsArgs {
 
 CL_DEV const float* obs_plane(const ObsArgs& a, int s) {
     const int kind = s >> 28, plane = (s >> 20) & 0xFF, b = s & 0xFFFFF;
-    const long long pl = (long long)a.n_env * a.n_bldg;
+    // (the LSTM stage's and the flexible loads' planes are never pitched: the host refuses a pitch for districts that have them)
+    const long long pl = (long long)a.ld * a.n_bldg;
     const float* base = kind == 0 ? a.state + plane * pl : kind == 1 ? a.out_bldg + plane * pl
                       : kind == 2 ? a.indoor_temp : a.extra + (long long)plane * a.n_extra_rows * a.n_env;
-    return base + (long long)b * a.n_env;
+    return base + (long long)b * (kind <= 1 ? a.ld : a.n_env);
 }
 
 // VEC = 4: row pitch is a multiple of 4 floats -> every lane owns fixed 16-byte column groups (its env-independent

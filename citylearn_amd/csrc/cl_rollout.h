@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int env0 = blockIdx.x * TILE + lane * VEC;
     const bool live = env0 < a.n_env;
-    const long long plane = (long long)a.n_bldg * a.n_env;
+    const long long plane = (long long)a.n_bldg * a.ld;            // (a.ld == a.n_env unless cl_dims.env_pitch pads the rows)
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
     const bool quirk = a.flags & CLD_REF_T0_QUIRK;
     const bool detail = a.flags & CLD_WRITE_DETAIL;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
         const int b = b_lo + w + m * a.nw;
         own[m] = b < b_hi;
         const int bc = own[m] ? b : (CHUNK ? min(b_lo + w, a.n_bldg - 1) : w);
-        off[m] = (long long)bc * a.n_env + env0;
+        off[m] = (long long)bc * a.ld + env0;
         cl::load_bp<FULL>(B[m], a.params + (long long)bc * CL_NP);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {

@@ -51,7 +51,7 @@ class StepEngine:
                  t0_quirk: bool = True, detail=False, n_act_cols: Optional[int] = None, kpi: bool = False,
                  n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0,
                  charger_detail: bool = False, ev_penalty_coefficient: float = 1.0, central_agent: bool = False, tuning: Optional[dict] = None,
-                 env_offset: int = 0, f64_maps: bool = False):
+                 env_offset: int = 0, f64_maps: bool = False, env_pitch: Optional[int] = None):
         """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
         simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
         at table row ``env_row0[g]`` -- different blocks replay different windows at once.
@@ -61,6 +61,11 @@ class StepEngine:
         drift (citylearn.py:1468-1472) and ``ev_drift`` ([table rows, n_ev], optional) replays given multipliers instead
         (what the parity tests do: the reference draws them from the unseeded global ``np.random``); ``charger_detail``
         also keeps every charger's electricity consumption and requested energy of the step (``charger_out``).
+
+        ``env_pitch`` (`cl_dims.env_pitch`): floats between consecutive building rows of the state / output planes.  Default: n_env -- except for
+        battery + PV districts whose batch is a large power-of-two multiple (n_env a multiple of 65 536, from 262 144 envs up), where the rows
+        are padded by 256 envs so that their byte stride is not a multiple of 256 KiB (17 x 1 048 576: the step's 153 streams alias in the
+        memory system at a 4 MiB stride, 4 - 7 %).  `state` / `out_bldg` stay `[planes, n_bldg, n_env]` tensors (views of the padded storage).
 
         ``f64_maps`` (`CLD_F64_MAPS`): evaluate the battery map in float64 with float32 rounding where the reference's float32 series
         round -- the reference's own precision model (energy_model.py:1027-1141), for free-running parity at 1e-4; slower launches,
@@ -153,13 +158,26 @@ class StepEngine:
             if key not in dict(_lib.Tuning._fields_) or key == 'kernel_name':
                 raise ValueError(f'unknown tuning field {key!r}')
             setattr(self.tuning, key, int(value))
+        # row pitch of the state / output planes (cl_dims.env_pitch): only where the library implements one
+        pitch_ok = self.lean and not kpi and self.flex_tables is None and not self.f64_maps and not detail and self.n_bldg <= 32
+        if env_pitch is None:
+            env_pitch = self.n_env + 256 if (pitch_ok and self.n_env >= 262144 and self.n_env % 65536 == 0) else self.n_env
+        env_pitch = int(env_pitch)
+        if env_pitch != self.n_env and (not pitch_ok or env_pitch < self.n_env or env_pitch % 4):
+            raise ValueError(f'env_pitch={env_pitch}: a multiple of 4 >= n_env, for battery + PV districts of up to 32 buildings without detail planes, '
+                             'streaming KPIs, flexible loads or f64_maps=True')
+        self.env_pitch = env_pitch
         self.dims = _lib.Dims(self.n_env, self.n_bldg, self.n_steps, self.n_act_cols, flags, self.n_ts_rows,
-                              None if self.env_row0 is None else self.env_row0.data_ptr(), ctypes.pointer(self.tuning), int(env_offset))
+                              None if self.env_row0 is None else self.env_row0.data_ptr(), ctypes.pointer(self.tuning), int(env_offset),
+                              0 if env_pitch == self.n_env else env_pitch, 0)
         with torch.cuda.device(self.device):
             self.params = torch.from_numpy(tables.params.view(np.int32).copy()).to(self.device)
             self.ts = torch.from_numpy(np.ascontiguousarray(tables.ts)).to(self.device)
-            self.state = torch.zeros((abi.CL_NS, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device)
-            self.out_bldg = torch.zeros((abi.CL_NO, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device)
+            self._state_store = torch.zeros((abi.CL_NS, self.n_bldg, self.env_pitch), dtype=torch.float32, device=self.device)
+            self._out_store = torch.zeros((abi.CL_NO, self.n_bldg, self.env_pitch), dtype=torch.float32, device=self.device)
+            # (views of the padded storage when the rows carry a pitch: same base address, row stride env_pitch)
+            self.state = self._state_store[:, :, :self.n_env]
+            self.out_bldg = self._out_store[:, :, :self.n_env]
             self._out_env = torch.zeros((abi.CL_NQ, self.n_env), dtype=torch.float32, device=self.device)
             self.kpi_bldg = torch.zeros((abi.CL_NKB, self.n_bldg, self.n_env), dtype=torch.float32, device=self.device) if kpi else None
             self.kpi_env = torch.zeros((abi.CL_NKE, self.n_env), dtype=torch.float32, device=self.device) if kpi else None

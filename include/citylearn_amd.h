@@ -372,6 +372,14 @@ typedef struct cl_dims {
     int64_t env_offset;       /* index of this shard's first env in the whole (multi-GPU) batch: added to the env index wherever it keys
                                  a random stream (rollout policy, unconnected-EV drift), so that ranks given the same seed draw disjoint
                                  streams and a sharded run reproduces the unsharded one.  0 on a single GPU. */
+    int32_t env_pitch;        /* floats between consecutive building rows of the `state` / `out_bldg` planes ([plane][n_bldg][env_pitch], the first
+                                 n_env entries of a row used); 0 = n_env.  A batch whose row stride n_env x 4 B is a large power of two (2^20
+                                 envs: 4 MiB) makes the 17 x 9 streams of a step alias in the memory system -- 4 - 7 % at 17 x 1 048 576 --
+                                 which a pitch of n_env + 256 removes.  Multiple of 4, >= n_env.  Implemented where that regime exists:
+                                 CLD_LEAN districts of up to 32 buildings without CLD_KPI / flexible loads / CLD_F64_MAPS (cl_reset_f32,
+                                 cl_step_f32, cl_step_observe_f32, cl_observe_f32, cl_rollout_f32, cl_rollout_seq_f32); every other call
+                                 returns CL_EINVAL for a pitch other than n_env.  `out_env`, `actions`, `obs` keep their own strides. */
+    int32_t reserved0;
 } cl_dims;
 
 /* ABI version of the loaded library (== CL_ABI_VERSION of the header it was built from). */

@@ -108,7 +108,7 @@ def test_integration_stub_allocates_what_the_header_says():
 def test_header_constants_are_consistent():
     assert abi.CLP_USED <= abi.CL_NP and abi.CLP_L_FIRST % 16 == 0 and abi.CLP_L_LAST - abi.CLP_L_FIRST < 32
     assert abi.CLT_ICOP_DHW < abi.CL_NF and abi.CLO_RESERVED < abi.CL_NO and abi.CLQ_REWARD < abi.CL_NQ
-    assert ctypes.sizeof(_lib.Dims) == 48 and ctypes.sizeof(_lib.Tuning) == 64
+    assert ctypes.sizeof(_lib.Dims) == 56 and ctypes.sizeof(_lib.Tuning) == 64          # (56 since ABI 7: env_pitch + a reserved word)
     assert abi.CLD_REWARD_MASK >> abi.CLD_REWARD_SHIFT >= abi.CLR_SOLAR_PENALTY
 
 

@@ -147,3 +147,66 @@ def test_streaming_kpis_with_episode_offsets():
             torch.testing.assert_close(building[k][:, sl], v, rtol=1e-6, atol=1e-9, equal_nan=True, msg=k)
         for k, v in d_ref.items():
             torch.testing.assert_close(district[k][sl], v, rtol=1e-6, atol=1e-9, equal_nan=True, msg=k)
+
+
+@pytest.mark.parametrize('kind', ['RewardFunction', 'MARL'])
+@pytest.mark.parametrize('tuning,f64', [(dict(vec=1, lean_variant=2), False), (dict(vec=2, lean_variant=2), False), (dict(vec=4, lean_variant=2), False),
+                                        (dict(vec=2, lean_variant=1), False), (dict(envmajor=1), False), (dict(envmajor=1, vec=2), False),
+                                        (dict(vec=4, lean_variant=2), 'chain'), (dict(envmajor=1), 'chain')])
+def test_env_pitch_changes_nothing_but_the_row_stride(kind, tuning, f64):
+    """`cl_dims.env_pitch` (round 5): the building rows of the state / output planes padded beyond n_env -- what keeps a
+    2^20-env batch's 4 MiB row stride from aliasing in the memory system.  A pitched engine (516 envs, rows 772 floats apart) and a plain one
+    step, reset, roll out and observe bit for bit alike in the lean kernel at every pack width, the general kernel, the env-major kernel and
+    under CLD_F64_CHAIN; `state` / `out_bldg` keep their logical shape; the pad entries never reach a result."""
+    from citylearn_amd import abi
+    from citylearn_amd.engine import StepEngine
+    from citylearn_amd.observations import ObservationLayout
+    from citylearn_amd.observe import ObservationWriter
+    g = golden('g2022_all')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E = 516
+    a, b = StepEngine(tab, E, reward=kind, tuning=tuning, f64_maps=f64), StepEngine(tab, E, reward=kind, tuning=tuning, f64_maps=f64, env_pitch=E + 256)
+    assert a.env_pitch == E and b.env_pitch == E + 256 and b.dims.env_pitch == E + 256
+    assert b.state.shape == a.state.shape == (abi.CL_NS, 17, E) and b.state.stride(1) == E + 256 and b.out_bldg.stride(1) == E + 256
+    b._state_store[:, :, E:] = 7.5e8                       # poison the pad entries: nothing may read them into a result
+    b.trace_kernels()
+    dep_tables, _ = ObservationLayout(spec, 'current', False).episode(tab).compact()
+    wa, wb = ObservationWriter(a, dep_tables, None), ObservationWriter(b, dep_tables, None)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    for t in range(16):
+        act = torch.rand((a.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        if t % 2:
+            a.step(act, t); oa = wa.write(t + 1).clone()
+            ob = b.step_observe(act, wb, t)
+        else:
+            a.step(act, t); b.step(act, t)
+            oa, ob = wa.write(t + 1).clone(), wb.write(t + 1)
+        assert torch.equal(a.state, b.state) and torch.equal(a.out_bldg[:2], b.out_bldg[:2]) and torch.equal(a.out_env, b.out_env), (t, b.last_kernels)
+        assert torch.equal(oa, ob), t
+    if not f64 or f64 == 'chain':
+        acts = torch.rand((8, a.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        ra, rb = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
+        a.rollout(8, actions=acts, ret_env=ra); b.rollout(8, actions=acts, ret_env=rb)
+        assert torch.equal(a.state, b.state) and torch.equal(a.out_env, b.out_env) and torch.equal(ra, rb)
+    a.reset(); b.reset()
+    assert torch.equal(a.state, b.state)
+
+
+def test_env_pitch_defaults_and_refusals():
+    from citylearn_amd import _lib, abi
+    from citylearn_amd.engine import StepEngine
+    tab = golden('g2022_all').spec().episode_tables(0)
+    big = StepEngine(tab, 262144)
+    assert big.env_pitch == 262144 + 256 and big.state.shape[-1] == 262144          # padded by default where the stride would alias
+    assert StepEngine(tab, 65536).env_pitch == 65536 and StepEngine(tab, 262144, kpi=True).env_pitch == 262144
+    del big
+    with pytest.raises(ValueError):
+        StepEngine(tab, 512, env_pitch=514)
+    with pytest.raises(ValueError):
+        StepEngine(golden('g2020_cz1').spec().episode_tables(0), 512, env_pitch=768)     # thermal district: no pitch
+    eng = StepEngine(tab, 512)
+    eng.dims.env_pitch = 500
+    with pytest.raises(_lib.EngineError) as e:
+        eng.step(torch.zeros((eng.n_act_cols, 512), device='cuda'))
+    assert e.value.code == abi.CL_EINVAL and 'env_pitch' in str(e.value)
