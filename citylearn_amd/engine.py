@@ -63,9 +63,10 @@ class StepEngine:
         also keeps every charger's electricity consumption and requested energy of the step (``charger_out``).
 
         ``env_pitch`` (`cl_dims.env_pitch`): floats between consecutive building rows of the state / output planes.  Default: n_env -- except for
-        battery + PV districts whose batch is a large power-of-two multiple (n_env a multiple of 65 536, from 262 144 envs up), where the rows
-        are padded by 256 envs so that their byte stride is not a multiple of 256 KiB (17 x 1 048 576: the step's 153 streams alias in the
-        memory system at a 4 MiB stride, 4 - 7 %).  `state` / `out_bldg` stay `[planes, n_bldg, n_env]` tensors (views of the padded storage).
+        battery + PV districts whose batch is a large power-of-two multiple (n_env a multiple of 65 536, from 524 288 envs up), where the rows
+        are padded by 256 envs so that their byte stride is not a multiple of 256 KiB: the step's 153 streams alias in the memory system at
+        such strides (17 x 524 288: 74.2 -> 63.7 us, 17 x 1 048 576: 124.0 -> 121.5 us; at 262 144 envs, where the Infinity Cache still holds
+        most of the step, the pad costs 3 % and is not applied: profiles/r05c_*).  `state` / `out_bldg` stay `[planes, n_bldg, n_env]` tensors (views of the padded storage).
 
         ``f64_maps`` (`CLD_F64_MAPS`): evaluate the battery map in float64 with float32 rounding where the reference's float32 series
         round -- the reference's own precision model (energy_model.py:1027-1141), for free-running parity at 1e-4; slower launches,
@@ -161,7 +162,7 @@ class StepEngine:
         # row pitch of the state / output planes (cl_dims.env_pitch): only where the library implements one
         pitch_ok = self.lean and not kpi and self.flex_tables is None and not self.f64_maps and not detail and self.n_bldg <= 32
         if env_pitch is None:
-            env_pitch = self.n_env + 256 if (pitch_ok and self.n_env >= 262144 and self.n_env % 65536 == 0) else self.n_env
+            env_pitch = self.n_env + 256 if (pitch_ok and self.n_env >= 524288 and self.n_env % 65536 == 0) else self.n_env
         env_pitch = int(env_pitch)
         if env_pitch != self.n_env and (not pitch_ok or env_pitch < self.n_env or env_pitch % 4):
             raise ValueError(f'env_pitch={env_pitch}: a multiple of 4 >= n_env, for battery + PV districts of up to 32 buildings without detail planes, '

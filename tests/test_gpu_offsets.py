@@ -184,7 +184,7 @@ def test_env_pitch_changes_nothing_but_the_row_stride(kind, tuning, f64):
             oa, ob = wa.write(t + 1).clone(), wb.write(t + 1)
         assert torch.equal(a.state, b.state) and torch.equal(a.out_bldg[:2], b.out_bldg[:2]) and torch.equal(a.out_env, b.out_env), (t, b.last_kernels)
         assert torch.equal(oa, ob), t
-    if not f64 or f64 == 'chain':
+    if tuning.get('vec', 0) != 4:                              # (the fused rollout has no four-envs-per-lane instantiation to force)
         acts = torch.rand((8, a.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
         ra, rb = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
         a.rollout(8, actions=acts, ret_env=ra); b.rollout(8, actions=acts, ret_env=rb)
@@ -197,9 +197,12 @@ def test_env_pitch_defaults_and_refusals():
     from citylearn_amd import _lib, abi
     from citylearn_amd.engine import StepEngine
     tab = golden('g2022_all').spec().episode_tables(0)
-    big = StepEngine(tab, 262144)
-    assert big.env_pitch == 262144 + 256 and big.state.shape[-1] == 262144          # padded by default where the stride would alias
-    assert StepEngine(tab, 65536).env_pitch == 65536 and StepEngine(tab, 262144, kpi=True).env_pitch == 262144
+    big = StepEngine(tab, 524288)
+    assert big.env_pitch == 524288 + 256 and big.state.shape[-1] == 524288          # padded by default where the stride would alias
+    del big
+    assert StepEngine(tab, 65536).env_pitch == 65536 and StepEngine(tab, 262144).env_pitch == 262144
+    big = StepEngine(tab, 524288, kpi=True)
+    assert big.env_pitch == 524288
     del big
     with pytest.raises(ValueError):
         StepEngine(tab, 512, env_pitch=514)
