@@ -499,7 +499,9 @@ CL_DEV void full_step_body(const StepArgs& a) {
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int env0 = blockIdx.x * TILE + lane * VEC;
+    constexpr bool SWAP = LP;                             // (the LP instantiations are launched with grid = (building chunks, env tiles): district_reduce's note)
+    const int bx = SWAP ? blockIdx.y : blockIdx.x, by = SWAP ? blockIdx.x : blockIdx.y;
+    const int env0 = bx * TILE + lane * VEC;
     const bool live = env0 < a.n_env;                     // n_env % 4 == 0 is enforced on the host
     const long long plane = (long long)a.n_bldg * a.n_env;
     const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
@@ -509,10 +511,10 @@ CL_DEV void full_step_body(const StepArgs& a) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
 
-    const int b_lo = blockIdx.y * a.b_chunk;
+    const int b_lo = by * a.b_chunk;
     const int b_hi = min(a.n_bldg, b_lo + a.b_chunk);
     const bool marl_partial = rkind == CLR_MARL && a.n_chunks > 1;
-    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(bx * TILE) / CL_ROW0_BLOCK] : 0);
     CL_TRACE_DECL;
     CL_TRACE_ENTRY(0);
     CL_TRACE_CYCLES_ENTRY(4);     // shader-clock cycles at entry (slot 12: at the end) -- gives the clock the launch ran at
@@ -543,7 +545,7 @@ CL_DEV void full_step_body(const StepArgs& a) {
         if (live && b_lo + w < b_hi) {
             full_load_in<VEC, false>(early, a, a.params + (long long)(b_lo + w) * CL_NP + CLP_F_FIRST, b_lo + w, env0, plane);
             have_early = true;
-            if constexpr (FOLDK) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane); fold_issued = true; }
+            if constexpr (FOLDK) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane, bx, by); fold_issued = true; }
         }
     }
     if constexpr (LP) {
@@ -565,7 +567,7 @@ CL_DEV void full_step_body(const StepArgs& a) {
             if constexpr (FOLDK) {
                 // (deferred finish: this wave's share of the previous step's chunk sums, issued behind the first building's plane loads --
                 //  fold_prefetch's note)
-                if (!fold_issued) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane); fold_issued = true; }
+                if (!fold_issued) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane, bx, by); fold_issued = true; }
             }
             clv::FP B;
             clv::load_fp<LP>(B, f);
@@ -676,11 +678,11 @@ CL_DEV void full_step_body(const StepArgs& a) {
     }
     if constexpr (FOLDK) {
         if (!folded) {
-            if (!fold_issued) fold_prev = fold_prefetch<TILE>(a, w, lane, plane);
+            if (!fold_issued) fold_prev = fold_prefetch<TILE>(a, w, lane, plane, bx, by);
             fold_stash(a, lds_fold, w, lane, fold_prev);
         }
     }
-    district_reduce<VEC, false, FOLDK, KPI, QLDS>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
+    district_reduce<VEC, false, FOLDK, KPI, QLDS, SWAP>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
     if constexpr (KPI) {
         // baseline district series: the per-building baselines in cl_kpi_kernel's association (16 strided partial sums, added in order).
         // (district_reduce's barriers came after every wave's LDS writes; MARL's extra sweep leaves this region alone.)

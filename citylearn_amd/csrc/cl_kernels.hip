@@ -181,12 +181,13 @@ CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, flo
 //     (profiles/r04_c4_fold_breakdown.log; 13.0 / 7.8 us with the second launch, whose own 4 - 5 us mostly overlap the next step):
 //     double-buffered rows + marker only 13.7 / 8.1 -- step launches now run back to back, each starting into the previous one's
 //     draining stores; + load and stash 14.9 / 8.4; + add-up without the load 14.4 / 8.6; everything 15.3 / 9.0.
+// (`bx`, `by`: the workgroup's env tile and building chunk -- blockIdx.x / .y, or swapped: see CL_SWAP below)
 template <int TILE>
-CL_DEV float fold_prefetch(const StepArgs& a, int w, int lane, long long plane) {
+CL_DEV float fold_prefetch(const StepArgs& a, int w, int lane, long long plane, int bx, int by) {
     if (a.fused_finish != 2) return 0.0f;
     const int opw = (NQ * TILE + a.n_chunks - 1) / a.n_chunks;           // district sums of an env tile per workgroup row (<= 16: host)
-    const int i = w * 64 + lane, chunk = i >> 4, o = (int)blockIdx.y * opw + (i & 15);
-    const int e = (int)blockIdx.x * TILE + o % TILE;
+    const int i = w * 64 + lane, chunk = i >> 4, o = by * opw + (i & 15);
+    const int e = bx * TILE + o % TILE;
     if (chunk < a.n_chunks && (i & 15) < opw && o < NQ * TILE && e < a.n_env)
         return a.out_bldg[(long long)CLO_RESERVED * plane + ((long long)((a.t + 1) & 1) * a.n_chunks + chunk) * NQ * a.n_env + (long long)(o / TILE) * a.n_env + e];
     return 0.0f;
@@ -195,10 +196,10 @@ CL_DEV void fold_stash(const StepArgs& a, float* lds_fold, int w, int lane, floa
     if (a.fused_finish == 2 && w < 16) lds_fold[w * 64 + lane] = v;        // [64 chunks][16 district sums]
 }
 template <int TILE>
-CL_DEV void fold_finish(const StepArgs& a, const float* lds_fold, int w, int lane) {
+CL_DEV void fold_finish(const StepArgs& a, const float* lds_fold, int w, int lane, int bx, int by) {
     const int opw = (NQ * TILE + a.n_chunks - 1) / a.n_chunks;
-    const int o = (int)blockIdx.y * opw + w;
-    if (w >= opw || w >= 16 || o >= NQ * TILE || (int)blockIdx.x * TILE + o % TILE >= a.n_env) return;       // wave-uniform
+    const int o = by * opw + w;
+    if (w >= opw || w >= 16 || o >= NQ * TILE || bx * TILE + o % TILE >= a.n_env) return;       // wave-uniform
     const int k = lane & 15;
     float pk = 0.0f;
     if (k < a.n_chunks) {
@@ -208,17 +209,22 @@ CL_DEV void fold_finish(const StepArgs& a, const float* lds_fold, int w, int lan
     float tot = 0.0f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), q));
-    if (lane == 0) a.out_env[(long long)(o / TILE) * a.n_env + (int)blockIdx.x * TILE + o % TILE] = tot;
+    if (lane == 0) a.out_env[(long long)(o / TILE) * a.n_env + bx * TILE + o % TILE] = tot;
 }
 
 // KPIS: the thread that writes an env's district net also feeds it to the env's streaming district accumulators (CLD_KPI, lean districts)
 // PRESTORED: the caller has kept the wave's partial sums in its LDS row all along (cl_full.h, the C4 shard's kernel: four accumulators fewer in
 // registers across the buildings of a wave) -- q_* are not read.
-template <int VEC, bool FLEX = false, bool FOLD = false, bool KPIS = false, bool PRESTORED = false>
+// SWAP (round 5): the launch's grid is (building chunks, env tiles) instead of (env tiles, building chunks).  Workgroups go to the eight XCDs
+// round-robin in x-major order: with the env tiles along x every XCD steps one tile of EVERY chunk and fetches every building's parameter
+// block and table row into its own L2 (C4 shard: 8 x 327 KB per step, most of the 4.5 MB the counters showed beyond the algorithmic bytes);
+// with the chunks along x an XCD owns a few chunks for all their env tiles.  The kernels that are always launched chunked use it.
+template <int VEC, bool FLEX = false, bool FOLD = false, bool KPIS = false, bool PRESTORED = false, bool SWAP = false>
 CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int env0, bool live, long long plane, int rkind,
                             const float (&q_net)[VEC], const float (&q_cost)[VEC], const float (&q_em)[VEC],
                             const float (&q_rw)[VEC], int stride, [[maybe_unused]] const float* lds_fold = nullptr) {
     constexpr int TILE = 64 * VEC;
+    const int bx = SWAP ? blockIdx.y : blockIdx.x, by = SWAP ? blockIdx.x : blockIdx.y;       // env tile, building chunk
     if constexpr (!PRESTORED) {
         float* mine = lds + (size_t)w * NQ * TILE + lane * VEC;
         vstore<VEC>(mine + 0 * TILE, q_net);
@@ -226,7 +232,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
         vstore<VEC>(mine + 2 * TILE, q_em);
         vstore<VEC>(mine + 3 * TILE, q_rw);
     }
-    const int tile_env0 = blockIdx.x * TILE;
+    const int tile_env0 = bx * TILE;
     // (KPIS) the control series' accumulators of the env whose district net this thread is about to write: in flight across the barrier
     [[maybe_unused]] KpiSeries pre;
     if constexpr (KPIS) {
@@ -264,7 +270,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
             float s = 0.0f;
             for (int k = 0; k < a.nw; ++k) s += lds[(size_t)k * NQ * TILE + i];
             if (tile_env0 + e < a.n_env) {
-                float* dst = scratch + ((long long)blockIdx.y * NQ + q) * a.n_env + tile_env0 + e;
+                float* dst = scratch + ((long long)by * NQ + q) * a.n_env + tile_env0 + e;
                 if (FOLD && a.fused_finish == 1) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *dst = s;
             }
@@ -278,7 +284,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
             reinterpret_cast<unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4)[a.t & 1] = 0u;
         if (a.fused_finish == 2) {
             // the previous step's district sums, behind this step's partial-sum stores (the exchange tile was complete at the barrier above)
-            fold_finish<TILE>(a, lds_fold, w, lane);
+            fold_finish<TILE>(a, lds_fold, w, lane, bx, by);
             if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
                 unsigned* marker = reinterpret_cast<unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane - 4);   // last 16 bytes of the plane
                 marker[a.t & 1] = (unsigned)a.t + 1u;
@@ -286,7 +292,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
             }
             return;
         }
-        unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (long long)a.n_chunks * NQ * a.n_env) + blockIdx.x;
+        unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (long long)a.n_chunks * NQ * a.n_env) + bx;
         // this thread's partial sums have left the CU: outside tgsplit mode a workgroup-scope release fence does NOT wait for outstanding
         // vector stores (it only orders LDS), so the wait is spelled out -- s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0) -- in front of it
         // (round-3 advisor finding: the ticket could otherwise become visible before the write-through partial sums are acknowledged)
@@ -433,11 +439,13 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
 template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, int PREC = 0, bool FOLD = false>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     constexpr bool F64 = PREC == 1;
+    constexpr bool SWAP = FOLD;                            // (the FOLD instantiations are always launched building-chunked: grid = (chunks, env tiles))
+    const int bx = SWAP ? blockIdx.y : blockIdx.x, by = SWAP ? blockIdx.x : blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int env0 = blockIdx.x * TILE + lane * VEC;
+    const int env0 = bx * TILE + lane * VEC;
     const bool live = env0 < a.n_env;                     // n_env % VEC == 0 is enforced on the host
     // (a row pitch exists for battery + PV districts only: the thermal / flexible-load instantiations never read it -- their scalar
     //  register file is full, one more live word costs them a scratch reservation)
@@ -451,11 +459,11 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
 
-    const int b_lo = blockIdx.y * a.b_chunk;
+    const int b_lo = by * a.b_chunk;
     const int b_hi = min(a.n_bldg, b_lo + a.b_chunk);
     const bool marl_partial = rkind == CLR_MARL && a.n_chunks > 1;
     // table row of this env tile: TILE divides CL_ROW0_BLOCK, so the offset is workgroup-uniform (scalar load)
-    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0);
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(bx * TILE) / CL_ROW0_BLOCK] : 0);
     // (FOLD, deferred finish) this wave's share of the previous step's chunk sums: the first load of the kernel
     [[maybe_unused]] float fold_prev = 0.0f;
     [[maybe_unused]] bool fold_issued = false, folded = false;
@@ -502,7 +510,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
             if constexpr (FOLD) {
                 // (deferred finish) this wave's share of the previous step's chunk sums: issued BEHIND the first building's plane loads --
                 // it crosses XCDs (another workgroup's L2 wrote it) and returns later than they do, and loads return in order
-                if (!fold_issued) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane); fold_issued = true; }
+                if (!fold_issued) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane, bx, by); fold_issued = true; }
             }
             float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_hd[VEC], o_dd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC], o_ws[VEC], o_sc[VEC], o_sh[VEC], o_sd[VEC];
             // chargers / washing machines of this building, advanced by cl_flex_kernel just before this launch
@@ -596,11 +604,11 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 
     if constexpr (FOLD) {
         if (!folded) {                                              // (waves without a building or beyond the batch)
-            if (!fold_issued) fold_prev = fold_prefetch<TILE>(a, w, lane, plane);
+            if (!fold_issued) fold_prev = fold_prefetch<TILE>(a, w, lane, plane, bx, by);
             fold_stash(a, lds_fold, w, lane, fold_prev);
         }
     }
-    district_reduce<VEC, FLEX, FOLD>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);
+    district_reduce<VEC, FLEX, FOLD, false, false, SWAP>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);
 }
 
 // Lean districts (battery + PV + load), at most two buildings per wave, one chunk: the headline shape.  Same arithmetic
@@ -959,9 +967,14 @@ __global__ void __launch_bounds__(1024) cl_step_lean_obs_kernel(const StepArgs a
 // lane (8-byte accesses, 128-thread workgroups so that the env tile still divides CL_ROW0_BLOCK) halve the number of memory instructions
 // and of wave-uniform operations per unit, at twice the registers per wave (two waves per SIMD instead of four, the same bytes in flight).
 // The district net of building b is parked in the register that held its state of charge (dead by then): no second array for MARL.
-template <int NB, bool NT, int VEC = 1, int PREC = 0>
+// ADMA (experiment, cl_tuning.lean_variant & 16): the action columns travel global -> LDS directly (global_load_lds_dword: no vector register
+// holds them while the state planes stream in) -- NB registers fewer per lane, five waves per SIMD instead of four at NB = 17.
+template <int NB, bool NT, int VEC = 1, int PREC = 0, bool ADMA = false>
 __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepArgs a) {
+    static_assert(!ADMA || VEC == 1, "the direct-to-LDS action loads are written for one env per lane");
     constexpr int THREADS = 256 / VEC, TILE = 256;
+    [[maybe_unused]] __shared__ float act_s[ADMA ? THREADS / 64 : 1][ADMA ? NB : 1][64];
+    [[maybe_unused]] const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int env = blockIdx.x * TILE + threadIdx.x * VEC;
     const bool live = env < a.n_env;                  // n_env % 4 == 0 (host): a lane's envs are all live or all dead
     const long long plane = (long long)a.n_bldg * a.ld;
@@ -998,9 +1011,14 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
             vload<VEC>(s_soc[b], a.state + CLS_B_SOC * plane + off);
             vload<VEC>(s_eff[b], a.state + CLS_B_EFF * plane + off);
             vload<VEC>(s_deg[b], a.state + CLS_B_DEGCAP * plane + off);
-            if (act_by_bldg) vload<VEC>(a_es[b], a.actions + (long long)b * a.act_stride_col + env);
+            if (act_by_bldg) {
+                if constexpr (ADMA) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.actions + (long long)b * a.act_stride_col + env),
+                                                                     (__attribute__((address_space(3))) void*)&act_s[wv][b][0], 4, 0, 0);
+                else vload<VEC>(a_es[b], a.actions + (long long)b * a.act_stride_col + env);
+            }
         }
     }
+    if constexpr (ADMA) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the direct-to-LDS loads have landed (the tile is read below)
     __syncthreads();
     if (!live) return;
     float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
@@ -1021,7 +1039,9 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float act_v = 0.0f;
-            if (B.a_es >= 0) act_v = act_by_bldg ? a_es[b][i] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)(env + i) * a.act_stride_env];
+            if constexpr (ADMA) {
+                if (B.a_es >= 0) act_v = act_by_bldg ? act_s[wv][b][threadIdx.x & 63] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)(env + i) * a.act_stride_env];
+            } else if (B.a_es >= 0) act_v = act_by_bldg ? a_es[b][i] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)(env + i) * a.act_stride_env];
             cl::State S;
             S.soc = batt ? s_soc[b][i] : 0.0f; S.eff = batt ? s_eff[b][i] : 1.0f; S.degcap = batt ? s_deg[b][i] : 0.0f;
             S.cs = S.hs = S.ds = 0.0f;
@@ -1770,7 +1790,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (envmajor_shape) {
             const dim3 egrid((unsigned)((dims->n_env + 255) / 256));
             const int enb = dims->n_bldg <= 17 ? 17 : 20;
-            name_add(tun, "cl_step_envmajor_kernel<%d, %s, 1, 2>", enb, a.nt ? "true" : "false");
+            name_add(tun, "cl_step_envmajor_kernel<%d, %s, 1, 2, false>", enb, a.nt ? "true" : "false");
             if (enb == 17) { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<17, true, 1, 2>), egrid, dim3(256), 0, s, a);
                              else hipLaunchKernelGGL((cl_step_envmajor_kernel<17, false, 1, 2>), egrid, dim3(256), 0, s, a); }
             else { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<20, true, 1, 2>), egrid, dim3(256), 0, s, a);
@@ -1792,7 +1812,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         } else if (full && tun.full_variant != 1) {
             // thermal / outage districts: the pack-generic kernel of cl_full.h at one env per lane (parameter blocks staged in LDS where chunked)
             if (det) CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, true, 1024, 4, false);
-            else if (lp) CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, true);
+            else if (lp) { const dim3 grid_xy = grid; { const dim3 grid(grid_xy.y, grid_xy.x); CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, true); } }
             else CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, false);
         } else {
             name_add(tun, "cl_step_kernel<%d, %s, %s, false, 2, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
@@ -1863,9 +1883,13 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         } else if (lp) {
             // parameter blocks staged in LDS (cl_full.h); full_variant = 3 keeps them in SGPRs (tests, A/B)
             a.fused_finish = (a.n_chunks > 1 && vec == 2 && !small) ? (tun.finish == 2 ? 1 : can_defer ? 2 : 0) : 0;
-            if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
-            else if (small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5, false);      // (96 VGPRs do not hold the staged operands: 61 scratch accesses)
-            else CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 4, true);
+            const dim3 grid_xy = grid;
+            {
+                const dim3 grid(grid_xy.y, grid_xy.x);       // the LP instantiations read (building chunk, env tile) from blockIdx: district_reduce's SWAP note
+                if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
+                else if (!small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 4, true);
+            }
+            if (vec != 1 && small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5, false);      // (96 VGPRs do not hold the staged operands: 61 scratch accesses)
         } else {
 #ifdef CL_TRACE                  // the stamps need a few registers: five waves per SIMD (what the 9-building launch holds) instead of six
             if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, false);
@@ -1899,11 +1923,17 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // district: three fewer register quadruples than the general 20)
         const int evec = tun.vec == 2 && act_stride_env == 1 ? 2 : 1;
         const int enb = dims->n_bldg <= 17 && tun.lean_variant != 8 ? 17 : 20;
-        name_add(tun, "cl_step_envmajor_kernel<%d, %s, %d, 0>", enb, a.nt ? "true" : "false", evec);
+        if ((tun.lean_variant & 16) && enb == 17 && evec == 1) {        // (experiment: action columns through direct-to-LDS loads)
+            name_add(tun, "cl_step_envmajor_kernel<17, %s, 1, 0, true>", a.nt ? "true" : "false");
+            if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<17, true, 1, 0, true>), egrid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((cl_step_envmajor_kernel<17, false, 1, 0, true>), egrid, dim3(256), 0, s, a);
+        } else {
+        name_add(tun, "cl_step_envmajor_kernel<%d, %s, %d, 0, false>", enb, a.nt ? "true" : "false", evec);
 #define CL_EM(NB_, V_) do { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<NB_, true, V_>), egrid, dim3(256 / V_), 0, s, a); \
                             else hipLaunchKernelGGL((cl_step_envmajor_kernel<NB_, false, V_>), egrid, dim3(256 / V_), 0, s, a); } while (0)
         if (enb == 17) { if (evec == 2) CL_EM(17, 2); else CL_EM(17, 1); }
         else { if (evec == 2) CL_EM(20, 2); else CL_EM(20, 1); }
+        }
 #undef CL_EM
     } else if (lean_shape) {
         // one workgroup per CU at most: with more rounds the generic kernel's smaller register file (52 vs 88 VGPRs, two
@@ -1941,8 +1971,9 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
                 return hip_fail(e, "hipFuncSetAttribute(cl_step_kernel<.., FOLD>)");
         }
-        if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, 0, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, 0, true>), grid, block, lds, s, a);
+        const dim3 grid_sw(grid.y, grid.x);                  // (chunks along x: district_reduce's SWAP note)
+        if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, 0, true>), grid_sw, block, lds, s, a);
+        else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, 0, true>), grid_sw, block, lds, s, a);
     } else {
         name_add(tun, "cl_step_kernel<%d, false, false, false, 0, false>", vec);
         switch (vec) {
