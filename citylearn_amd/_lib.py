@@ -133,9 +133,11 @@ def load() -> ctypes.CDLL:
     if _lib is not None:
         return _lib
     import torch  # noqa: F401  -- must come first: the HIP runtime torch ships is the one the kernels run on
-    if not LIB_PATH.exists():
-        raise EngineUnavailable(f'{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build())')
-    lib = ctypes.CDLL(str(LIB_PATH))
+    # CITYLEARN_AMD_LIB: an alternative build of the same library (A/B builds of scripts/: `build_variant`), never a different backend
+    path = Path(os.environ['CITYLEARN_AMD_LIB']).resolve() if os.environ.get('CITYLEARN_AMD_LIB') else LIB_PATH
+    if not path.exists():
+        raise EngineUnavailable(f'{path} not found: the HIP extension is not built (run __graft_entry__.build())')
+    lib = ctypes.CDLL(str(path))
     vp, i32, i64, u64, f32p = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p
     lib.cl_abi_version.restype = ctypes.c_int
     lib.cl_last_error.restype = ctypes.c_char_p

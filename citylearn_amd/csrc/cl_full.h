@@ -499,7 +499,7 @@ CL_DEV void full_step_body(const StepArgs& a) {
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr bool SWAP = LP;                             // (the LP instantiations are launched with grid = (building chunks, env tiles): district_reduce's note)
+    constexpr bool SWAP = LP && CL_SWAP_GRID;             // (the LP instantiations are launched with grid = (building chunks, env tiles): district_reduce's note)
     const int bx = SWAP ? blockIdx.y : blockIdx.x, by = SWAP ? blockIdx.x : blockIdx.y;
     const int env0 = bx * TILE + lane * VEC;
     const bool live = env0 < a.n_env;                     // n_env % 4 == 0 is enforced on the host

@@ -9,6 +9,9 @@
 // run to run -- no atomics on the step path.
 #include "cl_trace.h"
 #include "cl_unit.h"
+#ifndef CL_SWAP_GRID
+#define CL_SWAP_GRID false      // chunk-major grids for the always-chunked kernels (district_reduce's SWAP note): measured, NOT the default; -DCL_SWAP_GRID=true: the A/B build
+#endif
 #include "cl_philox.h"
 
 #include <type_traits>
@@ -215,10 +218,15 @@ CL_DEV void fold_finish(const StepArgs& a, const float* lds_fold, int w, int lan
 // KPIS: the thread that writes an env's district net also feeds it to the env's streaming district accumulators (CLD_KPI, lean districts)
 // PRESTORED: the caller has kept the wave's partial sums in its LDS row all along (cl_full.h, the C4 shard's kernel: four accumulators fewer in
 // registers across the buildings of a wave) -- q_* are not read.
-// SWAP (round 5): the launch's grid is (building chunks, env tiles) instead of (env tiles, building chunks).  Workgroups go to the eight XCDs
-// round-robin in x-major order: with the env tiles along x every XCD steps one tile of EVERY chunk and fetches every building's parameter
-// block and table row into its own L2 (C4 shard: 8 x 327 KB per step, most of the 4.5 MB the counters showed beyond the algorithmic bytes);
-// with the chunks along x an XCD owns a few chunks for all their env tiles.  The kernels that are always launched chunked use it.
+// SWAP (round 5, measured and NOT the default: build with -DCL_SWAP_GRID=true): the launch's grid is (building chunks, env tiles) instead of
+// (env tiles, building chunks).  Workgroups go to the eight XCDs round-robin in x-major order: with the env tiles along x every XCD steps one
+// tile of EVERY chunk and fetches every building's parameter block and table row into its own L2 (C4 shard: 8 x 327 KB per step); with the
+// chunks along x an XCD owns a few chunks for all their env tiles.  The counters confirm the traffic -- C4 shard 64.68 -> 62.46 MB per step =
+// 1.039 x algorithmic -- and the clock says no: alternating builds on one box (profiles/r05e_*), thermal shard 13.12 - 13.15 us tile-major
+// against 13.66 - 13.76 us chunk-major, battery + PV shard 8.80 - 8.84 against 9.00 - 9.75 us, the whole thermal config (1024 x 8192) 101.0
+// against 109.9 us.  An XCD that owns four chunks touches 128 building rows of every plane instead of all 1024: its requests crowd a
+// fraction of the rows the memory system interleaves over, and 2 MB of parameter re-reads (L2 misses that the Infinity Cache serves) were
+// never on the critical path.
 template <int VEC, bool FLEX = false, bool FOLD = false, bool KPIS = false, bool PRESTORED = false, bool SWAP = false>
 CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int env0, bool live, long long plane, int rkind,
                             const float (&q_net)[VEC], const float (&q_cost)[VEC], const float (&q_em)[VEC],
@@ -439,7 +447,7 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
 template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, int PREC = 0, bool FOLD = false>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     constexpr bool F64 = PREC == 1;
-    constexpr bool SWAP = FOLD;                            // (the FOLD instantiations are always launched building-chunked: grid = (chunks, env tiles))
+    constexpr bool SWAP = FOLD && CL_SWAP_GRID;            // (the FOLD instantiations are always launched building-chunked: grid = (chunks, env tiles))
     const int bx = SWAP ? blockIdx.y : blockIdx.x, by = SWAP ? blockIdx.x : blockIdx.y;
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
     constexpr int TILE = 64 * VEC;
@@ -967,14 +975,13 @@ __global__ void __launch_bounds__(1024) cl_step_lean_obs_kernel(const StepArgs a
 // lane (8-byte accesses, 128-thread workgroups so that the env tile still divides CL_ROW0_BLOCK) halve the number of memory instructions
 // and of wave-uniform operations per unit, at twice the registers per wave (two waves per SIMD instead of four, the same bytes in flight).
 // The district net of building b is parked in the register that held its state of charge (dead by then): no second array for MARL.
-// ADMA (experiment, cl_tuning.lean_variant & 16): the action columns travel global -> LDS directly (global_load_lds_dword: no vector register
-// holds them while the state planes stream in) -- NB registers fewer per lane, five waves per SIMD instead of four at NB = 17.
-template <int NB, bool NT, int VEC = 1, int PREC = 0, bool ADMA = false>
+// (Round 5, measured and dropped: the action columns through direct-to-LDS loads -- global_load_lds_dword, no vector register holds them
+//  while the state planes stream in: 96 instead of 110 registers, five waves per SIMD instead of four -- 17 x 1 048 576: 127.3 - 129.1 us
+//  against 125.2 - 125.4 us, alternating on one box (profiles/r05d_*): every load of the wave then has to land before its first building
+//  starts, and a fifth wave per SIMD does not pay for that.)
+template <int NB, bool NT, int VEC = 1, int PREC = 0>
 __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepArgs a) {
-    static_assert(!ADMA || VEC == 1, "the direct-to-LDS action loads are written for one env per lane");
     constexpr int THREADS = 256 / VEC, TILE = 256;
-    [[maybe_unused]] __shared__ float act_s[ADMA ? THREADS / 64 : 1][ADMA ? NB : 1][64];
-    [[maybe_unused]] const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int env = blockIdx.x * TILE + threadIdx.x * VEC;
     const bool live = env < a.n_env;                  // n_env % 4 == 0 (host): a lane's envs are all live or all dead
     const long long plane = (long long)a.n_bldg * a.ld;
@@ -1011,14 +1018,9 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
             vload<VEC>(s_soc[b], a.state + CLS_B_SOC * plane + off);
             vload<VEC>(s_eff[b], a.state + CLS_B_EFF * plane + off);
             vload<VEC>(s_deg[b], a.state + CLS_B_DEGCAP * plane + off);
-            if (act_by_bldg) {
-                if constexpr (ADMA) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.actions + (long long)b * a.act_stride_col + env),
-                                                                     (__attribute__((address_space(3))) void*)&act_s[wv][b][0], 4, 0, 0);
-                else vload<VEC>(a_es[b], a.actions + (long long)b * a.act_stride_col + env);
-            }
+            if (act_by_bldg) vload<VEC>(a_es[b], a.actions + (long long)b * a.act_stride_col + env);
         }
     }
-    if constexpr (ADMA) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the direct-to-LDS loads have landed (the tile is read below)
     __syncthreads();
     if (!live) return;
     float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
@@ -1039,9 +1041,7 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             float act_v = 0.0f;
-            if constexpr (ADMA) {
-                if (B.a_es >= 0) act_v = act_by_bldg ? act_s[wv][b][threadIdx.x & 63] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)(env + i) * a.act_stride_env];
-            } else if (B.a_es >= 0) act_v = act_by_bldg ? a_es[b][i] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)(env + i) * a.act_stride_env];
+            if (B.a_es >= 0) act_v = act_by_bldg ? a_es[b][i] : a.actions[(long long)B.a_es * a.act_stride_col + (long long)(env + i) * a.act_stride_env];
             cl::State S;
             S.soc = batt ? s_soc[b][i] : 0.0f; S.eff = batt ? s_eff[b][i] : 1.0f; S.degcap = batt ? s_deg[b][i] : 0.0f;
             S.cs = S.hs = S.ds = 0.0f;
@@ -1790,7 +1790,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (envmajor_shape) {
             const dim3 egrid((unsigned)((dims->n_env + 255) / 256));
             const int enb = dims->n_bldg <= 17 ? 17 : 20;
-            name_add(tun, "cl_step_envmajor_kernel<%d, %s, 1, 2, false>", enb, a.nt ? "true" : "false");
+            name_add(tun, "cl_step_envmajor_kernel<%d, %s, 1, 2>", enb, a.nt ? "true" : "false");
             if (enb == 17) { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<17, true, 1, 2>), egrid, dim3(256), 0, s, a);
                              else hipLaunchKernelGGL((cl_step_envmajor_kernel<17, false, 1, 2>), egrid, dim3(256), 0, s, a); }
             else { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<20, true, 1, 2>), egrid, dim3(256), 0, s, a);
@@ -1812,7 +1812,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         } else if (full && tun.full_variant != 1) {
             // thermal / outage districts: the pack-generic kernel of cl_full.h at one env per lane (parameter blocks staged in LDS where chunked)
             if (det) CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, true, 1024, 4, false);
-            else if (lp) { const dim3 grid_xy = grid; { const dim3 grid(grid_xy.y, grid_xy.x); CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, true); } }
+            else if (lp) { const dim3 grid_xy = grid; { const dim3 grid = CL_SWAP_GRID ? dim3(grid_xy.y, grid_xy.x) : grid_xy; CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, true); } }
             else CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, false);
         } else {
             name_add(tun, "cl_step_kernel<%d, %s, %s, false, 2, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
@@ -1885,7 +1885,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             a.fused_finish = (a.n_chunks > 1 && vec == 2 && !small) ? (tun.finish == 2 ? 1 : can_defer ? 2 : 0) : 0;
             const dim3 grid_xy = grid;
             {
-                const dim3 grid(grid_xy.y, grid_xy.x);       // the LP instantiations read (building chunk, env tile) from blockIdx: district_reduce's SWAP note
+                const dim3 grid = CL_SWAP_GRID ? dim3(grid_xy.y, grid_xy.x) : grid_xy;       // the LP instantiations read (building chunk, env tile) from blockIdx: district_reduce's SWAP note
                 if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
                 else if (!small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 4, true);
             }
@@ -1923,17 +1923,11 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // district: three fewer register quadruples than the general 20)
         const int evec = tun.vec == 2 && act_stride_env == 1 ? 2 : 1;
         const int enb = dims->n_bldg <= 17 && tun.lean_variant != 8 ? 17 : 20;
-        if ((tun.lean_variant & 16) && enb == 17 && evec == 1) {        // (experiment: action columns through direct-to-LDS loads)
-            name_add(tun, "cl_step_envmajor_kernel<17, %s, 1, 0, true>", a.nt ? "true" : "false");
-            if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<17, true, 1, 0, true>), egrid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((cl_step_envmajor_kernel<17, false, 1, 0, true>), egrid, dim3(256), 0, s, a);
-        } else {
-        name_add(tun, "cl_step_envmajor_kernel<%d, %s, %d, 0, false>", enb, a.nt ? "true" : "false", evec);
+        name_add(tun, "cl_step_envmajor_kernel<%d, %s, %d, 0>", enb, a.nt ? "true" : "false", evec);
 #define CL_EM(NB_, V_) do { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<NB_, true, V_>), egrid, dim3(256 / V_), 0, s, a); \
                             else hipLaunchKernelGGL((cl_step_envmajor_kernel<NB_, false, V_>), egrid, dim3(256 / V_), 0, s, a); } while (0)
         if (enb == 17) { if (evec == 2) CL_EM(17, 2); else CL_EM(17, 1); }
         else { if (evec == 2) CL_EM(20, 2); else CL_EM(20, 1); }
-        }
 #undef CL_EM
     } else if (lean_shape) {
         // one workgroup per CU at most: with more rounds the generic kernel's smaller register file (52 vs 88 VGPRs, two
@@ -1971,7 +1965,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
                 return hip_fail(e, "hipFuncSetAttribute(cl_step_kernel<.., FOLD>)");
         }
-        const dim3 grid_sw(grid.y, grid.x);                  // (chunks along x: district_reduce's SWAP note)
+        const dim3 grid_sw = CL_SWAP_GRID ? dim3(grid.y, grid.x) : grid;      // (chunks along x: district_reduce's SWAP note)
         if (vec == 1) hipLaunchKernelGGL((cl_step_kernel<1, false, false, false, 0, true>), grid_sw, block, lds, s, a);
         else hipLaunchKernelGGL((cl_step_kernel<4, false, false, false, 0, true>), grid_sw, block, lds, s, a);
     } else {

@@ -114,10 +114,9 @@ def test_env_major_lean_kernel(kind):
     tab = g.spec().episode_tables(0)
     E = 516
     e0, e1 = StepEngine(tab, E, reward=kind, tuning=dict(envmajor=2)), StepEngine(tab, E, reward=kind, tuning=dict(envmajor=1))
-    # (round 5 variants of the env-major kernel: action columns through direct-to-LDS loads, two envs per lane, the general 20-building bound --
+    # (round 5 variants of the env-major kernel: two envs per lane, the general 20-building bound --
     #  the same arithmetic in the same order: every plane and district sum bit for bit)
-    alts = [StepEngine(tab, E, reward=kind, tuning=dict(envmajor=1, **t)) for t in (dict(lean_variant=16), dict(vec=2), dict(lean_variant=8))]
-    alts[0].trace_kernels()
+    alts = [StepEngine(tab, E, reward=kind, tuning=dict(envmajor=1, **t)) for t in (dict(vec=2), dict(lean_variant=8))]
     gen = torch.Generator(device='cuda').manual_seed(3)
     for t in range(40):
         a = torch.rand((e0.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
@@ -126,7 +125,6 @@ def test_env_major_lean_kernel(kind):
         for e in alts:
             e.step(a, t)
             assert torch.equal(e.state, e1.state) and torch.equal(e.out_bldg[:2], e1.out_bldg[:2]) and torch.equal(e.out_env, e1.out_env), t
-        assert 'cl_step_envmajor_kernel<17, true, 1, 0, true>' in alts[0].last_kernels
         assert torch.equal(e0.state, e1.state) and torch.equal(e0.out_bldg[abi.CLO_NET], e1.out_bldg[abi.CLO_NET]), t
         if kind != 'MARL':                       # MARL multiplies by the district net, whose rounding depends on the order
             assert torch.equal(e0.out_bldg[abi.CLO_REWARD], e1.out_bldg[abi.CLO_REWARD]), t
@@ -232,7 +230,7 @@ def test_free_running_whole_fixture_f64(name, vec):
 
 
 CHAIN_CASES = [('g2022_all', 1, None, False, 'cl_step_lean_chain_kernel<1'), ('g2022_all', 2, None, False, 'cl_step_lean_chain_kernel<2'),
-               ('g2022_all', 4, None, False, 'cl_step_lean_chain_kernel<4'), ('g2022_all', 0, dict(envmajor=1), False, 'cl_step_envmajor_kernel<17, true, 1, 2, false>'),
+               ('g2022_all', 4, None, False, 'cl_step_lean_chain_kernel<4'), ('g2022_all', 0, dict(envmajor=1), False, 'cl_step_envmajor_kernel<17, true, 1, 2>'),
                ('g2022_all', 2, dict(lean_variant=1), False, 'cl_step_kernel<2, false, false, false, 2, false>'),
                ('g2020_cz1', 0, None, False, 'cl_step_full_chain_kernel<1, false, 1024, 4, false'), ('g2020_cz1', 0, dict(full_variant=5), False, 'cl_step_full_tp_chain_kernel<1, 4'),
                ('g2020_cz1', 1, dict(full_variant=1), False, 'cl_step_kernel<1, true, false, false, 2, false>'), ('g2020_cz1', 0, None, True, 'cl_step_full_chain_kernel<1, true'),
