@@ -323,7 +323,7 @@ def _live_traffic(kernels: str, extra_args, timeout: float = 60.0, steps: int = 
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         out = tempfile.mkdtemp(prefix=f'cl_pmc_{counter}_', dir='/tmp')
         cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', out, '-o', 'run', '--', sys.executable, str(Path(__file__).resolve()),
-               '--steps', str(steps), '--warmup', str(warmup), '--reps', '1', '--no-cpu-baseline', '--no-graph', '--no-streaming', '--no-traffic-pass', *extra_args]
+               '--steps', str(steps), '--warmup', str(warmup), '--reps', '1', '--no-cpu-baseline', '--no-graph', '--no-streaming', '--no-traffic-pass', '--no-chain-entry', *extra_args]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd='/tmp', env={**os.environ, 'TMPDIR': '/tmp'})
             files = list(Path(out).rglob('*counter_collection.csv'))
@@ -643,6 +643,20 @@ def run_rank(args):
                         'for the HBM-resident figure')
     units_per_step, n_bldg, spec, tables, what, env_pitch = wl.units_per_step, wl.eng.n_bldg, wl.spec, wl.tables, wl.what, wl.eng.env_pitch
 
+    if cfg == 'headline' and not args.f64_maps and not args.kpi and not args.no_chain_entry:
+        # the same shape under CLD_F64_CHAIN -- the precision mode that holds the north star's 1e-4 FREE-RUNNING on every fixture (the fp32
+        # map needs 1e-3 on the 2020 / 15-minute / heating fixtures): what that guarantee costs, in the same run
+        wl = None
+        torch.cuda.empty_cache()
+        wl_c = build_workload(cfg, E, device, rank, world, tuning, 'chain', False, args.table_hours)
+        _, _, c_launch, _, _ = measure(wl_c, 50, 200, 1, 2000)
+        rc = wl_c.roofline(c_launch)
+        roof['f64_chain'] = {'what': 'StepEngine(f64_maps="chain"): battery soc chain in float64, degraded capacity carried as the capacity loss; same planes, same bytes',
+                             'kernel': rc['kernel'], 'launch_us': rc['launch_us'], 'frac': rc['frac'], 'achieved': rc['achieved'], 'unit': rc['unit'],
+                             'cost_vs_fp32': rc['launch_us'] / roof['launch_us'], 'value': world * wl_c.units_per_step / c_launch}
+        wl_c = None
+        torch.cuda.empty_cache()
+
     if cfg == 'headline' and not args.no_streaming and E == ENVS_PER_GPU:
         wl = None
         torch.cuda.empty_cache()
@@ -754,6 +768,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-extra-configs', action='store_true', help='N > 1, headline: skip the C4 / C4-lean / C5 lines measured in the same run (`extra_configs`)')
     ap.add_argument('--no-traffic-pass', action='store_true', help='headline, N = 1: skip the two rocprofv3 --pmc child runs that measure roofline.traffic live')
     ap.add_argument('--no-streaming', action='store_true', help='skip the 17 x 1 048 576 HBM-streaming roofline entry of the headline')
+    ap.add_argument('--no-chain-entry', action='store_true', help='skip the CLD_F64_CHAIN entry of the headline line (roofline.f64_chain)')
     ap.add_argument('--f64-maps', action='store_true', help="CLD_F64_MAPS: battery map in the reference's mixed float64 / float32 precision (step configs)")
     ap.add_argument('--f64-chain', action='store_true', help='CLD_F64_CHAIN: the battery soc chain in float64, degraded capacity as the capacity loss -- free-running 1e-4 on the default planes')
     ap.add_argument('--kpi', action='store_true', help='CLD_KPI: update the streaming KPI accumulators every step (mode A-kpi of SURVEY 8d; step configs)')

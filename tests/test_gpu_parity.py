@@ -245,7 +245,8 @@ def test_free_running_whole_fixture_f64_chain(name, vec, tuning, detail, kernel)
     `test_free_running_whole_fixture`), in the lean kernel at every pack width, the env-major kernel, the general kernel, the
     thermal-specialised kernels (one tile and several tiles per workgroup) with and without the detail planes, outage rows included.
     Measured worst (tests/test_f64_maps_host.py runs the same header on the CPU): 0.07 x the bound."""
-    worst, eng = _run(name, 'RewardFunction', vec, detail=detail, teach=False, f64='chain', tuning=tuning)
+    # (district sums at the PLAIN tolerance too: the per-building values are the reference's to ~1e-6, what is left is a 17-term fp32 sum)
+    worst, eng = _run(name, 'RewardFunction', vec, detail=detail, teach=False, f64='chain', tuning=tuning, district_slack=(1.0, 1.0))
     assert kernel in eng.last_kernels, eng.last_kernels
     assert max(worst.values()) < 1.0, worst
     print(name, eng.last_kernels, {k: round(v, 3) for k, v in worst.items()})
