@@ -63,7 +63,7 @@ ENVS_PER_GPU = 65536
 STREAMING_ENVS = 1048576        # second roofline entry of the headline: working set >> 256 MB Infinity Cache
 GRAPH_CHUNK = 100
 METRIC = 'building-timesteps/sec at 17 bldgs x 65536 envs; HBM GB/s vs roofline'
-CONFIGS = ('headline', 'C2', 'C3', 'C4', 'C4-lean', 'C5', 'T9', 'C4-B', 'C4-lean-B')
+CONFIGS = ('headline', 'C2', 'C3', 'C3-6', 'C4', 'C4-lean', 'C5', 'T9', 'C4-B', 'C4-lean-B')
 
 
 # --------------------------------------------------------------------------------------------------- CPU baseline
@@ -500,6 +500,12 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
                             f'citylearn_challenge_2023_phase_2_local_evaluation (3 buildings: power outages, partial-load cooling, DHW tank, battery; '
                             f'first 720 h) x {E} envs per GPU; one step = cl_step_f32 (energy step + the delivered-demand planes the stage reads) + cl_lstm_step_f32 (LSTM indoor '
                             'temperature + ComfortReward): the whole CityLearnEnv.step of this schema', lstm=True, f64=f64, kpi=kpi)
+    if cfg == 'C3-6':
+        # the six-building 2023 district (SURVEY 8d lists it beside the three-building one): the first 96 hours that ship as the parity fixture s_2023_p3
+        spec = load_district(str(ROOT / 'tests' / 'golden' / 's_2023_p3' / 'dataset' / 'schema.json'))
+        return StepWorkload(cfg, spec, E, device, rank, tuning,
+                            f'citylearn_challenge_2023_phase_3_1 (6 buildings: power outages, partial-load cooling, DHW tank, battery; first 96 h) x {E} envs per GPU; '
+                            'one step = cl_step_f32 + cl_lstm_step_f32 (LSTM indoor temperature + ComfortReward)', lstm=True, f64=f64, kpi=kpi)
     if cfg == 'T9':
         spec = load_district(sample_schema('citylearn_challenge_2020_climate_zone_1_744h'))
         return StepWorkload(cfg, spec, E, device, rank, tuning,
@@ -534,7 +540,7 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
     raise SystemExit(f'unknown --config {cfg}')
 
 
-DEFAULT_ENVS = {'headline': ENVS_PER_GPU, 'C2': 4096, 'C3': 65536, 'C4': 1024, 'C4-lean': 1024, 'C5': 32768, 'T9': 65536, 'C4-B': 1024, 'C4-lean-B': 1024}
+DEFAULT_ENVS = {'headline': ENVS_PER_GPU, 'C2': 4096, 'C3': 65536, 'C3-6': 65536, 'C4': 1024, 'C4-lean': 1024, 'C5': 32768, 'T9': 65536, 'C4-B': 1024, 'C4-lean-B': 1024}
 
 
 # --------------------------------------------------------------------------------------------------- one rank
@@ -613,7 +619,7 @@ def run_rank(args):
         return walls, evs, reduce_max_seconds(kernel_s, dist, ctl_device), gather_seconds(mine, dist, ctl_device), gather_seconds(kernel_s, dist, ctl_device)
 
     wl = build_workload(cfg, E, device, rank, world, tuning, args.f64_maps, args.kpi, args.table_hours)
-    heavy = cfg in ('C3', 'C5', 'C4-B', 'C4-lean-B')     # ~100 us .. 1 ms per step: fewer steps in the kernel-time bracket
+    heavy = cfg in ('C3', 'C3-6', 'C5', 'C4-B', 'C4-lean-B')     # ~100 us .. 1 ms per step: fewer steps in the kernel-time bracket
     walls, evs, launch_s, per_rank, per_rank_kernel = measure(wl, args.warmup, args.steps, args.reps, max(args.steps, 200 if heavy else 2000))
     wall_med = statistics.median(walls)
     roof = wl.roofline(launch_s)
@@ -721,7 +727,7 @@ def run_rank(args):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if not args.f64_maps else 'f64 battery soc chain / f32' if args.f64_maps == 'chain' else 'f64 battery map / f32', 'data': 'synthetic',
             'config': {'workload': what, 'name': cfg, 'envs_per_gpu': E, 'buildings': n_bldg, 'env_pitch': env_pitch,
-                       'launch': 'hipGraph replay' if use_graph else 'eager', 'reward': 'ComfortReward' if cfg == 'C3' else 'RewardFunction',
+                       'launch': 'hipGraph replay' if use_graph else 'eager', 'reward': 'ComfortReward' if cfg in ('C3', 'C3-6') else 'RewardFunction',
                        'reps': args.reps, 'statistic': 'median of reps (each: MAX over ranks)',
                        **({'k_steps_per_launch': 24, 'step': 'one fused 24-step launch'} if cfg in ('C5', 'C4-B', 'C4-lean-B') else {})},
             'ranks': world, 'world_size_seen': world if dist is None else dist.get_world_size(),
@@ -776,9 +782,9 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.f64_chain:
         args.f64_maps = 'chain'
-    heavy = args.config in ('C3', 'C5', 'C4-B', 'C4-lean-B')
+    heavy = args.config in ('C3', 'C3-6', 'C5', 'C4-B', 'C4-lean-B')
     if args.steps is None:
-        args.steps = {'C3': 300, 'C5': 200, 'C4-B': 100, 'C4-lean-B': 200}.get(args.config, 5000)
+        args.steps = {'C3': 300, 'C3-6': 200, 'C5': 200, 'C4-B': 100, 'C4-lean-B': 200}.get(args.config, 5000)
     if args.warmup is None:
         args.warmup = 30 if heavy else 300
     return args
