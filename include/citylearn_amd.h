@@ -322,10 +322,11 @@ enum cl_reward_kind {
  * They travel with the call: the library keeps no mutable state of its own (re-entrant, thread-safe for disjoint buffers).
  * Results never depend on them beyond the documented last-bit summation-order effects of the env-major kernels. */
 typedef struct cl_tuning {
-    int32_t vec;            /* envs per lane of the step / rollout kernels: 1, 2 or 4 */
+    int32_t vec;            /* envs per lane of the step / rollout kernels: 1, 2 or 4 (the env-major kernel: 2 = two envs per lane, measured slower) */
     int32_t nw;             /* waves per workgroup (= building lanes) */
     int32_t no_chunks;      /* 1: never cut the building axis into gridDim.y chunks */
-    int32_t lean_variant;   /* lean districts: 1 = general kernel, 2 = latency-ordered lean kernel at any grid size */
+    int32_t lean_variant;   /* lean districts, bit mask: 1 = general kernel, 2 = latency-ordered lean kernel at any grid size, 4 = through the thermal
+                               kernel (experiments), 8 = the env-major kernel's general 20-building instantiation where the 17-building one would run (A/B) */
     int32_t envmajor;       /* env-major kernels (one lane = one env x all buildings): 0 = by batch size, 1 = always, 2 = never */
     int32_t flex_vec;       /* envs per lane of the flexible-load kernel: 1, 2 or 4 */
     int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent, 4 plane-transpose kernel (all columns env-dependent),
@@ -346,7 +347,7 @@ typedef struct cl_tuning {
                                (measured slower: csrc/cl_kernels.hip district_reduce; tests, A/B); 3 = DEFERRED: the step launch folds the
                                PREVIOUS step's chunk sums and leaves its own in the scratch rows -- `out_env` then trails the step by one
                                launch until cl_finish_f32 (below) is called.  Only for rewards that do not couple the buildings (not
-                               MARL / EV), without CLD_KPI / CLD_F64_MAPS / CLD_WRITE_DETAIL / flexible loads; every other call keeps
+                               MARL / EV), without CLD_KPI / CLD_F64_MAPS / CLD_F64_CHAIN / CLD_WRITE_DETAIL / flexible loads; every other call keeps
                                the second launch, and cl_finish_f32 is then a no-op (a launch that does not defer clears its step parity's marker, so the mode
                                may change between steps on live buffers).  cl_rollout_seq_f32 finishes its last step itself. */
     int32_t kpi_passes;     /* streaming KPIs of thermal / outage districts and of districts stepped with the detail planes: 0 = inside the step
@@ -410,8 +411,12 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
  * actions[k*act_stride_step + col*act_stride_col + env*act_stride_env].
  * `ret_env` [n_env] (optional) accumulates the district reward sum over the k steps (episode return);
  * out_bldg / out_env receive the values of the LAST step.
- * Limits of the fused kernel: battery + PV districts of up to 32 buildings, thermal / outage districts of up to 16, no streaming
- * KPIs (CLD_KPI), no flexible loads -- cl_rollout_seq_f32 below runs the same K steps as a launch sequence for everything else. */
+ * Districts of more than 32 battery + PV / 16 thermal buildings run building-chunked (round 5): workgroup rows of `cl_tuning.b_chunk` (default 32 /
+ * 16) buildings, the last step's chunk partial sums and each chunk's share of the return in the scratch rows of out_bldg's reserved plane
+ * (n_chunks x (CL_NQ + 1) rows of n_env floats), folded by ONE cl_finish_kernel launch per call -- out_env / ret_env are final on return.
+ * Limits of the fused kernel: no streaming KPIs (CLD_KPI), no flexible loads, no CLD_F64_MAPS (CLD_F64_CHAIN is available), and on a chunked
+ * district no reward that couples the buildings inside a step (CLR_MARL: CL_EINVAL) -- cl_rollout_seq_f32 below runs the same K steps as a
+ * launch sequence for everything else. */
 int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state,
                    const float* actions, int64_t act_stride_step, int64_t act_stride_col, int64_t act_stride_env,
                    const float* act_low, const float* act_high, uint64_t seed,

@@ -265,6 +265,24 @@ def test_f64_chain_teacher_forced_other_rewards(kind):
     assert max(worst.values()) < 1.0, worst
 
 
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1'])
+def test_f64_chain_with_streaming_kpis(name):
+    """CLD_F64_CHAIN + CLD_KPI (the engine adds the detail subset the KPI pass reads): the streaming accumulators of a free-running episode
+    next to the ones of the bit-identical float64 reference mode -- the same trajectory to ~1e-6, so the same sums."""
+    g = golden(name)
+    tab = g.spec().episode_tables(0)
+    E, K = 64, min(200, g.facts['steps'])
+    a, b = StepEngine(tab, E, kpi=True, f64_maps='chain'), StepEngine(tab, E, kpi=True, f64_maps=True)
+    assert a.detail == 'min' and a.kpi_bldg is not None
+    acts = torch.from_numpy(g.ref['actions']).cuda()
+    for t in range(K):
+        act = acts[t][:, None].expand(-1, E).contiguous()
+        a.step(act); b.step(act)
+    torch.testing.assert_close(a.kpi_bldg, b.kpi_bldg, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(a.kpi_env, b.kpi_env, rtol=1e-4, atol=1e-2)
+    assert float(a.kpi_bldg.abs().sum()) > 0
+
+
 def test_f64_chain_refusals_and_views():
     g = golden('g2022_all')
     tab = g.spec().episode_tables(0)
