@@ -140,34 +140,20 @@ CL_DEV F battery_energy(const cl::BattP& B, F E, F& soc, F& eff_s, F& degcap) {
     return eb;
 }
 
-// update_electrical_storage (building.py:1801-1812) in either precision model: PREC 0 the fp32 map above, PREC 2 CLD_F64_CHAIN
-// (cl::battery_charge_chain per env of the pack; `deg` is then the capacity loss).  `flex`: the downward flexibility where OUT, else unused.
-// `g`: the building's whole parameter row in global memory (PREC 2 reads its CLP_C_* block from there; unused otherwise).
-template <typename F, int PREC, bool OUT>
-CL_DEV F battery_any(const FP& B, [[maybe_unused]] const uint32_t* __restrict__ g, F a_es, F flex, F& soc, F& eff, F& deg) {
-    if constexpr (PREC == 2) {
-        cl::BattC bc;
-        cl::load_battc(bc, g);
-        F eb;
-        if constexpr (Tr<F>::N == 1) {
-            cl::State S = {soc, eff, deg, 0.0f, 0.0f, 0.0f};
-            eb = cl::battery_charge_chain(bc, a_es, OUT ? flex : INFINITY, S);
-            soc = S.soc; eff = S.eff; deg = S.degcap;
-        } else {
-#pragma unroll
-            for (int i = 0; i < Tr<F>::N; ++i) {
-                cl::State S = {soc[i], eff[i], deg[i], 0.0f, 0.0f, 0.0f};
-                eb[i] = cl::battery_charge_chain(bc, a_es[i], OUT ? flex[i] : INFINITY, S);
-                soc[i] = S.soc; eff[i] = S.eff; deg[i] = S.degcap;
-            }
-        }
-        return eb;
-    } else {
-        cl::BattP bp; load_batt_f(bp, B.f + (CLP_F_BATT - CLP_F_FIRST), B.r);
-        F E = a_es * bp.pdt;
-        if constexpr (OUT) E = vmin(E, flex);
-        return battery_energy<F>(bp, E, soc, eff, deg);
-    }
+// update_electrical_storage (building.py:1801-1812) under CLD_F64_CHAIN: cl::battery_charge_chain for the lane's env (`deg` is then the capacity
+// loss).  `flex`: the downward flexibility where OUT, else unused.  `g`: the building's whole parameter row in global memory (the CLP_C_* block).
+// One env per lane only: at two envs per lane every instantiation parks 24 - 176 bytes per lane in scratch -- the multi-tile kernel 16 bytes of its
+// table-row struct (the two-envs-per-lane kernels' old fragility), the chunked one plain register pressure under its 128-register cap -- however the
+// pack is taken apart; the host launches the chain's thermal kernels at one env per lane.
+template <typename F, bool OUT>
+CL_DEV F battery_chain(const uint32_t* __restrict__ g, F a_es, F flex, F& soc, F& eff, F& deg) {
+    static_assert(Tr<F>::N == 1, "CLD_F64_CHAIN in the pack-generic unit: one env per lane");
+    cl::BattC bc;
+    cl::load_battc(bc, g);
+    cl::State S = {soc, eff, deg, 0.0f, 0.0f, 0.0f};
+    const F eb = cl::battery_charge_chain(bc, a_es, OUT ? flex : INFINITY, S);
+    soc = S.soc; eff = S.eff; deg = S.degcap;
+    return eb;
 }
 
 // StorageDevice.charge under StorageTank.charge's power clamps (energy_model.py:719-768, 850-870)
@@ -245,7 +231,7 @@ CL_DEV void unit_step(const FP& B, const cl::Row& R, int t, bool first, const Ac
     const auto es_first = a.es < 0.0f;
     if constexpr (OUT) {
         if (has_batt) {
-            if constexpr (PREC == 2) eb_first = battery_any<F, PREC, true>(B, g, a.es, flexibility<F>(B, R, A), S_first.soc, S_first.eff, S_first.degcap);
+            if constexpr (PREC == 2) eb_first = battery_chain<F, true>(g, a.es, flexibility<F>(B, R, A), S_first.soc, S_first.eff, S_first.degcap);
             else {
                 cl::BattP bp; load_batt_f(bp, B.f + (CLP_F_BATT - CLP_F_FIRST), B.r);
                 eb_first = battery_energy<F>(bp, vmin(a.es * bp.pdt, flexibility<F>(B, R, A)), S_first.soc, S_first.eff, S_first.degcap);
@@ -279,7 +265,7 @@ CL_DEV void unit_step(const FP& B, const cl::Row& R, int t, bool first, const Ac
             soc = S.soc; eff = S.eff; deg = S.degcap;
             F fl = zero;
             if constexpr (OUT) fl = flexibility<F>(B, R, A);
-            eb_last = battery_any<F, PREC, OUT>(B, g, a.es, fl, soc, eff, deg);
+            eb_last = battery_chain<F, OUT>(g, a.es, fl, soc, eff, deg);
         } else {
             cl::BattP bp; load_batt_f(bp, B.f + (CLP_F_BATT - CLP_F_FIRST), B.r);
             F E = a.es * bp.pdt;
