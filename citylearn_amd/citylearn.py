@@ -147,7 +147,7 @@ class CityLearnEnv(_GymEnv):
 
     def __init__(self, schema: Union[str, Path, Mapping[str, Any]], device: str = 'cuda:0',
                  observation_mode: str = 'reference', reference_quirks: bool = True, ev_seed: int = None,
-                 ev_soc_drift=None, f64_maps: bool = False, **kwargs: Any):
+                 ev_soc_drift=None, f64_maps=None, **kwargs: Any):
         """`schema` and `**kwargs` exactly as the reference constructor (citylearn.py:133-205).  Extra arguments:
         `device`; `observation_mode`: ``'reference'`` returns the reference's observation semantics (values of step
         t+1 read before they are computed -- SoC / net read 0), ``'current'`` returns the SoC / net
@@ -155,15 +155,18 @@ class CityLearnEnv(_GymEnv):
         Districts with EVs: `ev_seed` keys the device's N(1, 0.2) stream of the unconnected-EV SoC drift (the reference
         draws it from the global, unseeded ``np.random``, citylearn.py:1468-1472; default: the schema's random_seed);
         `ev_soc_drift` ([episode steps, n_ev]) replays given multipliers instead.
-        `f64_maps` (`CLD_F64_MAPS`): the battery map in the reference's own mixed float64 / float32 precision -- the battery SoC series of a
-        free-running episode is then the reference's, bit for bit, at about three times the step time; not for
-        districts with EV chargers."""
+        `f64_maps`: precision of the battery map.  Default (None): ``'chain'`` (`CLD_F64_CHAIN`: the soc chain in float64,
+        a free-running episode stays inside 1e-4 of the reference's on every dataset family; ~2 % of a step) wherever the district admits it --
+        this class is the drop-in for the reference's own env, results first -- and the fp32 map for districts with EV chargers / washing
+        machines.  ``True`` (`CLD_F64_MAPS`): the reference's own mixed float64 / float32 precision -- the battery SoC series is then the
+        reference's, bit for bit, at about three times the step time.  ``False``: the fp32 map (`VectorCityLearnEnv`'s default)."""
         if observation_mode not in ('reference', 'current'):
             raise ValueError("observation_mode must be 'reference' or 'current'")
         self.district_spec: DistrictSpec = load_district(schema, **kwargs)
         self.electric_vehicles = list(self.district_spec.electric_vehicles)
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
-        self.f64_maps = f64_maps if f64_maps in ('chain', 'ref') else bool(f64_maps)      # ('chain': CLD_F64_CHAIN, the cheap 1e-4 mode)
+        self._f64_maps_arg = f64_maps                    # (None: resolved once the tables exist -- 'chain' where the district admits it)
+        self.f64_maps = f64_maps if f64_maps in ('chain', 'ref') else bool(f64_maps)
         self.device = device
         self.observation_mode = observation_mode
         self.reference_quirks = reference_quirks
@@ -350,6 +353,8 @@ class CityLearnEnv(_GymEnv):
         fused = stock and kind is not None and not self._fused_comfort
         self._fused_reward = fused
         names = {v: k for k, v in REWARD_KINDS.items()}
+        if self._f64_maps_arg is None:
+            self.f64_maps = 'chain' if StepEngine.chain_supported(self._tables) else False
         self._engine = StepEngine(self._tables, 4, device=self.device, reward=names[kind] if fused else 'RewardFunction',
                                   t0_quirk=self.reference_quirks, detail=True, charger_detail=True, central_agent=self.central_agent,
                                   ev_reward_weights=getattr(self.reward_function, 'weights', None), ev_drift=self._ev_drift,

@@ -277,6 +277,16 @@ class StepEngine:
         self._pending_t = None
         self.t = 0
 
+    @staticmethod
+    def chain_supported(tables: EpisodeTables) -> bool:
+        """Whether `f64_maps='chain'` (CLD_F64_CHAIN) can step this district: no EV chargers / washing machines, battery curves in the shape
+        the chain's ramp form assumes (every shipped dataset's)."""
+        if tables.flex is not None:
+            return False
+        has_batt = (tables.params[:, abi.CLP_FLAGS] & abi.CLF_BATTERY) != 0
+        valid = tables.params[:, abi.CLP_C_FIRST:abi.CLP_C_LAST + 1].copy().view(np.float64)[:, abi.CLPC_VALID]
+        return not bool(np.any(has_batt & (valid != 1.0)))
+
     @property
     def _deferred(self) -> bool:
         return int(self.tuning.finish) == 3 and self.n_bldg > 32

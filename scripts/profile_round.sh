@@ -1,88 +1,88 @@
 #!/bin/bash
-# Round profile recipe (run on the GPU box through gpurun): bench lines (default and the driver's --steps 20 --warmup 5), rocprofv3
-# kernel stats of the same command, HBM traffic counters in separate passes (collected on the kernel the bench line names:
-# scripts/check_profiles.py fails the run otherwise), one line + counters per BASELINE config, the A-kpi line, user-level step timings.
-# Outputs under gpurun_out/prof_$TAG/; copy what should be judged into profiles/ (scripts/collect_profiles.sh).
+# Round profile recipe (GPU box, through gpurun; the round-4 recipe: scripts/gpurun/profile_round_r04.sh): the default bench line and the driver's flags, rocprofv3 kernel stats of the same commands,
+# HBM counters in separate passes (collected on the kernel the line names; check_profiles.py also holds a line to the traffic of the summary it
+# cites), the HBM-streaming shape, one line (+ stats, + counters where HBM-bound) per BASELINE config, BASELINE config 4 WHOLE on one GPU in
+# mode A and in mode B, the CLD_F64_CHAIN lines, the KPI / float64-reference lines, user-level timings, the GPU suite.
+# Outputs under gpurun_out/prof_$TAG/; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 kernel_of() { python -c "import json,sys; print(json.load(open(sys.argv[1]))['roofline']['kernel'].split('+')[int(sys.argv[2])])" "$1" "${2:-0}"; }
-pmc_pass() {   # pmc_pass <name> <counters...> -- <command...>: one rocprofv3 --pmc run (no tracing domains beside it)
-  local name=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
-  rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $OUT/pmc_$name -o run -- "$@" > /dev/null 2>$OUT/pmc_$name.log
-}
+pmc_pass() { local name=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $OUT/pmc_$name -o run -- "$@" > /dev/null 2>$OUT/pmc_$name.log; }
+trace() { local name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -o run -- "$@" > $OUT/under_rocprof_$name.json 2>$OUT/trace_$name.log
+  cp $OUT/trace_$name/*kernel_stats.csv $OUT/${name}_kernel_stats.csv 2>/dev/null; }
+counters() {   # counters <name> <kernel> -- <command...>: FETCH_SIZE / WRITE_SIZE passes + summary
+  local name=$1 kern=$2; shift 3
+  for ctr in FETCH_SIZE WRITE_SIZE; do pmc_pass ${name}_$ctr $ctr -- "$@"; done
+  python scripts/pmc_summary.py $OUT/${TAG}_${name}_pmc_summary.json "$kern" $OUT/pmc_${name}_FETCH_SIZE/*counter_collection.csv $OUT/pmc_${name}_WRITE_SIZE/*counter_collection.csv > /dev/null; }
 FAIL=0
+chk() { python scripts/check_profiles.py "$@" >> $OUT/check.log || FAIL=1; }
+# ---- GPU suite ----
+(timeout 1200 python -m pytest tests -m gpu -q > $OUT/gpu_suite.log 2>&1; echo "rc=$?" >> $OUT/gpu_suite.log); tail -4 $OUT/gpu_suite.log
 # ---- headline ----
 python bench.py > $OUT/bench_line.json 2>$OUT/bench_line.err
-python bench.py --steps 20 --warmup 5 > $OUT/bench_line_driver_flags.json 2>$OUT/bench_line_driver_flags.err
-BENCH="python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-streaming --no-traffic-pass"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2>$OUT/trace.log
-cp $OUT/trace/*kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_driver_flags.json 2>/dev/null
+BENCH="python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-streaming --no-traffic-pass --no-chain-entry"
+trace bench $BENCH
 K=$(kernel_of $OUT/bench_line.json)
-for c in FETCH_SIZE WRITE_SIZE; do
-  pmc_pass bench_$c $c -- python bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-graph --no-streaming --no-traffic-pass
-done
-python scripts/pmc_summary.py $OUT/bench_pmc_summary.json "$K" $OUT/pmc_bench_FETCH_SIZE/*counter_collection.csv $OUT/pmc_bench_WRITE_SIZE/*counter_collection.csv > /dev/null
-python scripts/check_profiles.py --duration-tol 0.05 $OUT/bench_line.json $OUT/bench_pmc_summary.json $OUT/bench_kernel_stats.csv >> $OUT/check.log || FAIL=1
-# ---- HBM-streaming entry (17 x 1 048 576): counters on the kernel that line names ----
-python bench.py --envs-per-gpu 1048576 --steps 20 --warmup 5 --reps 3 --no-cpu-baseline > $OUT/bench_streaming_line.json 2>$OUT/bench_streaming_line.err
-KS=$(kernel_of $OUT/bench_streaming_line.json)
-for c in FETCH_SIZE WRITE_SIZE; do
-  pmc_pass streaming_$c $c -- python bench.py --envs-per-gpu 1048576 --steps 30 --warmup 5 --reps 1 --no-cpu-baseline --no-graph
-done
-python scripts/pmc_summary.py $OUT/streaming_pmc_summary.json "$KS" $OUT/pmc_streaming_FETCH_SIZE/*counter_collection.csv $OUT/pmc_streaming_WRITE_SIZE/*counter_collection.csv > /dev/null
-python scripts/check_profiles.py $OUT/bench_streaming_line.json $OUT/streaming_pmc_summary.json >> $OUT/check.log || FAIL=1
-# rocprofv3 duration of the HBM-true shape (the judge's round-3 gap): same command shape as the line above; the kernel's AverageNs must
-# agree with the line's HIP-event launch_us within 5 %
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_streaming -o run -- python bench.py --envs-per-gpu 1048576 --steps 200 --warmup 20 --reps 3 --no-cpu-baseline > $OUT/bench_streaming_under_rocprof.json 2>$OUT/trace_streaming.log
-cp $OUT/trace_streaming/*kernel_stats.csv $OUT/streaming_kernel_stats.csv 2>/dev/null
-python scripts/check_profiles.py --duration-tol 0.05 $OUT/bench_streaming_line.json $OUT/streaming_kernel_stats.csv >> $OUT/check.log || FAIL=1
-# ---- one line per BASELINE config (+ HBM counters for the A-mode ones, kernel stats for all) ----
+counters bench "$K" -- python bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-graph --no-streaming --no-traffic-pass --no-chain-entry
+chk --duration-tol 0.05 $OUT/bench_line.json $OUT/${TAG}_bench_pmc_summary.json $OUT/bench_kernel_stats.csv
+# ---- HBM-streaming entry (17 x 1 048 576) ----
+SB="python bench.py --envs-per-gpu 1048576 --no-cpu-baseline --no-streaming --no-traffic-pass --no-chain-entry"
+KS=$(python -c "import json; print(json.load(open('$OUT/bench_line.json'))['roofline']['hbm_streaming']['kernel'])")
+counters streaming "$KS" -- $SB --steps 30 --warmup 5 --reps 1 --no-graph
+$SB --steps 20 --warmup 5 --reps 3 --traffic-summary $OUT/${TAG}_streaming_pmc_summary.json > $OUT/bench_streaming_line.json 2>/dev/null
+trace streaming $SB --steps 200 --warmup 20 --reps 3
+chk --duration-tol 0.05 $OUT/bench_streaming_line.json $OUT/${TAG}_streaming_pmc_summary.json $OUT/streaming_kernel_stats.csv
+# ---- one line per BASELINE config ----
 for c in C2 C3 C4 C4-lean C5 T9; do
   n=$(echo $c | tr 'A-Z' 'a-z' | tr -d '-')
-  python bench.py --config $c > $OUT/bench_$c.json 2>$OUT/bench_$c.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$n -o run -- python bench.py --config $c --reps 1 > /dev/null 2>$OUT/trace_$n.log
-  cp $OUT/trace_$n/*kernel_stats.csv $OUT/${n}_kernel_stats.csv 2>/dev/null
-  python scripts/check_profiles.py $OUT/bench_$c.json $OUT/${n}_kernel_stats.csv >> $OUT/check.log || FAIL=1
   case $c in C2|C4|C4-lean|T9)
-    KC=$(kernel_of $OUT/bench_$c.json)
-    for ctr in FETCH_SIZE WRITE_SIZE; do
-      pmc_pass ${n}_$ctr $ctr -- python bench.py --config $c --steps 300 --warmup 50 --reps 1 --no-graph
-    done
-    python scripts/pmc_summary.py $OUT/${n}_pmc_summary.json "$KC" $OUT/pmc_${n}_FETCH_SIZE/*counter_collection.csv $OUT/pmc_${n}_WRITE_SIZE/*counter_collection.csv > /dev/null
-    python scripts/check_profiles.py $OUT/bench_$c.json $OUT/${n}_pmc_summary.json >> $OUT/check.log || FAIL=1;;
+    python bench.py --config $c --reps 1 --steps 500 > $OUT/tmp.json 2>/dev/null
+    counters $n "$(kernel_of $OUT/tmp.json)" -- python bench.py --config $c --steps 300 --warmup 50 --reps 1 --no-graph
+    python bench.py --config $c --traffic-summary $OUT/${TAG}_${n}_pmc_summary.json > $OUT/bench_$c.json 2>$OUT/bench_$c.err
+    chk $OUT/bench_$c.json $OUT/${TAG}_${n}_pmc_summary.json;;
+  *) python bench.py --config $c > $OUT/bench_$c.json 2>$OUT/bench_$c.err;;
   esac
+  trace $n python bench.py --config $c --reps 1
+  chk $OUT/bench_$c.json $OUT/${n}_kernel_stats.csv
 done
-# C4 shards with the second launch per step (cl_tuning.finish = 1) next to the deferred finish of the lines above: same box, same session
+# ---- BASELINE config 4 whole on one GPU: mode A with counters, mode B ----
 for c in C4 C4-lean; do
-  CL_TUNE_FINISH=1 python bench.py --config $c > $OUT/bench_${c}_second_launch.json 2>/dev/null
+  n=$(echo $c | tr 'A-Z' 'a-z' | tr -d '-')_8192
+  python bench.py --config $c --envs-per-gpu 8192 --steps 500 --reps 1 > $OUT/tmp.json 2>/dev/null
+  counters $n "$(kernel_of $OUT/tmp.json)" -- python bench.py --config $c --envs-per-gpu 8192 --steps 200 --warmup 40 --reps 1 --no-graph
+  python bench.py --config $c --envs-per-gpu 8192 --steps 2000 --reps 3 --traffic-summary $OUT/${TAG}_${n}_pmc_summary.json > $OUT/bench_${c}_8192.json 2>/dev/null
+  trace $n python bench.py --config $c --envs-per-gpu 8192 --steps 2000 --reps 1
+  chk --duration-tol 0.05 $OUT/bench_${c}_8192.json $OUT/${TAG}_${n}_pmc_summary.json $OUT/${n}_kernel_stats.csv
 done
-# C3 / C5: vector-ALU counters of the LSTM and the rollout kernel (their bound is instruction issue, not HBM)
-pmc_pass c3_SQ SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- python bench.py --config C3 --steps 60 --warmup 20 --reps 1 --no-graph
-python scripts/pmc_by_kernel.py cl_lstm_kernel $OUT/pmc_c3_SQ/*counter_collection.csv > $OUT/c3_lstm_sq_by_kernel.jsonl
-pmc_pass c5_SQ SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- python bench.py --config C5 --steps 40 --warmup 10 --reps 1 --no-graph
-python scripts/pmc_by_kernel.py cl_rollout_kernel $OUT/pmc_c5_SQ/*counter_collection.csv > $OUT/c5_rollout_sq_by_kernel.jsonl
-# ---- streaming KPIs (mode A-kpi), CLD_F64_MAPS cost, user-level step ----
-python bench.py --kpi --no-streaming --no-cpu-baseline --no-traffic-pass > $OUT/bench_kpi.json 2>$OUT/bench_kpi.err
-python bench.py --kpi --config C3 > $OUT/bench_kpi_C3.json 2>$OUT/bench_kpi_C3.err
-# thermal district with streaming KPIs inside the step launch (cl_step_full_kpi_kernel): line, kernel stats, HBM counters
-python bench.py --kpi --config T9 --no-cpu-baseline > $OUT/bench_kpi_T9.json 2>$OUT/bench_kpi_T9.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_kpi_t9 -o run -- python bench.py --kpi --config T9 --reps 1 --no-cpu-baseline > /dev/null 2>$OUT/trace_kpi_t9.log
-cp $OUT/trace_kpi_t9/*kernel_stats.csv $OUT/kpi_t9_kernel_stats.csv 2>/dev/null
-python scripts/check_profiles.py $OUT/bench_kpi_T9.json $OUT/kpi_t9_kernel_stats.csv >> $OUT/check.log || FAIL=1
-KC=$(kernel_of $OUT/bench_kpi_T9.json)
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  pmc_pass kpi_t9_$ctr $ctr -- python bench.py --kpi --config T9 --steps 300 --warmup 50 --reps 1 --no-graph --no-cpu-baseline
+for c in C4-B C4-lean-B; do
+  for E in 1024 8192; do python bench.py --config $c --envs-per-gpu $E > $OUT/bench_${c}_$E.json 2>/dev/null; done
 done
-python scripts/pmc_summary.py $OUT/kpi_t9_pmc_summary.json "$KC" $OUT/pmc_kpi_t9_FETCH_SIZE/*counter_collection.csv $OUT/pmc_kpi_t9_WRITE_SIZE/*counter_collection.csv > /dev/null
-python scripts/check_profiles.py $OUT/bench_kpi_T9.json $OUT/kpi_t9_pmc_summary.json >> $OUT/check.log || FAIL=1
-python bench.py --f64-maps --no-streaming --no-cpu-baseline --no-traffic-pass > $OUT/bench_f64_maps.json 2>$OUT/bench_f64_maps.err
-for s in env_step_bench f64_cost ev_step_bench observe_bench; do
-  timeout 600 python scripts/$s.py > $OUT/${s}.log 2>$OUT/$s.err
-done
+trace c4leanb python bench.py --config C4-lean-B --reps 1
+# ---- CLD_F64_CHAIN ----
+python bench.py --f64-chain --no-cpu-baseline --no-traffic-pass > $OUT/bench_chain.json 2>$OUT/bench_chain.err
+trace chain $BENCH --f64-chain
+chk --duration-tol 0.05 $OUT/bench_chain.json $OUT/chain_kernel_stats.csv
+for c in T9 C4 C5; do python bench.py --config $c --f64-chain > $OUT/bench_chain_$c.json 2>/dev/null; done
+python bench.py --f64-maps --no-streaming --no-cpu-baseline --no-traffic-pass > $OUT/bench_f64_maps.json 2>/dev/null
+# ---- streaming KPIs ----
+python bench.py --kpi --no-streaming --no-cpu-baseline --no-traffic-pass > $OUT/bench_kpi.json 2>/dev/null
+python bench.py --kpi --config T9 --no-cpu-baseline > $OUT/bench_kpi_T9.json 2>/dev/null
+# ---- user-level timings ----
+for s in env_step_bench observe_bench ev_step_bench; do timeout 400 python scripts/$s.py > $OUT/${s}.log 2>$OUT/$s.err; done
 cat $OUT/check.log
 echo "profile check: FAIL=$FAIL"
-ls $OUT | head -80
+python - <<PY
+import json, glob
+for f in sorted(glob.glob('$OUT/bench_*.json')):
+    try:
+        d = json.load(open(f)); r = d['roofline']
+        print(f.split('/')[-1], 'value %.3e' % d['value'], 'launch_us %.2f' % r['launch_us'], 'frac %.3f' % r['frac'], r['kernel'], 'traffic', r.get('traffic'))
+    except Exception as e:
+        print(f, 'unreadable', e)
+PY
 exit $FAIL
