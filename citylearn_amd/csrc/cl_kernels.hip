@@ -1094,8 +1094,8 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
 // (Round 5, measured and dropped -- a building-major kernel for the streaming regime: four-wave workgroups over 256 envs at four envs per lane,
 //  wave w taking buildings w, w + 4, ..., all plane loads up front like above but 1 KB per wave instruction instead of 256 B, parameters from an
 //  LDS copy, 148 VGPRs = three waves per SIMD.  17 x 1 048 576, alternating runs on one box (profiles/r05g_*): 114.9 / 129.1 / 129.2 us against
-//  115.9 / 120.4 / 125.8 us for this kernel -- the same range; each PROCESS lands somewhere in it and stays there for thousands of launches, i.e. the
-//  spread is where the allocator put the planes, not the kernel.  17 x 262 144: 30.9 vs 26.0 us.  Wider accesses are not what this shape lacks.)
+//  115.9 / 120.4 / 125.8 us for this kernel -- the same range; each PROCESS lands somewhere in it and stays there for thousands of launches (not a
+//  function of the planes' virtual addresses: profiles/r05i_placement.log).  17 x 262 144: 30.9 vs 26.0 us.  Wider accesses are not what this shape lacks.)
 #ifndef CL_TU_NOSLP      /* (cl_noslp_tu.hip compiles only what its two kernels need) */
 // Second pass for building-chunked launches: add the per-chunk partial district sums.  One workgroup = 64 envs x ONE district
 // quantity x 16 waves; wave w adds chunks w, w+16, ... (independent loads issued four at a time: one memory round trip for up
