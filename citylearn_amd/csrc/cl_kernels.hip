@@ -953,6 +953,20 @@ __global__ void __launch_bounds__(1024) cl_step_lean_chain_kernel(const StepArgs
     lean_step_body<VEC, false, NT, false, false, 2>(a, lds, nullptr);
 }
 
+// ... with the streaming KPI accumulators updated by the step launch (cl_step_lean_kpi_kernel's epilogue), and with the compact observation of
+// the next row written by it (cl_step_lean_obs_kernel's): the chain changes the battery map, nothing around it
+template <int VEC, bool NT>
+__global__ void __launch_bounds__(1024) cl_step_lean_kpi_chain_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lean_step_body<VEC, false, NT, false, true, 2>(a, lds, nullptr);
+}
+
+template <int VEC, bool NT>
+__global__ void __launch_bounds__(1024) cl_step_lean_obs_chain_kernel(const StepArgs a, const ObsFusedArgs of) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    lean_step_body<VEC, false, NT, true, false, 2>(a, lds, &of);
+}
+
 template <int VEC, bool NT>
 __global__ void __launch_bounds__(1024) cl_step_lean_kpi_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1384,6 +1398,7 @@ extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int ke
     case 111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1>), grid, block, lds, s, r); break;
     // CLD_F64_CHAIN (one env per lane: 2000 + key)
     case 2012: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, true, false, 2>), grid, block, lds, s, r); break;
+    case 2022: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2, true, false, 2>), grid, block, lds, s, r); break;
     case 2111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1, true, false, 2>), grid, block, lds, s, r); break;
     case 3012: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, true, true, 2>), grid, block, lds, s, r); break;
     case 3111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1, true, true, 2>), grid, block, lds, s, r); break;
@@ -1689,7 +1704,9 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (chain) {
         if (f64) return fail(CL_EINVAL, "CLD_F64_CHAIN and CLD_F64_MAPS are two precision models of the same map: pick one");
         if (flex) return fail(CL_EINVAL, "CLD_F64_CHAIN is not implemented for districts with flexible loads (the EV batteries of cl_flex_kernel are fp32)");
-        if ((dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL)) return fail(CL_EINVAL, "CLD_F64_CHAIN with CLD_KPI needs CLD_WRITE_DETAIL");
+        // (streaming KPIs without the detail planes: the lean step launch updates them itself under the chain too; a thermal district needs the planes)
+        if ((dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL) && (full || dims->n_bldg > 32))
+            return fail(CL_EINVAL, "CLD_F64_CHAIN with CLD_KPI needs CLD_WRITE_DETAIL (except for battery + PV districts of up to 32 buildings)");
         if (full) vec = 1;                     // (the thermal unit around the float64 chain spills at two envs per lane)
     }
     if (f64) {
@@ -1801,12 +1818,25 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             else { if (a.nt) hipLaunchKernelGGL((cl_step_envmajor_kernel<20, true, 1, 2>), egrid, dim3(256), 0, s, a);
                    else hipLaunchKernelGGL((cl_step_envmajor_kernel<20, false, 1, 2>), egrid, dim3(256), 0, s, a); }
         } else if (!full && lean_shape) {
+            const bool obs_fused = of && rkind_host != CLR_MARL && !kpi_lean;      // (MARL's reward plane is finished after the sweep the tile is filled in)
+            const size_t lds_x = lds + (kpi_lean ? CL_OBS_FUSED_BLDG * sizeof(float) : obs_fused ? (size_t)tile * of->pitch * sizeof(float) : 0);
+#define CL_CHAIN_CASE(V) case V: \
+            name_add(tun, "%s<" #V ", %s>", kpi_lean ? "cl_step_lean_kpi_chain_kernel" : obs_fused ? "cl_step_lean_obs_chain_kernel" : "cl_step_lean_chain_kernel", a.nt ? "true" : "false"); \
+            if (kpi_lean) { \
+                if (a.nt) hipLaunchKernelGGL((cl_step_lean_kpi_chain_kernel<V, true>), grid, block, lds_x, s, a); \
+                else hipLaunchKernelGGL((cl_step_lean_kpi_chain_kernel<V, false>), grid, block, lds_x, s, a); \
+            } else if (obs_fused) { \
+                if (a.nt) hipLaunchKernelGGL((cl_step_lean_obs_chain_kernel<V, true>), grid, block, lds_x, s, a, *of); \
+                else hipLaunchKernelGGL((cl_step_lean_obs_chain_kernel<V, false>), grid, block, lds_x, s, a, *of); \
+                *fused = true; \
+            } else if (a.nt) hipLaunchKernelGGL((cl_step_lean_chain_kernel<V, true>), grid, block, lds, s, a); \
+            else hipLaunchKernelGGL((cl_step_lean_chain_kernel<V, false>), grid, block, lds, s, a); \
+            break;
             switch (vec) {
-            case 1: CL_LAUNCH_NT(cl_step_lean_chain_kernel, 1); break;
-            case 2: CL_LAUNCH_NT(cl_step_lean_chain_kernel, 2); break;
-            case 4: CL_LAUNCH_NT(cl_step_lean_chain_kernel, 4); break;
+            CL_CHAIN_CASE(1) CL_CHAIN_CASE(2) CL_CHAIN_CASE(4)
             default: return fail(CL_EINVAL, "bad vec %d", vec);
             }
+#undef CL_CHAIN_CASE
         } else if (tp_kernel) {
             // thermal districts, several env tiles per workgroup (cl_step_full_tp_kernel's launch shape)
             a.nw = tp_nw;
@@ -2174,14 +2204,15 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     // (scripts/rollout_vec_probe.py); chunked districts: the workgroup count is env tiles x chunks
     const long long wg2 = (long long)((dims->n_env + 127) / 128) * a.n_chunks, rounds2 = (wg2 + 255) / 256;
     const bool full_rounds = (long long)dims->n_env * a.n_chunks >= 32768 && wg2 * 100 >= rounds2 * 256 * 85 && dims->n_env >= 128;
-    const bool chain = dims->flags & CLD_F64_CHAIN;          // (the float64 soc chain: instantiated at one env per lane)
-    const int vec = chain ? 1 : tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && full_rounds) ? 2 : 1);
+    const bool chain = dims->flags & CLD_F64_CHAIN;          // (the float64 soc chain: two envs per lane only where one workgroup row holds the district)
+    int vec = tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && full_rounds) ? 2 : 1);
+    if (chain && (chunked || full || vec > 2)) vec = 1;
     const int tile = 64 * vec;
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
     const int key = (full ? 100 : 0) + vec * 10 + mb;
-    if ((key != 11 && key != 12 && key != 21 && key != 22 && key != 111) || ((chunked || chain) && key != 12 && key != 22 && key != 111) || (chain && key == 22))
+    if ((key != 11 && key != 12 && key != 21 && key != 22 && key != 111) || ((chunked || chain) && key != 12 && key != 22 && key != 111) || (chain && chunked && key == 22))
         return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
     const bool pin = chunked || chain || (long long)grid * a.nw > 5 * 1024;
     name_reset(tun);

@@ -129,7 +129,7 @@ class StepEngine:
         flags |= abi.CLD_LEAN if self.lean else 0
         # the streaming KPI passes read the detail planes -- except for battery + PV districts of up to 32 buildings, whose step kernel
         # updates the per-building accumulators itself (cl_step_lean_kpi_kernel): no detail planes, no second pass
-        kpi_in_step = kpi and self.lean and self.n_bldg <= 32 and self.flex_tables is None and not f64_maps
+        kpi_in_step = kpi and self.lean and self.n_bldg <= 32 and self.flex_tables is None and not self.f64_maps     # (fp32 or the float64 chain)
         # ... and for thermal / outage districts stepped by the one-env-per-lane thermal kernel (cl_step_full_kpi_kernel; any launch override
         # that selects another kernel falls back to the detail subset + the KPI launch)
         kpi_in_full_step = (kpi and not self.lean and self.n_bldg <= 32 and self.flex_tables is None and not f64_maps

@@ -301,7 +301,11 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
                                          default three state planes: what seeds the fp32 map's drift on the steep part of the capacity-power
                                          curve is the float32 rounding of the degraded capacity, not the arithmetic.
                                          Available in every step kernel and in the fused rollout; mutually exclusive with CLD_F64_MAPS;
-                                         districts with flexible loads keep the fp32 map (their EV batteries are fp32). */
+                                         districts with flexible loads keep the fp32 map (their EV batteries are fp32).  With CLD_KPI:
+                                         battery + PV districts of up to 32 buildings update the accumulators inside the step launch as in
+                                         fp32 (cl_step_lean_kpi_chain_kernel); thermal / chunked districts need CLD_WRITE_DETAIL (the KPI
+                                         launch reads the detail subset).  cl_step_observe_f32 fills the observation tile from the same
+                                         launch as in fp32 (cl_step_lean_obs_chain_kernel). */
 #define CLD_DETAIL_MIN     (1u << 12) /* with CLD_WRITE_DETAIL: write only the detail planes another kernel of the path reads -- CLO_BASE_NET,
                                          CLO_EXPECTED, CLO_SERVED (the streaming KPI pass) and CLO_COOL_DEM, CLO_HEAT_DEM (the LSTM stage) -- and
                                          leave the other ten alone (5 instead of 15 extra planes per step) */

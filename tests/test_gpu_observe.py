@@ -242,3 +242,29 @@ def test_step_observe_matches_step_then_observe(E, tuning, offsets, kind, normal
         assert torch.equal(got, ref), t
         assert torch.equal(wb._buffer[:, wb.n_cols:], torch.zeros_like(wb._buffer[:, wb.n_cols:]))        # pad columns stay zero
     assert got.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize('E,tuning', [(65536, None), (772, dict(vec=2)), (516, None)])
+def test_step_observe_under_the_f64_chain(E, tuning):
+    """`CLD_F64_CHAIN` through `cl_step_observe_f32`: the lean chain launch fills the observation tile itself
+    (`cl_step_lean_obs_chain_kernel`) -- bit-identical to the chain `step` followed by `ObservationWriter.write`."""
+    from citylearn_amd.engine import StepEngine
+    from citylearn_amd.observations import ObservationLayout
+    from citylearn_amd.observe import ObservationWriter
+    spec = golden('g2022_all').spec()
+    tab = spec.episode_tables(0)
+    dep_tables, _ = ObservationLayout(spec, 'current', False).episode(tab).compact()
+    a_eng, b_eng = StepEngine(tab, E, f64_maps='chain', tuning=tuning), StepEngine(tab, E, f64_maps='chain', tuning=tuning)
+    wa, wb = ObservationWriter(a_eng, dep_tables, None), ObservationWriter(b_eng, dep_tables, None)
+    b_eng.trace_kernels()
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    for t in range(12):
+        act = torch.rand((a_eng.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        a_eng.step(act, t)
+        ref = wa.write(t + 1).clone()
+        got = b_eng.step_observe(act, wb, t)
+        assert torch.equal(a_eng.state, b_eng.state) and torch.equal(a_eng.out_bldg[:2], b_eng.out_bldg[:2]), t
+        assert torch.equal(a_eng.out_env, b_eng.out_env), t
+        assert torch.equal(got, ref), t
+    assert b_eng.last_kernels.startswith('cl_step_lean_obs_chain_kernel<') and '+' not in b_eng.last_kernels, b_eng.last_kernels
+    assert got.abs().sum().item() > 0
