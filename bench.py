@@ -470,6 +470,13 @@ class RolloutWorkload:
         inst = self.inst
         peak = VALU_LANES * VALU_CLOCK_GHZ                      # G lane-instructions / s
         ach = self.units_per_step * inst / launch_s / 1e9
+        if self.eng.f64_chain:
+            # the chain's float64 instructions issue at half rate and its count per unit-step was not collected: no VALU fraction claimed
+            return {'bound': 'valu', 'achieved': None, 'peak': peak, 'unit': 'G lane-instructions/s', 'frac': None, 'kernel': self.kernels,
+                    'launch_us': launch_s * 1e6, 'units_per_launch': self.units_per_step, 'traffic': None,
+                    'hbm_bytes_per_unit_step': self.bytes_per_unit(),
+                    'note': 'CLD_F64_CHAIN fused rollout: the fp32 kernel of this config is the one priced against the VALU-issue bound (profiles/r05i: 61.8 vs 44.5 us '
+                            'per 24-step launch at 17 x 32 768)'}
         return {'bound': 'valu', 'achieved': ach, 'peak': peak, 'unit': 'G lane-instructions/s', 'frac': ach / peak, 'kernel': self.kernels,
                 'launch_us': launch_s * 1e6, 'units_per_launch': self.units_per_step, 'valu_instructions_per_unit_step': inst,
                 'valu_instructions_source': self.inst_source, 'traffic': None, 'hbm_bytes_per_unit_step': self.bytes_per_unit(),
