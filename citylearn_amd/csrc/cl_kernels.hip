@@ -185,34 +185,42 @@ CL_DEV void kpi_series_update(float* __restrict__ k, long long n_env, int t, flo
 //     double-buffered rows + marker only 13.7 / 8.1 -- step launches now run back to back, each starting into the previous one's
 //     draining stores; + load and stash 14.9 / 8.4; + add-up without the load 14.4 / 8.6; everything 15.3 / 9.0.
 // (`bx`, `by`: the workgroup's env tile and building chunk -- blockIdx.x / .y, or swapped: see CL_SWAP below)
+// (round 5) The exchange tile is [n_chunks][W] with W = 16, 32 or 64 district sums per workgroup row (`opw` rounded up; n_chunks x W <= 1024 =
+// one value per thread of the 16-wave workgroup: host): launches with FEWER, LARGER chunks defer too -- the whole BASELINE config 4 on one GPU
+// runs 8 chunks of 128 buildings (91 vs 103 us with 32 chunks of 32), where a workgroup row folds 64 sums, four per wave.
+CL_DEV int fold_shift(int opw) { return opw <= 16 ? 4 : opw <= 32 ? 5 : 6; }
 template <int TILE>
 CL_DEV float fold_prefetch(const StepArgs& a, int w, int lane, long long plane, int bx, int by) {
     if (a.fused_finish != 2) return 0.0f;
-    const int opw = (NQ * TILE + a.n_chunks - 1) / a.n_chunks;           // district sums of an env tile per workgroup row (<= 16: host)
-    const int i = w * 64 + lane, chunk = i >> 4, o = by * opw + (i & 15);
+    const int opw = (NQ * TILE + a.n_chunks - 1) / a.n_chunks;           // district sums of an env tile per workgroup row (<= 64: host)
+    const int sh = fold_shift(opw);
+    const int i = w * 64 + lane, chunk = i >> sh, j = i & ((1 << sh) - 1), o = by * opw + j;
     const int e = bx * TILE + o % TILE;
-    if (chunk < a.n_chunks && (i & 15) < opw && o < NQ * TILE && e < a.n_env)
+    if (chunk < a.n_chunks && j < opw && o < NQ * TILE && e < a.n_env)
         return a.out_bldg[(long long)CLO_RESERVED * plane + ((long long)((a.t + 1) & 1) * a.n_chunks + chunk) * NQ * a.n_env + (long long)(o / TILE) * a.n_env + e];
     return 0.0f;
 }
 CL_DEV void fold_stash(const StepArgs& a, float* lds_fold, int w, int lane, float v) {
-    if (a.fused_finish == 2 && w < 16) lds_fold[w * 64 + lane] = v;        // [64 chunks][16 district sums]
+    if (a.fused_finish == 2 && w < 16) lds_fold[w * 64 + lane] = v;        // [n_chunks][W district sums]
 }
 template <int TILE>
 CL_DEV void fold_finish(const StepArgs& a, const float* lds_fold, int w, int lane, int bx, int by) {
     const int opw = (NQ * TILE + a.n_chunks - 1) / a.n_chunks;
-    const int o = by * opw + w;
-    if (w >= opw || w >= 16 || o >= NQ * TILE || bx * TILE + o % TILE >= a.n_env) return;       // wave-uniform
+    const int sh = fold_shift(opw);
     const int k = lane & 15;
-    float pk = 0.0f;
-    if (k < a.n_chunks) {
+    for (int j = w; j < opw; j += 16) {                                  // wave-uniform: district sums w, w + 16, ... of the row
+        const int o = by * opw + j;
+        if (o >= NQ * TILE || bx * TILE + o % TILE >= a.n_env) continue;
+        float pk = 0.0f;
+        if (k < a.n_chunks) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk += k + 16 * j < a.n_chunks ? lds_fold[(k + 16 * j) * 16 + w] : 0.0f;
+            for (int c = 0; c < 4; ++c) pk += k + 16 * c < a.n_chunks ? lds_fold[((k + 16 * c) << sh) + j] : 0.0f;
+        }
+        float tot = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), q));
+        if (lane == 0) a.out_env[(long long)(o / TILE) * a.n_env + bx * TILE + o % TILE] = tot;
     }
-    float tot = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pk), q));
-    if (lane == 0) a.out_env[(long long)(o / TILE) * a.n_env + bx * TILE + o % TILE] = tot;
 }
 
 // KPIS: the thread that writes an env's district net also feeds it to the env's streaming district accumulators (CLD_KPI, lean districts)
@@ -1729,6 +1737,21 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // building per wave in two generations (scripts/c4_sweep.py, profiles/r02_c4_chunk_sweep.log)
         const long long per_cu = ((long long)dims->n_bldg * grid_x + 2048) / 4096;
         if (per_cu >= 2 && r < 2) r = 2;
+        // (round 5) the thermal kernel with staged parameter blocks (cl_full.h LP) on batches of several workgroup generations: FEWER, LARGER
+        // chunks -- one or two workgroups per CU, each wave walking 8 - 16 buildings -- instead of eight generations of two buildings per
+        // wave.  1024 buildings (scripts/gpurun/r05_call12.sh, profiles/r05m_*): x 8192 envs 103.0 / 95.3 / 91.4 / 91.6 us with chunks of
+        // 32 / 64 / 128 / 256; x 4096: 55.0 / 50.9 / 48.7 / 78.4 (128 workgroups leave half the CUs idle); x 2048: 26.6 / 30.1 / 36.4 / 61.0
+        // and x 1024: 13.2 / 21.5 / 34.5 / 60.2 -- those stay at 32.  (Battery + PV districts, cl_step_kernel: 32 stays best, 8192 envs:
+        // 63.8 / 60.3 / 64.9 / 67.4 us with 24 / 32 / 48 / 64.)
+        const bool lp_shape = !(dims->flags & CLD_LEAN) && !(tun.lean_variant & 4) && !flex && !(dims->flags & (CLD_WRITE_DETAIL | CLD_F64_MAPS)) && vec == 2 &&
+                              tun.full_variant != 1 && tun.full_variant != 3;
+        if (lp_shape && (long long)dims->n_bldg * grid_x >= 32ll * 1024) {
+            long long want = ((long long)dims->n_bldg * grid_x + 255) / 256;          // buildings per chunk for 256 workgroups ...
+            r = 2; while (16 * r < want && r < 8) r *= 2;                            // ... as a power of two, 128 at most (40 KB of staged blocks)
+        }
+        // ... whose plane stores take the non-temporal hint at every batch size (the footprint rule above is the battery + PV kernels': 1024 x
+        // 8192 envs 101.2 -> 100.0 us, x 4096 54.3 -> 53.3 us, chunks of 128: 91.4 -> 89.1 us; profiles/r05l_*, r05m_*)
+        if (lp_shape && tun.nt_stores == 0) a.nt = 1;
         a.b_chunk = tun.b_chunk > 0 ? tun.b_chunk : (int)(16 * r);
         a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
         if (a.n_chunks == 1) a.b_chunk = dims->n_bldg;
@@ -1744,11 +1767,15 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // Deferred finish (cl_tuning.finish = 3): the launch folds the PREVIOUS step's chunk sums and leaves its own for the next launch or for
     // cl_finish_f32 (district_reduce).  Only where nothing of the path reads out_env inside the step: no coupled reward (MARL's per-building
     // rewards need the district net of the same step, reward_function.py:132-143; the EV reward likewise), no streaming KPIs, no flexible
-    // loads, and the kernels that carry the fold (the FOLD instantiations below); a 16-wave workgroup folds at most 16 district sums (<= 64 chunks),
+    // loads, and the kernels that carry the fold (the FOLD instantiations below); a 16-wave workgroup folds at most 64 district sums of at most 64 chunks, 1024 partial sums in all,
     // and the reserved plane has to hold both buffers and the marker words.  Anything else keeps the second launch.
     const int fold_per_row = a.n_chunks > 1 ? (NQ * tile + a.n_chunks - 1) / a.n_chunks : 0;
+    // (battery + PV districts keep the 16-sum limit: where more sums per row would be needed -- 1024 x 4096 / 8192 envs at four envs per lane --
+    //  the folding instantiation's 107 registers cost more than the second launch: 32.8 vs 32.0 us, 65.2 vs 61.3 us, profiles/r05n_*)
+    const int fold_w = fold_per_row <= 16 ? 16 : fold_per_row <= 32 ? 32 : 64;          // row width of the exchange tile (fold_shift)
     const bool can_defer = a.n_chunks > 1 && tun.finish == 3 && rkind_host != CLR_MARL && rkind_host != CLR_EV && !flex &&
-                           !(dims->flags & (CLD_KPI | CLD_F64_MAPS | CLD_F64_CHAIN | CLD_WRITE_DETAIL)) && fold_per_row <= 16 && a.nw == 16 && a.n_chunks <= 64 &&
+                           !(dims->flags & (CLD_KPI | CLD_F64_MAPS | CLD_F64_CHAIN | CLD_WRITE_DETAIL)) && fold_per_row <= (full ? 64 : 16) && a.n_chunks * fold_w <= 1024 &&
+                           a.nw == 16 && a.n_chunks <= 64 &&
                            (2ll * a.n_chunks * NQ + 1) * dims->n_env <= (long long)dims->n_bldg * dims->n_env - 4;
     const dim3 grid(grid_x, a.n_chunks);
     const bool det = dims->flags & CLD_WRITE_DETAIL;
@@ -1769,7 +1796,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     //  can issue its plane loads, while its scalar reads hit the constant cache: 10.7 vs 8.7 us; full_variant = 2 forces it, 3 forbids it)
     const bool lp = full && !flex && !det && !f64 && tun.full_variant != 1 && tun.full_variant != 3 && vec <= 2 && (a.n_chunks > 1 || tun.full_variant == 2);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float) + (lp ? (size_t)a.b_chunk * CL_LP_WORDS * sizeof(uint32_t) : 0) +
-                       (can_defer ? 64 * 16 * sizeof(float) : 0);          // (+ the [64 chunks][16 sums] exchange tile of the deferred fold)
+                       (can_defer ? 1024 * sizeof(float) : 0);          // (+ the [chunks][16 / 32 / 64 sums] exchange tile of the deferred fold)
     const dim3 block(64 * a.nw);
     hipStream_t s = (hipStream_t)stream;
     // Thermal districts whose batch can be cut into ONE 16-wave workgroup per CU: a workgroup takes `tiles` 128-env tiles (two envs per
@@ -1921,6 +1948,14 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             const dim3 grid_xy = grid;
             {
                 const dim3 grid = CL_SWAP_GRID ? dim3(grid_xy.y, grid_xy.x) : grid_xy;       // the LP instantiations read (building chunk, env tile) from blockIdx: district_reduce's SWAP note
+                if (vec != 1 && !small && lds > 64 * 1024) {
+                    // (chunks of 128 buildings: 40 KB of staged blocks + 32 KB of reduction rows + the exchange tile -- more dynamic LDS than a
+                    //  kernel gets without opting in where the runtime enforces the 64 KB default)
+                    const void* fn = a.nt ? reinterpret_cast<const void*>(cl_step_full_kernel<2, false, 1024, 4, true, true>)
+                                          : reinterpret_cast<const void*>(cl_step_full_kernel<2, false, 1024, 4, true, false>);
+                    if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+                        return hip_fail(e, "hipFuncSetAttribute(cl_step_full_kernel<2, .., LP>)");
+                }
                 if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
                 else if (!small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 1024, 4, true);
             }

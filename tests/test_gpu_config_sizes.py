@@ -225,6 +225,40 @@ def test_c4_shard_deferred_finish(fixture, kind):
     assert torch.equal(ret_d, ret_r) and torch.equal(dfr._out_env, ref._out_env)
 
 
+@pytest.mark.parametrize('fixture,b_chunk,E', [('g2020_cz1', 128, 1024), ('g2020_cz1', 64, 640), ('g2020_cz1', None, 4096)])
+def test_deferred_finish_with_larger_chunks(fixture, b_chunk, E):
+    """Round 5: the deferred fold's exchange tile holds [chunks][16 / 32 / 64 district sums], so launches with fewer, larger chunks defer
+    too -- 8 chunks of 128 buildings (64 sums per workgroup row, four per wave), 16 of 64 (32 sums; ragged last env tile), and the
+    geometry the library now picks itself for the thermal district at 4096 envs (`b_chunk=None`: chunks of 128, 256 workgroups).
+    Planes and -- once folded -- district sums bit for bit against the same geometry with the second launch.  (Thermal districts only:
+    the battery + PV kernel keeps the second launch where a row would fold more than 16 sums -- measured slower.)"""
+    spec, tab = _c4_district(fixture)
+    K = 5
+    geo = dict(b_chunk=b_chunk) if b_chunk else {}
+    ref = StepEngine(tab, E, tuning=dict(finish=1, **geo))
+    dfr = StepEngine(tab, E, tuning=dict(finish=3, **geo))
+    ref.trace_kernels(); dfr.trace_kernels()
+    low, high = spec.action_limits()
+    rng = np.random.RandomState(E)
+    acts = torch.from_numpy(rng.uniform(low[:, None], high[:, None], size=(K, len(low), E)).astype(np.float32)).cuda()
+    prev = None
+    for t in range(K):
+        ref.step(acts[t], t); dfr.step(acts[t], t)
+        assert 'cl_finish_kernel' in ref.last_kernels and 'cl_finish_kernel' not in dfr.last_kernels, (ref.last_kernels, dfr.last_kernels)
+        if prev is not None:
+            assert torch.equal(dfr._out_env, prev)                    # not folded yet: the previous step's district sums
+        assert torch.equal(dfr.state, ref.state)
+        assert torch.equal(dfr.out_bldg[:abi.CLO_RESERVED], ref.out_bldg[:abi.CLO_RESERVED])
+        if t % 2 == 0 or t == K - 1:
+            assert torch.equal(dfr.out_env, ref.out_env), (t, (dfr.out_env - ref.out_env).abs().max().item())
+        prev = ref.out_env.clone()
+    torch.testing.assert_close(ref.district_net.double(), ref.net.double().sum(dim=0), rtol=1e-5, atol=1e-2)
+    assert float(ref.out_env.abs().sum()) > 0
+    ref.reset(); dfr.reset()
+    ref.step_many(acts); dfr.step_many(acts)
+    assert dfr._pending_t is None and torch.equal(dfr._out_env, ref._out_env) and torch.equal(dfr.state, ref.state)
+
+
 def test_deferred_finish_through_step_observe():
     """`StepEngine.step_observe`'s one-call path (`cl_step_observe_f32`) runs the same step launch as `step` -- on a chunked
     district under `finish = 3` it defers the district sums too, so a later read of `out_env` must fold them (it used to return the
