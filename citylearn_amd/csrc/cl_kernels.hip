@@ -1745,7 +1745,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         // 63.8 / 60.3 / 64.9 / 67.4 us with 24 / 32 / 48 / 64.)
         const bool lp_shape = !(dims->flags & CLD_LEAN) && !(tun.lean_variant & 4) && !flex && !(dims->flags & (CLD_WRITE_DETAIL | CLD_F64_MAPS)) && vec == 2 &&
                               tun.full_variant != 1 && tun.full_variant != 3;
-        if (lp_shape && (long long)dims->n_bldg * grid_x >= 32ll * 1024) {
+        if (lp_shape && dims->n_bldg >= 256 && (long long)dims->n_bldg * grid_x >= 32ll * 1024) {     // (measured on 1024 buildings; smaller districts keep the rule above)
             long long want = ((long long)dims->n_bldg * grid_x + 255) / 256;          // buildings per chunk for 256 workgroups ...
             r = 2; while (16 * r < want && r < 8) r *= 2;                            // ... as a power of two, 128 at most (40 KB of staged blocks)
         }
