@@ -252,17 +252,21 @@ def timed_reps(runner: Runner, reset_fn, warmup: int, steps: int, reps: int, dis
             if dist is not None:
                 _barrier(dist)
             torch.cuda.synchronize()
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
-            ev0.record(stream)
             runner.advance(warmup, steps)
-            ev1.record(stream)
             stream.synchronize()
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0          # this rank's K steps, synchronize to synchronize; the line reports the MAX over ranks
             if dist is not None:
                 _barrier(dist)                       # the closing barrier of the bracket: after the clock is read -- a 30 us RCCL barrier inside
                                                      # a 20-step region would bill every rank 1.5 us per step for the collective's own latency
+            # the same K steps once more between HIP events (diagnostic `timed_region_event_us_per_step`), OUTSIDE the wall-clock region: two
+            # event records inside a 20-step region cost it ~3 us = 2 % (scripts/r05_k20_overhead.py, profiles/r05q_k20_overhead.log)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(stream)
+            runner.advance(warmup, steps)
+            ev1.record(stream)
+            stream.synchronize()
             out.append((wall, ev0.elapsed_time(ev1) / 1e3))
         # Kernel duration for the roofline: HIP events on the launch stream around `kernel_steps` consecutive steps of the same loop
         # (graphs of GRAPH_CHUNK steps, captured and replayed once beforehand) enqueued behind a lead-in chunk, so that the bracket
