@@ -131,16 +131,19 @@ def test_c4_shard_1024_buildings_x_1024_envs(fixture, kind):
     """BASELINE config 4's per-GPU shard (synthetic district: the fixture's buildings tiled to 1024 with jittered device sizes,
     1024 envs): 64 building chunks along gridDim.y, partial district sums finished by cl_finish_kernel, MARL's per-building
     reward by cl_marl_reward_kernel.  Every env has its own actions; each step starts from the C oracle's state."""
+    _c4_against_the_c_oracle(fixture, kind, 1024, 12)
+
+
+def _c4_against_the_c_oracle(fixture, kind, E, steps, tuning=None):
     from oracle.c_oracle import COracle, OS, OO
     spec, tab = _c4_district(fixture)
-    E = 1024
-    eng = StepEngine(tab, E, reward=kind)
+    eng = StepEngine(tab, E, reward=kind, tuning=tuning)
     ora = COracle(spec, tab, E, reward=kind)
     assert eng.n_bldg == 1024
     low, high = spec.action_limits()
     rng = np.random.RandomState(11)
     worst = {}
-    for t in range(12):
+    for t in range(steps):
         a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
         a[:, 0] = 0.0
         a[:, 1], a[:, 2] = low, high
@@ -165,6 +168,23 @@ def test_c4_shard_1024_buildings_x_1024_envs(fixture, kind):
         torch.testing.assert_close(eng.district_net.double(), eng.net.double().sum(dim=0), rtol=1e-5, atol=1e-2)
         torch.testing.assert_close(eng.district_reward.double(), eng.reward_bldg.double().sum(dim=0), rtol=2e-5, atol=1e-2)
     assert max(worst.values()) < 1.0, (fixture, kind, worst)
+    return eng
+
+
+@pytest.mark.parametrize('fixture', ['g2020_cz1', 'g2022_all'])
+def test_c4_whole_config_1024_buildings_x_8192_envs(fixture):
+    """BASELINE config 4 WHOLE on one GPU -- 8.4 M (env, building) units, every env with its own actions, each step from the C oracle's
+    state -- under the tuning `bench.py --config C4 --envs-per-gpu 8192` runs with (deferred finish): the thermal district in the chunk
+    geometry the library picks for multi-generation batches (8 chunks of 128 buildings, 64 district sums folded per workgroup row), the
+    battery + PV district in chunks of 32 with the second launch."""
+    eng = _c4_against_the_c_oracle(fixture, 'RewardFunction', 8192, 3, tuning=dict(finish=3))
+    eng.trace_kernels()
+    a = torch.zeros((eng.n_act_cols, 8192), device='cuda')
+    eng.step(a, 3)
+    if fixture == 'g2020_cz1':
+        assert eng.last_kernels == 'cl_step_full_kernel<2, false, 1024, 4, true, true>', eng.last_kernels      # folds its predecessor's sums: no second launch
+    else:
+        assert eng.last_kernels == 'cl_step_kernel<4, false, false, false, 0, false>+cl_finish_kernel', eng.last_kernels
 
 
 @pytest.mark.parametrize('kind', REWARDS)
