@@ -12,6 +12,9 @@
 #ifndef CL_SWAP_GRID
 #define CL_SWAP_GRID false      // chunk-major grids for the always-chunked kernels (district_reduce's SWAP note): measured, NOT the default; -DCL_SWAP_GRID=true: the A/B build
 #endif
+#ifndef CL_LEAN_NT_LOADS
+#define CL_LEAN_NT_LOADS true          // A/B build flag: false = no non-temporal hint on any plane load of the latency-ordered lean kernels (lean_step_body's note)
+#endif
 #include "cl_philox.h"
 
 #include <type_traits>
@@ -85,8 +88,9 @@ CL_DEV void vload(float (&dst)[VEC], const float* __restrict__ p) {
     }
 }
 
-// Load from a state / action plane in HBM; NT as in pstore (measured together with the nt stores on cl_step_lean_kernel,
-// 17 x 65 536: 7.32 -> 7.18 us; the copy-floor pattern of scripts/launch_gap.py: 5.65 -> 5.41 us).
+// Load from a state / action plane in HBM; NT as in pstore (measured together with the nt stores on cl_step_lean_kernel in round 2,
+// 17 x 65 536: 7.32 -> 7.18 us; the copy-floor pattern of scripts/launch_gap.py: 5.65 -> 5.41 us -- and measured AGAIN in round 5, where
+// the hint costs the headline instantiation 1 us: which instantiations keep it is lean_step_body's `NTL`).
 template <int VEC, bool NT>
 CL_DEV void pload(float (&dst)[VEC], const float* __restrict__ p) {
     if constexpr (NT) {
@@ -627,6 +631,100 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     district_reduce<VEC, FLEX, FOLD, false, false, SWAP>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);
 }
 
+// Building-chunked battery + PV districts (BASELINE config 4 with the 2022 device set), latency-ordered (round 5).  cl_step_kernel walks a
+// dependent chain per building -- parameter block (scalar loads) -> battery flag / action column -> plane loads -> arithmetic -> stores --
+// and a wave of a chunked launch walks it b_chunk / 16 times.  Here a wave issues the plane loads of its FIRST building before it touches a
+// parameter and those of its NEXT building before it computes the current one: the addresses depend on the building index only (and on
+// CLD_ES_COL_IS_BLDG for the action column; other column maps load the action once the block is there).  The parameter block and the table
+// row still arrive by scalar loads (staged in LDS they would sit in 36 vector registers per lane: 44 bytes of scratch at four envs per lane).
+// Non-battery buildings' planes are fetched and ignored.  Same arithmetic, same summation order as cl_step_kernel<VEC, false, false>:
+// bit-identical planes and sums.
+template <int VEC, bool NT, bool FOLD>
+__global__ void __launch_bounds__(1024) cl_step_lean_chunk_kernel(const StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC] | (FOLD) exchange tile
+    constexpr int TILE = 64 * VEC;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env0 = bx * TILE + lane * VEC;
+    const bool live = env0 < a.n_env;
+    const int ld = a.n_env;                                       // (no row pitch for districts of more than 32 buildings: host)
+    const long long plane = (long long)a.n_bldg * ld;
+    const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    const bool quirk = a.flags & CLD_REF_T0_QUIRK;
+    const bool act_by_bldg = (a.flags & CLD_ES_COL_IS_BLDG) && a.act_stride_env == 1;
+    const int b_lo = by * a.b_chunk;
+    const int b_hi = min(a.n_bldg, b_lo + a.b_chunk);
+    const bool marl_partial = rkind == CLR_MARL;                  // (always chunked: cl_finish_kernel scales by the district net)
+    const int ts_row = a.t + (a.env_row0 ? a.env_row0[(bx * TILE) / CL_ROW0_BLOCK] : 0);
+    [[maybe_unused]] float* lds_fold = lds + (size_t)a.nw * NQ * TILE;
+    struct In { float soc[VEC], eff[VEC], deg[VEC], act[VEC]; };
+    auto fetch = [&](In& x, int b) {
+        const long long off = (long long)b * ld + env0;
+        vload<VEC>(x.soc, a.state + CLS_B_SOC * plane + off);
+        vload<VEC>(x.eff, a.state + CLS_B_EFF * plane + off);
+        vload<VEC>(x.deg, a.state + CLS_B_DEGCAP * plane + off);
+        if (act_by_bldg) vload<VEC>(x.act, a.actions + (long long)b * a.act_stride_col + env0);
+    };
+    In cur;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) cur.soc[i] = cur.eff[i] = cur.deg[i] = cur.act[i] = 0.0f;
+    int b = b_lo + w;
+    if (live && b < b_hi) fetch(cur, b);
+    [[maybe_unused]] float fold_prev = 0.0f;
+    [[maybe_unused]] bool folded = false;
+    if constexpr (FOLD) fold_prev = fold_prefetch<TILE>(a, w, lane, plane, bx, by);      // behind the first building's plane loads (fold_prefetch's note)
+    float q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
+    for (; b < b_hi; b += a.nw) {
+        cl::Bp B;
+        cl::load_bp<false>(B, a.params + (long long)b * CL_NP);
+        cl::Row R;
+        cl::load_row<false>(R, a.ts + ((long long)ts_row * a.n_bldg + b) * CL_NF, B.flags);
+        if (live) {
+            const long long off = (long long)b * ld + env0;
+            const bool batt = B.flags & CLF_BATTERY;
+            float a_es[VEC];
+            if (act_by_bldg) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) a_es[i] = B.a_es >= 0 ? cur.act[i] : 0.0f;
+            } else load_action<VEC>(a_es, a, B.a_es, env0);
+            float o_soc[VEC], o_eff[VEC], o_deg[VEC], o_net[VEC], o_rw[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                cl::State S;
+                S.soc = batt ? cur.soc[i] : 0.0f; S.eff = batt ? cur.eff[i] : 1.0f; S.degcap = batt ? cur.deg[i] : 0.0f;
+                S.cs = S.hs = S.ds = 0.0f; S.eff_lo = S.deg_lo = 0.0f;
+                const cl::Act act = {0.0f, 0.0f, 0.0f, a_es[i], 0.0f, 0.0f};
+                cl::Out O;
+                cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
+                const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
+                o_soc[i] = S.soc; o_eff[i] = S.eff; o_deg[i] = S.degcap; o_net[i] = O.net; o_rw[i] = rw;
+                q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
+                q_rw[i] += marl_partial ? cl::marl_reward(O.net, 1.0f) : rw;
+            }
+            if constexpr (FOLD) {
+                if (!folded && b + a.nw >= b_hi) { fold_stash(a, lds_fold, w, lane, fold_prev); folded = true; }     // before the LAST building's stores
+            }
+            // the NEXT building's plane loads, into the registers the arithmetic has just released and IN FRONT of this building's stores: the
+            // wait for them at the top of the next iteration then allows the stores to be outstanding (loads and stores share one counter)
+            if (b + a.nw < b_hi) fetch(cur, b + a.nw);
+            if (batt) {
+                pstore<VEC, NT>(a.state + CLS_B_SOC * plane + off, o_soc);
+                pstore<VEC, NT>(a.state + CLS_B_EFF * plane + off, o_eff);
+                pstore<VEC, NT>(a.state + CLS_B_DEGCAP * plane + off, o_deg);
+            }
+            pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
+            if (rkind != CLR_MARL) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+        }
+    }
+    if constexpr (FOLD) {
+        if (!folded) fold_stash(a, lds_fold, w, lane, fold_prev);      // (waves without a building or beyond the batch)
+    }
+    district_reduce<VEC, false, FOLD>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);
+}
+
 // Lean districts (battery + PV + load), at most two buildings per wave, one chunk: the headline shape.  Same arithmetic
 // as cl_step_kernel<VEC, false, false>; the memory operations are re-ordered for latency.  A kernel with this launch
 // shape and these byte counts but no energy model runs in 5.4 us at 17 x 65 536 (scripts/copy_floor.py) against 8.1 us
@@ -679,6 +777,13 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
     for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
     float s_soc[2][VEC], s_eff[2][VEC], s_deg[2][VEC], a_es[2][VEC];
     [[maybe_unused]] float s_efl[2][VEC], s_dgl[2][VEC];             // CLD_F64_MAPS: low words of efficiency / degraded capacity
+    // Non-temporal hint on the plane LOADS (the stores: StepArgs::nt): by instantiation, from alternating A/B builds on one box at 17 buildings
+    // (-DCL_LEAN_NT_LOADS=false against the default; profiles/r05_nt_loads/): four envs per lane 65 536 envs 7.52 - 7.56 us with the hint,
+    // 6.49 us WITHOUT (49 152: 6.82 / 6.40; 81 920: 11.0 / 10.1) -- the round-2 measurement that introduced the hint (7.32 -> 7.18 us) predates
+    // the eight-tensor action ring and the full-year tables; two envs per lane 24 576 / 32 768 envs 4.49 - 4.54 / 4.78 - 4.91 us with, 4.74 - 4.76 /
+    // 4.99 - 5.02 without; one env per lane 8 192 / 16 384 envs 3.45 / 4.00 with, 3.34 / 3.78 without; the KPI epilogue's instantiation (four
+    // envs per lane) 12.54 us with, 14.78 without.  (With plain STORES the loads' hint is immaterial: 7.29 / 7.31 us.)
+    constexpr bool NTL = NT && CL_LEAN_NT_LOADS && (KPI || OBS || VEC == 2);
     CL_TRACE_DECL;
     CL_TRACE_ENTRY(0);
     CL_TRACE_CYCLES_ENTRY(4);
@@ -687,14 +792,14 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
         for (int m = 0; m < 2; ++m) {
             if (!own[m]) continue;
             const long long off = (long long)bb[m] * a.ld + env0;          // every building has its state rows: no flag test
-            pload<VEC, NT>(s_soc[m], a.state + CLS_B_SOC * plane + off);
-            pload<VEC, NT>(s_eff[m], a.state + CLS_B_EFF * plane + off);
-            pload<VEC, NT>(s_deg[m], a.state + CLS_B_DEGCAP * plane + off);
+            pload<VEC, NTL>(s_soc[m], a.state + CLS_B_SOC * plane + off);
+            pload<VEC, NTL>(s_eff[m], a.state + CLS_B_EFF * plane + off);
+            pload<VEC, NTL>(s_deg[m], a.state + CLS_B_DEGCAP * plane + off);
             if constexpr (F64) {
-                pload<VEC, NT>(s_efl[m], a.state + CLS_B_EFF_LO * plane + off);
-                pload<VEC, NT>(s_dgl[m], a.state + CLS_B_DEGCAP_LO * plane + off);
+                pload<VEC, NTL>(s_efl[m], a.state + CLS_B_EFF_LO * plane + off);
+                pload<VEC, NTL>(s_dgl[m], a.state + CLS_B_DEGCAP_LO * plane + off);
             }
-            if (act_by_bldg) pload<VEC, NT>(a_es[m], a.actions + (long long)bb[m] * a.act_stride_col + env0);
+            if (act_by_bldg) pload<VEC, NTL>(a_es[m], a.actions + (long long)bb[m] * a.act_stride_col + env0);
         }
     }
 #pragma unroll
@@ -2022,6 +2127,22 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
 #undef CL_LEAN_CASE
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
+    } else if (a.n_chunks > 1 && tun.finish != 2 && (vec == 1 || vec == 4) && !(tun.lean_variant & 16)) {
+        // building-chunked battery + PV districts: the latency-ordered chunk kernel (lean_variant & 16 keeps cl_step_kernel: tests, A/B)
+        a.fused_finish = can_defer ? 2 : 0;
+        const size_t lds_c = lds;
+        name_add(tun, "cl_step_lean_chunk_kernel<%d, %s, %s>", vec, a.nt ? "true" : "false", can_defer ? "true" : "false");
+#define CL_LC(V, N, F) do { \
+            if (lds_c > 64 * 1024) { \
+                if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cl_step_lean_chunk_kernel<V, N, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c); e != hipSuccess) \
+                    return hip_fail(e, "hipFuncSetAttribute(cl_step_lean_chunk_kernel)"); \
+            } \
+            hipLaunchKernelGGL((cl_step_lean_chunk_kernel<V, N, F>), grid, block, lds_c, s, a); } while (0)
+#define CL_LC_NF(V) do { if (a.nt) { if (can_defer) CL_LC(V, true, true); else CL_LC(V, true, false); } \
+                         else { if (can_defer) CL_LC(V, false, true); else CL_LC(V, false, false); } } while (0)
+        if (vec == 1) CL_LC_NF(1); else CL_LC_NF(4);
+#undef CL_LC_NF
+#undef CL_LC
     } else if (a.n_chunks > 1 && (tun.finish == 2 || can_defer) && (vec == 1 || vec == 4)) {
         // building-chunked battery + PV districts (C4 with the 2022 device set): the instantiations that fold the chunk sums themselves
         // (finish = 2: their own, inside the launch; finish = 3: the previous step's, deferred)

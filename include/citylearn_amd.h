@@ -330,7 +330,8 @@ typedef struct cl_tuning {
     int32_t nw;             /* waves per workgroup (= building lanes) */
     int32_t no_chunks;      /* 1: never cut the building axis into gridDim.y chunks */
     int32_t lean_variant;   /* lean districts, bit mask: 1 = general kernel, 2 = latency-ordered lean kernel at any grid size, 4 = through the thermal
-                               kernel (experiments), 8 = the env-major kernel's general 20-building instantiation where the 17-building one would run (A/B) */
+                               kernel (experiments), 8 = the env-major kernel's general 20-building instantiation where the 17-building one would run (A/B),
+                               16 = building-chunked launches through cl_step_kernel instead of cl_step_lean_chunk_kernel (tests, A/B) */
     int32_t envmajor;       /* env-major kernels (one lane = one env x all buildings): 0 = by batch size, 1 = always, 2 = never */
     int32_t flex_vec;       /* envs per lane of the flexible-load kernel: 1, 2 or 4 */
     int32_t obs_variant;    /* observation epilogue: 1 row-wise, 2 LDS-tile, 3 wave-independent, 4 plane-transpose kernel (all columns env-dependent),

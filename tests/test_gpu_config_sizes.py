@@ -184,7 +184,7 @@ def test_c4_whole_config_1024_buildings_x_8192_envs(fixture):
     if fixture == 'g2020_cz1':
         assert eng.last_kernels == 'cl_step_full_kernel<2, false, 1024, 4, true, true>', eng.last_kernels      # folds its predecessor's sums: no second launch
     else:
-        assert eng.last_kernels == 'cl_step_kernel<4, false, false, false, 0, false>+cl_finish_kernel', eng.last_kernels
+        assert eng.last_kernels == 'cl_step_lean_chunk_kernel<4, false, false>+cl_finish_kernel', eng.last_kernels
 
 
 @pytest.mark.parametrize('kind', REWARDS)
@@ -279,6 +279,33 @@ def test_deferred_finish_with_larger_chunks(fixture, b_chunk, E):
     assert dfr._pending_t is None and torch.equal(dfr._out_env, ref._out_env) and torch.equal(dfr.state, ref.state)
 
 
+@pytest.mark.parametrize('E,kind,finish', [(1024, 'RewardFunction', 3), (1024, 'MARL', 0), (1280, 'SolarPenaltyReward', 0), (256, 'RewardFunction', 0),
+                                            (8192, 'RewardFunction', 3)])
+def test_lean_chunk_kernel_equals_the_general_kernel(E, kind, finish):
+    """`cl_step_lean_chunk_kernel` (round 5): the building-chunked battery + PV launch with the next building's plane loads issued ahead of
+    the current one's stores -- same arithmetic and summation order as `cl_step_kernel<VEC, false, false>` (`lean_variant = 16`), so every
+    plane and every district sum bit for bit: four envs per lane (1024 / 1280 envs: ragged last tile; 8192: the whole config), one env per
+    lane (256 envs), the deferred fold, MARL's chunk-partial reward."""
+    spec, tab = _c4_district('g2022_all')
+    K = 4
+    new = StepEngine(tab, E, reward=kind, tuning=dict(finish=finish))
+    old = StepEngine(tab, E, reward=kind, tuning=dict(finish=finish, lean_variant=16))
+    new.trace_kernels(); old.trace_kernels()
+    low, high = spec.action_limits()
+    rng = np.random.RandomState(E)
+    acts = torch.from_numpy(rng.uniform(low[:, None], high[:, None], size=(K, len(low), E)).astype(np.float32)).cuda()
+    for t in range(K):
+        new.step(acts[t], t); old.step(acts[t], t)
+        assert new.last_kernels.startswith('cl_step_lean_chunk_kernel<') and 'lean_chunk' not in old.last_kernels, (new.last_kernels, old.last_kernels)
+        assert torch.equal(new.state, old.state)
+        assert torch.equal(new.out_bldg[:abi.CLO_RESERVED], old.out_bldg[:abi.CLO_RESERVED])
+        assert torch.equal(new.out_env, old.out_env), (t, (new.out_env - old.out_env).abs().max().item())
+    vec = 4 if E >= 512 else 1
+    deferred = finish == 3 and kind != 'MARL' and E <= 1280
+    assert new.last_kernels.split('+')[0] == f'cl_step_lean_chunk_kernel<{vec}, true, {"true" if deferred else "false"}>' or E == 8192, new.last_kernels
+    assert float(new.out_env.abs().sum()) > 0
+
+
 def test_deferred_finish_through_step_observe():
     """`StepEngine.step_observe`'s one-call path (`cl_step_observe_f32`) runs the same step launch as `step` -- on a chunked
     district under `finish = 3` it defers the district sums too, so a later read of `out_env` must fold them (it used to return the
@@ -310,7 +337,7 @@ def test_deferred_finish_through_step_observe():
         ref.step(act, t)
         want = wa.write(t + 1).clone()
         got = dfr.step_observe(act, wb, t)
-        assert 'cl_finish_kernel' not in dfr.last_kernels and ', 0, true>' in dfr.last_kernels, dfr.last_kernels      # the FOLD instantiation, deferred
+        assert 'cl_finish_kernel' not in dfr.last_kernels and dfr.last_kernels.endswith(', true>'), dfr.last_kernels      # the FOLD instantiation, deferred
         assert dfr._pending_t == t
         assert torch.equal(got, want) and torch.equal(dfr.state, ref.state), t
         if t % 2 == 0:                                                  # (odd steps are folded by the next launch instead)
