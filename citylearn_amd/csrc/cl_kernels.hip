@@ -783,7 +783,9 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
     // the eight-tensor action ring and the full-year tables; two envs per lane 24 576 / 32 768 envs 4.49 - 4.54 / 4.78 - 4.91 us with, 4.74 - 4.76 /
     // 4.99 - 5.02 without; one env per lane 8 192 / 16 384 envs 3.45 / 4.00 with, 3.34 / 3.78 without; the KPI epilogue's instantiation (four
     // envs per lane) 12.54 us with, 14.78 without.  (With plain STORES the loads' hint is immaterial: 7.29 / 7.31 us.)
-    constexpr bool NTL = NT && CL_LEAN_NT_LOADS && (KPI || OBS || VEC == 2);
+    // The flexible-load instantiation (EV districts, behind cl_flex_kernel) keeps it too: 16.2 / 19.7 us per step with, 17.4 / 22.8 without
+    // (scripts/ev_step_bench.py, MARL / EV reward, profiles/r05z_ev_step_bench.log against r05w_ev_step_bench.log).
+    constexpr bool NTL = NT && CL_LEAN_NT_LOADS && (KPI || OBS || FLEX || VEC == 2);
     CL_TRACE_DECL;
     CL_TRACE_ENTRY(0);
     CL_TRACE_CYCLES_ENTRY(4);
