@@ -1930,18 +1930,21 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (!tp_kernel || tp_nw > 16)
             return fail(CL_EINVAL, "full_variant = 5: %d tiles x %d envs per lane x %d waves is not a launch of cl_step_full_tp_kernel for this district", tp_tiles, tp_vec, tp_nw);
     } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && (tp_small || tp_tiles * dims->n_bldg >= 12) && tp_grid > 192 && tp_grid <= 256;
-    // (up to 352 workgroups: between 65 536 and 90 112 envs the latency-ordered kernel still beats the general and the env-major one,
-    //  17 x 81 920: 11.4 vs 12.7 / 12.9 us, scripts/lean_gap_sizes.py; from 106 496 envs the env-major kernel wins, 17 x 114 688: 13.5 vs 14.7 us)
+    // (up to 480 workgroups -- two 9-wave workgroups per CU are resident at once, so up to 512 the launch is still ONE generation: re-measured
+    //  at the end of round 5, after the latency-ordered kernel lost the non-temporal hint on its loads (scripts/gpurun/r05_call24.sh,
+    //  profiles/r05_nt_loads/r05y.log), 17 buildings x 98 304 / 106 496 / 114 688 / 131 072 / 163 840 / 196 608 / 262 144 envs: 10.6 / 11.0 /
+    //  11.8 / 15.5 / 19.2 / 22.6 / 31.7 us against 13.2 / 13.2 / 13.5 / 15.6 / 19.2 / 21.3 / 26.2 us for the env-major kernel -- the old rule
+    //  (352 workgroups, env-major from 106 496 envs) had the general kernel at 98 304 envs, 13.0 us)
     // streaming KPIs without the detail planes: the lean kernel updates the per-building accumulators itself, at any grid size
     const bool kpi_lean = (dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL) && !kpi_full;
-    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 352 || (tun.lean_variant & 2) || kpi_lean) && !((tun.lean_variant & 1) && !kpi_lean);
+    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 480 || (tun.lean_variant & 2) || kpi_lean) && !((tun.lean_variant & 1) && !kpi_lean);
     // without the detail planes only cl_step_lean_kpi_kernel updates the per-building accumulators (and writes the baseline plane
     // cl_kpi_env_kernel sums): a launch shape that cannot take it must not silently leave them stale
     if (kpi_lean && (full || flex || !lean_shape))
         return fail(CL_EINVAL, "CLD_KPI without CLD_WRITE_DETAIL needs a step launch that updates the accumulators itself (battery + PV: n_bldg=%d <= 2 x nw=%d "
                                "waves, no chunks; thermal: one env per lane, no chunks, no flexible loads, no CLD_F64_MAPS): drop the cl_tuning override or set CLD_WRITE_DETAIL",
                     dims->n_bldg, a.nw);
-    const bool envmajor_shape = !full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env >= 106496));
+    const bool envmajor_shape = !full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env > 122880));
     if (chain) {
         if (envmajor_shape) {
             const dim3 egrid((unsigned)((dims->n_env + 255) / 256));

@@ -105,7 +105,7 @@ def test_lean_kernel_variants_are_bit_identical(kind, vec):
 
 @pytest.mark.parametrize('kind', REWARDS)
 def test_env_major_lean_kernel(kind):
-    """The env-major lean kernel (one wave = 64 envs x every building; used from 106 496 envs up) against the reference
+    """The env-major lean kernel (one wave = 64 envs x every building; used above 122 880 envs) against the reference
     (teacher-forced) and against the building-major kernel: identical per-building planes for the per-building rewards,
     district sums equal up to the summation order (env-major adds in building order, like the reference)."""
     worst, eng = _run('g2022_all', kind, 0, detail=False, teach=True, steps=240, tuning=dict(envmajor=1))
