@@ -785,7 +785,8 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
     // envs per lane) 12.54 us with, 14.78 without.  (With plain STORES the loads' hint is immaterial: 7.29 / 7.31 us.)
     // The flexible-load instantiation (EV districts, behind cl_flex_kernel) keeps it too: 16.2 / 19.7 us per step with, 17.4 / 22.8 without
     // (scripts/ev_step_bench.py, MARL / EV reward, profiles/r05z_ev_step_bench.log against r05w_ev_step_bench.log).
-    constexpr bool NTL = NT && CL_LEAN_NT_LOADS && (KPI || OBS || FLEX || VEC == 2);
+    // The observation epilogue's (cl_step_observe_f32, 65 536 envs): 9.30 - 9.35 us with, 8.84 - 8.85 without (scripts/step_observe_bench.py).
+    constexpr bool NTL = NT && CL_LEAN_NT_LOADS && (KPI || FLEX || VEC == 2);
     CL_TRACE_DECL;
     CL_TRACE_ENTRY(0);
     CL_TRACE_CYCLES_ENTRY(4);
