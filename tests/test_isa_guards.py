@@ -153,6 +153,10 @@ def test_scratch_memory_is_confined_to_the_known_instantiations(units):
     for pat in (r'cl_step_full_kernelILi2ELb0ELi1024ELi4ELb1ELb[01]EE', r'cl_step_full_kernelILi1ELb0ELi1024ELi5ELb1ELb[01]EE'):
         hits = [k for k in main_meta if re.search(pat, k)]
         assert len(hits) == 2 and all(main_meta[k]['private_seg_size'] == 0 for k in hits), (pat, [(k, main_meta[k]) for k in hits])
+    # the latency-ordered chunk kernel of battery + PV districts (round 5): the next building's inputs reuse the registers the arithmetic
+    # released -- a second input set or LDS-staged blocks cost 36 - 44 bytes of scratch at four envs per lane
+    hits = [k for k in main_meta if 'cl_step_lean_chunk_kernelILi4E' in k]
+    assert len(hits) == 4 and all(main_meta[k]['private_seg_size'] == 0 and main_meta[k]['num_vgpr'] <= 128 for k in hits), [(k, main_meta[k]) for k in hits]
     for kernels, meta in units:
         for k, m in meta.items():
             if not m.get('private_seg_size'):
