@@ -118,6 +118,26 @@ def test_config_sizes_with_distinct_actions_against_the_c_oracle(name, E, steps,
     assert max(worst.values()) < 1.0, (name, E, kind, worst)
 
 
+@pytest.mark.parametrize('E,expect', [(16384, 'cl_step_lean_kernel<1, '), (32768, 'cl_step_lean_kernel<2, '), (65536, 'cl_step_lean_kernel<4, '),
+                                       (98304, 'cl_step_lean_kernel<4, '), (122880, 'cl_step_lean_kernel<4, '), (122884, 'cl_step_envmajor_kernel<17, '),
+                                       (262144, 'cl_step_envmajor_kernel<17, ')])
+def test_kernel_selection_by_batch_size(E, expect):
+    """Which kernel steps the 17-building battery + PV district at which batch size (csrc/cl_kernels.hip step_impl; re-measured at the end of
+    round 5, profiles/r05_nt_loads/r05y.log): the latency-ordered kernel at one / two / four envs per lane while the launch is one wave
+    generation (up to 480 workgroups = 122 880 envs), the env-major kernel beyond -- and the two agree on every per-building plane."""
+    tab = golden('g2022_all').spec().episode_tables(0)
+    eng = StepEngine(tab, E)
+    eng.trace_kernels()
+    ref = StepEngine(tab, E, tuning=dict(lean_variant=1, envmajor=2))          # the general kernel
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    for t in range(3):
+        a = torch.rand((eng.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        eng.step(a, t); ref.step(a, t)
+    assert eng.last_kernels.startswith(expect), eng.last_kernels
+    assert torch.equal(eng.state, ref.state) and torch.equal(eng.out_bldg[:2], ref.out_bldg[:2])
+    torch.testing.assert_close(eng.out_env, ref.out_env, rtol=2e-6, atol=2e-5)
+
+
 @lru_cache(maxsize=None)
 def _c4_district(fixture: str):
     from citylearn_amd.synthetic import tile_district
