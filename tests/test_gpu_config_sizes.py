@@ -326,6 +326,30 @@ def test_lean_chunk_kernel_equals_the_general_kernel(E, kind, finish):
     assert float(new.out_env.abs().sum()) > 0
 
 
+def test_lean_chunk_kernel_with_a_sparse_action_map():
+    """... and where the battery action column of building b is NOT b (two of 64 buildings without an active battery action: the flag
+    CLD_ES_COL_IS_BLDG is off, the kernel loads the action once the parameter block is there) -- same bits as the general kernel."""
+    from dataclasses import replace
+    from citylearn_amd.synthetic import tile_district
+    spec = tile_district(golden('g2022_all').spec(), 64)
+    blds = list(spec.buildings)
+    for i in (3, 10):
+        blds[i].action_metadata = {**blds[i].action_metadata, 'electrical_storage': False}
+    spec = replace(spec, buildings=blds)
+    tab = spec.episode_tables(0)
+    E = 8192
+    new, old = StepEngine(tab, E), StepEngine(tab, E, tuning=dict(lean_variant=16))
+    assert new.n_act_cols == 62 and not (new.dims.flags & abi.CLD_ES_COL_IS_BLDG)
+    new.trace_kernels()
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    for t in range(4):
+        a = torch.rand((new.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
+        new.step(a, t); old.step(a, t)
+        assert torch.equal(new.state, old.state) and torch.equal(new.out_bldg[:2], old.out_bldg[:2]) and torch.equal(new.out_env, old.out_env), t
+    assert new.last_kernels.startswith('cl_step_lean_chunk_kernel<4, '), new.last_kernels
+    assert float(new.state[abi.CLS_B_SOC, 3].abs().max()) == 0.0 and float(new.state[abi.CLS_B_SOC, 4].abs().max()) > 0.0      # the idle battery stays empty
+
+
 def test_deferred_finish_through_step_observe():
     """`StepEngine.step_observe`'s one-call path (`cl_step_observe_f32`) runs the same step launch as `step` -- on a chunked
     district under `finish = 3` it defers the district sums too, so a later read of `out_env` must fold them (it used to return the
