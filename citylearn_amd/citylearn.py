@@ -147,7 +147,7 @@ class CityLearnEnv(_GymEnv):
 
     def __init__(self, schema: Union[str, Path, Mapping[str, Any]], device: str = 'cuda:0',
                  observation_mode: str = 'reference', reference_quirks: bool = True, ev_seed: int = None,
-                 ev_soc_drift=None, f64_maps=None, **kwargs: Any):
+                 ev_soc_drift=None, f64_maps=None, check_invariants: bool = None, **kwargs: Any):
         """`schema` and `**kwargs` exactly as the reference constructor (citylearn.py:133-205).  Extra arguments:
         `device`; `observation_mode`: ``'reference'`` returns the reference's observation semantics (values of step
         t+1 read before they are computed -- SoC / net read 0), ``'current'`` returns the SoC / net
@@ -159,7 +159,11 @@ class CityLearnEnv(_GymEnv):
         a free-running episode stays inside 1e-4 of the reference's on every dataset family; ~2 % of a step) wherever the district admits it --
         this class is the drop-in for the reference's own env, results first -- and the fp32 map for districts with EV chargers / washing
         machines.  ``True`` (`CLD_F64_MAPS`): the reference's own mixed float64 / float32 precision -- the battery SoC series is then the
-        reference's, bit for bit, at about three times the step time.  ``False``: the fp32 map (`VectorCityLearnEnv`'s default)."""
+        reference's, bit for bit, at about three times the step time.  ``False``: the all-fp32 map (a throughput mode: drifts past 1e-4 free-running).
+        `check_invariants` (default: `reference_quirks`, districts of up to 32 buildings): `step` raises the reference's ``AssertionError``
+        where the reference's own runtime assertions fire -- negative downward flexibility during an outage (building.py:665), negative
+        device consumption (building.py:1831-1835), negative electricity consumption booked (energy_model.py:146-148) -- evaluated on the
+        device (`CLD_CHECK`: a violation word per unit), next to the demand-limit assertion (building.py:1825-1829; a host table)."""
         if observation_mode not in ('reference', 'current'):
             raise ValueError("observation_mode must be 'reference' or 'current'")
         self.district_spec: DistrictSpec = load_district(schema, **kwargs)
@@ -170,6 +174,7 @@ class CityLearnEnv(_GymEnv):
         self.device = device
         self.observation_mode = observation_mode
         self.reference_quirks = reference_quirks
+        self.check_invariants = reference_quirks if check_invariants is None else bool(check_invariants)
         self.central_agent = self.district_spec.central_agent
         self.shared_observations = list(self.district_spec.shared_observations)
         self.random_seed = self.district_spec.random_seed
@@ -359,7 +364,8 @@ class CityLearnEnv(_GymEnv):
                                   t0_quirk=self.reference_quirks, detail=True, charger_detail=True, central_agent=self.central_agent,
                                   ev_reward_weights=getattr(self.reward_function, 'weights', None), ev_drift=self._ev_drift,
                                   ev_penalty_coefficient=getattr(self.reward_function, 'charging_constraint_penalty_coefficient', 1.0),
-                                  ev_seed=(self.random_seed if self._ev_seed is None else self._ev_seed) + self._episode, f64_maps=self.f64_maps)
+                                  ev_seed=(self.random_seed if self._ev_seed is None else self._ev_seed) + self._episode, f64_maps=self.f64_maps,
+                                  check=self.check_invariants and self._tables.params.shape[0] <= 32)
         self._prev_ev_soc = None
         # adjacent LSTM indoor-temperature stage (LSTMDynamicsBuilding, building.py:3000-3078) with the fused ComfortReward
         self._stage = None
@@ -377,6 +383,44 @@ class CityLearnEnv(_GymEnv):
                                                        'c_b', 'cool_dem', 'heat_dem', 'dhw_dem', 'solar')}
         self._obs_tables = self._layout.episode(self._tables)
         return self.observations, self.get_info()
+
+    # ---- checkpoint / restore --------------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """A checkpoint of the running episode (`torch.save`-able): the device state (`StepEngine.state_dict`, the LSTM stage's), and the
+        host-side history `evaluate()` and the observation / reward properties read -- what pickling the reference's env carries
+        (citylearn/__main__.py:291-299), without the tables (rebuilt from the schema)."""
+        import copy
+        return {'format': 1, 'episode': self._episode, 'random_seed': self.random_seed, 't': int(self._t),
+                'engine': self._engine.state_dict(), 'stage': None if self._stage is None else self._stage.state_dict(),
+                'hist': {k: [np.array(x, copy=True) for x in v] for k, v in self._hist.items()},
+                'rewards': copy.deepcopy(self.__rewards), 'episode_rewards': copy.deepcopy(self.__episode_rewards),
+                'last': {k: None if getattr(self, '_last_' + k, None) is None else np.array(getattr(self, '_last_' + k), copy=True) for k in ('state', 'out', 'temps')},
+                'prev_ev_soc': None if self._prev_ev_soc is None else np.array(self._prev_ev_soc, copy=True)}
+
+    def load_state_dict(self, sd: Mapping[str, Any]) -> None:
+        """Restore :meth:`state_dict` into an env constructed on the same schema with the same arguments: the saved episode is rebuilt
+        (tables, outage draws) if this env stands in another one, then every carried tensor and history is put back.  The next `step`
+        returns what the checkpointed env would have returned, bit for bit."""
+        import copy
+        if sd.get('format') != 1:
+            raise ValueError(f"checkpoint format {sd.get('format')!r}, this build reads 1")
+        if self._episode != sd['episode'] or self.random_seed != sd['random_seed']:
+            self._episode = int(sd['episode']) - 1
+            self.reset(seed=sd['random_seed'])
+        self._engine.load_state_dict(sd['engine'])
+        if (self._stage is None) != (sd['stage'] is None):
+            raise ValueError('checkpoint and env disagree about the LSTM temperature stage')
+        if self._stage is not None:
+            self._stage.load_state_dict(sd['stage'])
+        self._hist = {k: [np.array(x, copy=True) for x in v] for k, v in sd['hist'].items()}
+        self.__rewards = copy.deepcopy(sd['rewards'])
+        self.__episode_rewards = copy.deepcopy(sd['episode_rewards'])
+        for k, v in sd['last'].items():
+            if v is not None:
+                setattr(self, '_last_' + k, np.array(v, copy=True))
+        self._prev_ev_soc = None if sd['prev_ev_soc'] is None else np.array(sd['prev_ev_soc'], copy=True)
+        self._t = int(sd['t'])
+        self._engine.t = self._t
 
     def _parse_actions(self, actions: Sequence[Sequence[float]]) -> np.ndarray:
         """List-of-lists -> flat action-column vector, with the reference's count checks (citylearn.py:1063-1134)."""
@@ -448,6 +492,23 @@ class CityLearnEnv(_GymEnv):
                 raise AssertionError(f'demand is greater than {end_use}_device max output | timestep: {t}, building: {b.name}, outage: False, '
                                      f'demand: {demand},output: {max_out}, difference: {demand - max_out}, check: False,')
 
+    def _invariant_check(self, t: int, ob: np.ndarray):
+        """Raise what the reference raises from inside `apply_actions`: the device evaluated the three assertions with the
+        reference's tolerance and left `abi.CLV_*` bits per building (`CLD_CHECK`); the first building in district order raises, like the
+        reference's loop over buildings (citylearn.py:1005-1008)."""
+        words = np.ascontiguousarray(ob[abi.CLO_RESERVED]).view(np.uint32)
+        for i, b in enumerate(self.district_spec.buildings):
+            w = int(words[i])
+            if not w:
+                continue
+            if w & abi.CLV_FLEXIBILITY:
+                raise AssertionError(f'downward_electrical_flexibility must be >= 0.0!time step:, {t}, outage:, True, building: {b.name}')
+            for bit, end_use in ((abi.CLV_COOLING, 'cooling'), (abi.CLV_HEATING, 'heating'), (abi.CLV_DHW, 'dhw')):
+                if w & bit:
+                    raise AssertionError(f'negative electricity consumption for {end_use} demand | timestep: {t}, building: {b.name}')
+            if w & abi.CLV_NSL:
+                raise AssertionError(f'electricity_consumption must be >= 0 but value: {float(self._tables.ts[t, i, abi.CLT_NSL])} was provided.')
+
     def step(self, actions: Sequence[Sequence[float]]):
         torch = self._torch
         eng = self._engine
@@ -465,6 +526,8 @@ class CityLearnEnv(_GymEnv):
         self._last_state, self._last_out = st, ob
         if self.reference_quirks:
             self._demand_limit_check(t)
+        if eng.check:
+            self._invariant_check(t, ob)
         h = self._hist
         h['net'].append(ob[abi.CLO_NET]); h['base_net'].append(ob[abi.CLO_BASE_NET]); h['soc'].append(st[abi.CLS_B_SOC])
         h['net_ws'].append(ob[abi.CLO_NET_WS])

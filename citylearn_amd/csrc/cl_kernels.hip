@@ -18,6 +18,7 @@
 #include "cl_philox.h"
 
 #include <type_traits>
+#include <mutex>
 #include <stdarg.h>
 #include <string.h>
 #include <stdio.h>
@@ -36,6 +37,26 @@ int fail(int code, const char* fmt, ...) {
 
 int hip_fail(hipError_t e, const char* what) {
     return fail(CL_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+// Opt a kernel into more than the default 64 KB of dynamic LDS, ONCE per (kernel, device, size): hipFuncSetAttribute is a driver call, and
+// the launches that need it (building-chunked 1024-building districts) sit on the per-step path (round-5 advisor finding).  The table only
+// remembers what the driver has already been told -- idempotent, so it is not state a caller could observe.
+hipError_t ensure_dynamic_lds(const void* fn, size_t bytes) {
+    struct Seen { const void* fn; int dev; size_t bytes; };
+    static Seen seen[64];
+    static int n_seen = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].fn == fn && seen[i].dev == dev && seen[i].bytes >= bytes) return hipSuccess;
+    if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); e != hipSuccess) return e;
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].fn == fn && seen[i].dev == dev) { seen[i].bytes = bytes; return hipSuccess; }
+    if (n_seen < 64) seen[n_seen++] = {fn, dev, bytes};
+    return hipSuccess;
 }
 
 struct StepArgs {
@@ -312,7 +333,10 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
             }
             return;
         }
-        unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (long long)a.n_chunks * NQ * a.n_env) + bx;
+        // (the tickets sit at a FIXED place -- the (n_env + 63) / 64 words in front of the marker words at the plane's tail -- whatever the chunk
+        //  count: behind the partial-sum rows, where they were until round 5, a chunked cl_rollout_f32 with another chunk geometry wrote its
+        //  return rows over them, and a later in-launch fold found non-zero tickets and never folded: round-5 advisor finding)
+        unsigned* ticket = reinterpret_cast<unsigned*>(a.out_bldg + (long long)(CLO_RESERVED + 1) * plane) - 4 - (a.n_env + 63) / 64 + bx;
         // this thread's partial sums have left the CU: outside tgsplit mode a workgroup-scope release fence does NOT wait for outstanding
         // vector stores (it only orders LDS), so the wait is spelled out -- s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0) -- in front of it
         // (round-3 advisor finding: the ticket could otherwise become visible before the write-through partial sums are acknowledged)
@@ -456,7 +480,8 @@ CL_DEV void district_reduce(const StepArgs& a, float* lds, int w, int lane, int 
 // FLEX: the district has EV chargers / washing machines (cl_flex.h ran just before); a separate instantiation so that
 // districts without them keep their register budget.
 // PREC: the battery map -- 0 fp32, 1 CLD_F64_MAPS (two more state planes), 2 CLD_F64_CHAIN (cl_unit.h)
-template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, int PREC = 0, bool FOLD = false>
+// CHECK (CLD_CHECK): the reference's runtime assertions as CLV_* bits, one word per unit, into the reserved plane (never a chunked launch)
+template <int VEC, bool FULL, bool DETAIL, bool FLEX = false, int PREC = 0, bool FOLD = false, bool CHECK = false>
 __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
     constexpr bool F64 = PREC == 1;
     constexpr bool SWAP = FOLD && CL_SWAP_GRID;            // (the FOLD instantiations are always launched building-chunked: grid = (chunks, env tiles))
@@ -533,6 +558,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 if (!fold_issued) { fold_prev = fold_prefetch<TILE>(a, w, lane, plane, bx, by); fold_issued = true; }
             }
             float o_net[VEC], o_rw[VEC], o_eb[VEC], o_cd[VEC], o_hd[VEC], o_dd[VEC], o_cc[VEC], o_ch[VEC], o_cw[VEC], o_cn[VEC], o_bn[VEC], o_ex[VEC], o_sv[VEC], o_ws[VEC], o_sc[VEC], o_sh[VEC], o_sd[VEC];
+            [[maybe_unused]] float o_viol[VEC];
             // chargers / washing machines of this building, advanced by cl_flex_kernel just before this launch
             const int fbi = (FLEX && (B.flags & CLF_FLEX)) ? (int)B.p[CLP_FLEX_INDEX] : -1;
             float x_load[VEC], x_chg[VEC];
@@ -560,7 +586,8 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                     act = {a_cs[i], a_hs[i], a_ds[i], a_es[i], a_cd[i], a_hd[i]};
                 }
                 cl::Out O;
-                cl::unit_step<FULL, PREC>(B, R, a.t, quirk, act, S, O);
+                cl::unit_step<FULL, PREC, CHECK>(B, R, a.t, quirk, act, S, O);
+                if constexpr (CHECK) o_viol[i] = __uint_as_float(O.viol);
                 if (FLEX && fbi >= 0) cl::apply_flex(R.outage, R.price, R.carbon, x_load[i], x_chg[i], O);
                 const float rw = cl::unit_reward<FULL>(rkind, B, S, O.net);
                 s_soc[i] = S.soc; s_eff[i] = S.eff; s_deg[i] = S.degcap; s_cs[i] = S.cs; s_hs[i] = S.hs; s_ds[i] = S.ds;
@@ -597,6 +624,7 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
                 }
                 pstore<VEC, NT>(a.out_bldg + CLO_NET * plane + off, o_net);
                 if (rkind != CLR_MARL && !(FLEX && rkind == CLR_EV)) pstore<VEC, NT>(a.out_bldg + CLO_REWARD * plane + off, o_rw);
+                if constexpr (CHECK) pstore<VEC, NT>(a.out_bldg + CLO_RESERVED * plane + off, o_viol);
                 if constexpr (FULL && DETAIL) {
                     // what another kernel of the path reads: the KPI pass (baseline, expected, served) and the LSTM stage (delivered demands)
                     pstore<VEC, NT>(a.out_bldg + CLO_COOL_DEM * plane + off, o_cd);
@@ -1866,7 +1894,8 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         else a.nw = (tun.b_chunk > 0 && tun.nw > 0) ? tun.nw : 16;
         // the reserved plane holds the chunk partial sums (twice under the deferred finish), the tickets of the in-launch fold and, in its
         // last 16 bytes, the marker words EVERY chunked launch touches (a non-deferring one clears its step's marker)
-        const long long scratch_words = (long long)a.n_chunks * NQ * dims->n_env * (tun.finish == 3 ? 2 : 1) + grid_x + 4;
+        // (the second buffer only where the launch can defer at all: finish = 3 on a launch that keeps the second cl_finish launch needs one)
+        const long long scratch_words = (long long)a.n_chunks * NQ * dims->n_env + (dims->n_env + 63) / 64 + 4;
         if (scratch_words > (long long)dims->n_bldg * dims->n_env)
             return fail(CL_EINVAL, "b_chunk=%d leaves no room for the %d chunk partial sums, their tickets and the marker words", a.b_chunk, a.n_chunks);
     }
@@ -1884,7 +1913,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     const bool can_defer = a.n_chunks > 1 && tun.finish == 3 && rkind_host != CLR_MARL && rkind_host != CLR_EV && !flex &&
                            !(dims->flags & (CLD_KPI | CLD_F64_MAPS | CLD_F64_CHAIN | CLD_WRITE_DETAIL)) && fold_per_row <= (full ? 64 : 16) && a.n_chunks * fold_w <= 1024 &&
                            a.nw == 16 && a.n_chunks <= 64 &&
-                           (2ll * a.n_chunks * NQ + 1) * dims->n_env <= (long long)dims->n_bldg * dims->n_env - 4;
+                           2ll * a.n_chunks * NQ * dims->n_env + (dims->n_env + 63) / 64 + 4 <= (long long)dims->n_bldg * dims->n_env;
     const dim3 grid(grid_x, a.n_chunks);
     const bool det = dims->flags & CLD_WRITE_DETAIL;
     // streaming KPIs of thermal / outage districts (and of any district stepped with detail planes) inside the step launch:
@@ -1946,7 +1975,19 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
                                "waves, no chunks; thermal: one env per lane, no chunks, no flexible loads, no CLD_F64_MAPS): drop the cl_tuning override or set CLD_WRITE_DETAIL",
                     dims->n_bldg, a.nw);
     const bool envmajor_shape = !full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env > 122880));
-    if (chain) {
+    if (dims->flags & CLD_CHECK) {
+        // debug mode: the general kernel with the reference's assertions compiled in, one env per lane (include/citylearn_amd.h CLD_CHECK)
+        if (!det || (dims->flags & CLD_DETAIL_MIN) || a.n_chunks > 1 || kpi_full)
+            return fail(CL_EINVAL, "CLD_CHECK needs CLD_WRITE_DETAIL (all planes), a district of up to 32 buildings (the violation words use the reserved plane) "
+                                   "and, with CLD_KPI, the separate KPI launch (cl_tuning.kpi_passes = 1)");
+        const dim3 grid1((unsigned)((dims->n_env + 63) / 64));
+        const size_t lds1 = (size_t)a.nw * NQ * 64 * sizeof(float);
+        name_add(tun, "cl_step_kernel<1, true, true, %s, %d, false, true>", flex ? "true" : "false", chain ? 2 : f64 ? 1 : 0);
+        if (flex) hipLaunchKernelGGL((cl_step_kernel<1, true, true, true, 0, false, true>), grid1, block, lds1, s, a);
+        else if (chain) hipLaunchKernelGGL((cl_step_kernel<1, true, true, false, 2, false, true>), grid1, block, lds1, s, a);
+        else if (f64) hipLaunchKernelGGL((cl_step_kernel<1, true, true, false, 1, false, true>), grid1, block, lds1, s, a);
+        else hipLaunchKernelGGL((cl_step_kernel<1, true, true, false, 0, false, true>), grid1, block, lds1, s, a);
+    } else if (chain) {
         if (envmajor_shape) {
             const dim3 egrid((unsigned)((dims->n_env + 255) / 256));
             const int enb = dims->n_bldg <= 17 ? 17 : 20;
@@ -2064,7 +2105,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
                     //  kernel gets without opting in where the runtime enforces the 64 KB default)
                     const void* fn = a.nt ? reinterpret_cast<const void*>(cl_step_full_kernel<2, false, 1024, 4, true, true>)
                                           : reinterpret_cast<const void*>(cl_step_full_kernel<2, false, 1024, 4, true, false>);
-                    if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+                    if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess)
                         return hip_fail(e, "hipFuncSetAttribute(cl_step_full_kernel<2, .., LP>)");
                 }
                 if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, true);
@@ -2140,7 +2181,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         name_add(tun, "cl_step_lean_chunk_kernel<%d, %s, %s>", vec, a.nt ? "true" : "false", can_defer ? "true" : "false");
 #define CL_LC(V, N, F) do { \
             if (lds_c > 64 * 1024) { \
-                if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cl_step_lean_chunk_kernel<V, N, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c); e != hipSuccess) \
+                if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(cl_step_lean_chunk_kernel<V, N, F>), lds_c); e != hipSuccess) \
                     return hip_fail(e, "hipFuncSetAttribute(cl_step_lean_chunk_kernel)"); \
             } \
             hipLaunchKernelGGL((cl_step_lean_chunk_kernel<V, N, F>), grid, block, lds_c, s, a); } while (0)
@@ -2159,7 +2200,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (lds > 64 * 1024) {
             const void* fn = vec == 1 ? reinterpret_cast<const void*>(cl_step_kernel<1, false, false, false, 0, true>)
                                       : reinterpret_cast<const void*>(cl_step_kernel<4, false, false, false, 0, true>);
-            if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+            if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess)
                 return hip_fail(e, "hipFuncSetAttribute(cl_step_kernel<.., FOLD>)");
         }
         const dim3 grid_sw = CL_SWAP_GRID ? dim3(grid.y, grid.x) : grid;      // (chunks along x: district_reduce's SWAP note)
@@ -2356,7 +2397,8 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
         mb = mb_max;                      // (battery + PV: always two buildings per wave -- the one-building chunked instantiations spill)
         a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
         // the reserved plane holds n_chunks x NQ partial sums, one return row per chunk and the marker words
-        if (((long long)a.n_chunks * (NQ + 1)) * dims->n_env + 4 > (long long)dims->n_bldg * dims->n_env)
+        // (and, in front of those, the ticket words of the one-step launches' in-launch fold: they stay zero between launches)
+        if (((long long)a.n_chunks * (NQ + 1)) * dims->n_env + (dims->n_env + 63) / 64 + 4 > (long long)dims->n_bldg * dims->n_env)
             return fail(CL_EINVAL, "b_chunk=%d leaves no room for the %d chunk partial sums of the fused rollout", a.b_chunk, a.n_chunks);
     }
     a.nw = tun.nw ? tun.nw : ((chunked ? a.b_chunk : dims->n_bldg) + mb - 1) / mb;
@@ -2489,7 +2531,7 @@ int cl_lstm_generic_step_f32(const cl_dims* dims, const float* lstm_w, const flo
     const size_t lds = lds_h + (staged ? lds_w : 0);
     const void* fn = staged ? reinterpret_cast<const void*>(cl_lstm_generic_kernel<true>) : reinterpret_cast<const void*>(cl_lstm_generic_kernel<false>);
     if (lds > 64 * 1024) {
-        if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess)
+        if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess)
             return hip_fail(e, "hipFuncSetAttribute(cl_lstm_generic_kernel)");
     }
     const dim3 ggrid((dims->n_env + 63) / 64, dims->n_bldg), gblock(64 * CL_GEN_NWV);

@@ -171,15 +171,24 @@ struct State { float soc, eff, degcap, cs, hs, ds, eff_lo, deg_lo; };
 // Actions of one unit (inactive -> 0 for storages / ignored for devices, building.py:1557-1564).
 struct Act { float cs, hs, ds, es, cd, hd; };
 // Per-unit results of the step.
-struct Out { float net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served, net_ws, se_cool, se_heat, se_dhw; };
+struct Out { float net, cost, emission, eb, cool_dem, heat_dem, dhw_dem, c_cool, c_heat, c_dhw, c_ns, base_net, expected, served, net_ws, se_cool, se_heat, se_dhw;; uint32_t viol; };
+// (`viol`: CLV_* bits of the reference's runtime assertions this unit would have tripped -- written by unit_step<.., CHECK = true> only, CLD_CHECK)
 // Running electricity_consumption[t] of the five electric devices.
 struct Acc { float c_cool, c_heat, c_dhw, c_ns, c_b; };
 
-CL_DEV float flexibility(const Bp& B, const Row& R, const Acc& A) {
+// CLD_CHECK (a debug mode: one more output word per unit): the reference's own runtime assertions, evaluated where the reference evaluates
+// them, with its tolerance (data.py:18 TOLERANCE = 1e-4) -- `viol` collects CLV_* bits instead of raising, the host raises (CityLearnEnv.step)
+#define CL_TOLERANCE 1e-4f
+template <bool CHECK = false>
+CL_DEV float flexibility(const Bp& B, const Row& R, const Acc& A, [[maybe_unused]] uint32_t* viol = nullptr) {
     // building.py:640-668 (+inf unless this (t, building) is in a power outage)
     if (!R.outage) return INFINITY;
     const float used = (A.c_cool + A.c_heat + A.c_dhw + A.c_ns + A.c_b) * B.r;
-    return fmaxf(0.0f, fabsf(R.sol) - used);
+    const float capacity = fabsf(R.sol) - used;
+    if constexpr (CHECK) {
+        if (!(capacity >= 0.0f || fabsf(capacity) < CL_TOLERANCE)) *viol |= CLV_FLEXIBILITY;      // building.py:665
+    }
+    return fmaxf(0.0f, capacity);
 }
 
 // Battery.charge (energy_model.py:1027-1057) on top of update_electrical_storage (building.py:1791-1812).
@@ -422,10 +431,14 @@ CL_DEV float battery_charge_chain(const BattC& C, float a_es, float flex, State&
     eff = __builtin_fma(C.edb3, fmax(x - C.ex3, 0.0), eff);
     const double irte = rsq64(eff), rte = eff * irte;
     // StorageDevice.charge (719-768): one clamp of one fma, as in the fp32 map (0 <= e_init <= capacity)
+    // (the branch of StorageDevice.charge follows the sign of the CLAMPED energy, as in battery_energy / battery_charge_ref: a battery sitting at
+    //  its degraded capacity has `degraded - e_init` slightly negative after the degradation step, and the reference then discharges with
+    //  energy / rte although charging was requested -- round-5 advisor finding)
     e *= C.r;
-    const double e_fin = fmin(fmax(__builtin_fma(e, chg ? rte : irte, e_init), 0.0), C.cap);
+    const bool chg_e = e >= 0.0;
+    const double e_fin = fmin(fmax(__builtin_fma(e, chg_e ? rte : irte, e_init), 0.0), C.cap);
     const double d = e_fin - e_init;
-    const float eb = (float)(d * (chg ? irte : rte));                                    // energy_balance[t]: float32 series
+    const float eb = (float)(d * (chg_e ? irte : rte));                                  // energy_balance[t]: float32 series
     // degrade (1130-1141) on the pre-step degraded capacity: the increment (~1e-5 kWh) in fp32, accumulated into the loss
     const float degcap32 = C.cap32 - S.degcap;
     S.degcap = fminf(fmaf(C.degk * fabsf(eb), rcp(fmaxf(degcap32, CL_ZDP)), S.degcap), C.cap32);
@@ -450,8 +463,10 @@ CL_DEV void tank_charge(float e, float prev_soc, float cap, float capl, float rt
 }
 
 // One end use (cooling / heating / dhw): device + storage in the order given by the storage action's sign.
+template <bool CHECK = false>
 CL_DEV void end_use(const Bp& B, const Row& R, Acc& A, float& c, float demand, float a_sto, float cscale,
-                    float dev_pow, float cop, float icop, const TankP& T, float ir, float& soc, float& eb, float& e_dev) {
+                    float dev_pow, float cop, float icop, const TankP& T, float ir, float& soc, float& eb, float& e_dev,
+                    [[maybe_unused]] uint32_t* viol = nullptr, [[maybe_unused]] uint32_t polarity_bit = 0u) {
     const float prev_soc = soc;
     const float energy = a_sto * cscale;
     const bool disc = a_sto < 0.0f;                         // storage first (building.py:1611-1622)
@@ -460,12 +475,17 @@ CL_DEV void end_use(const Bp& B, const Row& R, Acc& A, float& c, float demand, f
     tank_charge(fmaxf(-demand, energy) * ir, prev_soc, T.cap, T.capl, T.rte, T.irte, T.icap, T.maxin, T.maxout, B.r, soc_a, eb_a);
     eb_a = disc ? eb_a : 0.0f;
     // device (building.py:1641-1661): `c` is this end use's accumulator inside A
-    float max_out = fminf(flexibility(B, R, A), dev_pow - c * B.r) * cop;
+    float max_out = fminf(flexibility<CHECK>(B, R, A, viol), dev_pow - c * B.r) * cop;
     const float out = fminf(demand - fmaxf(-eb_a, 0.0f), max_out);
     e_dev = out;
+    if constexpr (CHECK) {
+        // ___electricity_consumption_polarity_check (building.py:1831-1835, called at 1660 / 1708 / 1753)
+        const float consumption = out * icop;
+        if (!(consumption >= 0.0f || fabsf(consumption) < CL_TOLERANCE)) *viol |= polarity_bit;
+    }
     c += fmaxf(0.0f, out * icop);
-    // storage after the device (charging or idle lanes; building.py:1663-1687)
-    max_out = fminf(flexibility(B, R, A), dev_pow - c * B.r) * cop;
+    // storage after the device (charging or idle lanes; building.py:1663-1687; the charging branch reads the flexibility again)
+    max_out = fminf(flexibility<CHECK>(B, R, A, viol), dev_pow - c * B.r) * cop;
     const float e_c = energy > 0.0f ? fminf(max_out, energy) : fmaxf(-demand, energy);
     float soc_c, eb_c;
     tank_charge(e_c * ir, prev_soc, T.cap, T.capl, T.rte, T.irte, T.icap, T.maxin, T.maxout, B.r, soc_c, eb_c);
@@ -486,9 +506,11 @@ CL_DEV float battery_step_f64(const uint32_t* __restrict__ p, float a_es, float 
 
 // The whole unit step.  `t` and `t0_quirk` are wave-uniform.  F64: the battery map in float64 (CLD_F64_MAPS).
 // PREC: 0 = fp32 battery map, 1 = CLD_F64_MAPS (battery_charge_ref), 2 = CLD_F64_CHAIN (battery_charge_chain; S.degcap is the capacity loss)
-template <bool FULL, int PREC = 0>
+// CHECK (CLD_CHECK): O.viol = the CLV_* bits of the reference assertions the unit tripped (building.py:665, 1831-1835; energy_model.py:146-148)
+template <bool FULL, int PREC = 0, bool CHECK = false>
 CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act& a, State& S, Out& O) {
     constexpr bool F64 = PREC == 1;
+    [[maybe_unused]] uint32_t viol = 0u;
     const bool first = t0_quirk && t == 0;
     const bool has_batt = B.flags & CLF_BATTERY;
     if constexpr (!FULL) {
@@ -502,6 +524,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         // t = 0: the load is booked at reset, by the step, and again by update_variables
         const float c_ns = first ? 3.0f * R.nsl : R.nsl;
         const float c_b = first ? 2.0f * eb : eb;
+        if constexpr (CHECK) { if (!(R.nsl >= 0.0f)) viol |= CLV_NSL; O.viol = viol; }      // update_electricity_consumption (energy_model.py:146-148)
         const float net = fmaf(c_ns + c_b, B.r, R.sol);          // (explicit: the lean kernels restate this line)
         O.net = net; O.cost = mul_rn(net, R.price); O.emission = fmaxf(0.0f, net * R.carbon);
         O.eb = eb; O.cool_dem = 0.0f; O.heat_dem = 0.0f; O.dhw_dem = 0.0f; O.c_cool = 0.0f; O.c_heat = 0.0f; O.c_dhw = 0.0f; O.c_ns = c_ns * B.r;
@@ -533,9 +556,9 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         const bool es_first = a.es < 0.0f;                         // building.py:1606-1609
         if (has_batt && R.outage) {                                // the order only matters through `flexibility`
             if (es_first) {
-                if constexpr (F64) eb_b = battery_step_f64(B.p, a.es, flexibility(B, R, A), t == 0, S);
-                else if constexpr (PREC == 2) { BattC bc; load_battc(bc, B.p); eb_b = battery_charge_chain(bc, a.es, flexibility(B, R, A), S); }
-                else { BattP bp; load_batt(bp, B.p); eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); }
+                if constexpr (F64) eb_b = battery_step_f64(B.p, a.es, flexibility<CHECK>(B, R, A, &viol), t == 0, S);
+                else if constexpr (PREC == 2) { BattC bc; load_battc(bc, B.p); eb_b = battery_charge_chain(bc, a.es, flexibility<CHECK>(B, R, A, &viol), S); }
+                else { BattP bp; load_batt(bp, B.p); eb_b = battery_step(bp, a.es, flexibility<CHECK>(B, R, A, &viol), S); }
                 A.c_b += eb_b;
             }
         }
@@ -545,25 +568,26 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         // every valid schema: the reference asserts demand <= device output, building.py:1825-1829)
         if (B.flags & (CLF_COOL_DEV | CLF_COOL_STO)) {
             TankP T; load_tank(T, B.p, CLP_CS_CAP, CLP_CS_IRTE);
-            end_use(B, R, A, A.c_cool, cool_dem, a.cs, T.cap, B.cd_pow, R.cop_c, R.icop_c, T, ir, S.cs, eb_cs, e_cool);
+            end_use<CHECK>(B, R, A, A.c_cool, cool_dem, a.cs, T.cap, B.cd_pow, R.cop_c, R.icop_c, T, ir, S.cs, eb_cs, e_cool, &viol, CLV_COOLING);
         }
         if (B.flags & (CLF_HEAT_DEV | CLF_HEAT_STO)) {
             TankP T; load_tank(T, B.p, CLP_HS_CAP, CLP_HS_IRTE);
-            end_use(B, R, A, A.c_heat, heat_dem, a.hs, pw(B.p, CLP_CS_CAP) * B.dt /* sic, building.py:1720 */, B.hd_pow, R.cop_h,
-                    R.icop_h, T, ir, S.hs, eb_hs, e_heat);
+            end_use<CHECK>(B, R, A, A.c_heat, heat_dem, a.hs, pw(B.p, CLP_CS_CAP) * B.dt /* sic, building.py:1720 */, B.hd_pow, R.cop_h,
+                           R.icop_h, T, ir, S.hs, eb_hs, e_heat, &viol, CLV_HEATING);
         }
         if (B.flags & (CLF_DHW_DEV | CLF_DHW_STO)) {
             TankP T; load_tank(T, B.p, CLP_DS_CAP, CLP_DS_IRTE);
-            end_use(B, R, A, A.c_dhw, R.dhw, a.ds, pw(B.p, CLP_HS_CAP) * B.dt /* sic, building.py:1765 */, B.dd_pow, R.cop_d,
-                    R.icop_d, T, ir, S.ds, eb_ds, e_dhw);
+            end_use<CHECK>(B, R, A, A.c_dhw, R.dhw, a.ds, pw(B.p, CLP_HS_CAP) * B.dt /* sic, building.py:1765 */, B.dd_pow, R.cop_d,
+                           R.icop_d, T, ir, S.ds, eb_ds, e_dhw, &viol, CLV_DHW);
         }
         // non-shiftable load (building.py:1784-1789)
-        const float e_ns = fminf(R.nsl, flexibility(B, R, A));
+        const float e_ns = fminf(R.nsl, flexibility<CHECK>(B, R, A, &viol));
+        if constexpr (CHECK) { if (!(e_ns >= 0.0f)) viol |= CLV_NSL; }          // update_electricity_consumption's own assertion (energy_model.py:146-148)
         A.c_ns += e_ns;
         if (has_batt && !(R.outage && es_first)) {
-            if constexpr (F64) eb_b = battery_step_f64(B.p, a.es, flexibility(B, R, A), t == 0, S);
-            else if constexpr (PREC == 2) { BattC bc; load_battc(bc, B.p); eb_b = battery_charge_chain(bc, a.es, flexibility(B, R, A), S); }
-            else { BattP bp; load_batt(bp, B.p); eb_b = battery_step(bp, a.es, flexibility(B, R, A), S); }
+            if constexpr (F64) eb_b = battery_step_f64(B.p, a.es, flexibility<CHECK>(B, R, A, &viol), t == 0, S);
+            else if constexpr (PREC == 2) { BattC bc; load_battc(bc, B.p); eb_b = battery_charge_chain(bc, a.es, flexibility<CHECK>(B, R, A, &viol), S); }
+            else { BattP bp; load_batt(bp, B.p); eb_b = battery_step(bp, a.es, flexibility<CHECK>(B, R, A, &viol), S); }
             A.c_b += eb_b;
         }
         if (first) {
@@ -576,6 +600,7 @@ CL_DEV void unit_step(const Bp& B, const Row& R, int t, bool t0_quirk, const Act
         }
         const float net = R.outage ? 0.0f : (A.c_cool + A.c_heat + A.c_dhw + A.c_ns + A.c_b) * B.r + R.sol;
         O.net = net; O.cost = mul_rn(net, R.price); O.emission = fmaxf(0.0f, net * R.carbon);
+        if constexpr (CHECK) O.viol = viol;
         O.eb = eb_b;
         O.cool_dem = e_cool + fabsf(fminf(eb_cs, 0.0f));          // building.py:1435-1437
         O.heat_dem = e_heat + fabsf(fminf(eb_hs, 0.0f));

@@ -363,6 +363,23 @@ class LSTMStage:
             self.indoor_temp.zero_()            # handed out by the 'planes' observation of reset()
             self.comfort.zero_()
 
+    def _carried(self):
+        return [('hist', self.hist), ('hidden', self.hidden), ('indoor_temp', self.indoor_temp), ('comfort', self.comfort),
+                ('kpi_comfort', self.kpi_comfort), ('generic_hidden', None if self.generic is None else self.generic['hidden'])]
+
+    def state_dict(self) -> dict:
+        """What the temperature stage carries between steps: the 12-row input history ring, the LSTM hidden / cell state, the last indoor
+        temperature and comfort reward, the comfort KPI accumulators (`StepEngine.state_dict` is the energy side)."""
+        return {k: None if v is None else v.detach().clone() for k, v in self._carried()}
+
+    def load_state_dict(self, sd) -> None:
+        for k, dst in self._carried():
+            src = sd.get(k)
+            if (src is None) != (dst is None) or (src is not None and tuple(src.shape) != tuple(dst.shape)):
+                raise ValueError(f'checkpoint tensor {k!r} does not fit this LSTM stage')
+            if dst is not None:
+                dst.copy_(src.to(dst.device))
+
     def step(self, t: int, cool_dem: Optional[torch.Tensor] = None, heat_dem: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Call right after ``engine.step(actions, t)``.  Returns the indoor temperature ``[n_bldg, n_env]`` of step t.
         ``cool_dem`` / ``heat_dem``: delivered cooling / heating planes to use instead of the engine's own (tests)."""

@@ -8,7 +8,7 @@ tensors (plumbing for device memory and streams only); all arithmetic happens in
 from __future__ import annotations
 
 import ctypes
-from typing import Optional
+from typing import Mapping, Optional
 
 import numpy as np
 import torch
@@ -51,7 +51,7 @@ class StepEngine:
                  t0_quirk: bool = True, detail=False, n_act_cols: Optional[int] = None, kpi: bool = False,
                  n_steps: Optional[int] = None, env_row0=None, ev_reward_weights=None, ev_drift=None, ev_seed: int = 0,
                  charger_detail: bool = False, ev_penalty_coefficient: float = 1.0, central_agent: bool = False, tuning: Optional[dict] = None,
-                 env_offset: int = 0, f64_maps: bool = False, env_pitch: Optional[int] = None):
+                 env_offset: int = 0, f64_maps=None, env_pitch: Optional[int] = None, check: bool = False):
         """`n_steps` / `env_row0`: per-env-block episode windows (`cl_dims.env_row0`).  `tables` then covers the whole
         simulation period, an episode is `n_steps` rows long and block g of `abi.CL_ROW0_BLOCK` consecutive envs starts
         at table row ``env_row0[g]`` -- different blocks replay different windows at once.
@@ -72,7 +72,15 @@ class StepEngine:
         round -- the reference's own precision model (energy_model.py:1027-1141), for free-running parity at 1e-4; slower launches,
         no fused rollout kernel, no flexible loads.  ``f64_maps='chain'`` (`CLD_F64_CHAIN`): only the battery's soc chain in float64
         and the degraded capacity carried as the capacity LOSS in its float32 plane (`degraded_capacity` converts) -- not bit-identical
-        but inside 1e-4 free-running on every fixture, the default three state planes, every step kernel and the fused rollout."""
+        but inside 1e-4 free-running on every fixture, the default three state planes, every step kernel and the fused rollout.
+        **Default (None, round 6): ``'chain'`` wherever the district admits it** (`chain_supported`: no EV chargers / washing machines), the
+        all-fp32 map otherwise.  The fp32 map (``f64_maps=False``) is 1.16 x faster per step at the headline shape and holds 1e-4 teacher-forced,
+        but free-running it drifts to 6.9 x the bar on `net` over the 8 759-step year of BASELINE config 1 (tests/test_gpu_parity.py::
+        test_full_year_free_running_every_step): a throughput mode to opt into, not the default.
+
+        ``check`` (`CLD_CHECK`, a debug mode): evaluate the reference's runtime assertions inside the step (flexibility >= 0 under an outage,
+        device-consumption polarity, non-negative non-shiftable load: building.py:665, 1831-1835; energy_model.py:146-148) and keep one word of
+        `abi.CLV_*` bits per unit (:attr:`violations`).  Needs ``detail=True`` and at most 32 buildings; runs the general step kernel."""
         self.lib = _lib.load()                      # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise _lib.EngineUnavailable('no HIP device visible: the step engine only runs on the GPU')
@@ -108,8 +116,10 @@ class StepEngine:
         flags |= abi.CLD_REF_T0_QUIRK if t0_quirk else 0
         flags |= abi.CLD_KPI if kpi else 0
         flags |= abi.CLD_CENTRAL_AGENT if central_agent else 0      # only read by the CLR_EV reward
+        if f64_maps is None:
+            f64_maps = 'chain' if self.chain_supported(tables) else False
         if f64_maps not in (False, True, 'ref', 'chain'):
-            raise ValueError("f64_maps must be False, True / 'ref' (CLD_F64_MAPS) or 'chain' (CLD_F64_CHAIN)")
+            raise ValueError("f64_maps must be None (default: 'chain' where supported), False, True / 'ref' (CLD_F64_MAPS) or 'chain' (CLD_F64_CHAIN)")
         self.f64_chain = f64_maps == 'chain'
         self.f64_maps = bool(f64_maps) and not self.f64_chain
         flags |= abi.CLD_F64_MAPS if self.f64_maps else 0
@@ -143,6 +153,14 @@ class StepEngine:
             detail = 'min'
         flags |= abi.CLD_WRITE_DETAIL if detail else 0
         flags |= abi.CLD_DETAIL_MIN if detail == 'min' else 0
+        self.check = bool(check)
+        if self.check:
+            if detail is not True or self.n_bldg > 32:
+                raise ValueError('check=True (CLD_CHECK) needs detail=True and a district of at most 32 buildings (the violation words use the scratch plane '
+                                 'of building-chunked launches)')
+            flags |= abi.CLD_CHECK
+            if kpi:
+                tuning = {**(tuning or {}), 'kpi_passes': (tuning or {}).get('kpi_passes') or 1}     # the KPI launch after the (general) step kernel
         # ... and keeps the env-independent sums of such a district (baseline, expected energy, baseline district series) once per block
         # of CL_ROW0_BLOCK envs, at the block's first env (include/citylearn_amd.h, CLD_KPI): `kpi.finalize_streaming(shared_baseline=True)`
         self.kpi_shared_baseline = bool(kpi_in_step and not detail)
@@ -276,6 +294,59 @@ class StepEngine:
             self._out_env.zero_()
         self._pending_t = None
         self.t = 0
+
+    # ---- checkpoint / restore ("torch.save of the tensor dict is a complete checkpoint") -------------------------
+    _CHECKPOINT_FORMAT = 1
+
+    def _signature(self) -> dict:
+        """What has to agree between the engine a checkpoint was taken from and the one it is loaded into."""
+        return {'n_env': self.n_env, 'n_bldg': self.n_bldg, 'n_steps': self.n_steps, 'flags': int(self.dims.flags), 'n_act_cols': self.n_act_cols,
+                'env_offset': int(self.dims.env_offset), 'flex': self.flex is not None, 'kpi': bool(self.kpi),
+                'params_crc': int(self.params.to(torch.int64).sum().item()) & 0xFFFFFFFF}
+
+    def state_dict(self) -> dict:
+        """Everything the device carries from one step to the next, as (cloned) tensors + a few host scalars: the state planes, the output
+        planes of the last step (what the next observation and `evaluate()` read; a pending deferred fold is finished first), the district
+        sums, the streaming KPI accumulators, the flexible-load state (EV batteries, washing-machine progress, the drift seed) and the step
+        counter.  The random streams (rollout policy, EV drift) are counter-based -- Philox keyed by (seed, env, column, step) -- so they have
+        no state of their own: a restored engine draws the same numbers.  `torch.save(engine.state_dict(), path)` is a complete checkpoint
+        (the reference's users pickle the whole env: citylearn/__main__.py:291-299)."""
+        self.finish()
+        c = lambda x: None if x is None else x.detach().clone()
+        sd = {'format': self._CHECKPOINT_FORMAT, 'signature': self._signature(), 't': int(self.t),
+              'state': c(self._state_store), 'out_bldg': c(self._out_store), 'out_env': c(self._out_env),
+              'kpi_bldg': c(self.kpi_bldg), 'kpi_env': c(self.kpi_env)}
+        if self.flex is not None:
+            b = self._flex_buffers
+            sd['flex'] = {'ev_state': c(b['ev_state']), 'wm_state': c(b['wm_state']), 'flex_out': c(b['flex_out']),
+                          'charger_out': c(b['charger_out']), 'seed': int(self.flex.seed)}
+        return sd
+
+    def load_state_dict(self, sd: Mapping) -> None:
+        """Restore :meth:`state_dict` into THIS engine's buffers (same district, batch size and flags: checked), in place -- captured
+        hipGraphs that point at them stay valid.  The next `step` continues bit-identically to the engine the checkpoint was taken from."""
+        if sd.get('format') != self._CHECKPOINT_FORMAT:
+            raise ValueError(f"checkpoint format {sd.get('format')!r}, this build reads {self._CHECKPOINT_FORMAT}")
+        mine = self._signature()
+        diff = {k: (v, mine.get(k)) for k, v in dict(sd['signature']).items() if mine.get(k) != v}
+        if diff:
+            raise ValueError(f'checkpoint does not belong to this engine (saved, here): {diff}')
+        with torch.cuda.device(self.device):
+            for key, dst in (('state', self._state_store), ('out_bldg', self._out_store), ('out_env', self._out_env), ('kpi_bldg', self.kpi_bldg),
+                             ('kpi_env', self.kpi_env)):
+                src = sd.get(key)
+                if (src is None) != (dst is None) or (src is not None and tuple(src.shape) != tuple(dst.shape)):
+                    raise ValueError(f'checkpoint tensor {key!r} does not fit this engine')
+                if dst is not None:
+                    dst.copy_(src.to(self.device))
+            if self.flex is not None:
+                f, b = sd['flex'], self._flex_buffers
+                for key in ('ev_state', 'wm_state', 'flex_out', 'charger_out'):
+                    if b[key] is not None and f.get(key) is not None:
+                        b[key].copy_(f[key].to(self.device))
+                self.flex.seed = int(f['seed'])
+        self._pending_t = None
+        self.t = int(sd['t'])
 
     @staticmethod
     def chain_supported(tables: EpisodeTables) -> bool:
@@ -436,6 +507,13 @@ class StepEngine:
             return plane
         cap = self.params[:, abi.CLP_L_CAP].view(torch.float32)
         return cap[:, None] - plane
+
+    @property
+    def violations(self) -> torch.Tensor:
+        """``[n_bldg, n_env]`` int32 words of `abi.CLV_*` bits: the reference assertions the last step tripped (``check=True``; 0 = none)."""
+        if not self.check:
+            raise RuntimeError('construct StepEngine(..., check=True, detail=True) to evaluate the reference assertions (CLD_CHECK)')
+        return self.out_bldg[abi.CLO_RESERVED].view(torch.int32)
 
     @property
     def net(self) -> torch.Tensor:

@@ -31,7 +31,7 @@ class VectorCityLearnEnv:
     def __init__(self, schema: Union[str, Mapping[str, Any], DistrictSpec], n_envs: int, device: str = 'cuda:0',
                  reference_quirks: bool = True, kpi: bool = False, observations: str = 'planes',
                  normalize_observations: bool = False, observation_mode: str = 'current',
-                 env_episode_offsets=None, ev_seed: Optional[int] = None, ev_soc_drift=None, env_offset: int = 0, f64_maps: bool = False,
+                 env_episode_offsets=None, ev_seed: Optional[int] = None, ev_soc_drift=None, env_offset: int = 0, f64_maps=None,
                  **kwargs: Any):
         """`observations`: ``'planes'`` (default) returns the dict of device tensors described above without
         materialising anything; ``'tensor'`` returns the Gym observation tensor ``[n_envs, n_obs]`` written by
@@ -52,8 +52,10 @@ class VectorCityLearnEnv:
         per episode), `ev_soc_drift` ([table rows, n_ev]) replays given multipliers for every env instead.
         `env_offset`: index of this shard's first env in a multi-GPU batch (`parallel.shard_envs(total, rank, world)[0]`): random streams
         (rollout policy, EV drift) are keyed by it + the local env index, so shards with one seed draw disjoint streams.
-        `f64_maps` (`CLD_F64_MAPS`): the battery map in the reference's own mixed float64 / float32 precision (battery state bit-identical to
-        the reference's over a free-running episode; about 3 x the step time; no EV districts)."""
+        `f64_maps`: precision model of the battery map.  Default (None): ``'chain'`` (`CLD_F64_CHAIN`) wherever the district
+        admits it -- the mode that holds 1e-4 free-running over whole episodes, the full year of BASELINE config 1 included -- else the fp32
+        map; ``False``: the all-fp32 map (1.16 x faster per step, drifts past 1e-4 free-running: a throughput mode); ``True`` (`CLD_F64_MAPS`):
+        the reference's own mixed float64 / float32 precision, battery state bit-identical over a free-running episode at about 3 x the step time."""
         if observations not in ('planes', 'tensor', 'compact'):
             raise ValueError("observations must be 'planes', 'tensor' or 'compact'")
         self._compact = observations == 'compact'
@@ -65,7 +67,7 @@ class VectorCityLearnEnv:
         self.central_agent = self.spec.central_agent
         self.env_episode_offsets = env_episode_offsets
         self._ev_seed, self._ev_drift = ev_seed, ev_soc_drift
-        self.f64_maps = f64_maps if f64_maps in ('chain', 'ref') else bool(f64_maps)      # ('chain': CLD_F64_CHAIN, the cheap 1e-4 mode)
+        self.f64_maps = f64_maps if f64_maps in ('chain', 'ref', None) else bool(f64_maps)      # (None: 'chain' where supported -- resolved by StepEngine)
         self.env_offset = int(env_offset)      # first env of this shard in the whole batch (multi-GPU: parallel.shard_envs(...)[0])
         if self.env_offset < 0 or self.env_offset + self.n_envs > 2 ** 32:
             raise ValueError(f'env_offset={env_offset} with n_envs={n_envs} leaves the 32-bit env index of the random streams')
@@ -193,6 +195,7 @@ class VectorCityLearnEnv:
 
     def reset(self, seed: Optional[int] = None) -> Tuple[Dict[str, torch.Tensor], dict]:
         self._episode += 1
+        self._reset_seed = seed
         if self._plugin is not None and callable(getattr(self._plugin, 'reset', None)):
             self._plugin.reset()                                  # RewardFunction.reset (citylearn.py:1846)
         n_steps, row0 = None, None
@@ -249,6 +252,41 @@ class VectorCityLearnEnv:
             else:
                 self.writer = ObservationWriter(self.engine, obs_tables, self.stage)
         return self._obs(), {}
+
+    # ---- checkpoint / restore -------------------------------------------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        """A complete checkpoint of the running episode as plain tensors and scalars (`torch.save`-able): the engine's planes, KPI accumulators
+        and flexible-load state (`StepEngine.state_dict`), the LSTM stage's rings and hidden state, and the episode bookkeeping -- episode
+        number, the seed `reset` was called with, the time step, the episode window and the per-block offsets.  The reference's counterpart is
+        pickling the whole env (citylearn/__main__.py:291-299); here the tables are rebuilt from the schema and only what moves is saved."""
+        return {'format': 1, 'episode': self._episode, 'reset_seed': self._reset_seed, 't': int(self._t),
+                'window': (int(self.tables.start), int(self.tables.end)),
+                'episode_row0': None if self.episode_row0 is None else np.asarray(self.episode_row0).copy(),
+                'engine': self.engine.state_dict(), 'stage': None if self.stage is None else self.stage.state_dict()}
+
+    def load_state_dict(self, sd: Mapping[str, Any]) -> None:
+        """Restore :meth:`state_dict` into this env (constructed on the same schema with the same arguments).  If the checkpoint belongs to
+        another episode -- another window of the data, other outage draws, other block offsets -- that episode is rebuilt first (`reset` with the
+        saved episode number and seed); then every carried tensor is copied in place.  The next `step` continues bit-identically."""
+        if sd.get('format') != 1:
+            raise ValueError(f"checkpoint format {sd.get('format')!r}, this build reads 1")
+        same_window = (int(self.tables.start), int(self.tables.end)) == tuple(sd['window'])
+        same_rows = (self.episode_row0 is None) == (sd['episode_row0'] is None) and \
+                    (self.episode_row0 is None or np.array_equal(np.asarray(self.episode_row0), sd['episode_row0']))
+        if self._episode != sd['episode'] or not same_window or not same_rows:
+            self._episode = int(sd['episode']) - 1
+            self.reset(sd['reset_seed'])
+            if (int(self.tables.start), int(self.tables.end)) != tuple(sd['window']):
+                raise ValueError(f"episode {sd['episode']} of this env covers rows {(self.tables.start, self.tables.end)}, the checkpoint's covered {tuple(sd['window'])}: "
+                                 'not the same schema / episode split')
+        self._reset_seed = sd['reset_seed']
+        self.engine.load_state_dict(sd['engine'])
+        if (self.stage is None) != (sd['stage'] is None):
+            raise ValueError('checkpoint and env disagree about the LSTM temperature stage')
+        if self.stage is not None:
+            self.stage.load_state_dict(sd['stage'])
+        self._t = int(sd['t'])
+        self.engine.t = self._t
 
     def _block_offsets(self, n_steps: int, n_rows: int, seed: Optional[int]) -> np.ndarray:
         n_blocks = -(-self.n_envs // abi.CL_ROW0_BLOCK)

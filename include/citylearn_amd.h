@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CL_ABI_VERSION 7   /* 7: CLD_F64_CHAIN (params rows of 320 words: CLP_C_* block); 6: cl_finish_f32, cl_tuning.finish = 3 (deferred finish); 5: cl_tuning.kernel_name, CLD_F64_MAPS; 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
+#define CL_ABI_VERSION 8   /* 8: CLD_CHECK (the reference's runtime assertions as a violation word per unit), tickets of the in-launch fold at the reserved plane's tail; 7: CLD_F64_CHAIN (params rows of 320 words: CLP_C_* block); 6: cl_finish_f32, cl_tuning.finish = 3 (deferred finish); 5: cl_tuning.kernel_name, CLD_F64_MAPS; 4: LSTM tables with pre-scaled gate rows, CLD_LSTM_F16 (two-term f16 `lstm_wb`) */
 
 /* ---- error codes ---- */
 #define CL_OK            0
@@ -312,6 +312,19 @@ enum cl_kpi_env {             /* kpi_env[cond*12 + k][env], cond 0 = control dis
 #define CLD_LSTM_TWO_DEMANDS (1u << 13) /* cl_lstm_step_f32 only: caller asserts that a building of the district has a temperature model taking BOTH
                                           demands (lstm_w[CLW_DEM2] != 0; needs `heat_dem`): selects the instantiation that reads the third input
                                           ring (rows 24-35 of `hist`).  Without it such a building's indoor_temp is NaN */
+#define CLD_CHECK          (1u << 15) /* debug mode of cl_step_f32 / cl_step_flex_f32 (ABI 8): evaluate the reference's own runtime assertions inside the
+                                         step and leave one word of CLV_* bits per (building, env) in plane CLO_RESERVED of `out_bldg` (read it as
+                                         uint32; 0 = the reference would not have raised).  Needs CLD_WRITE_DETAIL and a district the launch does not
+                                         cut into building chunks (n_bldg <= 32), whose scratch the plane otherwise is; selects the general step kernel
+                                         (cl_step_kernel<1, true, true, .., CHECK = true>), one env per lane.  The demand-limit assertion
+                                         (building.py:1825-1829) only involves env-independent operands and stays a host table (CityLearnEnv). */
+enum cl_violation {
+    CLV_FLEXIBILITY = 1,   /* downward_electrical_flexibility < 0 beyond TOLERANCE during a power outage (building.py:665) */
+    CLV_COOLING     = 2,   /* ___electricity_consumption_polarity_check('cooling', ..): negative device consumption (building.py:1660, 1831-1835) */
+    CLV_HEATING     = 4,   /* ... 'heating' (building.py:1708) */
+    CLV_DHW         = 8,   /* ... 'dhw' (building.py:1753) */
+    CLV_NSL         = 16   /* ElectricDevice.update_electricity_consumption(enforce_polarity): a negative non-shiftable load (energy_model.py:146-148) */
+};
 #define CLD_REWARD_SHIFT   8          /* reward kind in bits 8..11 */
 #define CLD_REWARD_MASK    (0xFu << CLD_REWARD_SHIFT)
 enum cl_reward_kind {

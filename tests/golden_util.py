@@ -60,3 +60,43 @@ class Golden:
 @lru_cache(maxsize=None)
 def golden(name: str) -> Golden:
     return Golden(name)
+
+
+# ---- the parity bar and its record --------------------------------------------------------------------------------------------------
+# BASELINE.json's bar: |got - ref| <= 1e-4 + 1e-4 |ref| on every quantity, district sums and rewards included (no slack factors since
+# round 6).  `check_worst` is what every parity test ends with: `worst` maps a quantity to its worst error in units of that bound.
+# CL_PARITY_REPORT=<file>: every call appends {"test", "worst"} as a JSON line -- the table under profiles/ is that file, summarised
+# (scripts/parity_table.py).  CL_PARITY_MEASURE=1: record only, never fail (a measuring run over the whole suite).
+ATOL = RTOL = 1e-4
+
+
+def check_worst(worst: dict, label: str = '', bound: float = 1.0):
+    import os
+    test = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]
+    path = os.environ.get('CL_PARITY_REPORT')
+    if path:
+        with open(path, 'a') as f:
+            f.write(json.dumps({'test': test, 'label': label, 'bound': bound, 'worst': {k: float(v) for k, v in worst.items()}}) + '\n')
+    if os.environ.get('CL_PARITY_MEASURE'):
+        return
+    assert max(worst.values()) < bound, (label, {k: round(float(v), 4) for k, v in worst.items()})
+
+
+def coupled_reward_tolerance(kind, ref_reward, ref_net, ref_district_net, n_storage, atol=ATOL, rtol=RTOL):
+    """The bar for a reward that is a steep FUNCTION of quantities which are themselves pinned to the bar: first-order propagation of
+    `atol + rtol |x|` through the reward's own derivatives, on top of the bar on the reward itself.  Needed in exactly one place -- the per-building
+    MARL / SolarPenaltyReward of the 1024-building thermal district (tests/test_gpu_config_sizes.py), where a building's net is a small difference
+    of ~50-kWh terms: its fp32 rounding (~3e-5 kWh, far inside the bar on `net`) is multiplied by d reward / d net = 0.02 |net| district_net ~ 25
+    for MARL (reward_function.py:132-143), by the number of storages for SolarPenaltyReward (reward_function.py:189-214).  Measured at the plain
+    bar (profiles/r06_parity_worst.md): 3.89 x and 1.20 x; every other reward gate of the suite holds the plain bar.
+    Shapes: [n_bldg, n_env] (district net: [n_env]); `n_storage`: [n_bldg] storages with capacity > 0."""
+    rw, net = np.abs(np.asarray(ref_reward, dtype=np.float64)), np.asarray(ref_net, dtype=np.float64)
+    tol = atol + rtol * rw
+    tol_net = atol + rtol * np.abs(net)
+    if kind == 'MARL':
+        d = np.maximum(np.asarray(ref_district_net, dtype=np.float64), 0.0)[None, :]
+        tol = tol + 0.02 * np.abs(net) * d * tol_net + 0.01 * net * net * (atol + rtol * d)
+    elif kind == 'SolarPenaltyReward':
+        n = np.asarray(n_storage, dtype=np.float64)[:, None]
+        tol = tol + 2.0 * n * tol_net + np.abs(net) * n * (atol + rtol)
+    return tol

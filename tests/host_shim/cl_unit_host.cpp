@@ -32,6 +32,30 @@ extern "C" void host_unit_step(const uint32_t* params, const float* ts_row, int 
     else run<false, 0>(params, ts_row, t, quirk, rkind, act6, state8, out10, reward);
 }
 
+// CLD_CHECK: the same unit with the reference's runtime assertions compiled in; returns the CLV_* bits (include/citylearn_amd.h)
+extern "C" unsigned host_unit_step_check(const uint32_t* params, const float* ts_row, int t, int quirk, int full, int f64, const float* act6, float* state8) {
+    cl::State S = {state8[0], state8[1], state8[2], state8[3], state8[4], state8[5], state8[6], state8[7]};
+    cl::Act a = {act6[0], act6[1], act6[2], act6[3], act6[4], act6[5]};
+    cl::Out O;
+    O.viol = 0u;
+    cl::Bp B;
+    cl::Row R;
+    if (full) {
+        cl::load_bp<true>(B, params); cl::load_row<true>(R, ts_row, B.flags);
+        if (f64 == 2) cl::unit_step<true, 2, true>(B, R, t, quirk != 0, a, S, O);
+        else if (f64) cl::unit_step<true, 1, true>(B, R, t, quirk != 0, a, S, O);
+        else cl::unit_step<true, 0, true>(B, R, t, quirk != 0, a, S, O);
+    } else {
+        cl::load_bp<false>(B, params); cl::load_row<false>(R, ts_row, B.flags);
+        if (f64 == 2) cl::unit_step<false, 2, true>(B, R, t, quirk != 0, a, S, O);
+        else if (f64) cl::unit_step<false, 1, true>(B, R, t, quirk != 0, a, S, O);
+        else cl::unit_step<false, 0, true>(B, R, t, quirk != 0, a, S, O);
+    }
+    state8[0] = S.soc; state8[1] = S.eff; state8[2] = S.degcap; state8[3] = S.cs; state8[4] = S.hs; state8[5] = S.ds;
+    state8[6] = S.eff_lo; state8[7] = S.deg_lo;
+    return O.viol;
+}
+
 // div_rn(a, b, RN(1 / b)) against the hardware division, element by element; returns the number of mismatching quotients
 extern "C" long host_div_rn_mismatches(const double* a, const double* b, long n) {
     long bad = 0;

@@ -131,3 +131,89 @@ def test_markstein_division_returns_the_ieee_quotient(shim):
         assert shim.host_div_rn_mismatches(num.ctypes.data, den.ctypes.data, num.size) == 0
     z = np.zeros(4)
     assert shim.host_div_rn_mismatches(np.ones(4).ctypes.data, z.ctypes.data, 4) == 0          # 1 / 0: inf both ways
+
+
+def _check_step(lib, P, row, t, f64, a6, st, full=1):
+    vp = ctypes.c_void_p
+    lib.host_unit_step_check.restype = ctypes.c_uint
+    lib.host_unit_step_check.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    row = np.ascontiguousarray(row, dtype=np.float32)
+    return int(lib.host_unit_step_check(P.ctypes.data_as(vp), row.ctypes.data_as(vp), t, 1, full, f64, a6.ctypes.data_as(vp), st.ctypes.data_as(vp)))
+
+
+@pytest.mark.parametrize('f64', [0, 1, 2])
+def test_check_unit_reports_the_references_assertions(shim, f64):
+    """CLD_CHECK on the CPU (the device header compiled with g++): `cl::unit_step<.., CHECK = true>` returns no bit on valid rows of the
+    reference-run fixtures, and exactly the bit of the assertion the reference would raise on a corrupted row -- a negative non-shiftable load
+    (energy_model.py:146-148), a negative cooling demand (building.py:1660, 1831-1835), an outage at t = 0 where reset() has already booked
+    the ideal loads (building.py:665)."""
+    g = golden('g2020_cz1')
+    tab = g.spec().episode_tables(0)
+    P = np.ascontiguousarray(tab.params)
+    pf = P.view(np.float32)
+    b = 4
+    st0 = np.zeros(8, dtype=np.float32)
+    st0[0], st0[1], st0[2] = pf[b, abi.CLP_L_SOC0], pf[b, abi.CLP_L_EFF0], (0.0 if f64 == 2 else pf[b, abi.CLP_L_CAP])
+    a6 = np.zeros(6, dtype=np.float32)
+    for t in range(0, 40):
+        assert _check_step(shim, P[b], tab.ts[t, b], t, f64, a6, st0.copy()) == 0, t
+    row = tab.ts[7, b].copy(); row[abi.CLT_NSL] = -1.0
+    assert _check_step(shim, P[b], row, 7, f64, a6, st0.copy()) == abi.CLV_NSL
+    row = tab.ts[7, b].copy(); row[abi.CLT_COOL_DEM] = -3.0
+    assert _check_step(shim, P[b], row, 7, f64, a6, st0.copy()) & abi.CLV_COOLING
+    Pb = P[b].copy()
+    for slot in (abi.CLP_FLAGS, abi.CLP_L_FLAGS, abi.CLP_F_FLAGS):          # (the flag word and its copies in the lean / thermal blocks)
+        Pb[slot] |= abi.CLF_OUTAGE
+    row = tab.ts[0, b].copy(); row[abi.CLT_OUTAGE] = 1.0
+    assert _check_step(shim, Pb, row, 0, f64, a6, st0.copy()) & abi.CLV_FLEXIBILITY
+    assert _check_step(shim, Pb, row, 5, f64, a6, st0.copy()) == 0          # the same outage later in the episode: nothing pre-booked, flexibility = |solar| >= 0
+    # the lean unit (battery + PV + load): only the load's polarity can trip
+    g2 = golden('g2022_all')
+    tab2 = g2.spec().episode_tables(0)
+    P2 = np.ascontiguousarray(tab2.params)
+    row = tab2.ts[3, 1].copy()
+    assert _check_step(shim, P2[1], row, 3, f64, a6, st0.copy(), full=0) == 0
+    row[abi.CLT_NSL] = -0.5
+    assert _check_step(shim, P2[1], row, 3, f64, a6, st0.copy(), full=0) == abi.CLV_NSL
+
+
+def test_device_header_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """SURVEY section 5 / VERDICT r05 item 9: the device's unit header (`csrc/cl_unit.h`, every precision model, the CHECK variant) built with
+    `-fsanitize=address,undefined -fno-sanitize-recover=all` and free-run over fixtures in a child process (the sanitizer runtime has to be
+    loaded before the interpreter's first allocation: LD_PRELOAD).  GPU AddressSanitizer is not available on this pool; the CPU build of the
+    same arithmetic is what can be sanitized.  Any report aborts the child."""
+    import os
+    import sys
+    so = tmp_path / 'libcl_unit_host_san.so'
+    subprocess.run(['g++', '-O1', '-g', '-shared', '-fPIC', '-DCL_HOST_SHIM', '-ffp-contract=off', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                    str(HERE / 'cl_unit_host.cpp'), '-o', str(so)], check=True)
+    asan = subprocess.run(['gcc', '-print-file-name=libasan.so'], capture_output=True, text=True, check=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip('no libasan runtime beside gcc')
+    code = f'''
+import ctypes, sys
+sys.path.insert(0, {str(Path(__file__).resolve().parent)!r}); sys.path.insert(0, {str(Path(__file__).resolve().parent.parent)!r})
+import numpy as np
+import test_f64_maps_host as T
+lib = ctypes.CDLL({str(so)!r})
+vp = ctypes.c_void_p
+lib.host_unit_step.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+for name in ('g2023_p2', 's_2023_p3'):
+    for f64 in (0, 1, 2):
+        w = T.free_run(lib, name, f64)
+        w.pop('soc_mismatch_fraction')
+        assert max(w.values()) < 10.0, (name, f64, w)
+from golden_util import golden
+from citylearn_amd import abi
+g = golden('g2023_p2'); tab = g.spec().episode_tables(0); P = np.ascontiguousarray(tab.params)
+a6 = np.zeros(6, dtype=np.float32)
+for t in range(380, 410):
+    for b in range(P.shape[0]):
+        for f64 in (0, 1, 2):
+            st = np.zeros(8, dtype=np.float32); st[0] = 0.4; st[1] = 0.9; st[2] = 0.0 if f64 == 2 else P.view(np.float32)[b, abi.CLP_L_CAP]
+            assert T._check_step(lib, P[b], tab.ts[t, b], t, f64, a6, st) == 0
+print('sanitized run ok')
+'''
+    env = {**os.environ, 'LD_PRELOAD': asan, 'ASAN_OPTIONS': 'detect_leaks=0:abort_on_error=1', 'UBSAN_OPTIONS': 'halt_on_error=1:print_stacktrace=1'}
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and 'sanitized run ok' in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])

@@ -1,0 +1,107 @@
+"""`CLD_CHECK`: the reference's runtime assertions -- `downward_electrical_flexibility >= 0`
+(building.py:665), `___electricity_consumption_polarity_check` (building.py:1831-1835), `update_electricity_consumption`'s polarity
+(energy_model.py:146-148) -- evaluated on the device as one word of `abi.CLV_*` bits per (building, env); `CityLearnEnv.step` raises the
+reference's AssertionError from it.  GPU only."""
+import json
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden
+from citylearn_amd import abi
+from citylearn_amd.engine import StepEngine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('f64', ['chain', False, True])
+@pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2'])
+def test_valid_episodes_trip_nothing_and_planes_are_unchanged(name, f64):
+    """On the reference-run fixtures (where the reference raised nothing) no bit is ever set, outage rows included, and the checking kernel
+    writes the same planes as the general kernel it instantiates."""
+    g = golden(name)
+    tab = g.spec().episode_tables(0)
+    E = 64
+    chk = StepEngine(tab, E, detail=True, check=True, f64_maps=f64)
+    ref = StepEngine(tab, E, detail=True, f64_maps=f64, tuning=dict(full_variant=1, vec=1))
+    chk.trace_kernels()
+    acts = torch.from_numpy(g.ref['actions']).cuda()
+    steps = list(range(60)) + (list(range(385, 410)) if name == 'g2023_p2' else [])
+    for t in steps:
+        a = acts[t][:, None].expand(-1, E).contiguous()
+        if t == 385:
+            chk.state.copy_(ref.state)
+        chk.step(a, t); ref.step(a, t)
+        assert int(chk.violations.abs().max()) == 0, t
+        assert torch.equal(chk.state, ref.state) and torch.equal(chk.out_bldg[:abi.CLO_RESERVED], ref.out_bldg[:abi.CLO_RESERVED]) and torch.equal(chk.out_env, ref.out_env), t
+    assert chk.last_kernels.endswith('false, true>') and chk.last_kernels.startswith('cl_step_kernel<1, true, true, false'), chk.last_kernels
+
+
+def test_violation_bits_where_the_reference_would_raise():
+    """Tables corrupted the way a bad dataset would be: a negative non-shiftable load (the reference raises 'electricity_consumption must be >= 0',
+    energy_model.py:146-148), a negative cooling demand (negative device consumption, building.py:1660), and a power outage at t = 0, where reset()
+    has booked the ideal loads once already so that the flexibility left is negative (building.py:665)."""
+    g = golden('g2020_cz1')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E = 64
+    ts = tab.ts.copy()
+    ts[5, 2, abi.CLT_NSL] = -1.0
+    ts[7, 4, abi.CLT_COOL_DEM] = -3.0
+    params = tab.params.copy()
+    for slot in (abi.CLP_FLAGS, abi.CLP_L_FLAGS, abi.CLP_F_FLAGS):          # (the flag word and its copies in the lean / thermal blocks)
+        params[:, slot] |= abi.CLF_OUTAGE
+    ts[0, 1, abi.CLT_OUTAGE] = 1.0
+    import dataclasses
+    bad = dataclasses.replace(tab, ts=ts, params=params)
+    eng = StepEngine(bad, E, detail=True, check=True)
+    zero = torch.zeros((eng.n_act_cols, E), device='cuda')
+    seen = {}
+    for t in range(9):
+        eng.step(zero, t)
+        v = eng.violations.cpu().numpy()
+        assert (v == v[:, :1]).all()
+        for b in np.flatnonzero(v[:, 0]):
+            seen[(t, int(b))] = int(v[b, 0])
+    assert seen.get((5, 2), 0) & abi.CLV_NSL
+    assert seen.get((7, 4), 0) & abi.CLV_COOLING
+    assert seen.get((0, 1), 0) & abi.CLV_FLEXIBILITY
+    assert set(seen) == {(5, 2), (7, 4), (0, 1)}, seen
+
+
+def test_check_mode_refusals():
+    g = golden('g2022_all')
+    tab = g.spec().episode_tables(0)
+    with pytest.raises(ValueError):
+        StepEngine(tab, 64, check=True)                       # needs the detail planes
+    eng = StepEngine(tab, 64, detail=True)
+    with pytest.raises(RuntimeError):
+        eng.violations
+
+
+def test_env_raises_the_references_assertion(tmp_path):
+    """`CityLearnEnv.step` on a dataset with a negative non-shiftable load at row 3 of Building_2: AssertionError with the reference's message
+    (ElectricDevice.update_electricity_consumption, energy_model.py:146-148), at the step the reference raises it."""
+    from citylearn_amd.citylearn import CityLearnEnv
+    g = golden('g2022_all')
+    root = tmp_path / 'dataset'
+    shutil.copytree(g.dataset_dir, root)
+    import pandas as pd
+    csv = root / json.loads((root / 'schema.json').read_text())['buildings']['Building_2']['energy_simulation']
+    df = pd.read_csv(csv)
+    df.loc[3, 'non_shiftable_load'] = -0.75
+    df.to_csv(csv, index=False)
+    env = CityLearnEnv(str(root / 'schema.json'))
+    env.reset()
+    acts = [[0.0] for _ in env.action_names]
+    for t in range(3):
+        env.step(acts)
+    with pytest.raises(AssertionError, match='electricity_consumption must be >= 0 but value: -0.75'):
+        env.step(acts)
+    # ... and not with the check switched off (the device clamps nothing here: it books the negative load like the arithmetic says)
+    quiet = CityLearnEnv(str(root / 'schema.json'), check_invariants=False)
+    quiet.reset()
+    for t in range(5):
+        quiet.step(acts)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import golden, SWEEP
+from golden_util import golden, SWEEP, check_worst
 from citylearn_amd import _lib, abi
 from citylearn_amd.engine import StepEngine
 
@@ -30,7 +30,7 @@ def _err(got, ref, atol, rtol):
     return float(np.max(np.abs(np.asarray(got, dtype=np.float64) - ref) / (atol + rtol * np.abs(ref))))
 
 
-def _run(name, kind, vec, detail, teach, steps=None, E=64, atol=1e-4, rtol=1e-4, tuning=None, f64=False, district_slack=(4.0, 2.0)):
+def _run(name, kind, vec, detail, teach, steps=None, E=64, atol=1e-4, rtol=1e-4, tuning=None, f64=False, district_slack=(1.0, 1.0)):
     g = golden(name)
     spec = g.spec()
     tab = spec.episode_tables(0)
@@ -72,13 +72,15 @@ def _run(name, kind, vec, detail, teach, steps=None, E=64, atol=1e-4, rtol=1e-4,
     return worst, eng
 
 
+@pytest.mark.parametrize('f64', ['chain', False])
 @pytest.mark.parametrize('kind', REWARDS)
 @pytest.mark.parametrize('vec', [1, 2, 4])
-def test_lean_kernel_teacher_forced(kind, vec):
-    """2022 schema (17 buildings, battery + PV): the specialised lean kernel, every vector width, every fused reward."""
-    worst, eng = _run('g2022_all', kind, vec, detail=False, teach=True, steps=240 if vec > 1 or kind != 'RewardFunction' else None)
-    assert eng.lean
-    assert max(worst.values()) < 1.0, worst
+def test_lean_kernel_teacher_forced(kind, vec, f64):
+    """2022 schema (17 buildings, battery + PV): the specialised lean kernel, every vector width, every fused reward -- under the default
+    precision model (CLD_F64_CHAIN: the kernel the headline is quoted on since round 6) and as the all-fp32 map."""
+    worst, eng = _run('g2022_all', kind, vec, detail=False, teach=True, steps=240 if vec > 1 or kind != 'RewardFunction' else None, f64=f64)
+    assert eng.lean and ('chain' in eng.last_kernels) == (f64 == 'chain'), eng.last_kernels
+    check_worst(worst)
 
 
 @pytest.mark.parametrize('kind', ['RewardFunction', 'MARL'])
@@ -109,7 +111,8 @@ def test_env_major_lean_kernel(kind):
     (teacher-forced) and against the building-major kernel: identical per-building planes for the per-building rewards,
     district sums equal up to the summation order (env-major adds in building order, like the reference)."""
     worst, eng = _run('g2022_all', kind, 0, detail=False, teach=True, steps=240, tuning=dict(envmajor=1))
-    assert eng.lean and max(worst.values()) < 1.0, worst
+    assert eng.lean
+    check_worst(worst)
     g = golden('g2022_all')
     tab = g.spec().episode_tables(0)
     E = 516
@@ -139,13 +142,13 @@ def test_full_kernel_teacher_forced(name, kind):
     general kernel, with the detail planes (energy balance, device consumption, baseline net)."""
     steps = None if kind == 'RewardFunction' else 200
     worst, _ = _run(name, kind, 1, detail=True, teach=True, steps=steps)
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
 
 
 @pytest.mark.parametrize('name', ['g2020_cz1', 'g2023_p2'])
 def test_full_kernel_vec2(name):
     worst, _ = _run(name, 'RewardFunction', 2, detail=False, teach=True, steps=150)
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
 
 
 @pytest.mark.parametrize('name,kind,detail', [('g2020_cz1', 'RewardFunction', False), ('g2020_cz1', 'SolarPenaltyReward', True),
@@ -193,28 +196,34 @@ def test_dataset_sweep_teacher_forced(name):
     """Short runs of the other dataset families (baeda_3dem, 2021, 2020 climate zone 3, 2023 phase 1 and the six-building
     phase 3): general kernel with the detail planes, every step, 1e-4."""
     worst, _ = _run(name, 'RewardFunction', 1, detail=True, teach=True)
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
     worst, _ = _run(name, 'SolarPenaltyReward', 2, detail=False, teach=True)
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
 
 
 @pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 'g2023_heat'])
-def test_free_running_whole_fixture(name):
-    worst, _ = _run(name, 'RewardFunction', 1, detail=False, teach=False, atol=1e-3, rtol=1e-3)
-    assert max(worst.values()) < 1.0, worst
+def test_free_running_whole_fixture_plain_fp32(name):
+    """`f64_maps=False`, the all-fp32 battery map (the SIDE entry since round 6: 1.16 x faster per step, not the default), FREE-RUNNING over
+    whole fixtures.  It does NOT hold the north star's 1e-4 everywhere, which is why it is not the default: measured in units of
+    1e-4 + 1e-4 |ref| (profiles/r06_parity_worst.md) the per-building planes reach 0.69 (2022), 0.22 (2023) and 2.1 (2020 / 15-minute fixtures:
+    140-kWh batteries on the steep segment of the capacity-power curve) over ~720 steps, and 6.9 on `net` over the 8 759-step year
+    (test_full_year_free_running_every_step).  Gated here at 10 x the bar = 1e-3 + 1e-3 |ref| -- the documented accuracy of the fast mode --
+    with the two headline schemas held to the bar itself."""
+    worst, _ = _run(name, 'RewardFunction', 1, detail=False, teach=False, f64=False)
+    check_worst(worst, name + ' fp32 free-running', bound=1.0 if name in ('g2022_all', 'g2023_p2') else 10.0)
 
 
-@pytest.mark.parametrize('name', ['g2022_all', 'g2023_p2'])
-def test_free_running_at_the_north_star_bar_in_plain_fp32(name):
-    """BASELINE.json's bar -- 1e-4 relative -- FREE-RUNNING over the whole fixture with the default fp32 kernels (the ones the headline
-    speed is quoted on), on the two headline schemas: measured worst 0.69 x (2022, 17 buildings x 719 steps) and 0.22 x (2023, outage
-    path) of 1e-4 + 1e-4 |ref| in round 3; pinned here so that a regression to the looser 1e-3 gate of the test above cannot pass
-    unnoticed.  (The 2020 / 15-minute fixtures sit at 2.1 x on the per-building planes in plain fp32 -- battery map on the steep segment of
-    the capacity-power curve -- and reach the bar with CLD_F64_MAPS: next test.)  District sums keep `_run`'s stated slack: 17-term fp32
-    sums of O(100) kWh against the reference's float64 sums."""
-    worst, _ = _run(name, 'RewardFunction', 1, detail=False, teach=False, atol=1e-4, rtol=1e-4)
-    assert max(worst.values()) < 1.0, worst
-    print(name, {k: round(v, 3) for k, v in worst.items()})
+@pytest.mark.parametrize('f64', ['chain', False])
+def test_full_year_free_running_every_step(f64):
+    """BASELINE config 1 (2022_phase_1, 5 buildings, the reference's own 8 759-step episode, citylearn.py:978-1056 looped over the year) FREE-RUNNING
+    on the GPU, every step, every building: soc, efficiency, degraded capacity, net, reward, and the district net / cost / emission / reward, all
+    at 1e-4 + 1e-4 |ref| with no slack factor.  The default precision model (CLD_F64_CHAIN) holds the bar for the whole
+    year (host-side run of the same header: soc 0.015, net 0.063 of the bound); the all-fp32 map does not (net 6.9 x the bound by step 8 759:
+    a one-ulp seed on the steep segment of the capacity-power curve, never reset by a clamp for weeks) -- it is gated at its documented 1e-3
+    and is the reason the default changed."""
+    worst, eng = _run('g2022_p1_year', 'RewardFunction', 0, detail=False, teach=False, f64=f64, E=4)
+    print('year', f64, eng.last_kernels, {k: round(v, 3) for k, v in worst.items()})
+    check_worst(worst, f'g2022_p1_year free-running f64_maps={f64}', bound=1.0 if f64 == 'chain' else 10.0)
 
 
 @pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1', 'g2023_p2', 'g2020_15min', 'g2023_heat'])
@@ -225,7 +234,7 @@ def test_free_running_whole_fixture_f64(name, vec):
     and the battery state (soc, efficiency, degraded capacity) bit-identical to the reference's float32 values at every step."""
     worst, eng = _run(name, 'RewardFunction', vec, detail=False, teach=False, f64=True, district_slack=(1.0, 1.0))
     assert 'cl_step_lean_f64_kernel' in eng.last_kernels or ', 1, false>' in eng.last_kernels, eng.last_kernels      # cl_step_kernel<.., PREC = 1, FOLD = false>
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
     assert worst['soc'] == 0.0 and worst['eff'] == 0.0 and worst['degcap'] == 0.0, worst
 
 
@@ -248,7 +257,7 @@ def test_free_running_whole_fixture_f64_chain(name, vec, tuning, detail, kernel)
     # (district sums at the PLAIN tolerance too: the per-building values are the reference's to ~1e-6, what is left is a 17-term fp32 sum)
     worst, eng = _run(name, 'RewardFunction', vec, detail=detail, teach=False, f64='chain', tuning=tuning, district_slack=(1.0, 1.0))
     assert kernel in eng.last_kernels, eng.last_kernels
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
     print(name, eng.last_kernels, {k: round(v, 3) for k, v in worst.items()})
 
 
@@ -256,13 +265,13 @@ def test_free_running_whole_fixture_f64_chain(name, vec, tuning, detail, kernel)
 def test_dataset_sweep_free_running_f64_chain(name):
     """... and free-running over the short fixtures of every other dataset family, at 1e-4."""
     worst, _ = _run(name, 'RewardFunction', 0, detail=True, teach=False, f64='chain')
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
 
 
 @pytest.mark.parametrize('kind', ['MARL', 'SolarPenaltyReward'])
 def test_f64_chain_teacher_forced_other_rewards(kind):
     worst, _ = _run('g2020_cz1', kind, 0, detail=False, teach=True, f64='chain', steps=200)
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
 
 
 @pytest.mark.parametrize('name', ['g2022_all', 'g2020_cz1'])
@@ -321,7 +330,7 @@ def test_f64_chain_refusals_and_views():
 @pytest.mark.parametrize('name,kind', [('g2020_cz1', 'SolarPenaltyReward'), ('g2022_all', 'MARL'), ('g2023_p2', 'IndependentSACReward')])
 def test_f64_maps_with_detail_planes_and_other_rewards(name, kind):
     worst, _ = _run(name, kind, 1, detail=True, teach=False, f64=True, steps=300)
-    assert max(worst.values()) < 1.0, worst
+    check_worst(worst)
 
 
 def test_f64_maps_refuse_what_they_do_not_cover():
@@ -379,7 +388,7 @@ def test_batch_against_c_oracle_distinct_actions():
         eng, ora = StepEngine(tab, E, reward=kind), COracle(spec, tab, E, reward=kind)
         low, high = spec.action_limits()
         rng = np.random.RandomState(5)
-        worst = 0.0
+        worst = {}
         for t in range(40):
             a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
             a[:, 0] = 0.0
@@ -390,12 +399,11 @@ def test_batch_against_c_oracle_distinct_actions():
             a_dev = torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t() if t % 2 else torch.from_numpy(a).cuda()
             eng.step(a_dev, t)
             out, oe = ora.step(a, t)
-            worst = max(worst, _err(eng.soc.cpu().numpy(), ora.state[:, :, OS['SOC']].T, 1e-4, 1e-4),
-                        _err(eng.net.cpu().numpy(), out[:, :, OO['NET']].T, 1e-4, 1e-4),
-                        _err(eng.reward_bldg.cpu().numpy(), out[:, :, OO['REWARD']].T, 1e-4, 2e-4),
-                        _err(eng.district_net.cpu().numpy(), oe[:, 0], 4e-4, 1e-4),
-                        _err(eng.district_reward.cpu().numpy(), oe[:, 3], 4e-4, 2e-4))
-        assert worst < 1.0, (name, worst)
+            for key, got, ref in (('soc', eng.soc, ora.state[:, :, OS['SOC']].T), ('net', eng.net, out[:, :, OO['NET']].T),
+                                  ('reward', eng.reward_bldg, out[:, :, OO['REWARD']].T), ('d_net', eng.district_net, oe[:, 0]),
+                                  ('district_reward', eng.district_reward, oe[:, 3])):
+                worst[key] = max(worst.get(key, 0.0), _err(got.cpu().numpy(), ref, 1e-4, 1e-4))
+        check_worst(worst, name)
 
 
 def test_results_are_reproducible_and_layout_independent():
@@ -448,7 +456,7 @@ def test_large_district_building_chunked_grid(fixture, kind, B):
     ora = COracle(spec, tab, E, reward=kind)
     low, high = spec.action_limits()
     rng = np.random.RandomState(8)
-    worst = 0.0
+    worst = {}
     for t in range(12):
         a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
         for pl, key in ((abi.CLS_B_SOC, 'SOC'), (abi.CLS_B_EFF, 'EFF'), (abi.CLS_B_DEGCAP, 'DEGCAP'), (abi.CLS_CS_SOC, 'CS'),
@@ -460,15 +468,14 @@ def test_large_district_building_chunked_grid(fixture, kind, B):
         eng.step(a_dev, t)                                          # chunked (B > 32, few env tiles)
         ref1.step(a_dev, t)                                         # one workgroup row per env tile
         out, oe = ora.step(a, t)
-        worst = max(worst, _err(eng.soc.cpu().numpy(), ora.state[:, :, OS['SOC']].T, 1e-4, 1e-4),
-                    _err(eng.net.cpu().numpy(), out[:, :, OO['NET']].T, 1e-4, 1e-4),
-                    _err(eng.reward_bldg.cpu().numpy(), out[:, :, OO['REWARD']].T, 1e-3, 2e-4),
-                    _err(eng.district_net.cpu().numpy(), oe[:, 0], 1e-2, 1e-4),
-                    _err(eng.district_reward.cpu().numpy(), oe[:, 3], 1e-2, 2e-4))
+        for key, got, ref in (('soc', eng.soc, ora.state[:, :, OS['SOC']].T), ('net', eng.net, out[:, :, OO['NET']].T),
+                              ('reward', eng.reward_bldg, out[:, :, OO['REWARD']].T), ('d_net', eng.district_net, oe[:, 0]),
+                              ('district_reward', eng.district_reward, oe[:, 3])):
+            worst[key] = max(worst.get(key, 0.0), _err(got.cpu().numpy(), ref, 1e-4, 1e-4))
         assert torch.equal(eng.state, ref1.state) and torch.equal(eng.net, ref1.net)
         torch.testing.assert_close(eng.out_env, ref1.out_env, rtol=1e-5, atol=1e-3)
         torch.testing.assert_close(eng.reward_bldg, ref1.reward_bldg, rtol=1e-5, atol=1e-4)
-    assert worst < 1.0, worst
+    check_worst(worst, fixture)
 
 
 @pytest.mark.parametrize('E', [65536, 131072])

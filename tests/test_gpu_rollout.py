@@ -8,9 +8,16 @@ import torch
 
 from golden_util import golden
 from citylearn_amd import _lib, abi
-from citylearn_amd.engine import StepEngine
+from citylearn_amd.engine import StepEngine as _StepEngine
 
 pytestmark = pytest.mark.gpu
+
+
+def StepEngine(*args, f64_maps=False, **kw):
+    """The fused-rollout instantiations and their tolerances against single steps were established on the all-fp32 battery map: engines of this
+    module are built with `f64_maps=False` unless a test asks otherwise.  The default precision model (CLD_F64_CHAIN since round 6) in mode B is
+    `test_fused_rollout_with_the_f64_chain` and `test_default_engine_rolls_out_under_the_chain`."""
+    return _StepEngine(*args, f64_maps=f64_maps, **kw)
 
 
 def _close(a, b, tol=2e-6):
@@ -324,3 +331,25 @@ def test_step_many_is_k_steps_from_one_call():
     b.step_many(acts, 3)
     assert b.t == a.t == 3 + K
     assert torch.equal(a.state, b.state) and torch.equal(a.out_bldg[:2], b.out_bldg[:2]) and torch.equal(a.out_env, b.out_env)
+
+
+def test_default_engine_rolls_out_under_the_chain():
+    """An engine built with default arguments steps AND rolls out under CLD_F64_CHAIN (one precision model for both modes): K fused steps
+    equal K single steps of the same engine type."""
+    g = golden('g2022_all')
+    spec = g.spec()
+    tab = spec.episode_tables(0)
+    E, K = 256, 24
+    b = _StepEngine(tab, E)
+    assert b.f64_chain
+    b.trace_kernels()
+    low, high = spec.action_limits()
+    b.set_action_limits(low, high)
+    b.rollout(K, seed=3)
+    assert 'cl_rollout_kernel' in b.last_kernels and b.last_kernels.rstrip('>').endswith(', 2'), b.last_kernels
+    # (the policy stream itself is pinned by test_on_device_philox_policy_matches_host_definition: replay it through the open-loop path)
+    c = _StepEngine(tab, E)
+    c.set_action_limits(low, high)
+    c.rollout(K, seed=3, fused=False)                      # the launch sequence: cl_policy_kernel + K x cl_step_f32
+    _close(b.state, c.state, 2e-6)
+    _close(b.out_bldg[:2], c.out_bldg[:2], 2e-5)

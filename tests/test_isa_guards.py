@@ -116,7 +116,7 @@ def test_f64_map_kernels_have_no_scratch(units):
     """CLD_F64_MAPS instantiations: the float64 battery parameters selected by value, not through struct addresses (the first build
     parked the 26-double block in scratch: 208 bytes per lane), and the thermal unit only at one env per lane (it spills at two)."""
     (kernels, meta), _ = units
-    names = [k for k in kernels if 'cl_step_lean_f64_kernel' in k or re.search(r'cl_step_kernelILi[12]ELb[01]ELb[01]ELb0ELi1ELb0EE', k)]
+    names = [k for k in kernels if 'cl_step_lean_f64_kernel' in k or re.search(r'cl_step_kernelILi[12]ELb[01]ELb[01]ELb0ELi1ELb0ELb0EE', k)]
     assert len(names) >= 8, names
     for k in names:
         assert meta[k]['private_seg_size'] == 0, k
@@ -128,25 +128,28 @@ def test_in_kernel_fold_uses_scoped_accesses_not_cache_maintenance(units):
     """`district_reduce<.., FOLD>` (cl_tuning.finish = 2): the chunk partial sums and the ticket cross XCDs through agent-scope accesses
     (`sc1` stores / loads, one atomic) -- and nothing in the kernel writes back or invalidates the L2 (round 1's version did: 177 us)."""
     (kernels, _), _ = units
-    for pat in (r'cl_step_full_kernelILi2ELb0ELi1024ELi4ELb1ELb1EE', r'cl_step_kernelILi4ELb0ELb0ELb0ELi0ELb1EE'):
+    for pat in (r'cl_step_full_kernelILi2ELb0ELi1024ELi4ELb1ELb1EE', r'cl_step_kernelILi4ELb0ELb0ELb0ELi0ELb1ELb0EE'):
         ins = kernels[_one(kernels, pat)]
         assert not [i for i in ins if i.startswith(('buffer_wbl2', 'buffer_inv'))]
         assert sum(1 for i in ins if i.startswith('global_store_dword') and i.endswith('sc1')) >= 2        # partial sums, ticket reset
         assert sum(1 for i in ins if i.startswith('global_load_dword') and i.endswith('sc1')) >= 16        # the fold: sixteen loads in flight
         assert sum(1 for i in ins if i.startswith('global_atomic_add')) == 1
     # the instantiations that never fold keep their register budget (the fold is a template parameter, not a run-time branch)
-    k = _one(kernels, r'cl_step_kernelILi1ELb0ELb0ELb0ELi0ELb0EE')
+    k = _one(kernels, r'cl_step_kernelILi1ELb0ELb0ELb0ELi0ELb0ELb0EE')
     assert not [i for i in kernels[k] if i.endswith('sc1')]
 
 
 def test_scratch_memory_is_confined_to_the_known_instantiations(units):
     """No kernel of the library touches scratch memory except the ones listed here with their byte counts (two or three VGPRs parked once per
     wave under a 1024-thread workgroup's 128-register cap; the FLEX thermal kernel with detail planes: 13): a new entry is a regression."""
-    known = {r'cl_step_kernelILi2ELb1ELb1ELb1ELi0ELb0EE': 52, r'cl_step_full_kernelILi2ELb1ELi1024ELi4ELb0ELb[01]EE': 8,
+    known = {r'cl_step_kernelILi2ELb1ELb1ELb1ELi0ELb0ELb0EE': 52, r'cl_step_full_kernelILi2ELb1ELi1024ELi4ELb0ELb[01]EE': 8,
              r'cl_step_full_kernelILi2ELb0ELi576ELi5ELb0ELb[01]EE': 8, r'cl_step_full_kernelILi2ELb0ELi1024ELi5ELb0ELb[01]EE': 8,     # (the second: forced launches only)
              # the thermal step with the streaming KPI epilogue: 36 bytes RESERVED (slots of scalar registers that ended up parked in
              # vector-register lanes instead) and never accessed -- checked below
-             r'cl_step_full_kpi_kernelILb[01]E': 36}
+             r'cl_step_full_kpi_kernelILb[01]E': 36,
+             # CLD_CHECK (round 6): the DEBUG instantiations of the general kernel -- one violation word more per unit; a few registers parked in
+             # scratch cost a 4-env single-district launch nothing (never selected for a production batch)
+             r'cl_step_kernelILi1ELb1ELb1ELb[01]ELi[012]ELb0ELb1EE': 64}
     # the building-chunked thermal launches (BASELINE config 4; parameter blocks staged in LDS): 16 / 12 bytes per lane until round 4 -- the C4
     # shard's 1.145 x HBM traffic (VERDICT r04) -- none since their district accumulators live in the wave's LDS row (cl_full.h, QLDS)
     main_meta = units[0][1]
