@@ -667,7 +667,9 @@ __global__ void __launch_bounds__(1024) cl_step_kernel(const StepArgs a) {
 // row still arrive by scalar loads (staged in LDS they would sit in 36 vector registers per lane: 44 bytes of scratch at four envs per lane).
 // Non-battery buildings' planes are fetched and ignored.  Same arithmetic, same summation order as cl_step_kernel<VEC, false, false>:
 // bit-identical planes and sums.
-template <int VEC, bool NT, bool FOLD>
+// PREC = 2 (round 6): the battery's soc chain in float64 (CLD_F64_CHAIN, the engine's default precision model) -- the chunked districts' default path
+// had been the general kernel plus the second launch.
+template <int VEC, bool NT, bool FOLD, int PREC = 0>
 __global__ void __launch_bounds__(1024) cl_step_lean_chunk_kernel(const StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC] | (FOLD) exchange tile
     constexpr int TILE = 64 * VEC;
@@ -726,7 +728,7 @@ __global__ void __launch_bounds__(1024) cl_step_lean_chunk_kernel(const StepArgs
                 S.cs = S.hs = S.ds = 0.0f; S.eff_lo = S.deg_lo = 0.0f;
                 const cl::Act act = {0.0f, 0.0f, 0.0f, a_es[i], 0.0f, 0.0f};
                 cl::Out O;
-                cl::unit_step<false>(B, R, a.t, quirk, act, S, O);
+                cl::unit_step<false, PREC>(B, R, a.t, quirk, act, S, O);
                 const float rw = cl::unit_reward<false>(rkind, B, S, O.net);
                 o_soc[i] = S.soc; o_eff[i] = S.eff; o_deg[i] = S.degcap; o_net[i] = O.net; o_rw[i] = rw;
                 q_net[i] += O.net; q_cost[i] += O.cost; q_em[i] += O.emission;
@@ -1685,6 +1687,23 @@ __global__ void cl_return_kernel(float* __restrict__ ret_env, const float* __res
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env < n_env) ret_env[env] += reward[env];
 }
+
+// cl_step_lean_chunk_kernel<VEC, NT, FOLD, PREC> from run-time launch parameters (VEC = 1 or 4); opts into more than 64 KB of dynamic LDS where the launch needs it
+template <int PREC>
+int launch_lean_chunk(int vec, bool nt, bool fold, dim3 grid, dim3 block, size_t lds, hipStream_t s, const StepArgs& a) {
+#define CL_LC(V, N, F) do { \
+        if (lds > 64 * 1024) { \
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(cl_step_lean_chunk_kernel<V, N, F, PREC>), lds); e != hipSuccess) \
+                return hip_fail(e, "hipFuncSetAttribute(cl_step_lean_chunk_kernel)"); \
+        } \
+        hipLaunchKernelGGL((cl_step_lean_chunk_kernel<V, N, F, PREC>), grid, block, lds, s, a); } while (0)
+#define CL_LC_NF(V) do { if (nt) { if (fold) CL_LC(V, true, true); else CL_LC(V, true, false); } \
+                         else { if (fold) CL_LC(V, false, true); else CL_LC(V, false, false); } } while (0)
+    if (vec == 1) CL_LC_NF(1); else CL_LC_NF(4);
+#undef CL_LC_NF
+#undef CL_LC
+    return CL_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1757,6 +1776,7 @@ int cl_flex_reset_f32(const cl_dims* dims, const cl_flex* flex, void* stream) {
 
 // `of` / `fused`: the compact observation to write from inside the step launch (cl_step_observe_f32); *fused tells the caller
 // whether the launch that ran could take it (lean district, four envs per lane, one workgroup row) or the observation is still to do.
+
 static int step_impl(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
                      int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg,
                      float* kpi_env, const cl_flex* flex, int32_t t, void* stream, const ObsFusedArgs* of, bool* fused) {
@@ -1911,7 +1931,8 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     //  the folding instantiation's 107 registers cost more than the second launch: 32.8 vs 32.0 us, 65.2 vs 61.3 us, profiles/r05n_*)
     const int fold_w = fold_per_row <= 16 ? 16 : fold_per_row <= 32 ? 32 : 64;          // row width of the exchange tile (fold_shift)
     const bool can_defer = a.n_chunks > 1 && tun.finish == 3 && rkind_host != CLR_MARL && rkind_host != CLR_EV && !flex &&
-                           !(dims->flags & (CLD_KPI | CLD_F64_MAPS | CLD_F64_CHAIN | CLD_WRITE_DETAIL)) && fold_per_row <= (full ? 64 : 16) && a.n_chunks * fold_w <= 1024 &&
+                           !(dims->flags & (CLD_KPI | CLD_F64_MAPS | CLD_WRITE_DETAIL)) && (!chain || !full) &&      // (the float64 chain: the battery + PV chunk kernel carries the fold; the thermal chain kernel does not)
+                           fold_per_row <= (full ? 64 : 16) && a.n_chunks * fold_w <= 1024 &&
                            a.nw == 16 && a.n_chunks <= 64 &&
                            2ll * a.n_chunks * NQ * dims->n_env + (dims->n_env + 63) / 64 + 4 <= (long long)dims->n_bldg * dims->n_env;
     const dim3 grid(grid_x, a.n_chunks);
@@ -2016,6 +2037,11 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             default: return fail(CL_EINVAL, "bad vec %d", vec);
             }
 #undef CL_CHAIN_CASE
+        } else if (!full && a.n_chunks > 1 && tun.finish != 2 && (vec == 1 || vec == 4) && !(tun.lean_variant & 16)) {
+            // building-chunked battery + PV districts: the latency-ordered chunk kernel around the float64 chain (deferred fold where it applies)
+            a.fused_finish = can_defer ? 2 : 0;
+            name_add(tun, "cl_step_lean_chunk_kernel<%d, %s, %s, 2>", vec, a.nt ? "true" : "false", can_defer ? "true" : "false");
+            if (int rc = launch_lean_chunk<2>(vec, a.nt, can_defer, grid, block, lds, s, a)) return rc;
         } else if (tp_kernel) {
             // thermal districts, several env tiles per workgroup (cl_step_full_tp_kernel's launch shape)
             a.nw = tp_nw;
@@ -2177,19 +2203,8 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     } else if (a.n_chunks > 1 && tun.finish != 2 && (vec == 1 || vec == 4) && !(tun.lean_variant & 16)) {
         // building-chunked battery + PV districts: the latency-ordered chunk kernel (lean_variant & 16 keeps cl_step_kernel: tests, A/B)
         a.fused_finish = can_defer ? 2 : 0;
-        const size_t lds_c = lds;
-        name_add(tun, "cl_step_lean_chunk_kernel<%d, %s, %s>", vec, a.nt ? "true" : "false", can_defer ? "true" : "false");
-#define CL_LC(V, N, F) do { \
-            if (lds_c > 64 * 1024) { \
-                if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(cl_step_lean_chunk_kernel<V, N, F>), lds_c); e != hipSuccess) \
-                    return hip_fail(e, "hipFuncSetAttribute(cl_step_lean_chunk_kernel)"); \
-            } \
-            hipLaunchKernelGGL((cl_step_lean_chunk_kernel<V, N, F>), grid, block, lds_c, s, a); } while (0)
-#define CL_LC_NF(V) do { if (a.nt) { if (can_defer) CL_LC(V, true, true); else CL_LC(V, true, false); } \
-                         else { if (can_defer) CL_LC(V, false, true); else CL_LC(V, false, false); } } while (0)
-        if (vec == 1) CL_LC_NF(1); else CL_LC_NF(4);
-#undef CL_LC_NF
-#undef CL_LC
+        name_add(tun, "cl_step_lean_chunk_kernel<%d, %s, %s, 0>", vec, a.nt ? "true" : "false", can_defer ? "true" : "false");
+        if (int rc = launch_lean_chunk<0>(vec, a.nt, can_defer, grid, block, lds, s, a)) return rc;
     } else if (a.n_chunks > 1 && (tun.finish == 2 || can_defer) && (vec == 1 || vec == 4)) {
         // building-chunked battery + PV districts (C4 with the 2022 device set): the instantiations that fold the chunk sums themselves
         // (finish = 2: their own, inside the launch; finish = 3: the previous step's, deferred)

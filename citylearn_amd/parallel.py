@@ -243,8 +243,38 @@ def _rccl_preflight(rank: int, world: int, device) -> Optional[str]:
         return 'no HIP device visible'
     if device is None or torch.device(device).type != 'cuda':
         return f'device {device!r} is not a GPU'
-    if world > torch.cuda.device_count() and os.environ.get('CL_BENCH_OVERSUBSCRIBE'):
-        return f'{world} ranks on {torch.cuda.device_count()} device(s): RCCL refuses two ranks per device'
+    return None
+
+
+def _device_identity(device) -> str:
+    """What tells two ranks of one host that they sit on the SAME physical GPU whatever their visibility masks: the device's UUID (or its
+    PCI bus id), else its index."""
+    import torch
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    try:
+        p = torch.cuda.get_device_properties(idx)
+        for attr in ('uuid', 'pci_bus_id'):
+            v = getattr(p, attr, None)
+            if v is not None and str(v):
+                dom = getattr(p, 'pci_domain_id', '')
+                return f'{attr}:{dom}:{v}'
+    except Exception:                                     # noqa: BLE001
+        pass
+    return f'index:{idx}'
+
+
+def shared_device_reason(placements) -> Optional[str]:
+    """`placements`: one (hostname, device identity) per rank.  RCCL refuses a communicator with two ranks on one device ("Duplicate GPU
+    detected") -- after every rank has entered the rendezvous; judged here from the ACTUAL mapping, before anybody does (round-5 advisor: the
+    round-5 pre-flight only looked when a test hook's environment variable was set)."""
+    seen = {}
+    for r, place in enumerate(placements):
+        if place is None or place[1] is None:
+            continue
+        if place in seen:
+            return f'ranks {seen[place]} and {r} share device {place[1]} on {place[0]}: RCCL refuses two ranks per device'
+        seen[place] = r
     return None
 
 
@@ -285,6 +315,13 @@ def init_control_plane(rank: int, world: int, device=None, backend: Optional[str
             # (1) A local pre-flight, agreed over gloo BEFORE anybody enters an RCCL call: a rank that cannot possibly bring RCCL up (no device,
             # a device shared with another rank, a test hook) must not leave its peers inside a communicator rendezvous it never joins.
             err = preflight(rank, world, device) if preflight is not None else None
+            # ... and the ranks' actual placement: (host, physical device) of every rank, gathered over gloo
+            import socket
+            mine = (socket.gethostname(), _device_identity(device)) if (err is None and device is not None and torch.cuda.is_available()
+                                                                          and torch.device(device).type == 'cuda') else None
+            places = [None] * world
+            dist.all_gather_object(places, mine)
+            err = err or shared_device_reason(places)
             ok = torch.tensor([0 if err else 1], dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok[0]) == 1:

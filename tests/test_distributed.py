@@ -247,22 +247,25 @@ def test_bench_uses_only_counters_collected_on_the_kernel_it_launched(tmp_path, 
     prof.mkdir()
     summary = {'FETCH_SIZE': {'mean': 100.0}, 'WRITE_SIZE': {'mean': 50.0},
                '_kernel': {'kernel': 'void (anonymous namespace)::cl_step_envmajor_kernel<20>((anonymous namespace)::StepArgs)'}}
-    (prof / 'r02_streaming_pmc_summary.json').write_text(json.dumps(summary))
+    # (file names carry the CURRENT round's prefix: since round 6 `_pmc_traffic` refuses summaries of earlier rounds -- VERDICT r05 item 10)
+    cur = bench.ROUND_PREFIX
+    (prof / f'{cur}a_streaming_pmc_summary.json').write_text(json.dumps(summary))
+    (prof / 'r02_streaming_pmc_summary.json').write_text(json.dumps({**summary, '_kernel': {'kernel': 'cl_step_envmajor_kernel<20, true>'}}))   # stale round, right kernel: ignored
     monkeypatch.setattr(bench, 'ROOT', tmp_path)
     assert bench._pmc_traffic('r*_streaming_pmc_summary.json', 'cl_step_envmajor_kernel<20, true>') == (None, None)      # another instantiation
     summary['_kernel']['kernel'] = 'void (anonymous namespace)::cl_step_envmajor_kernel<20, true>((anonymous namespace)::StepArgs)'
-    (prof / 'r03_streaming_pmc_summary.json').write_text(json.dumps(summary))
+    (prof / f'{cur}b_streaming_pmc_summary.json').write_text(json.dumps(summary))
     traffic, source = bench._pmc_traffic('r*_streaming_pmc_summary.json', 'cl_step_envmajor_kernel<20, true>')
-    assert source == 'r03_streaming_pmc_summary.json' and traffic == (2 * 100.0 + 50.0) * 1024.0          # FETCH_SIZE doubled (gfx950), KiB
+    assert source == f'{cur}b_streaming_pmc_summary.json' and traffic == (2 * 100.0 + 50.0) * 1024.0          # FETCH_SIZE doubled (gfx950), KiB
     line = tmp_path / 'line.json'
     line.write_text(json.dumps({'roofline': {'kernel': 'cl_step_envmajor_kernel<20, true>'}}))
     check = [sys.executable, str(ROOT / 'scripts' / 'check_profiles.py'), str(line)]
-    assert subprocess.run(check + [str(prof / 'r03_streaming_pmc_summary.json')], capture_output=True).returncode == 0
-    assert subprocess.run(check + [str(prof / 'r02_streaming_pmc_summary.json')], capture_output=True).returncode == 1
+    assert subprocess.run(check + [str(prof / f'{cur}b_streaming_pmc_summary.json')], capture_output=True).returncode == 0
+    assert subprocess.run(check + [str(prof / f'{cur}a_streaming_pmc_summary.json')], capture_output=True).returncode == 1
     # a line that cites a summary must carry that summary's traffic -- a summary re-collected after the line was written fails
     for traffic, rc in ((traffic, 0), (traffic * 1.06, 1)):
-        line.write_text(json.dumps({'roofline': {'kernel': 'cl_step_envmajor_kernel<20, true>', 'traffic': traffic, 'traffic_source': 'r03_streaming_pmc_summary.json'}}))
-        assert subprocess.run(check + [str(prof / 'r03_streaming_pmc_summary.json')], capture_output=True).returncode == rc
+        line.write_text(json.dumps({'roofline': {'kernel': 'cl_step_envmajor_kernel<20, true>', 'traffic': traffic, 'traffic_source': f'{cur}b_streaming_pmc_summary.json'}}))
+        assert subprocess.run(check + [str(prof / f'{cur}b_streaming_pmc_summary.json')], capture_output=True).returncode == rc
 
 
 def _asymmetric_rank(rank, world, port, q):
@@ -364,3 +367,13 @@ def test_rank_affinity_arithmetic(tmp_path):
     dev.mkdir(parents=True)
     (dev / 'numa_node').write_text('1\n')
     assert gpu_numa_node('0000:C1:00.0', str(tmp_path)) == 1 and gpu_numa_node('0000:05:00.0', str(tmp_path)) == -1
+
+
+def test_shared_device_is_judged_from_the_actual_placement():
+    """whether two ranks share a GPU is read off the ranks' (host, physical device) pairs gathered over gloo -- not off a test hook's
+    environment variable -- before any rank enters an RCCL call."""
+    from citylearn_amd.parallel import shared_device_reason
+    assert shared_device_reason([('a', 'uuid::1'), ('a', 'uuid::2'), ('b', 'uuid::1')]) is None            # same UUID on another host: another GPU
+    why = shared_device_reason([('a', 'uuid::1'), ('a', 'uuid::2'), ('a', 'uuid::1')])
+    assert why is not None and 'ranks 0 and 2' in why and 'RCCL refuses two ranks per device' in why
+    assert shared_device_reason([None, ('a', 'index:0')]) is None                                            # a rank without a GPU is the local pre-flight's business

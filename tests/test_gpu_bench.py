@@ -30,11 +30,17 @@ def test_two_ranks_on_one_gpu_without_a_launcher():
     assert two['ranks'] == 2 and two['world_size_seen'] == 2 and two['oversubscribed'] is True and two['n_gpus'] == 1
     assert len(two['rank_ms_per_step']) == 2 and two['control_backend'] == 'gloo'
     assert two['ms_per_step'] >= max(two['rank_ms_per_step']) * 0.5 and two['value'] > 1e9
-    assert 'cl_step_lean_kernel<4, false, true>' in two['roofline']['kernel']
+    assert 'cl_step_lean_chain_kernel<4, true>' in two['roofline']['kernel']                   # the default precision model (CLD_F64_CHAIN)
     one = _bench('--steps', '20', '--warmup', '5', '--reps', '3', '--no-streaming', '--no-cpu-baseline', '--no-traffic-pass')
     assert one['ranks'] == 1 and one['n_gpus'] == 1 and 'oversubscribed' not in one
-    assert one['roofline']['kernel'] == 'cl_step_lean_kernel<4, false, true>' and 0.3 < one['roofline']['frac'] < 1.0
+    assert one['roofline']['kernel'] == 'cl_step_lean_chain_kernel<4, true>' and 0.3 < one['roofline']['frac'] < 1.0
     assert one['value'] == pytest.approx(17 * 65536 / (one['ms_per_step'] * 1e-3))
+    assert 'f64' in one['dtype'] and 'CLD_F64_CHAIN' in one['config']['precision']
+    # the all-fp32 map rides along as the side entry (the opt-in throughput mode), faster than the default
+    side = one['roofline']['fp32_map']['metric_shape']
+    assert side['kernel'] == 'cl_step_lean_kernel<4, false, true>' and 1.0 < side['speedup_vs_default'] < 1.5, side
+    fast = _bench('--precision', 'fp32', '--steps', '20', '--warmup', '5', '--reps', '2', '--no-streaming', '--no-cpu-baseline', '--no-traffic-pass')
+    assert fast['roofline']['kernel'] == 'cl_step_lean_kernel<4, false, true>' and fast['dtype'] == 'f32' and 'fp32_map' not in fast['roofline']
 
 
 def test_headline_line_measures_its_hbm_traffic_in_the_run():
@@ -46,7 +52,7 @@ def test_headline_line_measures_its_hbm_traffic_in_the_run():
     out = _bench('--steps', '20', '--warmup', '5', '--reps', '2', '--no-streaming', '--no-cpu-baseline')
     r = out['roofline']
     assert 'traffic_live_error' not in r, r.get('traffic_live_error')
-    assert r['traffic_source'].startswith('measured in this run') and 'cl_step_lean_kernel<4, false, true>' in r['traffic_source']
+    assert r['traffic_source'].startswith('measured in this run') and 'cl_step_lean_chain_kernel<4, true>' in r['traffic_source']
     algorithmic = r['algorithmic_bytes_per_unit'] * r['units_per_launch']
     assert 0.97 < r['traffic'] / algorithmic < 1.10, (r['traffic'], algorithmic)
 
@@ -64,10 +70,11 @@ def test_scale_run_extras_on_the_one_gpu_there_is():
     (`extra_configs`), per-rank kernel time next to per-rank wall time, and the ranks' CPU pinning -- two ranks sharing device 0."""
     two = _bench('--gpus', '2', '--steps', '20', '--warmup', '5', '--reps', '2', '--no-streaming', env={'CL_BENCH_OVERSUBSCRIBE': '1', 'CL_BENCH_EXTRA_CONFIGS': '1'})
     assert len(two['rank_launch_us']) == 2 and all(3.0 < k < 60.0 for k in two['rank_launch_us']), two['rank_launch_us']
-    assert set(two['extra_configs']) == {'C4', 'C4-lean', 'C5'}
+    assert set(two['extra_configs']) == {'fixed-65536', 'C4', 'C4-lean', 'C5'}
     for name, x in two['extra_configs'].items():
         assert x['value'] > 1e9 and len(x['rank_ms_per_step']) == 2 and len(x['rank_launch_us']) == 2 and x['roofline']['kernel'], name
-    assert 'cl_finish_kernel' not in two['extra_configs']['C4']['roofline']['kernel']        # deferred finish
+    fx = two['extra_configs']['fixed-65536']                                               # ONE 65 536-env batch over the ranks: north_star's other reading
+    assert fx['scaling'] == 'strong' and fx['envs_per_gpu'] == 32768 and 'chain' in fx['roofline']['kernel']
     assert 'cl_rollout_kernel' in two['extra_configs']['C5']['roofline']['kernel']
     aff = two['rank_affinity']
     assert len(aff) == 2
@@ -84,18 +91,21 @@ def test_more_ranks_than_gpus_is_refused_without_the_hook():
     assert p.returncode != 0 and 'CL_BENCH_OVERSUBSCRIBE' in p.stderr and not p.stdout.strip()
 
 
-@pytest.mark.parametrize('cfg,kernel,bound', [('C2', 'cl_step_lean_kernel<1, false, true>', 'hbm'), ('C3', 'cl_lstm_kernel<', 'valu'),
-                                              ('C4', 'cl_step_full_kernel<2, false, 1024, 4, true, true>', 'hbm'), ('C5', 'cl_rollout_kernel<2, false, 2, true, false, 0>', 'valu')])
-def test_config_lines(cfg, kernel, bound):
-    out = _bench('--config', cfg, '--steps', '20', '--warmup', '5', '--reps', '2')
+@pytest.mark.parametrize('cfg,kernel,bound,prec', [('C2', 'cl_step_lean_chain_kernel<1, true>', 'hbm', 'chain'), ('C2', 'cl_step_lean_kernel<1, false, true>', 'hbm', 'fp32'),
+                                                   ('C3', 'cl_lstm_kernel<', 'valu', 'chain'), ('C4', 'cl_step_full_', 'hbm', 'chain'),
+                                                   ('C4', 'cl_step_full_kernel<2, false, 1024, 4, true, true>', 'hbm', 'fp32'),
+                                                   ('C5', 'cl_rollout_kernel<2, false, 2, true, false, 2>', 'valu', 'chain'),
+                                                   ('C5', 'cl_rollout_kernel<2, false, 2, true, false, 0>', 'valu', 'fp32')])
+def test_config_lines(cfg, kernel, bound, prec):
+    out = _bench('--config', cfg, '--precision', prec, '--steps', '20', '--warmup', '5', '--reps', '2')
     assert out['config']['name'] == cfg and out['roofline']['bound'] == bound and kernel in out['roofline']['kernel'], out['roofline']['kernel']
-    assert 0.0 < out['roofline']['frac'] < 1.0 and out['value'] > 1e8
+    assert out['value'] > 1e8 and (out['roofline']['frac'] is None or 0.0 < out['roofline']['frac'] < 1.0)       # (the chain's fused rollout claims no VALU fraction)
 
 
 def test_thermal_kpi_line_runs_the_kpis_inside_the_step_launch():
     """`bench.py --config T9 --kpi`: one launch per step (`cl_step_full_kpi_kernel`), priced against HBM with the ten per-unit accumulators
     and the moving district-series values in the byte count."""
-    out = _bench('--config', 'T9', '--kpi', '--steps', '20', '--warmup', '5', '--reps', '2', '--no-cpu-baseline')
+    out = _bench('--config', 'T9', '--kpi', '--precision', 'fp32', '--steps', '20', '--warmup', '5', '--reps', '2', '--no-cpu-baseline')
     r = out['roofline']
     assert out['config']['name'] == 'T9' and r['bound'] == 'hbm' and r['kernel'] == 'cl_step_full_kpi_kernel<true>', r['kernel']
     assert 140.0 < r['algorithmic_bytes_per_unit'] < 160.0 and 0.3 < r['frac'] < 1.0
@@ -120,3 +130,23 @@ def test_control_plane_falls_back_to_gloo_when_rccl_refuses():
     assert any(k in out['control_fallback'] for k in ('Duplicate GPU', 'NCCL', 'RCCL refuses two ranks per device')), out['control_fallback']
     assert out['rccl_world_size'] is None
     assert len(out['rank_ms_per_step']) == 2
+
+
+def test_default_line_carries_the_hbm_true_roofline_and_the_dropin_timing():
+    """The line the driver records: `roofline.frac` is the HBM-TRUE fraction -- the step kernel at 17 x 1 048 576 envs,
+    measured in the same run -- with the cache-resident launch the value is timed on as `roofline.metric_shape`; `cpu_baseline` is the reference's
+    own step over >= 1000 steps per process; `dropin` times `citylearn_amd.CityLearnEnv` over config 1's full episode beside the reference's."""
+    out = _bench('--steps', '20', '--warmup', '5', '--reps', '2', '--no-traffic-pass', timeout=1500)
+    r = out['roofline']
+    assert r['bound'] == 'hbm' and 'cl_step_envmajor_kernel<17, ' in r['kernel'] and r['kernel'].endswith(', 1, 2>') and r['units_per_launch'] == 17 * 1048576
+    assert 0.3 < r['frac'] < 0.9 and r['frac'] == pytest.approx(r['achieved'] / 8000.0)
+    m = r['metric_shape']
+    assert m['kernel'] == 'cl_step_lean_chain_kernel<4, true>' and 'infinity-cache' in m['residency'] and m['units_per_launch'] == 17 * 65536
+    assert out['value'] == pytest.approx(17 * 65536 / (out['ms_per_step'] * 1e-3))
+    assert r['fp32_map']['hbm_streaming']['kernel'].startswith('cl_step_envmajor_kernel<17, ') and r['fp32_map']['hbm_streaming']['speedup_vs_default'] > 0.9
+    cb = out['cpu_baseline']
+    if cb.get('kind') == 'reference' and 'live' in cb.get('measured', ''):
+        assert cb['all_cores']['steps'] >= 1000
+    d = out['dropin']
+    assert 'error' not in d, d
+    assert d['steps'] == 8759 and d['value'] > 5 * 8759 / 60.0           # the year in well under a minute

@@ -31,11 +31,12 @@ def test_valid_episodes_trip_nothing_and_planes_are_unchanged(name, f64):
     steps = list(range(60)) + (list(range(385, 410)) if name == 'g2023_p2' else [])
     for t in steps:
         a = acts[t][:, None].expand(-1, E).contiguous()
-        if t == 385:
-            chk.state.copy_(ref.state)
         chk.step(a, t); ref.step(a, t)
         assert int(chk.violations.abs().max()) == 0, t
-        assert torch.equal(chk.state, ref.state) and torch.equal(chk.out_bldg[:abi.CLO_RESERVED], ref.out_bldg[:abi.CLO_RESERVED]) and torch.equal(chk.out_env, ref.out_env), t
+        # (state, net, reward and the district sums bit for bit; the fifteen detail planes to a few ulp: which of their products the compiler fuses
+        #  into multiply-adds differs from instantiation to instantiation of the general kernel -- tests/test_gpu_parity.py says the same of it)
+        assert torch.equal(chk.state, ref.state) and torch.equal(chk.out_bldg[:2], ref.out_bldg[:2]) and torch.equal(chk.out_env, ref.out_env), t
+        torch.testing.assert_close(chk.out_bldg[2:abi.CLO_RESERVED], ref.out_bldg[2:abi.CLO_RESERVED], rtol=2e-6, atol=2e-6)
     assert chk.last_kernels.endswith('false, true>') and chk.last_kernels.startswith('cl_step_kernel<1, true, true, false'), chk.last_kernels
 
 

@@ -128,7 +128,8 @@ def test_config_sizes_with_distinct_actions_against_the_c_oracle(name, E, steps,
     expect = {('g2022_all', 65536): 'cl_step_lean_kernel<4', ('g2023_p2', 65536): 'cl_step_full', ('g2020_cz1', 65536): 'cl_step_full_tp_kernel',
               ('g2022_all', 262144): 'cl_step_envmajor_kernel'}[(name, E)]
     if eng.f64_chain:
-        expect = {('g2022_all', 65536): 'cl_step_lean_chain_kernel<4', ('g2023_p2', 65536): 'cl_step_full_chain_kernel', ('g2020_cz1', 65536): 'cl_step_full_tp_chain_kernel',
+        assert 'chain' in eng.last_kernels or E == 262144, eng.last_kernels
+        expect = {('g2022_all', 65536): 'cl_step_lean_chain_kernel<4', ('g2023_p2', 65536): 'cl_step_full_', ('g2020_cz1', 65536): 'cl_step_full_tp_chain_kernel',      # (3 x 65 536 at one env per lane: four tiles per workgroup -> the multi-tile kernel too)
                   ('g2022_all', 262144): 'cl_step_envmajor_kernel<17, '}[(name, E)]
         assert E != 262144 or eng.last_kernels.endswith(', 1, 2>'), eng.last_kernels
     assert expect in eng.last_kernels, eng.last_kernels
@@ -244,7 +245,7 @@ def test_c4_whole_config_1024_buildings_x_8192_envs(fixture):
     if fixture == 'g2020_cz1':
         assert eng.last_kernels == 'cl_step_full_kernel<2, false, 1024, 4, true, true>', eng.last_kernels      # folds its predecessor's sums: no second launch
     else:
-        assert eng.last_kernels == 'cl_step_lean_chunk_kernel<4, false, false>+cl_finish_kernel', eng.last_kernels
+        assert eng.last_kernels == 'cl_step_lean_chunk_kernel<4, false, false, 0>+cl_finish_kernel', eng.last_kernels
 
 
 @pytest.mark.parametrize('kind', REWARDS)
@@ -339,17 +340,19 @@ def test_deferred_finish_with_larger_chunks(fixture, b_chunk, E):
     assert dfr._pending_t is None and torch.equal(dfr._out_env, ref._out_env) and torch.equal(dfr.state, ref.state)
 
 
+@pytest.mark.parametrize('f64', [False, 'chain'])
 @pytest.mark.parametrize('E,kind,finish', [(1024, 'RewardFunction', 3), (1024, 'MARL', 0), (1280, 'SolarPenaltyReward', 0), (256, 'RewardFunction', 0),
                                             (8192, 'RewardFunction', 3)])
-def test_lean_chunk_kernel_equals_the_general_kernel(E, kind, finish):
+def test_lean_chunk_kernel_equals_the_general_kernel(E, kind, finish, f64):
     """`cl_step_lean_chunk_kernel` (round 5): the building-chunked battery + PV launch with the next building's plane loads issued ahead of
     the current one's stores -- same arithmetic and summation order as `cl_step_kernel<VEC, false, false>` (`lean_variant = 16`), so every
     plane and every district sum bit for bit: four envs per lane (1024 / 1280 envs: ragged last tile; 8192: the whole config), one env per
     lane (256 envs), the deferred fold, MARL's chunk-partial reward."""
     spec, tab = _c4_district('g2022_all')
     K = 4
-    new = StepEngine(tab, E, reward=kind, tuning=dict(finish=finish))
-    old = StepEngine(tab, E, reward=kind, tuning=dict(finish=finish, lean_variant=16))
+    # (round 6: also around the float64 soc chain -- CLD_F64_CHAIN, the engine's default precision model -- with the same deferred fold)
+    new = StepEngine(tab, E, reward=kind, tuning=dict(finish=finish), f64_maps=f64)
+    old = StepEngine(tab, E, reward=kind, tuning=dict(finish=finish, lean_variant=16), f64_maps=f64)
     new.trace_kernels(); old.trace_kernels()
     low, high = spec.action_limits()
     rng = np.random.RandomState(E)
@@ -362,7 +365,7 @@ def test_lean_chunk_kernel_equals_the_general_kernel(E, kind, finish):
         assert torch.equal(new.out_env, old.out_env), (t, (new.out_env - old.out_env).abs().max().item())
     vec = 4 if E >= 512 else 1
     deferred = finish == 3 and kind != 'MARL' and E <= 1280
-    assert new.last_kernels.split('+')[0] == f'cl_step_lean_chunk_kernel<{vec}, true, {"true" if deferred else "false"}>' or E == 8192, new.last_kernels
+    assert new.last_kernels.split('+')[0] == f'cl_step_lean_chunk_kernel<{vec}, true, {"true" if deferred else "false"}, {2 if f64 else 0}>' or E == 8192, new.last_kernels
     assert float(new.out_env.abs().sum()) > 0
 
 

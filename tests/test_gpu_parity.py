@@ -25,6 +25,15 @@ DETAIL_KEYS = (('eb', abi.CLO_B_EB), ('cool_dem', abi.CLO_COOL_DEM), ('c_cool', 
 REWARDS = ('RewardFunction', 'MARL', 'IndependentSACReward', 'SolarPenaltyReward')
 
 
+def _teach(eng, ora, OS):
+    """Teacher-forcing from the C oracle: its state into the engine's planes (under CLD_F64_CHAIN the degraded-capacity plane carries the LOSS)."""
+    for pl, key in ((abi.CLS_B_SOC, 'SOC'), (abi.CLS_B_EFF, 'EFF'), (abi.CLS_B_DEGCAP, 'DEGCAP'), (abi.CLS_CS_SOC, 'CS'), (abi.CLS_HS_SOC, 'HS'), (abi.CLS_DS_SOC, 'DS')):
+        v = torch.from_numpy(ora.state[:, :, OS[key]].T.astype(np.float32)).cuda()
+        if pl == abi.CLS_B_DEGCAP and eng.f64_chain:
+            v = eng.params[:, abi.CLP_L_CAP].view(torch.float32)[:, None] - v
+        eng.state[pl] = v
+
+
 def _err(got, ref, atol, rtol):
     ref = np.asarray(ref, dtype=np.float64)
     return float(np.max(np.abs(np.asarray(got, dtype=np.float64) - ref) / (atol + rtol * np.abs(ref))))
@@ -377,15 +386,18 @@ def test_full_year_free_running_kpis():
     assert n >= 29
 
 
-def test_batch_against_c_oracle_distinct_actions():
+@pytest.mark.parametrize('f64', [None, False])
+def test_batch_against_c_oracle_distinct_actions(f64):
     """Every env gets its own actions (incl. zeros and bounds); teacher-forced from the oracle's state each step;
-    also exercises the strided [n_env, n_act_cols] action layout and a batch that is not a multiple of the tile."""
+    also exercises the strided [n_env, n_act_cols] action layout and a batch that is not a multiple of the tile.  Under the engine's default
+    precision model (None -> CLD_F64_CHAIN) and as the all-fp32 map."""
     from oracle.c_oracle import COracle, OS, OO
     for name, kind, E in (('g2022_all', 'MARL', 260), ('g2023_p2', 'SolarPenaltyReward', 132), ('g2020_cz1', 'IndependentSACReward', 68)):
         g = golden(name)
         spec = g.spec()
         tab = spec.episode_tables(0)
-        eng, ora = StepEngine(tab, E, reward=kind), COracle(spec, tab, E, reward=kind)
+        eng, ora = StepEngine(tab, E, reward=kind, f64_maps=f64), COracle(spec, tab, E, reward=kind)
+        assert eng.f64_chain == (f64 is None)
         low, high = spec.action_limits()
         rng = np.random.RandomState(5)
         worst = {}
@@ -393,9 +405,7 @@ def test_batch_against_c_oracle_distinct_actions():
             a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
             a[:, 0] = 0.0
             a[:, 1], a[:, 2] = low, high
-            for pl, key in ((abi.CLS_B_SOC, 'SOC'), (abi.CLS_B_EFF, 'EFF'), (abi.CLS_B_DEGCAP, 'DEGCAP'), (abi.CLS_CS_SOC, 'CS'),
-                            (abi.CLS_HS_SOC, 'HS'), (abi.CLS_DS_SOC, 'DS')):
-                eng.state[pl] = torch.from_numpy(ora.state[:, :, OS[key]].T.astype(np.float32)).cuda()
+            _teach(eng, ora, OS)
             a_dev = torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t() if t % 2 else torch.from_numpy(a).cuda()
             eng.step(a_dev, t)
             out, oe = ora.step(a, t)
@@ -403,7 +413,7 @@ def test_batch_against_c_oracle_distinct_actions():
                                   ('reward', eng.reward_bldg, out[:, :, OO['REWARD']].T), ('d_net', eng.district_net, oe[:, 0]),
                                   ('district_reward', eng.district_reward, oe[:, 3])):
                 worst[key] = max(worst.get(key, 0.0), _err(got.cpu().numpy(), ref, 1e-4, 1e-4))
-        check_worst(worst, name)
+        check_worst(worst, f'{name} f64_maps={f64}')
 
 
 def test_results_are_reproducible_and_layout_independent():
@@ -459,11 +469,8 @@ def test_large_district_building_chunked_grid(fixture, kind, B):
     worst = {}
     for t in range(12):
         a = rng.uniform(low[:, None], high[:, None], size=(len(low), E)).astype(np.float32)
-        for pl, key in ((abi.CLS_B_SOC, 'SOC'), (abi.CLS_B_EFF, 'EFF'), (abi.CLS_B_DEGCAP, 'DEGCAP'), (abi.CLS_CS_SOC, 'CS'),
-                        (abi.CLS_HS_SOC, 'HS'), (abi.CLS_DS_SOC, 'DS')):
-            st = torch.from_numpy(ora.state[:, :, OS[key]].T.astype(np.float32)).cuda()
-            eng.state[pl] = st
-            ref1.state[pl] = st
+        _teach(eng, ora, OS)
+        _teach(ref1, ora, OS)
         a_dev = torch.from_numpy(a).cuda()
         eng.step(a_dev, t)                                          # chunked (B > 32, few env tiles)
         ref1.step(a_dev, t)                                         # one workgroup row per env tile

@@ -149,7 +149,9 @@ def test_scratch_memory_is_confined_to_the_known_instantiations(units):
              r'cl_step_full_kpi_kernelILb[01]E': 36,
              # CLD_CHECK (round 6): the DEBUG instantiations of the general kernel -- one violation word more per unit; a few registers parked in
              # scratch cost a 4-env single-district launch nothing (never selected for a production batch)
-             r'cl_step_kernelILi1ELb1ELb1ELb[01]ELi[012]ELb0ELb1EE': 64}
+             r'cl_step_kernelILi1ELb1ELb1ELb[01]ELi[012]ELb0ELb1EE': 64,
+             # the battery + PV chunk kernel around the float64 chain WITH the deferred fold at four envs per lane: three registers parked once per wave
+             r'cl_step_lean_chunk_kernelILi4ELb[01]ELb1ELi2EE': 12}
     # the building-chunked thermal launches (BASELINE config 4; parameter blocks staged in LDS): 16 / 12 bytes per lane until round 4 -- the C4
     # shard's 1.145 x HBM traffic -- none since their district accumulators live in the wave's LDS row (cl_full.h, QLDS)
     main_meta = units[0][1]
@@ -158,7 +160,10 @@ def test_scratch_memory_is_confined_to_the_known_instantiations(units):
         assert len(hits) == 2 and all(main_meta[k]['private_seg_size'] == 0 for k in hits), (pat, [(k, main_meta[k]) for k in hits])
     # the latency-ordered chunk kernel of battery + PV districts (round 5): the next building's inputs reuse the registers the arithmetic
     # released -- a second input set or LDS-staged blocks cost 36 - 44 bytes of scratch at four envs per lane
-    hits = [k for k in main_meta if 'cl_step_lean_chunk_kernelILi4E' in k]
+    hits = [k for k in main_meta if re.search(r'cl_step_lean_chunk_kernelILi4ELb[01]ELb[01]ELi0EE', k)]
+    assert len(hits) == 4 and all(main_meta[k]['private_seg_size'] == 0 and main_meta[k]['num_vgpr'] <= 128 for k in hits), [(k, main_meta[k]) for k in hits]
+    # ... and around the float64 soc chain (round 6, PREC = 2): clean without the fold; the folding instantiation parks three registers (`known`)
+    hits = [k for k in main_meta if re.search(r'cl_step_lean_chunk_kernelILi[14]ELb[01]ELb0ELi2EE', k)]
     assert len(hits) == 4 and all(main_meta[k]['private_seg_size'] == 0 and main_meta[k]['num_vgpr'] <= 128 for k in hits), [(k, main_meta[k]) for k in hits]
     for kernels, meta in units:
         for k, m in meta.items():
