@@ -1251,6 +1251,15 @@ __global__ void __launch_bounds__(256 / VEC) cl_step_envmajor_kernel(const StepA
     vstore<VEC>(a.out_env + (long long)CLQ_REWARD * a.n_env + env, q_rw);
 }
 
+// (Round 6, measured and dropped -- two attempts at the HBM-streaming shape, 17 x 1 048 576 envs, profiles/r06d_streaming_ab.log:
+//  (1) a PERSISTENT, software-pipelined form: 768 workgroups walking several env tiles each, the registers of building b re-filled with the next tile's
+//  planes as soon as building b of the current tile is computed, on the theory that the plain kernel's four resident generations run in lockstep -- a
+//  164 MB load burst, then arithmetic with the read path idle, four times over.  The 68 loop-carried plane registers + the unit's temporaries need 168
+//  registers (three waves per SIMD, still 112 / 160 bytes of scratch in the fp32 / chain instantiation), the compiler's s_waitcnt placement needs a
+//  static building count and a branch-free tile loop to keep the prefetches in flight at all, and the result is 155 - 178 us (fp32) / 228 - 271 us
+//  (chain) against 124 - 126 / 134 us: a wave that issues four loads per building paces its memory requests by its own arithmetic.
+//  (2) narrower workgroups (one or two waves instead of four, so that waves retire and start one at a time): 142 / 158 us against 134 us.
+//  What this shape wants is what it has: every load of a wave issued up front, sixteen waves per CU.)
 // (Round 5, measured and dropped -- a building-major kernel for the streaming regime: four-wave workgroups over 256 envs at four envs per lane,
 //  wave w taking buildings w, w + 4, ..., all plane loads up front like above but 1 KB per wave instruction instead of 256 B, parameters from an
 //  LDS copy, 148 VGPRs = three waves per SIMD.  17 x 1 048 576, alternating runs on one box (profiles/r05g_*): 114.9 / 129.1 / 129.2 us against
@@ -1857,7 +1866,14 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     int vec = full ? 1 : pick_vec(dims->n_env, dims->n_bldg, act_stride_env == 1);
     if (will_chunk && act_stride_env == 1) {               // few envs, many buildings: width from the unit count
         const long long units = (long long)dims->n_env * dims->n_bldg;
-        vec = full ? (units >= (1ll << 19) && dims->n_env >= 256 ? 2 : 1) : (units >= (1ll << 19) && dims->n_env >= 512 ? 4 : 1);
+        // (under the float64 chain the four-env pack pays off one octave later -- scripts/r06_cliffs.py, profiles/r06c_cliffs_chain.jsonl: 33 x 16 384 and
+        //  128 x 4 096, both 2^19 units, 13.8 / 12.6 us at four envs per lane against 12.2 / 9.8 us at one)
+        const long long lean4 = (dims->flags & CLD_F64_CHAIN) ? (1ll << 20) : (1ll << 19);
+        vec = full ? (units >= (1ll << 19) && dims->n_env >= 256 ? 2 : 1) : (units >= lean4 && dims->n_env >= 512 ? 4 : 1);
+        // (chain, districts just beyond the 32-building limit of the one-row kernels on batches of >= 2048 one-env tiles: two rows of ~17 buildings at four
+        //  envs per lane leave every wave one or two buildings behind a long load chain -- 33 x 262 144: 117.5 us against 74 us for the UNCHUNKED general
+        //  kernel at one env per lane, which the grid rule below selects by itself once the tile count reaches 2048; profiles/r06d_cliffs_chain.jsonl)
+        if (!full && (dims->flags & CLD_F64_CHAIN) && dims->n_bldg <= 40 && dims->n_env >= 131072) vec = 1;
     }
     if (tun.vec) vec = tun.vec;
     // CLD_F64_MAPS: the battery map in float64 -- general and lean step kernels at one or two envs per lane (a double is two VGPRs)
@@ -1910,6 +1926,12 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         if (lp_shape && tun.nt_stores == 0) a.nt = 1;
         a.b_chunk = tun.b_chunk > 0 ? tun.b_chunk : (int)(16 * r);
         a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
+        if (tun.b_chunk <= 0 && a.n_chunks > 1) {
+            // balanced chunks (round 6): 33 buildings were cut 16 + 16 + 1 -- a third workgroup row per env tile for one building; now round(33 / 16) = 2
+            // rows of 17 (one wave of the sixteen walks two buildings).  Districts that divide evenly (1024 / 32) keep their geometry.
+            const int nc = (int)((2ll * dims->n_bldg + a.b_chunk) / (2ll * a.b_chunk));       // round(n_bldg / b_chunk)
+            if (nc >= 2) { a.n_chunks = nc; a.b_chunk = (dims->n_bldg + nc - 1) / nc; a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk; }
+        }
         if (a.n_chunks == 1) a.b_chunk = dims->n_bldg;
         else a.nw = (tun.b_chunk > 0 && tun.nw > 0) ? tun.nw : 16;
         // the reserved plane holds the chunk partial sums (twice under the deferred finish), the tickets of the in-launch fold and, in its
@@ -1952,7 +1974,10 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // thermal kernel with the parameter blocks of the workgroup's buildings staged in LDS
     // (for the building-chunked launches only -- a workgroup of the 9 x 65 536 launch would wait for the staging round trip before it
     //  can issue its plane loads, while its scalar reads hit the constant cache: 10.7 vs 8.7 us; full_variant = 2 forces it, 3 forbids it)
-    const bool lp = full && !flex && !det && !f64 && tun.full_variant != 1 && tun.full_variant != 3 && vec <= 2 && (a.n_chunks > 1 || tun.full_variant == 2);
+    // (not under the float64 chain unless forced: its one-env-per-lane thermal kernel reads the blocks through the constant cache faster -- chunked 1024-,
+    //  512-, 256-building districts 1.06 - 1.21 x, profiles/r06c_cliffs_chain.jsonl -- and a 512-building chunk's 160 KB of staged blocks do not exist)
+    const bool lp = full && !flex && !det && !f64 && tun.full_variant != 1 && tun.full_variant != 3 && vec <= 2 &&
+                    ((a.n_chunks > 1 && !chain) || tun.full_variant == 2) && (size_t)a.b_chunk * CL_LP_WORDS * sizeof(uint32_t) <= 96 * 1024;
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float) + (lp ? (size_t)a.b_chunk * CL_LP_WORDS * sizeof(uint32_t) : 0) +
                        (can_defer ? 1024 * sizeof(float) : 0);          // (+ the [chunks][16 / 32 / 64 sums] exchange tile of the deferred fold)
     const dim3 block(64 * a.nw);
@@ -1971,7 +1996,11 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     const bool tp_small = !tp_forced && tiles1 > 192 && tiles1 <= 256 && dims->n_bldg >= 6 && dims->n_bldg <= 16;
     const int tp_vec = (tp_forced && tun.vec == 1) || tp_small || chain ? 1 : 2;       // (the float64 chain spills at two envs per lane)
     const int tp_auto_tiles = tp_small ? 1 : (int)((dims->n_env + 256 * 64 * tp_vec - 1) / (256 * 64 * tp_vec));      // one workgroup per CU
-    const int tp_tiles = tp_forced ? (tun.b_chunk > 0 ? tun.b_chunk : CL_ROW0_BLOCK / (64 * tp_vec)) : tp_auto_tiles;
+    // (chain, round 6: where one workgroup per CU would need more tiles than LDS holds -- 17 / 20 thermal buildings x 262 144 envs -- four tiles per
+    //  workgroup in several generations still beat the one-tile kernel 1.36 x / 1.16 x: profiles/r06c_cliffs_chain.jsonl)
+    const size_t tp_tile_bytes = ((size_t)dims->n_bldg * NQ + 1) * 64 * tp_vec * sizeof(float);
+    const bool tp_capped = chain && !tp_forced && !tp_small && (size_t)tp_auto_tiles * tp_tile_bytes > 150 * 1024 && 4 * tp_tile_bytes <= 150 * 1024 && dims->n_bldg >= 6;
+    const int tp_tiles = tp_forced ? (tun.b_chunk > 0 ? tun.b_chunk : CL_ROW0_BLOCK / (64 * tp_vec)) : tp_capped ? 4 : tp_auto_tiles;
     const int tp_nw = tp_forced && tun.nw ? tun.nw : (tp_small ? dims->n_bldg : 16);
     const unsigned tp_grid = (unsigned)((dims->n_env + tp_tiles * 64 * tp_vec - 1) / (tp_tiles * 64 * tp_vec));
     const size_t tp_lds = ((size_t)tp_tiles * dims->n_bldg * NQ + tp_tiles) * 64 * tp_vec * sizeof(float);
@@ -1980,7 +2009,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     if (tp_forced) {
         if (!tp_kernel || tp_nw > 16)
             return fail(CL_EINVAL, "full_variant = 5: %d tiles x %d envs per lane x %d waves is not a launch of cl_step_full_tp_kernel for this district", tp_tiles, tp_vec, tp_nw);
-    } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && (tp_small || tp_tiles * dims->n_bldg >= 12) && tp_grid > 192 && tp_grid <= 256;
+    } else tp_kernel = tp_kernel && tun.full_variant == 0 && !tun.vec && !tun.nw && (tp_small || tp_tiles * dims->n_bldg >= 12) && ((tp_grid > 192 && tp_grid <= 256) || tp_capped);
     // (up to 480 workgroups -- two 9-wave workgroups per CU are resident at once, so up to 512 the launch is still ONE generation: re-measured
     //  at the end of round 5, after the latency-ordered kernel lost the non-temporal hint on its loads (scripts/gpurun/r05_call24.sh,
     //  profiles/r05_nt_loads/r05y.log), 17 buildings x 98 304 / 106 496 / 114 688 / 131 072 / 163 840 / 196 608 / 262 144 envs: 10.6 / 11.0 /
@@ -1988,14 +2017,18 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     //  (352 workgroups, env-major from 106 496 envs) had the general kernel at 98 304 envs, 13.0 us)
     // streaming KPIs without the detail planes: the lean kernel updates the per-building accumulators itself, at any grid size
     const bool kpi_lean = (dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL) && !kpi_full;
-    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 480 || (tun.lean_variant & 2) || kpi_lean) && !((tun.lean_variant & 1) && !kpi_lean);
+    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 480 || (tun.lean_variant & 2) || kpi_lean || (chain && dims->n_bldg > 17 && dims->n_bldg <= 20)) &&
+                            !((tun.lean_variant & 1) && !kpi_lean);
     // without the detail planes only cl_step_lean_kpi_kernel updates the per-building accumulators (and writes the baseline plane
     // cl_kpi_env_kernel sums): a launch shape that cannot take it must not silently leave them stale
     if (kpi_lean && (full || flex || !lean_shape))
         return fail(CL_EINVAL, "CLD_KPI without CLD_WRITE_DETAIL needs a step launch that updates the accumulators itself (battery + PV: n_bldg=%d <= 2 x nw=%d "
                                "waves, no chunks; thermal: one env per lane, no chunks, no flexible loads, no CLD_F64_MAPS): drop the cl_tuning override or set CLD_WRITE_DETAIL",
                     dims->n_bldg, a.nw);
-    const bool envmajor_shape = !full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean && (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env > 122880));
+    // (chain: the 20-building instantiation holds 140 registers -- three waves per SIMD -- and loses to the building-major kernel, 41.6 vs 33.6 us at
+    //  20 x 262 144: only districts of up to 17 buildings go env-major by themselves; profiles/r06c_cliffs_chain.jsonl)
+    const bool envmajor_shape = !full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean &&
+                                (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env > 122880 && !(chain && dims->n_bldg > 17)));
     if (dims->flags & CLD_CHECK) {
         // debug mode: the general kernel with the reference's assertions compiled in, one env per lane (include/citylearn_amd.h CLD_CHECK)
         if (!det || (dims->flags & CLD_DETAIL_MIN) || a.n_chunks > 1 || kpi_full)

@@ -1,7 +1,10 @@
 """Bench hygiene: every PMC / kernel-stats summary under a profile directory must have been collected on the kernel the bench line
 next to it names (`roofline.kernel` is what the library reports having launched, `cl_tuning.kernel_name`).
 
-    python scripts/check_profiles.py [--duration-tol 0.05] <bench_line.json> <pmc_summary.json | kernel_stats.csv> [...]
+    python scripts/check_profiles.py [--duration-tol 0.05] [--entry metric_shape] <bench_line.json> <pmc_summary.json | kernel_stats.csv> [...]
+
+`--entry NAME` checks the sub-object `roofline.NAME` instead of `roofline` itself (round 6: the headline line's `roofline` is the HBM-true
+17 x 1 048 576 launch, `roofline.metric_shape` the cache-resident 17 x 65 536 launch the value is timed on).
 
 Exit code 1 (and a message per mismatch) when a summary belongs to another kernel: stale counters must not sit beside a newer kernel.
 A line whose `roofline.traffic_source` names a summary file must also carry THAT file's traffic ((2 x FETCH_SIZE + WRITE_SIZE) KiB): a
@@ -13,9 +16,16 @@ import json
 import sys
 
 
+ENTRY = None
+
+
+def roofline_of(line_path):
+    r = json.load(open(line_path))['roofline']
+    return r[ENTRY] if ENTRY else r
+
+
 def kernels_of(line_path):
-    d = json.load(open(line_path))
-    r = d['roofline']
+    r = roofline_of(line_path)
     names = [k for k in (r.get('kernel') or '').split('+') if k]
     return names
 
@@ -23,11 +33,15 @@ def kernels_of(line_path):
 def main():
     argv = sys.argv[1:]
     tol = None
-    if argv and argv[0] == '--duration-tol':
-        tol, argv = float(argv[1]), argv[2:]
+    global ENTRY
+    while argv and argv[0] in ('--duration-tol', '--entry'):
+        if argv[0] == '--duration-tol':
+            tol, argv = float(argv[1]), argv[2:]
+        else:
+            ENTRY, argv = argv[1], argv[2:]
     line, files = argv[0], argv[1:]
     want = kernels_of(line)
-    roof = json.load(open(line))['roofline']
+    roof = roofline_of(line)
     launch_us = roof.get('launch_us')
     bad = 0
     for f in files:

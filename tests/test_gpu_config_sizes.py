@@ -424,7 +424,7 @@ def test_deferred_finish_through_step_observe():
         ref.step(act, t)
         want = wa.write(t + 1).clone()
         got = dfr.step_observe(act, wb, t)
-        assert 'cl_finish_kernel' not in dfr.last_kernels and dfr.last_kernels.endswith(', true>'), dfr.last_kernels      # the FOLD instantiation, deferred
+        assert 'cl_finish_kernel' not in dfr.last_kernels and dfr.last_kernels.endswith(', true, 0>'), dfr.last_kernels      # the FOLD instantiation (fp32 map), deferred
         assert dfr._pending_t == t
         assert torch.equal(got, want) and torch.equal(dfr.state, ref.state), t
         if t % 2 == 0:                                                  # (odd steps are folded by the next launch instead)
@@ -628,3 +628,27 @@ def test_streaming_kpis_in_the_thermal_step_launch_with_detail_planes_and_episod
         assert torch.equal(fused.state, ref.state) and torch.equal(fused.out_env, ref.out_env) and torch.equal(fused.out_bldg[:-1], ref.out_bldg[:-1])
         assert torch.equal(fused.kpi_bldg, ref.kpi_bldg) and torch.equal(fused.kpi_env, ref.kpi_env)
         assert float(fused.kpi_bldg.abs().sum()) > 0
+
+
+def _selection_map():
+    import json
+    from pathlib import Path
+    f = Path(__file__).resolve().parent / 'golden' / 'kernel_selection_r06.json'
+    return json.loads(f.read_text()) if f.exists() else []
+
+
+@pytest.mark.parametrize('cell', _selection_map(), ids=lambda c: f"{c['kind']}-{c['B']}x{c['E']}")
+def test_kernel_selection_map(cell):
+    """the launch-geometry rules of `cl_step_f32` (csrc/cl_kernels.hip step_impl) pinned over the whole map they were checked
+    on -- B in {3 .. 1024} buildings x E in {4 096 .. 262 144} envs (100 000: not a power of two), battery + PV and thermal districts, the default
+    precision model -- not only at the four district sizes they were tuned at.  `tests/golden/kernel_selection_r06.json` is the kernel each cell
+    selected in the measuring session (scripts/r06_cliffs.py -> profiles/r06e_cliffs_chain.jsonl, where no forced alternative beat the default by
+    more than 10 %): a rule change that moves a cell shows up here and has to come with a new measurement."""
+    from citylearn_amd.synthetic import tile_district
+    base = golden('g2022_all' if cell['kind'] == 'lean' else 'g2020_cz1').spec()
+    B, E = cell['B'], cell['E']
+    spec = tile_district(base, B, jitter=0.0 if B <= len(base.buildings) else 0.1)
+    eng = _StepEngine(spec.episode_tables(0), E, tuning={'finish': 3} if B > 32 else None)
+    eng.trace_kernels()
+    eng.step(torch.zeros((eng.n_act_cols, E), device='cuda'), 1)
+    assert eng.last_kernels == cell['kernel'], (cell, eng.last_kernels)

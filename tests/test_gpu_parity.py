@@ -575,3 +575,4 @@ def test_multi_tile_thermal_kernel_with_episode_offsets():
         torch.testing.assert_close(tp.out_env, ref.out_env, rtol=1e-5, atol=1e-3)
     # the blocks really ran different windows
     assert not torch.equal(ref.out_bldg[abi.CLO_NET][:, :256], ref.out_bldg[abi.CLO_NET][:, 256:512])
+
