@@ -345,6 +345,41 @@ CL_DEV F marl_partial(F net) {       // sign(-net) * 0.01 * net^2 (cl::marl_rewa
 
 namespace {
 
+// (OBS, round 6) cl_step_observe_f32 on thermal / outage districts: the compact observation of the NEXT row -- every column an affine map of a plane
+// value the wave that stepped the building still holds (battery / tank states of charge, net, reward) -- written into the workgroup's
+// [envs][pitch] LDS tile and streamed out behind the district reduction, like the battery + PV launch does (lean_step_body).  `row0`: the first of
+// the lane's envs inside the tile; `ts_delta`: the env block's episode offset (cl_dims.env_row0).  The list is wave-uniform (kernel arguments).
+template <typename F>
+CL_DEV void obs_fill(const ObsFusedArgs& of, float* __restrict__ tile, int b, int row0, int ts_delta, const clv::St<F>& S, F net, F rw) {
+    const float* __restrict__ trow = of.table + (size_t)(of.row + ts_delta) * of.n_cols;
+    for (int d = of.start[b]; d < of.start[b + 1]; ++d) {
+        const int col = of.deps[d].col, src = of.deps[d].src;
+        const float scale = of.deps[d].scale, base = trow[col];
+        const int pl = (src >> 20) & 0xFF;
+        F v;
+        if ((src >> 28) == CLOB_KIND_OUT) v = pl == CLO_NET ? net : rw;
+        else v = pl == CLS_B_SOC ? S.soc : pl == CLS_B_EFF ? S.eff : pl == CLS_B_DEGCAP ? S.degcap : pl == CLS_CS_SOC ? S.cs : pl == CLS_HS_SOC ? S.hs : S.ds;
+        if constexpr (clv::Tr<F>::N == 1) tile[(size_t)row0 * of.pitch + col] = fmaf(v, scale, base);
+        else {
+#pragma unroll
+            for (int i = 0; i < clv::Tr<F>::N; ++i) tile[(size_t)(row0 + i) * of.pitch + col] = fmaf(v[i], scale, base);
+        }
+    }
+}
+
+// ... pad columns zeroed (like cl_observe_f32) by the whole workgroup before the barrier, the tile streamed out in 16-byte stores after it
+CL_DEV void obs_pad(const ObsFusedArgs& of, float* __restrict__ tile, int rows) {
+    const int np = of.pitch - of.n_cols;
+    for (int i = threadIdx.x; i < rows * np; i += blockDim.x) tile[(size_t)(i / np) * of.pitch + of.n_cols + i % np] = 0.0f;
+}
+CL_DEV void obs_flush(const ObsFusedArgs& of, const float* __restrict__ tile, int env_first, int rows) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* src4 = reinterpret_cast<const f4*>(tile);
+    f4* dst4 = reinterpret_cast<f4*>(of.obs + (size_t)env_first * of.pitch);
+    const int total4 = rows * of.pitch / 4;                           // (pitch % 4 == 0: host)
+    for (int q = threadIdx.x; q < total4; q += blockDim.x) __builtin_nontemporal_store(src4[q], dst4 + q);
+}
+
 // What a wave loads for one building: issued as one batch, ahead of the previous building's arithmetic.
 template <typename F>
 struct FullIn {
@@ -477,10 +512,11 @@ constexpr int CL_LP_WORDS = (CLP_F_LAST - CLP_F_FIRST + 1) + CL_NF;      // 64 +
 // (576-thread workgroups, three waves per SIMD, 168 registers with a few spills; the vector ALUs are ~40 % busy at one env per lane
 // and the pack halves their work): bit-identical and 24 - 29 us against 17.7 us at 9 x 65 536, slower at every size tried -- the
 // waves in flight, not the instruction count, carry this kernel.
-template <int VEC, bool DETAIL, bool LP, bool NT, bool KPI, int PREC = 0>
-CL_DEV void full_step_body(const StepArgs& a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC], then (LP) [buildings of the workgroup][CL_LP_WORDS] or (KPI) [n_bldg][64*VEC] baselines
+template <int VEC, bool DETAIL, bool LP, bool NT, bool KPI, int PREC = 0, bool OBS = false>
+CL_DEV void full_step_body(const StepArgs& a, [[maybe_unused]] const ObsFusedArgs* of = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC], then (LP) [buildings of the workgroup][CL_LP_WORDS] or (KPI) [n_bldg][64*VEC] baselines or (OBS) [64*VEC][pitch]
     static_assert(!KPI || (DETAIL && !LP && VEC == 1), "the KPI epilogue is written for one env per lane, with the baseline / expected / served values of the detail unit");
+    static_assert(!OBS || (!LP && !KPI && !DETAIL), "the fused observation tile shares the LDS region behind the reduction rows");
     using F = typename Vec<VEC>::type;
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
@@ -577,6 +613,7 @@ CL_DEV void full_step_body(const StepArgs& a) {
             if (R.outage) clv::unit_step<F, true, DETAIL, PREC>(B, R, a.t, first, act, S, O, grow);
             else clv::unit_step<F, false, DETAIL, PREC>(B, R, a.t, first, act, S, O, grow);
             F rw = clv::unit_reward<F>(rkind, B, S, O.net);
+            if constexpr (OBS) obs_fill<F>(*of, lds + (size_t)a.nw * NQ * TILE, b, lane * VEC, ts_row - a.t, S, O.net, rw);
             CL_TRACE_AFTER(2 + 4 * tr_i, rw);
             CL_TRACE_AFTER(2 + 4 * tr_i, S.soc);
             if constexpr (FOLDK) {
@@ -668,7 +705,9 @@ CL_DEV void full_step_body(const StepArgs& a) {
             fold_stash(a, lds_fold, w, lane, fold_prev);
         }
     }
+    if constexpr (OBS) obs_pad(*of, lds + (size_t)a.nw * NQ * TILE, TILE);
     district_reduce<VEC, false, FOLDK, KPI, QLDS, SWAP>(a, lds, w, lane, env0, live, plane, rkind, q_net, q_cost, q_em, q_rw, a.nw, lds_fold);      // (LP, two envs per lane: the C4 shard's kernel, which may fold its chunk sums)
+    if constexpr (OBS) obs_flush(*of, lds + (size_t)a.nw * NQ * TILE, bx * TILE, min(TILE, a.n_env - bx * TILE));      // (district_reduce's first barrier came after every wave's tile writes; never chunked: host)
     if constexpr (KPI) {
         // baseline district series: the per-building baselines in cl_kpi_kernel's association (16 strided partial sums, added in order).
         // (district_reduce's barriers came after every wave's LDS writes; MARL's extra sweep leaves this region alone.)
@@ -697,6 +736,12 @@ __global__ void __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(WPE))
     full_step_body<VEC, DETAIL, LP, NT, false, 2>(a);
 }
 
+// ... with the compact observation of the next row written by the same launch (cl_step_observe_f32; one env per lane, one workgroup row)
+template <int PREC, bool NT>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) cl_step_full_obs_kernel(const StepArgs a, const ObsFusedArgs of) {
+    full_step_body<1, false, false, NT, false, PREC, true>(a, &of);
+}
+
 template <bool NT>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) cl_step_full_kpi_kernel(const StepArgs a) {
     full_step_body<1, true, false, NT, true>(a);
@@ -709,9 +754,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
 // in building order (the reference's order, citylearn.py:1909-1918).
 // (Round 3, tried: a wave that walks two items fetching the second item's planes before it stores the first one's -- the stores otherwise
 //  fence the loads behind them.  102 instead of 77 registers and SLOWER: 9 x 65 536 8.44 vs 7.86 us, 9 x 262 144 29.9 vs 29.2 us.)
-template <int VEC, bool NT, int PREC>
-CL_DEV void full_tp_body(const StepArgs& a, const int tp) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [tp * n_bldg][NQ][64*VEC], then [tp][64*VEC]
+template <int VEC, bool NT, int PREC, bool OBS = false>
+CL_DEV void full_tp_body(const StepArgs& a, const int tp, [[maybe_unused]] const ObsFusedArgs* of = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [tp * n_bldg][NQ][64*VEC], then [tp][64*VEC], then (OBS) [tp * 64*VEC][pitch]
     using F = typename Vec<VEC>::type;
     constexpr int TILE = 64 * VEC;
     const int lane = threadIdx.x & 63;
@@ -723,6 +768,7 @@ CL_DEV void full_tp_body(const StepArgs& a, const int tp) {
     const int ts_row = a.t + (a.env_row0 ? a.env_row0[tile0 / CL_ROW0_BLOCK] : 0);       // tp * TILE <= CL_ROW0_BLOCK (host)
     const int n_items = tp * a.n_bldg;
     const bool marl = rkind == CLR_MARL;
+    [[maybe_unused]] float* otile = lds + ((size_t)n_items * NQ + tp) * TILE;
     for (int j = w; j < n_items; j += a.nw) {
         const int h = j / a.n_bldg, b = j - h * a.n_bldg;
         const int env0 = tile0 + h * TILE + lane * VEC;
@@ -743,6 +789,7 @@ CL_DEV void full_tp_body(const StepArgs& a, const int tp) {
             if (R.outage) clv::unit_step<F, true, false, PREC>(B, R, a.t, first, act, S, O, grow);
             else clv::unit_step<F, false, false, PREC>(B, R, a.t, first, act, S, O, grow);
             const F rw = clv::unit_reward<F>(rkind, B, S, O.net);
+            if constexpr (OBS) obs_fill<F>(*of, otile, b, h * TILE + lane * VEC, ts_row - a.t, S, O.net, rw);
             const long long off = (long long)b * a.n_env + env0;
             if (B.flags & CLF_BATTERY) {
                 full_store<VEC, NT>(a.state + CLS_B_SOC * plane + off, S.soc);
@@ -760,7 +807,9 @@ CL_DEV void full_tp_body(const StepArgs& a, const int tp) {
         full_store<VEC, false>(row + CLQ_NET * TILE, net); full_store<VEC, false>(row + CLQ_COST * TILE, cost);
         full_store<VEC, false>(row + CLQ_EMISSION * TILE, em); full_store<VEC, false>(row + CLQ_REWARD * TILE, rws);
     }
+    if constexpr (OBS) obs_pad(*of, otile, tp * TILE);
     __syncthreads();
+    if constexpr (OBS) obs_flush(*of, otile, tile0, min(tp * TILE, a.n_env - tile0));      // (the workgroup's tiles are consecutive envs: one contiguous block of rows)
     float* dnet = lds + (size_t)n_items * NQ * TILE;                  // [tp][TILE]: district net (MARL)
     auto sum_rows = [&](int q_lo, int q_hi) {
         const int nq = q_hi - q_lo;
@@ -807,6 +856,12 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))
 template <int VEC, int WPE, bool NT>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(WPE))) cl_step_full_tp_chain_kernel(const StepArgs a, const int tp) {
     full_tp_body<VEC, NT, 2>(a, tp);
+}
+
+// ... with the compact observation of the next row written by the same launch (cl_step_observe_f32)
+template <int VEC, int PREC, bool NT>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) cl_step_full_tp_obs_kernel(const StepArgs a, const int tp, const ObsFusedArgs of) {
+    full_tp_body<VEC, NT, PREC, true>(a, tp, &of);
 }
 
 }  // namespace

@@ -784,6 +784,7 @@ struct ObsFusedArgs {
     int n_cols, pitch, row;
     short start[CL_OBS_FUSED_BLDG + 1]; // deps[start[b] .. start[b + 1]) belong to building b
     cl_obs_dep deps[CLOB_MAX_DEPS];     // grouped by building
+    int lean_ok;                        // (host) the battery + PV launch can fill it: <= CL_OBS_FUSED_PER_BLDG columns per building, battery / net / reward planes only
 };
 
 template <int VEC, bool FLEX, bool NT, bool OBS, bool KPI = false, int PREC = 0>
@@ -1697,6 +1698,29 @@ __global__ void cl_return_kernel(float* __restrict__ ret_env, const float* __res
     if (env < n_env) ret_env[env] += reward[env];
 }
 
+// the thermal kernels that write the compact observation themselves (cl_full.h OBS): more than 64 KB of dynamic LDS where the tile asks for it
+template <int PREC>
+int launch_full_obs(bool nt, dim3 grid, dim3 block, size_t lds, hipStream_t s, const StepArgs& a, const ObsFusedArgs& of, const cl_tuning& tun) {
+    name_add(tun, "cl_step_full_obs_kernel<%d, %s>", PREC, nt ? "true" : "false");
+    const void* fn = nt ? reinterpret_cast<const void*>(cl_step_full_obs_kernel<PREC, true>) : reinterpret_cast<const void*>(cl_step_full_obs_kernel<PREC, false>);
+    if (lds > 64 * 1024)
+        if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(cl_step_full_obs_kernel)");
+    if (nt) hipLaunchKernelGGL((cl_step_full_obs_kernel<PREC, true>), grid, block, lds, s, a, of);
+    else hipLaunchKernelGGL((cl_step_full_obs_kernel<PREC, false>), grid, block, lds, s, a, of);
+    return CL_OK;
+}
+template <int VEC, int PREC>
+int launch_tp_obs(bool nt, dim3 grid, dim3 block, size_t lds, hipStream_t s, const StepArgs& a, int tp, const ObsFusedArgs& of, const cl_tuning& tun) {
+    name_add(tun, "cl_step_full_tp_obs_kernel<%d, %d, %s>", VEC, PREC, nt ? "true" : "false");
+    if (lds > 150 * 1024) return fail(CL_EINVAL, "fused observation tile: %zu bytes of LDS", lds);
+    const void* fn = nt ? reinterpret_cast<const void*>(cl_step_full_tp_obs_kernel<VEC, PREC, true>) : reinterpret_cast<const void*>(cl_step_full_tp_obs_kernel<VEC, PREC, false>);
+    if (lds > 64 * 1024)
+        if (hipError_t e = ensure_dynamic_lds(fn, lds); e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(cl_step_full_tp_obs_kernel)");
+    if (nt) hipLaunchKernelGGL((cl_step_full_tp_obs_kernel<VEC, PREC, true>), grid, block, lds, s, a, tp, of);
+    else hipLaunchKernelGGL((cl_step_full_tp_obs_kernel<VEC, PREC, false>), grid, block, lds, s, a, tp, of);
+    return CL_OK;
+}
+
 // cl_step_lean_chunk_kernel<VEC, NT, FOLD, PREC> from run-time launch parameters (VEC = 1 or 4); opts into more than 64 KB of dynamic LDS where the launch needs it
 template <int PREC>
 int launch_lean_chunk(int vec, bool nt, bool fold, dim3 grid, dim3 block, size_t lds, hipStream_t s, const StepArgs& a) {
@@ -1708,7 +1732,7 @@ int launch_lean_chunk(int vec, bool nt, bool fold, dim3 grid, dim3 block, size_t
         hipLaunchKernelGGL((cl_step_lean_chunk_kernel<V, N, F, PREC>), grid, block, lds, s, a); } while (0)
 #define CL_LC_NF(V) do { if (nt) { if (fold) CL_LC(V, true, true); else CL_LC(V, true, false); } \
                          else { if (fold) CL_LC(V, false, true); else CL_LC(V, false, false); } } while (0)
-    if (vec == 1) CL_LC_NF(1); else CL_LC_NF(4);
+    if (vec == 1) CL_LC_NF(1); else if (vec == 2) CL_LC_NF(2); else CL_LC_NF(4);
 #undef CL_LC_NF
 #undef CL_LC
     return CL_OK;
@@ -1789,6 +1813,10 @@ int cl_flex_reset_f32(const cl_dims* dims, const cl_flex* flex, void* stream) {
 static int step_impl(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
                      int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg,
                      float* kpi_env, const cl_flex* flex, int32_t t, void* stream, const ObsFusedArgs* of, bool* fused) {
+    // (`of`: the compact observation the step launch may write itself -- the battery + PV kernels under their own limits (`lean_ok`), the thermal
+    //  kernels of cl_full.h for any listed battery / tank / net / reward column)
+    const ObsFusedArgs* const of_full = of;
+    if (of && !of->lean_ok) of = nullptr;
     if (int rc = check_dims(dims)) return rc;
     const cl_tuning& tun = tuning_of(dims);
     name_reset(tun);
@@ -2017,6 +2045,9 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     //  (352 workgroups, env-major from 106 496 envs) had the general kernel at 98 304 envs, 13.0 us)
     // streaming KPIs without the detail planes: the lean kernel updates the per-building accumulators itself, at any grid size
     const bool kpi_lean = (dims->flags & CLD_KPI) && !(dims->flags & CLD_WRITE_DETAIL) && !kpi_full;
+    // cl_step_observe_f32 on a thermal / outage district: the step launch fills the compact observation itself (cl_full.h OBS) where it is one
+    // workgroup row of the one-env-per-lane kernel or the multi-tile kernel, without detail planes / KPIs / a coupled reward
+    const bool obs_full = of_full && full && !flex && !det && !f64 && !(dims->flags & CLD_KPI) && a.n_chunks == 1 && rkind_host != CLR_MARL && tuning_of(dims).obs_variant == 0;
     const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 480 || (tun.lean_variant & 2) || kpi_lean || (chain && dims->n_bldg > 17 && dims->n_bldg <= 20)) &&
                             !((tun.lean_variant & 1) && !kpi_lean);
     // without the detail planes only cl_step_lean_kpi_kernel updates the per-building accumulators (and writes the baseline plane
@@ -2070,7 +2101,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             default: return fail(CL_EINVAL, "bad vec %d", vec);
             }
 #undef CL_CHAIN_CASE
-        } else if (!full && a.n_chunks > 1 && tun.finish != 2 && (vec == 1 || vec == 4) && !(tun.lean_variant & 16)) {
+        } else if (!full && a.n_chunks > 1 && tun.finish != 2 && (vec == 1 || vec == 2 || vec == 4) && !(tun.lean_variant & 16)) {
             // building-chunked battery + PV districts: the latency-ordered chunk kernel around the float64 chain (deferred fold where it applies)
             a.fused_finish = can_defer ? 2 : 0;
             name_add(tun, "cl_step_lean_chunk_kernel<%d, %s, %s, 2>", vec, a.nt ? "true" : "false", can_defer ? "true" : "false");
@@ -2079,13 +2110,22 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             // thermal districts, several env tiles per workgroup (cl_step_full_tp_kernel's launch shape)
             a.nw = tp_nw;
             const dim3 g2(tp_grid), b2(64 * a.nw);
+            if (obs_full) {
+                const size_t l2 = tp_lds + (size_t)tp_tiles * 64 * of_full->pitch * sizeof(float);
+                if (int rc = launch_tp_obs<1, 2>(a.nt, g2, b2, l2, s, a, tp_tiles, *of_full, tun)) return rc;
+                *fused = true;
+            } else {
             name_add(tun, "cl_step_full_tp_chain_kernel<1, 4, %s>", a.nt ? "true" : "false");
             if (a.nt) hipLaunchKernelGGL((cl_step_full_tp_chain_kernel<1, 4, true>), g2, b2, tp_lds, s, a, tp_tiles);
             else hipLaunchKernelGGL((cl_step_full_tp_chain_kernel<1, 4, false>), g2, b2, tp_lds, s, a, tp_tiles);
+            }
         } else if (full && tun.full_variant != 1) {
             // thermal / outage districts: the pack-generic kernel of cl_full.h at one env per lane (parameter blocks staged in LDS where chunked)
             if (det) CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, true, 1024, 4, false);
-            else if (lp) { const dim3 grid_xy = grid; { const dim3 grid = CL_SWAP_GRID ? dim3(grid_xy.y, grid_xy.x) : grid_xy; CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, true); } }
+            else if (obs_full && !lp) {
+                if (int rc = launch_full_obs<2>(a.nt, grid, block, lds + (size_t)64 * of_full->pitch * sizeof(float), s, a, *of_full, tun)) return rc;
+                *fused = true;
+            } else if (lp) { const dim3 grid_xy = grid; { const dim3 grid = CL_SWAP_GRID ? dim3(grid_xy.y, grid_xy.x) : grid_xy; CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, true); } }
             else CL_LAUNCH_NT(cl_step_full_chain_kernel, 1, false, 1024, 4, false);
         } else {
             name_add(tun, "cl_step_kernel<%d, %s, %s, false, 2, false>", vec, full ? "true" : "false", full && det ? "true" : "false");
@@ -2133,6 +2173,11 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         a.nw = tp_nw;
         const dim3 g2(tp_grid), b2(64 * a.nw);
         const size_t l2 = tp_lds;
+        if (obs_full) {
+            const size_t lo = l2 + (size_t)tp_tiles * 64 * tp_vec * of_full->pitch * sizeof(float);
+            if (int rc = tp_vec == 2 ? launch_tp_obs<2, 0>(a.nt, g2, b2, lo, s, a, tp_tiles, *of_full, tun) : launch_tp_obs<1, 0>(a.nt, g2, b2, lo, s, a, tp_tiles, *of_full, tun)) return rc;
+            *fused = true;
+        } else {
         name_add(tun, "cl_step_full_tp_kernel<%d, 4, %s>", tp_vec, a.nt ? "true" : "false");
         if (tp_vec == 2) {
             if (a.nt) hipLaunchKernelGGL((cl_step_full_tp_kernel<2, 4, true>), g2, b2, l2, s, a, tp_tiles);
@@ -2140,6 +2185,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         } else {
             if (a.nt) hipLaunchKernelGGL((cl_step_full_tp_kernel<1, 4, true>), g2, b2, l2, s, a, tp_tiles);
             else hipLaunchKernelGGL((cl_step_full_tp_kernel<1, 4, false>), g2, b2, l2, s, a, tp_tiles);
+        }
         }
     } else if (full && tun.full_variant != 1 && vec <= 2) {
         // thermal / outage districts: the pack-generic kernel of cl_full.h
@@ -2172,6 +2218,10 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             }
             if (vec != 1 && small) CL_LAUNCH_NT(cl_step_full_kernel, 2, false, 576, 5, false);      // (96 VGPRs do not hold the staged operands: 61 scratch accesses)
         } else {
+            if (vec == 1 && obs_full) {
+                if (int rc = launch_full_obs<0>(a.nt, grid, block, lds + (size_t)64 * of_full->pitch * sizeof(float), s, a, *of_full, tun)) return rc;
+                *fused = true;
+            } else
 #ifdef CL_TRACE                  // the stamps need a few registers: five waves per SIMD (what the 9-building launch holds) instead of six
             if (vec == 1) CL_LAUNCH_NT(cl_step_full_kernel, 1, false, 1024, 5, false);
 #else
@@ -2233,7 +2283,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
 #undef CL_LEAN_CASE
         default: return fail(CL_EINVAL, "bad vec %d", vec);
         }
-    } else if (a.n_chunks > 1 && tun.finish != 2 && (vec == 1 || vec == 4) && !(tun.lean_variant & 16)) {
+    } else if (a.n_chunks > 1 && tun.finish != 2 && (vec == 1 || vec == 2 || vec == 4) && !(tun.lean_variant & 16)) {
         // building-chunked battery + PV districts: the latency-ordered chunk kernel (lean_variant & 16 keeps cl_step_kernel: tests, A/B)
         a.fused_finish = can_defer ? 2 : 0;
         name_add(tun, "cl_step_lean_chunk_kernel<%d, %s, %s, 0>", vec, a.nt ? "true" : "false", can_defer ? "true" : "false");
@@ -2329,20 +2379,28 @@ int cl_step_observe_f32(const cl_dims* dims, const uint32_t* params, const float
     // what the step launch itself can write: columns fed by the planes a lean wave holds in registers, rows padded to 16 bytes
     ObsFusedArgs of;
     bool can = obs_pitch == ((n_cols + 3) & ~3) && dims->n_bldg <= CL_OBS_FUSED_BLDG && tuning_of(dims).obs_variant == 0;
+    bool lean_planes = true;                        // only what a battery + PV wave holds: battery state, net, reward
     int n = 0;
     for (int b = 0; b < dims->n_bldg && can; ++b) {
         of.start[b] = (short)n;
         for (int d = 0; d < n_deps; ++d) {
             const int src = deps[d].src, kind = src >> 28, pl = (src >> 20) & 0xFF;
             if (deps[d].col < 0 || deps[d].col >= n_cols || src < 0) return fail(CL_EINVAL, "deps[%d]: col=%d src=%d", d, deps[d].col, src);
+            // (under CLD_F64_CHAIN the degraded-capacity plane carries the capacity LOSS: not an observation source -- round-5 advisor)
+            if (kind == CLOB_KIND_STATE && pl == CLS_B_DEGCAP && (dims->flags & CLD_F64_CHAIN))
+                return fail(CL_EINVAL, "deps[%d]: CLS_B_DEGCAP holds capacity - degraded_capacity under CLD_F64_CHAIN and cannot feed an observation column", d);
             if ((src & 0xFFFFF) != b) continue;
-            can = can && ((kind == CLOB_KIND_STATE && (pl == CLS_B_SOC || pl == CLS_B_EFF || pl == CLS_B_DEGCAP)) ||
-                          (kind == CLOB_KIND_OUT && (pl == CLO_NET || pl == CLO_REWARD)));
+            const bool lean_pl = (kind == CLOB_KIND_STATE && (pl == CLS_B_SOC || pl == CLS_B_EFF || pl == CLS_B_DEGCAP)) ||
+                                 (kind == CLOB_KIND_OUT && (pl == CLO_NET || pl == CLO_REWARD));
+            lean_planes = lean_planes && lean_pl;
+            can = can && (lean_pl || (kind == CLOB_KIND_STATE && (pl == CLS_CS_SOC || pl == CLS_HS_SOC || pl == CLS_DS_SOC)));      // + the tank planes of the thermal kernels
             of.deps[n++] = deps[d];
         }
     }
     can = can && n == n_deps;                       // (a building index beyond n_bldg would have been skipped)
-    for (int b = 0; b < dims->n_bldg && can; ++b) can = (b + 1 < dims->n_bldg ? of.start[b + 1] : n) - of.start[b] <= CL_OBS_FUSED_PER_BLDG;
+    bool lean_ok = can && lean_planes;
+    for (int b = 0; b < dims->n_bldg && lean_ok; ++b) lean_ok = (b + 1 < dims->n_bldg ? of.start[b + 1] : n) - of.start[b] <= CL_OBS_FUSED_PER_BLDG;
+    of.lean_ok = lean_ok ? 1 : 0;
     for (int b = dims->n_bldg; b <= CL_OBS_FUSED_BLDG; ++b) of.start[b] = (short)n;
     of.obs = obs; of.table = obs_table; of.n_cols = n_cols; of.pitch = obs_pitch; of.row = obs_row;
     bool fused = false;

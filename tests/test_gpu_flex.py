@@ -45,9 +45,14 @@ def test_flex_step_matches_oracle_and_reference(name):
     flex_b = tab.flex.flex_bldg
     worst = {}
 
-    def close(name, got, exp, rtol=2e-4, atol=2e-4):
+    plain = {}                                   # the same errors in units of the plain bar, 1e-4 + 1e-4 |ref| (recorded: profiles/r06_parity_worst.md)
+
+    # (round 6: every gate of this test at the plain bar, 1e-4 + 1e-4 |ref| -- measured worst 0.64 x, profiles/r06_parity_worst.md; rounds 3 - 5 gated
+    #  the EV planes at 2e-4 and the district sums at 2e-3 absolute)
+    def close(name, got, exp, rtol=1e-4, atol=1e-4):
         err = np.abs(got - exp) / (atol + rtol * np.abs(exp))
         worst[name] = max(worst.get(name, 0.0), float(err.max()))
+        plain[name] = max(plain.get(name, 0.0), float((np.abs(got - exp) / (1e-4 + 1e-4 * np.abs(exp))).max()))
         np.testing.assert_allclose(got, exp, rtol=rtol, atol=atol, err_msg=f'{name} t={t}')
 
     flips = 0
@@ -66,16 +71,16 @@ def test_flex_step_matches_oracle_and_reference(name):
         close('chargers_total', eng.flex_out[abi.CLX_CHARGERS, :, 0].cpu().numpy(), g.ref['chargers_total'][t][flex_b])
         close('load', eng.flex_out[abi.CLX_LOAD, :, 0].cpu().numpy(), (g.ref['chargers_total'][t] + g.ref['wms_total'][t])[flex_b])
         close('net', eng.net[:, 0].cpu().numpy(), g.ref['net'][t])
-        close('base_net', eng.out_bldg[abi.CLO_BASE_NET, :, 0].cpu().numpy(), g.ref['base_net'][t], atol=5e-4)
+        close('base_net', eng.out_bldg[abi.CLO_BASE_NET, :, 0].cpu().numpy(), g.ref['base_net'][t])
         close('soc', eng.soc[:, 0].cpu().numpy(), g.ref['soc'][t])
-        close('d_net', eng.out_env[abi.CLQ_NET, 0].cpu().numpy(), g.ref['d_net'][t], atol=2e-3)
-        close('d_cost', eng.out_env[abi.CLQ_COST, 0].cpu().numpy(), g.ref['d_cost'][t], atol=2e-3)
+        close('d_net', eng.out_env[abi.CLQ_NET, 0].cpu().numpy(), g.ref['d_net'][t])
+        close('d_cost', eng.out_env[abi.CLQ_COST, 0].cpu().numpy(), g.ref['d_cost'][t])
         if name == 'g_cc_demo':
-            close('violation', eng.flex_out[abi.CLX_VIOLATION, :, 0].cpu().numpy(), g.ref['cc_violation_kwh'][t][flex_b], atol=5e-4)
+            close('violation', eng.flex_out[abi.CLX_VIOLATION, :, 0].cpu().numpy(), g.ref['cc_violation_kwh'][t][flex_b])
             fb = list(flex_b).index(14)                                         # Building_15: limit 12 kW, phases 7 / 5 kW
             head = out['cc_headroom'][14][0]
             got = eng.flex_out[abi.CLX_HEADROOM:abi.CLX_HEADROOM + 3, fb, 0].cpu().numpy()
-            close('headroom', got, np.array([head['building'], head['phase_a'], head['phase_b']]), atol=5e-4)
+            close('headroom', got, np.array([head['building'], head['phase_a'], head['phase_b']]))
         # the reward has hard thresholds on SoC differences: allow a float32 / float64 disagreement on a handful of steps
         rw, ref_rw = eng.reward_bldg[:, 0].cpu().numpy(), g.ref['env_rewards'][t]
         if spec.central_agent:                                   # one value: the sum, scaled by the district MARL reward
@@ -85,6 +90,8 @@ def test_flex_step_matches_oracle_and_reference(name):
         flips += int(bad.sum())
         close('d_reward', eng.out_env[abi.CLQ_REWARD, 0].cpu().numpy(), eng.reward_bldg[:, 0].cpu().numpy().sum(), atol=1e-4)
     assert flips <= 3, flips
+    from golden_util import check_worst
+    check_worst({k: v for k, v in plain.items() if k not in ('ev_degcap', 'd_reward')}, f'{name} EV district (fp32 batteries)')
     print('worst scaled errors', {k: round(v, 3) for k, v in worst.items()}, 'reward threshold flips', flips)
 
 

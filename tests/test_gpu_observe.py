@@ -268,3 +268,66 @@ def test_step_observe_under_the_f64_chain(E, tuning):
         assert torch.equal(got, ref), t
     assert b_eng.last_kernels.startswith('cl_step_lean_obs_chain_kernel<') and '+' not in b_eng.last_kernels, b_eng.last_kernels
     assert got.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize('f64', [None, False])
+@pytest.mark.parametrize('name,E,tuning,kernel', [('g2020_cz1', 65536, None, 'cl_step_full_tp_obs_kernel<'), ('g2020_cz1', 4996, dict(full_variant=5), 'cl_step_full_tp_obs_kernel<'),
+                                                  ('g2020_cz1', 772, None, 'cl_step_full_obs_kernel<'), ('s_2020_cz3', 516, None, 'cl_step_full_obs_kernel<'),
+                                                  ('g2020_15min', 1284, dict(full_variant=5), 'cl_step_full_tp_obs_kernel<')])
+def test_step_observe_on_thermal_districts_is_one_launch(name, E, tuning, kernel, f64):
+    """`cl_step_observe_f32` on thermal districts (heat pump, heater, tanks: the 2020 schemas) -- the thermal step kernels of
+    cl_full.h write the compact observation of row t + 1 themselves (battery AND tank states of charge, net: building.py:1115-1219, 1336-1481 return
+    them from one `step`), the multi-tile kernel (9 x 65 536; forced at a ragged 4 996 / 1 284) and the one-tile kernel at one env per lane, under
+    the default precision model and the all-fp32 map.  ONE launch, and state, outputs, district sums and the observation matrix bit-identical to
+    `step` followed by `ObservationWriter.write`; pad columns zero."""
+    from citylearn_amd.engine import StepEngine
+    from citylearn_amd.observations import ObservationLayout
+    from citylearn_amd.observe import ObservationWriter
+    spec = golden(name).spec()
+    tab = spec.episode_tables(0)
+    dep_tables, _ = ObservationLayout(spec, 'current', False).episode(tab).compact()
+    a_eng, b_eng = StepEngine(tab, E, f64_maps=f64, tuning=tuning), StepEngine(tab, E, f64_maps=f64, tuning=tuning)
+    assert not a_eng.lean
+    wa, wb = ObservationWriter(a_eng, dep_tables, None), ObservationWriter(b_eng, dep_tables, None)
+    assert wa.n_deps == wa.n_cols > 17                       # more than the battery + net columns: tank states of charge too
+    b_eng.trace_kernels()
+    low, high = spec.action_limits()
+    lo, hi = torch.from_numpy(low).cuda()[:, None], torch.from_numpy(high).cuda()[:, None]
+    gen = torch.Generator(device='cuda').manual_seed(E)
+    for t in range(10):
+        act = (lo + torch.rand((a_eng.n_act_cols, E), device='cuda', generator=gen) * (hi - lo)).contiguous()
+        a_eng.step(act, t)
+        ref = wa.write(t + 1).clone()
+        got = b_eng.step_observe(act, wb, t)
+        assert torch.equal(a_eng.state, b_eng.state) and torch.equal(a_eng.out_bldg[:2], b_eng.out_bldg[:2]), t
+        assert torch.equal(a_eng.out_env, b_eng.out_env), t
+        assert torch.equal(got, ref), (t, (got - ref).abs().max().item())
+        assert torch.equal(wb._buffer[:, wb.n_cols:], torch.zeros_like(wb._buffer[:, wb.n_cols:]))
+    assert b_eng.last_kernels.startswith(kernel) and '+' not in b_eng.last_kernels, b_eng.last_kernels
+    assert got.abs().sum().item() > 0
+    # MARL finishes its reward plane after the sweep the tile is filled in: two launches, same result
+    m_a, m_b = StepEngine(tab, E, reward='MARL', f64_maps=f64, tuning=tuning), StepEngine(tab, E, reward='MARL', f64_maps=f64, tuning=tuning)
+    w_a, w_b = ObservationWriter(m_a, dep_tables, None), ObservationWriter(m_b, dep_tables, None)
+    m_b.trace_kernels()
+    act = (lo + torch.rand((m_a.n_act_cols, E), device='cuda', generator=gen) * (hi - lo)).contiguous()
+    m_a.step(act, 0)
+    assert torch.equal(m_b.step_observe(act, w_b, 0), w_a.write(1)) and '_obs_kernel' not in m_b.last_kernels, m_b.last_kernels
+
+
+def test_degraded_capacity_is_not_an_observation_source_under_the_chain():
+    """under CLD_F64_CHAIN the CLS_B_DEGCAP plane carries `capacity - degraded_capacity`; `cl_step_observe_f32` refuses a column fed by it."""
+    import ctypes
+    from citylearn_amd import _lib, abi
+    from citylearn_amd.engine import StepEngine
+    from citylearn_amd.observations import ObservationLayout
+    from citylearn_amd.observe import ObservationWriter
+    spec = golden('g2022_all').spec()
+    tab = spec.episode_tables(0)
+    dep_tables, _ = ObservationLayout(spec, 'current', False).episode(tab).compact()
+    eng = StepEngine(tab, 64)
+    assert eng.f64_chain
+    w = ObservationWriter(eng, dep_tables, None)
+    w._deps[0].src = (abi.CLOB_KIND_STATE << 28) | (abi.CLS_B_DEGCAP << 20) | 0
+    with pytest.raises(_lib.EngineError) as e:
+        eng.step_observe(torch.zeros((eng.n_act_cols, 64), device='cuda'), w, 0)
+    assert e.value.code == abi.CL_EINVAL and 'CLS_B_DEGCAP' in str(e.value)
