@@ -4,7 +4,13 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import golden, GOLDEN
+from golden_util import golden, GOLDEN, check_worst
+
+
+def _bar(worst, key, got, ref):
+    """Accumulate |got - ref| / (1e-4 + 1e-4 |ref|) -- the north-star bar -- into `worst[key]`."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    worst[key] = max(worst.get(key, 0.0), float(np.max(np.abs(got - ref) / (1e-4 + 1e-4 * np.abs(ref)))))
 
 pytestmark = pytest.mark.gpu
 
@@ -38,13 +44,16 @@ def test_env_matches_reference_api_and_rewards(name):
     assert info == {} and [len(o) for o in obs] == [len(n) for n in env.observation_names]
     K = 120
     kind = 'RewardFunction' if kw else g.facts['reward_type']
+    # (round 6: the drop-in env runs the default precision model -- CLD_F64_CHAIN -- and every series of this free-running episode is held to the plain
+    #  bar, 1e-4 + 1e-4 |ref|, rewards and district series included; rounds 1 - 5 gated the rewards at 1e-3 and the district net at 1e-3 + 2e-3)
+    worst = {}
     for t in range(K):
         obs, reward, terminated, truncated, info = env.step(_actions(g, env, t))
         ref = g.ref['reward_' + kind][t]
         ref = [ref.sum()] if env.central_agent else ref
-        np.testing.assert_allclose(reward, ref, rtol=1e-3, atol=1e-3)
+        _bar(worst, 'reward', reward, ref)
         assert not truncated and info == {} and terminated == (t == env.time_steps - 2)
-    np.testing.assert_allclose(env.net_electricity_consumption, g.ref['d_net'][:K], rtol=1e-3, atol=2e-3)
+    _bar(worst, 'd_net', env.net_electricity_consumption, g.ref['d_net'][:K])
     # end-use series of the completed steps, per building and summed (building.py:384-470, citylearn.py:700-870)
     pairs = (('cooling_electricity_consumption', 'c_cool'), ('heating_electricity_consumption', 'c_heat'), ('dhw_electricity_consumption', 'c_dhw'),
              ('non_shiftable_load_electricity_consumption', 'c_ns'), ('electrical_storage_electricity_consumption', 'c_b'),
@@ -52,13 +61,13 @@ def test_env_matches_reference_api_and_rewards(name):
     for prop, key in pairs:
         got = np.stack([getattr(b, prop) for b in env.buildings], axis=1)
         assert got.shape == (K, len(env.buildings))
-        np.testing.assert_allclose(got, g.ref[key][:K], rtol=1e-4, atol=2e-4, err_msg=prop)
+        _bar(worst, key, got, g.ref[key][:K])
         if not prop.startswith('net_'):
-            np.testing.assert_allclose(getattr(env, prop), g.ref[key][:K].astype(np.float64).sum(axis=1), rtol=1e-4, atol=1e-3, err_msg=prop)
+            _bar(worst, key + '_district', getattr(env, prop), g.ref[key][:K].astype(np.float64).sum(axis=1))
     parts = sum(getattr(env, p) for p in ('cooling_electricity_consumption', 'heating_electricity_consumption', 'dhw_electricity_consumption',
                                           'non_shiftable_load_electricity_consumption', 'electrical_storage_electricity_consumption', 'solar_generation'))
     grid = g.ref['outage'][:K].sum(axis=1) == 0 if 'outage' in g.ref.files else np.ones(K, dtype=bool)
-    np.testing.assert_allclose(parts[grid], g.ref['d_net'][:K][grid], rtol=1e-4, atol=5e-3)       # building.py:2686-2693
+    _bar(worst, 'd_net_from_parts', parts[grid], g.ref['d_net'][:K][grid])                         # building.py:2686-2693
     assert float(env.solar_generation.min()) < 0.0 and float(env.solar_generation.max()) <= 0.0
     with pytest.raises(AttributeError):
         env.no_such_series
@@ -73,10 +82,11 @@ def test_env_matches_reference_api_and_rewards(name):
     booked = env._history_array('base_net')
     moved = not np.allclose(base, booked, rtol=1e-6, atol=1e-6)
     assert moved == (name == 'g2023_heat')
-    np.testing.assert_allclose(booked, g.ref['base_net'][:K], rtol=1e-4, atol=2e-4)
+    _bar(worst, 'base_net', booked, g.ref['base_net'][:K])
     np.testing.assert_allclose(getattr(env, base_name), base.astype(np.float64).sum(axis=1), rtol=1e-5, atol=1e-4)
     if not moved:
-        np.testing.assert_allclose(getattr(env, base_name), g.ref['base_net'][:K].sum(axis=1), rtol=1e-4, atol=2e-3)
+        _bar(worst, 'base_net_district', getattr(env, base_name), g.ref['base_net'][:K].sum(axis=1))
+    check_worst(worst, f'CityLearnEnv {name} free-running {K} steps')
     b0 = env.buildings[0]
     no_pv = getattr(b0, base_name + '_and_pv')
     np.testing.assert_allclose(no_pv, base[:, 0] - b0.solar_generation, rtol=1e-6, atol=1e-5)
@@ -117,12 +127,14 @@ def test_env_full_episode_kpis_and_termination():
     got = {f'{r.level}|{r.name}|{r.cost_function}': r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
     ref = dict(zip([str(x) for x in g.ref['kpi_names']], g.ref['kpi_values']))
     n = 0
+    kw_worst = {}
     for k, v in ref.items():
         fn = k.split('|')[-1]
         if fn.startswith(('discomfort', 'one_minus_thermal')):
             continue                                               # need the LSTM indoor temperature (next stage)
-        np.testing.assert_allclose(got[k], v, rtol=2e-3, atol=1e-4, err_msg=k)   # free-running fp32 episode
+        _bar(kw_worst, fn, got[k], v)                                # (round 6: the plain bar on every KPI of the free-running episode; was rtol 2e-3)
         n += 1
+    check_worst(kw_worst, 'CityLearnEnv g2023_p2 full-episode KPIs')
     assert n >= 20                                                 # incl. the two unserved-energy (outage) KPIs
     obs2, _ = env.reset()
     assert env.time_step == 0 and env.episode == 1
@@ -250,11 +262,13 @@ def test_evaluate_under_non_default_conditions(name):
         frame = env.evaluate(control_condition=getattr(EC, c), baseline_condition=getattr(EC, b))
         got = {f'{r.level}|{r.name}|{r.cost_function}': r.value for r in frame.itertuples() if r.value is not None and not np.isnan(r.value)}
         n = 0
+        worst = {}
         for k, v in ref.items():
             if k.split('|')[-1].startswith(('discomfort', 'one_minus_thermal')) or abs(v) > 1e3:
                 continue
-            np.testing.assert_allclose(got[k], v, rtol=3e-3, atol=2e-4, err_msg=f'{pair} {k}')
+            _bar(worst, k.split('|')[-1], got[k], v)               # (round 6: the plain bar; was rtol 3e-3)
             n += 1
+        check_worst(worst, f'CityLearnEnv {name} evaluate({pair})')
         assert n >= 20, (pair, n)
     if name == 'g2022_all':
         with pytest.raises(AttributeError):                      # partial-load series only exist on dynamics buildings
