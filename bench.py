@@ -527,6 +527,12 @@ class RolloutWorkload:
                         'peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz'}
 
 
+def load_c2_spec(hours: int):
+    from citylearn_amd import load_district
+    from citylearn_amd.data import sample_schema
+    return load_district(sample_schema(f'citylearn_challenge_2022_phase_all_{hours}h'))
+
+
 def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning: dict, f64: bool = False, kpi: bool = False, hours: int = 8760):
     from citylearn_amd import load_district
     from citylearn_amd.data import sample_schema
@@ -572,7 +578,7 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
                                f'jittered +-10 %) x {E} envs per GPU, cl_rollout_f32 mode B on the building-chunked district: 24 fused env steps per launch, unit state in '
                                'registers, on-device Philox4x32-10 uniform random policy, one cl_finish_kernel per launch (district sums of the last step + K-step returns); '
                                'env batch sharded over GPUs (8 x 1024 = the 8192 envs of BASELINE config 4), no collective',
-                               valu_per_unit_step=384.0 if thermal else 100.0,
+                               f64=f64, valu_per_unit_step=384.0 if thermal else 100.0,
                                valu_source=('profiles/archive/r02_thermal_*: 384 VALU instructions per unit of cl::unit_step<true>, the arithmetic the thermal fused kernel runs'
                                             if thermal else 'profiles/archive/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step (battery + PV fused kernel)'))
     if cfg in ('C4', 'C4-lean'):
@@ -764,6 +770,20 @@ def run_rank(args):
             side['hbm_streaming'] = {k: fs[k] for k in ('kernel', 'launch_us', 'frac', 'achieved', 'unit', 'value')}
             side['hbm_streaming']['speedup_vs_default'] = roof['launch_us'] / fs['launch_us']
         roof['fp32_map'] = side
+
+    if cfg == 'C2' and not args.no_side_entries:
+        # BASELINE config 2 (17 x 4 096 envs) is 2.7 MB per step: one launch per step is launch latency whatever the kernel does.
+        # What a user who wants THROUGHPUT at this batch size gets is mode B -- 24 fused steps per launch, state in registers -- measured here beside mode A.
+        wl = None
+        torch.cuda.empty_cache()
+        spec_b = load_c2_spec(args.table_hours)
+        wl_b = RolloutWorkload('C2-B', spec_b, E, 24, device, rank, world, tuning, 'mode B at the C2 shape', f64=f64)
+        _, _, b_launch, _, _ = measure(wl_b, 10, 100, 1, 200)
+        roof['mode_b'] = {'what': f'cl_rollout_f32 at the same shape (17 buildings x {E} envs): 24 fused env steps per launch, on-device Philox policy, state in registers',
+                          'kernel': wl_b.kernels, 'launch_us_per_24_steps': b_launch * 1e6, 'us_per_step': b_launch * 1e6 / 24,
+                          'value': world * wl_b.units_per_step / b_launch, 'speedup_vs_mode_a': roof['launch_us'] / (b_launch * 1e6 / 24)}
+        wl_b = None
+        torch.cuda.empty_cache()
 
     # N > 1 on a real node: BASELINE configs 4 and 5 measured in the same lease (their per-GPU shards, weak scaling like the headline) -- the
     # driver's scaling run is the only time anybody sees N > 1, so the line carries them as `extra_configs` (--no-extra-configs skips them)

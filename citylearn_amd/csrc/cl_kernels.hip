@@ -2110,7 +2110,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             // thermal districts, several env tiles per workgroup (cl_step_full_tp_kernel's launch shape)
             a.nw = tp_nw;
             const dim3 g2(tp_grid), b2(64 * a.nw);
-            if (obs_full) {
+            if (obs_full && tp_lds + (size_t)tp_tiles * 64 * of_full->pitch * sizeof(float) <= 150 * 1024) {      // (a tile that does not fit: the two launches)
                 const size_t l2 = tp_lds + (size_t)tp_tiles * 64 * of_full->pitch * sizeof(float);
                 if (int rc = launch_tp_obs<1, 2>(a.nt, g2, b2, l2, s, a, tp_tiles, *of_full, tun)) return rc;
                 *fused = true;
@@ -2173,7 +2173,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
         a.nw = tp_nw;
         const dim3 g2(tp_grid), b2(64 * a.nw);
         const size_t l2 = tp_lds;
-        if (obs_full) {
+        if (obs_full && l2 + (size_t)tp_tiles * 64 * tp_vec * of_full->pitch * sizeof(float) <= 150 * 1024) {
             const size_t lo = l2 + (size_t)tp_tiles * 64 * tp_vec * of_full->pitch * sizeof(float);
             if (int rc = tp_vec == 2 ? launch_tp_obs<2, 0>(a.nt, g2, b2, lo, s, a, tp_tiles, *of_full, tun) : launch_tp_obs<1, 0>(a.nt, g2, b2, lo, s, a, tp_tiles, *of_full, tun)) return rc;
             *fused = true;
@@ -2521,15 +2521,31 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
     const dim3 block(64 * a.nw);
+    name_reset(tun);
+    // Thermal / outage districts without detail planes (round 6): the pack-generic unit of cl_full.h inside the K-step loop (cl_rollout_full_kernel),
+    // two envs per lane where the battery map is fp32 and the actions are contiguous along the envs; cl_tuning.full_variant = 1 keeps the scalar unit
+    const bool packed = full && mb == 1 && !(dims->flags & CLD_WRITE_DETAIL) && tun.full_variant != 1;
+    if (packed) {
+        const int fvec = (chain || (actions && act_stride_env != 1) || tun.vec == 1) ? 1 : 2;
+        const dim3 pgrid((unsigned)((dims->n_env + 64 * fvec - 1) / (64 * fvec)), (unsigned)a.n_chunks);
+        const size_t plds = (size_t)a.nw * NQ * 64 * fvec * sizeof(float);
+        name_add(tun, "cl_rollout_full_kernel<%d, %s, %d>", fvec, chunked ? "true" : "false", chain ? 2 : 0);
+#define CL_RF(V, C, P) hipLaunchKernelGGL((cl_rollout_full_kernel<V, C, P>), pgrid, block, plds, (hipStream_t)stream, r)
+        if (chain) { if (chunked) CL_RF(1, true, 2); else CL_RF(1, false, 2); }
+        else if (fvec == 2) { if (chunked) CL_RF(2, true, 0); else CL_RF(2, false, 0); }
+        else { if (chunked) CL_RF(1, true, 0); else CL_RF(1, false, 0); }
+#undef CL_RF
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_full_kernel launch");
+    } else {
     const int key = (full ? 100 : 0) + vec * 10 + mb;
     if ((key != 11 && key != 12 && key != 21 && key != 22 && key != 111) || ((chunked || chain) && key != 12 && key != 22 && key != 111) || (chain && chunked && key == 22))
         return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
     const bool pin = chunked || chain || (long long)grid * a.nw > 5 * 1024;
-    name_reset(tun);
     // (spelled as rocprofv3 prints them: every template argument, defaults included)
     name_add(tun, "cl_rollout_kernel<%d, %s, %d, %s, %s, %d>", vec, full ? "true" : "false", mb, (key == 12 && !pin) ? "false" : "true", chunked ? "true" : "false", chain ? 2 : 0);
     const int rc = cl_tu_launch_rollout(key + (chunked ? 1000 : 0) + (chain ? 2000 : 0), pin, grid, (unsigned)a.n_chunks, block.x, lds, stream, &r);
     if (rc) return hip_fail((hipError_t)rc, "cl_rollout_kernel launch");
+    }
     if (chunked && k_steps > 0) {
         // the last step's district sums (and the K-step return): one fold per launch
         StepArgs f = a;

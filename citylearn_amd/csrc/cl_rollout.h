@@ -312,5 +312,164 @@ __global__ void __launch_bounds__(1024) cl_rollout_kernel(const RolloutArgs r) {
     }
 }
 
+#ifndef CL_TU_NOSLP
+// ---- mode B for thermal / outage districts around the PACK-GENERIC unit of cl_full.h (round 6) ------------------------------------------------
+// cl_rollout_kernel<1, true, 1> above steps a thermal building with the scalar unit of cl_unit.h at one env per lane: 384 vector instructions per
+// unit-step, which made the fused rollout of the 1024-building thermal district SLOWER per step than mode A (17.6 vs 13.2 us at 1024 x 1024, fp32).
+// Here the same K-step loop runs clv::unit_step -- the arithmetic of the thermal step kernels, two envs per lane in packed fp32 where the battery map
+// is fp32 (the float64 chain keeps one env per lane, like every thermal kernel) -- with the unit state in registers for all K steps, one building
+// per wave, chunks of up to 16 buildings along gridDim.y.  Same action streams, same district reduction, same return rows as cl_rollout_kernel.
+// No detail planes (the host keeps cl_rollout_kernel for CLD_WRITE_DETAIL).  Lives in the main translation unit: it WANTS the packed instructions.
+template <int VEC>
+CL_DEV typename Vec<VEC>::type rollout_action_f(const RolloutArgs& r, int col, int env0, int t, int k, bool live) {
+    float d[VEC];
+    rollout_action<VEC>(d, r, col, env0, t, k, live);
+    if constexpr (VEC == 1) return d[0];
+    else { typename Vec<VEC>::type v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v[i] = d[i]; return v; }
+}
+
+template <int VEC, bool CHUNK, int PREC>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) cl_rollout_full_kernel(const RolloutArgs r) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
+    using F = typename Vec<VEC>::type;
+    const StepArgs& a = r.s;
+    constexpr int TILE = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env0 = blockIdx.x * TILE + lane * VEC;
+    const bool live = env0 < a.n_env;
+    const long long plane = (long long)a.n_bldg * a.n_env;
+    const int rkind = (a.flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT;
+    const bool quirk = a.flags & CLD_REF_T0_QUIRK;
+    const int b_lo = CHUNK ? blockIdx.y * a.b_chunk : 0;
+    const int b_hi = CHUNK ? min(a.n_bldg, b_lo + a.b_chunk) : a.n_bldg;
+    const int b = b_lo + w;
+    const bool own = b < b_hi;                                       // wave-uniform
+    const int bc = own ? b : min(b_lo, a.n_bldg - 1);
+    const uint32_t* __restrict__ f = a.params + (long long)bc * CL_NP + CLP_F_FIRST;
+    [[maybe_unused]] const uint32_t* __restrict__ grow = PREC == 2 ? a.params + (long long)bc * CL_NP : nullptr;
+    const uint32_t flags = clv::uword<false>(f, 0);
+    const int c_cs = (int)clv::uword<false>(f, 1), c_hs = (int)clv::uword<false>(f, 2), c_ds = (int)clv::uword<false>(f, 3), c_es = (int)clv::uword<false>(f, 4),
+              c_cd = (int)clv::uword<false>(f, 5), c_hd = (int)clv::uword<false>(f, 6), c_coh = (int)clv::uword<false>(f, 7);
+    const long long off = (long long)bc * a.n_env + env0;
+    const F zero = (F)(0.0f), one = (F)(1.0f);
+    clv::St<F> S = {zero, one, zero, zero, zero, zero};
+    if (live && own) {
+        if (flags & CLF_BATTERY) {
+            S.soc = full_load<VEC>(a.state + CLS_B_SOC * plane + off); S.eff = full_load<VEC>(a.state + CLS_B_EFF * plane + off);
+            S.degcap = full_load<VEC>(a.state + CLS_B_DEGCAP * plane + off);
+        }
+        if (flags & CLF_COOL_STO) S.cs = full_load<VEC>(a.state + CLS_CS_SOC * plane + off);
+        if (flags & CLF_HEAT_STO) S.hs = full_load<VEC>(a.state + CLS_HS_SOC * plane + off);
+        if (flags & CLF_DHW_STO) S.ds = full_load<VEC>(a.state + CLS_DS_SOC * plane + off);
+    }
+    float ret[VEC], q_net[VEC], q_cost[VEC], q_em[VEC], q_rw[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) ret[i] = 0.0f;
+    F last_net = zero, last_rw = zero;
+    PhiloxCache rnd[VEC];
+    const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0;   // workgroup-uniform
+    for (int k = 0; k < r.k_steps; ++k) {
+        const int t = r.t0 + k;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
+        if (own) {
+            clv::FP B;
+            clv::load_fp<false>(B, f);
+            cl::Row R;
+            cl::load_row_scalar<true>(R, a.ts + ((long long)(t + row0) * a.n_bldg + bc) * CL_NF, B.flags, nullptr);
+            float es[VEC];
+            rollout_action_cached<VEC>(es, rnd, r, c_es, env0, t, k, live);
+            clv::Ac<F> act;
+            if constexpr (VEC == 1) act.es = es[0];
+            else { _Pragma("unroll") for (int i = 0; i < VEC; ++i) act.es[i] = es[i]; }
+            act.cs = rollout_action_f<VEC>(r, c_cs, env0, t, k, live);
+            act.hs = rollout_action_f<VEC>(r, c_hs, env0, t, k, live);
+            act.ds = rollout_action_f<VEC>(r, c_ds, env0, t, k, live);
+            if (c_coh >= 0) {
+                const F c = rollout_action_f<VEC>(r, c_coh, env0, t, k, live);
+                act.cd = clv::vabs(clv::vmin(c, zero)); act.hd = clv::vabs(clv::vmax(c, zero));
+            } else {
+                act.cd = rollout_action_f<VEC>(r, c_cd, env0, t, k, live);
+                act.hd = rollout_action_f<VEC>(r, c_hd, env0, t, k, live);
+            }
+            clv::Ou<F> O;
+            const bool first = quirk && t == 0;
+            if (R.outage) clv::unit_step<F, true, false, PREC>(B, R, t, first, act, S, O, grow);
+            else clv::unit_step<F, false, false, PREC>(B, R, t, first, act, S, O, grow);
+            const F rw = clv::unit_reward<F>(rkind, B, S, O.net);
+            last_net = O.net; last_rw = rw;
+            full_accumulate<VEC>(q_net, O.net); full_accumulate<VEC>(q_cost, O.cost); full_accumulate<VEC>(q_em, O.emission); full_accumulate<VEC>(q_rw, rw);
+        }
+        if (rkind == CLR_MARL) {
+            // (never chunked: host) the MARL reward couples the buildings through the district net of THIS step: one LDS exchange per step
+            vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, q_net);
+            __syncthreads();
+            float dnet[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dnet[i] = 0.0f;
+            for (int kk = 0; kk < a.nw; ++kk) {
+                float part[VEC];
+                vload<VEC>(part, lds + (size_t)kk * TILE + lane * VEC);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) dnet[i] += part[i];
+            }
+            __syncthreads();
+            if (own) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float n_i, rw_i;
+                    if constexpr (VEC == 1) n_i = last_net; else n_i = last_net[i];
+                    rw_i = cl::marl_reward(n_i, dnet[i]);
+                    if constexpr (VEC == 1) last_rw = rw_i; else last_rw[i] = rw_i;
+                    ret[i] += rw_i;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) ret[i] += q_rw[i];
+        }
+    }
+    if (live && own) {
+        if (flags & CLF_BATTERY) {
+            full_store<VEC, false>(a.state + CLS_B_SOC * plane + off, S.soc); full_store<VEC, false>(a.state + CLS_B_EFF * plane + off, S.eff);
+            full_store<VEC, false>(a.state + CLS_B_DEGCAP * plane + off, S.degcap);
+        }
+        if (flags & CLF_COOL_STO) full_store<VEC, false>(a.state + CLS_CS_SOC * plane + off, S.cs);
+        if (flags & CLF_HEAT_STO) full_store<VEC, false>(a.state + CLS_HS_SOC * plane + off, S.hs);
+        if (flags & CLF_DHW_STO) full_store<VEC, false>(a.state + CLS_DS_SOC * plane + off, S.ds);
+        if (r.k_steps > 0) {
+            full_store<VEC, false>(a.out_bldg + CLO_NET * plane + off, last_net);
+            full_store<VEC, false>(a.out_bldg + CLO_REWARD * plane + off, last_rw);
+        }
+    }
+    if (r.k_steps > 0) {
+        if (rkind == CLR_MARL) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float rw_i;
+                if constexpr (VEC == 1) rw_i = last_rw; else rw_i = last_rw[i];
+                q_rw[i] = own ? rw_i : 0.0f;
+            }
+        }
+        district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind == CLR_MARL ? (int)CLR_DEFAULT : rkind, q_net, q_cost, q_em, q_rw, a.nw);
+    }
+    if (r.ret_env) {
+        __syncthreads();
+        vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, ret);
+        __syncthreads();
+        const int tile_env0 = blockIdx.x * TILE;
+        for (int e = threadIdx.x; e < TILE; e += blockDim.x) {
+            float s = 0.0f;
+            for (int kk = 0; kk < a.nw; ++kk) s += lds[(size_t)kk * TILE + e];
+            if (tile_env0 + e < a.n_env) {
+                if constexpr (CHUNK) a.out_bldg[(long long)CLO_RESERVED * plane + ((long long)a.n_chunks * NQ + blockIdx.y) * a.n_env + tile_env0 + e] = s;
+                else r.ret_env[tile_env0 + e] += s;
+            }
+        }
+    }
+}
+#endif  // CL_TU_NOSLP
+
 }  // namespace
 #endif  // __HIPCC__

@@ -365,7 +365,7 @@ typedef struct cl_tuning {
                                (measured slower: csrc/cl_kernels.hip district_reduce; tests, A/B); 3 = DEFERRED: the step launch folds the
                                PREVIOUS step's chunk sums and leaves its own in the scratch rows -- `out_env` then trails the step by one
                                launch until cl_finish_f32 (below) is called.  Only for rewards that do not couple the buildings (not
-                               MARL / EV), without CLD_KPI / CLD_F64_MAPS / CLD_F64_CHAIN / CLD_WRITE_DETAIL / flexible loads; every other call keeps
+                               MARL / EV), without CLD_KPI / CLD_F64_MAPS / CLD_WRITE_DETAIL / flexible loads (CLD_F64_CHAIN: battery + PV districts only); every other call keeps
                                the second launch, and cl_finish_f32 is then a no-op (a launch that does not defer clears its step parity's marker, so the mode
                                may change between steps on live buffers).  cl_rollout_seq_f32 finishes its last step itself. */
     int32_t kpi_passes;     /* streaming KPIs of thermal / outage districts and of districts stepped with the detail planes: 0 = inside the step
@@ -543,7 +543,10 @@ int cl_observe_f32(const cl_dims* dims, const float* obs_table, const int32_t* c
  * citylearn.py:1029-1042).  Same results as the two calls.  Where the step runs as one lean launch at four envs per lane (battery
  * + PV districts of up to 32 buildings from ~50 000 envs up) and the columns are fed by the battery state planes, the net or the
  * reward plane, the wave that stepped a building writes its columns from registers into an LDS tile and the step launch itself
- * streams the tile out: one launch instead of two (17 x 65 536: step + observe 16.8 -> 9.1 us).  Otherwise it IS the two calls. */
+ * streams the tile out: one launch instead of two (17 x 65 536: step + observe 16.8 -> 9.1 us).  Round 6: the thermal / outage step kernels
+ * do the same (cl_full.h OBS: districts of up to 32 buildings in one workgroup row, without detail planes / CLD_KPI / CLD_F64_MAPS / a MARL
+ * reward; columns fed by the battery and tank state planes, net or reward; 9 x 65 536 with 34 columns: 20.3 -> 12.1 us).  Otherwise it IS the
+ * two calls.  A column fed by CLS_B_DEGCAP is refused under CLD_F64_CHAIN (the plane then holds the capacity loss): CL_EINVAL. */
 int cl_step_observe_f32(const cl_dims* dims, const uint32_t* params, const float* ts, float* state, const float* actions,
                         int64_t act_stride_col, int64_t act_stride_env, float* out_bldg, float* out_env, float* kpi_bldg, float* kpi_env,
                         int32_t t, const float* obs_table, const int32_t* col_src, const float* col_scale, const cl_obs_dep* deps,

@@ -100,6 +100,10 @@ def test_config_lines(cfg, kernel, bound, prec):
     out = _bench('--config', cfg, '--precision', prec, '--steps', '20', '--warmup', '5', '--reps', '2')
     assert out['config']['name'] == cfg and out['roofline']['bound'] == bound and kernel in out['roofline']['kernel'], out['roofline']['kernel']
     assert out['value'] > 1e8 and (out['roofline']['frac'] is None or 0.0 < out['roofline']['frac'] < 1.0)       # (the chain's fused rollout claims no VALU fraction)
+    if cfg == 'C2':
+        # config 2 is launch latency in mode A (2.7 MB per step): the line says what mode B gives a user at the same batch size
+        mb = out['roofline']['mode_b']
+        assert 'cl_rollout_kernel' in mb['kernel'] and mb['speedup_vs_mode_a'] > 1.5 and mb['value'] > out['value'], mb
 
 
 def test_thermal_kpi_line_runs_the_kpis_inside_the_step_launch():

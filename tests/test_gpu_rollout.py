@@ -192,7 +192,9 @@ def test_chunked_fused_rollout_equals_single_steps(name, kind, B, E, tuning):
         ret_ref += a.district_reward.double()
     ret = torch.full((E,), 3.0, device='cuda')                       # (the return is ADDED to what the caller passes in)
     b.rollout(K, actions=acts, ret_env=ret)
-    assert 'cl_rollout_kernel' in b.last_kernels and b.last_kernels.endswith(', true, 0>+cl_finish_kernel'), b.last_kernels
+    # (round 6: thermal districts run the pack-generic unit of cl_full.h inside the K-step loop, cl_rollout_full_kernel -- two envs per lane on the fp32 map)
+    thermal = name == 'g2020_cz1'
+    assert ('cl_rollout_full_kernel<2, true, 0>' if thermal else 'cl_rollout_kernel') in b.last_kernels and b.last_kernels.endswith(', true, 0>+cl_finish_kernel'), b.last_kernels
     _close(b.state, a.state)
     _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
     # district sums over B buildings: the per-building tolerance times the district size
@@ -259,7 +261,8 @@ def test_fused_rollout_with_the_f64_chain(name, B, E):
     ret = torch.zeros(E, device='cuda')
     b.rollout(K, actions=acts, ret_env=ret)
     # (two envs per lane where the batch fills the chip in whole rounds -- 32 768 envs, the C5 shard -- else one)
-    assert ('cl_rollout_kernel<2, ' if E >= 32768 else 'cl_rollout_kernel<1, ') in b.last_kernels and ', 2>' in b.last_kernels, b.last_kernels
+    lean = name == 'g2022_all'
+    assert (('cl_rollout_kernel<2, ' if E >= 32768 else 'cl_rollout_kernel<1, ') if lean else 'cl_rollout_full_kernel<1, ') in b.last_kernels and ', 2>' in b.last_kernels, b.last_kernels
     _close(b.state, a.state)
     _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
     torch.testing.assert_close(b.out_env, a.out_env, rtol=1e-5, atol=1e-6 * max(B, 17))
@@ -353,3 +356,53 @@ def test_default_engine_rolls_out_under_the_chain():
     c.rollout(K, seed=3, fused=False)                      # the launch sequence: cl_policy_kernel + K x cl_step_f32
     _close(b.state, c.state, 2e-6)
     _close(b.out_bldg[:2], c.out_bldg[:2], 2e-5)
+
+
+@pytest.mark.parametrize('f64', [False, 'chain'])
+@pytest.mark.parametrize('name,B,E,kind', [('g2020_cz1', 0, 516, 'RewardFunction'), ('g2020_cz1', 0, 128, 'MARL'), ('g2023_p2', 0, 260, 'SolarPenaltyReward'),
+                                           ('g2020_cz1', 40, 132, 'IndependentSACReward'), ('s_2023_p3', 0, 64, 'RewardFunction')])
+def test_packed_thermal_rollout_against_the_scalar_unit_and_single_steps(name, B, E, kind, f64):
+    """VERDICT r05 item 6: `cl_rollout_full_kernel` -- mode B for thermal / outage districts around `clv::unit_step`, the pack-generic arithmetic of the
+    thermal STEP kernels (two envs per lane on the fp32 map, one under the float64 chain) -- against the scalar-unit rollout it replaces
+    (`cl_tuning.full_variant = 1` -> `cl_rollout_kernel<1, true, 1>`) and against K single steps: state, net, reward, district sums and K-step
+    return within the fused kernels' tolerance; one workgroup row and building-chunked; MARL (one LDS exchange per step); ragged env tiles;
+    outage rows of the 2023 fixtures (steps 380 .. 410); open-loop actions and the on-device Philox policy."""
+    from citylearn_amd.synthetic import tile_district
+    g = golden(name)
+    spec = tile_district(g.spec(), B) if B else g.spec()
+    tab = spec.episode_tables(0)
+    K = 24
+    t0 = 385 if (name == 'g2023_p2') else 0
+    low, high = spec.action_limits()
+    gen = torch.Generator(device='cuda').manual_seed(E + len(kind))
+    lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+    acts = lo[None, :, None] + torch.rand((K, len(low), E), device='cuda', generator=gen) * (hi - lo)[None, :, None]
+    a = StepEngine(tab, E, reward=kind, f64_maps=f64)
+    b = StepEngine(tab, E, reward=kind, f64_maps=f64)
+    c = StepEngine(tab, E, reward=kind, f64_maps=f64, tuning=dict(full_variant=1))
+    b.trace_kernels(); c.trace_kernels()
+    if t0:                                     # mid-episode start: some charge in every storage
+        for e in (a, b, c):
+            e.state[abi.CLS_B_SOC] = 0.5; e.state[abi.CLS_DS_SOC] = 0.3
+    ret_ref = torch.zeros(E, device='cuda', dtype=torch.float64)
+    for k in range(K):
+        a.step(acts[k], t0 + k)
+        ret_ref += a.district_reward.double()
+    rb, rc = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
+    b.rollout(K, actions=acts, ret_env=rb, t0=t0)
+    c.rollout(K, actions=acts, ret_env=rc, t0=t0)
+    assert b.last_kernels.startswith(f'cl_rollout_full_kernel<{1 if f64 else 2}, ') and c.last_kernels.startswith('cl_rollout_kernel<1, true, 1, '), (b.last_kernels, c.last_kernels)
+    nb = max(B, len(spec.buildings))
+    for x in (b, c):
+        _close(x.state, a.state)
+        _close(x.out_bldg[:2], a.out_bldg[:2], 2e-5)
+        torch.testing.assert_close(x.out_env, a.out_env, rtol=1e-5, atol=2e-6 * nb)
+    torch.testing.assert_close(rb.double(), ret_ref, rtol=1e-5, atol=2e-5 * nb * K)
+    torch.testing.assert_close(rb, rc, rtol=1e-5, atol=2e-5 * nb * K)
+    # the on-device policy draws the same stream in both kernels
+    p, q = StepEngine(tab, E, reward=kind, f64_maps=f64), StepEngine(tab, E, reward=kind, f64_maps=f64, tuning=dict(full_variant=1))
+    for e in (p, q):
+        e.set_action_limits(low, high)
+    p.rollout(12, seed=9, t0=t0); q.rollout(12, seed=9, t0=t0)
+    _close(p.state, q.state)
+    _close(p.out_bldg[:2], q.out_bldg[:2], 2e-5)
