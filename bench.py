@@ -477,7 +477,8 @@ class RolloutWorkload:
     dtype = 'f32'
 
     def __init__(self, name: str, spec, E: int, K: int, device: str, rank: int, world: int, tuning: dict, what: str, f64=False, valu_per_unit_step: float = 100.0,
-                 valu_source: str = 'profiles/archive/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step at two envs per lane, 101 at one'):
+                 valu_source: str = 'profiles/archive/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step at two envs per lane, 101 at one',
+                 valu_chain: float = None):
         import torch
         from citylearn_amd.engine import StepEngine
         self.name, self.what, self.E, self.K, self.device = name, what, E, K, device
@@ -492,7 +493,7 @@ class RolloutWorkload:
         self.period = self.n_windows
         self.units_per_step = self.eng.n_bldg * E * K
         self.kernels = None
-        self.inst, self.inst_source = valu_per_unit_step, valu_source
+        self.inst, self.inst_source, self.inst_chain = valu_per_unit_step, valu_source, valu_chain
 
     def step_fn(self, i: int):
         w = i % self.n_windows
@@ -509,10 +510,10 @@ class RolloutWorkload:
 
     def roofline(self, launch_s: float) -> dict:
         # VALU-issue bound: lane-instructions per (env, building, step) from the SQ counters of this kernel (`inst_source`)
-        inst = self.inst
+        inst = self.inst_chain if (self.eng.f64_chain and self.inst_chain) else self.inst
         peak = VALU_LANES * VALU_CLOCK_GHZ                      # G lane-instructions / s
         ach = self.units_per_step * inst / launch_s / 1e9
-        if self.eng.f64_chain:
+        if self.eng.f64_chain and not self.inst_chain:
             # the chain's float64 instructions issue at half rate and its count per unit-step was not collected: no VALU fraction claimed
             return {'bound': 'valu', 'achieved': None, 'peak': peak, 'unit': 'G lane-instructions/s', 'frac': None, 'kernel': self.kernels,
                     'launch_us': launch_s * 1e6, 'units_per_launch': self.units_per_step, 'traffic': None,
@@ -578,8 +579,10 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
                                f'jittered +-10 %) x {E} envs per GPU, cl_rollout_f32 mode B on the building-chunked district: 24 fused env steps per launch, unit state in '
                                'registers, on-device Philox4x32-10 uniform random policy, one cl_finish_kernel per launch (district sums of the last step + K-step returns); '
                                'env batch sharded over GPUs (8 x 1024 = the 8192 envs of BASELINE config 4), no collective',
-                               f64=f64, valu_per_unit_step=384.0 if thermal else 100.0,
-                               valu_source=('profiles/archive/r02_thermal_*: 384 VALU instructions per unit of cl::unit_step<true>, the arithmetic the thermal fused kernel runs'
+                               f64=f64, valu_per_unit_step=222.6 if thermal else 100.0, valu_chain=361.9 if thermal else None,
+                               valu_source=('profiles/r06l_c4b_*_sq_by_kernel.jsonl: SQ_INSTS_VALU of cl_rollout_full_kernel per launch x 64 lanes / (1024 x 1024 x 24 unit-steps) = '
+                                            '222.6 lane-instructions per unit-step at two envs per lane (packed fp32), 361.9 at one under the float64 chain (float64 instructions '
+                                            'counted as one issue each)'
                                             if thermal else 'profiles/archive/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step (battery + PV fused kernel)'))
     if cfg in ('C4', 'C4-lean'):
         from citylearn_amd.synthetic import tile_district

@@ -2498,7 +2498,11 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     if (chunked) {
         if (((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL)
             return fail(CL_EINVAL, "the fused rollout of a building-chunked district (n_bldg=%d) cannot couple the buildings inside a step (MARL): use cl_rollout_seq_f32", dims->n_bldg);
-        a.b_chunk = tun.b_chunk > 0 ? tun.b_chunk : 16 * mb_max;
+        // (the packed thermal kernel: EIGHT buildings = waves per workgroup -- three / two workgroups per CU instead of one sixteen-wave one at its
+        //  84 / 97 registers and 50 / 76 KB of LDS: 1024 buildings x 1024 / 2048 / 8192 envs 289 -> 263 / 557 -> 498 / 2173 -> 1873 us per 24 steps
+        //  under the float64 chain, 195 -> 183 / 378 -> 336 / 1458 -> 1258 us on the fp32 map; profiles/r06m_*)
+        const bool packed_shape = full && !(dims->flags & CLD_WRITE_DETAIL) && tun.full_variant != 1 && dims->n_act_cols <= 65536;
+        a.b_chunk = tun.b_chunk > 0 ? tun.b_chunk : packed_shape ? 8 : 16 * mb_max;
         if (a.b_chunk > 16 * mb_max) return fail(CL_EINVAL, "b_chunk=%d: a fused-rollout workgroup holds at most %d buildings of this district", a.b_chunk, 16 * mb_max);
         mb = mb_max;                      // (battery + PV: always two buildings per wave -- the one-building chunked instantiations spill)
         a.n_chunks = (dims->n_bldg + a.b_chunk - 1) / a.b_chunk;
@@ -2524,16 +2528,24 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     name_reset(tun);
     // Thermal / outage districts without detail planes (round 6): the pack-generic unit of cl_full.h inside the K-step loop (cl_rollout_full_kernel),
     // two envs per lane where the battery map is fp32 and the actions are contiguous along the envs; cl_tuning.full_variant = 1 keeps the scalar unit
-    const bool packed = full && mb == 1 && !(dims->flags & CLD_WRITE_DETAIL) && tun.full_variant != 1;
+    const bool packed = full && mb == 1 && !(dims->flags & CLD_WRITE_DETAIL) && tun.full_variant != 1 && dims->n_act_cols <= 65536;      // (column ids travel 16 bits each)
     if (packed) {
-        const int fvec = (chain || (actions && act_stride_env != 1) || tun.vec == 1) ? 1 : 2;
+        const bool marl = ((dims->flags & CLD_REWARD_MASK) >> CLD_REWARD_SHIFT) == CLR_MARL;      // (never chunked: refused above; one env per lane -- the two-env MARL instantiation parks 36 bytes in scratch)
+        const int fvec = (chain || marl || (actions && act_stride_env != 1) || tun.vec == 1) ? 1 : 2;
         const dim3 pgrid((unsigned)((dims->n_env + 64 * fvec - 1) / (64 * fvec)), (unsigned)a.n_chunks);
-        const size_t plds = (size_t)a.nw * NQ * 64 * fvec * sizeof(float);
-        name_add(tun, "cl_rollout_full_kernel<%d, %s, %d>", fvec, chunked ? "true" : "false", chain ? 2 : 0);
-#define CL_RF(V, C, P) hipLaunchKernelGGL((cl_rollout_full_kernel<V, C, P>), pgrid, block, plds, (hipStream_t)stream, r)
+        // LDS: the reduction rows, or MARL's exchange row + every wave's Philox blocks (cl_rollout_full_kernel's note) -- 100 / 152 KB at 16 waves
+        const size_t tile_b = (size_t)64 * fvec * sizeof(float);
+        const size_t rows = (size_t)a.nw * NQ * tile_b, rnd = (size_t)a.nw * tile_b + (size_t)a.nw * (fvec == 1 ? CL_ROLLOUT_RND_ROWS<1> : CL_ROLLOUT_RND_ROWS<2>) * tile_b;
+        const size_t plds = rows > rnd ? rows : rnd;
+        name_add(tun, "cl_rollout_full_kernel<%d, %s, %d, %s>", fvec, chunked ? "true" : "false", chain ? 2 : 0, marl ? "true" : "false");
+#define CL_RFM(V, C, P, M) do { \
+            if (plds > 64 * 1024) if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(cl_rollout_full_kernel<V, C, P, M>), plds); e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(cl_rollout_full_kernel)"); \
+            hipLaunchKernelGGL((cl_rollout_full_kernel<V, C, P, M>), pgrid, block, plds, (hipStream_t)stream, r); } while (0)
+#define CL_RF(V, C, P) do { if (marl && !C) CL_RFM(V, false, P, true); else CL_RFM(V, C, P, false); } while (0)
         if (chain) { if (chunked) CL_RF(1, true, 2); else CL_RF(1, false, 2); }
-        else if (fvec == 2) { if (chunked) CL_RF(2, true, 0); else CL_RF(2, false, 0); }
+        else if (fvec == 2) { if (chunked) CL_RFM(2, true, 0, false); else CL_RFM(2, false, 0, false); }
         else { if (chunked) CL_RF(1, true, 0); else CL_RF(1, false, 0); }
+#undef CL_RFM
 #undef CL_RF
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_full_kernel launch");
     } else {

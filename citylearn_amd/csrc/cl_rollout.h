@@ -328,9 +328,94 @@ CL_DEV typename Vec<VEC>::type rollout_action_f(const RolloutArgs& r, int col, i
     else { typename Vec<VEC>::type v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v[i] = d[i]; return v; }
 }
 
-template <int VEC, bool CHUNK, int PREC>
+// The on-device policy of a thermal building draws up to six columns per step, and a Philox block is 4 words = the column's next FOUR steps (cl_philox.h):
+// drawn per step and column, the blocks were two thirds of this kernel's vector work (2 x 125 of ~ 600 instructions per step at two envs per lane,
+// 32 of them quarter-rate 32 x 32 multiplies).  Each wave keeps the blocks of its building's first CL_ROLLOUT_SLOTS<VEC> active columns in LDS --
+// [slot][word][64 VEC], refreshed where t % 4 == 0 (and at the launch's first step), one ds_read per draw; the registers do not hold them (48 at
+// two envs per lane, 105 in use).  A fifth / sixth column at two envs per lane has a one-word slot, redrawn every step.  ONE copy of the block
+// function, in a loop that is not unrolled: six inlined copies (one per column, each behind its own wave-uniform branch) were scheduled into each
+// other -- 128 registers and 112 bytes of scratch.  The region sits behind MARL's exchange row and aliases the district reduction's rows (the K loop
+// ends with a barrier before anybody reduces).
+template <int VEC> constexpr int CL_ROLLOUT_SLOTS = VEC == 1 ? 6 : 4;
+
+template <int VEC> constexpr int CL_ROLLOUT_RND_ROWS = CL_ROLLOUT_SLOTS<VEC> * 4 + (6 - CL_ROLLOUT_SLOTS<VEC>);      // rows of 64 VEC words per wave
+
+template <int VEC>
+CL_DEV int rollout_rnd_row(int slot, int t) {
+    return slot < CL_ROLLOUT_SLOTS<VEC> ? slot * 4 + (t & 3) : CL_ROLLOUT_SLOTS<VEC> * 3 + slot;
+}
+
+// (re)draw what step t needs.  `cols_lo` / `cols_hi`: the unit's active column ids in slot order, 16 bits each (host: n_act_cols <= 65 536);
+// the loop walks the wide slots where t % 4 == 0 (and at the launch's first step) and the one-word slots every step -- nothing on three steps of
+// four for a building of up to CL_ROLLOUT_SLOTS columns.  (A loop over the unit's seven candidate columns with its selects and skips was ~ 100
+// scalar instructions and ~ 20 branches per step and wave: 4 waves per SIMD do not hide that -- SALU +77 %, vector-ALU busy 85 -> 66 %.)
+template <int VEC>
+CL_DEV void rollout_rnd_refresh(const RolloutArgs& r, uint32_t* __restrict__ rnd, unsigned long long cols_lo, uint32_t cols_hi, int n_slot, int env0, int lane, int t, int k) {
+    constexpr int TILE = 64 * VEC;
+    const bool four = k == 0 || (t & 3) == 0;
+#pragma unroll 1
+    for (int slot = four ? 0 : CL_ROLLOUT_SLOTS<VEC>; slot < n_slot; ++slot) {
+        const uint32_t col = slot < 4 ? (uint32_t)(cols_lo >> (16 * slot)) & 0xffffu : (cols_hi >> (16 * (slot - 4))) & 0xffffu;
+        cl::U4 blk[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) blk[i] = cl::philox_block(r.seed, (uint32_t)(env0 + i) + r.s.env_offset, col, (uint32_t)t >> 2);
+        if (slot < CL_ROLLOUT_SLOTS<VEC>) {
+            uint32_t* c = rnd + (size_t)slot * 4 * TILE + lane * VEC;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) c[w * TILE + i] = blk[i].w[w];
+            }
+        } else {
+            uint32_t* c = rnd + (size_t)rollout_rnd_row<VEC>(slot, t) * TILE + lane * VEC;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) c[i] = cl::philox_word(blk[i], (uint32_t)t & 3u);
+        }
+    }
+}
+
+// one column of the on-device policy from the wave's cached words / of the open-loop action tensor
+template <int VEC>
+CL_DEV typename Vec<VEC>::type rollout_action_drawn(const RolloutArgs& r, const uint32_t* rnd, int slot, int col, int lane, int t) {
+    constexpr int TILE = 64 * VEC;
+    float d[VEC];
+    if (col < 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] = 0.0f;
+    } else {
+        const float lo = r.act_low[col], span = r.act_high[col] - lo;
+        const uint32_t* w = rnd + (size_t)rollout_rnd_row<VEC>(slot, t) * TILE + lane * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] = fmaf(cl::u01(w[i]), span, lo);
+    }
+    if constexpr (VEC == 1) return d[0];
+    else { typename Vec<VEC>::type v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v[i] = d[i]; return v; }
+}
+
+template <int VEC>
+CL_DEV typename Vec<VEC>::type rollout_action_open(const RolloutArgs& r, int col, int env0, int k, bool live) {
+    float d[VEC];
+    if (col < 0 || !live) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) d[i] = 0.0f;
+    } else {
+        const float* p = r.s.actions + (long long)k * r.act_stride_step + (long long)col * r.s.act_stride_col;
+        if (r.s.act_stride_env == 1) vload<VEC>(d, p + env0);
+        else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) d[i] = p[(long long)(env0 + i) * r.s.act_stride_env];
+        }
+    }
+    if constexpr (VEC == 1) return d[0];
+    else { typename Vec<VEC>::type v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v[i] = d[i]; return v; }
+}
+
+// MARL: the reward couples the buildings through the district net of the SAME step -- one LDS exchange (two barriers) per step, its own instantiation:
+// with a barrier inside the K loop the no-clobber walk stops at it and calls every global read of the loop clobbered by the loop's LDS stores --
+// the wave-uniform parameter reads came back as vector loads + v_readfirstlane (never chunked: host).
+template <int VEC, bool CHUNK, int PREC, bool MARL = false>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) cl_rollout_full_kernel(const RolloutArgs r) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [nw][NQ][64*VEC]
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // max([nw][NQ][64*VEC], [nw][64*VEC] + [nw][slots][4][64*VEC])
     using F = typename Vec<VEC>::type;
     const StepArgs& a = r.s;
     constexpr int TILE = 64 * VEC;
@@ -367,41 +452,63 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) ret[i] = 0.0f;
     F last_net = zero, last_rw = zero;
-    PhiloxCache rnd[VEC];
+    uint32_t* rnd = reinterpret_cast<uint32_t*>(lds) + (size_t)a.nw * TILE + (size_t)w * CL_ROLLOUT_RND_ROWS<VEC> * TILE;      // this wave's Philox words
+    // slots in column order of the unit (wave-uniform), their column ids packed 16 bits each
+    int n_slot = 0;
+    unsigned long long cols_lo = 0ull;
+    uint32_t cols_hi = 0u;
+    auto slot_of = [&](int c) {
+        if (c < 0) return 0;
+        if (n_slot < 4) cols_lo |= (unsigned long long)(uint32_t)c << (16 * n_slot); else cols_hi |= (uint32_t)c << (16 * (n_slot - 4));
+        return n_slot++;
+    };
+    const int s_es = slot_of(c_es), s_cs = slot_of(c_cs), s_hs = slot_of(c_hs), s_ds = slot_of(c_ds), s_coh = slot_of(c_coh), s_cd = slot_of(c_cd), s_hd = slot_of(c_hd);
     const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0;   // workgroup-uniform
     for (int k = 0; k < r.k_steps; ++k) {
         const int t = r.t0 + k;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) q_net[i] = q_cost[i] = q_em[i] = q_rw[i] = 0.0f;
         if (own) {
+            // The building's parameter block is RE-READ every step through the scalar cache: hoisted out of the loop (it is loop-invariant) its ~ 60
+            // words outlive the SGPR file -- 93 v_writelane before the loop, 13 - 16 v_readlane per use inside it.  `z` is a zero the compiler cannot
+            // see through.  (Scalar only while the K loop holds no barrier: MARL's note above the kernel.)
+#ifndef CL_ROLLOUT_HOIST
+#define CL_ROLLOUT_HOIST 0
+#endif
+            int z;
+            if constexpr (CL_ROLLOUT_HOIST == 2) z = 0;
+            else asm("s_mov_b32 %0, 0" : "=s"(z) : "s"(k));      // (not volatile: that would be a store to everything, as far as the no-clobber walk knows)
+            const uint32_t* __restrict__ fz = f + z;
+            [[maybe_unused]] const uint32_t* __restrict__ gz = PREC == 2 ? grow + z : nullptr;
             clv::FP B;
-            clv::load_fp<false>(B, f);
+            clv::load_fp<false>(B, CL_ROLLOUT_HOIST == 1 ? f : fz);
+            B.f = fz;
             cl::Row R;
             cl::load_row_scalar<true>(R, a.ts + ((long long)(t + row0) * a.n_bldg + bc) * CL_NF, B.flags, nullptr);
-            float es[VEC];
-            rollout_action_cached<VEC>(es, rnd, r, c_es, env0, t, k, live);
             clv::Ac<F> act;
-            if constexpr (VEC == 1) act.es = es[0];
-            else { _Pragma("unroll") for (int i = 0; i < VEC; ++i) act.es[i] = es[i]; }
-            act.cs = rollout_action_f<VEC>(r, c_cs, env0, t, k, live);
-            act.hs = rollout_action_f<VEC>(r, c_hs, env0, t, k, live);
-            act.ds = rollout_action_f<VEC>(r, c_ds, env0, t, k, live);
-            if (c_coh >= 0) {
-                const F c = rollout_action_f<VEC>(r, c_coh, env0, t, k, live);
-                act.cd = clv::vabs(clv::vmin(c, zero)); act.hd = clv::vabs(clv::vmax(c, zero));
+            F a_coh = zero;
+            if (r.s.actions) {
+                act.es = rollout_action_open<VEC>(r, c_es, env0, k, live); act.cs = rollout_action_open<VEC>(r, c_cs, env0, k, live);
+                act.hs = rollout_action_open<VEC>(r, c_hs, env0, k, live); act.ds = rollout_action_open<VEC>(r, c_ds, env0, k, live);
+                act.cd = rollout_action_open<VEC>(r, c_cd, env0, k, live); act.hd = rollout_action_open<VEC>(r, c_hd, env0, k, live);
+                a_coh = rollout_action_open<VEC>(r, c_coh, env0, k, live);
             } else {
-                act.cd = rollout_action_f<VEC>(r, c_cd, env0, t, k, live);
-                act.hd = rollout_action_f<VEC>(r, c_hd, env0, t, k, live);
+                rollout_rnd_refresh<VEC>(r, rnd, cols_lo, cols_hi, n_slot, env0, lane, t, k);
+                act.es = rollout_action_drawn<VEC>(r, rnd, s_es, c_es, lane, t); act.cs = rollout_action_drawn<VEC>(r, rnd, s_cs, c_cs, lane, t);
+                act.hs = rollout_action_drawn<VEC>(r, rnd, s_hs, c_hs, lane, t); act.ds = rollout_action_drawn<VEC>(r, rnd, s_ds, c_ds, lane, t);
+                act.cd = rollout_action_drawn<VEC>(r, rnd, s_cd, c_cd, lane, t); act.hd = rollout_action_drawn<VEC>(r, rnd, s_hd, c_hd, lane, t);
+                a_coh = rollout_action_drawn<VEC>(r, rnd, s_coh, c_coh, lane, t);
             }
+            if (c_coh >= 0) { act.cd = clv::vabs(clv::vmin(a_coh, zero)); act.hd = clv::vabs(clv::vmax(a_coh, zero)); }
             clv::Ou<F> O;
             const bool first = quirk && t == 0;
-            if (R.outage) clv::unit_step<F, true, false, PREC>(B, R, t, first, act, S, O, grow);
-            else clv::unit_step<F, false, false, PREC>(B, R, t, first, act, S, O, grow);
+            if (R.outage) clv::unit_step<F, true, false, PREC>(B, R, t, first, act, S, O, gz);
+            else clv::unit_step<F, false, false, PREC>(B, R, t, first, act, S, O, gz);
             const F rw = clv::unit_reward<F>(rkind, B, S, O.net);
             last_net = O.net; last_rw = rw;
             full_accumulate<VEC>(q_net, O.net); full_accumulate<VEC>(q_cost, O.cost); full_accumulate<VEC>(q_em, O.emission); full_accumulate<VEC>(q_rw, rw);
         }
-        if (rkind == CLR_MARL) {
+        if constexpr (MARL) {
             // (never chunked: host) the MARL reward couples the buildings through the district net of THIS step: one LDS exchange per step
             vstore<VEC>(lds + (size_t)w * TILE + lane * VEC, q_net);
             __syncthreads();
@@ -430,6 +537,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
             for (int i = 0; i < VEC; ++i) ret[i] += q_rw[i];
         }
     }
+    __syncthreads();                                                 // (the Philox blocks alias the reduction rows)
     if (live && own) {
         if (flags & CLF_BATTERY) {
             full_store<VEC, false>(a.state + CLS_B_SOC * plane + off, S.soc); full_store<VEC, false>(a.state + CLS_B_EFF * plane + off, S.eff);
@@ -444,7 +552,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
         }
     }
     if (r.k_steps > 0) {
-        if (rkind == CLR_MARL) {
+        if constexpr (MARL) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float rw_i;
@@ -452,7 +560,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
                 q_rw[i] = own ? rw_i : 0.0f;
             }
         }
-        district_reduce<VEC>(a, lds, w, lane, env0, live, plane, rkind == CLR_MARL ? (int)CLR_DEFAULT : rkind, q_net, q_cost, q_em, q_rw, a.nw);
+        district_reduce<VEC>(a, lds, w, lane, env0, live, plane, MARL ? (int)CLR_DEFAULT : rkind, q_net, q_cost, q_em, q_rw, a.nw);
     }
     if (r.ret_env) {
         __syncthreads();

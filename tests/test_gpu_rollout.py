@@ -194,7 +194,8 @@ def test_chunked_fused_rollout_equals_single_steps(name, kind, B, E, tuning):
     b.rollout(K, actions=acts, ret_env=ret)
     # (round 6: thermal districts run the pack-generic unit of cl_full.h inside the K-step loop, cl_rollout_full_kernel -- two envs per lane on the fp32 map)
     thermal = name == 'g2020_cz1'
-    assert ('cl_rollout_full_kernel<2, true, 0>' if thermal else 'cl_rollout_kernel') in b.last_kernels and b.last_kernels.endswith(', true, 0>+cl_finish_kernel'), b.last_kernels
+    assert (b.last_kernels == 'cl_rollout_full_kernel<2, true, 0, false>+cl_finish_kernel') if thermal else \
+        ('cl_rollout_kernel' in b.last_kernels and b.last_kernels.endswith(', true, 0>+cl_finish_kernel')), b.last_kernels
     _close(b.state, a.state)
     _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
     # district sums over B buildings: the per-building tolerance times the district size
@@ -262,7 +263,8 @@ def test_fused_rollout_with_the_f64_chain(name, B, E):
     b.rollout(K, actions=acts, ret_env=ret)
     # (two envs per lane where the batch fills the chip in whole rounds -- 32 768 envs, the C5 shard -- else one)
     lean = name == 'g2022_all'
-    assert (('cl_rollout_kernel<2, ' if E >= 32768 else 'cl_rollout_kernel<1, ') if lean else 'cl_rollout_full_kernel<1, ') in b.last_kernels and ', 2>' in b.last_kernels, b.last_kernels
+    assert (('cl_rollout_kernel<2, ' if E >= 32768 else 'cl_rollout_kernel<1, ') if lean else 'cl_rollout_full_kernel<1, ') in b.last_kernels and \
+        (', 2>' if lean else ', 2, ') in b.last_kernels, b.last_kernels
     _close(b.state, a.state)
     _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
     torch.testing.assert_close(b.out_env, a.out_env, rtol=1e-5, atol=1e-6 * max(B, 17))
@@ -391,7 +393,9 @@ def test_packed_thermal_rollout_against_the_scalar_unit_and_single_steps(name, B
     rb, rc = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
     b.rollout(K, actions=acts, ret_env=rb, t0=t0)
     c.rollout(K, actions=acts, ret_env=rc, t0=t0)
-    assert b.last_kernels.startswith(f'cl_rollout_full_kernel<{1 if f64 else 2}, ') and c.last_kernels.startswith('cl_rollout_kernel<1, true, 1, '), (b.last_kernels, c.last_kernels)
+    marl = kind == 'MARL'                                # (one LDS exchange per step: its own instantiation, one env per lane)
+    assert b.last_kernels.startswith(f'cl_rollout_full_kernel<{1 if f64 or marl else 2}, ') and f", {'true' if marl else 'false'}>" in b.last_kernels and \
+        c.last_kernels.startswith('cl_rollout_kernel<1, true, 1, '), (b.last_kernels, c.last_kernels)
     nb = max(B, len(spec.buildings))
     for x in (b, c):
         _close(x.state, a.state)
@@ -406,3 +410,45 @@ def test_packed_thermal_rollout_against_the_scalar_unit_and_single_steps(name, B
     p.rollout(12, seed=9, t0=t0); q.rollout(12, seed=9, t0=t0)
     _close(p.state, q.state)
     _close(p.out_bldg[:2], q.out_bldg[:2], 2e-5)
+
+
+@pytest.mark.parametrize('f64', [False, 'chain'])
+def test_packed_rollout_with_six_action_columns(f64):
+    """The packed thermal rollout keeps the Philox blocks of a building's first four action columns in LDS at two envs per lane (six at one) and
+    redraws a fifth / sixth column's word every step: a district whose buildings act on all six columns (2023 phase-2 buildings given the two missing
+    tanks, a heating device and their actions) -- same streams as the scalar-unit kernel and as the policy's host definition."""
+    import copy
+    import dataclasses
+    spec = copy.deepcopy(golden('g2023_p2').spec())
+    for b in spec.buildings:
+        b.action_metadata = dict(b.action_metadata, cooling_storage=True, heating_storage=True, heating_device=True)
+        b.cooling_storage = dataclasses.replace(b.dhw_storage)
+        b.heating_storage = dataclasses.replace(b.dhw_storage)
+        b.heating_device = dataclasses.replace(b.cooling_device)
+    assert all(len(b.active_actions) == 6 for b in spec.buildings)
+    tab = spec.episode_tables(0)
+    E, K = 260, 11                                      # (t0 = 2: the first block covers steps 2 .. 3 only)
+    low, high = spec.action_limits()
+    p, q = StepEngine(tab, E, f64_maps=f64), StepEngine(tab, E, f64_maps=f64, tuning=dict(full_variant=1))
+    p.trace_kernels()
+    rp, rq = torch.zeros(E, device='cuda'), torch.zeros(E, device='cuda')
+    for e, ret in ((p, rp), (q, rq)):
+        e.set_action_limits(low, high)
+        e.rollout(K, seed=77, t0=2, ret_env=ret)
+    assert p.last_kernels.startswith(f'cl_rollout_full_kernel<{1 if f64 else 2}, false, '), p.last_kernels
+    _close(p.state, q.state)
+    _close(p.out_bldg[:2], q.out_bldg[:2], 2e-5)
+    torch.testing.assert_close(rp, rq, rtol=1e-5, atol=1e-3)
+    # ... and as K single steps on the actions the host definition of the stream gives (a sample of envs: one call per draw)
+    a = StepEngine(tab, E, f64_maps=f64)
+    lib = _lib.load()
+    lib.cl_philox_uniform.restype = ctypes.c_float
+    lib.cl_philox_uniform.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    sample = list(range(0, E, 37))
+    u = np.array([[[lib.cl_philox_uniform(77, e, c, 2 + k) for e in sample] for c in range(len(low))] for k in range(K)], dtype=np.float32)
+    acts = torch.zeros((K, len(low), E), device='cuda')
+    acts[:, :, sample] = torch.from_numpy((low[None, :, None] + u * (high - low)[None, :, None]).astype(np.float32)).cuda()
+    for k in range(K):
+        a.step(acts[k], 2 + k)
+    _close(p.state[:, :, sample], a.state[:, :, sample])
+    _close(p.out_bldg[:2][:, :, sample], a.out_bldg[:2][:, :, sample], 2e-5)
