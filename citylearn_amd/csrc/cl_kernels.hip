@@ -1949,6 +1949,21 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
             long long want = ((long long)dims->n_bldg * grid_x + 255) / 256;          // buildings per chunk for 256 workgroups ...
             r = 2; while (16 * r < want && r < 8) r *= 2;                            // ... as a power of two, 128 at most (40 KB of staged blocks)
         }
+        // (round 6) the thermal kernel around the float64 chain (one env per lane, parameter blocks through the constant cache): ONE workgroup per CU --
+        // 256 workgroups, chunks of up to 256 buildings.  1024 buildings x 1024 / 2048 / 4096 / 8192 envs with chunks of 32 / 64 / 128 / 256:
+        // 20.2 / 17.7 / 27.4 / 47.6, 37.4 / 33.5 / 31.3 / 48.8, 71.3 / 68.7 / 67.5 / 65.8, 149.7 / 137.3 / 129.5 / 125.4 us
+        // (scripts/gpurun/r06_call15.sh, profiles/r06o_*).
+        const bool chain_full_shape = chain && !(dims->flags & CLD_LEAN) && !flex && !(dims->flags & (CLD_WRITE_DETAIL | CLD_F64_MAPS)) && tun.full_variant != 1;
+        // 128 .. 1024 buildings x 1024 .. 65 536 envs (scripts/r06_chunk_sweep.py, profiles/r06p_chunks_*.jsonl): the rule is within 3 % of the best chunk size
+        // of every cell -- 128 x 16 384 36.4 -> 25.6 us, 256 x 16 384 66.9 -> 49.2, 512 x 16 384 153 -> 126, 1024 x 16 384 317 -> 249 (chunks as large as
+        // the district = one workgroup row, no second launch)
+        if (chain_full_shape && dims->n_bldg >= 128 && (long long)dims->n_bldg * grid_x >= 16ll * 1024) {
+            const long long want = ((long long)dims->n_bldg * grid_x + 255) / 256;
+            r = 2; while (16 * r < want && r < 16) r *= 2;
+        }
+        // (fp32 map, same sweep: up to 256 buildings x 65 536 envs in ONE workgroup row -- 128 buildings 113 -> 98 us, 256 buildings 204 -> 182 us; at
+        //  16 384 envs the chunked launch stays ahead, 29.0 vs 32.4 and 49.0 vs 59.1 us)
+        if (lp_shape && dims->n_bldg <= 256 && grid_x >= 512) r = 16;
         // ... whose plane stores take the non-temporal hint at every batch size (the footprint rule above is the battery + PV kernels': 1024 x
         // 8192 envs 101.2 -> 100.0 us, x 4096 54.3 -> 53.3 us, chunks of 128: 91.4 -> 89.1 us; profiles/r05l_*, r05m_*)
         if (lp_shape && tun.nt_stores == 0) a.nt = 1;
