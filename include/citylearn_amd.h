@@ -429,8 +429,11 @@ int cl_step_f32(const cl_dims* dims, const uint32_t* params, const float* ts, fl
  * actions[k*act_stride_step + col*act_stride_col + env*act_stride_env].
  * `ret_env` [n_env] (optional) accumulates the district reward sum over the k steps (episode return);
  * out_bldg / out_env receive the values of the LAST step.
+ * Thermal / outage districts without CLD_WRITE_DETAIL run the pack-generic unit of the thermal step kernels inside the K-step loop (round 6,
+ * cl_rollout_full_kernel: one building per wave, two envs per lane on the fp32 map, the Philox blocks of a building's columns cached in LDS for
+ * their four steps; `cl_tuning.full_variant` = 1 keeps the scalar-unit kernel for A/B; districts of more than 65 536 action columns keep it too).
  * Districts of more than 32 battery + PV / 16 thermal buildings run building-chunked (round 5): workgroup rows of `cl_tuning.b_chunk` (default 32 /
- * 16) buildings, the last step's chunk partial sums and each chunk's share of the return in the scratch rows of out_bldg's reserved plane
+ * 8) buildings, the last step's chunk partial sums and each chunk's share of the return in the scratch rows of out_bldg's reserved plane
  * (n_chunks x (CL_NQ + 1) rows of n_env floats), folded by ONE cl_finish_kernel launch per call -- out_env / ret_env are final on return.
  * Limits of the fused kernel: no streaming KPIs (CLD_KPI), no flexible loads, no CLD_F64_MAPS (CLD_F64_CHAIN is available), and on a chunked
  * district no reward that couples the buildings inside a step (CLR_MARL: CL_EINVAL) -- cl_rollout_seq_f32 below runs the same K steps as a
