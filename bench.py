@@ -579,9 +579,9 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
                                f'jittered +-10 %) x {E} envs per GPU, cl_rollout_f32 mode B on the building-chunked district: 24 fused env steps per launch, unit state in '
                                'registers, on-device Philox4x32-10 uniform random policy, one cl_finish_kernel per launch (district sums of the last step + K-step returns); '
                                'env batch sharded over GPUs (8 x 1024 = the 8192 envs of BASELINE config 4), no collective',
-                               f64=f64, valu_per_unit_step=222.6 if thermal else 100.0, valu_chain=361.9 if thermal else None,
-                               valu_source=('profiles/r06l_c4b_*_sq_by_kernel.jsonl: SQ_INSTS_VALU of cl_rollout_full_kernel per launch x 64 lanes / (1024 x 1024 x 24 unit-steps) = '
-                                            '222.6 lane-instructions per unit-step at two envs per lane (packed fp32), 361.9 at one under the float64 chain (float64 instructions '
+                               f64=f64, valu_per_unit_step=216.6 if thermal else 100.0, valu_chain=343.1 if thermal else None,
+                               valu_source=('profiles/r06w_c4b_*_sq_by_kernel.jsonl: SQ_INSTS_VALU of cl_rollout_full_kernel per launch x 64 lanes / (1024 x 1024 x 24 unit-steps) = '
+                                            '216.6 lane-instructions per unit-step at two envs per lane (packed fp32), 343.1 at one under the float64 chain (float64 instructions '
                                             'counted as one issue each)'
                                             if thermal else 'profiles/archive/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step (battery + PV fused kernel)'))
     if cfg in ('C4', 'C4-lean'):

@@ -350,7 +350,7 @@ CL_DEV int rollout_rnd_row(int slot, int t) {
 // four for a building of up to CL_ROLLOUT_SLOTS columns.  (A loop over the unit's seven candidate columns with its selects and skips was ~ 100
 // scalar instructions and ~ 20 branches per step and wave: 4 waves per SIMD do not hide that -- SALU +77 %, vector-ALU busy 85 -> 66 %.)
 template <int VEC>
-CL_DEV void rollout_rnd_refresh(const RolloutArgs& r, uint32_t* __restrict__ rnd, unsigned long long cols_lo, uint32_t cols_hi, int n_slot, int env0, int lane, int t, int k) {
+CL_DEV void rollout_rnd_refresh(const RolloutArgs& r, float* __restrict__ rnd, unsigned long long cols_lo, uint32_t cols_hi, int n_slot, int env0, int lane, int t, int k) {
     constexpr int TILE = 64 * VEC;
     const bool four = k == 0 || (t & 3) == 0;
 #pragma unroll 1
@@ -359,34 +359,36 @@ CL_DEV void rollout_rnd_refresh(const RolloutArgs& r, uint32_t* __restrict__ rnd
         cl::U4 blk[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) blk[i] = cl::philox_block(r.seed, (uint32_t)(env0 + i) + r.s.env_offset, col, (uint32_t)t >> 2);
+        // what the rows hold is the ACTION, a = low + u (high - low): the column's bounds are read here, once per block, not once per draw
+        // (two scalar loads and their round trip per column and step, from addresses that sat in spilled SGPRs)
+        const float lo = r.act_low[col], span = r.act_high[col] - lo;
         if (slot < CL_ROLLOUT_SLOTS<VEC>) {
-            uint32_t* c = rnd + (size_t)slot * 4 * TILE + lane * VEC;
+            float* c = rnd + (size_t)slot * 4 * TILE + lane * VEC;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) c[w * TILE + i] = blk[i].w[w];
+                for (int i = 0; i < VEC; ++i) c[w * TILE + i] = fmaf(cl::u01(blk[i].w[w]), span, lo);
             }
         } else {
-            uint32_t* c = rnd + (size_t)rollout_rnd_row<VEC>(slot, t) * TILE + lane * VEC;
+            float* c = rnd + (size_t)rollout_rnd_row<VEC>(slot, t) * TILE + lane * VEC;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) c[i] = cl::philox_word(blk[i], (uint32_t)t & 3u);
+            for (int i = 0; i < VEC; ++i) c[i] = fmaf(cl::u01(cl::philox_word(blk[i], (uint32_t)t & 3u)), span, lo);
         }
     }
 }
 
 // one column of the on-device policy from the wave's cached words / of the open-loop action tensor
 template <int VEC>
-CL_DEV typename Vec<VEC>::type rollout_action_drawn(const RolloutArgs& r, const uint32_t* rnd, int slot, int col, int lane, int t) {
+CL_DEV typename Vec<VEC>::type rollout_action_drawn(const float* rnd, int slot, int col, int lane, int t) {
     constexpr int TILE = 64 * VEC;
     float d[VEC];
     if (col < 0) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) d[i] = 0.0f;
     } else {
-        const float lo = r.act_low[col], span = r.act_high[col] - lo;
-        const uint32_t* w = rnd + (size_t)rollout_rnd_row<VEC>(slot, t) * TILE + lane * VEC;
+        const float* w = rnd + (size_t)rollout_rnd_row<VEC>(slot, t) * TILE + lane * VEC;
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) d[i] = fmaf(cl::u01(w[i]), span, lo);
+        for (int i = 0; i < VEC; ++i) d[i] = w[i];
     }
     if constexpr (VEC == 1) return d[0];
     else { typename Vec<VEC>::type v; _Pragma("unroll") for (int i = 0; i < VEC; ++i) v[i] = d[i]; return v; }
@@ -452,7 +454,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
 #pragma unroll
     for (int i = 0; i < VEC; ++i) ret[i] = 0.0f;
     F last_net = zero, last_rw = zero;
-    uint32_t* rnd = reinterpret_cast<uint32_t*>(lds) + (size_t)a.nw * TILE + (size_t)w * CL_ROLLOUT_RND_ROWS<VEC> * TILE;      // this wave's Philox words
+    float* rnd = lds + (size_t)a.nw * TILE + (size_t)w * CL_ROLLOUT_RND_ROWS<VEC> * TILE;      // this wave's drawn actions
     // slots in column order of the unit (wave-uniform), their column ids packed 16 bits each
     int n_slot = 0;
     unsigned long long cols_lo = 0ull;
@@ -494,10 +496,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
                 a_coh = rollout_action_open<VEC>(r, c_coh, env0, k, live);
             } else {
                 rollout_rnd_refresh<VEC>(r, rnd, cols_lo, cols_hi, n_slot, env0, lane, t, k);
-                act.es = rollout_action_drawn<VEC>(r, rnd, s_es, c_es, lane, t); act.cs = rollout_action_drawn<VEC>(r, rnd, s_cs, c_cs, lane, t);
-                act.hs = rollout_action_drawn<VEC>(r, rnd, s_hs, c_hs, lane, t); act.ds = rollout_action_drawn<VEC>(r, rnd, s_ds, c_ds, lane, t);
-                act.cd = rollout_action_drawn<VEC>(r, rnd, s_cd, c_cd, lane, t); act.hd = rollout_action_drawn<VEC>(r, rnd, s_hd, c_hd, lane, t);
-                a_coh = rollout_action_drawn<VEC>(r, rnd, s_coh, c_coh, lane, t);
+                act.es = rollout_action_drawn<VEC>(rnd, s_es, c_es, lane, t); act.cs = rollout_action_drawn<VEC>(rnd, s_cs, c_cs, lane, t);
+                act.hs = rollout_action_drawn<VEC>(rnd, s_hs, c_hs, lane, t); act.ds = rollout_action_drawn<VEC>(rnd, s_ds, c_ds, lane, t);
+                act.cd = rollout_action_drawn<VEC>(rnd, s_cd, c_cd, lane, t); act.hd = rollout_action_drawn<VEC>(rnd, s_hd, c_hd, lane, t);
+                a_coh = rollout_action_drawn<VEC>(rnd, s_coh, c_coh, lane, t);
             }
             if (c_coh >= 0) { act.cd = clv::vabs(clv::vmin(a_coh, zero)); act.hd = clv::vabs(clv::vmax(a_coh, zero)); }
             clv::Ou<F> O;
