@@ -65,6 +65,9 @@ for c in C4-B C4-lean-B; do
   for E in 1024 8192; do python bench.py --config $c --envs-per-gpu $E > $OUT/bench_${c}_$E.json 2>/dev/null; done
 done
 trace c4leanb python bench.py --config C4-lean-B --reps 1
+trace c4b python bench.py --config C4-B --reps 1
+chk $OUT/bench_C4-B_1024.json $OUT/c4b_kernel_stats.csv
+for E in 1024 8192; do python bench.py --config C4-B --envs-per-gpu $E --precision fp32 > $OUT/bench_fp32_C4-B_$E.json 2>/dev/null; done
 # ---- the all-fp32 map (the opt-in throughput mode) and the float64 reference mode ----
 python bench.py --precision fp32 --no-cpu-baseline --no-traffic-pass > $OUT/bench_fp32.json 2>$OUT/bench_fp32.err
 trace fp32 $BENCH --precision fp32
