@@ -1557,6 +1557,7 @@ extern "C" __attribute__((visibility("hidden"))) int cl_tu_launch_rollout(int ke
     case 2022: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2, true, false, 2>), grid, block, lds, s, r); break;
     case 2111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1, true, false, 2>), grid, block, lds, s, r); break;
     case 3012: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, true, true, 2>), grid, block, lds, s, r); break;
+    case 3022: hipLaunchKernelGGL((cl_rollout_kernel<2, false, 2, true, true, 2>), grid, block, lds, s, r); break;
     case 3111: hipLaunchKernelGGL((cl_rollout_kernel<1, true, 1, true, true, 2>), grid, block, lds, s, r); break;
     // building-chunked districts (gridDim.y workgroup rows; cl_rollout.h)
     case 1012: hipLaunchKernelGGL((cl_rollout_kernel<1, false, 2, true, true>), grid, block, lds, s, r); break;
@@ -2535,7 +2536,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
     const bool full_rounds = (long long)dims->n_env * a.n_chunks >= 32768 && wg2 * 100 >= rounds2 * 256 * 85 && dims->n_env >= 128;
     const bool chain = dims->flags & CLD_F64_CHAIN;          // (the float64 soc chain: two envs per lane only where one workgroup row holds the district)
     int vec = tun.vec ? tun.vec : ((!full && (actions == nullptr || act_stride_env == 1) && full_rounds) ? 2 : 1);
-    if (chain && (chunked || full || vec > 2)) vec = 1;
+    if (chain && (full || vec > 2)) vec = 1;                 // (chunked battery + PV districts keep the two-env pack under the chain too: 1024 x 1024 / x 8192 127.6 -> 107.9 / 932.9 -> 798.9 us per 24 steps, profiles/r06z_*)
     const int tile = 64 * vec;
     const unsigned grid = (unsigned)((dims->n_env + tile - 1) / tile);
     const size_t lds = (size_t)a.nw * NQ * tile * sizeof(float);
@@ -2565,7 +2566,7 @@ int cl_rollout_f32(const cl_dims* dims, const uint32_t* params, const float* ts,
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return hip_fail(e, "cl_rollout_full_kernel launch");
     } else {
     const int key = (full ? 100 : 0) + vec * 10 + mb;
-    if ((key != 11 && key != 12 && key != 21 && key != 22 && key != 111) || ((chunked || chain) && key != 12 && key != 22 && key != 111) || (chain && chunked && key == 22))
+    if ((key != 11 && key != 12 && key != 21 && key != 22 && key != 111) || ((chunked || chain) && key != 12 && key != 22 && key != 111) )
         return fail(CL_EINVAL, "no rollout kernel for vec %d / buildings-per-wave %d / %s", vec, mb, full ? "full" : "lean");
     const bool pin = chunked || chain || (long long)grid * a.nw > 5 * 1024;
     // (spelled as rocprofv3 prints them: every template argument, defaults included)

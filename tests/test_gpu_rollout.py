@@ -452,3 +452,37 @@ def test_packed_rollout_with_six_action_columns(f64):
         a.step(acts[k], 2 + k)
     _close(p.state[:, :, sample], a.state[:, :, sample])
     _close(p.out_bldg[:2][:, :, sample], a.out_bldg[:2][:, :, sample], 2e-5)
+
+
+@pytest.mark.parametrize('B,E,vec', [(64, 16384, 2), (70, 1028, 1), (1024, 256, 1), (1024, 1024, 2)])
+def test_chunked_fused_rollout_under_the_chain_at_both_pack_widths(B, E, vec):
+    """The building-chunked battery + PV rollout around the float64 chain: one env per lane where the launch is small, TWO where its 128-env workgroups
+    fill the chip (round 6: `cl_rollout_kernel<2, false, 2, true, true, 2>`, 1024 x 1024 127.6 -> 107.9 us per 24 steps) -- against K single steps
+    under the same precision model, open-loop actions and the on-device policy (whose stream does not depend on the pack width)."""
+    from citylearn_amd.synthetic import tile_district
+    spec = tile_district(golden('g2022_all').spec(), B)
+    tab = spec.episode_tables(0)
+    K = 24
+    low, high = spec.action_limits()
+    gen = torch.Generator(device='cuda').manual_seed(B * 7 + E)
+    lo, hi = torch.from_numpy(low).cuda(), torch.from_numpy(high).cuda()
+    acts = lo[None, :, None] + torch.rand((K, len(low), E), device='cuda', generator=gen) * (hi - lo)[None, :, None]
+    a, b = StepEngine(tab, E, f64_maps='chain'), StepEngine(tab, E, f64_maps='chain')
+    b.trace_kernels()
+    ret_ref = torch.zeros(E, device='cuda', dtype=torch.float64)
+    for k in range(K):
+        a.step(acts[k])
+        ret_ref += a.district_reward.double()
+    ret = torch.zeros(E, device='cuda')
+    b.rollout(K, actions=acts, ret_env=ret)
+    assert b.last_kernels == f'cl_rollout_kernel<{vec}, false, 2, true, true, 2>+cl_finish_kernel', b.last_kernels
+    _close(b.state, a.state)
+    _close(b.out_bldg[:2], a.out_bldg[:2], 2e-5)
+    torch.testing.assert_close(b.out_env, a.out_env, rtol=1e-5, atol=1e-6 * B)
+    torch.testing.assert_close(ret.double(), ret_ref, rtol=1e-5, atol=2e-5 * B)
+    p, q = StepEngine(tab, E, f64_maps='chain'), StepEngine(tab, E, f64_maps='chain', tuning=dict(vec=3 - vec))
+    for e in (p, q):
+        e.set_action_limits(low, high)
+        e.rollout(12, seed=5)
+    _close(p.state, q.state)
+    _close(p.out_bldg[:2], q.out_bldg[:2], 2e-5)
