@@ -797,8 +797,10 @@ def run_rank(args):
         torch.cuda.empty_cache()
         # `fixed-65536`: north_star's sentence also reads as ONE 65 536-env batch split over the N GPUs (strong scaling: 65 536 / N envs per rank --
         # at N = 8 a launch-bound 8 192-env kernel); the headline above is the weak-scaling reading (65 536 envs PER GPU).  Both are in the line.
-        for xc in ('fixed-65536', 'C4', 'C4-lean', 'C5'):
-            x_steps, x_warm = (200, 30) if xc == 'C5' else (2000, 200)
+        # (round 6: BASELINE config 4 also in mode B -- `C4-B` / `C4-lean-B`, one step = one fused 24-step launch -- the config's fast path since the
+        #  thermal district runs the packed unit there)
+        for xc in ('fixed-65536', 'C4', 'C4-lean', 'C5', 'C4-B', 'C4-lean-B'):
+            x_steps, x_warm = {'C5': (200, 30), 'C4-B': (100, 10), 'C4-lean-B': (200, 20)}.get(xc, (2000, 200))
             if os.environ.get('CL_BENCH_EXTRA_CONFIGS') == '1':
                 x_steps, x_warm = x_steps // 10, x_warm // 10
             if xc == 'fixed-65536':
@@ -807,7 +809,7 @@ def run_rank(args):
                 wl_x.what += f'; FIXED total batch: {ENVS_PER_GPU} envs split over {world} rank(s) = {e_fixed} envs per GPU (strong scaling)'
             else:
                 wl_x = build_workload(xc, DEFAULT_ENVS[xc], device, rank, world, tuning, f64, False, args.table_hours)
-            x_walls, _, x_launch, x_rank, x_rank_k = measure(wl_x, x_warm, x_steps, 3, 200 if xc == 'C5' else 2000)
+            x_walls, _, x_launch, x_rank, x_rank_k = measure(wl_x, x_warm, x_steps, 3, x_steps if xc in ('C5', 'C4-B', 'C4-lean-B') else 2000)
             x_wall = statistics.median(x_walls)
             extra[xc] = {'workload': wl_x.what, 'value': world * wl_x.units_per_step * x_steps / x_wall, 'unit': 'building-timesteps/s',
                          'ms_per_step': x_wall / x_steps * 1e3, 'steps': x_steps, 'warmup': x_warm, 'reps': 3, 'envs_per_gpu': wl_x.E,

@@ -70,12 +70,14 @@ def test_scale_run_extras_on_the_one_gpu_there_is():
     (`extra_configs`), per-rank kernel time next to per-rank wall time, and the ranks' CPU pinning -- two ranks sharing device 0."""
     two = _bench('--gpus', '2', '--steps', '20', '--warmup', '5', '--reps', '2', '--no-streaming', env={'CL_BENCH_OVERSUBSCRIBE': '1', 'CL_BENCH_EXTRA_CONFIGS': '1'})
     assert len(two['rank_launch_us']) == 2 and all(3.0 < k < 60.0 for k in two['rank_launch_us']), two['rank_launch_us']
-    assert set(two['extra_configs']) == {'fixed-65536', 'C4', 'C4-lean', 'C5'}
+    assert set(two['extra_configs']) == {'fixed-65536', 'C4', 'C4-lean', 'C5', 'C4-B', 'C4-lean-B'}
     for name, x in two['extra_configs'].items():
         assert x['value'] > 1e9 and len(x['rank_ms_per_step']) == 2 and len(x['rank_launch_us']) == 2 and x['roofline']['kernel'], name
     fx = two['extra_configs']['fixed-65536']                                               # ONE 65 536-env batch over the ranks: north_star's other reading
     assert fx['scaling'] == 'strong' and fx['envs_per_gpu'] == 32768 and 'chain' in fx['roofline']['kernel']
     assert 'cl_rollout_kernel' in two['extra_configs']['C5']['roofline']['kernel']
+    assert two['extra_configs']['C4-B']['roofline']['kernel'].startswith('cl_rollout_full_kernel<1, true, 2, false>')      # (config 4's thermal district in mode B: the packed unit)
+    assert two['extra_configs']['C4-B']['value'] > two['extra_configs']['C4']['value']
     aff = two['rank_affinity']
     assert len(aff) == 2
     if aff[0] is not None:                                   # (None: the box does not expose the GPU's NUMA node)
