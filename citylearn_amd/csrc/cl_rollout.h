@@ -464,7 +464,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4))) 
         if (n_slot < 4) cols_lo |= (unsigned long long)(uint32_t)c << (16 * n_slot); else cols_hi |= (uint32_t)c << (16 * (n_slot - 4));
         return n_slot++;
     };
-    const int s_es = slot_of(c_es), s_cs = slot_of(c_cs), s_hs = slot_of(c_hs), s_ds = slot_of(c_ds), s_coh = slot_of(c_coh), s_cd = slot_of(c_cd), s_hd = slot_of(c_hd);
+    const int s_es = slot_of(c_es), s_cs = slot_of(c_cs), s_hs = slot_of(c_hs), s_ds = slot_of(c_ds), s_coh = slot_of(c_coh),
+              // (a combined cooling-or-heating column takes the place of the two device columns, building.py:1557-1564: at most six columns, six slots)
+              s_cd = c_coh >= 0 ? 0 : slot_of(c_cd), s_hd = c_coh >= 0 ? 0 : slot_of(c_hd);
     const int row0 = a.env_row0 ? a.env_row0[(blockIdx.x * TILE) / CL_ROW0_BLOCK] : 0;   // workgroup-uniform
     for (int k = 0; k < r.k_steps; ++k) {
         const int t = r.t0 + k;
