@@ -774,15 +774,21 @@ def run_rank(args):
             side['hbm_streaming']['speedup_vs_default'] = roof['launch_us'] / fs['launch_us']
         roof['fp32_map'] = side
 
-    if cfg == 'C2' and not args.no_side_entries:
+    if cfg in ('C2', 'T9') and not args.no_side_entries and not args.kpi:
         # BASELINE config 2 (17 x 4 096 envs) is 2.7 MB per step: one launch per step is launch latency whatever the kernel does.
         # What a user who wants THROUGHPUT at this batch size gets is mode B -- 24 fused steps per launch, state in registers -- measured here beside mode A.
         wl = None
         torch.cuda.empty_cache()
-        spec_b = load_c2_spec(args.table_hours)
-        wl_b = RolloutWorkload('C2-B', spec_b, E, 24, device, rank, world, tuning, 'mode B at the C2 shape', f64=f64)
+        # (T9, round 6: the thermal district through the packed unit of cl_rollout_full_kernel)
+        if cfg == 'C2':
+            spec_b = load_c2_spec(args.table_hours)
+        else:
+            from citylearn_amd import load_district
+            from citylearn_amd.data import sample_schema
+            spec_b = load_district(sample_schema('citylearn_challenge_2020_climate_zone_1_744h'))
+        wl_b = RolloutWorkload(cfg + '-B', spec_b, E, 24, device, rank, world, tuning, f'mode B at the {cfg} shape', f64=f64)
         _, _, b_launch, _, _ = measure(wl_b, 10, 100, 1, 200)
-        roof['mode_b'] = {'what': f'cl_rollout_f32 at the same shape (17 buildings x {E} envs): 24 fused env steps per launch, on-device Philox policy, state in registers',
+        roof['mode_b'] = {'what': f'cl_rollout_f32 at the same shape ({len(spec_b.buildings)} buildings x {E} envs): 24 fused env steps per launch, on-device Philox policy, state in registers',
                           'kernel': wl_b.kernels, 'launch_us_per_24_steps': b_launch * 1e6, 'us_per_step': b_launch * 1e6 / 24,
                           'value': world * wl_b.units_per_step / b_launch, 'speedup_vs_mode_a': roof['launch_us'] / (b_launch * 1e6 / 24)}
         wl_b = None

@@ -97,7 +97,8 @@ def test_more_ranks_than_gpus_is_refused_without_the_hook():
                                                    ('C3', 'cl_lstm_kernel<', 'valu', 'chain'), ('C4', 'cl_step_full_', 'hbm', 'chain'),
                                                    ('C4', 'cl_step_full_kernel<2, false, 1024, 4, true, true>', 'hbm', 'fp32'),
                                                    ('C5', 'cl_rollout_kernel<2, false, 2, true, false, 2>', 'valu', 'chain'),
-                                                   ('C5', 'cl_rollout_kernel<2, false, 2, true, false, 0>', 'valu', 'fp32')])
+                                                   ('C5', 'cl_rollout_kernel<2, false, 2, true, false, 0>', 'valu', 'fp32'),
+                                                   ('T9', 'cl_step_full_tp_chain_kernel<1, 4, true>', 'hbm', 'chain')])
 def test_config_lines(cfg, kernel, bound, prec):
     out = _bench('--config', cfg, '--precision', prec, '--steps', '20', '--warmup', '5', '--reps', '2')
     assert out['config']['name'] == cfg and out['roofline']['bound'] == bound and kernel in out['roofline']['kernel'], out['roofline']['kernel']
@@ -106,6 +107,10 @@ def test_config_lines(cfg, kernel, bound, prec):
         # config 2 is launch latency in mode A (2.7 MB per step): the line says what mode B gives a user at the same batch size
         mb = out['roofline']['mode_b']
         assert 'cl_rollout_kernel' in mb['kernel'] and mb['speedup_vs_mode_a'] > 1.5 and mb['value'] > out['value'], mb
+    if cfg == 'T9':
+        # ... and the thermal district in mode B: the packed unit inside the K-step loop (round 6)
+        mb = out['roofline']['mode_b']
+        assert mb['kernel'].startswith('cl_rollout_full_kernel<1, false, 2, false>') and mb['speedup_vs_mode_a'] > 1.0, mb
 
 
 def test_thermal_kpi_line_runs_the_kpis_inside_the_step_launch():
