@@ -581,7 +581,8 @@ def build_workload(cfg: str, E: int, device: str, rank: int, world: int, tuning:
                                'env batch sharded over GPUs (8 x 1024 = the 8192 envs of BASELINE config 4), no collective',
                                f64=f64, valu_per_unit_step=216.6 if thermal else 100.0, valu_chain=343.1 if thermal else None,
                                valu_source=('profiles/r06w_c4b_*_sq_by_kernel.jsonl: SQ_INSTS_VALU of cl_rollout_full_kernel per launch x 64 lanes / (1024 x 1024 x 24 unit-steps) = '
-                                            '216.6 lane-instructions per unit-step at two envs per lane (packed fp32), 343.1 at one under the float64 chain (float64 instructions '
+                                            '216.6 lane-instructions per unit-step at two envs per lane (packed fp32), 343.1 at one under the float64 chain (the same counts at 8192 envs, '
+                                            'profiles/r06z6_*, where GRBM_GUI_ACTIVE puts the clock at 2.38 GHz and SQ_ACTIVE_INST_VALU at 1.01 x the launch: frac ~ 1 = saturated; float64 instructions '
                                             'counted as one issue each)'
                                             if thermal else 'profiles/archive/r02b_rollout_pmc_by_kernel.jsonl: 100 VALU instructions per unit-step (battery + PV fused kernel)'))
     if cfg in ('C4', 'C4-lean'):
