@@ -2064,7 +2064,20 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // cl_step_observe_f32 on a thermal / outage district: the step launch fills the compact observation itself (cl_full.h OBS) where it is one
     // workgroup row of the one-env-per-lane kernel or the multi-tile kernel, without detail planes / KPIs / a coupled reward
     const bool obs_full = of_full && full && !flex && !det && !f64 && !(dims->flags & CLD_KPI) && a.n_chunks == 1 && rkind_host != CLR_MARL && tuning_of(dims).obs_variant == 0;
-    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 480 || (tun.lean_variant & 2) || kpi_lean || (chain && dims->n_bldg > 17 && dims->n_bldg <= 20)) &&
+    // Env-major or building-major above one wave generation?  Re-measured in round 6, both kernels alternating in ONE process (scripts/r06_lean_vs_envmajor.py,
+    // profiles/r06_lean_vs_envmajor*.log; a process lands in a +- 4 % band, which is what hid this in round 5):
+    //  * the env-major kernel wins where the step's footprint is of the order of the Infinity Cache -- 17 x 262 144: 25.8 / 30.7 us (fp32 / chain) against 27.9 /
+    //    32.2 for the latency-ordered building-major kernel at four envs per lane; 9 x 262 144: 16.1 / 18.8 against 19.2 / 21.4;
+    //  * far beyond the cache the building-major kernel's 16-byte accesses win again: 17 x 1 048 576 -- the HBM-true shape of the bench line -- 104.6 - 111.8 us
+    //    against 113.5 - 127.6 us (fp32) and 113.5 - 120.4 against 125.6 - 134.4 (chain) in three processes, 17 x 2 097 152 222 - 224 / 236 against 225 - 247 /
+    //    245 - 261, 20 x 1 048 576 (fp32) 126 - 129 against 133 - 140: districts of 16 .. 20 buildings from 16 Mi units;
+    //  * under the float64 chain the building-major kernel holds on longer below: 17 x 147 456 / 163 840 / 180 224 20.5 / 21.8 / 22.8 us against 23.4 / 24.2 /
+    //    25.2 (196 608: 24.4 - 25.6 against 25.8 - 26.5; 229 376: even); 9 and 6 buildings: 131 072 envs 10.1 / 7.6 against 11.1 / 8.6, even or behind from 147 456.
+    const bool stream_lean = dims->n_bldg >= 16 && (long long)dims->n_bldg * dims->n_env >= (16ll << 20);
+    const int em_min = !chain ? 122880 : dims->n_bldg >= 16 ? 196608 : 131072;
+    const bool em_auto = dims->n_env > em_min && !(chain && dims->n_bldg > 17) && !stream_lean;
+    const bool lean_beyond = tun.envmajor == 0 && !full && dims->n_bldg <= 20 && dims->n_env > 122880 && !em_auto;      // (what the env-major rule no longer takes)
+    const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 480 || (tun.lean_variant & 2) || kpi_lean || lean_beyond) &&
                             !((tun.lean_variant & 1) && !kpi_lean);
     // without the detail planes only cl_step_lean_kpi_kernel updates the per-building accumulators (and writes the baseline plane
     // cl_kpi_env_kernel sums): a launch shape that cannot take it must not silently leave them stale
@@ -2075,7 +2088,7 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     // (chain: the 20-building instantiation holds 140 registers -- three waves per SIMD -- and loses to the building-major kernel, 41.6 vs 33.6 us at
     //  20 x 262 144: only districts of up to 17 buildings go env-major by themselves; profiles/r06c_cliffs_chain.jsonl)
     const bool envmajor_shape = !full && a.n_chunks == 1 && dims->n_bldg <= 20 && !kpi_lean &&
-                                (tun.envmajor == 1 || (tun.envmajor == 0 && dims->n_env > 122880 && !(chain && dims->n_bldg > 17)));
+                                (tun.envmajor == 1 || (tun.envmajor == 0 && em_auto));
     if (dims->flags & CLD_CHECK) {
         // debug mode: the general kernel with the reference's assertions compiled in, one env per lane (include/citylearn_amd.h CLD_CHECK)
         if (!det || (dims->flags & CLD_DETAIL_MIN) || a.n_chunks > 1 || kpi_full)

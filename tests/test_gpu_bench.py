@@ -149,12 +149,12 @@ def test_default_line_carries_the_hbm_true_roofline_and_the_dropin_timing():
     own step over >= 1000 steps per process; `dropin` times `citylearn_amd.CityLearnEnv` over config 1's full episode beside the reference's."""
     out = _bench('--steps', '20', '--warmup', '5', '--reps', '2', '--no-traffic-pass', timeout=1500)
     r = out['roofline']
-    assert r['bound'] == 'hbm' and 'cl_step_envmajor_kernel<17, ' in r['kernel'] and r['kernel'].endswith(', 1, 2>') and r['units_per_launch'] == 17 * 1048576
+    assert r['bound'] == 'hbm' and r['kernel'] == 'cl_step_lean_chain_kernel<4, true>' and r['units_per_launch'] == 17 * 1048576      # (round 6: the building-major kernel from 16 Mi units)
     assert 0.3 < r['frac'] < 0.9 and r['frac'] == pytest.approx(r['achieved'] / 8000.0)
     m = r['metric_shape']
     assert m['kernel'] == 'cl_step_lean_chain_kernel<4, true>' and 'infinity-cache' in m['residency'] and m['units_per_launch'] == 17 * 65536
     assert out['value'] == pytest.approx(17 * 65536 / (out['ms_per_step'] * 1e-3))
-    assert r['fp32_map']['hbm_streaming']['kernel'].startswith('cl_step_envmajor_kernel<17, ') and r['fp32_map']['hbm_streaming']['speedup_vs_default'] > 0.9
+    assert r['fp32_map']['hbm_streaming']['kernel'].startswith('cl_step_lean_kernel<4, ') and r['fp32_map']['hbm_streaming']['speedup_vs_default'] > 0.9
     cb = out['cpu_baseline']
     if cb.get('kind') == 'reference' and 'live' in cb.get('measured', ''):
         assert cb['all_cores']['steps'] >= 1000
