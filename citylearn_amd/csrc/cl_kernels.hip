@@ -817,6 +817,8 @@ CL_DEV void lean_step_body(const StepArgs& a, float* lds, const ObsFusedArgs* of
     // The flexible-load instantiation (EV districts, behind cl_flex_kernel) keeps it too: 16.2 / 19.7 us per step with, 17.4 / 22.8 without
     // (scripts/ev_step_bench.py, MARL / EV reward, profiles/r05z_ev_step_bench.log against r05w_ev_step_bench.log).
     // The observation epilogue's (cl_step_observe_f32, 65 536 envs): 9.30 - 9.35 us with, 8.84 - 8.85 without (scripts/step_observe_bench.py).
+    // (round 6, the HBM-streaming shape 17 x 1 048 576 now that this kernel runs it: the hint on every load, A/B builds in alternating processes --
+    //  115.8 - 118.3 us without against 120.0 - 121.3 with on the fp32 map, 120.6 - 123.9 against 113.6 - 121.7 under the chain: nothing; profiles/r06_stream_ntl_ab.log)
     constexpr bool NTL = NT && CL_LEAN_NT_LOADS && (KPI || FLEX || VEC == 2);
     CL_TRACE_DECL;
     CL_TRACE_ENTRY(0);
