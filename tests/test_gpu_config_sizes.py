@@ -648,7 +648,8 @@ def test_kernel_selection_map(cell):
     on -- B in {3 .. 1024} buildings x E in {4 096 .. 262 144} envs (100 000: not a power of two), battery + PV and thermal districts, the default
     precision model -- not only at the four district sizes they were tuned at.  `tests/golden/kernel_selection_r06.json` is the kernel each cell
     selected in the measuring session (scripts/r06_cliffs.py -> profiles/r06e_cliffs_chain.jsonl, where no forced alternative beat the default by
-    more than 10 %): a rule change that moves a cell shows up here and has to come with a new measurement."""
+    more than 10 %): a rule change that moves a cell shows up here and has to come with a new measurement.  Eight cells beyond that map pin the round-6
+    rule between the env-major and the building-major kernel (17 x 147 456 ... 2 097 152, 9 / 20 x 1 048 576; profiles/r06_lean_vs_envmajor*.log)."""
     from citylearn_amd.synthetic import tile_district
     base = golden('g2022_all' if cell['kind'] == 'lean' else 'g2020_cz1').spec()
     B, E = cell['B'], cell['E']
