@@ -2072,15 +2072,20 @@ static int step_impl(const cl_dims* dims, const uint32_t* params, const float* t
     //    32.2 for the latency-ordered building-major kernel at four envs per lane; 9 x 262 144: 16.1 / 18.8 against 19.2 / 21.4;
     //  * far beyond the cache the building-major kernel's 16-byte accesses win again: 17 x 1 048 576 -- the HBM-true shape of the bench line -- 104.6 - 111.8 us
     //    against 113.5 - 127.6 us (fp32) and 113.5 - 120.4 against 125.6 - 134.4 (chain) in three processes, 17 x 2 097 152 222 - 224 / 236 against 225 - 247 /
-    //    245 - 261, 20 x 1 048 576 (fp32) 126 - 129 against 133 - 140: districts of 16 .. 20 buildings from 16 Mi units;
+    //    245 - 261, 20 x 1 048 576 (fp32) 126 - 129 against 133 - 140;
     //  * under the float64 chain the building-major kernel holds on longer below: 17 x 147 456 / 163 840 / 180 224 20.5 / 21.8 / 22.8 us against 23.4 / 24.2 /
     //    25.2 (196 608: 24.4 - 25.6 against 25.8 - 26.5; 229 376: even); 9 and 6 buildings: 131 072 envs 10.1 / 7.6 against 11.1 / 8.6, even or behind from 147 456.
-    const bool stream_lean = dims->n_bldg >= 16 && (long long)dims->n_bldg * dims->n_env >= (16ll << 20);
+    //  * (scripts/r06_stream_map.py, 6 .. 20 buildings x 393 216 .. 2 097 152 envs, five variants side by side, medians of three rounds; profiles/r06_stream_map*.jsonl)
+    //    from 12 buildings and 8 Mi units the building-major kernel WITH non-temporal stores is the best or within 3 % of it in 25 of 30 cells -- 12 x 786 432 /
+    //    1 048 576: 57.0 / 75.0 us against 62.8 / 84.3 (fp32), 57.0 / 75.0 against 68.9 / 94.0 (chain); 20 x 524 288 / 786 432 (fp32): 61.2 / 93.2 against 72.8 / 106.9;
+    //    6 and 9 buildings are mixed and keep the env-major kernel.
+    const bool stream_lean = dims->n_bldg >= 12 && (long long)dims->n_bldg * dims->n_env >= (8ll << 20);
     const int em_min = !chain ? 122880 : dims->n_bldg >= 16 ? 196608 : 131072;
     const bool em_auto = dims->n_env > em_min && !(chain && dims->n_bldg > 17) && !stream_lean;
     const bool lean_beyond = tun.envmajor == 0 && !full && dims->n_bldg <= 20 && dims->n_env > 122880 && !em_auto;      // (what the env-major rule no longer takes)
     const bool lean_shape = a.n_chunks == 1 && dims->n_bldg <= 2 * a.nw && (grid_x <= 480 || (tun.lean_variant & 2) || kpi_lean || lean_beyond) &&
                             !((tun.lean_variant & 1) && !kpi_lean);
+    if (lean_beyond && stream_lean && lean_shape && tun.nt_stores == 0) a.nt = 1;      // (8 .. 16 Mi units: the footprint rule above says plain stores -- measured on the env-major kernel)
     // without the detail planes only cl_step_lean_kpi_kernel updates the per-building accumulators (and writes the baseline plane
     // cl_kpi_env_kernel sums): a launch shape that cannot take it must not silently leave them stale
     if (kpi_lean && (full || flex || !lean_shape))

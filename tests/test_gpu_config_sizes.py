@@ -139,13 +139,13 @@ def test_config_sizes_with_distinct_actions_against_the_c_oracle(name, E, steps,
 @pytest.mark.parametrize('E,expect', [(16384, 'cl_step_lean_kernel<1, '), (32768, 'cl_step_lean_kernel<2, '), (65536, 'cl_step_lean_kernel<4, '),
                                        (98304, 'cl_step_lean_kernel<4, '), (122880, 'cl_step_lean_kernel<4, '), (122884, 'cl_step_envmajor_kernel<17, '),
                                        (196608, 'cl_step_envmajor_kernel<17, '), (196612, 'cl_step_envmajor_kernel<17, '), (262144, 'cl_step_envmajor_kernel<17, '),
-                                       (1048576, 'cl_step_lean_kernel<4, ')])
+                                       (524288, 'cl_step_lean_kernel<4, false, true>'), (1048576, 'cl_step_lean_kernel<4, ')])
 @pytest.mark.parametrize('precision', ['default', 'fp32'])
 def test_kernel_selection_by_batch_size(E, expect, precision):
     """Which kernel steps the 17-building battery + PV district at which batch size (csrc/cl_kernels.hip step_impl; re-measured at the end of
     round 5, profiles/r05_nt_loads/r05y.log, and in round 6 with both kernels alternating in one process, profiles/r06_lean_vs_envmajor*.log): the
     latency-ordered kernel at one / two / four envs per lane while the launch is one wave generation (up to 480 workgroups = 122 880 envs; under the
-    float64 chain up to 196 608 envs), the env-major kernel beyond -- and the latency-ordered kernel again from 16 Mi units (17 x 1 048 576, the HBM-true
+    float64 chain up to 196 608 envs), the env-major kernel beyond -- and the latency-ordered kernel again from 8 Mi units (17 x 1 048 576, the HBM-true
     shape of the bench line: 16-byte accesses win far beyond the Infinity Cache).  The kernels agree on every per-building plane."""
     tab = golden('g2022_all').spec().episode_tables(0)
     f64 = None if precision == 'default' else False
@@ -155,7 +155,7 @@ def test_kernel_selection_by_batch_size(E, expect, precision):
     if eng.f64_chain:                                  # (the chain instantiations; the env-major kernel takes over later: csrc/cl_kernels.hip step_impl)
         if E in (122884, 196608):
             expect = 'cl_step_lean_kernel<4, '
-        expect = expect.replace('cl_step_lean_kernel<', 'cl_step_lean_chain_kernel<')
+        expect = expect.replace('cl_step_lean_kernel<4, false, true>', 'cl_step_lean_kernel<4, true>').replace('cl_step_lean_kernel<', 'cl_step_lean_chain_kernel<')
     gen = torch.Generator(device='cuda').manual_seed(E)
     for t in range(3):
         a = torch.rand((eng.n_act_cols, E), device='cuda', generator=gen) * 2 - 1
