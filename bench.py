@@ -290,8 +290,8 @@ def timed_reps(runner: Runner, reset_fn, warmup: int, steps: int, reps: int, dis
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             runner.advance(warmup, steps)
-            stream.synchronize()
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()                 # (the device-wide wait covers the launch stream: a stream.synchronize() in front of it was a second
+                                                     #  host round trip inside the region -- 8.96 - 9.29 -> 8.89 - 8.95 us per step at the driver's K = 20)
             wall = time.perf_counter() - t0          # this rank's K steps, synchronize to synchronize; the line reports the MAX over ranks
             if dist is not None:
                 _barrier(dist)                       # the closing barrier of the bracket: after the clock is read -- a 30 us RCCL barrier inside
